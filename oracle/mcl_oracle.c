@@ -1,0 +1,880 @@
+/* mcl_oracle.c -- CPU restatement of the auv_particle_filter hot path.  See mcl_oracle.h.
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Build: make -C oracle  (gcc -O2 -ffp-contract=off).
+ * Citations are relative to /root/reference/auv_particle_filter/scripts/. */
+#include "mcl_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ST(c, i) state[(size_t)(c) * (size_t)n + (size_t)(i)]
+static const double PI = 3.14159265358979323846;
+
+/* ------------------------------------------------------------------ geometry helpers */
+/* Python/numpy floored modulo then shift: (a + pi) % (2 pi) - pi  (auv_particle.py:48, auv_pf.py:229) */
+double orc_wrap_pi(double a) {
+  const double b = 2.0 * PI;
+  double s = a + PI;
+  double m = fmod(s, b);
+  if (m != 0.0) {
+    if (m < 0.0) m += b;
+  } else {
+    m = copysign(0.0, b);
+  }
+  return m - PI;
+}
+
+/* quaternion (x,y,z,w) -> 4x4 homogeneous matrix, tf.transformations.quaternion_matrix semantics:
+ * scale by sqrt(2/|q|^2), outer product. */
+static void quat_matrix3(const double qin[4], double R[9]) {
+  double nq = qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3];
+  if (nq < 2.220446049250313e-16 * 4.0) {
+    R[0] = R[4] = R[8] = 1.0;
+    R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0.0;
+    return;
+  }
+  double s = sqrt(2.0 / nq);
+  double q[4] = {qin[0] * s, qin[1] * s, qin[2] * s, qin[3] * s};
+  double o[4][4];
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) o[a][b] = q[a] * q[b];
+  R[0] = 1.0 - o[1][1] - o[2][2];
+  R[1] = o[0][1] - o[2][3];
+  R[2] = o[0][2] + o[1][3];
+  R[3] = o[0][1] + o[2][3];
+  R[4] = 1.0 - o[0][0] - o[2][2];
+  R[5] = o[1][2] - o[0][3];
+  R[6] = o[0][2] - o[1][3];
+  R[7] = o[1][2] + o[0][3];
+  R[8] = 1.0 - o[0][0] - o[1][1];
+}
+
+/* euler_from_quaternion(q, 'sxyz') = euler_from_matrix(quaternion_matrix(q)) (auv_particle.py:50) */
+void orc_euler_from_quat(const double q[4], double rpy[3]) {
+  double M[9];
+  quat_matrix3(q, M);
+  double cy = sqrt(M[0] * M[0] + M[3] * M[3]);
+  if (cy > 2.220446049250313e-16 * 4.0) {
+    rpy[0] = atan2(M[7], M[8]);
+    rpy[1] = atan2(-M[6], cy);
+    rpy[2] = atan2(M[3], M[0]);
+  } else {
+    rpy[0] = atan2(-M[5], M[4]);
+    rpy[1] = atan2(-M[6], cy);
+    rpy[2] = 0.0;
+  }
+}
+
+void orc_quat_from_euler(double roll, double pitch, double yaw, double q[4]) {
+  double cr = cos(roll / 2.0), sr = sin(roll / 2.0);
+  double cp = cos(pitch / 2.0), sp = sin(pitch / 2.0);
+  double cy = cos(yaw / 2.0), sy = sin(yaw / 2.0);
+  q[0] = cp * (sr * cy) - sp * (cr * sy);
+  q[1] = cp * (sr * sy) + sp * (cr * cy);
+  q[2] = cp * (cr * sy) - sp * (sr * cy);
+  q[3] = cp * (cr * cy) + sp * (sr * sy);
+}
+
+void orc_matrix_from_tf(const double t[3], const double q[4], double M[16]) {
+  double R[9];
+  quat_matrix3(q, R);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) M[r * 4 + c] = R[r * 3 + c];
+    M[r * 4 + 3] = t[r];
+  }
+  M[12] = M[13] = M[14] = 0.0;
+  M[15] = 1.0;
+}
+
+/* correct static-xyz rotation Rz(yaw) Ry(pitch) Rx(roll) */
+static void rot_rpy(double roll, double pitch, double yaw, double R[9]) {
+  double cr = cos(roll), sr = sin(roll), cp = cos(pitch), sp = sin(pitch), cy = cos(yaw), sy = sin(yaw);
+  R[0] = cy * cp;
+  R[1] = cy * sp * sr - sy * cr;
+  R[2] = cy * sp * cr + sy * sr;
+  R[3] = sy * cp;
+  R[4] = sy * sp * sr + cy * cr;
+  R[5] = sy * sp * cr - cy * sr;
+  R[6] = -sp;
+  R[7] = cp * sr;
+  R[8] = cp * cr;
+}
+
+static void mat3_mul(const double A[9], const double B[9], double C[9]) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double s = 0.0;
+      for (int k = 0; k < 3; ++k) s += A[r * 3 + k] * B[k * 3 + c];
+      C[r * 3 + c] = s;
+    }
+}
+
+/* ------------------------------------------------------------------ a2 add_noise */
+void orc_add_noise(int n, double* state, const double cov[6], const double* normals) {
+  for (int i = 0; i < n; ++i)
+    for (int c = 0; c < 6; ++c) ST(c, i) = ST(c, i) + sqrt(cov[c]) * normals[(size_t)i * 6 + c];
+}
+
+/* ------------------------------------------------------------------ a4/a5 motion_pred */
+void orc_predict(int n, double* state, const double v[3], double wz, const double q[4], double z,
+                 double dt, const double pcov[6], const double* normals) {
+  double e[3];
+  orc_euler_from_quat(q, e); /* hoisted: identical for every particle (auv_particle.py:50-53) */
+  const double roll = e[0], pitch = e[1];
+  double sq[6];
+  for (int c = 0; c < 6; ++c) sq[c] = sqrt(pcov[c]);
+  const double vdt[3] = {v[0] * dt, v[1] * dt, v[2] * dt};
+  /* fullRotation's malformed Ry' (auv_particle.py:90-92): row 2 = [-sin p, cos p, 0] */
+  const double cp = cos(pitch), sp = sin(pitch), cr = cos(roll), sr = sin(roll);
+  const double Ry[9] = {cp, 0.0, sp, 0.0, 1.0, 0.0, -sp, cp, 0.0};
+  const double Rx[9] = {1.0, 0.0, 0.0, 0.0, cr, -sr, 0.0, sr, cr};
+  double M1[9];
+  mat3_mul(Ry, Rx, M1);
+  for (int i = 0; i < n; ++i) {
+    double nz[6] = {0, 0, 0, 0, 0, 0};
+    if (normals)
+      for (int c = 0; c < 6; ++c) nz[c] = sq[c] * normals[(size_t)i * 6 + c];
+    double yaw_t = orc_wrap_pi(ST(5, i) + wz * dt + nz[5]);
+    double cy = cos(yaw_t), sy = sin(yaw_t);
+    const double Rz[9] = {cy, -sy, 0.0, sy, cy, 0.0, 0.0, 0.0, 1.0};
+    double R[9];
+    mat3_mul(Rz, M1, R);
+    double s0 = (R[0] * vdt[0] + R[1] * vdt[1] + R[2] * vdt[2]) + nz[0];
+    double s1 = (R[3] * vdt[0] + R[4] * vdt[1] + R[5] * vdt[2]) + nz[1];
+    ST(0, i) += s0;
+    ST(1, i) += s1;
+    ST(2, i) = z;
+    ST(3, i) = roll;
+    ST(4, i) = pitch;
+    ST(5, i) = yaw_t;
+  }
+}
+
+/* ------------------------------------------------------------------ a7 GPS weight */
+void orc_gps_weights(int n, const double* state, const double m2o[16], double gx, double gy,
+                     double sigma, double* w_raw, double* lw) {
+  const double s2 = sigma * sigma;
+  const double lognorm = log(2.0 * PI * s2);
+  for (int i = 0; i < n; ++i) {
+    double x = ST(0, i), y = ST(1, i), z = ST(2, i);
+    double px = m2o[0] * x + m2o[1] * y + m2o[2] * z + m2o[3];
+    double py = m2o[4] * x + m2o[5] * y + m2o[6] * z + m2o[7];
+    double dx = gx - px, dy = gy - py;
+    double maha = (dx * dx + dy * dy) / s2;
+    if (lw) lw[i] = -0.5 * maha - lognorm;
+    if (w_raw) w_raw[i] = exp(-0.5 * maha) / (2.0 * PI * s2);
+  }
+}
+
+/* ------------------------------------------------------------------ numpy summation */
+static double np_pairwise(const double* a, int64_t n, int64_t st) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int64_t i = 0; i < n; ++i) r += a[i * st];
+    return r;
+  } else if (n <= 128) {
+    double r[8];
+    int64_t i;
+    for (int j = 0; j < 8; ++j) r[j] = a[j * st];
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[(i + j) * st];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i * st];
+    return res;
+  } else {
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, n2, st) + np_pairwise(a + n2 * st, n - n2, st);
+  }
+}
+/* numpy 2.2 add.reduce on a 1-D double array (what `weights.sum()`, auv_pf.py:172, and
+ * np.mean(col), auv_pf.py:231, execute): the iterator hands the inner loop chunks of 8192
+ * elements; each chunk is pairwise-summed and the chunk sums accumulate left to right.
+ * Verified bit-equal to numpy 2.2.6 in tests/test_oracle_golden.py. */
+double orc_numpy_pairwise_sum(const double* a, int64_t n, int64_t stride) {
+  double res = 0.0;
+  for (int64_t i = 0; i < n; i += 8192) {
+    int64_t c = n - i < 8192 ? n - i : 8192;
+    res += np_pairwise(a + i * stride, c, stride);
+  }
+  return res;
+}
+
+void orc_normalise_ref(int n, double* w) {
+  for (int i = 0; i < n; ++i) w[i] += 1.e-200; /* auv_pf.py:165 */
+  double s = orc_numpy_pairwise_sum(w, n, 1);  /* auv_pf.py:172 */
+  for (int i = 0; i < n; ++i) w[i] /= s;
+}
+
+/* ------------------------------------------------------------------ resampling.py, reference-exact */
+static int merge_positions(int n, const double* pos, const double* cs, int32_t* idx) {
+  /* the two-pointer loop of resampling.py:107-113 / :161-167 */
+  int i = 0, j = 0, err = 0;
+  while (i < n) {
+    if (j >= n) { /* reference raises IndexError here */
+      err = -1;
+      idx[i++] = n - 1;
+      continue;
+    }
+    if (pos[i] < cs[j]) {
+      idx[i] = j;
+      ++i;
+    } else {
+      ++j;
+    }
+  }
+  return err;
+}
+
+int orc_systematic_ref(int n, const double* w, double u, int32_t* idx) {
+  double* cs = (double*)malloc(sizeof(double) * (size_t)n * 2);
+  double* pos = cs + n;
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) {
+    acc += w[i]; /* np.cumsum: sequential */
+    cs[i] = acc;
+    pos[i] = (u + (double)i) / (double)n; /* resampling.py:157 */
+  }
+  int e = merge_positions(n, pos, cs, idx);
+  free(cs);
+  return e;
+}
+
+int orc_stratified_ref(int n, const double* w, const double* u, int32_t* idx) {
+  double* cs = (double*)malloc(sizeof(double) * (size_t)n * 2);
+  double* pos = cs + n;
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) {
+    acc += w[i];
+    cs[i] = acc;
+    pos[i] = (u[i] + (double)i) / (double)n; /* resampling.py:103 */
+  }
+  int e = merge_positions(n, pos, cs, idx);
+  free(cs);
+  return e;
+}
+
+/* np.searchsorted(cs, keys) side='left' exactly as numpy's binsearch<left> executes it:
+ * the bounds are carried from key to key, which matters when cs is NOT monotone (A.6). */
+static void np_searchsorted_left(const double* arr, int64_t arr_len, const double* key, int64_t key_len,
+                                 int32_t* out) {
+  int64_t min_idx = 0, max_idx = arr_len;
+  if (key_len == 0) return;
+  double last = key[0];
+  for (int64_t t = 0; t < key_len; ++t) {
+    const double kv = key[t];
+    if (last < kv) {
+      max_idx = arr_len;
+    } else {
+      min_idx = 0;
+      max_idx = (max_idx < arr_len) ? (max_idx + 1) : arr_len;
+    }
+    last = kv;
+    while (min_idx < max_idx) {
+      int64_t mid = min_idx + ((max_idx - min_idx) >> 1);
+      if (arr[mid] < kv)
+        min_idx = mid + 1;
+      else
+        max_idx = mid;
+    }
+    out[t] = (int32_t)min_idx;
+  }
+}
+
+int orc_multinomial_ref(int n, const double* w, const double* u, int32_t* idx) {
+  double* cs = (double*)malloc(sizeof(double) * (size_t)n);
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) {
+    acc += w[i];
+    cs[i] = acc;
+  }
+  cs[n - 1] = 1.0; /* resampling.py:193 */
+  np_searchsorted_left(cs, n, u, n, idx);
+  free(cs);
+  return 0;
+}
+
+int orc_naive_ref(int n, const double* w, double u01, int32_t* idx) {
+  double* cdf = (double*)malloc(sizeof(double) * (size_t)n);
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) {
+    acc += w[i];
+    cdf[i] = acc;
+  }
+  const double step = 1.0 / (double)n;
+  const double off = 0.0 + (step - 0.0) * u01; /* np.random.uniform(0, 1/N), resampling.py:123 */
+  int ind = 0, err = 0;
+  for (int i = 0; i < n; ++i) {
+    double rid = (0.0 + (double)i * step) + off; /* np.arange(0.0, 1.0, 1/N)[i] + u */
+    while (ind < n && rid > cdf[ind]) ++ind;
+    if (ind >= n) {
+      err = -1;
+      ind = n - 1;
+    }
+    idx[i] = ind;
+  }
+  free(cdf);
+  return err;
+}
+
+int orc_residual_k(int n, const double* w) {
+  long k = 0;
+  for (int i = 0; i < n; ++i) k += (long)floor((double)n * w[i]);
+  return (int)k;
+}
+
+int orc_residual_ref(int n, const double* w, const double* u, int32_t* idx) {
+  long* copies = (long*)malloc(sizeof(long) * (size_t)n);
+  double* res = (double*)malloc(sizeof(double) * (size_t)n);
+  int k = 0;
+  for (int i = 0; i < n; ++i) {
+    copies[i] = (long)floor((double)n * w[i]); /* resampling.py:61 */
+    for (long c = 0; c < copies[i] && k < n; ++c) idx[k++] = i;
+  }
+  if (k < n) {
+    double s = 0.0; /* builtins.sum: 0 + r0 + r1 + ... left to right (resampling.py:71) */
+    for (int i = 0; i < n; ++i) {
+      res[i] = w[i] - (double)copies[i]; /* sic: FilterPy subtracts from w, not N*w (A.6) */
+      s += res[i];
+    }
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) {
+      acc += res[i] / s;
+      res[i] = acc;
+    }
+    res[n - 1] = 1.0;
+    np_searchsorted_left(res, n, u, n - k, idx + k);
+  }
+  free(copies);
+  free(res);
+  return k;
+}
+
+/* ------------------------------------------------------------------ a12 keep/lost/dupes */
+int orc_lost_dupes(int n, const int32_t* idx, int32_t* lost, int32_t* dupes) {
+  unsigned char* seen = (unsigned char*)calloc((size_t)n, 1);
+  int nd = 0, nl = 0;
+  /* dupes = indices with the FIRST occurrence of each distinct value removed, order kept
+   * (list.remove drops the first match; auv_pf.py:185-187) */
+  for (int i = 0; i < n; ++i) {
+    int32_t j = idx[i];
+    if (!seen[j])
+      seen[j] = 1;
+    else
+      dupes[nd++] = j;
+  }
+  for (int i = 0; i < n; ++i)
+    if (!seen[i]) lost[nl++] = i; /* ascending (auv_pf.py:184) */
+  free(seen);
+  (void)nd;
+  return nl;
+}
+
+void orc_reassign(int n, double* state, int n_lost, const int32_t* lost, const int32_t* dupes) {
+  for (int k = 0; k < n_lost; ++k)
+    for (int c = 0; c < 6; ++c) ST(c, lost[k]) = ST(c, dupes[k]); /* auv_pf.py:195-198 */
+}
+
+/* ------------------------------------------------------------------ a13 mean / cov */
+void orc_mean_cov(int n, const double* state, double mean6[6], double* yaw_mean, double cov9[9]) {
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) /* ndarray.mean(axis=0): row-by-row accumulation (A.9) */
+    for (int c = 0; c < 6; ++c) acc[c] += ST(c, i);
+  for (int c = 0; c < 6; ++c) mean6[c] = acc[c] / (double)n;
+  double* wy = (double*)malloc(sizeof(double) * (size_t)n);
+  for (int i = 0; i < n; ++i) wy[i] = orc_wrap_pi(ST(5, i));
+  *yaw_mean = orc_numpy_pairwise_sum(wy, n, 1) / (double)n; /* np.mean of the column (auv_pf.py:231) */
+  free(wy);
+  double c00 = 0, c11 = 0, c22 = 0, c01 = 0, c02 = 0, c12 = 0;
+  for (int i = 0; i < n; ++i) {
+    double dx = ST(0, i) - mean6[0], dy = ST(1, i) - mean6[1], dz = ST(2, i) - mean6[2];
+    c00 += dx * dx;
+    c11 += dy * dy;
+    c22 += dz * dz;
+    c01 += dx * dy;
+    c02 += dx * dz;
+    c12 += dy * dz;
+  }
+  const double N = (double)n;
+  cov9[0] = c00 / N;
+  cov9[1] = c01 / N;
+  cov9[2] = c02 / N;
+  cov9[3] = c01 / N; /* only [1,0] is mirrored (auv_pf.py:246) */
+  cov9[4] = c11 / N;
+  cov9[5] = c12 / N;
+  cov9[6] = 0.0;
+  cov9[7] = 0.0;
+  cov9[8] = c22 / N;
+}
+
+/* ================================================================== fixed-point spec */
+/* Deterministic exp: only IEEE +,*,fma,rint and bit ops, identical sequence on CPU and GPU. */
+double orc_det_exp(double x) {
+  if (!(x >= -700.0)) return 0.0; /* also NaN and -inf */
+  if (x > 709.0) return INFINITY;
+  const double LOG2E = 1.44269504088896338700e+00;
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  double k = rint(x * LOG2E);
+  double r = fma(-k, LN2_HI, x);
+  r = fma(-k, LN2_LO, r);
+  /* Taylor degree 13, Horner with fma */
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  int64_t ki = (int64_t)k;
+  uint64_t bits = (uint64_t)(ki + 1023) << 52;
+  double scale;
+  memcpy(&scale, &bits, 8);
+  return p * scale;
+}
+
+static int ceil_log2_i64(int64_t n) {
+  int l = 0;
+  while (((int64_t)1 << l) < n) ++l;
+  return l;
+}
+
+uint64_t orc_fixed_weights(int n, const double* lw, int mode, int64_t n_global, uint64_t* q, double* w_lin) {
+  double* w = (double*)malloc(sizeof(double) * (size_t)n);
+  double m_lw = -INFINITY;
+  for (int i = 0; i < n; ++i)
+    if (lw[i] > m_lw) m_lw = lw[i];
+  for (int i = 0; i < n; ++i) {
+    if (mode == 0)
+      w[i] = orc_det_exp(lw[i]) + 1.e-200;
+    else
+      w[i] = (m_lw == -INFINITY) ? 1.0 : orc_det_exp(lw[i] - m_lw);
+  }
+  double mw = 0.0;
+  for (int i = 0; i < n; ++i)
+    if (w[i] > mw) mw = w[i];
+  const int s = 63 - ceil_log2_i64(n_global);
+  const double scale = ldexp(1.0, s);
+  uint64_t tot = 0;
+  for (int i = 0; i < n; ++i) {
+    q[i] = (uint64_t)((w[i] / mw) * scale);
+    tot += q[i];
+    if (w_lin) w_lin[i] = w[i];
+  }
+  free(w);
+  return tot;
+}
+
+void orc_systematic_ncum(int n, const uint64_t* q, uint64_t c_offset, uint64_t total, int64_t n_global,
+                         uint64_t u53, uint32_t* ncum) {
+  typedef unsigned __int128 u128;
+  uint64_t c = c_offset;
+  for (int j = 0; j < n; ++j) {
+    c += q[j];
+    u128 A = (u128)c * (u128)(uint64_t)n_global;
+    uint64_t a = (uint64_t)(A / (u128)total);
+    uint64_t r = (uint64_t)(A % (u128)total);
+    uint32_t extra = (((u128)r << 53) > (u128)u53 * (u128)total) ? 1u : 0u;
+    ncum[j] = (uint32_t)a + extra;
+  }
+}
+
+void orc_indices_from_ncum(int64_t n_global, const uint32_t* ncum, int64_t i0, int64_t cnt, int32_t* idx) {
+  for (int64_t t = 0; t < cnt; ++t) {
+    uint32_t i = (uint32_t)(i0 + t);
+    int64_t lo = 0, hi = n_global; /* first j with ncum[j] > i */
+    while (lo < hi) {
+      int64_t mid = lo + ((hi - lo) >> 1);
+      if (ncum[mid] > i)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    idx[t] = (int32_t)(lo < n_global ? lo : n_global - 1);
+  }
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 + Box-Muller */
+void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                    uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+
+static void box_muller(uint32_t a, uint32_t b, double* n0, double* n1) {
+  double u1 = ((double)a + 0.5) * (1.0 / 4294967296.0);
+  double u2 = ((double)b + 0.5) * (1.0 / 4294967296.0);
+  double r = sqrt(-2.0 * log(u1));
+  double t = 2.0 * PI * u2;
+  *n0 = r * cos(t);
+  *n1 = r * sin(t);
+}
+
+void orc_native_normals(int n, int64_t gid0, uint64_t seed, uint32_t purpose, uint32_t step, double* normals) {
+  for (int i = 0; i < n; ++i) {
+    uint32_t gid = (uint32_t)(gid0 + i);
+    uint32_t o[4];
+    double* z = normals + (size_t)i * 6;
+    orc_philox4x32(gid, 0u, step, purpose, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    if (purpose == 1) { /* predict: x, y, yaw */
+      double a, b, c, d;
+      box_muller(o[0], o[1], &a, &b);
+      box_muller(o[2], o[3], &c, &d);
+      z[0] = a;
+      z[1] = b;
+      z[2] = z[3] = z[4] = 0.0;
+      z[5] = c;
+    } else {
+      box_muller(o[0], o[1], &z[0], &z[1]);
+      box_muller(o[2], o[3], &z[2], &z[3]);
+      orc_philox4x32(gid, 1u, step, purpose, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+      box_muller(o[0], o[1], &z[4], &z[5]);
+    }
+  }
+}
+
+uint64_t orc_native_u53(uint64_t seed, uint32_t step) {
+  uint32_t o[4];
+  orc_philox4x32(0xFFFFFFFFu, 0u, step, 3u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  return ((uint64_t)(o[0] >> 5) << 26) | (uint64_t)(o[1] >> 6);
+}
+
+/* ================================================================== MBES self-oracle */
+static int solve_first_root(double c0, double c1, double c2, double tlo, double thi, double* root) {
+  /* smallest root of c0 + c1 t + c2 t^2 in [tlo, thi] */
+  double r[2];
+  int nr = 0;
+  if (c2 == 0.0) {
+    if (c1 != 0.0) r[nr++] = -c0 / c1;
+  } else {
+    double disc = c1 * c1 - 4.0 * c2 * c0;
+    if (disc >= 0.0) {
+      double sq = sqrt(disc);
+      double qv = -0.5 * (c1 + (c1 >= 0.0 ? sq : -sq));
+      if (qv != 0.0) {
+        r[nr++] = c0 / qv;
+        r[nr++] = qv / c2;
+      } else {
+        r[nr++] = 0.0;
+      }
+    }
+  }
+  int ok = 0;
+  double best = 0.0;
+  for (int i = 0; i < nr; ++i)
+    if (r[i] >= tlo && r[i] <= thi && (!ok || r[i] < best)) {
+      best = r[i];
+      ok = 1;
+    }
+  *root = best;
+  return ok;
+}
+
+double orc_ray_grid(const orc_grid* g, const double o[3], const double d[3], double r_max) {
+  const double X0 = g->ox, X1 = g->ox + (g->nx - 1) * g->res;
+  const double Y0 = g->oy, Y1 = g->oy + (g->ny - 1) * g->res;
+  double t0 = 0.0, t1 = r_max;
+  const double lo[2] = {X0, Y0}, hi[2] = {X1, Y1};
+  for (int a = 0; a < 2; ++a) {
+    if (d[a] == 0.0) {
+      if (o[a] < lo[a] || o[a] > hi[a]) return r_max;
+    } else {
+      double ta = (lo[a] - o[a]) / d[a], tb = (hi[a] - o[a]) / d[a];
+      if (ta > tb) {
+        double s = ta;
+        ta = tb;
+        tb = s;
+      }
+      if (ta > t0) t0 = ta;
+      if (tb < t1) t1 = tb;
+    }
+  }
+  if (!(t0 <= t1)) return r_max;
+  const double eps = 1e-9 * g->res;
+  double px = o[0] + t0 * d[0], py = o[1] + t0 * d[1];
+  int ix = (int)floor((px - g->ox) / g->res), iy = (int)floor((py - g->oy) / g->res);
+  if (ix < 0) ix = 0;
+  if (ix > g->nx - 2) ix = g->nx - 2;
+  if (iy < 0) iy = 0;
+  if (iy > g->ny - 2) iy = g->ny - 2;
+  /* when the entry point sits exactly on a cell border moving in the negative direction, start in
+   * the lower cell */
+  if (d[0] < 0.0 && ix > 0 && (g->ox + ix * g->res) >= px) --ix;
+  if (d[1] < 0.0 && iy > 0 && (g->oy + iy * g->res) >= py) --iy;
+  double t_in = t0;
+  int first = 1;
+  for (;;) {
+    const double cx = g->ox + ix * g->res, cy = g->oy + iy * g->res;
+    double tx = INFINITY, ty = INFINITY;
+    if (d[0] > 0.0)
+      tx = (cx + g->res - o[0]) / d[0];
+    else if (d[0] < 0.0)
+      tx = (cx - o[0]) / d[0];
+    if (d[1] > 0.0)
+      ty = (cy + g->res - o[1]) / d[1];
+    else if (d[1] < 0.0)
+      ty = (cy - o[1]) / d[1];
+    double t_out = tx < ty ? tx : ty;
+    if (t_out > t1) t_out = t1;
+    const double h00 = g->z[(size_t)ix * g->ny + iy], h10 = g->z[(size_t)(ix + 1) * g->ny + iy];
+    const double h01 = g->z[(size_t)ix * g->ny + iy + 1], h11 = g->z[(size_t)(ix + 1) * g->ny + iy + 1];
+    const double B = h10 - h00, C = h01 - h00, D = h00 - h10 - h01 + h11;
+    const double u0 = (o[0] - cx) / g->res, v0 = (o[1] - cy) / g->res;
+    const double du = d[0] / g->res, dv = d[1] / g->res;
+    const double c0 = o[2] - (h00 + B * u0 + C * v0 + D * u0 * v0);
+    const double c1 = d[2] - (B * du + C * dv + D * (u0 * dv + v0 * du));
+    const double c2 = -D * du * dv;
+    if (first) {
+      double f0 = c0 + c1 * t_in + c2 * t_in * t_in;
+      if (f0 <= 0.0) return t_in; /* origin (or map entry point) at/below the seabed */
+      first = 0;
+    }
+    double root;
+    if (solve_first_root(c0, c1, c2, t_in - eps, t_out + eps, &root)) {
+      if (root < t0) root = t0;
+      return root < r_max ? root : r_max;
+    }
+    if (t_out >= t1) return r_max;
+    if (tx < ty)
+      ix += d[0] > 0.0 ? 1 : -1;
+    else
+      iy += d[1] > 0.0 ? 1 : -1;
+    if (ix < 0 || iy < 0 || ix > g->nx - 2 || iy > g->ny - 2) return r_max;
+    t_in = t_out;
+  }
+}
+
+static int ray_tri(const double o[3], const double d[3], const float* a, const float* b, const float* c,
+                   double* t_out) {
+  const double eps = 1e-12;
+  double e1[3] = {(double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2]};
+  double e2[3] = {(double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2]};
+  double p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+  double det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
+  if (fabs(det) < 1e-300) return 0;
+  double inv = 1.0 / det;
+  double s[3] = {o[0] - a[0], o[1] - a[1], o[2] - a[2]};
+  double u = (s[0] * p[0] + s[1] * p[1] + s[2] * p[2]) * inv;
+  if (u < -eps || u > 1.0 + eps) return 0;
+  double qv[3] = {s[1] * e1[2] - s[2] * e1[1], s[2] * e1[0] - s[0] * e1[2], s[0] * e1[1] - s[1] * e1[0]};
+  double v = (d[0] * qv[0] + d[1] * qv[1] + d[2] * qv[2]) * inv;
+  if (v < -eps || u + v > 1.0 + eps) return 0;
+  double t = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * inv;
+  if (t < 0.0) return 0;
+  *t_out = t;
+  return 1;
+}
+
+double orc_ray_mesh_brute(const float* verts, const uint32_t* tris, int64_t nt, const double o[3],
+                          const double d[3], double r_max) {
+  double best = r_max;
+  for (int64_t k = 0; k < nt; ++k) {
+    double t;
+    if (ray_tri(o, d, verts + 3 * (size_t)tris[3 * k], verts + 3 * (size_t)tris[3 * k + 1],
+                verts + 3 * (size_t)tris[3 * k + 2], &t) &&
+        t < best)
+      best = t;
+  }
+  return best;
+}
+
+struct orc_mesh {
+  const float* verts;
+  const uint32_t* tris;
+  int64_t nt;
+  double x0, y0, cs;
+  int gx, gy;
+  int64_t* start;
+  int32_t* list;
+};
+
+static void tri_cells(const orc_mesh* m, int64_t k, int* ax0, int* ax1, int* ay0, int* ay1) {
+  double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+  for (int c = 0; c < 3; ++c) {
+    const float* v = m->verts + 3 * (size_t)m->tris[3 * k + c];
+    if (v[0] < xmin) xmin = v[0];
+    if (v[0] > xmax) xmax = v[0];
+    if (v[1] < ymin) ymin = v[1];
+    if (v[1] > ymax) ymax = v[1];
+  }
+  int a0 = (int)floor((xmin - m->x0) / m->cs), a1 = (int)floor((xmax - m->x0) / m->cs);
+  int b0 = (int)floor((ymin - m->y0) / m->cs), b1 = (int)floor((ymax - m->y0) / m->cs);
+  if (a0 < 0) a0 = 0;
+  if (b0 < 0) b0 = 0;
+  if (a1 > m->gx - 1) a1 = m->gx - 1;
+  if (b1 > m->gy - 1) b1 = m->gy - 1;
+  *ax0 = a0;
+  *ax1 = a1;
+  *ay0 = b0;
+  *ay1 = b1;
+}
+
+orc_mesh* orc_mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int64_t nt) {
+  orc_mesh* m = (orc_mesh*)calloc(1, sizeof(orc_mesh));
+  m->verts = verts;
+  m->tris = tris;
+  m->nt = nt;
+  double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+  for (int64_t i = 0; i < nv; ++i) {
+    if (verts[3 * i] < xmin) xmin = verts[3 * i];
+    if (verts[3 * i] > xmax) xmax = verts[3 * i];
+    if (verts[3 * i + 1] < ymin) ymin = verts[3 * i + 1];
+    if (verts[3 * i + 1] > ymax) ymax = verts[3 * i + 1];
+  }
+  double area = (xmax - xmin) * (ymax - ymin);
+  double cs = sqrt(area / (double)(nt / 2 > 0 ? nt / 2 : 1));
+  if (!(cs > 0.0)) cs = 1.0;
+  m->cs = cs;
+  m->x0 = xmin;
+  m->y0 = ymin;
+  m->gx = (int)floor((xmax - xmin) / cs) + 1;
+  m->gy = (int)floor((ymax - ymin) / cs) + 1;
+  size_t nc = (size_t)m->gx * (size_t)m->gy;
+  m->start = (int64_t*)calloc(nc + 1, sizeof(int64_t));
+  for (int64_t k = 0; k < nt; ++k) {
+    int a0, a1, b0, b1;
+    tri_cells(m, k, &a0, &a1, &b0, &b1);
+    for (int a = a0; a <= a1; ++a)
+      for (int b = b0; b <= b1; ++b) m->start[(size_t)a * m->gy + b + 1]++;
+  }
+  for (size_t c = 0; c < nc; ++c) m->start[c + 1] += m->start[c];
+  m->list = (int32_t*)malloc(sizeof(int32_t) * (size_t)(m->start[nc] > 0 ? m->start[nc] : 1));
+  int64_t* fill = (int64_t*)calloc(nc, sizeof(int64_t));
+  for (int64_t k = 0; k < nt; ++k) {
+    int a0, a1, b0, b1;
+    tri_cells(m, k, &a0, &a1, &b0, &b1);
+    for (int a = a0; a <= a1; ++a)
+      for (int b = b0; b <= b1; ++b) {
+        size_t c = (size_t)a * m->gy + b;
+        m->list[m->start[c] + fill[c]++] = (int32_t)k;
+      }
+  }
+  free(fill);
+  return m;
+}
+
+void orc_mesh_free(orc_mesh* m) {
+  if (!m) return;
+  free(m->start);
+  free(m->list);
+  free(m);
+}
+
+double orc_ray_mesh(const orc_mesh* m, const double o[3], const double d[3], double r_max) {
+  const double X1 = m->x0 + m->gx * m->cs, Y1 = m->y0 + m->gy * m->cs;
+  double t0 = 0.0, t1 = r_max;
+  const double lo[2] = {m->x0, m->y0}, hi[2] = {X1, Y1};
+  for (int a = 0; a < 2; ++a) {
+    if (d[a] == 0.0) {
+      if (o[a] < lo[a] || o[a] > hi[a]) return r_max;
+    } else {
+      double ta = (lo[a] - o[a]) / d[a], tb = (hi[a] - o[a]) / d[a];
+      if (ta > tb) {
+        double s = ta;
+        ta = tb;
+        tb = s;
+      }
+      if (ta > t0) t0 = ta;
+      if (tb < t1) t1 = tb;
+    }
+  }
+  if (!(t0 <= t1)) return r_max;
+  double px = o[0] + t0 * d[0], py = o[1] + t0 * d[1];
+  int ix = (int)floor((px - m->x0) / m->cs), iy = (int)floor((py - m->y0) / m->cs);
+  if (ix < 0) ix = 0;
+  if (ix > m->gx - 1) ix = m->gx - 1;
+  if (iy < 0) iy = 0;
+  if (iy > m->gy - 1) iy = m->gy - 1;
+  const double eps = 1e-9 * m->cs;
+  for (;;) {
+    const double cx = m->x0 + ix * m->cs, cy = m->y0 + iy * m->cs;
+    double tx = INFINITY, ty = INFINITY;
+    if (d[0] > 0.0)
+      tx = (cx + m->cs - o[0]) / d[0];
+    else if (d[0] < 0.0)
+      tx = (cx - o[0]) / d[0];
+    if (d[1] > 0.0)
+      ty = (cy + m->cs - o[1]) / d[1];
+    else if (d[1] < 0.0)
+      ty = (cy - o[1]) / d[1];
+    double t_out = tx < ty ? tx : ty;
+    if (t_out > t1) t_out = t1;
+    size_t c = (size_t)ix * m->gy + iy;
+    double best = INFINITY;
+    for (int64_t e = m->start[c]; e < m->start[c + 1]; ++e) {
+      int64_t k = m->list[e];
+      double t;
+      if (ray_tri(o, d, m->verts + 3 * (size_t)m->tris[3 * k], m->verts + 3 * (size_t)m->tris[3 * k + 1],
+                  m->verts + 3 * (size_t)m->tris[3 * k + 2], &t) &&
+          t <= t_out + eps && t < best)
+        best = t;
+    }
+    if (best < INFINITY) return best < r_max ? best : r_max;
+    if (t_out >= t1) return r_max;
+    if (tx < ty)
+      ix += d[0] > 0.0 ? 1 : -1;
+    else
+      iy += d[1] > 0.0 ? 1 : -1;
+    if (ix < 0 || iy < 0 || ix > m->gx - 1 || iy > m->gy - 1) return r_max;
+  }
+}
+
+void orc_mbes_update(int n, const double* state, const double m2o[16], const double sensor_off[6],
+                     int map_kind, const void* map, const float* beam_angles, const float* ranges, int B,
+                     double sigma, double r_max, double* lw, double* exp_out) {
+  double Ro[9];
+  rot_rpy(sensor_off[3], sensor_off[4], sensor_off[5], Ro);
+  double Rm[9] = {m2o[0], m2o[1], m2o[2], m2o[4], m2o[5], m2o[6], m2o[8], m2o[9], m2o[10]};
+  const double lognorm = log(sigma * sqrt(2.0 * PI));
+  for (int i = 0; i < n; ++i) {
+    double Rp[9], Rmp[9], Rs[9];
+    rot_rpy(ST(3, i), ST(4, i), ST(5, i), Rp);
+    mat3_mul(Rm, Rp, Rmp);
+    mat3_mul(Rmp, Ro, Rs);
+    double x = ST(0, i), y = ST(1, i), z = ST(2, i);
+    double o[3];
+    for (int r = 0; r < 3; ++r)
+      o[r] = (m2o[r * 4 + 0] * x + m2o[r * 4 + 1] * y + m2o[r * 4 + 2] * z + m2o[r * 4 + 3]) +
+             (Rmp[r * 3 + 0] * sensor_off[0] + Rmp[r * 3 + 1] * sensor_off[1] + Rmp[r * 3 + 2] * sensor_off[2]);
+    double acc = 0.0;
+    int nvalid = 0;
+    for (int b = 0; b < B; ++b) {
+      double th = (double)beam_angles[b];
+      double ds[3] = {0.0, sin(th), -cos(th)};
+      double d[3];
+      for (int r = 0; r < 3; ++r) d[r] = Rs[r * 3 + 0] * ds[0] + Rs[r * 3 + 1] * ds[1] + Rs[r * 3 + 2] * ds[2];
+      double e = map_kind == 0 ? orc_ray_grid((const orc_grid*)map, o, d, r_max)
+                               : orc_ray_mesh((const orc_mesh*)map, o, d, r_max);
+      if (exp_out) exp_out[(size_t)i * B + b] = e;
+      float rm = ranges ? ranges[b] : 0.0f;
+      if (ranges && rm > 0.0f && rm == rm) {
+        double dr = ((double)rm - e) / sigma;
+        acc += dr * dr;
+        ++nvalid;
+      }
+    }
+    if (lw) lw[i] = -0.5 * acc - (double)nvalid * lognorm;
+  }
+}

@@ -1,0 +1,306 @@
+"""ctypes binding of the CPU oracle (oracle/libmcl_oracle.so).
+
+TEST INFRASTRUCTURE, NOT PRODUCT: imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package smarc_navigation_amd never imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'libmcl_oracle.so')
+
+_f64p = np.ctypeslib.ndpointer(np.float64, flags='C_CONTIGUOUS')
+_f32p = np.ctypeslib.ndpointer(np.float32, flags='C_CONTIGUOUS')
+_i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags='C_CONTIGUOUS')
+_u64p = np.ctypeslib.ndpointer(np.uint64, flags='C_CONTIGUOUS')
+
+
+def build(force=False):
+    src = os.path.join(_HERE, 'mcl_oracle.c')
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-s', '-B'], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    return _SO
+
+
+class _Grid(C.Structure):
+    _fields_ = [('nx', C.c_int), ('ny', C.c_int), ('ox', C.c_double), ('oy', C.c_double),
+                ('res', C.c_double), ('z', C.c_void_p)]
+
+
+def _load():
+    build()
+    L = C.CDLL(_SO)
+    d, i, i64, u64, u32, vp = C.c_double, C.c_int, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p
+    sig = {
+        'orc_euler_from_quat': (None, [_f64p, _f64p]),
+        'orc_quat_from_euler': (None, [d, d, d, _f64p]),
+        'orc_matrix_from_tf': (None, [_f64p, _f64p, _f64p]),
+        'orc_wrap_pi': (d, [d]),
+        'orc_add_noise': (None, [i, _f64p, _f64p, _f64p]),
+        'orc_predict': (None, [i, _f64p, _f64p, d, _f64p, d, d, _f64p, vp]),
+        'orc_gps_weights': (None, [i, _f64p, _f64p, d, d, d, vp, vp]),
+        'orc_numpy_pairwise_sum': (d, [vp, i64, i64]),
+        'orc_normalise_ref': (None, [i, _f64p]),
+        'orc_systematic_ref': (i, [i, _f64p, d, _i32p]),
+        'orc_stratified_ref': (i, [i, _f64p, _f64p, _i32p]),
+        'orc_multinomial_ref': (i, [i, _f64p, _f64p, _i32p]),
+        'orc_naive_ref': (i, [i, _f64p, d, _i32p]),
+        'orc_residual_ref': (i, [i, _f64p, _f64p, _i32p]),
+        'orc_residual_k': (i, [i, _f64p]),
+        'orc_lost_dupes': (i, [i, _i32p, _i32p, _i32p]),
+        'orc_reassign': (None, [i, _f64p, i, _i32p, _i32p]),
+        'orc_mean_cov': (None, [i, _f64p, _f64p, _f64p, _f64p]),
+        'orc_det_exp': (d, [d]),
+        'orc_fixed_weights': (u64, [i, _f64p, i, i64, _u64p, vp]),
+        'orc_systematic_ncum': (None, [i, _u64p, u64, u64, i64, u64, _u32p]),
+        'orc_indices_from_ncum': (None, [i64, _u32p, i64, i64, _i32p]),
+        'orc_philox4x32': (None, [u32, u32, u32, u32, u32, u32, _u32p]),
+        'orc_native_normals': (None, [i, i64, u64, u32, u32, _f64p]),
+        'orc_native_u53': (u64, [u64, u32]),
+        'orc_ray_grid': (d, [C.POINTER(_Grid), _f64p, _f64p, d]),
+        'orc_ray_mesh_brute': (d, [_f32p, _u32p, i64, _f64p, _f64p, d]),
+        'orc_mesh_build': (vp, [_f32p, i64, _u32p, i64]),
+        'orc_mesh_free': (None, [vp]),
+        'orc_ray_mesh': (d, [vp, _f64p, _f64p, d]),
+        'orc_mbes_update': (None, [i, _f64p, _f64p, _f64p, i, vp, _f32p, vp, i, d, d, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+_L = _load()
+
+
+def _c(a, dt=np.float64):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ---- state helpers: tests use (n, 6) row arrays; the oracle uses SoA (6, n)
+def to_soa(poses):
+    return np.ascontiguousarray(np.asarray(poses, dtype=np.float64).T)
+
+
+def from_soa(soa):
+    return np.ascontiguousarray(soa.T)
+
+
+def euler_from_quat(q):
+    out = np.zeros(3)
+    _L.orc_euler_from_quat(_c(q), out)
+    return out
+
+
+def quat_from_euler(r, p, y):
+    out = np.zeros(4)
+    _L.orc_quat_from_euler(r, p, y, out)
+    return out
+
+
+def matrix_from_tf(t, q):
+    out = np.zeros(16)
+    _L.orc_matrix_from_tf(_c(t), _c(q), out)
+    return out.reshape(4, 4)
+
+
+def wrap_pi(a):
+    return _L.orc_wrap_pi(float(a))
+
+
+def add_noise(soa, cov, normals):
+    _L.orc_add_noise(soa.shape[1], soa, _c(cov), _c(normals))
+
+
+def predict(soa, v, wz, q, z, dt, pcov, normals=None):
+    nz = None if normals is None else _c(normals)
+    _L.orc_predict(soa.shape[1], soa, _c(v), float(wz), _c(q), float(z), float(dt), _c(pcov),
+                   None if nz is None else nz.ctypes.data)
+
+
+def gps_weights(soa, m2o, gx, gy, sigma):
+    n = soa.shape[1]
+    w, lw = np.zeros(n), np.zeros(n)
+    _L.orc_gps_weights(n, soa, _c(m2o).reshape(-1), float(gx), float(gy), float(sigma),
+                       w.ctypes.data, lw.ctypes.data)
+    return w, lw
+
+
+def numpy_sum(a, stride=1):
+    a = _c(a)
+    return _L.orc_numpy_pairwise_sum(a.ctypes.data, a.size // stride, stride)
+
+
+def normalise_ref(w_raw):
+    w = _c(w_raw).copy()
+    _L.orc_normalise_ref(w.size, w)
+    return w
+
+
+def systematic_ref(w, u):
+    w = _c(w)
+    idx = np.zeros(w.size, np.int32)
+    rc = _L.orc_systematic_ref(w.size, w, float(u), idx)
+    return idx, rc
+
+
+def stratified_ref(w, u):
+    w = _c(w)
+    idx = np.zeros(w.size, np.int32)
+    rc = _L.orc_stratified_ref(w.size, w, _c(u), idx)
+    return idx, rc
+
+
+def multinomial_ref(w, u):
+    w = _c(w)
+    idx = np.zeros(w.size, np.int32)
+    rc = _L.orc_multinomial_ref(w.size, w, _c(u), idx)
+    return idx, rc
+
+
+def naive_ref(w, u01):
+    w = _c(w)
+    idx = np.zeros(w.size, np.int32)
+    rc = _L.orc_naive_ref(w.size, w, float(u01), idx)
+    return idx, rc
+
+
+def residual_k(w):
+    w = _c(w)
+    return _L.orc_residual_k(w.size, w)
+
+
+def residual_ref(w, u):
+    w = _c(w)
+    idx = np.zeros(w.size, np.int32)
+    u = _c(u) if len(u) else np.zeros(1)
+    k = _L.orc_residual_ref(w.size, w, u, idx)
+    return idx, k
+
+
+def lost_dupes(idx):
+    idx = _c(idx, np.int32)
+    lost = np.zeros(idx.size, np.int32)
+    dupes = np.zeros(idx.size, np.int32)
+    nl = _L.orc_lost_dupes(idx.size, idx, lost, dupes)
+    return lost[:nl].copy(), dupes[:nl].copy()
+
+
+def reassign(soa, lost, dupes):
+    _L.orc_reassign(soa.shape[1], soa, len(lost), _c(lost, np.int32), _c(dupes, np.int32))
+
+
+def mean_cov(soa):
+    mean, yaw, cov = np.zeros(6), np.zeros(1), np.zeros(9)
+    _L.orc_mean_cov(soa.shape[1], soa, mean, yaw, cov)
+    return mean, float(yaw[0]), cov
+
+
+def det_exp(x):
+    return _L.orc_det_exp(float(x))
+
+
+def fixed_weights(lw, mode, n_global=None):
+    lw = _c(lw)
+    q = np.zeros(lw.size, np.uint64)
+    wl = np.zeros(lw.size)
+    tot = _L.orc_fixed_weights(lw.size, lw, int(mode), int(n_global or lw.size), q, wl.ctypes.data)
+    return q, int(tot), wl
+
+
+def systematic_ncum(q, u53, c_offset=0, total=None, n_global=None):
+    q = _c(q, np.uint64)
+    if total is None:
+        total = int(q.sum(dtype=np.uint64))
+    out = np.zeros(q.size, np.uint32)
+    _L.orc_systematic_ncum(q.size, q, int(c_offset), int(total), int(n_global or q.size), int(u53), out)
+    return out
+
+
+def indices_from_ncum(ncum, i0=0, cnt=None):
+    ncum = _c(ncum, np.uint32)
+    cnt = ncum.size - i0 if cnt is None else cnt
+    idx = np.zeros(cnt, np.int32)
+    _L.orc_indices_from_ncum(ncum.size, ncum, int(i0), int(cnt), idx)
+    return idx
+
+
+def systematic_fixed(lw, mode, u53):
+    """Full fixed-point systematic resample of one shard-less filter: indices + ncum."""
+    q, tot, _ = fixed_weights(lw, mode)
+    ncum = systematic_ncum(q, u53, 0, tot, q.size)
+    return indices_from_ncum(ncum), ncum, q
+
+
+def u_to_u53(u):
+    return int(np.floor(float(u) * 9007199254740992.0))
+
+
+def philox(c, k):
+    out = np.zeros(4, np.uint32)
+    _L.orc_philox4x32(c[0], c[1], c[2], c[3], k[0], k[1], out)
+    return out
+
+
+def native_normals(n, gid0, seed, purpose, step):
+    out = np.zeros((n, 6))
+    _L.orc_native_normals(n, int(gid0), int(seed), int(purpose), int(step), out)
+    return out
+
+
+def native_u53(seed, step):
+    return int(_L.orc_native_u53(int(seed), int(step)))
+
+
+class Grid(object):
+    def __init__(self, z, origin, res):
+        self.z = _c(z, np.float32)
+        self.s = _Grid(self.z.shape[0], self.z.shape[1], float(origin[0]), float(origin[1]), float(res),
+                       self.z.ctypes.data)
+
+    def ray(self, o, d, r_max):
+        return _L.orc_ray_grid(C.byref(self.s), _c(o), _c(d), float(r_max))
+
+    def _map(self):
+        return 0, C.addressof(self.s)
+
+
+class Mesh(object):
+    def __init__(self, verts, tris):
+        self.verts = _c(verts, np.float32)
+        self.tris = _c(tris, np.uint32)
+        self.h = _L.orc_mesh_build(self.verts, self.verts.shape[0], self.tris, self.tris.shape[0])
+
+    def __del__(self):
+        if getattr(self, 'h', None):
+            _L.orc_mesh_free(self.h)
+            self.h = None
+
+    def ray(self, o, d, r_max):
+        return _L.orc_ray_mesh(self.h, _c(o), _c(d), float(r_max))
+
+    def ray_brute(self, o, d, r_max):
+        return _L.orc_ray_mesh_brute(self.verts, self.tris, self.tris.shape[0], _c(o), _c(d), float(r_max))
+
+    def _map(self):
+        return 1, self.h
+
+
+def mbes_update(soa, m2o, sensor_off, amap, beam_angles, ranges, sigma, r_max, want_expected=True):
+    n = soa.shape[1]
+    ba = _c(beam_angles, np.float32)
+    B = ba.size
+    lw = np.zeros(n)
+    ex = np.zeros((n, B)) if want_expected else None
+    kind, ptr = amap._map()
+    rg = None if ranges is None else _c(ranges, np.float32)
+    _L.orc_mbes_update(n, soa, _c(m2o).reshape(-1), _c(sensor_off), kind, ptr, ba,
+                       None if rg is None else rg.ctypes.data, B, float(sigma), float(r_max),
+                       lw.ctypes.data, None if ex is None else ex.ctypes.data)
+    return lw, ex

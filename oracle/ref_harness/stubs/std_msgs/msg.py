@@ -1,0 +1,3 @@
+class Bool(object):
+    def __init__(self, data=False):
+        self.data = data

@@ -1,0 +1,11 @@
+"""tf2_ros stand-in (TEST INFRASTRUCTURE ONLY)."""
+
+
+class Buffer(object):
+    def lookup_transform(self, *a, **k):
+        raise RuntimeError("no tf in harness")
+
+
+class TransformListener(object):
+    def __init__(self, buf):
+        pass

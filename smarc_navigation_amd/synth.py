@@ -1,0 +1,139 @@
+"""Synthetic input streams for tests and bench (numpy only, no GPU, no reference code).
+
+Follows SURVEY.md section 8(d): the odometry stream is what sam_dead_reckoning's dr_node
+publishes (body-frame DVL twist, IMU yaw rate, roll/pitch quaternion, pressure depth;
+reference contract: sam_dead_reckoning/scripts/dr_node.py:165-246), the GPS fixes are
+truth + N(0, sigma), the bathymetry is a smooth swell plus fBm noise.
+"""
+import math
+import numpy as np
+
+
+def quat_from_rpy(roll, pitch, yaw):
+    """Static-xyz Euler -> quaternion (x, y, z, w); vectorised."""
+    hr, hp, hy = np.asarray(roll) / 2.0, np.asarray(pitch) / 2.0, np.asarray(yaw) / 2.0
+    cr, sr = np.cos(hr), np.sin(hr)
+    cp, sp = np.cos(hp), np.sin(hp)
+    cy, sy = np.cos(hy), np.sin(hy)
+    return np.stack([sr * cp * cy - cr * sp * sy,
+                     cr * sp * cy + sr * cp * sy,
+                     cr * cp * sy - sr * sp * cy,
+                     cr * cp * cy + sr * sp * sy], axis=-1)
+
+
+def wrap_pi(a):
+    return (a + np.pi) % (2 * np.pi) - np.pi
+
+
+def odom_stream(n_steps=3000, dt=0.02, t0=100.0, x0=0.0, y0=0.0, yaw0=0.0, z_mean=-2.0):
+    """Lawn-mower-ish track.  Returns dict of arrays:
+    stamp[n], v[n,3] (body frame), wz[n], q[n,4], z[n], rpy[n,3], truth[n,6] (pose in the
+    odom frame after integrating sample k with the noise-free motion model)."""
+    k = np.arange(n_steps)
+    t = k * dt
+    stamp = t0 + (k + 1) * dt
+    v = np.stack([1.0 + 0.05 * np.sin(0.1 * t), 0.02 * np.sin(0.3 * t), np.zeros(n_steps)], axis=1)
+    # piecewise yaw rate: straight legs with +-0.1 rad/s turns
+    phase = (t % 40.0)
+    leg = (np.floor(t / 40.0).astype(int)) % 2
+    wz = np.where(phase > 30.0, np.where(leg == 0, 0.1, -0.1), 0.0)
+    roll = 0.02 * np.sin(0.5 * t)
+    pitch = 0.02 * np.cos(0.5 * t)
+    z = z_mean - 0.5 * np.sin(0.05 * t)
+    truth = np.zeros((n_steps, 6))
+    x, y, yaw = x0, y0, yaw0
+    dr_yaw = np.zeros(n_steps)
+    for i in range(n_steps):
+        yaw = float(wrap_pi(yaw + wz[i] * dt))
+        cr, sr = math.cos(roll[i]), math.sin(roll[i])
+        cp, sp = math.cos(pitch[i]), math.sin(pitch[i])
+        cy, sy = math.cos(yaw), math.sin(yaw)
+        vx, vy, vz = v[i] * dt
+        x += cy * cp * vx + (cy * sp * sr - sy * cr) * vy + (cy * sp * cr + sy * sr) * vz
+        y += sy * cp * vx + (sy * sp * sr + cy * cr) * vy + (sy * sp * cr - cy * sr) * vz
+        truth[i] = (x, y, z[i], roll[i], pitch[i], yaw)
+        dr_yaw[i] = yaw
+    q = quat_from_rpy(roll, pitch, dr_yaw)
+    return dict(stamp=stamp, dt=dt, t0=t0, v=v, wz=wz, q=q, z=z,
+                rpy=np.stack([roll, pitch, dr_yaw], axis=1), truth=truth)
+
+
+def rigid_matrix(tx, ty, tz, roll, pitch, yaw):
+    """4x4 homogeneous transform T(t) * R(static-xyz rpy)."""
+    cr, sr = math.cos(roll), math.sin(roll)
+    cp, sp = math.cos(pitch), math.sin(pitch)
+    cy, sy = math.cos(yaw), math.sin(yaw)
+    m = np.identity(4)
+    m[:3, :3] = [[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                 [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                 [-sp, cp * sr, cp * cr]]
+    m[:3, 3] = (tx, ty, tz)
+    return m
+
+
+def gps_fixes(truth, m2o, every=50, sigma=1.0, seed=2):
+    """GPS fixes in the MAP frame: m2o * truth_xy + N(0, sigma).  Returns (step_idx, xy)."""
+    rs = np.random.RandomState(seed)
+    idx = np.arange(every - 1, truth.shape[0], every)
+    p = np.concatenate([truth[idx, :3], np.ones((idx.size, 1))], axis=1).dot(m2o.T)[:, :2]
+    return idx, p + sigma * rs.randn(idx.size, 2)
+
+
+def _value_noise(nx, ny, cells, rs):
+    """Bilinear-interpolated lattice noise with `cells` lattice cells across the grid."""
+    lat = rs.rand(cells + 2, cells + 2) * 2.0 - 1.0
+    gx = np.linspace(0.0, cells, nx, endpoint=False)
+    gy = np.linspace(0.0, cells, ny, endpoint=False)
+    ix, iy = gx.astype(int), gy.astype(int)
+    fx, fy = gx - ix, gy - iy
+    fx = fx * fx * (3 - 2 * fx)
+    fy = fy * fy * (3 - 2 * fy)
+    a = lat[np.ix_(ix, iy)]
+    b = lat[np.ix_(ix + 1, iy)]
+    c = lat[np.ix_(ix, iy + 1)]
+    d = lat[np.ix_(ix + 1, iy + 1)]
+    FX, FY = fx[:, None], fy[None, :]
+    return a * (1 - FX) * (1 - FY) + b * FX * (1 - FY) + c * (1 - FX) * FY + d * FX * FY
+
+
+def bathymetry_grid(nx=512, ny=512, res=1.0, origin=(-64.0, -256.0), seed=3, depth=-20.0,
+                    swell=3.0, fbm_amp=0.5):
+    """Height grid z[ix, iy] (fp32, C order, x-major): depth + swell*sin(x/17)cos(y/23) + fBm.
+    Node (ix, iy) sits at (origin_x + ix*res, origin_y + iy*res) in the map frame."""
+    rs = np.random.RandomState(seed)
+    x = origin[0] + res * np.arange(nx)
+    y = origin[1] + res * np.arange(ny)
+    z = depth + swell * np.sin(x[:, None] / 17.0) * np.cos(y[None, :] / 23.0)
+    amp, cells, tot = 1.0, 8, 0.0
+    noise = np.zeros((nx, ny))
+    for _ in range(5):
+        noise += amp * _value_noise(nx, ny, cells, rs)
+        tot += amp
+        amp *= 0.5
+        cells *= 2
+    z = z + fbm_amp * noise / tot * 2.0
+    return np.ascontiguousarray(z, dtype=np.float32)
+
+
+def mesh_from_grid(z, res, origin):
+    """Triangulate a height grid: verts[nv,3] fp32, tris[nt,3] uint32; 2 triangles per cell,
+    split along the (ix,iy)-(ix+1,iy+1) diagonal."""
+    nx, ny = z.shape
+    ix, iy = np.meshgrid(np.arange(nx), np.arange(ny), indexing='ij')
+    verts = np.stack([origin[0] + res * ix, origin[1] + res * iy, z], axis=-1)
+    verts = verts.reshape(-1, 3).astype(np.float32)
+    v00 = (ix[:-1, :-1] * ny + iy[:-1, :-1]).reshape(-1)
+    v10 = v00 + ny
+    v01 = v00 + 1
+    v11 = v00 + ny + 1
+    tris = np.concatenate([np.stack([v00, v10, v11], axis=1),
+                           np.stack([v00, v11, v01], axis=1)], axis=0).astype(np.uint32)
+    return verts, tris
+
+
+def beam_angles(n_beams, half_swath=math.pi / 3):
+    """LaserScan-style fan: angle_min=-half_swath, equal increments, inclusive of +half_swath
+    (mbes_processors/mbes_toy_processor/src/toy_mbes_manipulator.cpp:69-73 geometry)."""
+    if n_beams == 1:
+        return np.zeros(1, dtype=np.float32)
+    return np.linspace(-half_swath, half_swath, n_beams).astype(np.float32)
