@@ -1,0 +1,195 @@
+/* mcl.h -- C ABI of the MI355X-native Monte-Carlo localization engine (libmcl_hip.so).
+ *
+ * Drop-in boundary for the hot path of smarc_navigation's auv_particle_filter node.  The
+ * reference has no FFI of its own (its hot path is Python inside the rospy node); this ABI sits
+ * at the seam between the node's ROS plumbing (auv_pf.py) and its numerics (auv_particle.py,
+ * resampling.py).  Each entry point cites the reference code it replaces, relative to
+ * /root/reference/auv_particle_filter/scripts/.
+ *
+ * Conventions: extern "C"; opaque handle; every call returns an int status (MCL_OK == 0,
+ * negative = error, mcl_last_error() gives the text); no exceptions cross the boundary; caller
+ * owns every host buffer, the library owns every device buffer; one handle is used by one
+ * thread at a time (the reference's three unlocked rospy threads are specified away,
+ * SURVEY.md A.10).  All particle math is IEEE fp64 like the reference; state is SoA in HBM:
+ * six arrays x, y, z, roll, pitch, yaw of n doubles (odom frame).  There is NO CPU fallback:
+ * without a gfx950 device mcl_create() fails with MCL_ERR_NO_DEVICE.
+ */
+#ifndef MCL_H
+#define MCL_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCL_ABI_VERSION 1
+
+typedef struct mcl_handle mcl_handle;
+
+enum mcl_status {
+  MCL_OK = 0,
+  MCL_ERR_INVALID = -1,     /* bad argument */
+  MCL_ERR_NO_DEVICE = -2,   /* no HIP device / not gfx950 */
+  MCL_ERR_HIP = -3,         /* a HIP runtime call failed */
+  MCL_ERR_UNSUPPORTED = -4, /* valid request this build does not implement */
+  MCL_ERR_STATE = -5,       /* call order (e.g. update_mbes before set_map_*) */
+  MCL_ERR_COMM = -6,        /* RCCL failure */
+  MCL_ERR_ALLOC = -7
+};
+
+enum mcl_resample_scheme {
+  MCL_RESAMPLE_SYSTEMATIC = 0, /* resampling.py:135-168 -- the GPU production scheme */
+  MCL_RESAMPLE_RESIDUAL = 1,   /* resampling.py:27-76   -- what auv_pf.py:182 calls */
+  MCL_RESAMPLE_STRATIFIED = 2, /* resampling.py:80-114 */
+  MCL_RESAMPLE_MULTINOMIAL = 3 /* resampling.py:171-194 */
+};
+
+enum mcl_rng_mode {
+  MCL_RNG_NATIVE = 0, /* Philox4x32-10 keyed by (seed, step, GLOBAL particle id): grid/GPU-count invariant */
+  MCL_RNG_REPLAY = 1  /* caller passes the normals/uniforms (parity with numpy's MT19937 stream) */
+};
+
+enum mcl_comm_mode {
+  MCL_COMM_NONE = 0,  /* single shard */
+  MCL_COMM_RCCL = 1,  /* one process per GPU, RCCL over xGMI (mcl_comm_init) */
+  MCL_COMM_LOCAL = 2  /* several shards in ONE process (same or different GPUs); test harness */
+};
+
+enum mcl_weight_mode {
+  MCL_WEIGHT_LINEAR_FLOOR = 0, /* w = exp(lw) + 1e-200   (auv_pf.py:165, GPS update) */
+  MCL_WEIGHT_LOG_SHIFT = 1,    /* w = exp(lw - max lw)   (MBES update, log domain) */
+  MCL_WEIGHT_LINEAR = 2        /* the values ARE linear weights (mcl_resample_indices) */
+};
+
+typedef struct mcl_config {
+  int64_t n_particles;   /* particles owned by THIS shard (auv_pf.py:27 `particle_count`) */
+  int64_t n_global;      /* total over all shards; 0 -> n_particles */
+  int64_t global_offset; /* global id of this shard's particle 0 */
+  int32_t device;        /* HIP device ordinal */
+  int32_t rank, world;   /* shard index / count (world 0 or 1 -> single shard) */
+  int32_t resample_scheme;
+  int32_t rng_mode;
+  int32_t comm_mode;
+  uint64_t seed;
+  double init_cov[6];     /* auv_pf.py:46-50  `init_covariance`             order x,y,z,roll,pitch,yaw */
+  double process_cov[6];  /* auv_pf.py:40-44  `motion_covariance` */
+  double resample_cov[6]; /* auv_pf.py:52-56  `resampling_noise_covariance` */
+  double meas_std;        /* auv_pf.py:39     `measurement_std` (GPS) */
+  double m2o[16];         /* row-major 4x4 map<-odom, matrix_from_tf (auv_particle.py:110-125) */
+} mcl_config;
+
+/* The fields of nav_msgs/Odometry the filter consumes (auv_particle.py:45-70). */
+typedef struct mcl_odom {
+  double stamp; /* header.stamp.to_sec() */
+  double v[3];  /* twist.twist.linear, body frame */
+  double w_z;   /* twist.twist.angular.z */
+  double q[4];  /* pose.pose.orientation x,y,z,w */
+  double z;     /* pose.pose.position.z */
+} mcl_odom;
+
+/* Per-kernel device time accumulated with HIP events on the handle's stream while timing is on. */
+enum mcl_kernel_id {
+  MCL_K_PREDICT = 0,
+  MCL_K_UPDATE_GPS = 1,
+  MCL_K_UPDATE_MBES = 2,
+  MCL_K_NORMALISE = 3, /* max-reduce + exp + fixed-point quantise */
+  MCL_K_SCAN = 4,      /* u64 prefix scan + offspring counts */
+  MCL_K_RESAMPLE = 5,  /* lost-slot scan + reassign gather + noise */
+  MCL_K_MEAN_COV = 6,
+  MCL_K_NOISE = 7,
+  MCL_K_COMM = 8,
+  MCL_K_COUNT = 9
+};
+typedef struct mcl_timing {
+  double ms[MCL_K_COUNT];       /* summed device milliseconds */
+  int64_t launches[MCL_K_COUNT]; /* number of timed regions */
+} mcl_timing;
+
+/* ---- library ------------------------------------------------------------------------- */
+int mcl_abi_version(void);
+const char* mcl_status_string(int status);
+const char* mcl_last_error(const mcl_handle* h); /* h may be NULL: last create() error */
+int mcl_device_count(int* count);
+
+/* ---- lifetime: replaces auv_pf.__init__'s particle list (auv_pf.py:89-94) ---------------- */
+int mcl_create(const mcl_config* cfg, mcl_handle** out);
+int mcl_destroy(mcl_handle* h);
+/* Particle.__init__: pose = 0 + add_noise(init_cov) (auv_particle.py:24,30).
+ * replay_normals: n x 6 doubles, particle-major (REPLAY mode) or NULL (NATIVE). */
+int mcl_init_particles(mcl_handle* h, const double* replay_normals);
+
+/* ---- a3/a4/a5: auv_pf.predict + Particle.motion_pred (auv_pf.py:213-216, auv_particle.py:38-97)
+ * dt <= 0 is a no-op like the reference's `time > old_time` gate (auv_pf.py:205). */
+int mcl_predict(mcl_handle* h, const mcl_odom* odom, double dt, const double* replay_normals);
+
+/* ---- a6/a7: auv_pf.update + Particle.compute_weight (auv_pf.py:135-167, auv_particle.py:100-106)
+ * (gx, gy) = the GPS fix already transformed utm->map (the reference repeats that transform per
+ * particle with identical result, auv_pf.py:151).  Leaves log-weights on the device. */
+int mcl_update_gps(mcl_handle* h, double gx_map, double gy_map);
+
+/* ---- a15: MBES measurement update (no reference symbol; north_star).  Map in the MAP frame. */
+int mcl_set_map_grid(mcl_handle* h, const float* z, int32_t nx, int32_t ny, double origin_x,
+                     double origin_y, double res); /* z[ix*ny + iy] at (ox + ix*res, oy + iy*res) */
+int mcl_set_map_mesh(mcl_handle* h, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt);
+/* ranges[b] <= 0 or NaN marks an invalid beam; beam b looks along (0, sin a_b, -cos a_b) in the
+ * sensor frame; sensor_offset = x,y,z,roll,pitch,yaw of the sensor in base_link (NULL = zeros). */
+int mcl_update_mbes(mcl_handle* h, const float* ranges, const float* beam_angles, int32_t n_beams,
+                    double sigma, double r_max, const double sensor_offset[6]);
+/* expected ranges of particles [first, first+count) x n_beams (host floats); parity/diagnostics */
+int mcl_mbes_expected(mcl_handle* h, int64_t first, int64_t count, const float* beam_angles,
+                      int32_t n_beams, double r_max, const double sensor_offset[6], float* out);
+
+/* ---- a8-a12 + a2: auv_pf.resample (auv_pf.py:169-198): normalise, resample, keep/lost/dupes
+ * reassign, add_noise(resampling_noise_covariance).
+ * uniforms: REPLAY: scheme-dependent draws in reference order (systematic: 1); NATIVE: NULL.
+ * replay_normals: n x 6 post-resample noise draws (REPLAY) or NULL. */
+int mcl_resample(mcl_handle* h, const double* uniforms, int64_t n_uniforms, const double* replay_normals);
+
+/* ---- a13: loc_loop/update_loc_pose (auv_pf.py:218-285) */
+int mcl_mean_cov(mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9]);
+/* PoseArray payload: n x 7 doubles (x,y,z,qx,qy,qz,qw), quaternion_from_euler per particle */
+int mcl_get_poses(mcl_handle* h, double* pose7);
+
+/* ---- state access (checkpoint / tests).  soa: 6 x n doubles; w: n normalised weights or NULL */
+int mcl_get_particles(mcl_handle* h, double* soa, double* w);
+int mcl_set_particles(mcl_handle* h, const double* soa);
+int mcl_get_log_weights(mcl_handle* h, double* lw);
+int mcl_set_log_weights(mcl_handle* h, const double* lw, int32_t weight_mode);
+int mcl_get_last_indices(mcl_handle* h, int32_t* idx);      /* FilterPy-style ancestor indices, n */
+int mcl_get_last_offspring_cdf(mcl_handle* h, uint32_t* ncum); /* n_global cumulative offspring counts */
+int mcl_get_fixed_weights(mcl_handle* h, uint64_t* q, uint64_t* total);
+
+/* ---- one fused filter step, fully asynchronous on the handle's stream (bench / production):
+ * predict -> MBES update -> normalise -> resample(+noise) -> mean/cov.  NATIVE rng only. */
+int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* ranges,
+                  const float* beam_angles, int32_t n_beams, double sigma, double r_max,
+                  const double sensor_offset[6]);
+int mcl_sync(mcl_handle* h);
+/* mean/cov computed by the last mcl_step_mbes (syncs the stream) */
+int mcl_last_mean_cov(mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9]);
+
+/* ---- resampling.py as free functions on the GPU (fixed-point CDF):
+ * weights need not be normalised; out: n int32 ancestor indices. */
+int mcl_resample_indices(int32_t scheme, const double* weights, int64_t n, const double* uniforms,
+                         int64_t n_uniforms, int32_t device, int32_t* out);
+
+/* ---- multi-GPU: particles shard by contiguous global id; RCCL all-reduce (max log-w),
+ * all-gather (shard totals, offspring CDF, ancestor states) */
+int mcl_comm_unique_id(char id[128]);
+int mcl_comm_init(mcl_handle* h, const char id[128]); /* MCL_COMM_RCCL: collective over all ranks */
+/* MCL_COMM_LOCAL: all shards live in this process; the exchange steps are device copies.  The
+ * sharded algorithm (and therefore every result bit) is the one the RCCL path runs. */
+int mcl_group_resample(mcl_handle** shards, int32_t n_shards, const double* uniforms, int64_t n_uniforms,
+                       const double* const* replay_normals /* per shard, or NULL */);
+int mcl_group_mean_cov(mcl_handle** shards, int32_t n_shards, double mean6[6], double* yaw_mean,
+                       double cov9[9]);
+
+/* ---- instrumentation */
+int mcl_timing_enable(mcl_handle* h, int32_t on);
+int mcl_timing_get(mcl_handle* h, mcl_timing* out); /* syncs, returns and resets the accumulators */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCL_H */

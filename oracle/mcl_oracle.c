@@ -453,12 +453,14 @@ uint64_t orc_fixed_weights(int n, const double* lw, int mode, int64_t n_global, 
   for (int i = 0; i < n; ++i) {
     if (mode == 0)
       w[i] = orc_det_exp(lw[i]) + 1.e-200;
-    else
+    else if (mode == 1)
       w[i] = (m_lw == -INFINITY) ? 1.0 : orc_det_exp(lw[i] - m_lw);
+    else
+      w[i] = lw[i] > 0.0 ? lw[i] : 0.0; /* mode 2: linear weights given directly */
   }
-  double mw = 0.0;
-  for (int i = 0; i < n; ++i)
-    if (w[i] > mw) mw = w[i];
+  /* normaliser = the weight of the max-log-weight particle (exact, order-free; not max(w), so the
+   * spec does not depend on det_exp being monotone) */
+  const double mw = (mode == 0) ? orc_det_exp(m_lw) + 1.e-200 : (mode == 1 ? 1.0 : m_lw);
   const int s = 63 - ceil_log2_i64(n_global);
   const double scale = ldexp(1.0, s);
   uint64_t tot = 0;

@@ -64,7 +64,8 @@ void orc_mean_cov(int n, const double* state, double mean6[6], double* yaw_mean,
  * DESIGN.md "Resampling arithmetic").  Deterministic, order-free (integer sums). */
 double orc_det_exp(double x);
 /* mode 0 (GPS/reference): w = det_exp(lw) + 1e-200;  mode 1 (MBES/log domain): w = det_exp(lw - max lw).
- * q_i = floor(w_i / max_w * 2^(63 - ceil_log2(n_global))).  Returns total T = sum q. */
+ * q_i = floor(w_i / mw * 2^(63 - ceil_log2(n_global))), mw = weight of the max-lw particle.
+ * Multi-shard: pass m_lw_global via lw of all shards (the caller concatenates).  Returns T = sum q. */
 uint64_t orc_fixed_weights(int n, const double* lw, int mode, int64_t n_global, uint64_t* q,
                            double* w_lin);
 /* ncum[j] = #{ i in [0,N) : (U53 + i*2^53) * T < C_j * N * 2^53 },  C = inclusive scan of q

@@ -1,0 +1,1128 @@
+// mcl_api.hip -- host side of libmcl_hip.so: the C ABI declared in include/mcl.h.
+// C++ host code that owns the device buffers, orders kernels on one HIP stream per handle and
+// runs the shard-exchange steps over RCCL (one process per GPU) or device copies (LOCAL group).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mcl.h"
+#include "mcl_kernels.h"
+#include "mcl_mbes.h"
+#include "mcl_mesh.h"
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct TimedRegion {
+  hipEvent_t a, b;
+  int k;
+};
+
+}  // namespace
+
+struct mcl_handle {
+  mcl_config cfg;
+  long long n = 0, ng = 0, goff = 0;
+  int rank = 0, world = 1;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // particle state: two ping-pong SoA buffers of 6*n doubles; multi-shard: a global copy
+  double* state[2] = {nullptr, nullptr};
+  int cur = 0;
+  double* state_glob = nullptr;  // 6*ng (world > 1)
+  double* lw = nullptr;          // n log-weights
+  double* wnorm = nullptr;       // n (lazily)
+  u64* q = nullptr;              // n fixed-point weights
+  u32* ncum = nullptr;           // ng offspring CDF (global)
+  u32* zcum = nullptr;           // ng lost-slot ranks (global)
+  u64* tile64 = nullptr;
+  u32* tile32 = nullptr;
+  long long ntiles_loc = 0, ntiles_glob = 0;
+  double* part = nullptr;     // reduction partials [7][MCL_MAX_GRID]
+  double* scal = nullptr;     // device scalars: [0] max lw, [8..14] sums7, [16..21] cov6
+  u64* totals = nullptr;      // device, world entries (+1 scratch)
+  int* idx = nullptr;         // n (lazily)
+  double* replay_dev = nullptr;
+  double* pose7 = nullptr;
+  double* host_pin = nullptr;  // pinned: 16 doubles
+  // MBES
+  float2* beam_sc = nullptr;
+  float* ranges_dev = nullptr;
+  float* exp_dev = nullptr;
+  size_t exp_cap = 0;
+  int beams_cap = 0;
+  std::vector<float> beam_cache;  // last uploaded angles
+  float* grid = nullptr;
+  int gnx = 0, gny = 0;
+  double gox = 0, goy = 0, gres = 1;
+  float gzmin = 0, gzmax = 0;
+  MeshDev* mesh = nullptr;
+  int map_kind = -1;  // 0 grid, 1 mesh
+  // bookkeeping
+  int weight_mode = 0;
+  bool have_lw = false, have_cdf = false, have_meancov = false;
+  uint32_t step_predict = 0, step_resample = 0;
+  bool timing = false;
+  std::vector<TimedRegion> regions;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  mcl_timing tacc;
+  ncclComm_t comm = nullptr;
+  std::string err;
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                        \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      char buf_[512];                                                                          \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      (h)->err = buf_;                                                                         \
+      return MCL_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+#define NCCLCHK(h, call)                                                                       \
+  do {                                                                                         \
+    ncclResult_t e_ = (call);                                                                  \
+    if (e_ != ncclSuccess) {                                                                   \
+      char buf_[512];                                                                          \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(e_), __FILE__, __LINE__); \
+      (h)->err = buf_;                                                                         \
+      return MCL_ERR_COMM;                                                                     \
+    }                                                                                          \
+  } while (0)
+#define RET_IF(x)           \
+  do {                      \
+    int rc_ = (x);          \
+    if (rc_ != MCL_OK) return rc_; \
+  } while (0)
+
+int fail(mcl_handle* h, int code, const char* msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+int grid_for(long long n, int block = MCL_BLOCK) {
+  long long g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > MCL_MAX_GRID) g = MCL_MAX_GRID;
+  return (int)g;
+}
+int grid_tiles(long long ntiles) {
+  if (ntiles < 1) ntiles = 1;
+  return (int)(ntiles > MCL_MAX_GRID ? MCL_MAX_GRID : ntiles);
+}
+
+StatePtrs state_ptrs(double* base, long long n) {
+  StatePtrs s;
+  for (int c = 0; c < 6; ++c) s.c[c] = base + (size_t)c * n;
+  return s;
+}
+
+void t_begin(mcl_handle* h, int k) {
+  if (!h->timing) return;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (!h->ev_pool.empty()) {
+    ev = h->ev_pool.back();
+    h->ev_pool.pop_back();
+  } else {
+    hipEventCreate(&ev.first);
+    hipEventCreate(&ev.second);
+  }
+  hipEventRecord(ev.first, h->stream);
+  h->regions.push_back(TimedRegion{ev.first, ev.second, k});
+}
+void t_end(mcl_handle* h) {
+  if (!h->timing) return;
+  hipEventRecord(h->regions.back().b, h->stream);
+}
+void t_collect(mcl_handle* h) {
+  for (auto& r : h->regions) {
+    float ms = 0.f;
+    hipEventSynchronize(r.b);
+    hipEventElapsedTime(&ms, r.a, r.b);
+    h->tacc.ms[r.k] += ms;
+    h->tacc.launches[r.k] += 1;
+    h->ev_pool.push_back({r.a, r.b});
+  }
+  h->regions.clear();
+}
+
+// euler_from_quaternion(q,'sxyz') -- tf.transformations' published algorithm (auv_particle.py:50)
+void euler_from_quat(const double qin[4], double rpy[3]) {
+  double nq = qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3];
+  double M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (nq >= 2.220446049250313e-16 * 4.0) {
+    double s = std::sqrt(2.0 / nq);
+    double q[4] = {qin[0] * s, qin[1] * s, qin[2] * s, qin[3] * s};
+    double o[4][4];
+    for (int a = 0; a < 4; ++a)
+      for (int b = 0; b < 4; ++b) o[a][b] = q[a] * q[b];
+    M[0] = 1.0 - o[1][1] - o[2][2];
+    M[1] = o[0][1] - o[2][3];
+    M[2] = o[0][2] + o[1][3];
+    M[3] = o[0][1] + o[2][3];
+    M[4] = 1.0 - o[0][0] - o[2][2];
+    M[5] = o[1][2] - o[0][3];
+    M[6] = o[0][2] - o[1][3];
+    M[7] = o[1][2] + o[0][3];
+    M[8] = 1.0 - o[0][0] - o[1][1];
+  }
+  double cy = std::sqrt(M[0] * M[0] + M[3] * M[3]);
+  if (cy > 2.220446049250313e-16 * 4.0) {
+    rpy[0] = std::atan2(M[7], M[8]);
+    rpy[1] = std::atan2(-M[6], cy);
+    rpy[2] = std::atan2(M[3], M[0]);
+  } else {
+    rpy[0] = std::atan2(-M[5], M[4]);
+    rpy[1] = std::atan2(-M[6], cy);
+    rpy[2] = 0.0;
+  }
+}
+
+void philox_host(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t o[4]) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  o[0] = c0;
+  o[1] = c1;
+  o[2] = c2;
+  o[3] = c3;
+}
+uint64_t native_u53(uint64_t seed, uint32_t step) {
+  uint32_t o[4];
+  philox_host(0xFFFFFFFFu, 0u, step, 3u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  return ((uint64_t)(o[0] >> 5) << 26) | (uint64_t)(o[1] >> 6);
+}
+
+int ceil_log2(long long n) {
+  int l = 0;
+  while ((1ll << l) < n) ++l;
+  return l;
+}
+
+NoiseArgs noise_args(const mcl_handle* h, const double cov[6], uint32_t purpose, uint32_t step) {
+  NoiseArgs a;
+  for (int c = 0; c < 6; ++c) a.sq[c] = std::sqrt(cov[c]);
+  a.k0 = (uint32_t)h->cfg.seed;
+  a.k1 = (uint32_t)(h->cfg.seed >> 32);
+  a.step = step;
+  a.purpose = purpose;
+  a.gid0 = h->goff;
+  return a;
+}
+
+int upload_replay(mcl_handle* h, const double* normals) {
+  if (!h->replay_dev) HIPCHK(h, hipMalloc(&h->replay_dev, sizeof(double) * 6 * (size_t)h->n));
+  HIPCHK(h, hipMemcpyAsync(h->replay_dev, normals, sizeof(double) * 6 * (size_t)h->n, hipMemcpyHostToDevice,
+                           h->stream));
+  return MCL_OK;
+}
+
+int set_device(mcl_handle* h) {
+  HIPCHK(h, hipSetDevice(h->device));
+  return MCL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// resample pipeline, written over a set of shards so that the RCCL path (one shard per process)
+// and the LOCAL test group (several shards in one process) execute the same phases.
+// ------------------------------------------------------------------------------------------
+int phase_local_max(mcl_handle* h) {
+  RET_IF(set_device(h));
+  t_begin(h, MCL_K_NORMALISE);
+  const int g = grid_for(h->n);
+  k_max_partial<<<g, MCL_BLOCK, 0, h->stream>>>(h->lw, h->n, h->part);
+  k_max_final<<<1, 1024, 0, h->stream>>>(h->part, g, h->scal);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+
+int exchange_max(mcl_handle** sh, int ns) {
+  if (ns == 1) {
+    mcl_handle* h = sh[0];
+    if (h->comm) {
+      t_begin(h, MCL_K_COMM);
+      NCCLCHK(h, ncclAllReduce(h->scal, h->scal, 1, ncclDouble, ncclMax, h->comm, h->stream));
+      t_end(h);
+    }
+    return MCL_OK;
+  }
+  double m = -INFINITY;
+  for (int s = 0; s < ns; ++s) {
+    double v;
+    RET_IF(set_device(sh[s]));
+    HIPCHK(sh[s], hipMemcpyAsync(&v, sh[s]->scal, sizeof(double), hipMemcpyDeviceToHost, sh[s]->stream));
+    HIPCHK(sh[s], hipStreamSynchronize(sh[s]->stream));
+    if (v > m) m = v;
+  }
+  for (int s = 0; s < ns; ++s) {
+    RET_IF(set_device(sh[s]));
+    HIPCHK(sh[s], hipMemcpyAsync(sh[s]->scal, &m, sizeof(double), hipMemcpyHostToDevice, sh[s]->stream));
+    HIPCHK(sh[s], hipStreamSynchronize(sh[s]->stream));
+  }
+  return MCL_OK;
+}
+
+int phase_quantise(mcl_handle* h) {
+  RET_IF(set_device(h));
+  const double scale = std::ldexp(1.0, 63 - ceil_log2(h->ng));
+  t_begin(h, MCL_K_NORMALISE);
+  k_q_tile_sums<<<grid_tiles(h->ntiles_loc), MCL_BLOCK, 0, h->stream>>>(h->lw, h->n, h->scal, h->weight_mode,
+                                                                        scale, h->q, h->tile64);
+  t_end(h);
+  t_begin(h, MCL_K_SCAN);
+  k_scan_tile_sums<u64><<<1, 1024, 0, h->stream>>>(h->tile64, h->ntiles_loc, h->totals + h->rank);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+
+int exchange_totals(mcl_handle** sh, int ns) {
+  if (ns == 1) {
+    mcl_handle* h = sh[0];
+    if (h->comm) {
+      t_begin(h, MCL_K_COMM);
+      NCCLCHK(h, ncclAllGather(h->totals + h->rank, h->totals, 1, ncclUint64, h->comm, h->stream));
+      t_end(h);
+    }
+    return MCL_OK;
+  }
+  std::vector<u64> t(ns);
+  for (int s = 0; s < ns; ++s) {
+    RET_IF(set_device(sh[s]));
+    HIPCHK(sh[s], hipMemcpyAsync(&t[s], sh[s]->totals + s, sizeof(u64), hipMemcpyDeviceToHost, sh[s]->stream));
+    HIPCHK(sh[s], hipStreamSynchronize(sh[s]->stream));
+  }
+  for (int s = 0; s < ns; ++s) {
+    RET_IF(set_device(sh[s]));
+    HIPCHK(sh[s], hipMemcpyAsync(sh[s]->totals, t.data(), sizeof(u64) * ns, hipMemcpyHostToDevice, sh[s]->stream));
+    HIPCHK(sh[s], hipStreamSynchronize(sh[s]->stream));
+  }
+  return MCL_OK;
+}
+
+int phase_cdf(mcl_handle* h, uint64_t u53) {
+  RET_IF(set_device(h));
+  CdfArgs a;
+  a.totals = h->totals;
+  a.rank = h->rank;
+  a.world = h->world;
+  a.n_global = (u64)h->ng;
+  a.u53 = u53;
+  t_begin(h, MCL_K_SCAN);
+  k_offspring_cdf<<<grid_tiles(h->ntiles_loc), MCL_BLOCK, 0, h->stream>>>(h->q, h->n, h->tile64, a,
+                                                                          h->ncum + h->goff);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+
+// all-gather of the offspring CDF slices and of the pre-resample state (north_star: "all-gather
+// before resampling"); shards are contiguous and equal-sized
+int exchange_cdf_state(mcl_handle** sh, int ns) {
+  if (ns == 1) {
+    mcl_handle* h = sh[0];
+    if (h->comm) {
+      t_begin(h, MCL_K_COMM);
+      NCCLCHK(h, ncclGroupStart());
+      NCCLCHK(h, ncclAllGather(h->ncum + h->goff, h->ncum, (size_t)h->n, ncclUint32, h->comm, h->stream));
+      for (int c = 0; c < 6; ++c)
+        NCCLCHK(h, ncclAllGather(h->state[h->cur] + (size_t)c * h->n, h->state_glob + (size_t)c * h->ng,
+                                 (size_t)h->n, ncclDouble, h->comm, h->stream));
+      NCCLCHK(h, ncclGroupEnd());
+      t_end(h);
+    }
+    return MCL_OK;
+  }
+  for (int s = 0; s < ns; ++s) HIPCHK(sh[s], hipStreamSynchronize(sh[s]->stream));
+  for (int d = 0; d < ns; ++d) {
+    mcl_handle* D = sh[d];
+    RET_IF(set_device(D));
+    for (int s = 0; s < ns; ++s) {
+      mcl_handle* S = sh[s];
+      if (s != d)
+        HIPCHK(D, hipMemcpyAsync(D->ncum + S->goff, S->ncum + S->goff, sizeof(u32) * (size_t)S->n,
+                                 hipMemcpyDefault, D->stream));
+      for (int c = 0; c < 6; ++c)
+        HIPCHK(D, hipMemcpyAsync(D->state_glob + (size_t)c * D->ng + S->goff, S->state[S->cur] + (size_t)c * S->n,
+                                 sizeof(double) * (size_t)S->n, hipMemcpyDefault, D->stream));
+    }
+    HIPCHK(D, hipStreamSynchronize(D->stream));
+  }
+  return MCL_OK;
+}
+
+int phase_reassign(mcl_handle* h, const double* replay_normals) {
+  RET_IF(set_device(h));
+  if (replay_normals) RET_IF(upload_replay(h, replay_normals));
+  t_begin(h, MCL_K_RESAMPLE);
+  k_zero_tile_sums<<<grid_tiles(h->ntiles_glob), MCL_BLOCK, 0, h->stream>>>(h->ncum, h->ng, h->tile32);
+  k_scan_tile_sums<u32><<<1, 1024, 0, h->stream>>>(h->tile32, h->ntiles_glob, h->tile32 + h->ntiles_glob);
+  k_zero_scan<<<grid_tiles(h->ntiles_glob), MCL_BLOCK, 0, h->stream>>>(h->ncum, h->ng, h->tile32, h->zcum);
+  ReassignArgs a;
+  const bool multi = h->world > 1;
+  a.src = multi ? state_ptrs(h->state_glob, h->ng) : state_ptrs(h->state[h->cur], h->n);
+  a.dst = state_ptrs(h->state[h->cur ^ 1], h->n);
+  a.n = h->n;
+  a.n_global = h->ng;
+  a.goff = h->goff;
+  a.nz = noise_args(h, h->cfg.resample_cov, 2u, h->step_resample);
+  a.add_noise = 1;
+  k_reassign_noise<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(a, h->ncum, h->zcum,
+                                                               replay_normals ? h->replay_dev : nullptr);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  h->cur ^= 1;
+  h->step_resample++;
+  h->have_cdf = true;
+  h->have_lw = false;
+  return MCL_OK;
+}
+
+int run_resample(mcl_handle** sh, int ns, const double* uniforms, long long nu,
+                 const double* const* replay_normals) {
+  mcl_handle* h0 = sh[0];
+  for (int s = 0; s < ns; ++s) {
+    if (!sh[s]->have_lw) return fail(sh[s], MCL_ERR_STATE, "resample: no weights (call an update first)");
+    if (sh[s]->cfg.resample_scheme != MCL_RESAMPLE_SYSTEMATIC)
+      return fail(sh[s], MCL_ERR_UNSUPPORTED,
+                  "resample: only MCL_RESAMPLE_SYSTEMATIC runs on the GPU in this build (no CPU fallback)");
+  }
+  uint64_t u53;
+  if (h0->cfg.rng_mode == MCL_RNG_REPLAY) {
+    if (!uniforms || nu < 1) return fail(h0, MCL_ERR_INVALID, "resample: REPLAY mode needs 1 uniform");
+    if (!(uniforms[0] >= 0.0 && uniforms[0] < 1.0)) return fail(h0, MCL_ERR_INVALID, "resample: u not in [0,1)");
+    u53 = (uint64_t)std::floor(uniforms[0] * 9007199254740992.0);
+  } else {
+    u53 = native_u53(h0->cfg.seed, h0->step_resample);
+  }
+  for (int s = 0; s < ns; ++s) RET_IF(phase_local_max(sh[s]));
+  RET_IF(exchange_max(sh, ns));
+  for (int s = 0; s < ns; ++s) RET_IF(phase_quantise(sh[s]));
+  RET_IF(exchange_totals(sh, ns));
+  for (int s = 0; s < ns; ++s) RET_IF(phase_cdf(sh[s], u53));
+  RET_IF(exchange_cdf_state(sh, ns));
+  for (int s = 0; s < ns; ++s)
+    RET_IF(phase_reassign(sh[s], (replay_normals && sh[s]->cfg.rng_mode == MCL_RNG_REPLAY) ? replay_normals[s]
+                                                                                          : nullptr));
+  return MCL_OK;
+}
+
+// ------------------------------------------------------------------------------------------ mean/cov
+int phase_mean_partial(mcl_handle* h) {
+  RET_IF(set_device(h));
+  t_begin(h, MCL_K_MEAN_COV);
+  const int g = grid_for(h->n);
+  k_mean_partial<<<g, MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, h->part);
+  k_sum_final<<<7, MCL_BLOCK, 0, h->stream>>>(h->part, g, h->scal + 8);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+int phase_cov_partial(mcl_handle* h) {
+  RET_IF(set_device(h));
+  t_begin(h, MCL_K_MEAN_COV);
+  const int g = grid_for(h->n);
+  k_cov_partial<<<g, MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, h->scal + 8,
+                                                1.0 / (double)h->ng, h->part);
+  k_sum_final<<<6, MCL_BLOCK, 0, h->stream>>>(h->part, g, h->scal + 16);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+int exchange_sums(mcl_handle** sh, int ns, int off, int cnt) {
+  if (ns == 1) {
+    mcl_handle* h = sh[0];
+    if (h->comm) {
+      t_begin(h, MCL_K_COMM);
+      NCCLCHK(h, ncclAllReduce(h->scal + off, h->scal + off, cnt, ncclDouble, ncclSum, h->comm, h->stream));
+      t_end(h);
+    }
+    return MCL_OK;
+  }
+  std::vector<double> acc(cnt, 0.0), tmp(cnt);
+  for (int s = 0; s < ns; ++s) {
+    RET_IF(set_device(sh[s]));
+    HIPCHK(sh[s], hipMemcpyAsync(tmp.data(), sh[s]->scal + off, sizeof(double) * cnt, hipMemcpyDeviceToHost,
+                                 sh[s]->stream));
+    HIPCHK(sh[s], hipStreamSynchronize(sh[s]->stream));
+    for (int k = 0; k < cnt; ++k) acc[k] += tmp[k];
+  }
+  for (int s = 0; s < ns; ++s) {
+    RET_IF(set_device(sh[s]));
+    HIPCHK(sh[s], hipMemcpyAsync(sh[s]->scal + off, acc.data(), sizeof(double) * cnt, hipMemcpyHostToDevice,
+                                 sh[s]->stream));
+    HIPCHK(sh[s], hipStreamSynchronize(sh[s]->stream));
+  }
+  return MCL_OK;
+}
+int run_mean_cov_async(mcl_handle** sh, int ns) {
+  for (int s = 0; s < ns; ++s) RET_IF(phase_mean_partial(sh[s]));
+  RET_IF(exchange_sums(sh, ns, 8, 7));
+  for (int s = 0; s < ns; ++s) RET_IF(phase_cov_partial(sh[s]));
+  RET_IF(exchange_sums(sh, ns, 16, 6));
+  for (int s = 0; s < ns; ++s) {
+    mcl_handle* h = sh[s];
+    RET_IF(set_device(h));
+    HIPCHK(h, hipMemcpyAsync(h->host_pin, h->scal + 8, sizeof(double) * 14, hipMemcpyDeviceToHost, h->stream));
+    h->have_meancov = true;
+  }
+  return MCL_OK;
+}
+// host_pin layout: [0..6] sums7, [7] pad, [8..13] cov sums6
+void finish_mean_cov(const mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9]) {
+  const double N = (double)h->ng;
+  const double* p = h->host_pin;
+  for (int c = 0; c < 6; ++c) mean6[c] = p[c] / N;
+  if (yaw_mean) *yaw_mean = p[6] / N;
+  const double* c = p + 8;
+  cov9[0] = c[0] / N;
+  cov9[1] = c[3] / N;
+  cov9[2] = c[4] / N;
+  cov9[3] = c[3] / N;  // only [1,0] mirrored (auv_pf.py:246)
+  cov9[4] = c[1] / N;
+  cov9[5] = c[5] / N;
+  cov9[6] = 0.0;
+  cov9[7] = 0.0;
+  cov9[8] = c[2] / N;
+}
+
+// ------------------------------------------------------------------------------------------ MBES
+int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, int B) {
+  if (B > h->beams_cap) {
+    if (h->beam_sc) hipFree(h->beam_sc);
+    if (h->ranges_dev) hipFree(h->ranges_dev);
+    HIPCHK(h, hipMalloc(&h->beam_sc, sizeof(float2) * (size_t)B));
+    HIPCHK(h, hipMalloc(&h->ranges_dev, sizeof(float) * (size_t)B));
+    h->beams_cap = B;
+    h->beam_cache.clear();
+  }
+  if ((int)h->beam_cache.size() != B || memcmp(h->beam_cache.data(), beam_angles, sizeof(float) * B) != 0) {
+    std::vector<float2> sc(B);
+    for (int b = 0; b < B; ++b) {
+      sc[b].x = (float)std::sin((double)beam_angles[b]);
+      sc[b].y = (float)std::cos((double)beam_angles[b]);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->beam_sc, sc.data(), sizeof(float2) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // sc is a local
+    h->beam_cache.assign(beam_angles, beam_angles + B);
+  }
+  if (ranges)
+    HIPCHK(h, hipMemcpyAsync(h->ranges_dev, ranges, sizeof(float) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+  return MCL_OK;
+}
+
+void rot_rpy(double roll, double pitch, double yaw, double R[9]) {
+  double cr = std::cos(roll), sr = std::sin(roll), cp = std::cos(pitch), sp = std::sin(pitch);
+  double cy = std::cos(yaw), sy = std::sin(yaw);
+  R[0] = cy * cp;
+  R[1] = cy * sp * sr - sy * cr;
+  R[2] = cy * sp * cr + sy * sr;
+  R[3] = sy * cp;
+  R[4] = sy * sp * sr + cy * cr;
+  R[5] = sy * sp * cr - cy * sr;
+  R[6] = -sp;
+  R[7] = cp * sr;
+  R[8] = cp * cr;
+}
+
+int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max, const double sensor_offset[6],
+                double* lw_out, float* exp_out, long long exp_first, long long exp_count) {
+  if (h->map_kind < 0) return fail(h, MCL_ERR_STATE, "update_mbes: no map (call mcl_set_map_grid/mesh first)");
+  static const double zero6[6] = {0, 0, 0, 0, 0, 0};
+  const double* so = sensor_offset ? sensor_offset : zero6;
+  MbesArgs a;
+  for (int c = 0; c < 6; ++c) a.st[c] = h->state[h->cur] + (size_t)c * h->n;
+  a.n = h->n;
+  for (int k = 0; k < 12; ++k) a.m2o[k] = h->cfg.m2o[k];
+  for (int k = 0; k < 3; ++k) a.off_t[k] = so[k];
+  rot_rpy(so[3], so[4], so[5], a.off_R);
+  a.beam_sc = h->beam_sc;
+  a.ranges = with_ranges ? h->ranges_dev : nullptr;
+  a.n_beams = B;
+  a.inv_sigma = (float)(1.0 / sigma);
+  a.r_max = (float)r_max;
+  a.lognorm = std::log(sigma * std::sqrt(2.0 * MCL_PI));
+  a.lw = lw_out;
+  a.exp_out = exp_out;
+  a.exp_first = exp_first;
+  a.exp_count = exp_count;
+  t_begin(h, MCL_K_UPDATE_MBES);
+  if (h->map_kind == 0) {
+    a.grid = h->grid;
+    a.nx = h->gnx;
+    a.ny = h->gny;
+    a.ox = h->gox;
+    a.oy = h->goy;
+    a.inv_res = 1.0 / h->gres;
+    a.res = (float)h->gres;
+    a.zmin_map = h->gzmin;
+    a.zmax_map = h->gzmax;
+    long long ngroups = (h->n + MBES_WAVES - 1) / MBES_WAVES;
+    int grid = (int)(ngroups < 65535 ? ngroups : 65535);
+    k_mbes_grid<<<grid, MBES_THREADS, 0, h->stream>>>(a);
+  } else {
+    int rc = mesh_launch(h->mesh, a, h->stream);
+    if (rc != MCL_OK) {
+      t_end(h);
+      return fail(h, rc, "update_mbes: mesh launch failed");
+    }
+  }
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+
+int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* replay_normals) {
+  if (!(dt > 0.0)) return MCL_OK;  // auv_pf.py:205 gate
+  double rpy[3];
+  euler_from_quat(od->q, rpy);
+  const double roll = rpy[0], pitch = rpy[1];
+  const double cp = std::cos(pitch), sp = std::sin(pitch), cr = std::cos(roll), sr = std::sin(roll);
+  // M1 = Ry' Rx with the reference's Ry' (auv_particle.py:90-92); rows 0,1 only
+  const double M1r0[3] = {cp, sp * sr, sp * cr};
+  const double M1r1[3] = {0.0, cr, -sr};
+  const double vdt[3] = {od->v[0] * dt, od->v[1] * dt, od->v[2] * dt};
+  PredictArgs a;
+  a.m0 = M1r0[0] * vdt[0] + M1r0[1] * vdt[1] + M1r0[2] * vdt[2];
+  a.m1 = M1r1[0] * vdt[0] + M1r1[1] * vdt[1] + M1r1[2] * vdt[2];
+  a.wzdt = od->w_z * dt;
+  a.z = od->z;
+  a.roll = roll;
+  a.pitch = pitch;
+  a.nz = noise_args(h, h->cfg.process_cov, 1u, h->step_predict);
+  const double* rp = nullptr;
+  if (h->cfg.rng_mode == MCL_RNG_REPLAY) {
+    if (replay_normals) {
+      RET_IF(upload_replay(h, replay_normals));
+      rp = h->replay_dev;
+    } else {
+      for (int c = 0; c < 6; ++c) a.nz.sq[c] = 0.0;  // REPLAY without draws: noise-free
+      rp = nullptr;
+    }
+  }
+  t_begin(h, MCL_K_PREDICT);
+  if (h->cfg.rng_mode == MCL_RNG_REPLAY && !rp) {
+    // noise-free: feed zeros through the native branch with sq = 0
+  }
+  k_predict<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, rp);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  h->step_predict++;
+  return MCL_OK;
+}
+
+}  // namespace
+
+// ============================================================================================ C ABI
+extern "C" {
+
+int mcl_abi_version(void) { return MCL_ABI_VERSION; }
+
+const char* mcl_status_string(int s) {
+  switch (s) {
+    case MCL_OK: return "ok";
+    case MCL_ERR_INVALID: return "invalid argument";
+    case MCL_ERR_NO_DEVICE: return "no gfx950 HIP device";
+    case MCL_ERR_HIP: return "HIP runtime error";
+    case MCL_ERR_UNSUPPORTED: return "unsupported";
+    case MCL_ERR_STATE: return "bad call order";
+    case MCL_ERR_COMM: return "RCCL error";
+    case MCL_ERR_ALLOC: return "allocation failed";
+  }
+  return "unknown status";
+}
+
+const char* mcl_last_error(const mcl_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int mcl_device_count(int* count) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  if (count) *count = n;
+  return MCL_OK;
+}
+
+int mcl_create(const mcl_config* cfg, mcl_handle** out) {
+  if (!cfg || !out) {
+    g_create_err = "mcl_create: null argument";
+    return MCL_ERR_INVALID;
+  }
+  *out = nullptr;
+  if (cfg->n_particles < 1 || cfg->n_particles > 0x7fffffffll) {
+    g_create_err = "mcl_create: n_particles out of range";
+    return MCL_ERR_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    g_create_err = "mcl_create: no HIP device visible (this library has no CPU fallback)";
+    return MCL_ERR_NO_DEVICE;
+  }
+  if (cfg->device < 0 || cfg->device >= ndev) {
+    g_create_err = "mcl_create: device ordinal out of range";
+    return MCL_ERR_INVALID;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_err = std::string("mcl_create: device is not gfx950 (found ") + prop.gcnArchName + ")";
+    return MCL_ERR_NO_DEVICE;
+  }
+  mcl_handle* h = new mcl_handle();
+  h->cfg = *cfg;
+  h->n = cfg->n_particles;
+  h->world = cfg->world > 1 ? cfg->world : 1;
+  h->rank = h->world > 1 ? cfg->rank : 0;
+  h->ng = cfg->n_global > 0 ? cfg->n_global : cfg->n_particles;
+  h->goff = h->world > 1 ? cfg->global_offset : 0;
+  h->device = cfg->device;
+  memset(&h->tacc, 0, sizeof h->tacc);
+  if (h->ng > 0xffffffffll || h->goff + h->n > h->ng || h->rank >= h->world) {
+    g_create_err = "mcl_create: inconsistent shard geometry";
+    delete h;
+    return MCL_ERR_INVALID;
+  }
+  if (h->world > 1 && (h->ng != h->n * h->world || h->goff != h->n * h->rank)) {
+    g_create_err = "mcl_create: shards must be equal-sized contiguous blocks (n_global = world * n_particles)";
+    delete h;
+    return MCL_ERR_INVALID;
+  }
+#define CREATE_CHK(call)                                                   \
+  do {                                                                     \
+    hipError_t e_ = (call);                                                \
+    if (e_ != hipSuccess) {                                                \
+      g_create_err = std::string(#call " failed: ") + hipGetErrorString(e_); \
+      mcl_destroy(h);                                                      \
+      return e_ == hipErrorOutOfMemory ? MCL_ERR_ALLOC : MCL_ERR_HIP;      \
+    }                                                                      \
+  } while (0)
+  CREATE_CHK(hipSetDevice(h->device));
+  CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const size_t n = (size_t)h->n, ng = (size_t)h->ng;
+  CREATE_CHK(hipMalloc(&h->state[0], sizeof(double) * 6 * n));
+  CREATE_CHK(hipMalloc(&h->state[1], sizeof(double) * 6 * n));
+  CREATE_CHK(hipMemsetAsync(h->state[0], 0, sizeof(double) * 6 * n, h->stream));
+  CREATE_CHK(hipMemsetAsync(h->state[1], 0, sizeof(double) * 6 * n, h->stream));
+  if (h->world > 1) CREATE_CHK(hipMalloc(&h->state_glob, sizeof(double) * 6 * ng));
+  CREATE_CHK(hipMalloc(&h->lw, sizeof(double) * n));
+  CREATE_CHK(hipMalloc(&h->q, sizeof(u64) * n));
+  CREATE_CHK(hipMalloc(&h->ncum, sizeof(u32) * ng));
+  CREATE_CHK(hipMalloc(&h->zcum, sizeof(u32) * ng));
+  h->ntiles_loc = (h->n + MCL_SCAN_TILE - 1) / MCL_SCAN_TILE;
+  h->ntiles_glob = (h->ng + MCL_SCAN_TILE - 1) / MCL_SCAN_TILE;
+  CREATE_CHK(hipMalloc(&h->tile64, sizeof(u64) * (size_t)(h->ntiles_loc + 1)));
+  CREATE_CHK(hipMalloc(&h->tile32, sizeof(u32) * (size_t)(h->ntiles_glob + 1)));
+  CREATE_CHK(hipMalloc(&h->part, sizeof(double) * 7 * MCL_MAX_GRID));
+  CREATE_CHK(hipMalloc(&h->scal, sizeof(double) * 32));
+  CREATE_CHK(hipMemsetAsync(h->scal, 0, sizeof(double) * 32, h->stream));
+  CREATE_CHK(hipMalloc(&h->totals, sizeof(u64) * (size_t)(h->world + 1)));
+  CREATE_CHK(hipMemsetAsync(h->totals, 0, sizeof(u64) * (size_t)(h->world + 1), h->stream));
+  CREATE_CHK(hipHostMalloc(&h->host_pin, sizeof(double) * 16, hipHostMallocDefault));
+  CREATE_CHK(hipStreamSynchronize(h->stream));
+#undef CREATE_CHK
+  *out = h;
+  return MCL_OK;
+}
+
+int mcl_destroy(mcl_handle* h) {
+  if (!h) return MCL_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  t_collect(h);
+  for (auto& e : h->ev_pool) {
+    hipEventDestroy(e.first);
+    hipEventDestroy(e.second);
+  }
+  if (h->comm) ncclCommDestroy(h->comm);
+  void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum,
+                  h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid};
+  for (void* b : bufs)
+    if (b) hipFree(b);
+  if (h->mesh) mesh_free(h->mesh);
+  if (h->host_pin) hipHostFree(h->host_pin);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return MCL_OK;
+}
+
+int mcl_init_particles(mcl_handle* h, const double* replay_normals) {
+  if (!h) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  const double* rp = nullptr;
+  if (h->cfg.rng_mode == MCL_RNG_REPLAY) {
+    if (!replay_normals) return fail(h, MCL_ERR_INVALID, "init_particles: REPLAY mode needs n x 6 normals");
+    RET_IF(upload_replay(h, replay_normals));
+    rp = h->replay_dev;
+  }
+  NoiseArgs a = noise_args(h, h->cfg.init_cov, 0u, 0u);
+  t_begin(h, MCL_K_NOISE);
+  k_add_noise<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, rp, 1);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  h->step_predict = 0;
+  h->step_resample = 0;
+  h->have_lw = h->have_cdf = false;
+  return MCL_OK;
+}
+
+int mcl_predict(mcl_handle* h, const mcl_odom* odom, double dt, const double* replay_normals) {
+  if (!h || !odom) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  return do_predict(h, odom, dt, replay_normals);
+}
+
+int mcl_update_gps(mcl_handle* h, double gx_map, double gy_map) {
+  if (!h) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  if (!(h->cfg.meas_std > 0.0)) return fail(h, MCL_ERR_INVALID, "update_gps: meas_std must be > 0");
+  GpsArgs a;
+  for (int k = 0; k < 4; ++k) {
+    a.r0[k] = h->cfg.m2o[k];
+    a.r1[k] = h->cfg.m2o[4 + k];
+  }
+  const double s2 = h->cfg.meas_std * h->cfg.meas_std;
+  a.gx = gx_map;
+  a.gy = gy_map;
+  a.inv_s2 = 1.0 / s2;
+  a.lognorm = std::log(2.0 * MCL_PI * s2);
+  t_begin(h, MCL_K_UPDATE_GPS);
+  k_gps_logw<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, h->lw);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  h->weight_mode = MCL_WEIGHT_LINEAR_FLOOR;
+  h->have_lw = true;
+  return MCL_OK;
+}
+
+int mcl_set_map_grid(mcl_handle* h, const float* z, int32_t nx, int32_t ny, double ox, double oy, double res) {
+  if (!h || !z || nx < 2 || ny < 2 || !(res > 0.0)) return fail(h, MCL_ERR_INVALID, "set_map_grid: bad argument");
+  RET_IF(set_device(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->grid) hipFree(h->grid);
+  h->grid = nullptr;
+  const size_t cnt = (size_t)nx * (size_t)ny;
+  HIPCHK(h, hipMalloc(&h->grid, sizeof(float) * cnt));
+  HIPCHK(h, hipMemcpy(h->grid, z, sizeof(float) * cnt, hipMemcpyHostToDevice));
+  float mn = z[0], mx = z[0];
+  for (size_t k = 1; k < cnt; ++k) {
+    if (z[k] < mn) mn = z[k];
+    if (z[k] > mx) mx = z[k];
+  }
+  h->gnx = nx;
+  h->gny = ny;
+  h->gox = ox;
+  h->goy = oy;
+  h->gres = res;
+  h->gzmin = mn;
+  h->gzmax = mx;
+  h->map_kind = 0;
+  return MCL_OK;
+}
+
+int mcl_set_map_mesh(mcl_handle* h, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt) {
+  if (!h || !verts || !tris || nv < 3 || nt < 1) return fail(h, MCL_ERR_INVALID, "set_map_mesh: bad argument");
+  RET_IF(set_device(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->mesh) mesh_free(h->mesh);
+  h->mesh = nullptr;
+  std::string err;
+  int rc = mesh_build(verts, nv, tris, nt, &h->mesh, &err);
+  if (rc != MCL_OK) {
+    h->err = err;
+    return rc;
+  }
+  h->map_kind = 1;
+  return MCL_OK;
+}
+
+int mcl_update_mbes(mcl_handle* h, const float* ranges, const float* beam_angles, int32_t B, double sigma,
+                    double r_max, const double sensor_offset[6]) {
+  if (!h || !ranges || !beam_angles || B < 1 || !(sigma > 0.0) || !(r_max > 0.0))
+    return fail(h, MCL_ERR_INVALID, "update_mbes: bad argument");
+  RET_IF(set_device(h));
+  RET_IF(upload_beams(h, ranges, beam_angles, B));
+  RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0));
+  h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
+  h->have_lw = true;
+  return MCL_OK;
+}
+
+int mcl_mbes_expected(mcl_handle* h, int64_t first, int64_t count, const float* beam_angles, int32_t B,
+                      double r_max, const double sensor_offset[6], float* out) {
+  if (!h || !beam_angles || !out || B < 1 || first < 0 || count < 1 || first + count > h->n)
+    return fail(h, MCL_ERR_INVALID, "mbes_expected: bad argument");
+  RET_IF(set_device(h));
+  RET_IF(upload_beams(h, nullptr, beam_angles, B));
+  const size_t need = (size_t)count * (size_t)B;
+  if (need > h->exp_cap) {
+    if (h->exp_dev) hipFree(h->exp_dev);
+    h->exp_dev = nullptr;
+    HIPCHK(h, hipMalloc(&h->exp_dev, sizeof(float) * need));
+    h->exp_cap = need;
+  }
+  RET_IF(launch_mbes(h, false, B, 1.0, r_max, sensor_offset, nullptr, h->exp_dev, first, count));
+  HIPCHK(h, hipMemcpyAsync(out, h->exp_dev, sizeof(float) * need, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MCL_OK;
+}
+
+int mcl_resample(mcl_handle* h, const double* uniforms, int64_t n_uniforms, const double* replay_normals) {
+  if (!h) return MCL_ERR_INVALID;
+  if (h->world > 1 && !h->comm)
+    return fail(h, MCL_ERR_STATE, "resample: multi-shard handle needs mcl_comm_init or mcl_group_resample");
+  if (h->cfg.rng_mode == MCL_RNG_REPLAY && !replay_normals)
+    return fail(h, MCL_ERR_INVALID, "resample: REPLAY mode needs n x 6 normals");
+  const double* rn[1] = {replay_normals};
+  return run_resample(&h, 1, uniforms, n_uniforms, rn);
+}
+
+int mcl_group_resample(mcl_handle** shards, int32_t ns, const double* uniforms, int64_t n_uniforms,
+                       const double* const* replay_normals) {
+  if (!shards || ns < 1) return MCL_ERR_INVALID;
+  for (int s = 0; s < ns; ++s)
+    if (!shards[s] || shards[s]->world != ns || shards[s]->rank != s)
+      return fail(shards[0], MCL_ERR_INVALID, "group_resample: shards must be ranks 0..n-1 of one world");
+  return run_resample(shards, ns, uniforms, n_uniforms, replay_normals);
+}
+
+int mcl_mean_cov(mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9]) {
+  if (!h || !mean6 || !cov9) return MCL_ERR_INVALID;
+  if (h->world > 1 && !h->comm) return fail(h, MCL_ERR_STATE, "mean_cov: multi-shard handle needs a communicator");
+  RET_IF(run_mean_cov_async(&h, 1));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  finish_mean_cov(h, mean6, yaw_mean, cov9);
+  return MCL_OK;
+}
+
+int mcl_group_mean_cov(mcl_handle** shards, int32_t ns, double mean6[6], double* yaw_mean, double cov9[9]) {
+  if (!shards || ns < 1 || !mean6 || !cov9) return MCL_ERR_INVALID;
+  RET_IF(run_mean_cov_async(shards, ns));
+  for (int s = 0; s < ns; ++s) {
+    RET_IF(set_device(shards[s]));
+    HIPCHK(shards[s], hipStreamSynchronize(shards[s]->stream));
+  }
+  finish_mean_cov(shards[0], mean6, yaw_mean, cov9);
+  return MCL_OK;
+}
+
+int mcl_last_mean_cov(mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9]) {
+  if (!h || !mean6 || !cov9) return MCL_ERR_INVALID;
+  if (!h->have_meancov) return fail(h, MCL_ERR_STATE, "last_mean_cov: nothing computed yet");
+  RET_IF(set_device(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  finish_mean_cov(h, mean6, yaw_mean, cov9);
+  return MCL_OK;
+}
+
+int mcl_get_poses(mcl_handle* h, double* pose7) {
+  if (!h || !pose7) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  if (!h->pose7) HIPCHK(h, hipMalloc(&h->pose7, sizeof(double) * 7 * (size_t)h->n));
+  k_poses<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, h->pose7);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(pose7, h->pose7, sizeof(double) * 7 * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MCL_OK;
+}
+
+int mcl_get_particles(mcl_handle* h, double* soa, double* w) {
+  if (!h || !soa) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  HIPCHK(h, hipMemcpyAsync(soa, h->state[h->cur], sizeof(double) * 6 * (size_t)h->n, hipMemcpyDeviceToHost,
+                           h->stream));
+  if (w) {
+    if (!h->have_cdf) return fail(h, MCL_ERR_STATE, "get_particles: weights exist only after a resample");
+    if (!h->wnorm) HIPCHK(h, hipMalloc(&h->wnorm, sizeof(double) * (size_t)h->n));
+    k_normalised_weights<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->q, h->n, h->totals, h->world, h->wnorm);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(w, h->wnorm, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MCL_OK;
+}
+
+int mcl_set_particles(mcl_handle* h, const double* soa) {
+  if (!h || !soa) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  HIPCHK(h, hipMemcpyAsync(h->state[h->cur], soa, sizeof(double) * 6 * (size_t)h->n, hipMemcpyHostToDevice,
+                           h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MCL_OK;
+}
+
+int mcl_get_log_weights(mcl_handle* h, double* lw) {
+  if (!h || !lw) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  HIPCHK(h, hipMemcpyAsync(lw, h->lw, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MCL_OK;
+}
+
+int mcl_set_log_weights(mcl_handle* h, const double* lw, int32_t weight_mode) {
+  if (!h || !lw || weight_mode < 0 || weight_mode > 2) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  HIPCHK(h, hipMemcpyAsync(h->lw, lw, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->weight_mode = weight_mode;
+  h->have_lw = true;
+  return MCL_OK;
+}
+
+int mcl_get_last_indices(mcl_handle* h, int32_t* idx) {
+  if (!h || !idx) return MCL_ERR_INVALID;
+  if (!h->have_cdf) return fail(h, MCL_ERR_STATE, "get_last_indices: no resample yet");
+  RET_IF(set_device(h));
+  if (!h->idx) HIPCHK(h, hipMalloc(&h->idx, sizeof(int) * (size_t)h->n));
+  k_indices<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->ncum, h->ng, h->goff, h->n, h->idx);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(idx, h->idx, sizeof(int) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MCL_OK;
+}
+
+int mcl_get_last_offspring_cdf(mcl_handle* h, uint32_t* ncum) {
+  if (!h || !ncum) return MCL_ERR_INVALID;
+  if (!h->have_cdf) return fail(h, MCL_ERR_STATE, "get_last_offspring_cdf: no resample yet");
+  RET_IF(set_device(h));
+  HIPCHK(h, hipMemcpyAsync(ncum, h->ncum, sizeof(u32) * (size_t)h->ng, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MCL_OK;
+}
+
+int mcl_get_fixed_weights(mcl_handle* h, uint64_t* q, uint64_t* total) {
+  if (!h || !q) return MCL_ERR_INVALID;
+  if (!h->have_cdf) return fail(h, MCL_ERR_STATE, "get_fixed_weights: no resample yet");
+  RET_IF(set_device(h));
+  HIPCHK(h, hipMemcpyAsync(q, h->q, sizeof(u64) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  std::vector<u64> t(h->world);
+  HIPCHK(h, hipMemcpyAsync(t.data(), h->totals, sizeof(u64) * (size_t)h->world, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (total) {
+    u64 T = 0;
+    for (u64 v : t) T += v;
+    *total = T;
+  }
+  return MCL_OK;
+}
+
+int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* ranges, const float* beam_angles,
+                  int32_t B, double sigma, double r_max, const double sensor_offset[6]) {
+  if (!h || !odom || !ranges || !beam_angles) return MCL_ERR_INVALID;
+  if (h->cfg.rng_mode != MCL_RNG_NATIVE) return fail(h, MCL_ERR_INVALID, "step_mbes: NATIVE rng only");
+  if (h->world > 1 && !h->comm) return fail(h, MCL_ERR_STATE, "step_mbes: multi-shard handle needs mcl_comm_init");
+  RET_IF(set_device(h));
+  RET_IF(do_predict(h, odom, dt, nullptr));
+  RET_IF(upload_beams(h, ranges, beam_angles, B));
+  RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0));
+  h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
+  h->have_lw = true;
+  RET_IF(run_resample(&h, 1, nullptr, 0, nullptr));
+  RET_IF(run_mean_cov_async(&h, 1));
+  return MCL_OK;
+}
+
+int mcl_sync(mcl_handle* h) {
+  if (!h) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MCL_OK;
+}
+
+int mcl_resample_indices(int32_t scheme, const double* weights, int64_t n, const double* uniforms,
+                         int64_t n_uniforms, int32_t device, int32_t* out) {
+  if (!weights || !out || n < 1) return MCL_ERR_INVALID;
+  mcl_config cfg;
+  memset(&cfg, 0, sizeof cfg);
+  cfg.n_particles = n;
+  cfg.device = device;
+  cfg.resample_scheme = scheme;
+  cfg.rng_mode = MCL_RNG_REPLAY;
+  mcl_handle* h = nullptr;
+  int rc = mcl_create(&cfg, &h);
+  if (rc != MCL_OK) return rc;
+  rc = mcl_set_log_weights(h, weights, MCL_WEIGHT_LINEAR);
+  if (rc == MCL_OK) {
+    // run the CDF phases only (no reassign): same code path as run_resample up to phase_cdf
+    if (scheme != MCL_RESAMPLE_SYSTEMATIC) {
+      g_create_err = "resample_indices: only MCL_RESAMPLE_SYSTEMATIC runs on the GPU in this build";
+      rc = MCL_ERR_UNSUPPORTED;
+    } else if (!uniforms || n_uniforms < 1 || !(uniforms[0] >= 0.0 && uniforms[0] < 1.0)) {
+      g_create_err = "resample_indices: systematic needs one uniform in [0,1)";
+      rc = MCL_ERR_INVALID;
+    } else {
+      uint64_t u53 = (uint64_t)std::floor(uniforms[0] * 9007199254740992.0);
+      rc = phase_local_max(h);
+      if (rc == MCL_OK) rc = phase_quantise(h);
+      if (rc == MCL_OK) rc = phase_cdf(h, u53);
+      if (rc == MCL_OK) {
+        h->have_cdf = true;
+        rc = mcl_get_last_indices(h, out);
+      }
+      if (rc != MCL_OK) g_create_err = h->err;
+    }
+  } else {
+    g_create_err = h->err;
+  }
+  mcl_destroy(h);
+  return rc;
+}
+
+int mcl_comm_unique_id(char id[128]) {
+  if (!id) return MCL_ERR_INVALID;
+  ncclUniqueId uid;
+  static_assert(sizeof(ncclUniqueId) <= 128, "unique id size");
+  if (ncclGetUniqueId(&uid) != ncclSuccess) {
+    g_create_err = "ncclGetUniqueId failed";
+    return MCL_ERR_COMM;
+  }
+  memset(id, 0, 128);
+  memcpy(id, &uid, sizeof uid);
+  return MCL_OK;
+}
+
+int mcl_comm_init(mcl_handle* h, const char id[128]) {
+  if (!h || !id) return MCL_ERR_INVALID;
+  if (h->world < 2) return MCL_OK;
+  RET_IF(set_device(h));
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  NCCLCHK(h, ncclCommInitRank(&h->comm, h->world, uid, h->rank));
+  return MCL_OK;
+}
+
+int mcl_timing_enable(mcl_handle* h, int32_t on) {
+  if (!h) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  t_collect(h);
+  h->timing = on != 0;
+  return MCL_OK;
+}
+
+int mcl_timing_get(mcl_handle* h, mcl_timing* out) {
+  if (!h || !out) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  t_collect(h);
+  *out = h->tacc;
+  memset(&h->tacc, 0, sizeof h->tacc);
+  return MCL_OK;
+}
+
+}  // extern "C"

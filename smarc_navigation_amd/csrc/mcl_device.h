@@ -1,0 +1,190 @@
+// mcl_device.h -- device-side helpers shared by the MCL kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MCL_WAVE 64
+#define MCL_PI 3.14159265358979323846
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---------------------------------------------------------------- wave / block reductions
+template <class T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, MCL_WAVE);
+  return v;  // valid in lane 0
+}
+template <class T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T w = __shfl_down(v, o, MCL_WAVE);
+    v = w > v ? w : v;
+  }
+  return v;
+}
+template <class T>
+__device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T w = __shfl_down(v, o, MCL_WAVE);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+// inclusive scan across the 64 lanes of a wave
+template <class T>
+__device__ __forceinline__ T wave_scan_incl(T v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    T w = __shfl_up(v, o, MCL_WAVE);
+    if (lane >= o) v += w;
+  }
+  return v;
+}
+
+// Block sum for blockDim.x <= 1024; result valid in thread 0.  `sh` must hold 16 T.
+template <class T>
+__device__ __forceinline__ T block_sum(T v, T* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  T r = T(0);
+  if (w == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    r = lane < nw ? sh[lane] : T(0);
+    r = wave_sum(r);
+  }
+  return r;
+}
+template <class T>
+__device__ __forceinline__ T block_max(T v, T* sh, T lowest) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  T r = lowest;
+  if (w == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    r = lane < nw ? sh[lane] : lowest;
+    r = wave_max(r);
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------- scalar math
+// (a + pi) % (2 pi) - pi with Python's floored modulo (auv_particle.py:48, auv_pf.py:229)
+__device__ __forceinline__ double wrap_pi(double a) {
+  const double b = 2.0 * MCL_PI;
+  double s = a + MCL_PI;
+  double m = fmod(s, b);
+  if (m != 0.0) {
+    if (m < 0.0) m += b;
+  } else {
+    m = 0.0;
+  }
+  return m - MCL_PI;
+}
+
+// Deterministic exp (DESIGN.md "Resampling arithmetic"): only fma/mul/rint/bit ops, the same
+// sequence as oracle/mcl_oracle.c:orc_det_exp, so CPU and GPU agree bit for bit.
+__device__ __forceinline__ double det_exp(double x) {
+#pragma clang fp contract(off)
+  if (!(x >= -700.0)) return 0.0;
+  if (x > 709.0) return __builtin_inf();
+  const double LOG2E = 1.44269504088896338700e+00;
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  double k = __builtin_rint(x * LOG2E);
+  double r = __builtin_fma(-k, LN2_HI, x);
+  r = __builtin_fma(-k, LN2_LO, r);
+  double p = 1.0 / 6227020800.0;
+  p = __builtin_fma(p, r, 1.0 / 479001600.0);
+  p = __builtin_fma(p, r, 1.0 / 39916800.0);
+  p = __builtin_fma(p, r, 1.0 / 3628800.0);
+  p = __builtin_fma(p, r, 1.0 / 362880.0);
+  p = __builtin_fma(p, r, 1.0 / 40320.0);
+  p = __builtin_fma(p, r, 1.0 / 5040.0);
+  p = __builtin_fma(p, r, 1.0 / 720.0);
+  p = __builtin_fma(p, r, 1.0 / 120.0);
+  p = __builtin_fma(p, r, 1.0 / 24.0);
+  p = __builtin_fma(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  long long ki = (long long)k;
+  u64 bits = (u64)(ki + 1023) << 52;
+  return p * __longlong_as_double((long long)bits);
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 + Box-Muller
+struct u32x4 {
+  u32 x, y, z, w;
+};
+__device__ __forceinline__ u32x4 philox4x32(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    u32 hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    u32 hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    u32 n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return u32x4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ void box_muller(u32 a, u32 b, double& n0, double& n1) {
+  double u1 = ((double)a + 0.5) * (1.0 / 4294967296.0);
+  double u2 = ((double)b + 0.5) * (1.0 / 4294967296.0);
+  double r = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincos(2.0 * MCL_PI * u2, &s, &c);
+  n0 = r * c;
+  n1 = r * s;
+}
+
+// ---------------------------------------------------------------- 128-bit helpers
+// floor(C * N / T) and remainder for C < 2^64, N < 2^32, T >= 1 (quotient <= N when C <= T)
+__device__ __forceinline__ void muldiv_u64(u64 C, u64 N, u64 T, u64& quo, u64& rem) {
+  const u64 a_lo = C * N, a_hi = __umul64hi(C, N);
+  // estimate from doubles: relative error ~2^-52, quotient < 2^33 -> off by at most 1
+  double est = ((double)C * (double)N) / (double)T;
+  u64 a = (u64)est;
+  // R = A - a*T as a signed 128-bit value
+  u64 p_lo = a * T, p_hi = __umul64hi(a, T);
+  u64 r_lo = a_lo - p_lo;
+  u64 r_hi = a_hi - p_hi - (a_lo < p_lo ? 1ull : 0ull);
+  // bring R into [0, T)
+  for (int it = 0; it < 4; ++it) {
+    if ((long long)r_hi < 0) {  // R < 0 : a too big
+      --a;
+      u64 t = r_lo + T;
+      r_hi += (t < r_lo) ? 1ull : 0ull;
+      r_lo = t;
+    } else if (r_hi != 0 || r_lo >= T) {  // R >= T : a too small
+      ++a;
+      u64 t = r_lo - T;
+      r_hi -= (r_lo < T) ? 1ull : 0ull;
+      r_lo = t;
+    } else {
+      break;
+    }
+  }
+  quo = a;
+  rem = r_lo;
+}
+// (r << 53) > U * T   for r < T <= 2^64-1, U < 2^53
+__device__ __forceinline__ bool shl53_gt_mul(u64 r, u64 U, u64 T) {
+  const u64 l_hi = r >> 11, l_lo = r << 53;
+  const u64 m_lo = U * T, m_hi = __umul64hi(U, T);
+  return l_hi > m_hi || (l_hi == m_hi && l_lo > m_lo);
+}

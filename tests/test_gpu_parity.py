@@ -1,0 +1,248 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on identical inputs and against the golden vectors from the reference."""
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from smarc_navigation_amd import engine
+    return engine
+
+
+class GpuBackend(object):
+    """Same driver interface as helpers.OracleBackend, but every op runs in libmcl_hip.so."""
+
+    def __init__(self, g, engine):
+        self.n = int(g['n'])
+        self.e = engine.Engine(self.n, init_cov=g['init_cov'], process_cov=g['motion_cov'],
+                               resample_cov=g['res_cov'], meas_std=float(g['meas_std']), m2o=g['m2o'],
+                               rng_mode=engine.RNG_REPLAY)
+        self.last_indices = self.last_w_raw = self.last_w_norm = None
+
+    def init(self, init_cov, normals):
+        self.e.init_particles(normals)
+
+    def predict(self, v, wz, q, z, dt, normals):
+        self.e.predict(v, wz, q, z, dt, normals)
+
+    def update_resample(self, gx, gy, rs):
+        self.e.update_gps(gx, gy)
+        self.last_w_raw = np.exp(self.e.get_log_weights()) + 1e-200
+        self.e.resample(rs.random_sample(), rs.randn(self.n, 6))
+        self.last_indices = self.e.last_indices()
+        q, tot = self.e.fixed_weights()
+        self.last_w_norm = q.astype(np.float64) / float(tot)
+
+    def state(self):
+        return np.ascontiguousarray(self.e.get_particles().T)
+
+    def mean_cov(self):
+        return self.e.mean_cov()
+
+
+@pytest.mark.parametrize('name', ['traj_predict_launch', 'traj_predict_motion2', 'traj_gps_systematic',
+                                  'traj_gps_systematic_n1000', 'traj_gps_systematic_fullcov'])
+def test_trajectory_replay_vs_reference_golden(name, eng, orc):
+    """Whole-filter parity with the reference node on recorded inputs + replayed RNG draws:
+    states 1e-9, normalised weights rel 1e-11, resample indices exact."""
+    g = helpers.load(name)
+    out = helpers.replay(g, GpuBackend(g, eng))
+    np.testing.assert_allclose(out['init_state'], g['init_state'], rtol=0, atol=1e-15)
+    for k in range(len(g['fix_idx'])):
+        assert np.array_equal(out['indices'][k], g['indices'][k]), (name, k)
+        np.testing.assert_allclose(out['weights_raw'][k], g['weights_raw'][k], rtol=1e-10, atol=0)
+        np.testing.assert_allclose(out['weights_norm'][k], g['weights_norm'][k], rtol=1e-10, atol=1e-15)
+        np.testing.assert_allclose(out['post_update_states'][k], g['post_update_states'][k], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.array(out['ckpt_states']), g['ckpt_states'], rtol=0, atol=1e-9)
+    mean = np.array(out['mean'])
+    np.testing.assert_allclose(mean[:, :3], g['mean_xyz'], rtol=0, atol=1e-9)
+    for k in range(mean.shape[0]):
+        q = orc.quat_from_euler(mean[k, 3], mean[k, 4], out['yaw'][k])
+        np.testing.assert_allclose(q, g['quat'][k], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(out['cov'][k], g['cov36'][k][:9], rtol=1e-9, atol=1e-15)
+
+
+def test_residual_scheme_fails_loudly(eng):
+    e = eng.Engine(64, resample_scheme=eng.RESIDUAL, rng_mode=eng.RNG_REPLAY)
+    e.init_particles(np.zeros((64, 6)))
+    e.update_gps(0.0, 0.0)
+    with pytest.raises(eng.MclError) as ei:
+        e.resample(0.5, np.zeros((64, 6)))
+    assert ei.value.status == -4
+
+
+def test_systematic_kat_vs_reference(eng):
+    """resampling.py:systematic_resample golden vectors through mcl_resample_indices."""
+    g = helpers.load('resampling_kat')
+    n_cases = 0
+    for tag in g['cases']:
+        key = tag + '_systematic_resample'
+        if key not in g:
+            continue
+        w = g[tag + '_w']
+        u = np.random.RandomState(int(g[tag + '_seed'])).random_sample(1)[0]
+        idx = eng.resample_indices(w, u)
+        assert np.array_equal(idx, g[key]), tag
+        n_cases += 1
+    assert n_cases >= 30
+
+
+@pytest.mark.parametrize('n', [1, 2, 7, 64, 1000, 2048, 2049, 4096, 65536, 1048576 + 3])
+@pytest.mark.parametrize('mode', [0, 1])
+def test_fixed_point_resample_bit_exact_vs_oracle(n, mode, eng, orc):
+    """q, offspring CDF, ancestor indices and the reassigned state are bit-identical to the
+    oracle's integer spec for any n (ragged tile edges included)."""
+    rs = np.random.RandomState(n * 2 + mode)
+    lw = -0.5 * (rs.randn(n) * 3.0) ** 2 + (2.0 if mode == 0 else -300.0)
+    if n > 10:
+        lw[rs.randint(0, n, size=n // 10)] = -1e4  # underflowing particles
+    u = rs.random_sample()
+    e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+    soa = rs.randn(6, n)
+    e.set_particles(soa)
+    e.set_log_weights(lw, mode)
+    e.resample(u, np.zeros((n, 6)))
+    q_ref, tot_ref, _ = orc.fixed_weights(lw, mode)
+    q, tot = e.fixed_weights()
+    assert tot == tot_ref and np.array_equal(q, q_ref)
+    ncum_ref = orc.systematic_ncum(q_ref, orc.u_to_u53(u), 0, tot_ref, n)
+    assert np.array_equal(e.last_offspring_cdf(), ncum_ref)
+    idx_ref = orc.indices_from_ncum(ncum_ref)
+    idx = e.last_indices()
+    assert np.array_equal(idx, idx_ref)
+    assert int(ncum_ref[-1]) == n and np.all(np.diff(idx.astype(np.int64)) >= 0)
+    # keep/lost/dupes reassign (auv_pf.py:183-198), zero noise -> exact copy semantics
+    lost, dupes = orc.lost_dupes(idx_ref)
+    ref = soa.copy()
+    orc.reassign(ref, lost, dupes)
+    assert np.array_equal(e.get_particles(), ref)
+    e.close()
+
+
+def test_fixed_point_matches_reference_fp64_indices(eng, orc):
+    """The integer CDF reproduces the reference's fp64 sequential-cumsum indices (differences are
+    possible only when a position falls within ~N*2^-53 of a CDF edge; report the count)."""
+    rs = np.random.RandomState(11)
+    mism = 0
+    for n in [128, 4096, 65536, 1 << 20]:
+        w = rs.rand(n) ** 4
+        w /= w.sum()
+        u = rs.random_sample()
+        ref, rc = orc.systematic_ref(w, u)
+        idx = eng.resample_indices(w, u)
+        d = int(np.count_nonzero(idx != ref))
+        mism += d
+        assert d <= 2, (n, d)
+    print('fixed-point vs fp64 reference index mismatches over 4 sizes:', mism)
+
+
+def test_predict_native_matches_oracle(eng, orc):
+    n = 5000
+    pc = [1e-3, 2e-3, 0, 0, 0, 1e-4]
+    e = eng.Engine(n, init_cov=[1, 2, 0.1, 0.01, 0.02, 0.3], process_cov=pc, seed=0xABCDEF0123)
+    e.init_particles()
+    s0 = e.get_particles()
+    ref0 = np.zeros((6, n))
+    orc.add_noise(ref0, [1, 2, 0.1, 0.01, 0.02, 0.3], orc.native_normals(n, 0, 0xABCDEF0123, 0, 0))
+    np.testing.assert_allclose(s0, ref0, rtol=0, atol=1e-13)
+    q = orc.quat_from_euler(0.05, -0.03, 1.0)
+    ref = s0.copy()
+    for step in range(3):
+        e.predict([1.2, 0.1, -0.05], 0.07, q, -3.5, 0.02)
+        orc.predict(ref, [1.2, 0.1, -0.05], 0.07, q, -3.5, 0.02, pc, orc.native_normals(n, 0, 0xABCDEF0123, 1, step))
+    np.testing.assert_allclose(e.get_particles(), ref, rtol=0, atol=1e-12)
+
+
+def test_native_normals_statistics(eng):
+    n = 1 << 20
+    e = eng.Engine(n, init_cov=[1, 1, 1, 1, 1, 1], seed=7)
+    e.init_particles()
+    s = e.get_particles()
+    assert np.all(np.abs(s.mean(axis=1)) < 5e-3)
+    assert np.all(np.abs(s.var(axis=1) - 1.0) < 1e-2)
+    c = np.corrcoef(s)
+    assert np.all(np.abs(c - np.eye(6)) < 5e-3)
+
+
+def test_gps_weights_match_oracle(eng, orc):
+    n = 4097
+    rs = np.random.RandomState(2)
+    from smarc_navigation_amd import synth
+    m2o = synth.rigid_matrix(3, -4, 0.5, 0.01, -0.02, 1.1)
+    e = eng.Engine(n, meas_std=1.7, m2o=m2o, rng_mode=eng.RNG_REPLAY)
+    soa = rs.randn(6, n) * np.array([[5], [5], [1], [0.1], [0.1], [1]])
+    e.set_particles(soa)
+    e.update_gps(1.5, -2.0)
+    w, lw = orc.gps_weights(soa, m2o, 1.5, -2.0, 1.7)
+    np.testing.assert_allclose(e.get_log_weights(), lw, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(np.exp(e.get_log_weights()), w, rtol=1e-12)
+
+
+def test_mean_cov_and_poses_match_oracle(eng, orc):
+    n = 100003
+    rs = np.random.RandomState(4)
+    soa = rs.randn(6, n) * np.array([[30], [20], [2], [0.2], [0.2], [4]]) + np.array([[100], [-50], [-5], [0], [0], [0]])
+    e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    mean, yaw, cov = e.mean_cov()
+    m_ref, y_ref, c_ref = orc.mean_cov(soa)
+    np.testing.assert_allclose(mean, m_ref, rtol=1e-12, atol=1e-12)
+    assert abs(yaw - y_ref) < 1e-12
+    np.testing.assert_allclose(cov, c_ref, rtol=1e-10, atol=1e-12)
+    assert cov[6] == 0.0 and cov[7] == 0.0 and cov[3] == cov[1]
+    poses = e.poses()
+    np.testing.assert_array_equal(poses[:, :3], soa[:3].T)
+    for i in [0, 1, 777, n - 1]:
+        np.testing.assert_allclose(poses[i, 3:], orc.quat_from_euler(soa[3, i], soa[4, i], soa[5, i]), atol=1e-14)
+
+
+@pytest.mark.parametrize('shards', [2, 4])
+def test_sharded_equals_unsharded_bitwise(shards, eng):
+    """particle shards + exchange steps give bit-identical states and indices."""
+    n = 8192 * shards
+    cov = dict(init_cov=[2, 2, 0, 0, 0, 0.05], process_cov=[1e-3, 1e-3, 0, 0, 0, 1e-5],
+               resample_cov=[0.01, 0.01, 0, 0, 0, 1e-4], meas_std=2.0, seed=99)
+    one = eng.Engine(n, **cov)
+    many = [eng.Engine(n // shards, rank=r, world=shards, n_global=n, global_offset=r * (n // shards), **cov)
+            for r in range(shards)]
+    for e in [one] + many:
+        e.init_particles()
+    from oracle import oracle as orc
+    q = orc.quat_from_euler(0.01, 0.02, 0.3)
+    for step in range(3):
+        for e in [one] + many:
+            e.predict([1.0, 0.05, 0.0], 0.02, q, -2.0, 0.02)
+            e.update_gps(0.1 * step, -0.05 * step)
+        one.resample()
+        eng.group_resample(many)
+        full = one.get_particles()
+        parts = np.concatenate([e.get_particles() for e in many], axis=1)
+        assert np.array_equal(full, parts), step
+        assert np.array_equal(one.last_indices(), np.concatenate([e.last_indices() for e in many]))
+        assert np.array_equal(one.last_offspring_cdf(), many[0].last_offspring_cdf())
+    m1 = one.mean_cov()
+    m2 = eng.group_mean_cov(many)
+    np.testing.assert_allclose(m1[0], m2[0], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(m1[2], m2[2], rtol=1e-11, atol=1e-13)
+
+
+def test_rccl_single_rank_world1_smoke(eng):
+    """The RCCL entry points work (world == 1 is a no-op communicator)."""
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128
+    e = eng.Engine(1024)
+    e.comm_init(uid)
+    e.init_particles()
+    e.update_gps(0, 0)
+    e.resample()
