@@ -211,7 +211,7 @@ def main():
             'pose_error_m': round(pose_err, 4),
         }
         if world == 1 and not a.no_cpu_baseline:
-            ns = a.cpu_particles or (512 if m['kind'] == 'grid' else 256)
+            ns = a.cpu_particles or (8192 if m['kind'] == 'grid' else 4096)
             out['cpu_baseline'] = cpu_baseline(m, stream, ranges, ba, sigma, r_max, cov, 1048576, ns)
         print(json.dumps(out))
     if dist is not None:

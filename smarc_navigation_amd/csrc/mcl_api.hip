@@ -577,9 +577,12 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.zmax_map = h->gzmax;
     long long ngroups = (h->n + MBES_WAVES - 1) / MBES_WAVES;
     int grid = (int)(ngroups < 65535 ? ngroups : 65535);
-    k_mbes_grid<<<grid, MBES_THREADS, 0, h->stream>>>(a);
+    if (with_ranges)
+      k_mbes_grid<false><<<grid, MBES_THREADS, 0, h->stream>>>(a);
+    else
+      k_mbes_grid<true><<<grid, MBES_THREADS, 0, h->stream>>>(a);
   } else {
-    int rc = mesh_launch(h->mesh, a, h->stream);
+    int rc = mesh_launch(h->mesh, a, !with_ranges, h->stream);
     if (rc != MCL_OK) {
       t_end(h);
       return fail(h, rc, "update_mbes: mesh launch failed");

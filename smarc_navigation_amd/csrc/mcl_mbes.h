@@ -190,6 +190,7 @@ __device__ __forceinline__ void mbes_pose(const MbesArgs& a, long long i, MbesPa
   P.valid = 1;
 }
 
+template <bool EXPECT_ONLY>
 __global__ void __launch_bounds__(MBES_THREADS) k_mbes_grid(MbesArgs a) {
   __shared__ float tile[MBES_TILE_FLOATS];
   __shared__ MbesParticle sp[MBES_WAVES];
@@ -309,9 +310,10 @@ __global__ void __launch_bounds__(MBES_THREADS) k_mbes_grid(MbesArgs a) {
       } else {
         e = a.r_max;
       }
-      if (a.exp_out && i >= a.exp_first && i < a.exp_first + a.exp_count)
-        a.exp_out[(size_t)(i - a.exp_first) * a.n_beams + b] = e;
-      if (a.ranges) {
+      if (EXPECT_ONLY) {
+        if (i >= a.exp_first && i < a.exp_first + a.exp_count)
+          a.exp_out[(size_t)(i - a.exp_first) * a.n_beams + b] = e;
+      } else {
         const float rm = a.ranges[b];
         if (rm > 0.f) {  // NaN fails the test
           const float d = (rm - e) * a.inv_sigma;
@@ -320,7 +322,7 @@ __global__ void __launch_bounds__(MBES_THREADS) k_mbes_grid(MbesArgs a) {
         }
       }
     }
-    if (a.lw) {
+    if (!EXPECT_ONLY) {
       double accd = wave_sum((double)acc);
       int nv = wave_sum(nvalid);
       if (lane == 0) a.lw[i] = -0.5 * accd - (double)nv * a.lognorm;

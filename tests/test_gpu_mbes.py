@@ -145,3 +145,101 @@ def test_full_filter_converges_on_synthetic_survey(eng, orc):
             errs.append(np.hypot(mean[0] - truth[0, 0], mean[1] - truth[1, 0]))
     print('position error per update:', np.round(errs, 3))
     assert errs[-1] < 0.3
+
+
+# ---------------------------------------------------------------------------- triangle mesh
+def _mesh_scene(n, nx=96, ny=80, seed=8):
+    origin = (-40.0, -35.0)
+    z = synth.bathymetry_grid(nx, ny, 1.0, origin, seed=seed)
+    verts, tris = synth.mesh_from_grid(z, 1.0, origin)
+    rs = np.random.RandomState(seed)
+    soa = rs.randn(6, n) * np.array([3.0, 3.0, 0.3, 0.05, 0.05, 3.0])[:, None]
+    soa[0] += 8.0
+    soa[1] += 5.0
+    soa[2] += -2.0
+    return z, origin, verts, tris, soa
+
+
+@pytest.mark.parametrize('n,B', [(48, 256), (5, 33)])
+def test_mesh_expected_ranges_and_logweights_vs_oracle(n, B, eng, orc):
+    z, origin, verts, tris, soa = _mesh_scene(n)
+    m2o = synth.rigid_matrix(0.5, 0.25, 0.0, 0.0, 0.0, -0.1)
+    ba = synth.beam_angles(B)
+    off = [0.2, 0.0, -0.1, 0.0, 0.02, 0.0]
+    e = eng.Engine(n, m2o=m2o, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_map_mesh(verts, tris)
+    mesh = orc.Mesh(verts, tris)
+    got = e.mbes_expected(0, n, ba, 80.0, off)
+    _, ref = orc.mbes_update(soa, m2o, off, mesh, ba, None, 0.2, 80.0)
+    err = np.abs(got - ref)
+    print('mesh: max |expected range error| = %.3e m over %d rays' % (err.max(), err.size))
+    assert err.max() <= 1e-3
+    assert ref.min() > 5.0 and ref.max() < 79.0
+    rs = np.random.RandomState(1)
+    ranges = (ref[0] + 0.2 * rs.randn(B)).astype(np.float32)
+    ranges[::5] = -1.0
+    e.update_mbes(ranges, ba, 0.2, 80.0, off)
+    lw = e.get_log_weights()
+    lw_ref, _ = orc.mbes_update(soa, m2o, off, mesh, ba, ranges, 0.2, 80.0)
+    rel = np.abs(lw - lw_ref) / np.maximum(1.0, np.abs(lw_ref))
+    print('mesh: max rel log-weight error %.3e' % rel.max())
+    assert rel.max() <= 2e-4
+
+
+def test_mesh_irregular_triangles_and_overhang(eng, orc):
+    """A non-heightfield soup: random triangles at several depths; nearest hit must win."""
+    rs = np.random.RandomState(3)
+    nt = 400
+    c = rs.uniform(-20, 20, size=(nt, 2))
+    zc = rs.uniform(-30, -10, size=nt)
+    verts = np.zeros((nt * 3, 3), np.float32)
+    for k in range(nt):
+        for j in range(3):
+            verts[3 * k + j] = (c[k, 0] + rs.uniform(-4, 4), c[k, 1] + rs.uniform(-4, 4), zc[k] + rs.uniform(-1, 1))
+    tris = np.arange(nt * 3, dtype=np.uint32).reshape(nt, 3)
+    n = 24
+    soa = np.zeros((6, n))
+    soa[0] = rs.uniform(-10, 10, n)
+    soa[1] = rs.uniform(-10, 10, n)
+    soa[2] = -2.0
+    soa[5] = rs.uniform(-3, 3, n)
+    ba = synth.beam_angles(128, 1.0)
+    e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_map_mesh(verts, tris)
+    got = e.mbes_expected(0, n, ba, 50.0)
+    mesh = orc.Mesh(verts, tris)
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, mesh, ba, None, 0.2, 50.0)
+    err = np.abs(got - ref)
+    bad = err > 1e-3
+    print('soup: %d/%d rays differ by > 1e-3 m (edge grazing), max %.3e' % (bad.sum(), err.size, err.max()))
+    assert bad.sum() <= 2
+    assert (ref < 50.0).sum() > 100 and (ref >= 50.0).sum() > 100
+
+
+def test_mesh_filter_step_runs_and_matches_grid_map(eng):
+    """The triangulated height field and the bilinear grid are different surfaces (planar vs
+    bilinear patches) but close: the two maps must give nearly the same posterior mean."""
+    n, B = 8192, 128
+    origin = (-64.0, -64.0)
+    z = synth.bathymetry_grid(128, 128, 1.0, origin, seed=3)
+    verts, tris = synth.mesh_from_grid(z, 1.0, origin)
+    ba = synth.beam_angles(B)
+    kw = dict(init_cov=[1, 1, 0, 0, 0, 0.01], resample_cov=[0.01, 0.01, 0, 0, 0, 1e-5], seed=5)
+    eg, em = eng.Engine(n, **kw), eng.Engine(n, **kw)
+    eg.set_map_grid(z, origin, 1.0)
+    em.set_map_mesh(verts, tris)
+    truth = np.array([[0.4], [-0.3], [-2.0], [0.0], [0.0], [0.1]])
+    one = eng.Engine(1, rng_mode=eng.RNG_REPLAY)
+    one.set_map_grid(z, origin, 1.0)
+    one.set_particles(truth)
+    ranges = one.mbes_expected(0, 1, ba, 80.0)[0]
+    means = []
+    for e in (eg, em):
+        e.init_particles()
+        e.update_mbes(ranges, ba, 0.2, 80.0)
+        e.resample()
+        means.append(e.mean_cov()[0])
+    assert np.hypot(means[0][0] - 0.4, means[0][1] + 0.3) < 0.2
+    assert np.hypot(means[0][0] - means[1][0], means[0][1] - means[1][1]) < 0.1
