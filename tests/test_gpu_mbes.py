@@ -148,8 +148,8 @@ def test_full_filter_converges_on_synthetic_survey(eng, orc):
 
 
 # ---------------------------------------------------------------------------- triangle mesh
-def _mesh_scene(n, nx=96, ny=80, seed=8):
-    origin = (-40.0, -35.0)
+def _mesh_scene(n, nx=136, ny=128, seed=8):
+    origin = (-60.0, -60.0)
     z = synth.bathymetry_grid(nx, ny, 1.0, origin, seed=seed)
     verts, tris = synth.mesh_from_grid(z, 1.0, origin)
     rs = np.random.RandomState(seed)
@@ -230,7 +230,7 @@ def test_mesh_filter_step_runs_and_matches_grid_map(eng):
     eg, em = eng.Engine(n, **kw), eng.Engine(n, **kw)
     eg.set_map_grid(z, origin, 1.0)
     em.set_map_mesh(verts, tris)
-    truth = np.array([[0.4], [-0.3], [-2.0], [0.0], [0.0], [0.1]])
+    truth = np.array([[0.4], [-0.3], [0.0], [0.0], [0.0], [0.1]])  # init leaves z = roll = pitch = 0
     one = eng.Engine(1, rng_mode=eng.RNG_REPLAY)
     one.set_map_grid(z, origin, 1.0)
     one.set_particles(truth)
