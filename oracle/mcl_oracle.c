@@ -445,11 +445,21 @@ static int ceil_log2_i64(int64_t n) {
   return l;
 }
 
-uint64_t orc_fixed_weights(int n, const double* lw, int mode, int64_t n_global, uint64_t* q, double* w_lin) {
-  double* w = (double*)malloc(sizeof(double) * (size_t)n);
-  double m_lw = -INFINITY;
+double orc_max(int n, const double* v) {
+  double m = -INFINITY;
   for (int i = 0; i < n; ++i)
-    if (lw[i] > m_lw) m_lw = lw[i];
+    if (v[i] > m) m = v[i];
+  return m;
+}
+
+uint64_t orc_fixed_weights(int n, const double* lw, int mode, int64_t n_global, uint64_t* q, double* w_lin) {
+  return orc_fixed_weights_m(n, lw, mode, n_global, orc_max(n, lw), q, w_lin);
+}
+
+/* shard form: the caller supplies the GLOBAL max log-weight (all-reduce max over shards) */
+uint64_t orc_fixed_weights_m(int n, const double* lw, int mode, int64_t n_global, double m_lw, uint64_t* q,
+                             double* w_lin) {
+  double* w = (double*)malloc(sizeof(double) * (size_t)n);
   for (int i = 0; i < n; ++i) {
     if (mode == 0)
       w[i] = orc_det_exp(lw[i]) + 1.e-200;

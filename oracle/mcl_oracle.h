@@ -68,6 +68,9 @@ double orc_det_exp(double x);
  * Multi-shard: pass m_lw_global via lw of all shards (the caller concatenates).  Returns T = sum q. */
 uint64_t orc_fixed_weights(int n, const double* lw, int mode, int64_t n_global, uint64_t* q,
                            double* w_lin);
+double orc_max(int n, const double* v);
+uint64_t orc_fixed_weights_m(int n, const double* lw, int mode, int64_t n_global, double m_lw_global,
+                             uint64_t* q, double* w_lin);
 /* ncum[j] = #{ i in [0,N) : (U53 + i*2^53) * T < C_j * N * 2^53 },  C = inclusive scan of q
  * (+ c_offset), N = n_global, T = total.  ncum is this shard's slice. */
 void orc_systematic_ncum(int n, const uint64_t* q, uint64_t c_offset, uint64_t total, int64_t n_global,

@@ -57,6 +57,7 @@ def _load():
         'orc_mean_cov': (None, [i, _f64p, _f64p, _f64p, _f64p]),
         'orc_det_exp': (d, [d]),
         'orc_fixed_weights': (u64, [i, _f64p, i, i64, _u64p, vp]),
+        'orc_fixed_weights_m': (u64, [i, _f64p, i, i64, d, _u64p, vp]),
         'orc_systematic_ncum': (None, [i, _u64p, u64, u64, i64, u64, _u32p]),
         'orc_indices_from_ncum': (None, [i64, _u32p, i64, i64, _i32p]),
         'orc_philox4x32': (None, [u32, u32, u32, u32, u32, u32, _u32p]),
@@ -212,6 +213,13 @@ def fixed_weights(lw, mode, n_global=None):
     wl = np.zeros(lw.size)
     tot = _L.orc_fixed_weights(lw.size, lw, int(mode), int(n_global or lw.size), q, wl.ctypes.data)
     return q, int(tot), wl
+
+
+def fixed_weights_shard(lw, mode, n_global, m_lw_global):
+    lw = _c(lw)
+    q = np.zeros(lw.size, np.uint64)
+    tot = _L.orc_fixed_weights_m(lw.size, lw, int(mode), int(n_global), float(m_lw_global), q, None)
+    return q, int(tot)
 
 
 def systematic_ncum(q, u53, c_offset=0, total=None, n_global=None):
