@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, 'libmcl_hip.so')
+SO_PATH = os.environ.get('MCL_LIB', os.path.join(_HERE, 'libmcl_hip.so'))  # MCL_LIB: kernel-variant A/B runs
 
 MCL_K_NAMES = ['predict', 'update_gps', 'update_mbes', 'normalise', 'scan', 'resample', 'mean_cov', 'noise', 'comm']
 

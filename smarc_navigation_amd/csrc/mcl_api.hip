@@ -55,6 +55,7 @@ struct mcl_handle {
   float2* beam_sc = nullptr;
   float* ranges_dev = nullptr;
   float* exp_dev = nullptr;
+  MbesPose* pose_dev = nullptr;
   size_t exp_cap = 0;
   int beams_cap = 0;
   std::vector<float> beam_cache;  // last uploaded angles
@@ -564,7 +565,9 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.exp_out = exp_out;
   a.exp_first = exp_first;
   a.exp_count = exp_count;
-  t_begin(h, MCL_K_UPDATE_MBES);
+  if (!h->pose_dev) HIPCHK(h, hipMalloc(&h->pose_dev, sizeof(MbesPose) * (size_t)h->n));
+  a.pose = h->pose_dev;
+  memset(&a.mesh, 0, sizeof a.mesh);
   if (h->map_kind == 0) {
     a.grid = h->grid;
     a.nx = h->gnx;
@@ -575,18 +578,33 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.res = (float)h->gres;
     a.zmin_map = h->gzmin;
     a.zmax_map = h->gzmax;
-    long long ngroups = (h->n + MBES_WAVES - 1) / MBES_WAVES;
-    int grid = (int)(ngroups < 65535 ? ngroups : 65535);
-    if (with_ranges)
-      k_mbes_grid<false><<<grid, MBES_THREADS, 0, h->stream>>>(a);
-    else
-      k_mbes_grid<true><<<grid, MBES_THREADS, 0, h->stream>>>(a);
   } else {
-    int rc = mesh_launch(h->mesh, a, !with_ranges, h->stream);
-    if (rc != MCL_OK) {
-      t_end(h);
-      return fail(h, rc, "update_mbes: mesh launch failed");
-    }
+    const MeshDev* m = h->mesh;
+    a.mesh = mesh_args(m);
+    a.grid = nullptr;
+    a.nx = m->gx + 1;
+    a.ny = m->gy + 1;
+    a.ox = m->x0;
+    a.oy = m->y0;
+    a.inv_res = 1.0 / m->cs;
+    a.res = (float)m->cs;
+    a.zmin_map = m->zmin;
+    a.zmax_map = m->zmax;
+  }
+  const long long ngroups = (h->n + MBES_WAVES - 1) / MBES_WAVES;
+  const int grid = (int)(ngroups < 4096 ? ngroups : 4096);
+  t_begin(h, MCL_K_UPDATE_MBES);
+  k_mbes_pose<<<grid_for(h->n), 256, 0, h->stream>>>(a);
+  if (h->map_kind == 0) {
+    if (with_ranges)
+      k_mbes_cast<0, false><<<grid, MBES_THREADS, 0, h->stream>>>(a);
+    else
+      k_mbes_cast<0, true><<<grid, MBES_THREADS, 0, h->stream>>>(a);
+  } else {
+    if (with_ranges)
+      k_mbes_cast<1, false><<<grid, MBES_THREADS, 0, h->stream>>>(a);
+    else
+      k_mbes_cast<1, true><<<grid, MBES_THREADS, 0, h->stream>>>(a);
   }
   t_end(h);
   HIPCHK(h, hipGetLastError());
@@ -754,7 +772,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->comm) ncclCommDestroy(h->comm);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid};
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev};
   for (void* b : bufs)
     if (b) hipFree(b);
   if (h->mesh) mesh_free(h->mesh);

@@ -1,16 +1,49 @@
 // mcl_mbes.h -- MBES measurement update: per-particle, per-beam ray-cast against the bathymetric
 // map -> expected ranges -> Gaussian log-likelihood (north_star; no reference symbol).
 //
-// Mapping: one wavefront per particle, lanes = consecutive beams (coherent fan: neighbouring lanes
-// walk neighbouring cells).  A workgroup of P waves stages the height tile that bounds the fans of
-// its P particles into LDS once, then every ray marches the tile from LDS in fp32, tile-local
-// coordinates.  Not HBM-bound: per step the compulsory HBM traffic is 48 B/particle + the map once.
+// Two kernels per update:
+//   k_mbes_pose : one thread per particle, fp64 -> sensor pose record (origin in map cell units,
+//                 two columns of R_map_sensor) in HBM (48 B/particle).
+//   k_mbes_cast : one WAVEFRONT per particle, lanes = consecutive beams (a fan is coherent:
+//                 neighbouring lanes walk neighbouring cells).  A workgroup of MBES_WAVES particles
+//                 reduces the footprint of its fans, stages the bounding map tile into LDS once
+//                 (heights for a grid, per-cell z-ranges for a mesh), then every ray runs a
+//                 "while-while" traversal in fp32 tile-local coordinates: a cheap 2-D DDA loop that
+//                 only looks for the next candidate cell (LDS reject test), and a reconverged exact
+//                 test (bilinear-patch quadratic / Moller-Trumbore on the cell's triangle records).
+// Bound: VALU issue + LDS reads (rocprof: VALU pipe ~87 % busy); compulsory HBM traffic is only
+// 48 B + 8 B per particle plus the map tile reads (L2-resident).
 #pragma once
 #include "mcl_device.h"
 
-#define MBES_WAVES 16                        // particles per workgroup
+#ifndef MBES_WAVES
+#define MBES_WAVES 8                         // particles per workgroup
+#endif
+#ifndef MBES_MIN_WAVES_PER_SIMD
+#define MBES_MIN_WAVES_PER_SIMD 6            // __launch_bounds__ 2nd argument: <= 80 VGPRs, 3 workgroups/CU
+#endif
+#ifndef MBES_MIN_WAVES_MESH
+#define MBES_MIN_WAVES_MESH 6
+#endif
 #define MBES_THREADS (MBES_WAVES * 64)
-#define MBES_TILE_FLOATS 12288               // 48 KiB height tile in LDS
+#ifndef MBES_TILE_FLOATS
+#define MBES_TILE_FLOATS 8192                // 32 KiB tile in LDS
+#endif
+
+struct MbesPose {   // 48 B
+  double um, vm;    // sensor origin in GLOBAL cell units (fp64: precise before the tile shift)
+  float oz;
+  float c1[3], c2[3];  // columns 1, 2 of R_map_sensor:  D_b = sin a_b * c1 - cos a_b * c2
+  float pad;
+};
+
+struct MeshArgs {
+  const float4* tri;       // 3 float4 per (cell, triangle) record: v0 - cell corner, e1, e2
+  const u32* cell_start;   // gx*gy + 1
+  const float2* cell_z;    // (zmin, zmax) per cell
+  int gx, gy;
+  float cs;
+};
 
 struct MbesArgs {
   const double* st[6];  // x,y,z,roll,pitch,yaw (odom frame)
@@ -18,65 +51,162 @@ struct MbesArgs {
   double m2o[12];       // rows 0..2 of map<-odom
   double off_t[3];      // sensor offset translation in base_link
   double off_R[9];      // sensor offset rotation
+  MbesPose* pose;       // n records (scratch, written by k_mbes_pose)
   const float2* beam_sc;  // (sin a_b, cos a_b)
-  const float* ranges;    // measured (nullptr -> expected-only call)
+  const float* ranges;    // measured
   int n_beams;
   const float* grid;      // z[ix*ny + iy]
-  int nx, ny;
+  int nx, ny;             // grid: nodes; mesh: cells + 1
   double ox, oy, inv_res;
   float res;
   float zmin_map, zmax_map;
   float inv_sigma, r_max;
   double lognorm;         // log(sigma sqrt(2 pi))
-  double* lw;             // out: log-likelihood per particle (may be nullptr)
-  float* exp_out;         // out: expected ranges [(i-exp_first)*B + b] (may be nullptr)
+  double* lw;             // out: log-likelihood per particle
+  float* exp_out;         // out (EXPECT_ONLY): expected ranges [(i-exp_first)*B + b]
   long long exp_first, exp_count;
+  MeshArgs mesh;
 };
 
-struct HeightLDS {
-  const float* t;
-  int th;  // tile nodes in y (row pitch)
-  __device__ __forceinline__ void corners(int ix, int iy, float& h00, float& h10, float& h01, float& h11) const {
-    const float* p = t + ix * th + iy;
-    h00 = p[0];
-    h01 = p[1];
-    h10 = p[th];
-    h11 = p[th + 1];
-  }
-};
-struct HeightGlobal {
-  const float* g;
-  int ny;
-  __device__ __forceinline__ void corners(int ix, int iy, float& h00, float& h10, float& h01, float& h11) const {
-    const float* p = g + (size_t)ix * ny + iy;
-    h00 = p[0];
-    h01 = p[1];
-    h10 = p[ny];
-    h11 = p[ny + 1];
-  }
-};
+__device__ __forceinline__ float uniform_f32(float x) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+}
+__device__ __forceinline__ double uniform_f64(double x) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+  const unsigned hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-// First intersection of the ray (u0 + t du, v0 + t dv, oz + t dz), u/v in CELL units of a cw x ch
-// cell domain, t in metres, with the bilinear height field.  Returns r_max when there is none.
-// Same definition as oracle/mcl_oracle.c:orc_ray_grid (fp64) -- here fp32, tile-local.
-template <class H>
-__device__ __forceinline__ float march_heightfield(const H& hm, int cw, int ch, float u0, float v0, float oz,
-                                                   float du, float dv, float dz, float t_lo, float r_max) {
+// ------------------------------------------------------------------ pose pre-kernel
+__global__ void __launch_bounds__(256) k_mbes_pose(MbesArgs a) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < a.n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const double x = a.st[0][i], y = a.st[1][i], z = a.st[2][i];
+    double sr, cr, sp, cp, sy, cy;
+    sincos(a.st[3][i], &sr, &cr);
+    sincos(a.st[4][i], &sp, &cp);
+    sincos(a.st[5][i], &sy, &cy);
+    const double Rp[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
+                          sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
+                          -sp,     cp * sr,                cp * cr};
+    double Rmp[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        Rmp[r * 3 + c] = a.m2o[r * 4 + 0] * Rp[c] + a.m2o[r * 4 + 1] * Rp[3 + c] + a.m2o[r * 4 + 2] * Rp[6 + c];
+    double o[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      o[r] = (a.m2o[r * 4 + 0] * x + a.m2o[r * 4 + 1] * y + a.m2o[r * 4 + 2] * z + a.m2o[r * 4 + 3]) +
+             (Rmp[r * 3 + 0] * a.off_t[0] + Rmp[r * 3 + 1] * a.off_t[1] + Rmp[r * 3 + 2] * a.off_t[2]);
+    MbesPose P;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      P.c1[r] = (float)(Rmp[r * 3 + 0] * a.off_R[1] + Rmp[r * 3 + 1] * a.off_R[4] + Rmp[r * 3 + 2] * a.off_R[7]);
+      P.c2[r] = (float)(Rmp[r * 3 + 0] * a.off_R[2] + Rmp[r * 3 + 1] * a.off_R[5] + Rmp[r * 3 + 2] * a.off_R[8]);
+    }
+    P.um = (o[0] - a.ox) * a.inv_res;
+    P.vm = (o[1] - a.oy) * a.inv_res;
+    P.oz = (float)o[2];
+    P.pad = 0.f;
+    a.pose[i] = P;
+  }
+}
+
+// ------------------------------------------------------------------ per-cell exact tests
+// Bilinear patch: first root of f(t) = ray_z(t) - h(u(t), v(t)) in [t_in, t_out] (fp32 restatement
+// of oracle/mcl_oracle.c:orc_ray_grid).  uc, vc = ray origin relative to the cell corner (cells).
+__device__ __forceinline__ bool patch_hit(float h00, float h10, float h01, float h11, float uc, float vc, float oz,
+                                          float du, float dv, float dz, float t_in, float t_out, bool check_entry,
+                                          float& t_hit) {
+  const float B = h10 - h00, C = h01 - h00, D = (h00 - h10) - (h01 - h11);
+  const float c0 = oz - (h00 + B * uc + C * vc + D * uc * vc);
+  const float c1 = dz - (B * du + C * dv + D * (uc * dv + vc * du));
+  const float c2 = -D * du * dv;
+  if (check_entry) {
+    const float f0 = c0 + t_in * (c1 + t_in * c2);
+    if (f0 <= 0.f) {  // origin / map entry at or below the seabed
+      t_hit = t_in;
+      return true;
+    }
+  }
+  const float f_out = c0 + t_out * (c1 + t_out * c2);
+  bool hit = f_out <= 0.f;
+  float hi_t = t_out;
+  if (!hit && c2 != 0.f) {  // grazing: both ends above, dips below in between
+    const float tv = -0.5f * c1 * fast_rcp(c2);
+    if (tv > t_in && tv < t_out && c0 + tv * (c1 + tv * c2) < 0.f) {
+      hit = true;
+      hi_t = tv;
+    }
+  }
+  if (!hit) return false;
+  float root;
+  if (fabsf(c2) < 1e-12f) {
+    root = -c0 * fast_rcp(c1);
+  } else {
+    const float disc = fmaxf(c1 * c1 - 4.f * c2 * c0, 0.f);
+    const float sq = fast_sqrt(disc);
+    const float qv = -0.5f * (c1 + (c1 >= 0.f ? sq : -sq));
+    const float r1 = qv != 0.f ? c0 * fast_rcp(qv) : 0.f;
+    const float r2 = qv * fast_rcp(c2);
+    const float ra = fminf(r1, r2), rb = fmaxf(r1, r2);
+    root = (ra >= t_in - 1e-3f && ra <= hi_t + 1e-3f) ? ra : rb;
+  }
+  t_hit = fminf(fmaxf(root, t_in), hi_t);
+  return true;
+}
+
+// nearest hit of the ray with the triangles binned in global cell (gix, giy); ray origin given
+// relative to that cell's corner (metres).  Accepts t in [0, t_hi].
+__device__ __forceinline__ float cell_triangles_hit(const MeshArgs& ma, int gix, int giy, float olx, float oly,
+                                                    float olz, float dx, float dy, float dz, float t_hi) {
+  const size_t c = (size_t)gix * ma.gy + giy;
+  const u32 s = ma.cell_start[c], e = ma.cell_start[c + 1];
+  float best = __builtin_inff();
+  const float EPS = 2e-5f;
+  for (u32 k = s; k < e; ++k) {
+    const float4 v0 = ma.tri[3 * (size_t)k], e1 = ma.tri[3 * (size_t)k + 1], e2 = ma.tri[3 * (size_t)k + 2];
+    const float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x;
+    const float det = e1.x * px + e1.y * py + e1.z * pz;
+    if (fabsf(det) < 1e-20f) continue;
+    const float inv = fast_rcp(det);
+    const float sx = olx - v0.x, sy = oly - v0.y, sz = olz - v0.z;
+    const float u = (sx * px + sy * py + sz * pz) * inv;
+    const float qx = sy * e1.z - sz * e1.y, qy = sz * e1.x - sx * e1.z, qz = sx * e1.y - sy * e1.x;
+    const float v = (dx * qx + dy * qy + dz * qz) * inv;
+    const float t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv;
+    if (u >= -EPS && v >= -EPS && u + v <= 1.f + EPS && t >= 0.f && t <= t_hi && t < best) best = t;
+  }
+  return best;
+}
+
+// ------------------------------------------------------------------ the ray traversal
+// MAP 0: `tile` holds node heights, pitch th (nodes); window of cw x ch cells.
+// MAP 1: `tile` holds (zmin,zmax) per cell as float2, pitch th (cells).
+// LDS=true: tile is the LDS copy with origin (tx0,ty0); LDS=false: tile is the global array, (0,0).
+template <int MAP, bool LDS>
+__device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th, const MbesArgs& a, int tx0, int ty0,
+                                          int cw, int ch, float u0, float v0, float oz, float du, float dv, float dx,
+                                          float dy, float dz, float t_lo, float r_max) {
   float t0 = t_lo, t1 = r_max;
-  // clip to the domain [0,cw] x [0,ch]
+  const float inv_du = du != 0.f ? fast_rcp(du) : 0.f, inv_dv = dv != 0.f ? fast_rcp(dv) : 0.f;
+  // clip to the window [0,cw] x [0,ch]
   if (du == 0.f) {
     if (u0 < 0.f || u0 > (float)cw) return r_max;
   } else {
-    float inv = 1.f / du;
-    float ta = (0.f - u0) * inv, tb = ((float)cw - u0) * inv;
+    const float ta = (0.f - u0) * inv_du, tb = ((float)cw - u0) * inv_du;
     t0 = fmaxf(t0, fminf(ta, tb));
     t1 = fminf(t1, fmaxf(ta, tb));
   }
   if (dv == 0.f) {
     if (v0 < 0.f || v0 > (float)ch) return r_max;
   } else {
-    float inv = 1.f / dv;
-    float ta = (0.f - v0) * inv, tb = ((float)ch - v0) * inv;
+    const float ta = (0.f - v0) * inv_dv, tb = ((float)ch - v0) * inv_dv;
     t0 = fmaxf(t0, fminf(ta, tb));
     t1 = fminf(t1, fmaxf(ta, tb));
   }
@@ -86,144 +216,119 @@ __device__ __forceinline__ float march_heightfield(const H& hm, int cw, int ch, 
   int iy = min(max((int)floorf(pv), 0), ch - 1);
   if (du < 0.f && ix > 0 && (float)ix >= pu) --ix;
   if (dv < 0.f && iy > 0 && (float)iy >= pv) --iy;
-  const int sx = du > 0.f ? 1 : -1, sy = dv > 0.f ? 1 : -1;
-  const float inv_du = du != 0.f ? 1.f / du : 0.f, inv_dv = dv != 0.f ? 1.f / dv : 0.f;
   const float INF = __builtin_inff();
+  const int sx = du > 0.f ? 1 : -1, sy = dv > 0.f ? 1 : -1;
+  const float dtx = fabsf(inv_du), dty = fabsf(inv_dv);
+  float tnx = du != 0.f ? ((float)(ix + (du > 0.f ? 1 : 0)) - u0) * inv_du : INF;
+  float tny = dv != 0.f ? ((float)(iy + (dv > 0.f ? 1 : 0)) - v0) * inv_dv : INF;
   float t_in = t0;
-  float z_in = oz + t_in * dz;
-  bool first = true;
-  const int max_steps = cw + ch + 4;
-  for (int step = 0; step < max_steps; ++step) {
-    const float tnx = du != 0.f ? ((float)(ix + (du > 0.f ? 1 : 0)) - u0) * inv_du : INF;
-    const float tny = dv != 0.f ? ((float)(iy + (dv > 0.f ? 1 : 0)) - v0) * inv_dv : INF;
-    float t_out = fminf(fminf(tnx, tny), t1);
-    float h00, h10, h01, h11;
-    hm.corners(ix, iy, h00, h10, h01, h11);
-    const float hmax = fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
-    const float z_out = oz + t_out * dz;
-    if (fminf(z_in, z_out) <= hmax || first) {
-      const float uc = u0 - (float)ix, vc = v0 - (float)iy;
-      const float B = h10 - h00, C = h01 - h00, D = (h00 - h10) - (h01 - h11);
-      const float c0 = oz - (h00 + B * uc + C * vc + D * uc * vc);
-      const float c1 = dz - (B * du + C * dv + D * (uc * dv + vc * du));
-      const float c2 = -D * du * dv;
-      if (first) {
-        const float f0 = c0 + t_in * (c1 + t_in * c2);
-        if (f0 <= 0.f) return t_in;  // origin / map entry at or below the seabed
-        first = false;
+  float z_in = oz + t0 * dz;
+  bool first = (MAP == 0);
+  float result = r_max;
+  int guard = cw + ch + 4;
+  for (;;) {
+    // ---- phase 1: walk cells until one might contain the surface (LDS reject test only)
+    bool cand = false;
+    float t_out = t1, z_out = z_in;
+    float h00 = 0.f, h10 = 0.f, h01 = 0.f, h11 = 0.f;
+    while (guard > 0) {
+      --guard;
+      t_out = fminf(fminf(tnx, tny), t1);
+      z_out = oz + t_out * dz;
+      const float zlo = fminf(z_in, z_out);
+      if (MAP == 0) {
+        const float* p = LDS ? (const float*)tile + ix * th + iy
+                             : (const float*)tile + (size_t)ix * th + iy;
+        h00 = p[0];
+        h01 = p[1];
+        h10 = p[th];
+        h11 = p[th + 1];
+        cand = first || zlo <= fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
+      } else {
+        const float2 zr = LDS ? ((const float2*)tile)[ix * th + iy] : ((const float2*)tile)[(size_t)ix * th + iy];
+        cand = zlo <= zr.y + 1e-4f && fmaxf(z_in, z_out) >= zr.x - 1e-4f;
       }
-      const float f_out = c0 + t_out * (c1 + t_out * c2);
-      bool hit = f_out <= 0.f;
-      float hi_t = t_out;
-      if (!hit && c2 != 0.f) {  // grazing: both ends above, dips below in between
-        const float tv = -0.5f * c1 / c2;
-        if (tv > t_in && tv < t_out && c0 + tv * (c1 + tv * c2) < 0.f) {
-          hit = true;
-          hi_t = tv;
-        }
+      if (cand) break;
+      if (t_out >= t1) break;
+      const bool stepx = tnx <= tny;
+      ix += stepx ? sx : 0;
+      iy += stepx ? 0 : sy;
+      tnx += stepx ? dtx : 0.f;
+      tny += stepx ? 0.f : dty;
+      t_in = t_out;
+      z_in = z_out;
+    }
+    if (!cand) break;
+    // ---- phase 2: exact test in the candidate cell (lanes reconverge here)
+    if (MAP == 0) {
+      float t_hit;
+      if (patch_hit(h00, h10, h01, h11, u0 - (float)ix, v0 - (float)iy, oz, du, dv, dz, t_in, t_out, first, t_hit)) {
+        result = fminf(t_hit, r_max);
+        break;
       }
-      if (hit) {
-        // smallest root in [t_in, hi_t]; f(t_in) > 0 >= f(hi_t)
-        float root;
-        if (c2 == 0.f) {
-          root = -c0 / c1;
-        } else {
-          const float disc = fmaxf(c1 * c1 - 4.f * c2 * c0, 0.f);
-          const float sq = sqrtf(disc);
-          const float qv = -0.5f * (c1 + (c1 >= 0.f ? sq : -sq));
-          const float r1 = qv != 0.f ? c0 / qv : 0.f;
-          const float r2 = qv / c2;
-          const float ra = fminf(r1, r2), rb = fmaxf(r1, r2);
-          root = (ra >= t_in - 1e-3f && ra <= hi_t + 1e-3f) ? ra : rb;
-        }
-        root = fminf(fmaxf(root, t_in), hi_t);
-        return fminf(root, r_max);
+      first = false;
+    } else {
+      const float t = cell_triangles_hit(a.mesh, tx0 + ix, ty0 + iy, (u0 - (float)ix) * a.mesh.cs,
+                                         (v0 - (float)iy) * a.mesh.cs, oz, dx, dy, dz, t_out + 1e-4f);
+      if (t < INF) {
+        result = fminf(t, r_max);
+        break;
       }
     }
-    if (t_out >= t1) return r_max;
-    if (tnx <= tny)
-      ix += sx;
-    else
-      iy += sy;
-    if (ix < 0 || iy < 0 || ix >= cw || iy >= ch) return r_max;
+    if (t_out >= t1 || guard <= 0) break;
+    const bool stepx = tnx <= tny;
+    ix += stepx ? sx : 0;
+    iy += stepx ? 0 : sy;
+    tnx += stepx ? dtx : 0.f;
+    tny += stepx ? 0.f : dty;
     t_in = t_out;
     z_in = z_out;
   }
-  return r_max;
+  return result;
 }
 
-struct MbesParticle {  // per-particle pose constants shared through LDS
-  double um, vm;       // sensor origin in GLOBAL cell units (double: precise before tile shift)
-  float oz;
-  float c1[3], c2[3];  // columns 1, 2 of R_map_sensor:  D_b = sin a_b * c1 - cos a_b * c2
-  int valid;
-};
+// ------------------------------------------------------------------ the cast kernel
+template <int MAP, bool EXPECT_ONLY>
+__global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_SIMD : MBES_MIN_WAVES_MESH)) k_mbes_cast(MbesArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[MBES_TILE_FLOATS];
+  __shared__ float red[5][MBES_WAVES];  // umin, umax, vmin, vmax, zmax per wave
 
-__device__ __forceinline__ void mbes_pose(const MbesArgs& a, long long i, MbesParticle& P) {
-  const double x = a.st[0][i], y = a.st[1][i], z = a.st[2][i];
-  double sr, cr, sp, cp, sy, cy;
-  sincos(a.st[3][i], &sr, &cr);
-  sincos(a.st[4][i], &sp, &cp);
-  sincos(a.st[5][i], &sy, &cy);
-  const double Rp[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
-                        sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
-                        -sp,     cp * sr,                cp * cr};
-  double Rmp[9];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      Rmp[r * 3 + c] = a.m2o[r * 4 + 0] * Rp[c] + a.m2o[r * 4 + 1] * Rp[3 + c] + a.m2o[r * 4 + 2] * Rp[6 + c];
-  double o[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-    o[r] = (a.m2o[r * 4 + 0] * x + a.m2o[r * 4 + 1] * y + a.m2o[r * 4 + 2] * z + a.m2o[r * 4 + 3]) +
-           (Rmp[r * 3 + 0] * a.off_t[0] + Rmp[r * 3 + 1] * a.off_t[1] + Rmp[r * 3 + 2] * a.off_t[2]);
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    P.c1[r] = (float)(Rmp[r * 3 + 0] * a.off_R[1] + Rmp[r * 3 + 1] * a.off_R[4] + Rmp[r * 3 + 2] * a.off_R[7]);
-    P.c2[r] = (float)(Rmp[r * 3 + 0] * a.off_R[2] + Rmp[r * 3 + 1] * a.off_R[5] + Rmp[r * 3 + 2] * a.off_R[8]);
-  }
-  P.um = (o[0] - a.ox) * a.inv_res;
-  P.vm = (o[1] - a.oy) * a.inv_res;
-  P.oz = (float)o[2];
-  P.valid = 1;
-}
-
-template <bool EXPECT_ONLY>
-__global__ void __launch_bounds__(MBES_THREADS) k_mbes_grid(MbesArgs a) {
-  __shared__ float tile[MBES_TILE_FLOATS];
-  __shared__ MbesParticle sp[MBES_WAVES];
-  __shared__ float red[4][MBES_WAVES];  // umin, umax, vmin, vmax per wave ; later zmax
-  __shared__ int tinfo[6];              // tx0, ty0, tw, th, use_lds
-  __shared__ float tzmax;
-
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long ngroups = (a.n + MBES_WAVES - 1) / MBES_WAVES;
   const float inv_res = (float)a.inv_res;
+  // window limits: grid nodes nx x ny; mesh cells (nx-1) x (ny-1)
+  const int lim_x = MAP == 0 ? a.nx - 1 : a.nx - 2, lim_y = MAP == 0 ? a.ny - 1 : a.ny - 2;
+  const int tile_cap = MAP == 0 ? MBES_TILE_FLOATS : MBES_TILE_FLOATS / 2;
 
   for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const long long i = grp * MBES_WAVES + w;
-    __syncthreads();  // previous group's tile / sp fully consumed
-    if (threadIdx.x < MBES_WAVES) {
-      long long ip = grp * MBES_WAVES + threadIdx.x;
-      if (ip < a.n)
-        mbes_pose(a, ip, sp[threadIdx.x]);
-      else
-        sp[threadIdx.x].valid = 0;
+    const bool valid = i < a.n;
+    MbesPose P;
+    if (valid) {
+      // the record is wave-uniform: pin it in SGPRs (frees ~11 VGPRs per lane)
+      const MbesPose Pv = a.pose[i];
+      P.um = uniform_f64(Pv.um);
+      P.vm = uniform_f64(Pv.vm);
+      P.oz = uniform_f32(Pv.oz);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        P.c1[r] = uniform_f32(Pv.c1[r]);
+        P.c2[r] = uniform_f32(Pv.c2[r]);
+      }
     }
-    __syncthreads();
-    const MbesParticle P = sp[w];
-    // ---- footprint of this wave's fan (global cell units) -> block bbox
-    float umin = (float)P.um, umax = umin, vmin = (float)P.vm, vmax = vmin;
-    if (P.valid) {
+    // ---- footprint of this wave's fan (global cell units)
+    float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = umin, vmax = umax;
+    if (valid) {
+      umin = umax = (float)P.um;
+      vmin = vmax = (float)P.vm;
       for (int b = lane; b < a.n_beams; b += 64) {
         const float2 sc = a.beam_sc[b];
         const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
         const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
         const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
         float t_end = a.r_max;
-        if (dz < -1e-6f) t_end = fminf(t_end, fmaxf((a.zmin_map - P.oz) / dz, 0.f));
+        if (dz < -1e-6f) t_end = fminf(t_end, fmaxf((a.zmin_map - P.oz) * fast_rcp(dz), 0.f));
         const float ue = (float)P.um + t_end * dx * inv_res, ve = (float)P.vm + t_end * dy * inv_res;
         umin = fminf(umin, ue);
         umax = fmaxf(umax, ue);
@@ -235,60 +340,73 @@ __global__ void __launch_bounds__(MBES_THREADS) k_mbes_grid(MbesArgs a) {
     umax = wave_max(umax);
     vmin = wave_min(vmin);
     vmax = wave_max(vmax);
+    __syncthreads();  // previous group's tile and red[] fully consumed
     if (lane == 0) {
-      const bool ok = P.valid != 0;
-      red[0][w] = ok ? umin : __builtin_inff();
-      red[1][w] = ok ? umax : -__builtin_inff();
-      red[2][w] = ok ? vmin : __builtin_inff();
-      red[3][w] = ok ? vmax : -__builtin_inff();
+      red[0][w] = umin;
+      red[1][w] = umax;
+      red[2][w] = vmin;
+      red[3][w] = vmax;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      float a0 = red[0][0], a1 = red[1][0], b0 = red[2][0], b1 = red[3][0];
-      for (int k = 1; k < MBES_WAVES; ++k) {
-        a0 = fminf(a0, red[0][k]);
-        a1 = fmaxf(a1, red[1][k]);
-        b0 = fminf(b0, red[2][k]);
-        b1 = fmaxf(b1, red[3][k]);
-      }
-      // node range [tx0, tx1] clipped to the map, one cell of margin for fp32 slop
-      int tx0 = max((int)floorf(a0) - 1, 0), tx1 = min((int)floorf(a1) + 2, a.nx - 1);
-      int ty0 = max((int)floorf(b0) - 1, 0), ty1 = min((int)floorf(b1) + 2, a.ny - 1);
-      int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
-      int use = (tw >= 2 && th >= 2 && (long long)tw * th <= MBES_TILE_FLOATS) ? 1 : 0;
-      if (tw < 2 || th < 2) use = -1;  // fans entirely off the map
-      tinfo[0] = tx0;
-      tinfo[1] = ty0;
-      tinfo[2] = tw;
-      tinfo[3] = th;
-      tinfo[4] = use;
+    // every wave derives the same tile window (no second barrier)
+    float a0 = red[0][lane & (MBES_WAVES - 1)], a1 = red[1][lane & (MBES_WAVES - 1)];
+    float b0 = red[2][lane & (MBES_WAVES - 1)], b1 = red[3][lane & (MBES_WAVES - 1)];
+#pragma unroll
+    for (int o = MBES_WAVES / 2; o > 0; o >>= 1) {
+      a0 = fminf(a0, __shfl_xor(a0, o, 64));
+      a1 = fmaxf(a1, __shfl_xor(a1, o, 64));
+      b0 = fminf(b0, __shfl_xor(b0, o, 64));
+      b1 = fmaxf(b1, __shfl_xor(b1, o, 64));
     }
-    __syncthreads();
-    const int tx0 = tinfo[0], ty0 = tinfo[1], tw = tinfo[2], th = tinfo[3], use = tinfo[4];
+    int tx0, ty0, tw, th, use;
+    {
+      // grid: node range; mesh: cell range; clipped to the map, one cell of margin for fp32 slop
+      tx0 = max((int)floorf(a0) - 1, 0);
+      ty0 = max((int)floorf(b0) - 1, 0);
+      const int tx1 = min((int)floorf(a1) + (MAP == 0 ? 2 : 1), lim_x);
+      const int ty1 = min((int)floorf(b1) + (MAP == 0 ? 2 : 1), lim_y);
+      tw = tx1 - tx0 + 1;
+      th = ty1 - ty0 + 1;
+      const int need = MAP == 0 ? 2 : 1;
+      use = (tw >= need && th >= need && (long long)tw * th <= tile_cap) ? 1 : 0;
+      if (!(a0 <= a1) || tw < need || th < need) use = -1;  // no valid fan / fans entirely off the map
+      tx0 = __builtin_amdgcn_readfirstlane(tx0);
+      ty0 = __builtin_amdgcn_readfirstlane(ty0);
+      tw = __builtin_amdgcn_readfirstlane(tw);
+      th = __builtin_amdgcn_readfirstlane(th);
+      use = __builtin_amdgcn_readfirstlane(use);
+    }
     float zmax = a.zmax_map;
     if (use == 1) {
-      // ---- stage the tile (coalesced along iy) and find its max height
+      // ---- stage the tile (coalesced along iy) and its max height
       float m = -__builtin_inff();
       const int cells = tw * th;
-      for (int k = threadIdx.x; k < cells; k += MBES_THREADS) {
-        const int ix = k / th, iy = k - ix * th;
-        const float h = a.grid[(size_t)(tx0 + ix) * a.ny + (ty0 + iy)];
-        tile[k] = h;
-        m = fmaxf(m, h);
+      if (MAP == 0) {
+        for (int k = threadIdx.x; k < cells; k += MBES_THREADS) {
+          const int ix = k / th, iy = k - ix * th;
+          const float h = a.grid[(size_t)(tx0 + ix) * a.ny + (ty0 + iy)];
+          tile[k] = h;
+          m = fmaxf(m, h);
+        }
+      } else {
+        float2* t2 = (float2*)tile;
+        for (int k = threadIdx.x; k < cells; k += MBES_THREADS) {
+          const int ix = k / th, iy = k - ix * th;
+          const float2 zr = a.mesh.cell_z[(size_t)(tx0 + ix) * a.mesh.gy + (ty0 + iy)];
+          t2[k] = zr;
+          m = fmaxf(m, zr.y);
+        }
       }
       m = wave_max(m);
-      if (lane == 0) red[0][w] = m;
+      if (lane == 0) red[4][w] = m;
       __syncthreads();
-      if (threadIdx.x == 0) {
-        float mm = red[0][0];
-        for (int k = 1; k < MBES_WAVES; ++k) mm = fmaxf(mm, red[0][k]);
-        tzmax = mm;
-      }
-      __syncthreads();
-      zmax = tzmax;
+      float mm = red[4][lane & (MBES_WAVES - 1)];
+#pragma unroll
+      for (int o = MBES_WAVES / 2; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+      zmax = mm;
     }
-    if (!P.valid) continue;
-    // ---- march this particle's beams
+    if (!valid) continue;
+    // ---- cast this particle's beams
     float acc = 0.f;
     int nvalid = 0;
     const float u0 = use == 1 ? (float)(P.um - (double)tx0) : (float)P.um;
@@ -298,15 +416,19 @@ __global__ void __launch_bounds__(MBES_THREADS) k_mbes_grid(MbesArgs a) {
       const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
       const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
       const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
-      float t_lo = 0.f;  // skip the water column above the tile's highest node
-      if (dz < 0.f && P.oz > zmax) t_lo = fmaxf((zmax - P.oz) / dz - 1e-3f, 0.f);
+      float t_lo = 0.f;  // skip the water column above the tile's highest point
+      if (dz < 0.f && P.oz > zmax) t_lo = fmaxf((zmax - P.oz) * fast_rcp(dz) - 1e-3f, 0.f);
       float e;
       if (use == 1) {
-        HeightLDS hm{tile, th};
-        e = march_heightfield(hm, tw - 1, th - 1, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, t_lo, a.r_max);
+        e = cast_ray<MAP, true>(tile, th, a, tx0, ty0, MAP == 0 ? tw - 1 : tw, MAP == 0 ? th - 1 : th, u0, v0, P.oz,
+                                dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max);
       } else if (use == 0) {
-        HeightGlobal hm{a.grid, a.ny};
-        e = march_heightfield(hm, a.nx - 1, a.ny - 1, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, t_lo, a.r_max);
+        if (MAP == 0)
+          e = cast_ray<MAP, false>(a.grid, a.ny, a, 0, 0, a.nx - 1, a.ny - 1, u0, v0, P.oz, dx * inv_res, dy * inv_res,
+                                   dx, dy, dz, t_lo, a.r_max);
+        else
+          e = cast_ray<MAP, false>(a.mesh.cell_z, a.mesh.gy, a, 0, 0, a.mesh.gx, a.mesh.gy, u0, v0, P.oz,
+                                   dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max);
       } else {
         e = a.r_max;
       }
@@ -323,8 +445,8 @@ __global__ void __launch_bounds__(MBES_THREADS) k_mbes_grid(MbesArgs a) {
       }
     }
     if (!EXPECT_ONLY) {
-      double accd = wave_sum((double)acc);
-      int nv = wave_sum(nvalid);
+      const double accd = wave_sum((double)acc);
+      const int nv = wave_sum(nvalid);
       if (lane == 0) a.lw[i] = -0.5 * accd - (double)nv * a.lognorm;
     }
   }
