@@ -145,6 +145,9 @@ int mcl_mbes_expected(mcl_handle* h, int64_t first, int64_t count, const float* 
  * uniforms: REPLAY: scheme-dependent draws in reference order (systematic: 1); NATIVE: NULL.
  * replay_normals: n x 6 post-resample noise draws (REPLAY) or NULL. */
 int mcl_resample(mcl_handle* h, const double* uniforms, int64_t n_uniforms, const double* replay_normals);
+/* number of uniforms the next mcl_resample consumes in REPLAY mode: systematic 1, stratified and
+ * multinomial n, residual n - sum(floor(n w)) (resampling.py:74; computed here from the weights) */
+int mcl_resample_prepare(mcl_handle* h, int64_t* n_uniforms);
 
 /* ---- a13: loc_loop/update_loc_pose (auv_pf.py:218-285) */
 int mcl_mean_cov(mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9]);

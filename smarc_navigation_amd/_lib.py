@@ -52,6 +52,7 @@ SYMBOLS = {
     'mcl_update_mbes': (C.c_int, [_vp, _vp, _vp, _i32, _d, _d, _vp]),
     'mcl_mbes_expected': (C.c_int, [_vp, _i64, _i64, _vp, _i32, _d, _vp, _vp]),
     'mcl_resample': (C.c_int, [_vp, _vp, _i64, _vp]),
+    'mcl_resample_prepare': (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     'mcl_mean_cov': (C.c_int, [_vp, _vp, _vp, _vp]),
     'mcl_get_poses': (C.c_int, [_vp, _vp]),
     'mcl_get_particles': (C.c_int, [_vp, _vp, _vp]),

@@ -14,6 +14,7 @@
 #include "mcl_kernels.h"
 #include "mcl_mbes.h"
 #include "mcl_mesh.h"
+#include "mcl_resample_alt.h"
 
 namespace {
 
@@ -56,6 +57,14 @@ struct mcl_handle {
   float* ranges_dev = nullptr;
   float* exp_dev = nullptr;
   MbesPose* pose_dev = nullptr;
+  // alternative resamplers (lazily allocated)
+  u64* cq = nullptr;       // inclusive scan of q
+  u64* u53 = nullptr;      // uniforms as 53-bit integers
+  u32 *cnt = nullptr, *first = nullptr, *flags = nullptr, *fcum = nullptr, *copies = nullptr, *ccum = nullptr;
+  int* dupes = nullptr;
+  double *cs = nullptr, *chunk = nullptr, *uni_dev = nullptr;
+  long long residual_k = -1;  // copies count cached by mcl_resample_prepare
+  bool idx_explicit = false;  // last resample produced idx[] directly (non-systematic)
   size_t exp_cap = 0;
   int beams_cap = 0;
   std::vector<float> beam_cache;  // last uploaded angles
@@ -397,14 +406,167 @@ int phase_reassign(mcl_handle* h, const double* replay_normals) {
   return MCL_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// stratified / multinomial / residual (single shard): explicit ancestor vector + generic reassign
+// ------------------------------------------------------------------------------------------
+template <class T>
+int lazy_alloc(mcl_handle* h, T** p, size_t count) {
+  if (!*p) HIPCHK(h, hipMalloc(p, sizeof(T) * count));
+  return MCL_OK;
+}
+int alt_alloc(mcl_handle* h) {
+  const size_t n = (size_t)h->n;
+  RET_IF(lazy_alloc(h, &h->cq, n));
+  RET_IF(lazy_alloc(h, &h->u53, n));
+  RET_IF(lazy_alloc(h, &h->cnt, n));
+  RET_IF(lazy_alloc(h, &h->first, n));
+  RET_IF(lazy_alloc(h, &h->flags, n));
+  RET_IF(lazy_alloc(h, &h->fcum, n));
+  RET_IF(lazy_alloc(h, &h->copies, n));
+  RET_IF(lazy_alloc(h, &h->ccum, n));
+  RET_IF(lazy_alloc(h, &h->dupes, n));
+  RET_IF(lazy_alloc(h, &h->cs, n));
+  RET_IF(lazy_alloc(h, &h->chunk, n / 8192 + 2));
+  RET_IF(lazy_alloc(h, &h->uni_dev, n));
+  RET_IF(lazy_alloc(h, &h->wnorm, n));
+  RET_IF(lazy_alloc(h, &h->idx, n));
+  return MCL_OK;
+}
+// inclusive u32 scan of `in` into `out` (n local); uses tile32 as scratch
+int scan_u32(mcl_handle* h, const u32* in, u32* out) {
+  k_u32_tile_sums<<<grid_tiles(h->ntiles_loc), MCL_BLOCK, 0, h->stream>>>(in, h->n, h->tile32);
+  k_scan_tile_sums<u32><<<1, 1024, 0, h->stream>>>(h->tile32, h->ntiles_loc, h->tile32 + h->ntiles_glob);
+  k_u32_scan<<<grid_tiles(h->ntiles_loc), MCL_BLOCK, 0, h->stream>>>(in, h->n, h->tile32, out);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+// residual: normalise like auv_pf.py:172 (numpy's summation order), copies = floor(N w), k = sum
+int residual_prepare(mcl_handle* h) {
+  if (h->residual_k >= 0) return MCL_OK;
+  RET_IF(alt_alloc(h));
+  RET_IF(phase_local_max(h));
+  const long long nchunks = (h->n + 8191) / 8192;
+  t_begin(h, MCL_K_NORMALISE);
+  k_linear_weights<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->lw, h->n, h->scal, h->weight_mode, h->wnorm);
+  if (h->weight_mode == MCL_WEIGHT_LINEAR) {
+    // free-function form (resampling.py): the caller's weights are used as they are, no renormalisation
+    const double one = 1.0;
+    HIPCHK(h, hipMemcpyAsync(h->scal + 1, &one, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  } else {
+    k_np_chunk_sums<<<(unsigned)((nchunks + 63) / 64), 64, 0, h->stream>>>(h->wnorm, h->n, h->chunk);
+    k_np_sum_final<<<1, 64, 0, h->stream>>>(h->chunk, nchunks, h->scal + 1);
+  }
+  k_residual_copies<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->wnorm, h->n, h->scal + 1, h->copies);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  RET_IF(scan_u32(h, h->copies, h->ccum));
+  u32 k = 0;
+  HIPCHK(h, hipMemcpyAsync(&k, h->ccum + (h->n - 1), sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->residual_k = k > (u32)h->n ? h->n : (long long)k;
+  return MCL_OK;
+}
+long long uniforms_needed(mcl_handle* h, int* rc) {
+  *rc = MCL_OK;
+  switch (h->cfg.resample_scheme) {
+    case MCL_RESAMPLE_SYSTEMATIC: return 1;
+    case MCL_RESAMPLE_STRATIFIED:
+    case MCL_RESAMPLE_MULTINOMIAL: return h->n;
+    case MCL_RESAMPLE_RESIDUAL:
+      *rc = residual_prepare(h);
+      return *rc == MCL_OK ? h->n - h->residual_k : 0;
+  }
+  *rc = MCL_ERR_INVALID;
+  return 0;
+}
+int make_uniforms(mcl_handle* h, const double* uniforms, long long nu, long long need) {
+  if (need <= 0) return MCL_OK;
+  const double* rp = nullptr;
+  if (h->cfg.rng_mode == MCL_RNG_REPLAY) {
+    if (!uniforms || nu < need) return fail(h, MCL_ERR_INVALID, "resample: not enough replay uniforms for this scheme");
+    HIPCHK(h, hipMemcpyAsync(h->uni_dev, uniforms, sizeof(double) * (size_t)need, hipMemcpyHostToDevice, h->stream));
+    rp = h->uni_dev;
+  }
+  k_make_u53<<<grid_for(need), MCL_BLOCK, 0, h->stream>>>(rp, need, (u32)h->cfg.seed, (u32)(h->cfg.seed >> 32),
+                                                        h->step_resample, h->u53);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+int alt_indices(mcl_handle* h, const double* uniforms, long long nu) {
+  RET_IF(set_device(h));
+  RET_IF(alt_alloc(h));
+  const int scheme = h->cfg.resample_scheme;
+  if (scheme == MCL_RESAMPLE_RESIDUAL) {
+    RET_IF(residual_prepare(h));
+    const long long k = h->residual_k, need = h->n - k;
+    RET_IF(make_uniforms(h, uniforms, nu, need));
+    t_begin(h, MCL_K_SCAN);
+    if (k > 0) k_residual_head<<<grid_for(k), MCL_BLOCK, 0, h->stream>>>(h->ccum, h->n, k, h->idx);
+    if (need > 0) {
+      k_residual_cumsum<<<1, 64, 0, h->stream>>>(h->wnorm, h->copies, h->n, h->cs);
+      k_residual_searchsorted<<<1, 64, 0, h->stream>>>(h->cs, h->n, h->u53, need, h->idx + k);
+    }
+    t_end(h);
+  } else {
+    RET_IF(phase_local_max(h));
+    RET_IF(phase_quantise(h));
+    RET_IF(make_uniforms(h, uniforms, nu, h->n));
+    t_begin(h, MCL_K_SCAN);
+    k_u64_scan<<<grid_tiles(h->ntiles_loc), MCL_BLOCK, 0, h->stream>>>(h->q, h->n, h->tile64, h->cq);
+    if (scheme == MCL_RESAMPLE_STRATIFIED)
+      k_stratified_idx<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->cq, h->u53, h->n, h->idx);
+    else
+      k_multinomial_idx<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->cq, h->u53, h->n, h->idx);
+    t_end(h);
+  }
+  HIPCHK(h, hipGetLastError());
+  h->idx_explicit = true;
+  h->have_cdf = false;
+  return MCL_OK;
+}
+int run_resample_alt(mcl_handle* h, const double* uniforms, long long nu, const double* replay_normals) {
+  RET_IF(alt_indices(h, uniforms, nu));
+  // keep/lost/dupes for an arbitrary ancestor vector (auv_pf.py:183-198) + noise
+  if (replay_normals) RET_IF(upload_replay(h, replay_normals));
+  t_begin(h, MCL_K_RESAMPLE);
+  HIPCHK(h, hipMemsetAsync(h->cnt, 0, sizeof(u32) * (size_t)h->n, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->first, 0xff, sizeof(u32) * (size_t)h->n, h->stream));
+  k_idx_hist<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->idx, h->n, h->cnt, h->first);
+  k_flags<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->idx, h->cnt, h->first, h->n, 0, h->flags);
+  RET_IF(scan_u32(h, h->flags, h->zcum));
+  k_flags<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->idx, h->cnt, h->first, h->n, 1, h->flags);
+  RET_IF(scan_u32(h, h->flags, h->fcum));
+  k_compact_dupes<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->idx, h->flags, h->fcum, h->n, h->dupes);
+  ReassignIdxArgs a;
+  a.src = state_ptrs(h->state[h->cur], h->n);
+  a.dst = state_ptrs(h->state[h->cur ^ 1], h->n);
+  a.n = h->n;
+  a.nz = noise_args(h, h->cfg.resample_cov, 2u, h->step_resample);
+  k_reassign_idx<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(a, h->cnt, h->zcum, h->dupes,
+                                                             replay_normals ? h->replay_dev : nullptr);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  h->cur ^= 1;
+  h->step_resample++;
+  h->have_cdf = false;
+  h->idx_explicit = true;
+  h->have_lw = false;
+  h->residual_k = -1;
+  return MCL_OK;
+}
+
 int run_resample(mcl_handle** sh, int ns, const double* uniforms, long long nu,
                  const double* const* replay_normals) {
   mcl_handle* h0 = sh[0];
   for (int s = 0; s < ns; ++s) {
     if (!sh[s]->have_lw) return fail(sh[s], MCL_ERR_STATE, "resample: no weights (call an update first)");
-    if (sh[s]->cfg.resample_scheme != MCL_RESAMPLE_SYSTEMATIC)
-      return fail(sh[s], MCL_ERR_UNSUPPORTED,
-                  "resample: only MCL_RESAMPLE_SYSTEMATIC runs on the GPU in this build (no CPU fallback)");
+    if (sh[s]->cfg.resample_scheme != MCL_RESAMPLE_SYSTEMATIC) {
+      if (ns > 1 || sh[s]->world > 1)
+        return fail(sh[s], MCL_ERR_UNSUPPORTED, "resample: only the systematic scheme is sharded across GPUs");
+      return run_resample_alt(sh[s], uniforms, nu, replay_normals ? replay_normals[0] : nullptr);
+    }
   }
   uint64_t u53;
   if (h0->cfg.rng_mode == MCL_RNG_REPLAY) {
@@ -772,7 +934,8 @@ int mcl_destroy(mcl_handle* h) {
   if (h->comm) ncclCommDestroy(h->comm);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev};
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->cq, h->u53, h->cnt, h->first,
+                  h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev};
   for (void* b : bufs)
     if (b) hipFree(b);
   if (h->mesh) mesh_free(h->mesh);
@@ -828,6 +991,7 @@ int mcl_update_gps(mcl_handle* h, double gx_map, double gy_map) {
   HIPCHK(h, hipGetLastError());
   h->weight_mode = MCL_WEIGHT_LINEAR_FLOOR;
   h->have_lw = true;
+  h->residual_k = -1;
   return MCL_OK;
 }
 
@@ -881,6 +1045,7 @@ int mcl_update_mbes(mcl_handle* h, const float* ranges, const float* beam_angles
   RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0));
   h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
   h->have_lw = true;
+  h->residual_k = -1;
   return MCL_OK;
 }
 
@@ -911,6 +1076,15 @@ int mcl_resample(mcl_handle* h, const double* uniforms, int64_t n_uniforms, cons
     return fail(h, MCL_ERR_INVALID, "resample: REPLAY mode needs n x 6 normals");
   const double* rn[1] = {replay_normals};
   return run_resample(&h, 1, uniforms, n_uniforms, rn);
+}
+
+int mcl_resample_prepare(mcl_handle* h, int64_t* n_uniforms) {
+  if (!h || !n_uniforms) return MCL_ERR_INVALID;
+  if (!h->have_lw) return fail(h, MCL_ERR_STATE, "resample_prepare: no weights (call an update first)");
+  RET_IF(set_device(h));
+  int rc;
+  *n_uniforms = uniforms_needed(h, &rc);
+  return rc;
 }
 
 int mcl_group_resample(mcl_handle** shards, int32_t ns, const double* uniforms, int64_t n_uniforms,
@@ -1002,16 +1176,19 @@ int mcl_set_log_weights(mcl_handle* h, const double* lw, int32_t weight_mode) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->weight_mode = weight_mode;
   h->have_lw = true;
+  h->residual_k = -1;
   return MCL_OK;
 }
 
 int mcl_get_last_indices(mcl_handle* h, int32_t* idx) {
   if (!h || !idx) return MCL_ERR_INVALID;
-  if (!h->have_cdf) return fail(h, MCL_ERR_STATE, "get_last_indices: no resample yet");
+  if (!h->have_cdf && !h->idx_explicit) return fail(h, MCL_ERR_STATE, "get_last_indices: no resample yet");
   RET_IF(set_device(h));
   if (!h->idx) HIPCHK(h, hipMalloc(&h->idx, sizeof(int) * (size_t)h->n));
-  k_indices<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->ncum, h->ng, h->goff, h->n, h->idx);
-  HIPCHK(h, hipGetLastError());
+  if (!h->idx_explicit) {
+    k_indices<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->ncum, h->ng, h->goff, h->n, h->idx);
+    HIPCHK(h, hipGetLastError());
+  }
   HIPCHK(h, hipMemcpyAsync(idx, h->idx, sizeof(int) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MCL_OK;
@@ -1053,6 +1230,7 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
   RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0));
   h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
   h->have_lw = true;
+  h->residual_k = -1;
   RET_IF(run_resample(&h, 1, nullptr, 0, nullptr));
   RET_IF(run_mean_cov_async(&h, 1));
   return MCL_OK;
@@ -1079,10 +1257,12 @@ int mcl_resample_indices(int32_t scheme, const double* weights, int64_t n, const
   if (rc != MCL_OK) return rc;
   rc = mcl_set_log_weights(h, weights, MCL_WEIGHT_LINEAR);
   if (rc == MCL_OK) {
-    // run the CDF phases only (no reassign): same code path as run_resample up to phase_cdf
     if (scheme != MCL_RESAMPLE_SYSTEMATIC) {
-      g_create_err = "resample_indices: only MCL_RESAMPLE_SYSTEMATIC runs on the GPU in this build";
-      rc = MCL_ERR_UNSUPPORTED;
+      int64_t need = 0;
+      rc = mcl_resample_prepare(h, &need);
+      if (rc == MCL_OK) rc = alt_indices(h, uniforms, n_uniforms);
+      if (rc == MCL_OK) rc = mcl_get_last_indices(h, out);
+      if (rc != MCL_OK) g_create_err = h->err;
     } else if (!uniforms || n_uniforms < 1 || !(uniforms[0] >= 0.0 && uniforms[0] < 1.0)) {
       g_create_err = "resample_indices: systematic needs one uniform in [0,1)";
       rc = MCL_ERR_INVALID;

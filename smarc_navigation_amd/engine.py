@@ -112,6 +112,11 @@ class Engine(object):
         nz = _f64(normals)
         self._ck(self.lib.mcl_resample(self.h, _ptr(u), 0 if u is None else u.size, _ptr(nz)))
 
+    def resample_prepare(self):
+        k = C.c_int64(0)
+        self._ck(self.lib.mcl_resample_prepare(self.h, C.byref(k)))
+        return int(k.value)
+
     def mean_cov(self):
         mean, yaw, cov = np.zeros(6), np.zeros(1), np.zeros(9)
         self._ck(self.lib.mcl_mean_cov(self.h, _ptr(mean), _ptr(yaw), _ptr(cov)))
