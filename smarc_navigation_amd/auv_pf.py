@@ -1,0 +1,241 @@
+"""Host-side mirror of the reference node class `auv_pf` (auv_particle_filter/scripts/auv_pf.py):
+same class name, method names, parameter names/defaults and message fields -- the per-particle
+Python loops are replaced by calls through the C ABI (libmcl_hip.so).  ROS-free core: transport
+(publishers, tf) is injected; `ros_node.py` plugs in rospy when ROS is installed.
+
+Divergences from the reference, all documented in INTEGRATION.md:
+  * one owner lock around the handle (the reference's three rospy threads are unlocked);
+  * the GPS gate `self.time > self.old_time` (auv_pf.py:126, only true mid-callback) is "every fix
+    while not diving";
+  * default resampling scheme on the GPU is systematic (resampling.py:135); pass
+    resample_scheme='residual' for the node's literal behaviour (auv_pf.py:182).
+"""
+import math
+import threading
+
+import numpy as np
+
+from . import engine as _engine
+from . import msgs as _msgs
+
+_SCHEMES = {'systematic': _engine.SYSTEMATIC, 'residual': _engine.RESIDUAL,
+            'stratified': _engine.STRATIFIED, 'multinomial': _engine.MULTINOMIAL}
+
+DEFAULT_PARAMS = {
+    # auv_pf.py:27-31
+    'particle_count': 10, 'map_frame': 'map', 'base_frame': 'base_link', 'utm_frame': 'utm',
+    'odom_frame': 'sam/odom',
+    # auv_pf.py:39 (+ launch defaults auv_pf.launch:17-20 for the three strings, which have no code default)
+    'measurement_std': 0.01,
+    'motion_covariance': '[0.0000, 0.0000, 0.0, 0.0, 0.0, 0.000000000001]',
+    'init_covariance': '[0.1, 0.1, 0.0, 0.0, 0.0, 0.0]',
+    'resampling_noise_covariance': '[1., 1., 0.0, 0.0, 0.0, 0.0001]',
+    # topics (auv_pf.py:64,71,101,106,110)
+    'particle_poses_topic': '/particle_poses', 'odom_corrected_topic': '/average_pose',
+    'aux_dive': '/dive', 'gps_odom_topic': '/gps', 'odom_topic': 'odom',
+    # new, behaviour-preserving defaults
+    'resample_scheme': 'systematic', 'seed': 0, 'device': 0,
+    'mbes_topic': '/mbes_scan', 'mbes_std': 0.2, 'mbes_sensor_offset': '[0.0, 0.0, 0.0, 0.0, 0.0, 0.0]',
+}
+
+
+def parse_cov_string(cov_string):
+    """The reference's ad-hoc parser (auv_pf.py:40-44): strip brackets, split on ', '."""
+    cov_string = cov_string.replace('[', '')
+    cov_string = cov_string.replace(']', '')
+    cov_list = list(cov_string.split(", "))
+    return list(map(float, cov_list))
+
+
+def quaternion_from_euler(roll, pitch, yaw):
+    """tf.transformations.quaternion_from_euler, axes 'sxyz' (auv_pf.py:233)."""
+    cr, sr = math.cos(roll / 2.0), math.sin(roll / 2.0)
+    cp, sp = math.cos(pitch / 2.0), math.sin(pitch / 2.0)
+    cy, sy = math.cos(yaw / 2.0), math.sin(yaw / 2.0)
+    return [cp * (sr * cy) - sp * (cr * sy), cp * (sr * sy) + sp * (cr * cy),
+            cp * (cr * sy) - sp * (sr * cy), cp * (cr * cy) + sp * (sr * sy)]
+
+
+def matrix_from_tf(translation, rotation):
+    """auv_particle.py:110-125: 4x4 from a tf translation (x,y,z) and quaternion (x,y,z,w)."""
+    q = np.array(rotation[:4], dtype=np.float64)
+    nq = float(np.dot(q, q))
+    m = np.identity(4)
+    if nq >= np.finfo(float).eps * 4.0:
+        q *= math.sqrt(2.0 / nq)
+        o = np.outer(q, q)
+        m[:3, :3] = [[1.0 - o[1, 1] - o[2, 2], o[0, 1] - o[2, 3], o[0, 2] + o[1, 3]],
+                     [o[0, 1] + o[2, 3], 1.0 - o[0, 0] - o[2, 2], o[1, 2] - o[0, 3]],
+                     [o[0, 2] - o[1, 3], o[1, 2] + o[0, 3], 1.0 - o[0, 0] - o[1, 1]]]
+    m[:3, 3] = translation[:3]
+    return m
+
+
+class RecordingTransport(object):
+    """Default transport: keeps what the node would have published / broadcast."""
+
+    def __init__(self, utm2map=None):
+        self.utm2map = np.identity(4) if utm2map is None else np.asarray(utm2map, dtype=np.float64)
+        self.particle_poses, self.odom_corrected, self.tf = [], [], []
+
+    def transformPoint(self, frame, pt):  # tf.TransformListener.transformPoint (auv_pf.py:151)
+        v = self.utm2map.dot(np.array([pt.point.x, pt.point.y, pt.point.z, 1.0]))
+        out = _msgs.PointStamped()
+        out.header.frame_id = frame
+        out.point.x, out.point.y, out.point.z = float(v[0]), float(v[1]), float(v[2])
+        return out
+
+    def publish_poses(self, msg):
+        self.particle_poses.append(msg)
+
+    def publish_odom(self, msg):
+        self.odom_corrected.append(msg)
+
+    def sendTransform(self, trans, rot, stamp, child, parent):
+        self.tf.append((list(trans), list(rot), stamp, child, parent))
+
+    def now(self):
+        return _msgs.Time(0.0)
+
+
+class auv_pf(object):
+
+    def __init__(self, params=None, m2o_mat=None, transport=None, rng_mode=_engine.RNG_NATIVE):
+        p = dict(DEFAULT_PARAMS)
+        p.update(params or {})
+        self.params = p
+        self.pc = int(p['particle_count'])
+        self.map_frame, self.base_frame = p['map_frame'], p['base_frame']
+        self.utm_frame, self.odom_frame = p['utm_frame'], p['odom_frame']
+        meas_std = float(p['measurement_std'])
+        motion_cov = parse_cov_string(p['motion_covariance'])
+        init_cov = parse_cov_string(p['init_covariance'])
+        self.res_noise_cov = parse_cov_string(p['resampling_noise_covariance'])
+        self.mbes_std = float(p['mbes_std'])
+        self.mbes_sensor_offset = parse_cov_string(p['mbes_sensor_offset'])
+        self.transport = transport if transport is not None else RecordingTransport()
+        self.m2o_mat = np.identity(4) if m2o_mat is None else np.asarray(m2o_mat, dtype=np.float64)
+        self.lock = threading.Lock()
+        # the particle list of auv_pf.py:89-94 lives in HBM
+        self.particles = _engine.Engine(self.pc, init_cov=init_cov, process_cov=motion_cov,
+                                        resample_cov=self.res_noise_cov, meas_std=meas_std, m2o=self.m2o_mat,
+                                        seed=int(p['seed']), rng_mode=rng_mode,
+                                        resample_scheme=_SCHEMES[p['resample_scheme']], device=int(p['device']))
+        self._replay = None  # REPLAY mode: object with randn(n,6) / random_sample(k)
+        if rng_mode == _engine.RNG_NATIVE:
+            self.particles.init_particles()
+        self.poses = _msgs.PoseArray()
+        self.poses.header.frame_id = self.odom_frame
+        self.loc_pose = _msgs.Odometry()
+        self.loc_pose.header.frame_id = self.odom_frame
+        self.loc_pose.child_frame_id = self.base_frame
+        self.cov = np.zeros((3, 3))
+        self.time = 0.0
+        self.old_time = 0.0
+        self.diving = True  # auv_pf.py:103
+        self.odom_latest = None
+        self.has_map = False
+
+    # ---- REPLAY-mode RNG source (parity runs): rs must offer randn(n, 6) and random_sample(k)
+    def set_replay_source(self, rs):
+        self._replay = rs
+        self.particles.init_particles(rs.randn(self.pc, 6))
+
+    def start_timing(self, stamp):
+        """auv_pf.py:96-98: `Start timing now`."""
+        self.time = float(stamp)
+        self.old_time = float(stamp)
+
+    # ---- callbacks, same names as the reference
+    def dive_cb(self, dive_msg):
+        self.diving = dive_msg.data
+
+    def odom_callback(self, odom_msg):
+        with self.lock:
+            self.time = odom_msg.header.stamp.to_sec()
+            self.odom_latest = odom_msg
+            if self.old_time and self.time > self.old_time:
+                self.predict(odom_msg)
+            self.old_time = self.time
+
+    def predict(self, odom_t):
+        dt = self.time - self.old_time
+        tw, po = odom_t.twist.twist, odom_t.pose.pose
+        nz = self._replay.randn(self.pc, 6) if self._replay is not None else None
+        self.particles.predict([tw.linear.x, tw.linear.y, tw.linear.z], tw.angular.z,
+                               [po.orientation.x, po.orientation.y, po.orientation.z, po.orientation.w],
+                               po.position.z, dt, nz, stamp=self.time)
+
+    def gps_odom_cb(self, gps_odom):
+        with self.lock:
+            if self.old_time and not self.diving:
+                weights = self.update(gps_odom)
+                self.resample(weights)
+
+    def update(self, gps_odom):
+        goal_point = _msgs.PointStamped()
+        goal_point.header.frame_id = self.utm_frame
+        goal_point.point.x = gps_odom.pose.pose.position.x
+        goal_point.point.y = gps_odom.pose.pose.position.y
+        goal_point.point.z = 0.
+        gps_map = self.transport.transformPoint(self.map_frame, goal_point)  # once, not per particle
+        self.particles.update_gps(gps_map.point.x, gps_map.point.y)
+        return self.particles  # the weights stay in HBM; resample() consumes them there
+
+    def resample(self, weights):
+        if self._replay is not None:
+            need = self.particles.resample_prepare()
+            u = self._replay.random_sample(need) if need != 1 else self._replay.random_sample()
+            self.particles.resample(u, self._replay.randn(self.pc, 6))
+        else:
+            self.particles.resample()
+
+    def reassign_poses(self, lost, dupes):
+        """Folded into resample() on the device (auv_pf.py:195-198 semantics)."""
+        return None
+
+    # ---- MBES (north_star): map + ping callback
+    def set_map_grid(self, z, origin, res):
+        with self.lock:
+            self.particles.set_map_grid(z, origin, res)
+            self.has_map = True
+
+    def set_map_mesh(self, verts, tris):
+        with self.lock:
+            self.particles.set_map_mesh(verts, tris)
+            self.has_map = True
+
+    def mbes_cb(self, scan):
+        with self.lock:
+            if not (self.old_time and self.has_map):
+                return
+            n = len(scan.ranges)
+            angles = scan.angle_min + scan.angle_increment * np.arange(n)
+            self.particles.update_mbes(np.asarray(scan.ranges, dtype=np.float32), angles.astype(np.float32),
+                                       self.mbes_std, float(scan.range_max), self.mbes_sensor_offset)
+            self.resample(self.particles)
+
+    # ---- publishing, auv_pf.py:218-285
+    def update_loc_pose(self, pose_list=None):
+        mean, yaw, cov9 = self.particles.mean_cov()
+        lp = self.loc_pose
+        lp.pose.pose.position.x, lp.pose.pose.position.y, lp.pose.pose.position.z = mean[0], mean[1], mean[2]
+        quat_t = quaternion_from_euler(mean[3], mean[4], yaw)
+        lp.pose.pose.orientation = _msgs.Quaternion(*quat_t)
+        lp.header.stamp = self.transport.now()
+        self.cov = np.array(cov9).reshape(3, 3)
+        lp.pose.covariance = [0.] * 36
+        for i in range(3):
+            for j in range(3):
+                lp.pose.covariance[i * 3 + j] = float(self.cov[i, j])
+        self.transport.publish_odom(lp)
+        self.transport.sendTransform([mean[0], mean[1], 0.], quat_t, self.transport.now(), self.base_frame,
+                                     self.odom_frame)
+        return mean, yaw, cov9
+
+    def loc_loop(self, event=None):
+        with self.lock:
+            self.poses.data = self.particles.poses()  # (n, 7): position + quaternion_from_euler per particle
+            self.poses.header.stamp = self.transport.now()
+            self.update_loc_pose()
+            self.transport.publish_poses(self.poses)
