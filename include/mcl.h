@@ -140,6 +140,16 @@ int mcl_update_mbes(mcl_handle* h, const float* ranges, const float* beam_angles
 int mcl_mbes_expected(mcl_handle* h, int64_t first, int64_t count, const float* beam_angles,
                       int32_t n_beams, double r_max, const double sensor_offset[6], float* out);
 
+/* ---- landmark update with k-nearest-neighbour data association (BASELINE config 5; nearest
+ * reference analogues: auv_ekf_localization/src/ekf_localization.cpp:479-524 max-likelihood
+ * landmark, auv_ekf_slam/src/ekf_slam.cpp:100-103 chi-square gate).  Landmarks in the MAP frame
+ * (n x 3 doubles); detections in the SENSOR frame (n_det x 3 doubles, NaN row = invalid);
+ * 1 <= k <= 4; gate = chi-square threshold on |p - l|^2 / sigma^2; accumulate != 0 adds the
+ * log-likelihood to the one an earlier update left (e.g. MBES ranges + landmarks of one ping). */
+int mcl_set_landmarks(mcl_handle* h, const double* xyz, int64_t n_landmarks);
+int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, double sigma, int32_t k,
+                         double gate, const double sensor_offset[6], int32_t accumulate);
+
 /* ---- a8-a12 + a2: auv_pf.resample (auv_pf.py:169-198): normalise, resample, keep/lost/dupes
  * reassign, add_noise(resampling_noise_covariance).
  * uniforms: REPLAY: scheme-dependent draws in reference order (systematic: 1); NATIVE: NULL.

@@ -890,3 +890,60 @@ void orc_mbes_update(int n, const double* state, const double m2o[16], const dou
     if (lw) lw[i] = -0.5 * acc - (double)nvalid * lognorm;
   }
 }
+
+/* ------------------------------------------------------------------ landmark k-NN update
+ * SELF-ORACLE (parity unpinned: the reference PF has no landmark model; nearest analogues
+ * auv_ekf_localization/src/ekf_localization.cpp:479-524, auv_ekf_slam/src/ekf_slam.cpp:100-103).
+ * Brute force over all landmarks: maha_j = |p_d - l_j|^2 / sigma^2; over the k nearest with
+ * maha <= gate: lw_d = log sum exp(-maha/2), else -gate/2;  lw = sum_d lw_d - D * lognorm. */
+void orc_landmark_update(int n, const double* state, const double m2o[16], const double sensor_off[6],
+                         const double* lm, int64_t n_lm, const double* det, int n_det, double sigma, int k,
+                         double gate, double* lw) {
+  double Ro[9];
+  rot_rpy(sensor_off[3], sensor_off[4], sensor_off[5], Ro);
+  double Rm[9] = {m2o[0], m2o[1], m2o[2], m2o[4], m2o[5], m2o[6], m2o[8], m2o[9], m2o[10]};
+  const double lognorm = 1.5 * log(2.0 * PI) + 3.0 * log(sigma);
+  for (int i = 0; i < n; ++i) {
+    double Rp[9], Rmp[9], Rs[9];
+    rot_rpy(ST(3, i), ST(4, i), ST(5, i), Rp);
+    mat3_mul(Rm, Rp, Rmp);
+    mat3_mul(Rmp, Ro, Rs);
+    double x = ST(0, i), y = ST(1, i), z = ST(2, i), o[3];
+    for (int r = 0; r < 3; ++r)
+      o[r] = (m2o[r * 4 + 0] * x + m2o[r * 4 + 1] * y + m2o[r * 4 + 2] * z + m2o[r * 4 + 3]) +
+             (Rmp[r * 3 + 0] * sensor_off[0] + Rmp[r * 3 + 1] * sensor_off[1] + Rmp[r * 3 + 2] * sensor_off[2]);
+    double acc = 0.0;
+    int nvalid = 0;
+    for (int d = 0; d < n_det; ++d) {
+      const double* zd = det + 3 * d;
+      if (!(zd[0] == zd[0] && zd[1] == zd[1] && zd[2] == zd[2])) continue;
+      double p[3];
+      for (int r = 0; r < 3; ++r) p[r] = o[r] + Rs[r * 3] * zd[0] + Rs[r * 3 + 1] * zd[1] + Rs[r * 3 + 2] * zd[2];
+      double best[8];
+      for (int q = 0; q < k; ++q) best[q] = INFINITY;
+      for (int64_t j = 0; j < n_lm; ++j) {
+        double dx = p[0] - lm[3 * j], dy = p[1] - lm[3 * j + 1], dz = p[2] - lm[3 * j + 2];
+        double m = (dx * dx + dy * dy + dz * dz) / (sigma * sigma);
+        if (m <= gate)
+          for (int q = 0; q < k; ++q)
+            if (m < best[q]) {
+              double t = best[q];
+              best[q] = m;
+              m = t;
+            }
+      }
+      double lwd;
+      if (best[0] == INFINITY) {
+        lwd = -0.5 * gate;
+      } else {
+        double s = 0.0;
+        for (int q = 0; q < k; ++q)
+          if (best[q] != INFINITY) s += exp(-0.5 * (best[q] - best[0]));
+        lwd = -0.5 * best[0] + log(s);
+      }
+      acc += lwd;
+      ++nvalid;
+    }
+    lw[i] = acc - (double)nvalid * lognorm;
+  }
+}

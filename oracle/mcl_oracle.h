@@ -106,6 +106,10 @@ double orc_ray_mesh(const orc_mesh* m, const double o[3], const double d[3], dou
 void orc_mbes_update(int n, const double* state, const double m2o[16], const double sensor_off[6],
                      int map_kind, const void* map, const float* beam_angles, const float* ranges, int B,
                      double sigma, double r_max, double* lw, double* exp_out);
+/* landmark update with k-NN association (SELF-ORACLE, brute force over all landmarks) */
+void orc_landmark_update(int n, const double* state, const double m2o[16], const double sensor_off[6],
+                         const double* lm, int64_t n_lm, const double* det, int n_det, double sigma, int k,
+                         double gate, double* lw);
 #ifdef __cplusplus
 }
 #endif

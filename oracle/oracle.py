@@ -68,6 +68,7 @@ def _load():
         'orc_mesh_build': (vp, [_f32p, i64, _u32p, i64]),
         'orc_mesh_free': (None, [vp]),
         'orc_ray_mesh': (d, [vp, _f64p, _f64p, d]),
+        'orc_landmark_update': (None, [i, _f64p, _f64p, _f64p, _f64p, i64, _f64p, i, d, i, d, _f64p]),
         'orc_mbes_update': (None, [i, _f64p, _f64p, _f64p, i, vp, _f32p, vp, i, d, d, vp, vp]),
     }
     for name, (res, args) in sig.items():
@@ -312,3 +313,11 @@ def mbes_update(soa, m2o, sensor_off, amap, beam_angles, ranges, sigma, r_max, w
                        None if rg is None else rg.ctypes.data, B, float(sigma), float(r_max),
                        lw.ctypes.data, None if ex is None else ex.ctypes.data)
     return lw, ex
+
+
+def landmark_update(soa, m2o, sensor_off, landmarks, det, sigma, k=1, gate=11.345):
+    lm, dt = _c(landmarks), _c(det)
+    lw = np.zeros(soa.shape[1])
+    _L.orc_landmark_update(soa.shape[1], soa, _c(m2o).reshape(-1), _c(sensor_off), lm, lm.shape[0], dt,
+                           dt.shape[0], float(sigma), int(k), float(gate), lw)
+    return lw

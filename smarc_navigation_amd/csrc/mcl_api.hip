@@ -15,6 +15,7 @@
 #include "mcl_mbes.h"
 #include "mcl_mesh.h"
 #include "mcl_resample_alt.h"
+#include "mcl_landmarks.h"
 
 namespace {
 
@@ -73,6 +74,9 @@ struct mcl_handle {
   double gox = 0, goy = 0, gres = 1;
   float gzmin = 0, gzmax = 0;
   MeshDev* mesh = nullptr;
+  LandmarkDev* landmarks = nullptr;
+  double* det_dev = nullptr;
+  int det_cap = 0;
   int map_kind = -1;  // 0 grid, 1 mesh
   // bookkeeping
   int weight_mode = 0;
@@ -939,6 +943,8 @@ int mcl_destroy(mcl_handle* h) {
   for (void* b : bufs)
     if (b) hipFree(b);
   if (h->mesh) mesh_free(h->mesh);
+  if (h->landmarks) landmarks_free(h->landmarks);
+  if (h->det_dev) hipFree(h->det_dev);
   if (h->host_pin) hipHostFree(h->host_pin);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -1065,6 +1071,73 @@ int mcl_mbes_expected(mcl_handle* h, int64_t first, int64_t count, const float* 
   RET_IF(launch_mbes(h, false, B, 1.0, r_max, sensor_offset, nullptr, h->exp_dev, first, count));
   HIPCHK(h, hipMemcpyAsync(out, h->exp_dev, sizeof(float) * need, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MCL_OK;
+}
+
+int mcl_set_landmarks(mcl_handle* h, const double* xyz, int64_t n_landmarks) {
+  if (!h || !xyz || n_landmarks < 1) return fail(h, MCL_ERR_INVALID, "set_landmarks: bad argument");
+  RET_IF(set_device(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->landmarks) landmarks_free(h->landmarks);
+  h->landmarks = new LandmarkDev();
+  h->landmarks->host_xyz.assign(xyz, xyz + 3 * n_landmarks);
+  return MCL_OK;
+}
+
+int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, double sigma, int32_t k, double gate,
+                         const double sensor_offset[6], int32_t accumulate) {
+  if (!h || !det_xyz || n_det < 1 || !(sigma > 0.0) || k < 1 || k > LM_MAX_K || !(gate > 0.0))
+    return fail(h, MCL_ERR_INVALID, "update_landmarks: bad argument (1 <= k <= 4)");
+  if (!h->landmarks) return fail(h, MCL_ERR_STATE, "update_landmarks: no feature map (call mcl_set_landmarks first)");
+  if (accumulate && !h->have_lw) return fail(h, MCL_ERR_STATE, "update_landmarks: nothing to accumulate onto");
+  RET_IF(set_device(h));
+  std::string err;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int rc = landmarks_build(h->landmarks, sigma * std::sqrt(gate), &err);
+  if (rc != MCL_OK) {
+    h->err = err;
+    return rc;
+  }
+  if (n_det > h->det_cap) {
+    if (h->det_dev) hipFree(h->det_dev);
+    h->det_dev = nullptr;
+    HIPCHK(h, hipMalloc(&h->det_dev, sizeof(double) * 3 * (size_t)n_det));
+    h->det_cap = n_det;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->det_dev, det_xyz, sizeof(double) * 3 * (size_t)n_det, hipMemcpyHostToDevice, h->stream));
+  static const double zero6[6] = {0, 0, 0, 0, 0, 0};
+  const double* so = sensor_offset ? sensor_offset : zero6;
+  LandmarkArgs a;
+  for (int c = 0; c < 6; ++c) a.st[c] = h->state[h->cur] + (size_t)c * h->n;
+  a.n = h->n;
+  for (int q = 0; q < 12; ++q) a.m2o[q] = h->cfg.m2o[q];
+  for (int q = 0; q < 3; ++q) a.off_t[q] = so[q];
+  rot_rpy(so[3], so[4], so[5], a.off_R);
+  a.det = h->det_dev;
+  a.n_det = n_det;
+  a.lm = h->landmarks->lm;
+  a.cell_start = h->landmarks->cell_start;
+  a.gx = h->landmarks->gx;
+  a.gy = h->landmarks->gy;
+  a.x0 = h->landmarks->x0;
+  a.y0 = h->landmarks->y0;
+  a.inv_cs = 1.0 / h->landmarks->cs;
+  a.inv_s2 = 1.0 / (sigma * sigma);
+  a.gate = gate;
+  a.lognorm = 1.5 * std::log(2.0 * MCL_PI) + 3.0 * std::log(sigma);
+  a.k = k;
+  a.accumulate = accumulate ? 1 : 0;
+  a.lw = h->lw;
+  t_begin(h, MCL_K_UPDATE_MBES);
+  const long long per_block = 256 / LM_SUB;
+  long long blocks = (h->n + per_block - 1) / per_block;
+  if (blocks > 16384) blocks = 16384;
+  k_landmark_update<<<(unsigned)blocks, 256, 0, h->stream>>>(a);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  if (!accumulate) h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
+  h->have_lw = true;
+  h->residual_k = -1;
   return MCL_OK;
 }
 

@@ -107,6 +107,15 @@ class Engine(object):
                                             _ptr(so), _ptr(out)))
         return out
 
+    def set_landmarks(self, xyz):
+        a = _f64(xyz)
+        self._ck(self.lib.mcl_set_landmarks(self.h, _ptr(a), a.shape[0]))
+
+    def update_landmarks(self, det_xyz, sigma, k=1, gate=11.345, sensor_offset=None, accumulate=False):
+        d, so = _f64(det_xyz), _f64(sensor_offset)
+        self._ck(self.lib.mcl_update_landmarks(self.h, _ptr(d), d.shape[0], float(sigma), int(k), float(gate),
+                                               _ptr(so), 1 if accumulate else 0))
+
     def resample(self, uniforms=None, normals=None):
         u = None if uniforms is None else _f64(np.atleast_1d(uniforms))
         nz = _f64(normals)

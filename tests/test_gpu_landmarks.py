@@ -1,0 +1,100 @@
+"""Landmark k-NN data-association update (BASELINE config 5) vs the brute-force fp64 self-oracle.
+PARITY UNPINNED vs the reference: auv_particle_filter has no landmark model."""
+import numpy as np
+import pytest
+
+from smarc_navigation_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n, n_lm=4096, n_det=16, seed=6):
+    rs = np.random.RandomState(seed)
+    lm = np.stack([rs.uniform(-64, 448, n_lm), rs.uniform(-256, 256, n_lm), rs.uniform(-24, -16, n_lm)], axis=1)
+    soa = rs.randn(6, n) * np.array([1.0, 1.0, 0.2, 0.02, 0.02, 0.05])[:, None]
+    soa[0] += 100.0
+    soa[1] += 20.0
+    soa[2] += -2.0
+    truth = np.array([100.0, 20.0, -2.0, 0.0, 0.0, 0.0])
+    # detections = the landmarks nearest to the truth sensor, seen from the truth pose, + noise
+    d2 = (lm[:, 0] - truth[0]) ** 2 + (lm[:, 1] - truth[1]) ** 2
+    near = np.argsort(d2)[:n_det]
+    det = lm[near] - truth[:3] + 0.05 * rs.randn(n_det, 3)  # truth has identity rotation
+    return lm, soa, det
+
+
+@pytest.mark.parametrize('k', [1, 2, 4])
+def test_landmark_update_matches_bruteforce_oracle(k):
+    from smarc_navigation_amd import engine as eng
+    from oracle import oracle as orc
+    n = 3000
+    lm, soa, det = _scene(n)
+    det[3] = np.nan  # an invalid detection is skipped
+    m2o = synth.rigid_matrix(0.5, -0.5, 0.0, 0.0, 0.0, 0.02)
+    off = [0.1, 0.0, -0.2, 0.0, 0.01, 0.0]
+    e = eng.Engine(n, m2o=m2o, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_landmarks(lm)
+    e.update_landmarks(det, 0.5, k=k, gate=11.345, sensor_offset=off)
+    lw = e.get_log_weights()
+    ref = orc.landmark_update(soa, m2o, off, lm, det, 0.5, k, 11.345)
+    np.testing.assert_allclose(lw, ref, rtol=1e-11, atol=1e-9)
+    assert np.std(ref) > 1.0  # the update discriminates between particles
+
+
+def test_landmark_dense_map_exercises_knn_mixture():
+    """Many landmarks inside one gate: the k-nearest bookkeeping matters."""
+    from smarc_navigation_amd import engine as eng
+    from oracle import oracle as orc
+    rs = np.random.RandomState(2)
+    n = 500
+    lm = np.stack([rs.uniform(-5, 5, 3000), rs.uniform(-5, 5, 3000), rs.uniform(-1, 1, 3000)], axis=1)
+    soa = np.zeros((6, n))
+    soa[0] = rs.uniform(-2, 2, n)
+    soa[1] = rs.uniform(-2, 2, n)
+    soa[5] = rs.uniform(-3, 3, n)
+    det = rs.uniform(-2, 2, size=(20, 3))  # more than 16 detections: lanes loop
+    e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_landmarks(lm)
+    for k in (1, 3):
+        e.update_landmarks(det, 0.3, k=k, gate=9.0)
+        ref = orc.landmark_update(soa, np.identity(4), [0] * 6, lm, det, 0.3, k, 9.0)
+        np.testing.assert_allclose(e.get_log_weights(), ref, rtol=1e-11, atol=1e-9)
+
+
+def test_landmarks_accumulate_onto_mbes_and_filter_converges():
+    from smarc_navigation_amd import engine as eng
+    n = 20000
+    lm, soa, det = _scene(n)
+    origin = (-64.0, -256.0)
+    z = synth.bathymetry_grid(512, 512, 1.0, origin, seed=3)
+    ba = synth.beam_angles(64)
+    e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_map_grid(z, origin, 1.0)
+    e.set_landmarks(lm)
+    one = eng.Engine(1, rng_mode=eng.RNG_REPLAY)
+    one.set_map_grid(z, origin, 1.0)
+    one.set_particles(np.array([[100.0], [20.0], [-2.0], [0.0], [0.0], [0.0]]))
+    ranges = one.mbes_expected(0, 1, ba, 80.0)[0]
+    e.update_mbes(ranges, ba, 0.2, 80.0)
+    lw_mbes = e.get_log_weights()
+    e.update_landmarks(det, 0.5, k=2, accumulate=True)
+    lw_both = e.get_log_weights()
+    e.update_landmarks(det, 0.5, k=2, accumulate=False)
+    lw_lm = e.get_log_weights()
+    np.testing.assert_allclose(lw_both, lw_mbes + lw_lm, rtol=1e-12, atol=1e-9)
+    e.set_log_weights(lw_both, eng.WEIGHT_LOG_SHIFT)
+    e.resample(0.37, np.zeros((n, 6)))
+    mean, _, _ = e.mean_cov()
+    assert np.hypot(mean[0] - 100.0, mean[1] - 20.0) < 0.15
+
+
+def test_update_landmarks_needs_a_feature_map():
+    from smarc_navigation_amd import engine as eng
+    e = eng.Engine(16)
+    e.init_particles()
+    with pytest.raises(eng.MclError) as ei:
+        e.update_landmarks(np.zeros((2, 3)), 0.5)
+    assert ei.value.status == -5
