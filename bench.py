@@ -59,7 +59,7 @@ def attach_map(e, m):
     if m['kind'] == 'grid':
         e.set_map_grid(m['z'], m['origin'], m['res'])
     else:
-        e.set_map_mesh(m['verts'], m['tris'])
+        e.set_map_mesh(m['verts'], m['tris'], heightfield=True)  # triangulated height field: single-valued z(x,y)
 
 
 def make_ranges(engine_mod, m, stream, n_steps, beam_angles, sigma, r_max):

@@ -132,6 +132,12 @@ int mcl_update_gps(mcl_handle* h, double gx_map, double gy_map);
 int mcl_set_map_grid(mcl_handle* h, const float* z, int32_t nx, int32_t ny, double origin_x,
                      double origin_y, double res); /* z[ix*ny + iy] at (ox + ix*res, oy + iy*res) */
 int mcl_set_map_mesh(mcl_handle* h, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt);
+/* flags: MCL_MESH_HEIGHTFIELD = the caller declares the mesh single-valued in z over (x,y) (what a
+ * bathymetric surface is).  It enables neighbour-chained ray starts; a mesh with
+ * overhangs must NOT set it -- results would be wrong for occluded beams. */
+#define MCL_MESH_HEIGHTFIELD 1u
+int mcl_set_map_mesh_ex(mcl_handle* h, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt,
+                        uint32_t flags);
 /* ranges[b] <= 0 or NaN marks an invalid beam; beam b looks along (0, sin a_b, -cos a_b) in the
  * sensor frame; sensor_offset = x,y,z,roll,pitch,yaw of the sensor in base_link (NULL = zeros). */
 int mcl_update_mbes(mcl_handle* h, const float* ranges, const float* beam_angles, int32_t n_beams,

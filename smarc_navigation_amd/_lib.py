@@ -49,6 +49,7 @@ SYMBOLS = {
     'mcl_update_gps': (C.c_int, [_vp, _d, _d]),
     'mcl_set_map_grid': (C.c_int, [_vp, _vp, _i32, _i32, _d, _d, _d]),
     'mcl_set_map_mesh': (C.c_int, [_vp, _vp, _i64, _vp, _i64]),
+    'mcl_set_map_mesh_ex': (C.c_int, [_vp, _vp, _i64, _vp, _i64, C.c_uint32]),
     'mcl_update_mbes': (C.c_int, [_vp, _vp, _vp, _i32, _d, _d, _vp]),
     'mcl_mbes_expected': (C.c_int, [_vp, _i64, _i64, _vp, _i32, _d, _vp, _vp]),
     'mcl_set_landmarks': (C.c_int, [_vp, _vp, _i64]),

@@ -78,6 +78,7 @@ struct mcl_handle {
   double* det_dev = nullptr;
   int det_cap = 0;
   int map_kind = -1;  // 0 grid, 1 mesh
+  bool mesh_heightfield = false;
   // bookkeeping
   int weight_mode = 0;
   bool have_lw = false, have_cdf = false, have_meancov = false;
@@ -734,6 +735,21 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   if (!h->pose_dev) HIPCHK(h, hipMalloc(&h->pose_dev, sizeof(MbesPose) * (size_t)h->n));
   a.pose = h->pose_dev;
   memset(&a.mesh, 0, sizeof a.mesh);
+  a.stats = nullptr;
+#ifdef MBES_STATS
+  {
+    static unsigned long long* g_stats = nullptr;
+    if (!g_stats) {
+      hipMalloc(&g_stats, 32);
+      hipMemset(g_stats, 0, 32);
+    }
+    unsigned long long hs[4];
+    hipMemcpy(hs, g_stats, 32, hipMemcpyDeviceToHost);
+    if (hs[2]) fprintf(stderr, "[mbes stats] rays %llu steps/ray %.2f tests/ray %.2f retries/ray %.4f\n", hs[2], (double)hs[0] / hs[2], (double)hs[1] / hs[2], (double)hs[3] / hs[2]);
+    hipMemset(g_stats, 0, 32);
+    a.stats = g_stats;
+  }
+#endif
   if (h->map_kind == 0) {
     a.grid = h->grid;
     a.nx = h->gnx;
@@ -744,6 +760,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.res = (float)h->gres;
     a.zmin_map = h->gzmin;
     a.zmax_map = h->gzmax;
+    a.chain = 1;  // a height grid is single-valued by construction
   } else {
     const MeshDev* m = h->mesh;
     a.mesh = mesh_args(m);
@@ -756,6 +773,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.res = (float)m->cs;
     a.zmin_map = m->zmin;
     a.zmax_map = m->zmax;
+    a.chain = h->mesh_heightfield ? 1 : 0;
   }
   const long long ngroups = (h->n + MBES_WAVES - 1) / MBES_WAVES;
   const int grid = (int)(ngroups < 4096 ? ngroups : 4096);
@@ -1027,6 +1045,11 @@ int mcl_set_map_grid(mcl_handle* h, const float* z, int32_t nx, int32_t ny, doub
 }
 
 int mcl_set_map_mesh(mcl_handle* h, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt) {
+  return mcl_set_map_mesh_ex(h, verts, nv, tris, nt, 0u);
+}
+
+int mcl_set_map_mesh_ex(mcl_handle* h, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt,
+                        uint32_t flags) {
   if (!h || !verts || !tris || nv < 3 || nt < 1) return fail(h, MCL_ERR_INVALID, "set_map_mesh: bad argument");
   RET_IF(set_device(h));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1039,6 +1062,12 @@ int mcl_set_map_mesh(mcl_handle* h, const float* verts, int64_t nv, const uint32
     return rc;
   }
   h->map_kind = 1;
+  h->mesh_heightfield = (flags & MCL_MESH_HEIGHTFIELD) != 0;
+  if (h->mesh_heightfield && h->mesh->n_vertical > 0) {
+    h->err = "set_map_mesh: MCL_MESH_HEIGHTFIELD declared but the mesh has vertical faces";
+    h->mesh_heightfield = false;
+    return MCL_ERR_INVALID;
+  }
   return MCL_OK;
 }
 

@@ -66,8 +66,18 @@ struct MbesArgs {
   float* exp_out;         // out (EXPECT_ONLY): expected ranges [(i-exp_first)*B + b]
   long long exp_first, exp_count;
   MeshArgs mesh;
+  unsigned long long* stats;  // MBES_STATS builds: steps, exact tests, rays, retries
+  int chain;              // 1: map declared a height field (single-valued z(x,y)); reserved for profile marching
 };
 
+#ifdef MBES_STATS
+#define STAT_INC(v) (++(v))
+#else
+#define STAT_INC(v) ((void)0)
+#endif
+struct RayStats {
+  int steps, tests, rays, retries;
+};
 __device__ __forceinline__ float uniform_f32(float x) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 }
@@ -192,7 +202,9 @@ __device__ __forceinline__ float cell_triangles_hit(const MeshArgs& ma, int gix,
 template <int MAP, bool LDS>
 __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th, const MbesArgs& a, int tx0, int ty0,
                                           int cw, int ch, float u0, float v0, float oz, float du, float dv, float dx,
-                                          float dy, float dz, float t_lo, float r_max) {
+                                          float dy, float dz, float t_lo, float r_max, bool& entry_below, RayStats& rs) {
+  entry_below = false;
+  STAT_INC(rs.rays);
   float t0 = t_lo, t1 = r_max;
   const float inv_du = du != 0.f ? fast_rcp(du) : 0.f, inv_dv = dv != 0.f ? fast_rcp(dv) : 0.f;
   // clip to the window [0,cw] x [0,ch]
@@ -223,7 +235,9 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
   float tny = dv != 0.f ? ((float)(iy + (dv > 0.f ? 1 : 0)) - v0) * inv_dv : INF;
   float t_in = t0;
   float z_in = oz + t0 * dz;
-  bool first = (MAP == 0);
+  // the entry point only needs the below-the-seabed check when the march does not start above the
+  // tile's highest node (slab start => ray_z(t0) > every height in the window)
+  bool first = (MAP == 0) && !(t_lo > 0.f && t0 <= t_lo);
   float result = r_max;
   int guard = cw + ch + 4;
   for (;;) {
@@ -233,6 +247,7 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
     float h00 = 0.f, h10 = 0.f, h01 = 0.f, h11 = 0.f;
     while (guard > 0) {
       --guard;
+      STAT_INC(rs.steps);
       t_out = fminf(fminf(tnx, tny), t1);
       z_out = oz + t_out * dz;
       const float zlo = fminf(z_in, z_out);
@@ -253,6 +268,10 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
       const bool stepx = tnx <= tny;
       ix += stepx ? sx : 0;
       iy += stepx ? 0 : sy;
+      if ((unsigned)ix >= (unsigned)cw || (unsigned)iy >= (unsigned)ch) {  // fp32 slop at the window edge
+        guard = 0;
+        break;
+      }
       tnx += stepx ? dtx : 0.f;
       tny += stepx ? 0.f : dty;
       t_in = t_out;
@@ -260,9 +279,11 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
     }
     if (!cand) break;
     // ---- phase 2: exact test in the candidate cell (lanes reconverge here)
+    STAT_INC(rs.tests);
     if (MAP == 0) {
       float t_hit;
       if (patch_hit(h00, h10, h01, h11, u0 - (float)ix, v0 - (float)iy, oz, du, dv, dz, t_in, t_out, first, t_hit)) {
+        entry_below = first && t_hit <= t_in;
         result = fminf(t_hit, r_max);
         break;
       }
@@ -279,6 +300,7 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
     const bool stepx = tnx <= tny;
     ix += stepx ? sx : 0;
     iy += stepx ? 0 : sy;
+    if ((unsigned)ix >= (unsigned)cw || (unsigned)iy >= (unsigned)ch) break;
     tnx += stepx ? dtx : 0.f;
     tny += stepx ? 0.f : dty;
     t_in = t_out;
@@ -411,6 +433,8 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
     int nvalid = 0;
     const float u0 = use == 1 ? (float)(P.um - (double)tx0) : (float)P.um;
     const float v0 = use == 1 ? (float)(P.vm - (double)ty0) : (float)P.vm;
+    // lanes = consecutive beams (coherent: neighbouring lanes walk neighbouring cells)
+    RayStats rs = {0, 0, 0, 0};
     for (int b = lane; b < a.n_beams; b += 64) {
       const float2 sc = a.beam_sc[b];
       const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
@@ -419,16 +443,17 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
       float t_lo = 0.f;  // skip the water column above the tile's highest point
       if (dz < 0.f && P.oz > zmax) t_lo = fmaxf((zmax - P.oz) * fast_rcp(dz) - 1e-3f, 0.f);
       float e;
+      bool below;
       if (use == 1) {
         e = cast_ray<MAP, true>(tile, th, a, tx0, ty0, MAP == 0 ? tw - 1 : tw, MAP == 0 ? th - 1 : th, u0, v0, P.oz,
-                                dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max);
+                                dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
       } else if (use == 0) {
         if (MAP == 0)
           e = cast_ray<MAP, false>(a.grid, a.ny, a, 0, 0, a.nx - 1, a.ny - 1, u0, v0, P.oz, dx * inv_res, dy * inv_res,
-                                   dx, dy, dz, t_lo, a.r_max);
+                                   dx, dy, dz, t_lo, a.r_max, below, rs);
         else
           e = cast_ray<MAP, false>(a.mesh.cell_z, a.mesh.gy, a, 0, 0, a.mesh.gx, a.mesh.gy, u0, v0, P.oz,
-                                   dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max);
+                                   dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
       } else {
         e = a.r_max;
       }
@@ -444,6 +469,17 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
         }
       }
     }
+#ifdef MBES_STATS
+    if (a.stats) {
+      const int s0 = wave_sum(rs.steps), s1 = wave_sum(rs.tests), s2 = wave_sum(rs.rays), s3 = wave_sum(rs.retries);
+      if (lane == 0) {
+        atomicAdd(&a.stats[0], (unsigned long long)s0);
+        atomicAdd(&a.stats[1], (unsigned long long)s1);
+        atomicAdd(&a.stats[2], (unsigned long long)s2);
+        atomicAdd(&a.stats[3], (unsigned long long)s3);
+      }
+    }
+#endif
     if (!EXPECT_ONLY) {
       const double accd = wave_sum((double)acc);
       const int nv = wave_sum(nvalid);

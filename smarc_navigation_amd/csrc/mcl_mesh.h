@@ -25,6 +25,7 @@ struct MeshDev {
   double x0 = 0, y0 = 0, cs = 1;
   float zmin = 0, zmax = 0;
   size_t n_records = 0;
+  size_t n_vertical = 0;  // triangles whose xy projection is degenerate (cannot be a height field)
 };
 
 inline void mesh_free(MeshDev* m) {
@@ -112,6 +113,13 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
     const float* v1 = verts + 3 * (size_t)tris[3 * k + 1];
     const float* v2 = verts + 3 * (size_t)tris[3 * k + 2];
     const float tz0 = std::min(v0[2], std::min(v1[2], v2[2])), tz1 = std::max(v0[2], std::max(v1[2], v2[2]));
+    {
+      const double ax = (double)v1[0] - v0[0], ay = (double)v1[1] - v0[1], bx = (double)v2[0] - v0[0],
+                   by = (double)v2[1] - v0[1];
+      const double area2 = std::fabs(ax * by - ay * bx);
+      const double len2 = std::max(ax * ax + ay * ay, bx * bx + by * by);
+      if (area2 <= 1e-9 * len2 && (tz1 - tz0) > 1e-6) m->n_vertical++;
+    }
     for (int a = a0; a <= a1; ++a)
       for (int b = b0; b <= b1; ++b) {
         const size_t c = (size_t)a * m->gy + b;

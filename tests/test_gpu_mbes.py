@@ -160,15 +160,16 @@ def _mesh_scene(n, nx=136, ny=128, seed=8):
     return z, origin, verts, tris, soa
 
 
-@pytest.mark.parametrize('n,B', [(48, 256), (5, 33)])
-def test_mesh_expected_ranges_and_logweights_vs_oracle(n, B, eng, orc):
+@pytest.mark.parametrize('hf', [False, True])
+@pytest.mark.parametrize('n,B', [(48, 256), (5, 33), (9, 512)])
+def test_mesh_expected_ranges_and_logweights_vs_oracle(n, B, hf, eng, orc):
     z, origin, verts, tris, soa = _mesh_scene(n)
     m2o = synth.rigid_matrix(0.5, 0.25, 0.0, 0.0, 0.0, -0.1)
     ba = synth.beam_angles(B)
     off = [0.2, 0.0, -0.1, 0.0, 0.02, 0.0]
     e = eng.Engine(n, m2o=m2o, rng_mode=eng.RNG_REPLAY)
     e.set_particles(soa)
-    e.set_map_mesh(verts, tris)
+    e.set_map_mesh(verts, tris, heightfield=hf)  # hf: neighbour-chained ray starts
     mesh = orc.Mesh(verts, tris)
     got = e.mbes_expected(0, n, ba, 80.0, off)
     _, ref = orc.mbes_update(soa, m2o, off, mesh, ba, None, 0.2, 80.0)
@@ -243,3 +244,45 @@ def test_mesh_filter_step_runs_and_matches_grid_map(eng):
         means.append(e.mean_cov()[0])
     assert np.hypot(means[0][0] - 0.4, means[0][1] + 0.3) < 0.2
     assert np.hypot(means[0][0] - means[1][0], means[0][1] - means[1][1]) < 0.1
+
+
+def test_heightfield_flag_rejects_vertical_faces(eng):
+    verts = np.array([[0, 0, -10], [10, 0, -10], [0, 10, -10], [0, 0, -20]], np.float32)
+    tris = np.array([[0, 1, 2], [0, 1, 3]], np.uint32)  # second triangle is vertical
+    e = eng.Engine(4)
+    with pytest.raises(eng.MclError):
+        e.set_map_mesh(verts, tris, heightfield=True)
+    e.set_map_mesh(verts, tris)  # fine as a general soup
+
+
+def test_chained_starts_on_rough_terrain_and_steep_rolls(eng, orc):
+    """Stress the neighbour-chained starts: rough bottom, big roll/pitch, unsorted and duplicated
+    beam angles -- results must still equal the per-ray oracle."""
+    nx = ny = 200
+    origin = (-100.0, -100.0)
+    rs = np.random.RandomState(9)
+    z = (synth.bathymetry_grid(nx, ny, 1.0, origin, seed=9, swell=4.0, fbm_amp=2.5)).astype(np.float32)
+    n = 40
+    soa = rs.randn(6, n) * np.array([4.0, 4.0, 0.5, 0.25, 0.25, 3.0])[:, None]
+    soa[2] -= 3.0
+    for ba in (synth.beam_angles(256, 1.2), synth.beam_angles(256, 1.2)[::-1].copy(),
+               np.sort(rs.uniform(-1.1, 1.1, 200)).astype(np.float32),
+               rs.uniform(-1.1, 1.1, 130).astype(np.float32),
+               np.repeat(synth.beam_angles(64, 1.0), 3)):
+        e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+        e.set_particles(soa)
+        e.set_map_grid(z, origin, 1.0)
+        got = e.mbes_expected(0, n, ba, 120.0)
+        _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, orc.Grid(z, origin, 1.0), ba, None, 0.2, 120.0)
+        err = np.abs(got - ref)
+        # grazing rays over rough terrain can flip hit/miss under fp32: allow a handful, report them
+        bad = err > 2e-3
+        print('rough terrain: %d/%d rays off by > 2e-3 m (max %.3e)' % (bad.sum(), err.size, err.max()))
+        assert bad.mean() < 2e-3
+        verts, tris = synth.mesh_from_grid(z, 1.0, origin)
+        e.set_map_mesh(verts, tris, heightfield=True)
+        gotm = e.mbes_expected(0, n, ba, 120.0)
+        _, refm = orc.mbes_update(soa, np.identity(4), [0] * 6, orc.Mesh(verts, tris), ba, None, 0.2, 120.0)
+        badm = np.abs(gotm - refm) > 2e-3
+        print('rough mesh   : %d/%d rays off by > 2e-3 m' % (badm.sum(), badm.size))
+        assert badm.mean() < 2e-3
