@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -88,6 +89,12 @@ struct mcl_handle {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   mcl_timing tacc;
   ncclComm_t comm = nullptr;
+  // overlap of the pre-resample state all-gather with the measurement update (second communicator,
+  // second stream); falls back to an in-line gather when the split is unavailable
+  ncclComm_t comm2 = nullptr;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_state_ready = nullptr, ev_gather_done = nullptr;
+  bool gather_inflight = false;
   std::string err;
 };
 
@@ -356,12 +363,19 @@ int exchange_cdf_state(mcl_handle** sh, int ns) {
     mcl_handle* h = sh[0];
     if (h->comm) {
       t_begin(h, MCL_K_COMM);
-      NCCLCHK(h, ncclGroupStart());
-      NCCLCHK(h, ncclAllGather(h->ncum + h->goff, h->ncum, (size_t)h->n, ncclUint32, h->comm, h->stream));
-      for (int c = 0; c < 6; ++c)
-        NCCLCHK(h, ncclAllGather(h->state[h->cur] + (size_t)c * h->n, h->state_glob + (size_t)c * h->ng,
-                                 (size_t)h->n, ncclDouble, h->comm, h->stream));
-      NCCLCHK(h, ncclGroupEnd());
+      if (h->gather_inflight) {
+        // the state went out right after predict and travelled under the measurement update
+        NCCLCHK(h, ncclAllGather(h->ncum + h->goff, h->ncum, (size_t)h->n, ncclUint32, h->comm, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather_done, 0));
+        h->gather_inflight = false;
+      } else {
+        NCCLCHK(h, ncclGroupStart());
+        NCCLCHK(h, ncclAllGather(h->ncum + h->goff, h->ncum, (size_t)h->n, ncclUint32, h->comm, h->stream));
+        for (int c = 0; c < 6; ++c)
+          NCCLCHK(h, ncclAllGather(h->state[h->cur] + (size_t)c * h->n, h->state_glob + (size_t)c * h->ng,
+                                   (size_t)h->n, ncclDouble, h->comm, h->stream));
+        NCCLCHK(h, ncclGroupEnd());
+      }
       t_end(h);
     }
     return MCL_OK;
@@ -384,6 +398,22 @@ int exchange_cdf_state(mcl_handle** sh, int ns) {
   return MCL_OK;
 }
 
+// The pre-resample state is final once predict has run (updates only read it): send it on the
+// second communicator/stream so the 48 B x N_global all-gather overlaps the ray-cast.
+int start_state_gather(mcl_handle* h) {
+  if (!h->comm2 || !h->state_glob) return MCL_OK;
+  HIPCHK(h, hipEventRecord(h->ev_state_ready, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_state_ready, 0));
+  NCCLCHK(h, ncclGroupStart());
+  for (int c = 0; c < 6; ++c)
+    NCCLCHK(h, ncclAllGather(h->state[h->cur] + (size_t)c * h->n, h->state_glob + (size_t)c * h->ng, (size_t)h->n,
+                             ncclDouble, h->comm2, h->comm_stream));
+  NCCLCHK(h, ncclGroupEnd());
+  HIPCHK(h, hipEventRecord(h->ev_gather_done, h->comm_stream));
+  h->gather_inflight = true;
+  return MCL_OK;
+}
+
 int phase_reassign(mcl_handle* h, const double* replay_normals) {
   RET_IF(set_device(h));
   if (replay_normals) RET_IF(upload_replay(h, replay_normals));
@@ -392,7 +422,7 @@ int phase_reassign(mcl_handle* h, const double* replay_normals) {
   k_scan_tile_sums<u32><<<1, 1024, 0, h->stream>>>(h->tile32, h->ntiles_glob, h->tile32 + h->ntiles_glob);
   k_zero_scan<<<grid_tiles(h->ntiles_glob), MCL_BLOCK, 0, h->stream>>>(h->ncum, h->ng, h->tile32, h->zcum);
   ReassignArgs a;
-  const bool multi = h->world > 1;
+  const bool multi = h->world > 1 || (h->comm && h->state_glob);
   a.src = multi ? state_ptrs(h->state_glob, h->ng) : state_ptrs(h->state[h->cur], h->n);
   a.dst = state_ptrs(h->state[h->cur ^ 1], h->n);
   a.n = h->n;
@@ -953,7 +983,11 @@ int mcl_destroy(mcl_handle* h) {
     hipEventDestroy(e.first);
     hipEventDestroy(e.second);
   }
+  if (h->comm2) ncclCommDestroy(h->comm2);
   if (h->comm) ncclCommDestroy(h->comm);
+  if (h->comm_stream) hipStreamDestroy(h->comm_stream);
+  if (h->ev_state_ready) hipEventDestroy(h->ev_state_ready);
+  if (h->ev_gather_done) hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
                   h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->cq, h->u53, h->cnt, h->first,
@@ -1328,6 +1362,7 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
   if (h->world > 1 && !h->comm) return fail(h, MCL_ERR_STATE, "step_mbes: multi-shard handle needs mcl_comm_init");
   RET_IF(set_device(h));
   RET_IF(do_predict(h, odom, dt, nullptr));
+  RET_IF(start_state_gather(h));
   RET_IF(upload_beams(h, ranges, beam_angles, B));
   RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0));
   h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
@@ -1401,11 +1436,23 @@ int mcl_comm_unique_id(char id[128]) {
 
 int mcl_comm_init(mcl_handle* h, const char id[128]) {
   if (!h || !id) return MCL_ERR_INVALID;
-  if (h->world < 2) return MCL_OK;
+  const char* force = getenv("MCL_FORCE_COMM");  // test hook: exercise the RCCL paths with one rank
+  if (h->world < 2 && !(force && force[0] == '1')) return MCL_OK;
   RET_IF(set_device(h));
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof uid);
   NCCLCHK(h, ncclCommInitRank(&h->comm, h->world, uid, h->rank));
+  if (!h->state_glob) HIPCHK(h, hipMalloc(&h->state_glob, sizeof(double) * 6 * (size_t)h->ng));
+  // second communicator + stream for the overlapped state all-gather; optional
+  const char* no_overlap = getenv("MCL_NO_OVERLAP");
+  if (!(no_overlap && no_overlap[0] == '1') && ncclCommSplit(h->comm, 0, h->rank, &h->comm2, nullptr) == ncclSuccess &&
+      h->comm2) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_state_ready, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_gather_done, hipEventDisableTiming));
+  } else {
+    h->comm2 = nullptr;
+  }
   return MCL_OK;
 }
 

@@ -310,6 +310,38 @@ def test_sharded_equals_unsharded_bitwise(shards, eng):
     np.testing.assert_allclose(m1[2], m2[2], rtol=1e-11, atol=1e-13)
 
 
+def test_rccl_paths_with_one_rank_match_plain_filter(eng, monkeypatch):
+    """MCL_FORCE_COMM=1 builds a 1-rank RCCL communicator: all-reduce / all-gather calls, the second
+    communicator and the overlapped state all-gather of mcl_step_mbes run for real, and must not
+    change a single bit of the result."""
+    from smarc_navigation_amd import synth
+    from oracle import oracle as orc
+    n, B = 16384, 64
+    origin = (-64.0, -64.0)
+    z = synth.bathymetry_grid(128, 128, 1.0, origin, seed=3)
+    ba = synth.beam_angles(B)
+    cov = dict(init_cov=[1, 1, 0, 0, 0, 0.01], process_cov=[1e-3, 1e-3, 0, 0, 0, 1e-5],
+               resample_cov=[0.01, 0.01, 0, 0, 0, 1e-4], seed=21)
+    q = orc.quat_from_euler(0.0, 0.0, 0.1)
+    ranges = np.full(B, 21.0, np.float32)
+    results = []
+    for force, no_overlap in (('0', '0'), ('1', '0'), ('1', '1')):
+        monkeypatch.setenv('MCL_FORCE_COMM', force)
+        monkeypatch.setenv('MCL_NO_OVERLAP', no_overlap)
+        e = eng.Engine(n, **cov)
+        e.comm_init(eng.comm_unique_id())
+        e.set_map_grid(z, origin, 1.0)
+        e.init_particles()
+        for k in range(4):
+            e.step_mbes([1.0, 0.0, 0.0], 0.02, q, -2.0, 0.02, ranges, ba, 0.5, 80.0)
+        e.sync()
+        results.append((e.get_particles(), e.last_mean_cov()[0]))
+        e.close()
+    for st, mean in results[1:]:
+        assert np.array_equal(st, results[0][0])
+        np.testing.assert_allclose(mean, results[0][1], rtol=1e-13, atol=1e-13)
+
+
 def test_rccl_single_rank_world1_smoke(eng):
     """The RCCL entry points work (world == 1 is a no-op communicator)."""
     uid = eng.comm_unique_id()
