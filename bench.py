@@ -192,6 +192,15 @@ def main():
                 entry.update(alg_bytes_per_step=alg[name], achieved_gbs=round(gbs, 2),
                              hbm_frac=round(gbs / HBM_PEAK_GBS, 5))
             kernels[name] = entry
+        # PMC-measured HBM traffic of the dominant kernel (offline rocprofv3 passes, profiles/r01_traffic.json)
+        traffic, pmc = None, {}
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
+                pmc = json.load(f).get(m['kind'], {})
+            if P == 1048576 and B == 512 and world == 1:
+                traffic = pmc.get('traffic_bytes_per_launch')
+        except (IOError, ValueError):
+            pass
         dom = max((k for k in kernels if k in alg), key=lambda k: tim[k][0])
         dom_ms = tim[dom][0] / a.steps
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
@@ -204,9 +213,13 @@ def main():
                                    'resample+mean/cov per step' % (P, B, m['desc']),
                        'particles_per_gpu': P, 'beams': B, 'map': m['kind'], 'parallelism': 'particle-shard x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': None,
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic,
                          'rays_per_s': round(P * B / (dom_ms * 1e-3), 1),
-                         'note': 'ray-cast is VALU/LDS-bound, not HBM-bound (SURVEY 8d); streaming kernels in "kernels"'},
+                         'valu_issue_frac': (round(pmc['valu_insts_per_launch'] * 4.0 / (dom_ms * 1e-3 * 2.4e9 * 1024), 3)
+                                             if pmc.get('valu_insts_per_launch') and traffic else None),
+                         'note': 'the ray-cast is VALU-issue-bound, not HBM-bound (SURVEY 8d): valu_issue_frac = PMC '
+                                 'SQ_INSTS_VALU x 4 cycles / (kernel time x 1024 SIMDs x 2.4 GHz); streaming kernels '
+                                 'are listed in "kernels" with their own HBM fractions'},
             'kernels': kernels,
             'pose_error_m': round(pose_err, 4),
         }
