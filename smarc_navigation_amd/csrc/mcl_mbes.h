@@ -14,6 +14,8 @@
 // Bound: VALU issue + LDS reads (rocprof: VALU pipe ~87 % busy); compulsory HBM traffic is only
 // 48 B + 8 B per particle plus the map tile reads (L2-resident).
 #pragma once
+#include <hip/hip_fp16.h>
+
 #include "mcl_device.h"
 
 #ifndef MBES_WAVES
@@ -38,9 +40,10 @@ struct MbesPose {   // 48 B
 };
 
 struct MeshArgs {
-  const float4* tri;       // 3 float4 per (cell, triangle) record: v0 - cell corner, e1, e2
+  const float4* tri;       // 3 float4 per (cell, triangle) record, plane form (mcl_mesh.h)
+  const float4* tri_mt;    // Moller-Trumbore records for near-vertical triangles (or nullptr)
   const u32* cell_start;   // gx*gy + 1
-  const float2* cell_z;    // (zmin, zmax) per cell
+  const uint2* cell_info;  // x = half2(zmin, zmax) conservative, y = start | count << 27
   int gx, gy;
   float cs;
 };
@@ -171,28 +174,49 @@ __device__ __forceinline__ bool patch_hit(float h00, float h10, float h01, float
   return true;
 }
 
-// nearest hit of the ray with the triangles binned in global cell (gix, giy); ray origin given
-// relative to that cell's corner (metres).  Accepts t in [0, t_hi].
-__device__ __forceinline__ float cell_triangles_hit(const MeshArgs& ma, int gix, int giy, float olx, float oly,
-                                                    float olz, float dx, float dy, float dz, float t_hi) {
-  const size_t c = (size_t)gix * ma.gy + giy;
-  const u32 s = ma.cell_start[c], e = ma.cell_start[c + 1];
+// nearest hit of the ray with the records [s, e) of one cell; ray origin relative to that cell's
+// corner (metres).  Accepts t in [0, t_hi].  Plane-form records: t from the plane equation, then
+// the barycentrics of the hit point in the xy projection (~26 VALU per triangle); near-vertical
+// triangles (flag) fall back to Moller-Trumbore on the second record array.
+__device__ __forceinline__ float records_hit(const MeshArgs& ma, u32 s, u32 e, float olx, float oly, float olz,
+                                             float dx, float dy, float dz, float t_hi) {
   float best = __builtin_inff();
   const float EPS = 2e-5f;
   for (u32 k = s; k < e; ++k) {
-    const float4 v0 = ma.tri[3 * (size_t)k], e1 = ma.tri[3 * (size_t)k + 1], e2 = ma.tri[3 * (size_t)k + 2];
-    const float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x;
-    const float det = e1.x * px + e1.y * py + e1.z * pz;
-    if (fabsf(det) < 1e-20f) continue;
-    const float inv = fast_rcp(det);
-    const float sx = olx - v0.x, sy = oly - v0.y, sz = olz - v0.z;
-    const float u = (sx * px + sy * py + sz * pz) * inv;
-    const float qx = sy * e1.z - sz * e1.y, qy = sz * e1.x - sx * e1.z, qz = sx * e1.y - sy * e1.x;
-    const float v = (dx * qx + dy * qy + dz * qz) * inv;
-    const float t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv;
+    const float4 r0 = ma.tri[3 * (size_t)k], r1 = ma.tri[3 * (size_t)k + 1];
+    const float2 r2 = *(const float2*)&ma.tri[3 * (size_t)k + 2];
+    float t, u, v;
+    if (r0.w == 0.f) {
+      const float den = fmaf(r0.x, dx, fmaf(r0.y, dy, dz));
+      t = (r0.z - fmaf(r0.x, olx, fmaf(r0.y, oly, olz))) * fast_rcp(den);
+      const float hx = fmaf(t, dx, olx) - r1.x, hy = fmaf(t, dy, oly) - r1.y;
+      u = fmaf(r1.z, hx, r1.w * hy);
+      v = fmaf(r2.x, hx, r2.y * hy);
+    } else {
+      const float4 v0 = ma.tri_mt[3 * (size_t)k], e1 = ma.tri_mt[3 * (size_t)k + 1], e2 = ma.tri_mt[3 * (size_t)k + 2];
+      const float px = dy * e2.z - dz * e2.y, py = dz * e2.x - dx * e2.z, pz = dx * e2.y - dy * e2.x;
+      const float det = e1.x * px + e1.y * py + e1.z * pz;
+      if (fabsf(det) < 1e-20f) continue;
+      const float inv = fast_rcp(det);
+      const float sx = olx - v0.x, sy = oly - v0.y, sz = olz - v0.z;
+      u = (sx * px + sy * py + sz * pz) * inv;
+      const float qx = sy * e1.z - sz * e1.y, qy = sz * e1.x - sx * e1.z, qz = sx * e1.y - sy * e1.x;
+      v = (dx * qx + dy * qy + dz * qz) * inv;
+      t = (e2.x * qx + e2.y * qy + e2.z * qz) * inv;
+    }
     if (u >= -EPS && v >= -EPS && u + v <= 1.f + EPS && t >= 0.f && t <= t_hi && t < best) best = t;
   }
   return best;
+}
+__device__ __forceinline__ float cell_triangles_hit(const MeshArgs& ma, int gix, int giy, float olx, float oly,
+                                                    float olz, float dx, float dy, float dz, float t_hi) {
+  const size_t c = (size_t)gix * ma.gy + giy;
+  return records_hit(ma, ma.cell_start[c], ma.cell_start[c + 1], olx, oly, olz, dx, dy, dz, t_hi);
+}
+// unpack a cell_info word pair
+__device__ __forceinline__ void cell_zrange(u32 hz, float& zlo, float& zhi) {
+  zlo = __half2float(__ushort_as_half((unsigned short)(hz & 0xffffu)));
+  zhi = __half2float(__ushort_as_half((unsigned short)(hz >> 16)));
 }
 
 // ------------------------------------------------------------------ the ray traversal
@@ -260,8 +284,10 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
         h11 = p[th + 1];
         cand = first || zlo <= fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
       } else {
-        const float2 zr = LDS ? ((const float2*)tile)[ix * th + iy] : ((const float2*)tile)[(size_t)ix * th + iy];
-        cand = zlo <= zr.y + 1e-4f && fmaxf(z_in, z_out) >= zr.x - 1e-4f;
+        const uint2 ci = LDS ? ((const uint2*)tile)[ix * th + iy] : ((const uint2*)tile)[(size_t)ix * th + iy];
+        float czlo, czhi;
+        cell_zrange(ci.x, czlo, czhi);
+        cand = zlo <= czhi + 1e-4f && fmaxf(z_in, z_out) >= czlo - 1e-4f;
       }
       if (cand) break;
       if (t_out >= t1) break;
@@ -307,6 +333,120 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
     z_in = z_out;
   }
   return result;
+}
+
+// ------------------------------------------------------------------ fast traversal (LDS tile)
+// Preconditions (checked per wave by the caller): the tile was not clipped by the map border, and
+// the sensor origin lies inside it with a cell of margin.  The footprint construction then
+// guarantees the ray stays inside the tile until it is below every node (t1), so no window
+// clipping and no per-step bounds tests are needed.  ~35 VALU of set-up, ~16 per cell, ~45 per
+// exact patch test (both roots of the patch quadratic at once: crossing and grazing cases).
+template <int MAP>
+__device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int th, int tw, const MbesArgs& a, int tx0,
+                                           int ty0, float u0, float v0, float oz, float du, float dv, float dz,
+                                           float zmax, float r_max, RayStats& rs) {
+  STAT_INC(rs.rays);
+  const float INF = __builtin_inff();
+  const float rdz = fast_rcp(dz);
+  float t_lo = 0.f, t1 = r_max;
+  if (dz < 0.f) {
+    if (oz > zmax) t_lo = fmaxf((zmax - oz) * rdz - 1e-3f, 0.f);  // skip the water column above the tile
+    t1 = fminf(r_max, (a.zmin_map - oz) * rdz + 1e-2f);           // below every node beyond this
+  }
+  const float pu = fmaf(t_lo, du, u0), pv = fmaf(t_lo, dv, v0);
+  const float fu = floorf(pu), fv = floorf(pv);
+  int ix = (int)fu, iy = (int)fv;
+  const float adu = fabsf(fast_rcp(du)), adv = fabsf(fast_rcp(dv));  // +inf for an axis-parallel ray
+  // distance to the next cell border along each axis; 0 * inf = NaN is ignored by min / fails <=
+  float tnx = fmaf(du > 0.f ? (fu + 1.f) - pu : pu - fu, adu, t_lo);
+  float tny = fmaf(dv > 0.f ? (fv + 1.f) - pv : pv - fv, adv, t_lo);
+  const int sx = du > 0.f ? 1 : -1, sy = dv > 0.f ? 1 : -1;
+  const int dax = sx * th;
+  int addr = ix * th + iy;
+  float t_in = t_lo, z_in = fmaf(t_lo, dz, oz);
+  bool first = !(t_lo > 0.f);  // only a march that starts at the sensor can begin under the seabed
+  for (int guard = 0; guard < 4096; ++guard) {
+    float t_out, z_out;
+    bool cand;
+    float h00 = 0.f, h10 = 0.f, h01 = 0.f, h11 = 0.f;
+    uint2 ci = make_uint2(0u, 0u);
+    // ---- phase 1: cells whose LDS bound the ray does not reach are skipped
+    for (;;) {
+      STAT_INC(rs.steps);
+      t_out = fminf(fminf(tnx, tny), t1);
+      z_out = fmaf(t_out, dz, oz);
+      const float zlo = fminf(z_in, z_out);
+      if (MAP == 0) {
+        const float* p = tile + addr;
+        h00 = p[0];
+        h01 = p[1];
+        h10 = p[th];
+        h11 = p[th + 1];
+        cand = zlo <= fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
+      } else {
+        ci = ((const uint2*)tile)[addr];
+        float czlo, czhi;
+        cell_zrange(ci.x, czlo, czhi);
+        cand = zlo <= czhi + 1e-4f && fmaxf(z_in, z_out) >= czlo - 1e-4f;
+      }
+      if (cand || t_out >= t1) break;
+      const bool stepx = tnx <= tny;
+      addr += stepx ? dax : sy;
+      ix += stepx ? sx : 0;
+      iy += stepx ? 0 : sy;
+      tnx += stepx ? adu : 0.f;
+      tny += stepx ? 0.f : adv;
+      t_in = t_out;
+      z_in = z_out;
+    }
+    if (!cand) return r_max;
+    // ---- phase 2: exact test (lanes reconverge here)
+    STAT_INC(rs.tests);
+    if (MAP == 0) {
+      const float uc = u0 - (float)ix, vc = v0 - (float)iy;
+      const float B = h10 - h00, C = h01 - h00, D = (h00 - h10) - (h01 - h11);
+      const float c0 = oz - (h00 + B * uc + C * vc + D * uc * vc);
+      const float c1 = dz - (B * du + C * dv + D * (uc * dv + vc * du));
+      const float c2 = -D * du * dv;
+      if (first) {
+        if (c0 + t_in * (c1 + t_in * c2) <= 0.f) return t_in;  // sensor at or below the seabed
+        first = false;
+      }
+      const float disc = fmaf(c1, c1, -4.f * c2 * c0);
+      if (disc >= 0.f) {
+        const float sq = fast_sqrt(disc);
+        const float qv = -0.5f * (c1 + (c1 >= 0.f ? sq : -sq));
+        const float r1 = c0 * fast_rcp(qv), r2 = qv * fast_rcp(c2);  // r2 = inf/NaN on a planar patch
+        const float lo = t_in - 1e-4f, hi = t_out + 1e-4f;
+        const float g1 = (r1 >= lo && r1 <= hi) ? r1 : INF, g2 = (r2 >= lo && r2 <= hi) ? r2 : INF;
+        const float root = fminf(g1, g2);
+        if (root < INF) return fminf(fminf(fmaxf(root, t_in), t_out), r_max);
+      }
+    } else {
+      first = false;
+      // the record range rides in the LDS tile word (start | count << 27): no dependent global load
+      const u32 rs0 = ci.y & 0x7ffffffu;
+      u32 cnt = ci.y >> 27;
+      if (cnt == 31u) {
+        if ((unsigned)ix >= (unsigned)tw || (unsigned)iy >= (unsigned)th) return r_max;
+        const size_t c = (size_t)(tx0 + ix) * a.mesh.gy + (ty0 + iy);
+        cnt = a.mesh.cell_start[c + 1] - a.mesh.cell_start[c];
+      }
+      const float t = records_hit(a.mesh, rs0, rs0 + cnt, (u0 - (float)ix) * a.mesh.cs, (v0 - (float)iy) * a.mesh.cs, oz,
+                                  du * a.res, dv * a.res, dz, t_out + 1e-4f);
+      if (t < INF) return fminf(t, r_max);
+    }
+    if (t_out >= t1) return r_max;
+    const bool stepx = tnx <= tny;
+    addr += stepx ? dax : sy;
+    ix += stepx ? sx : 0;
+    iy += stepx ? 0 : sy;
+    tnx += stepx ? adu : 0.f;
+    tny += stepx ? 0.f : adv;
+    t_in = t_out;
+    z_in = z_out;
+  }
+  return r_max;
 }
 
 // ------------------------------------------------------------------ the cast kernel
@@ -380,13 +520,16 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
       b0 = fminf(b0, __shfl_xor(b0, o, 64));
       b1 = fmaxf(b1, __shfl_xor(b1, o, 64));
     }
-    int tx0, ty0, tw, th, use;
+    int tx0, ty0, tw, th, use, clipped;
     {
       // grid: node range; mesh: cell range; clipped to the map, one cell of margin for fp32 slop
-      tx0 = max((int)floorf(a0) - 1, 0);
-      ty0 = max((int)floorf(b0) - 1, 0);
-      const int tx1 = min((int)floorf(a1) + (MAP == 0 ? 2 : 1), lim_x);
-      const int ty1 = min((int)floorf(b1) + (MAP == 0 ? 2 : 1), lim_y);
+      const int wx0 = (int)floorf(a0) - 1, wy0 = (int)floorf(b0) - 1;
+      const int wx1 = (int)floorf(a1) + (MAP == 0 ? 2 : 1), wy1 = (int)floorf(b1) + (MAP == 0 ? 2 : 1);
+      clipped = (wx0 < 0 || wy0 < 0 || wx1 > lim_x || wy1 > lim_y) ? 1 : 0;
+      tx0 = max(wx0, 0);
+      ty0 = max(wy0, 0);
+      const int tx1 = min(wx1, lim_x);
+      const int ty1 = min(wy1, lim_y);
       tw = tx1 - tx0 + 1;
       th = ty1 - ty0 + 1;
       const int need = MAP == 0 ? 2 : 1;
@@ -397,6 +540,7 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
       tw = __builtin_amdgcn_readfirstlane(tw);
       th = __builtin_amdgcn_readfirstlane(th);
       use = __builtin_amdgcn_readfirstlane(use);
+      clipped = __builtin_amdgcn_readfirstlane(clipped);
     }
     float zmax = a.zmax_map;
     if (use == 1) {
@@ -411,12 +555,14 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
           m = fmaxf(m, h);
         }
       } else {
-        float2* t2 = (float2*)tile;
+        uint2* t2 = (uint2*)tile;
         for (int k = threadIdx.x; k < cells; k += MBES_THREADS) {
           const int ix = k / th, iy = k - ix * th;
-          const float2 zr = a.mesh.cell_z[(size_t)(tx0 + ix) * a.mesh.gy + (ty0 + iy)];
-          t2[k] = zr;
-          m = fmaxf(m, zr.y);
+          const uint2 ci = a.mesh.cell_info[(size_t)(tx0 + ix) * a.mesh.gy + (ty0 + iy)];
+          t2[k] = ci;
+          float czlo, czhi;
+          cell_zrange(ci.x, czlo, czhi);
+          m = fmaxf(m, czhi);
         }
       }
       m = wave_max(m);
@@ -435,6 +581,8 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
     const float v0 = use == 1 ? (float)(P.vm - (double)ty0) : (float)P.vm;
     // lanes = consecutive beams (coherent: neighbouring lanes walk neighbouring cells)
     RayStats rs = {0, 0, 0, 0};
+    // wave-uniform choice: the fast traversal needs an unclipped tile and the sensor inside it
+    const bool fast = use == 1 && !clipped && u0 >= 1.f && v0 >= 1.f && u0 <= (float)(tw - 2) && v0 <= (float)(th - 2);
     for (int b = lane; b < a.n_beams; b += 64) {
       const float2 sc = a.beam_sc[b];
       const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
@@ -444,7 +592,9 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
       if (dz < 0.f && P.oz > zmax) t_lo = fmaxf((zmax - P.oz) * fast_rcp(dz) - 1e-3f, 0.f);
       float e;
       bool below;
-      if (use == 1) {
+      if (fast) {
+        e = cast_fast<MAP>(tile, th, tw, a, tx0, ty0, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max, rs);
+      } else if (use == 1) {
         e = cast_ray<MAP, true>(tile, th, a, tx0, ty0, MAP == 0 ? tw - 1 : tw, MAP == 0 ? th - 1 : th, u0, v0, P.oz,
                                 dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
       } else if (use == 0) {
@@ -452,7 +602,7 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
           e = cast_ray<MAP, false>(a.grid, a.ny, a, 0, 0, a.nx - 1, a.ny - 1, u0, v0, P.oz, dx * inv_res, dy * inv_res,
                                    dx, dy, dz, t_lo, a.r_max, below, rs);
         else
-          e = cast_ray<MAP, false>(a.mesh.cell_z, a.mesh.gy, a, 0, 0, a.mesh.gx, a.mesh.gy, u0, v0, P.oz,
+          e = cast_ray<MAP, false>(a.mesh.cell_info, a.mesh.gy, a, 0, 0, a.mesh.gx, a.mesh.gy, u0, v0, P.oz,
                                    dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
       } else {
         e = a.r_max;

@@ -11,6 +11,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -18,9 +19,10 @@
 #include "mcl_mbes.h"
 
 struct MeshDev {
-  float4* tri = nullptr;       // 3 float4 per (cell, triangle) record
+  float4* tri = nullptr;       // 3 float4 per (cell, triangle) record, plane form (see mesh_build)
+  float4* tri_mt = nullptr;    // Moller-Trumbore form (v0, e1, e2), only if some triangle is near-vertical
   u32* cell_start = nullptr;   // gx*gy + 1
-  float2* cell_z = nullptr;    // (zmin, zmax) per cell; empty = (+inf, -inf)
+  uint2* cell_info = nullptr;  // per cell: x = half2(zmin rounded down, zmax rounded up), y = start | count << 27
   int gx = 0, gy = 0;
   double x0 = 0, y0 = 0, cs = 1;
   float zmin = 0, zmax = 0;
@@ -32,8 +34,59 @@ inline void mesh_free(MeshDev* m) {
   if (!m) return;
   if (m->tri) (void)hipFree(m->tri);
   if (m->cell_start) (void)hipFree(m->cell_start);
-  if (m->cell_z) (void)hipFree(m->cell_z);
+  if (m->cell_info) (void)hipFree(m->cell_info);
+  if (m->tri_mt) (void)hipFree(m->tri_mt);
   delete m;
+}
+
+// float -> IEEE half bits with directed rounding (dir < 0: toward -inf, dir > 0: toward +inf)
+inline float half_bits_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+  uint32_t bits;
+  if (exp == 0) {
+    if (man == 0) {
+      bits = sign;
+    } else {  // subnormal
+      float f = (float)man * 5.9604644775390625e-08f;  // 2^-24
+      memcpy(&bits, &f, 4);
+      bits |= sign;
+    }
+  } else if (exp == 31) {
+    bits = sign | 0x7f800000u | (man << 13);
+  } else {
+    bits = sign | ((exp + 112u) << 23) | (man << 13);
+  }
+  float out;
+  memcpy(&out, &bits, 4);
+  return out;
+}
+inline uint16_t float_to_half_dir(float x, int dir) {
+  if (x != x) return 0x7e00u;
+  if (x > 65504.f) return dir > 0 ? 0x7c00u : 0x7bffu;    // +inf / max finite
+  if (x < -65504.f) return dir < 0 ? 0xfc00u : 0xfbffu;
+  // round to nearest first (via truncation of the magnitude), then fix the direction
+  uint32_t b;
+  memcpy(&b, &x, 4);
+  const uint32_t sign = (b >> 16) & 0x8000u;
+  const float ax = std::fabs(x);
+  uint16_t h;
+  if (ax < 6.103515625e-05f) {  // subnormal half range
+    h = (uint16_t)(ax * 16777216.0f);  // floor(ax / 2^-24)
+  } else {
+    uint32_t ab;
+    memcpy(&ab, &ax, 4);
+    const uint32_t exp = ((ab >> 23) & 0xffu) - 112u, man = (ab >> 13) & 0x3ffu;
+    h = (uint16_t)((exp << 10) | man);  // magnitude truncated toward zero
+  }
+  h |= (uint16_t)sign;
+  // h now is x rounded toward zero; step outward if the direction requires it
+  float back = half_bits_to_float(h);
+  if (dir > 0 && back < x) h = (h & 0x8000u) ? (uint16_t)(h - 1) : (uint16_t)(h + 1);
+  if (dir < 0 && back > x) h = (h & 0x8000u) ? (uint16_t)(h + 1) : (uint16_t)(h - 1);
+  if (dir > 0 && x > 0.f && back < x && (h & 0x7fffu) == 0x7c00u) h = 0x7c00u;
+  // crossing zero: rounding a tiny negative toward +inf gives -0 -> fine; tiny positive toward -inf gives +0
+  if (dir > 0 && x < 0.f && back < x && h == 0x7fffu) h = 0x8000u;
+  return h;
 }
 
 inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int64_t nt, MeshDev** out,
@@ -103,9 +156,25 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
     start[c + 1] += start[c];
   }
   m->n_records = start[nc];
-  std::vector<float4> rec(3 * std::max<size_t>(m->n_records, 1));
+  if (m->n_records >= (1ull << 27)) {
+    *err = "set_map_mesh: more than 2^27 (cell, triangle) records";
+    delete m;
+    return MCL_ERR_UNSUPPORTED;
+  }
+  std::vector<float4> rec(3 * std::max<size_t>(m->n_records, 1)), rec_mt;
   std::vector<float2> cz(nc, make_float2(INFINITY, -INFINITY));
   std::vector<u32> fill(nc, 0u);
+  bool any_vertical = false;
+  for (int64_t k = 0; k < nt && !any_vertical; ++k) {
+    const float* v0 = verts + 3 * (size_t)tris[3 * k];
+    const float* v1 = verts + 3 * (size_t)tris[3 * k + 1];
+    const float* v2 = verts + 3 * (size_t)tris[3 * k + 2];
+    const double ax = (double)v1[0] - v0[0], ay = (double)v1[1] - v0[1], az = (double)v1[2] - v0[2];
+    const double bx = (double)v2[0] - v0[0], by = (double)v2[1] - v0[1], bz = (double)v2[2] - v0[2];
+    const double nz = ax * by - ay * bx, nx = ay * bz - az * by, ny = az * bx - ax * bz;
+    if (std::fabs(nz) <= 1e-4 * std::sqrt(nx * nx + ny * ny + nz * nz)) any_vertical = true;
+  }
+  if (any_vertical) rec_mt.resize(rec.size());
   for (int64_t k = 0; k < nt; ++k) {
     int a0, a1, b0, b1;
     cell_range(k, a0, a1, b0, b1);
@@ -113,38 +182,60 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
     const float* v1 = verts + 3 * (size_t)tris[3 * k + 1];
     const float* v2 = verts + 3 * (size_t)tris[3 * k + 2];
     const float tz0 = std::min(v0[2], std::min(v1[2], v2[2])), tz1 = std::max(v0[2], std::max(v1[2], v2[2]));
-    {
-      const double ax = (double)v1[0] - v0[0], ay = (double)v1[1] - v0[1], bx = (double)v2[0] - v0[0],
-                   by = (double)v2[1] - v0[1];
-      const double area2 = std::fabs(ax * by - ay * bx);
-      const double len2 = std::max(ax * ax + ay * ay, bx * bx + by * by);
-      if (area2 <= 1e-9 * len2 && (tz1 - tz0) > 1e-6) m->n_vertical++;
-    }
+    const double ax = (double)v1[0] - v0[0], ay = (double)v1[1] - v0[1], az = (double)v1[2] - v0[2];
+    const double bx = (double)v2[0] - v0[0], by = (double)v2[1] - v0[1], bz = (double)v2[2] - v0[2];
+    const double nz = ax * by - ay * bx, nx = ay * bz - az * by, ny = az * bx - ax * bz;
+    const double nlen = std::sqrt(nx * nx + ny * ny + nz * nz);
+    const bool vertical = std::fabs(nz) <= 1e-4 * nlen;
+    if (vertical && (tz1 - tz0) > 1e-6) m->n_vertical++;
     for (int a = a0; a <= a1; ++a)
       for (int b = b0; b <= b1; ++b) {
         const size_t c = (size_t)a * m->gy + b;
         const size_t r = 3 * ((size_t)start[c] + fill[c]++);
         const double cx = m->x0 + a * cs, cy = m->y0 + b * cs;
-        rec[r + 0] = make_float4((float)(v0[0] - cx), (float)(v0[1] - cy), v0[2], 0.f);
-        rec[r + 1] = make_float4((float)((double)v1[0] - v0[0]), (float)((double)v1[1] - v0[1]),
-                                 (float)((double)v1[2] - v0[2]), 0.f);
-        rec[r + 2] = make_float4((float)((double)v2[0] - v0[0]), (float)((double)v2[1] - v0[1]),
-                                 (float)((double)v2[2] - v0[2]), 0.f);
+        const double lx = v0[0] - cx, ly = v0[1] - cy;  // v0 relative to the cell corner
+        if (!vertical) {
+          // plane z = pd - px*x - py*y (cell-local x, y); barycentrics (u, v) = M (x - lx, y - ly)
+          const double px = nx / nz, py = ny / nz, pd = (double)v0[2] + px * lx + py * ly;
+          const double det = ax * by - ay * bx;
+          rec[r + 0] = make_float4((float)px, (float)py, (float)pd, 0.f);
+          rec[r + 1] = make_float4((float)lx, (float)ly, (float)(by / det), (float)(-bx / det));
+          rec[r + 2] = make_float4((float)(-ay / det), (float)(ax / det), 0.f, 0.f);
+        } else {
+          rec[r + 0] = make_float4(0.f, 0.f, 0.f, 1.f);  // flag: use the Moller-Trumbore record
+          rec[r + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+          rec[r + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (any_vertical) {
+          rec_mt[r + 0] = make_float4((float)lx, (float)ly, v0[2], 0.f);
+          rec_mt[r + 1] = make_float4((float)ax, (float)ay, (float)az, 0.f);
+          rec_mt[r + 2] = make_float4((float)bx, (float)by, (float)bz, 0.f);
+        }
         cz[c].x = std::min(cz[c].x, tz0);
         cz[c].y = std::max(cz[c].y, tz1);
       }
   }
+  std::vector<uint2> info(nc);
+  for (size_t c = 0; c < nc; ++c) {
+    const u32 cnt = start[c + 1] - start[c];
+    const uint16_t hlo = float_to_half_dir(cz[c].x, -1), hhi = float_to_half_dir(cz[c].y, +1);
+    info[c].x = (u32)hlo | ((u32)hhi << 16);
+    info[c].y = start[c] | (std::min(cnt, 31u) << 27);  // count 31 = "31 or more": read cell_start
+  }
   hipError_t e1 = hipMalloc(&m->tri, sizeof(float4) * rec.size());
   hipError_t e2 = hipMalloc(&m->cell_start, sizeof(u32) * (nc + 1));
-  hipError_t e3 = hipMalloc(&m->cell_z, sizeof(float2) * nc);
-  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+  hipError_t e3 = hipMalloc(&m->cell_info, sizeof(uint2) * nc);
+  hipError_t e4 = any_vertical ? hipMalloc(&m->tri_mt, sizeof(float4) * rec_mt.size()) : hipSuccess;
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
     *err = "set_map_mesh: device allocation failed";
     mesh_free(m);
     return MCL_ERR_ALLOC;
   }
   if (hipMemcpy(m->tri, rec.data(), sizeof(float4) * rec.size(), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(m->cell_start, start.data(), sizeof(u32) * (nc + 1), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(m->cell_z, cz.data(), sizeof(float2) * nc, hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(m->cell_info, info.data(), sizeof(uint2) * nc, hipMemcpyHostToDevice) != hipSuccess ||
+      (any_vertical &&
+       hipMemcpy(m->tri_mt, rec_mt.data(), sizeof(float4) * rec_mt.size(), hipMemcpyHostToDevice) != hipSuccess)) {
     *err = "set_map_mesh: upload failed";
     mesh_free(m);
     return MCL_ERR_HIP;
@@ -156,8 +247,9 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
 inline MeshArgs mesh_args(const MeshDev* m) {
   MeshArgs ma;
   ma.tri = m->tri;
+  ma.tri_mt = m->tri_mt;
   ma.cell_start = m->cell_start;
-  ma.cell_z = m->cell_z;
+  ma.cell_info = m->cell_info;
   ma.gx = m->gx;
   ma.gy = m->gy;
   ma.cs = (float)m->cs;
