@@ -36,6 +36,8 @@ def parse():
     ap.add_argument('--beams', type=int, default=512)
     ap.add_argument('--map', default='mesh', choices=['grid', 'mesh'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mesh-general', action='store_true',
+                    help='do not use the structured-mesh path (detected for triangulated regular grids)')
     ap.add_argument('--cpu-particles', type=int, default=0, help='oracle sample size (0 = auto)')
     return ap.parse_args()
 
@@ -55,11 +57,14 @@ def build_map(kind):
                 desc='%d-triangle mesh (708x708 height field triangulated)' % tris.shape[0])
 
 
+a_mesh_general = [False]  # --mesh-general: force the triangle-record traversal (arbitrary soups)
+
+
 def attach_map(e, m):
     if m['kind'] == 'grid':
         e.set_map_grid(m['z'], m['origin'], m['res'])
     else:
-        e.set_map_mesh(m['verts'], m['tris'], heightfield=True)  # triangulated height field: single-valued z(x,y)
+        e.set_map_mesh(m['verts'], m['tris'], general=(a_mesh_general[0]))
 
 
 def make_ranges(engine_mod, m, stream, n_steps, beam_angles, sigma, r_max):
@@ -107,6 +112,7 @@ def cpu_baseline(m, stream, ranges, beam_angles, sigma, r_max, cov, n_full, n_sa
 
 def main():
     a = parse()
+    a_mesh_general[0] = a.mesh_general
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

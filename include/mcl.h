@@ -136,6 +136,9 @@ int mcl_set_map_mesh(mcl_handle* h, const float* verts, int64_t nv, const uint32
  * bathymetric surface is).  It enables neighbour-chained ray starts; a mesh with
  * overhangs must NOT set it -- results would be wrong for occluded beams. */
 #define MCL_MESH_HEIGHTFIELD 1u
+/* MCL_MESH_GENERAL: do not use the structured-mesh fast path even when the mesh is detected to be a
+ * triangulated regular height grid (testing / A-B runs of the general triangle-record traversal) */
+#define MCL_MESH_GENERAL 2u
 int mcl_set_map_mesh_ex(mcl_handle* h, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt,
                         uint32_t flags);
 /* ranges[b] <= 0 or NaN marks an invalid beam; beam b looks along (0, sin a_b, -cos a_b) in the

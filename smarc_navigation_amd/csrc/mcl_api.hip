@@ -80,6 +80,7 @@ struct mcl_handle {
   int det_cap = 0;
   int map_kind = -1;  // 0 grid, 1 mesh
   bool mesh_heightfield = false;
+  bool force_general_mesh = false;  // MCL_MESH_GENERAL: keep the triangle-record path even if structured
   // bookkeeping
   int weight_mode = 0;
   bool have_lw = false, have_cdf = false, have_meancov = false;
@@ -794,7 +795,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   } else {
     const MeshDev* m = h->mesh;
     a.mesh = mesh_args(m);
-    a.grid = nullptr;
+    a.grid = m->heights;  // non-null: structured mesh (triangulated regular height grid)
     a.nx = m->gx + 1;
     a.ny = m->gy + 1;
     a.ox = m->x0;
@@ -814,6 +815,11 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       k_mbes_cast<0, false><<<grid, MBES_THREADS, 0, h->stream>>>(a);
     else
       k_mbes_cast<0, true><<<grid, MBES_THREADS, 0, h->stream>>>(a);
+  } else if (h->mesh->heights && !h->force_general_mesh) {
+    if (with_ranges)
+      k_mbes_cast<2, false><<<grid, MBES_THREADS, 0, h->stream>>>(a);
+    else
+      k_mbes_cast<2, true><<<grid, MBES_THREADS, 0, h->stream>>>(a);
   } else {
     if (with_ranges)
       k_mbes_cast<1, false><<<grid, MBES_THREADS, 0, h->stream>>>(a);
@@ -1097,6 +1103,7 @@ int mcl_set_map_mesh_ex(mcl_handle* h, const float* verts, int64_t nv, const uin
   }
   h->map_kind = 1;
   h->mesh_heightfield = (flags & MCL_MESH_HEIGHTFIELD) != 0;
+  h->force_general_mesh = (flags & MCL_MESH_GENERAL) != 0;
   if (h->mesh_heightfield && h->mesh->n_vertical > 0) {
     h->err = "set_map_mesh: MCL_MESH_HEIGHTFIELD declared but the mesh has vertical faces";
     h->mesh_heightfield = false;

@@ -376,7 +376,7 @@ __device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int t
       t_out = fminf(fminf(tnx, tny), t1);
       z_out = fmaf(t_out, dz, oz);
       const float zlo = fminf(z_in, z_out);
-      if (MAP == 0) {
+      if (MAP != 1) {
         const float* p = tile + addr;
         h00 = p[0];
         h01 = p[1];
@@ -422,6 +422,35 @@ __device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int t
         const float root = fminf(g1, g2);
         if (root < INF) return fminf(fminf(fmaxf(root, t_in), t_out), r_max);
       }
+    } else if (MAP == 2) {
+      // structured mesh: the cell's two triangles are two planes through its corner heights; the
+      // diagonal (bit 0 of h00) selects the split.  Mirror the cell in u for the 10-01 diagonal so
+      // that only the 00-11 case remains: A = (00,10,11) for v <= u, B = (00,11,01) for v >= u.
+      first = false;
+      const bool flip = (__float_as_uint(h00) & 1u) != 0u;
+      float uc = u0 - (float)ix;
+      const float vc = v0 - (float)iy;
+      float dus = du;
+      float g00 = h00, g10 = h10, g01 = h01, g11 = h11;
+      if (flip) {
+        uc = 1.f - uc;
+        dus = -du;
+        g00 = h10;
+        g10 = h00;
+        g01 = h11;
+        g11 = h01;
+      }
+      const float lo = t_in - 1e-4f, hi = t_out + 1e-4f;
+      // plane A: z = g00 + (g10-g00) u + (g11-g10) v ; plane B: z = g00 + (g11-g01) u + (g01-g00) v
+      const float aA = g10 - g00, bA = g11 - g10, aB = g11 - g01, bB = g01 - g00;
+      const float zrel = oz - g00;
+      const float tA = -(zrel - aA * uc - bA * vc) * fast_rcp(dz - aA * dus - bA * dv);
+      const float tB = -(zrel - aB * uc - bB * vc) * fast_rcp(dz - aB * dus - bB * dv);
+      const float sA = (vc + tA * dv) - (uc + tA * dus), sB = (vc + tB * dv) - (uc + tB * dus);
+      const float gA = (tA >= lo && tA <= hi && sA <= 2e-5f) ? tA : INF;
+      const float gB = (tB >= lo && tB <= hi && sB >= -2e-5f) ? tB : INF;
+      const float root = fminf(gA, gB);
+      if (root < INF) return fminf(fmaxf(root, 0.f), r_max);
     } else {
       first = false;
       // the record range rides in the LDS tile word (start | count << 27): no dependent global load
@@ -460,8 +489,8 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
   const long long ngroups = (a.n + MBES_WAVES - 1) / MBES_WAVES;
   const float inv_res = (float)a.inv_res;
   // window limits: grid nodes nx x ny; mesh cells (nx-1) x (ny-1)
-  const int lim_x = MAP == 0 ? a.nx - 1 : a.nx - 2, lim_y = MAP == 0 ? a.ny - 1 : a.ny - 2;
-  const int tile_cap = MAP == 0 ? MBES_TILE_FLOATS : MBES_TILE_FLOATS / 2;
+  const int lim_x = MAP != 1 ? a.nx - 1 : a.nx - 2, lim_y = MAP != 1 ? a.ny - 1 : a.ny - 2;
+  const int tile_cap = MAP != 1 ? MBES_TILE_FLOATS : MBES_TILE_FLOATS / 2;
 
   for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const long long i = grp * MBES_WAVES + w;
@@ -524,7 +553,7 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
     {
       // grid: node range; mesh: cell range; clipped to the map, one cell of margin for fp32 slop
       const int wx0 = (int)floorf(a0) - 1, wy0 = (int)floorf(b0) - 1;
-      const int wx1 = (int)floorf(a1) + (MAP == 0 ? 2 : 1), wy1 = (int)floorf(b1) + (MAP == 0 ? 2 : 1);
+      const int wx1 = (int)floorf(a1) + (MAP != 1 ? 2 : 1), wy1 = (int)floorf(b1) + (MAP != 1 ? 2 : 1);
       clipped = (wx0 < 0 || wy0 < 0 || wx1 > lim_x || wy1 > lim_y) ? 1 : 0;
       tx0 = max(wx0, 0);
       ty0 = max(wy0, 0);
@@ -532,7 +561,7 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
       const int ty1 = min(wy1, lim_y);
       tw = tx1 - tx0 + 1;
       th = ty1 - ty0 + 1;
-      const int need = MAP == 0 ? 2 : 1;
+      const int need = MAP != 1 ? 2 : 1;
       use = (tw >= need && th >= need && (long long)tw * th <= tile_cap) ? 1 : 0;
       if (!(a0 <= a1) || tw < need || th < need) use = -1;  // no valid fan / fans entirely off the map
       tx0 = __builtin_amdgcn_readfirstlane(tx0);
@@ -547,7 +576,7 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
       // ---- stage the tile (coalesced along iy) and its max height
       float m = -__builtin_inff();
       const int cells = tw * th;
-      if (MAP == 0) {
+      if (MAP != 1) {
         for (int k = threadIdx.x; k < cells; k += MBES_THREADS) {
           const int ix = k / th, iy = k - ix * th;
           const float h = a.grid[(size_t)(tx0 + ix) * a.ny + (ty0 + iy)];
@@ -594,15 +623,20 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
       bool below;
       if (fast) {
         e = cast_fast<MAP>(tile, th, tw, a, tx0, ty0, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max, rs);
+      } else if (MAP == 2) {
+        // structured mesh off the fast path (map border, wide cloud): general mesh march on global memory
+        e = use < 0 ? a.r_max
+                    : cast_ray<1, false>(a.mesh.cell_info, a.mesh.gy, a, 0, 0, a.mesh.gx, a.mesh.gy, (float)P.um,
+                                         (float)P.vm, P.oz, dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
       } else if (use == 1) {
-        e = cast_ray<MAP, true>(tile, th, a, tx0, ty0, MAP == 0 ? tw - 1 : tw, MAP == 0 ? th - 1 : th, u0, v0, P.oz,
+        e = cast_ray<(MAP == 2 ? 1 : MAP), true>(tile, th, a, tx0, ty0, MAP == 0 ? tw - 1 : tw, MAP == 0 ? th - 1 : th, u0, v0, P.oz,
                                 dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
       } else if (use == 0) {
         if (MAP == 0)
-          e = cast_ray<MAP, false>(a.grid, a.ny, a, 0, 0, a.nx - 1, a.ny - 1, u0, v0, P.oz, dx * inv_res, dy * inv_res,
+          e = cast_ray<0, false>(a.grid, a.ny, a, 0, 0, a.nx - 1, a.ny - 1, u0, v0, P.oz, dx * inv_res, dy * inv_res,
                                    dx, dy, dz, t_lo, a.r_max, below, rs);
         else
-          e = cast_ray<MAP, false>(a.mesh.cell_info, a.mesh.gy, a, 0, 0, a.mesh.gx, a.mesh.gy, u0, v0, P.oz,
+          e = cast_ray<1, false>(a.mesh.cell_info, a.mesh.gy, a, 0, 0, a.mesh.gx, a.mesh.gy, u0, v0, P.oz,
                                    dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
       } else {
         e = a.r_max;

@@ -27,6 +27,8 @@ struct MeshDev {
   double x0 = 0, y0 = 0, cs = 1;
   float zmin = 0, zmax = 0;
   size_t n_records = 0;
+  // structured mesh (a triangulated regular height grid): node heights, diagonal bit in the LSB
+  float* heights = nullptr;  // (gx+1)*(gy+1), or nullptr if the mesh is not structured
   size_t n_vertical = 0;  // triangles whose xy projection is degenerate (cannot be a height field)
 };
 
@@ -36,6 +38,7 @@ inline void mesh_free(MeshDev* m) {
   if (m->cell_start) (void)hipFree(m->cell_start);
   if (m->cell_info) (void)hipFree(m->cell_info);
   if (m->tri_mt) (void)hipFree(m->tri_mt);
+  if (m->heights) (void)hipFree(m->heights);
   delete m;
 }
 
@@ -239,6 +242,86 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
     *err = "set_map_mesh: upload failed";
     mesh_free(m);
     return MCL_ERR_HIP;
+  }
+  // ---- structured-mesh detection: is this exactly a regular height grid with every cell split into
+  // two triangles along one of its diagonals?  Then node heights + one diagonal bit per cell describe
+  // it completely and the cast kernel can test the two planes from LDS (k_mbes_cast<2,*>).
+  {
+    const size_t nnx = (size_t)m->gx + 1, nny = (size_t)m->gy + 1;
+    bool ok = (size_t)nt == 2 * nc && (size_t)nv == nnx * nny;
+    std::vector<float> hts;
+    std::vector<int> node_of;
+    if (ok) {
+      hts.assign(nnx * nny, NAN);
+      node_of.assign((size_t)nv, -1);
+      for (int64_t i = 0; i < nv && ok; ++i) {
+        const double fx = ((double)verts[3 * i] - m->x0) / cs, fy = ((double)verts[3 * i + 1] - m->y0) / cs;
+        const double rx = std::round(fx), ry = std::round(fy);
+        if (std::fabs(fx - rx) > 1e-4 || std::fabs(fy - ry) > 1e-4 || rx < 0 || ry < 0 || rx >= nnx || ry >= nny) {
+          ok = false;
+          break;
+        }
+        const size_t node = (size_t)rx * nny + (size_t)ry;
+        if (hts[node] == hts[node]) ok = false;  // two vertices on one node
+        hts[node] = verts[3 * i + 2];
+        node_of[i] = (int)node;
+      }
+    }
+    std::vector<unsigned char> diag, seen;
+    if (ok) {
+      diag.assign(nc, 0);
+      seen.assign(nc, 0);  // bit 0: lower/first triangle seen, bit 1: the other
+      for (int64_t k = 0; k < nt && ok; ++k) {
+        int ixs[3], iys[3];
+        for (int c = 0; c < 3; ++c) {
+          const int node = node_of[tris[3 * k + c]];
+          ixs[c] = node / (int)nny;
+          iys[c] = node % (int)nny;
+        }
+        const int cx = std::min(ixs[0], std::min(ixs[1], ixs[2])), cy = std::min(iys[0], std::min(iys[1], iys[2]));
+        if (cx >= m->gx || cy >= m->gy) {
+          ok = false;
+          break;
+        }
+        int mask = 0;  // which corners: bit (dx + 2*dy)
+        for (int c = 0; c < 3; ++c) {
+          const int dx = ixs[c] - cx, dy = iys[c] - cy;
+          if (dx > 1 || dy > 1) ok = false;
+          mask |= 1 << (dx + 2 * dy);
+        }
+        if (!ok) break;
+        // corners: 1 = (0,0), 2 = (1,0), 4 = (0,1), 8 = (1,1)
+        const size_t c = (size_t)cx * m->gy + cy;
+        int d, half;
+        if (mask == (1 | 2 | 8)) { d = 0; half = 1; }        // 00,10,11  (v <= u)
+        else if (mask == (1 | 8 | 4)) { d = 0; half = 2; }   // 00,11,01  (v >= u)
+        else if (mask == (1 | 2 | 4)) { d = 1; half = 1; }   // 00,10,01  (u + v <= 1)
+        else if (mask == (2 | 8 | 4)) { d = 1; half = 2; }   // 10,11,01  (u + v >= 1)
+        else { ok = false; break; }
+        if (seen[c] && diag[c] != d) ok = false;
+        if (seen[c] & half) ok = false;
+        diag[c] = (unsigned char)d;
+        seen[c] |= (unsigned char)half;
+      }
+      for (size_t c = 0; c < nc && ok; ++c)
+        if (seen[c] != 3) ok = false;
+    }
+    if (ok) {
+      for (size_t ix = 0; ix < nnx; ++ix)
+        for (size_t iy = 0; iy < nny; ++iy) {
+          u32 b;
+          memcpy(&b, &hts[ix * nny + iy], 4);
+          const u32 dbit = (ix < (size_t)m->gx && iy < (size_t)m->gy) ? diag[ix * m->gy + iy] : 0u;
+          b = (b & ~1u) | dbit;  // the cell's diagonal rides in the LSB of its (0,0) corner height
+          memcpy(&hts[ix * nny + iy], &b, 4);
+        }
+      if (hipMalloc(&m->heights, sizeof(float) * hts.size()) != hipSuccess ||
+          hipMemcpy(m->heights, hts.data(), sizeof(float) * hts.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        *err = "set_map_mesh: device allocation failed";
+        mesh_free(m);
+        return MCL_ERR_ALLOC;
+      }
+    }
   }
   *out = m;
   return MCL_OK;

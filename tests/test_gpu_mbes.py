@@ -160,16 +160,18 @@ def _mesh_scene(n, nx=136, ny=128, seed=8):
     return z, origin, verts, tris, soa
 
 
-@pytest.mark.parametrize('hf', [False, True])
+@pytest.mark.parametrize('general', [False, True])
 @pytest.mark.parametrize('n,B', [(48, 256), (5, 33), (9, 512)])
-def test_mesh_expected_ranges_and_logweights_vs_oracle(n, B, hf, eng, orc):
+def test_mesh_expected_ranges_and_logweights_vs_oracle(n, B, general, eng, orc):
     z, origin, verts, tris, soa = _mesh_scene(n)
     m2o = synth.rigid_matrix(0.5, 0.25, 0.0, 0.0, 0.0, -0.1)
     ba = synth.beam_angles(B)
     off = [0.2, 0.0, -0.1, 0.0, 0.02, 0.0]
     e = eng.Engine(n, m2o=m2o, rng_mode=eng.RNG_REPLAY)
     e.set_particles(soa)
-    e.set_map_mesh(verts, tris, heightfield=hf)  # hf: neighbour-chained ray starts
+    # a triangulated regular grid is detected as a STRUCTURED mesh (two planes per cell from LDS);
+    # general=True forces the triangle-record traversal used for arbitrary soups
+    e.set_map_mesh(verts, tris, general=general)
     mesh = orc.Mesh(verts, tris)
     got = e.mbes_expected(0, n, ba, 80.0, off)
     _, ref = orc.mbes_update(soa, m2o, off, mesh, ba, None, 0.2, 80.0)
@@ -280,9 +282,48 @@ def test_chained_starts_on_rough_terrain_and_steep_rolls(eng, orc):
         print('rough terrain: %d/%d rays off by > 2e-3 m (max %.3e)' % (bad.sum(), err.size, err.max()))
         assert bad.mean() < 2e-3
         verts, tris = synth.mesh_from_grid(z, 1.0, origin)
-        e.set_map_mesh(verts, tris, heightfield=True)
+        e.set_map_mesh(verts, tris)
         gotm = e.mbes_expected(0, n, ba, 120.0)
         _, refm = orc.mbes_update(soa, np.identity(4), [0] * 6, orc.Mesh(verts, tris), ba, None, 0.2, 120.0)
         badm = np.abs(gotm - refm) > 2e-3
         print('rough mesh   : %d/%d rays off by > 2e-3 m' % (badm.sum(), badm.size))
         assert badm.mean() < 2e-3
+
+
+def test_structured_mesh_with_alternating_diagonals(eng, orc):
+    """Cells split along either diagonal (and triangles listed in shuffled order) are still detected
+    as a structured mesh and cast exactly."""
+    nx, ny = 90, 100
+    origin = (-45.0, -50.0)
+    z = synth.bathymetry_grid(nx, ny, 1.0, origin, seed=12, fbm_amp=1.5)
+    ixg, iyg = np.meshgrid(np.arange(nx), np.arange(ny), indexing='ij')
+    verts = np.stack([origin[0] + ixg, origin[1] + iyg, z], axis=-1).reshape(-1, 3).astype(np.float32)
+    tris = []
+    for ix in range(nx - 1):
+        for iy in range(ny - 1):
+            v00, v10, v01, v11 = ix * ny + iy, (ix + 1) * ny + iy, ix * ny + iy + 1, (ix + 1) * ny + iy + 1
+            if (ix + iy) % 2 == 0:
+                tris += [(v00, v10, v11), (v00, v11, v01)]
+            else:
+                tris += [(v00, v10, v01), (v10, v11, v01)]
+    tris = np.array(tris, np.uint32)
+    rs = np.random.RandomState(1)
+    tris = tris[rs.permutation(tris.shape[0])]
+    for k in range(tris.shape[0]):
+        tris[k] = np.roll(tris[k], rs.randint(3))
+    n = 30
+    soa = rs.randn(6, n) * np.array([3.0, 3.0, 0.3, 0.1, 0.1, 3.0])[:, None]
+    soa[2] -= 2.0
+    ba = synth.beam_angles(200, 1.0)
+    e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_map_mesh(verts, tris)
+    got = e.mbes_expected(0, n, ba, 80.0)
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, orc.Mesh(verts, tris), ba, None, 0.2, 80.0)
+    err = np.abs(got - ref)
+    print('alternating diagonals: max range error %.3e' % err.max())
+    assert err.max() <= 1e-3
+    e.set_map_mesh(verts, tris, general=True)
+    got2 = e.mbes_expected(0, n, ba, 80.0)
+    assert np.abs(got2 - ref).max() <= 1e-3
+    assert np.abs(got2 - got).max() <= 1e-3
