@@ -70,6 +70,7 @@ struct mcl_handle {
   size_t exp_cap = 0;
   int beams_cap = 0;
   std::vector<float> beam_cache;  // last uploaded angles
+  int beam_lo = -1, beam_hi = -1;  // extreme-angle beams (footprint shortcut)
   float* grid = nullptr;
   int gnx = 0, gny = 0;
   double gox = 0, goy = 0, gres = 1;
@@ -722,6 +723,16 @@ int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, i
     HIPCHK(h, hipMemcpyAsync(h->beam_sc, sc.data(), sizeof(float2) * (size_t)B, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));  // sc is a local
     h->beam_cache.assign(beam_angles, beam_angles + B);
+    int lo = 0, hi = 0;
+    bool finite = true;
+    for (int b = 0; b < B; ++b) {
+      if (!(beam_angles[b] == beam_angles[b])) finite = false;
+      if (beam_angles[b] < beam_angles[lo]) lo = b;
+      if (beam_angles[b] > beam_angles[hi]) hi = b;
+    }
+    const bool ok = finite && (double)beam_angles[hi] - (double)beam_angles[lo] < 3.0;  // span < pi
+    h->beam_lo = ok ? lo : -1;
+    h->beam_hi = ok ? hi : -1;
   }
   if (ranges)
     HIPCHK(h, hipMemcpyAsync(h->ranges_dev, ranges, sizeof(float) * (size_t)B, hipMemcpyHostToDevice, h->stream));
@@ -756,6 +767,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.beam_sc = h->beam_sc;
   a.ranges = with_ranges ? h->ranges_dev : nullptr;
   a.n_beams = B;
+  a.b_lo = h->beam_lo;
+  a.b_hi = h->beam_hi;
   a.inv_sigma = (float)(1.0 / sigma);
   a.r_max = (float)r_max;
   a.lognorm = std::log(sigma * std::sqrt(2.0 * MCL_PI));

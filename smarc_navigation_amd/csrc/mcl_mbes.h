@@ -58,6 +58,7 @@ struct MbesArgs {
   const float2* beam_sc;  // (sin a_b, cos a_b)
   const float* ranges;    // measured
   int n_beams;
+  int b_lo, b_hi;         // indices of the extreme beam angles (span < pi), or -1: scan every beam for the footprint
   const float* grid;      // z[ix*ny + iy]
   int nx, ny;             // grid: nodes; mesh: cells + 1
   double ox, oy, inv_res;
@@ -513,18 +514,41 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
     if (valid) {
       umin = umax = (float)P.um;
       vmin = vmax = (float)P.vm;
-      for (int b = lane; b < a.n_beams; b += 64) {
-        const float2 sc = a.beam_sc[b];
+      // The fan is planar, so the points where its beams reach depth z_min(map) are collinear and
+      // ordered by beam angle: the two extreme-angle beams bound the footprint, provided both point
+      // downward and reach z_min before r_max (then every beam between them does too).
+      bool simple = a.b_lo >= 0;
+      float ue[2], ve[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float2 sc = a.beam_sc[k == 0 ? max(a.b_lo, 0) : max(a.b_hi, 0)];
         const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
         const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
         const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
-        float t_end = a.r_max;
-        if (dz < -1e-6f) t_end = fminf(t_end, fmaxf((a.zmin_map - P.oz) * fast_rcp(dz), 0.f));
-        const float ue = (float)P.um + t_end * dx * inv_res, ve = (float)P.vm + t_end * dy * inv_res;
-        umin = fminf(umin, ue);
-        umax = fmaxf(umax, ue);
-        vmin = fminf(vmin, ve);
-        vmax = fmaxf(vmax, ve);
+        const float t_end = fmaxf((a.zmin_map - P.oz) * fast_rcp(dz), 0.f);
+        simple = simple && dz < -1e-4f && t_end <= a.r_max;
+        ue[k] = (float)P.um + t_end * dx * inv_res;
+        ve[k] = (float)P.vm + t_end * dy * inv_res;
+      }
+      if (simple) {
+        umin = fminf(umin, fminf(ue[0], ue[1]));
+        umax = fmaxf(umax, fmaxf(ue[0], ue[1]));
+        vmin = fminf(vmin, fminf(ve[0], ve[1]));
+        vmax = fmaxf(vmax, fmaxf(ve[0], ve[1]));
+      } else {
+        for (int b = lane; b < a.n_beams; b += 64) {
+          const float2 sc = a.beam_sc[b];
+          const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
+          const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
+          const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
+          float t_end = a.r_max;
+          if (dz < -1e-6f) t_end = fminf(t_end, fmaxf((a.zmin_map - P.oz) * fast_rcp(dz), 0.f));
+          const float ub = (float)P.um + t_end * dx * inv_res, vb = (float)P.vm + t_end * dy * inv_res;
+          umin = fminf(umin, ub);
+          umax = fmaxf(umax, ub);
+          vmin = fminf(vmin, vb);
+          vmax = fmaxf(vmax, vb);
+        }
       }
     }
     umin = wave_min(umin);
@@ -575,23 +599,27 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_S
     if (use == 1) {
       // ---- stage the tile (coalesced along iy) and its max height
       float m = -__builtin_inff();
-      const int cells = tw * th;
+      // rows go to waves, columns to lanes (coalesced along iy, no integer division)
       if (MAP != 1) {
-        for (int k = threadIdx.x; k < cells; k += MBES_THREADS) {
-          const int ix = k / th, iy = k - ix * th;
-          const float h = a.grid[(size_t)(tx0 + ix) * a.ny + (ty0 + iy)];
-          tile[k] = h;
-          m = fmaxf(m, h);
+        for (int ix = w; ix < tw; ix += MBES_WAVES) {
+          const float* src = a.grid + (size_t)(tx0 + ix) * a.ny + ty0;
+          for (int iy = lane; iy < th; iy += 64) {
+            const float h = src[iy];
+            tile[ix * th + iy] = h;
+            m = fmaxf(m, h);
+          }
         }
       } else {
         uint2* t2 = (uint2*)tile;
-        for (int k = threadIdx.x; k < cells; k += MBES_THREADS) {
-          const int ix = k / th, iy = k - ix * th;
-          const uint2 ci = a.mesh.cell_info[(size_t)(tx0 + ix) * a.mesh.gy + (ty0 + iy)];
-          t2[k] = ci;
-          float czlo, czhi;
-          cell_zrange(ci.x, czlo, czhi);
-          m = fmaxf(m, czhi);
+        for (int ix = w; ix < tw; ix += MBES_WAVES) {
+          const uint2* src = a.mesh.cell_info + (size_t)(tx0 + ix) * a.mesh.gy + ty0;
+          for (int iy = lane; iy < th; iy += 64) {
+            const uint2 ci = src[iy];
+            t2[ix * th + iy] = ci;
+            float czlo, czhi;
+            cell_zrange(ci.x, czlo, czhi);
+            m = fmaxf(m, czhi);
+          }
         }
       }
       m = wave_max(m);
