@@ -22,10 +22,10 @@
 #define MBES_WAVES 8                         // particles per workgroup
 #endif
 #ifndef MBES_MIN_WAVES_PER_SIMD
-#define MBES_MIN_WAVES_PER_SIMD 6            // __launch_bounds__ 2nd argument: <= 80 VGPRs, 3 workgroups/CU
+#define MBES_MIN_WAVES_PER_SIMD 8            // grid / structured mesh: <= 64 VGPRs, 4 workgroups (32 waves) per CU
 #endif
 #ifndef MBES_MIN_WAVES_MESH
-#define MBES_MIN_WAVES_MESH 6
+#define MBES_MIN_WAVES_MESH 6                // general triangle records: <= 80 VGPRs, 3 workgroups per CU
 #endif
 #define MBES_THREADS (MBES_WAVES * 64)
 #ifndef MBES_TILE_FLOATS
@@ -481,7 +481,7 @@ __device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int t
 
 // ------------------------------------------------------------------ the cast kernel
 template <int MAP, bool EXPECT_ONLY>
-__global__ void __launch_bounds__(MBES_THREADS, (MAP == 0 ? MBES_MIN_WAVES_PER_SIMD : MBES_MIN_WAVES_MESH)) k_mbes_cast(MbesArgs a) {
+__global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 ? MBES_MIN_WAVES_MESH : MBES_MIN_WAVES_PER_SIMD)) k_mbes_cast(MbesArgs a) {
   __shared__ __attribute__((aligned(16))) float tile[MBES_TILE_FLOATS];
   __shared__ float red[5][MBES_WAVES];  // umin, umax, vmin, vmax, zmax per wave
 
