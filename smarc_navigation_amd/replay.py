@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Recorded-stream replay + evaluation.
+
+Replays a recorded input stream (own .npz format, no rosbag dependency) through the node class
+(smarc_navigation_amd/auv_pf.py: the same callbacks the rospy wrapper registers) and scores the
+result the way the reference's visual_tools.py does at shutdown (finish_hld, visual_tools.py:61-76:
+path length of the GPS / DR / PF tracks and the norm of each track's final position), plus the
+RMSE between the PF mean pose and a reference track (the "pose RMSE vs ref" of the metric).
+
+Stream file (np.savez): stamp[n], v[n,3], wz[n], q[n,4], z[n]  (odometry, /sam/dr/odom);
+optional gps_idx[k], gps_xy_utm[k,2]; optional mbes_idx[m], mbes_ranges[m,B], mbes_angles[B],
+mbes_range_max; optional dr_xyz[n,3] (dead-reckoning track), truth_xyz[n,3]; t0.
+
+    python -m smarc_navigation_amd.replay stream.npz --particles 65536 [--map-grid map.npz] [--out traj.csv]
+"""
+import argparse
+import json
+
+import numpy as np
+
+
+def track_metrics(vec):
+    """visual_tools.py:61-76 for one 3 x n track: summed segment lengths and |last position|."""
+    vec = np.asarray(vec, dtype=np.float64)
+    dist = 0.
+    for i in range(1, vec.shape[1]):
+        dist += np.linalg.norm(vec[:, i] - vec[:, i - 1])
+    final = float(np.linalg.norm(vec[:, -1])) if vec.shape[1] else 0.0
+    return float(dist), final
+
+
+def pose_rmse(est_xy, ref_xy):
+    d = np.asarray(est_xy, dtype=np.float64) - np.asarray(ref_xy, dtype=np.float64)
+    return float(np.sqrt(np.mean(np.sum(d * d, axis=1))))
+
+
+def replay(stream, params=None, m2o=None, utm2map=None, grid=None, mesh=None, publish_every=5):
+    """Drive the node with a recorded stream; returns dict(pf_xyz[n_pub,3], pub_idx, summary)."""
+    from . import auv_pf as node
+    from . import msgs
+    tr = node.RecordingTransport(utm2map)
+    pf = node.auv_pf(params or {}, m2o_mat=m2o, transport=tr)
+    if grid is not None:
+        pf.set_map_grid(grid['z'], grid['origin'], float(grid['res']))
+    if mesh is not None:
+        pf.set_map_mesh(mesh['verts'], mesh['tris'])
+    n = len(stream['stamp'])
+    pf.start_timing(float(stream['t0']) if 't0' in stream else float(stream['stamp'][0]) - 0.02)
+    gps_at = {int(k): j for j, k in enumerate(stream['gps_idx'])} if 'gps_idx' in stream else {}
+    mbes_at = {int(k): j for j, k in enumerate(stream['mbes_idx'])} if 'mbes_idx' in stream else {}
+    pub_idx, pf_xyz = [], []
+    for k in range(n):
+        pf.odom_callback(msgs.odometry_from_stream(stream, k))
+        if k in gps_at:
+            g = msgs.Odometry()
+            g.pose.pose.position.x = float(stream['gps_xy_utm'][gps_at[k]][0])
+            g.pose.pose.position.y = float(stream['gps_xy_utm'][gps_at[k]][1])
+            pf.dive_cb(msgs.Bool(False))
+            pf.gps_odom_cb(g)
+        if k in mbes_at:
+            ang = np.asarray(stream['mbes_angles'], dtype=np.float64)
+            scan = msgs.LaserScan(stream['mbes_ranges'][mbes_at[k]], float(ang[0]),
+                                  float(ang[1] - ang[0]) if ang.size > 1 else 0.0,
+                                  float(stream['mbes_range_max']) if 'mbes_range_max' in stream else 100.0)
+            pf.mbes_cb(scan)
+        if (k + 1) % publish_every == 0 or k == n - 1:
+            pf.loc_loop(None)
+            p = tr.odom_corrected[-1].pose.pose.position
+            pub_idx.append(k)
+            pf_xyz.append([p.x, p.y, p.z])
+    pf_xyz = np.array(pf_xyz)
+    summary = {}
+    summary['pf_distance'], summary['pf_final'] = track_metrics(pf_xyz.T)
+    for name in ('dr_xyz', 'truth_xyz'):
+        if name in stream:
+            ref = np.asarray(stream[name])[pub_idx]
+            tag = name.split('_')[0]
+            summary[tag + '_distance'], summary[tag + '_final'] = track_metrics(ref.T)
+            summary['pf_rmse_vs_' + tag] = pose_rmse(pf_xyz[:, :2], ref[:, :2])
+    return dict(pf_xyz=pf_xyz, pub_idx=np.array(pub_idx), summary=summary)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
+    ap.add_argument('stream')
+    ap.add_argument('--particles', type=int, default=4096)
+    ap.add_argument('--map-grid', help='npz with z, origin, res')
+    ap.add_argument('--out', help='CSV of the published mean pose')
+    ap.add_argument('--seed', type=int, default=0)
+    a = ap.parse_args(argv)
+    stream = dict(np.load(a.stream, allow_pickle=False))
+    grid = dict(np.load(a.map_grid)) if a.map_grid else None
+    res = replay(stream, dict(particle_count=a.particles, seed=a.seed), grid=grid)
+    if a.out:
+        np.savetxt(a.out, np.column_stack([res['pub_idx'], res['pf_xyz']]), delimiter=',', header='step,x,y,z')
+    print(json.dumps(res['summary']))
+
+
+if __name__ == '__main__':
+    main()

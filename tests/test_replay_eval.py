@@ -1,0 +1,49 @@
+"""Replay / evaluation tool: the track metrics restate visual_tools.py:61-76 (CPU test); the replay
+end-to-end run needs the GPU."""
+import numpy as np
+import pytest
+
+from smarc_navigation_amd import replay as rp
+from smarc_navigation_amd import synth
+
+
+def test_track_metrics_match_visual_tools_formula():
+    rs = np.random.RandomState(0)
+    vec = np.cumsum(rs.randn(3, 50), axis=1)
+    dist, final = rp.track_metrics(vec)
+    ref = sum(np.linalg.norm(vec[:, i] - vec[:, i - 1]) for i in range(1, vec.shape[1]))
+    assert dist == pytest.approx(ref, rel=1e-15)
+    assert final == pytest.approx(np.linalg.norm(vec[:, -1]), rel=1e-15)
+    assert rp.pose_rmse([[0, 0], [3, 4]], [[0, 0], [0, 0]]) == pytest.approx(np.sqrt(12.5))
+
+
+@pytest.mark.gpu
+def test_replay_with_mbes_pings_tracks_the_truth():
+    from smarc_navigation_amd import engine
+    n_steps, B = 150, 96
+    st = synth.odom_stream(n_steps)
+    origin = (-64.0, -128.0)
+    z = synth.bathymetry_grid(256, 256, 1.0, origin, seed=3)
+    ba = synth.beam_angles(B)
+    e = engine.Engine(1, rng_mode=engine.RNG_REPLAY)
+    e.set_map_grid(z, origin, 1.0)
+    idx = np.arange(4, n_steps, 5)
+    ranges = np.zeros((idx.size, B), np.float32)
+    rs = np.random.RandomState(4)
+    for j, k in enumerate(idx):
+        e.set_particles(st['truth'][k][:, None].copy())
+        ranges[j] = e.mbes_expected(0, 1, ba, 80.0)[0] + 0.1 * rs.randn(B)
+    # a dead-reckoning track that drifts away from the truth
+    dr = st['truth'][:, :3].copy()
+    dr[:, 0] += 0.02 * np.arange(n_steps)
+    stream = dict(stamp=st['stamp'], v=st['v'], wz=st['wz'], q=st['q'], z=st['z'], t0=st['t0'],
+                  mbes_idx=idx, mbes_ranges=ranges, mbes_angles=ba, mbes_range_max=80.0,
+                  truth_xyz=st['truth'][:, :3], dr_xyz=dr)
+    out = rp.replay(stream, dict(particle_count=16384, init_covariance='[1.0, 1.0, 0.0, 0.0, 0.0, 0.01]',
+                                 motion_covariance='[0.0001, 0.0001, 0.0, 0.0, 0.0, 0.000001]',
+                                 resampling_noise_covariance='[0.01, 0.01, 0.0, 0.0, 0.0, 0.00001]', seed=2),
+                    grid=dict(z=z, origin=origin, res=1.0))
+    s = out['summary']
+    print(s)
+    assert s['pf_rmse_vs_truth'] < 0.35
+    assert abs(s['pf_distance'] - s['truth_distance']) < 1.0
