@@ -190,6 +190,9 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
 int mcl_sync(mcl_handle* h);
 /* mean/cov computed by the last mcl_step_mbes (syncs the stream) */
 int mcl_last_mean_cov(mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9]);
+/* mean poses (6 doubles each, oldest first) of the last `last_k` mean/cov evaluations (<= 4096 are
+ * kept in a pinned ring): lets a caller score a whole asynchronous run without per-step syncs */
+int mcl_mean_history(mcl_handle* h, int64_t last_k, double* mean6_out);
 
 /* ---- resampling.py as free functions on the GPU (fixed-point CDF):
  * weights need not be normalised; out: n int32 ancestor indices. */

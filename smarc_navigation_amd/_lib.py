@@ -68,6 +68,7 @@ SYMBOLS = {
     'mcl_step_mbes': (C.c_int, [_vp, C.POINTER(Odom), _d, _vp, _vp, _i32, _d, _d, _vp]),
     'mcl_sync': (C.c_int, [_vp]),
     'mcl_last_mean_cov': (C.c_int, [_vp, _vp, _vp, _vp]),
+    'mcl_mean_history': (C.c_int, [_vp, _i64, _vp]),
     'mcl_resample_indices': (C.c_int, [_i32, _vp, _i64, _vp, _i64, _i32, _vp]),
     'mcl_comm_unique_id': (C.c_int, [C.c_char_p]),
     'mcl_comm_init': (C.c_int, [_vp, C.c_char_p]),

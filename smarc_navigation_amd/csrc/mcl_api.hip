@@ -18,6 +18,8 @@
 #include "mcl_resample_alt.h"
 #include "mcl_landmarks.h"
 
+#define MEAN_RING 4096
+
 namespace {
 
 thread_local std::string g_create_err;
@@ -53,7 +55,8 @@ struct mcl_handle {
   int* idx = nullptr;         // n (lazily)
   double* replay_dev = nullptr;
   double* pose7 = nullptr;
-  double* host_pin = nullptr;  // pinned: 16 doubles
+  double* host_pin = nullptr;  // pinned ring: MEAN_RING entries of 16 doubles (sums7, pad, cov-sums6, pad2)
+  long long mean_count = 0;     // number of mean/cov results produced so far
   // MBES
   float2* beam_sc = nullptr;
   float* ranges_dev = nullptr;
@@ -681,15 +684,18 @@ int run_mean_cov_async(mcl_handle** sh, int ns) {
   for (int s = 0; s < ns; ++s) {
     mcl_handle* h = sh[s];
     RET_IF(set_device(h));
-    HIPCHK(h, hipMemcpyAsync(h->host_pin, h->scal + 8, sizeof(double) * 14, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->host_pin + 16 * (h->mean_count % MEAN_RING), h->scal + 8, sizeof(double) * 14,
+                             hipMemcpyDeviceToHost, h->stream));
+    h->mean_count++;
     h->have_meancov = true;
   }
   return MCL_OK;
 }
 // host_pin layout: [0..6] sums7, [7] pad, [8..13] cov sums6
-void finish_mean_cov(const mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9]) {
+void finish_mean_cov(const mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9], long long which = -1) {
   const double N = (double)h->ng;
-  const double* p = h->host_pin;
+  if (which < 0) which = h->mean_count - 1;
+  const double* p = h->host_pin + 16 * (which % MEAN_RING);
   for (int c = 0; c < 6; ++c) mean6[c] = p[c] / N;
   if (yaw_mean) *yaw_mean = p[6] / N;
   const double* c = p + 8;
@@ -986,7 +992,7 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
   CREATE_CHK(hipMemsetAsync(h->scal, 0, sizeof(double) * 32, h->stream));
   CREATE_CHK(hipMalloc(&h->totals, sizeof(u64) * (size_t)(h->world + 1)));
   CREATE_CHK(hipMemsetAsync(h->totals, 0, sizeof(u64) * (size_t)(h->world + 1), h->stream));
-  CREATE_CHK(hipHostMalloc(&h->host_pin, sizeof(double) * 16, hipHostMallocDefault));
+  CREATE_CHK(hipHostMalloc(&h->host_pin, sizeof(double) * 16 * MEAN_RING, hipHostMallocDefault));
   CREATE_CHK(hipStreamSynchronize(h->stream));
 #undef CREATE_CHK
   *out = h;
@@ -1278,6 +1284,18 @@ int mcl_last_mean_cov(mcl_handle* h, double mean6[6], double* yaw_mean, double c
   RET_IF(set_device(h));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   finish_mean_cov(h, mean6, yaw_mean, cov9);
+  return MCL_OK;
+}
+
+int mcl_mean_history(mcl_handle* h, int64_t last_k, double* mean6_out) {
+  if (!h || !mean6_out || last_k < 1) return MCL_ERR_INVALID;
+  if (last_k > h->mean_count || last_k > MEAN_RING) return fail(h, MCL_ERR_INVALID, "mean_history: not that many results kept");
+  RET_IF(set_device(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (long long k = 0; k < last_k; ++k) {
+    double yaw, cov9[9];
+    finish_mean_cov(h, mean6_out + 6 * k, &yaw, cov9, h->mean_count - last_k + k);
+  }
   return MCL_OK;
 }
 

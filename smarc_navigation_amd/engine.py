@@ -137,6 +137,11 @@ class Engine(object):
         self._ck(self.lib.mcl_last_mean_cov(self.h, _ptr(mean), _ptr(yaw), _ptr(cov)))
         return mean, float(yaw[0]), cov
 
+    def mean_history(self, last_k):
+        out = np.zeros((int(last_k), 6))
+        self._ck(self.lib.mcl_mean_history(self.h, int(last_k), _ptr(out)))
+        return out
+
     def poses(self):
         out = np.zeros((self.n, 7))
         self._ck(self.lib.mcl_get_poses(self.h, _ptr(out)))
