@@ -62,6 +62,7 @@ struct mcl_handle {
   float* ranges_dev = nullptr;
   float* exp_dev = nullptr;
   MbesPose* pose_dev = nullptr;
+  int* mbes_worklist = nullptr;  // ngroups + 1 ints; [ngroups] is the counter
   // alternative resamplers (lazily allocated)
   u64* cq = nullptr;       // inclusive scan of q
   u64* u53 = nullptr;      // uniforms as 53-bit integers
@@ -827,24 +828,31 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   }
   const long long ngroups = (h->n + MBES_WAVES - 1) / MBES_WAVES;
   const int grid = (int)(ngroups < 4096 ? ngroups : 4096);
+  if (!h->mbes_worklist) HIPCHK(h, hipMalloc(&h->mbes_worklist, sizeof(int) * (size_t)(ngroups + 1)));
+  a.worklist = h->mbes_worklist;
+  a.work_count = h->mbes_worklist + ngroups;
   t_begin(h, MCL_K_UPDATE_MBES);
+  HIPCHK(h, hipMemsetAsync(a.work_count, 0, sizeof(int), h->stream));
   k_mbes_pose<<<grid_for(h->n), 256, 0, h->stream>>>(a);
-  if (h->map_kind == 0) {
-    if (with_ranges)
-      k_mbes_cast<0, false><<<grid, MBES_THREADS, 0, h->stream>>>(a);
-    else
-      k_mbes_cast<0, true><<<grid, MBES_THREADS, 0, h->stream>>>(a);
-  } else if (h->mesh->heights && !h->force_general_mesh) {
-    if (with_ranges)
-      k_mbes_cast<2, false><<<grid, MBES_THREADS, 0, h->stream>>>(a);
-    else
-      k_mbes_cast<2, true><<<grid, MBES_THREADS, 0, h->stream>>>(a);
-  } else {
-    if (with_ranges)
-      k_mbes_cast<1, false><<<grid, MBES_THREADS, 0, h->stream>>>(a);
-    else
-      k_mbes_cast<1, true><<<grid, MBES_THREADS, 0, h->stream>>>(a);
-  }
+  // fast kernel over every group, then the general kernel over the few groups it deferred
+  const int ggrid = (int)(ngroups < 512 ? ngroups : 512);
+#define LAUNCH_CAST(MAPV)                                                          \
+  do {                                                                             \
+    if (with_ranges) {                                                             \
+      k_mbes_cast<MAPV, false, 0><<<grid, MBES_THREADS, 0, h->stream>>>(a);        \
+      k_mbes_cast<MAPV, false, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);       \
+    } else {                                                                       \
+      k_mbes_cast<MAPV, true, 0><<<grid, MBES_THREADS, 0, h->stream>>>(a);         \
+      k_mbes_cast<MAPV, true, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);        \
+    }                                                                              \
+  } while (0)
+  if (h->map_kind == 0)
+    LAUNCH_CAST(0);
+  else if (h->mesh->heights && !h->force_general_mesh)
+    LAUNCH_CAST(2);
+  else
+    LAUNCH_CAST(1);
+#undef LAUNCH_CAST
   t_end(h);
   HIPCHK(h, hipGetLastError());
   return MCL_OK;
@@ -1015,7 +1023,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev};
   for (void* b : bufs)
     if (b) hipFree(b);

@@ -70,6 +70,8 @@ struct MbesArgs {
   float* exp_out;         // out (EXPECT_ONLY): expected ranges [(i-exp_first)*B + b]
   long long exp_first, exp_count;
   MeshArgs mesh;
+  int* worklist;          // group ids deferred by the fast kernel (capacity = number of groups)
+  int* work_count;        // device counter, zeroed before every fast launch
   unsigned long long* stats;  // MBES_STATS builds: steps, exact tests, rays, retries
   int chain;              // 1: map declared a height field (single-valued z(x,y)); reserved for profile marching
 };
@@ -480,8 +482,13 @@ __device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int t
 }
 
 // ------------------------------------------------------------------ the cast kernel
-template <int MAP, bool EXPECT_ONLY>
-__global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 ? MBES_MIN_WAVES_MESH : MBES_MIN_WAVES_PER_SIMD)) k_mbes_cast(MbesArgs a) {
+// MODE 0: fast traversal only -- a workgroup whose tile is clipped by the map border, does not fit LDS
+//         or whose sensors are not inside it appends its group id to a.worklist and returns; this
+//         keeps the hot kernel free of the general code's registers (no scratch spills).
+// MODE 1: general traversal over the groups listed in a.worklist (usually none: map borders, wide clouds).
+template <int MAP, bool EXPECT_ONLY, int MODE>
+__global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MIN_WAVES_MESH : MBES_MIN_WAVES_PER_SIMD))
+    k_mbes_cast(MbesArgs a) {
   __shared__ __attribute__((aligned(16))) float tile[MBES_TILE_FLOATS];
   __shared__ float red[5][MBES_WAVES];  // umin, umax, vmin, vmax, zmax per wave
 
@@ -493,7 +500,9 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 ? MBES_MIN_WAVES_MESH 
   const int lim_x = MAP != 1 ? a.nx - 1 : a.nx - 2, lim_y = MAP != 1 ? a.ny - 1 : a.ny - 2;
   const int tile_cap = MAP != 1 ? MBES_TILE_FLOATS : MBES_TILE_FLOATS / 2;
 
-  for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  const long long nwork = MODE == 1 ? (long long)*a.work_count : ngroups;
+  for (long long it = blockIdx.x; it < nwork; it += gridDim.x) {
+    const long long grp = MODE == 1 ? (long long)a.worklist[it] : it;
     const long long i = grp * MBES_WAVES + w;
     const bool valid = i < a.n;
     MbesPose P;
@@ -595,6 +604,42 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 ? MBES_MIN_WAVES_MESH 
       use = __builtin_amdgcn_readfirstlane(use);
       clipped = __builtin_amdgcn_readfirstlane(clipped);
     }
+    if (MODE == 0) {
+      // block-uniform vote: every valid sensor must sit inside the (unclipped) tile with a cell of margin
+      const float ul = (float)(P.um - (double)tx0), vl = (float)(P.vm - (double)ty0);
+      const bool inside = !valid || (ul >= 1.f && vl >= 1.f && ul <= (float)(tw - 2) && vl <= (float)(th - 2));
+      if (lane == 0) red[4][w] = inside ? 1.f : 0.f;
+      __syncthreads();
+      float ok = red[4][lane & (MBES_WAVES - 1)];
+#pragma unroll
+      for (int o = MBES_WAVES / 2; o > 0; o >>= 1) ok = fminf(ok, __shfl_xor(ok, o, 64));
+      const bool all_fast = use == 1 && !clipped && ok > 0.5f;
+      if (!all_fast) {
+        if (use >= 0 && threadIdx.x == 0) a.worklist[atomicAdd(a.work_count, 1)] = (int)grp;
+        if (use < 0 && valid) {  // fans entirely off the map: every beam returns r_max
+          if (EXPECT_ONLY) {
+            if (i >= a.exp_first && i < a.exp_first + a.exp_count)
+              for (int b = lane; b < a.n_beams; b += 64) a.exp_out[(size_t)(i - a.exp_first) * a.n_beams + b] = a.r_max;
+          } else {
+            float acc0 = 0.f;
+            int nv0 = 0;
+            for (int b = lane; b < a.n_beams; b += 64) {
+              const float rm = a.ranges[b];
+              if (rm > 0.f) {
+                const float d = (rm - a.r_max) * a.inv_sigma;
+                acc0 += d * d;
+                ++nv0;
+              }
+            }
+            const double accd0 = wave_sum((double)acc0);
+            const int nvs = wave_sum(nv0);
+            if (lane == 0) a.lw[i] = -0.5 * accd0 - (double)nvs * a.lognorm;
+          }
+        }
+        continue;  // uniform for the whole workgroup
+      }
+      __syncthreads();  // red[4] is reused for the tile max below
+    }
     float zmax = a.zmax_map;
     if (use == 1) {
       // ---- stage the tile (coalesced along iy) and its max height
@@ -639,7 +684,7 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 ? MBES_MIN_WAVES_MESH 
     // lanes = consecutive beams (coherent: neighbouring lanes walk neighbouring cells)
     RayStats rs = {0, 0, 0, 0};
     // wave-uniform choice: the fast traversal needs an unclipped tile and the sensor inside it
-    const bool fast = use == 1 && !clipped && u0 >= 1.f && v0 >= 1.f && u0 <= (float)(tw - 2) && v0 <= (float)(th - 2);
+    const bool fast = MODE == 0;  // MODE 0 reaches this point only with every wave eligible
     for (int b = lane; b < a.n_beams; b += 64) {
       const float2 sc = a.beam_sc[b];
       const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
@@ -649,7 +694,7 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 ? MBES_MIN_WAVES_MESH 
       if (dz < 0.f && P.oz > zmax) t_lo = fmaxf((zmax - P.oz) * fast_rcp(dz) - 1e-3f, 0.f);
       float e;
       bool below;
-      if (fast) {
+      if (MODE == 0) {
         e = cast_fast<MAP>(tile, th, tw, a, tx0, ty0, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max, rs);
       } else if (MAP == 2) {
         // structured mesh off the fast path (map border, wide cloud): general mesh march on global memory
