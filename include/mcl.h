@@ -111,6 +111,9 @@ int mcl_abi_version(void);
 const char* mcl_status_string(int status);
 const char* mcl_last_error(const mcl_handle* h); /* h may be NULL: last create() error */
 int mcl_device_count(int* count);
+/* a14: matrix_from_tf (auv_particle.py:110-125): 4x4 row-major map<-odom from a tf translation
+ * (x,y,z) and quaternion (x,y,z,w); host-side helper for filling mcl_config.m2o */
+int mcl_matrix_from_tf(const double translation[3], const double quaternion[4], double m16[16]);
 
 /* ---- lifetime: replaces auv_pf.__init__'s particle list (auv_pf.py:89-94) ---------------- */
 int mcl_create(const mcl_config* cfg, mcl_handle** out);

@@ -42,6 +42,7 @@ SYMBOLS = {
     'mcl_status_string': (C.c_char_p, [C.c_int]),
     'mcl_last_error': (C.c_char_p, [_vp]),
     'mcl_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'mcl_matrix_from_tf': (C.c_int, [_vp, _vp, _vp]),
     'mcl_create': (C.c_int, [C.POINTER(Config), C.POINTER(_vp)]),
     'mcl_destroy': (C.c_int, [_vp]),
     'mcl_init_particles': (C.c_int, [_vp, _vp]),

@@ -55,3 +55,17 @@ def test_product_package_never_imports_oracle():
                 assert 'oracle' not in txt.replace('oracle/mcl_oracle.c', '').replace('the oracle', '').replace(
                     'fp64 oracle', '').lower() or f.endswith('.h') or f.endswith('.hip'), f
                 assert 'import oracle' not in txt and 'from oracle' not in txt and 'mcl_oracle.h' not in txt, f
+
+
+def test_matrix_from_tf_host_helper_matches_reference_golden():
+    """mcl_matrix_from_tf needs no GPU: check it against the reference's matrix_from_tf output."""
+    import numpy as np
+    from smarc_navigation_amd import _lib
+    from tests import helpers
+    g = helpers.load('particle_kat')
+    lib = _lib.load()
+    t = np.ascontiguousarray(g['mt_in'][:3])
+    q = np.ascontiguousarray(g['mt_in'][3:])
+    m = np.zeros(16)
+    assert lib.mcl_matrix_from_tf(t.ctypes.data, q.ctypes.data, m.ctypes.data) == 0
+    np.testing.assert_allclose(m.reshape(4, 4), g['mt_M'], rtol=0, atol=1e-15)
