@@ -426,33 +426,25 @@ __device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int t
         if (root < INF) return fminf(fminf(fmaxf(root, t_in), t_out), r_max);
       }
     } else if (MAP == 2) {
-      // structured mesh: the cell's two triangles are two planes through its corner heights; the
-      // diagonal (bit 0 of h00) selects the split.  Mirror the cell in u for the 10-01 diagonal so
-      // that only the 00-11 case remains: A = (00,10,11) for v <= u, B = (00,11,01) for v >= u.
+      // structured mesh: the cell's two triangles are two planes through its corner heights; bit 0
+      // of h00 selects the diagonal.  00-11 split: A = (00,10,11) where v <= u, B = (00,11,01) where
+      // v >= u.  10-01 split: C = (00,10,01) where u+v <= 1, D = (10,11,01) where u+v >= 1.
       first = false;
-      const bool flip = (__float_as_uint(h00) & 1u) != 0u;
-      float uc = u0 - (float)ix;
-      const float vc = v0 - (float)iy;
-      float dus = du;
-      float g00 = h00, g10 = h10, g01 = h01, g11 = h11;
-      if (flip) {
-        uc = 1.f - uc;
-        dus = -du;
-        g00 = h10;
-        g10 = h00;
-        g01 = h11;
-        g11 = h01;
-      }
+      const bool d1 = (__float_as_uint(h00) & 1u) != 0u;
+      const float uc = u0 - (float)ix, vc = v0 - (float)iy;
+      const float a1 = h10 - h00, b1 = d1 ? h01 - h00 : h11 - h10;           // first triangle (A or C)
+      const float a2 = h11 - h01, b2 = d1 ? h11 - h10 : h01 - h00;           // second triangle (B or D)
+      const float c2 = d1 ? (h10 - h11) + h01 : h00;
       const float lo = t_in - 1e-4f, hi = t_out + 1e-4f;
-      // plane A: z = g00 + (g10-g00) u + (g11-g10) v ; plane B: z = g00 + (g11-g01) u + (g01-g00) v
-      const float aA = g10 - g00, bA = g11 - g10, aB = g11 - g01, bB = g01 - g00;
-      const float zrel = oz - g00;
-      const float tA = -(zrel - aA * uc - bA * vc) * fast_rcp(dz - aA * dus - bA * dv);
-      const float tB = -(zrel - aB * uc - bB * vc) * fast_rcp(dz - aB * dus - bB * dv);
-      const float sA = (vc + tA * dv) - (uc + tA * dus), sB = (vc + tB * dv) - (uc + tB * dus);
-      const float gA = (tA >= lo && tA <= hi && sA <= 2e-5f) ? tA : INF;
-      const float gB = (tB >= lo && tB <= hi && sB >= -2e-5f) ? tB : INF;
-      const float root = fminf(gA, gB);
+      const float t1p = ((h00 + a1 * uc + b1 * vc) - oz) * fast_rcp(dz - a1 * du - b1 * dv);
+      const float t2p = ((c2 + a2 * uc + b2 * vc) - oz) * fast_rcp(dz - a2 * du - b2 * dv);
+      // side of the diagonal at each candidate point: s = v - u (00-11) or u + v - 1 (10-01)
+      const float su = d1 ? 1.f : -1.f, s0 = d1 ? -1.f : 0.f;
+      const float s1 = (vc + t1p * dv) + su * (uc + t1p * du) + s0;
+      const float s2 = (vc + t2p * dv) + su * (uc + t2p * du) + s0;
+      const float g1 = (t1p >= lo && t1p <= hi && s1 <= 2e-5f) ? t1p : INF;
+      const float g2 = (t2p >= lo && t2p <= hi && s2 >= -2e-5f) ? t2p : INF;
+      const float root = fminf(g1, g2);
       if (root < INF) return fminf(fmaxf(root, 0.f), r_max);
     } else {
       first = false;
