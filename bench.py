@@ -144,7 +144,15 @@ def main():
         import torch
         uid = [engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        e.comm_init(uid[0])
+        # RCCL prints a version banner on stdout at communicator creation: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            e.comm_init(uid[0])
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     attach_map(e, m)
     ranges = make_ranges(engine, m, stream, total_steps, ba, sigma, r_max)
     e.init_particles()

@@ -1,10 +1,12 @@
 #!/bin/bash
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
 for m in mesh grid; do
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof5_${m} -- python3 $R/bench.py --map $m --steps 50 --warmup 5 > $R/gpurun_out/bench5_${m}_prof.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc5_${m}_fetch -- python3 $R/bench.py --map $m --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc5_${m}_write -- python3 $R/bench.py --map $m --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/pmc5_${m}_sq -- python3 $R/bench.py --map $m --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof7_${m} -- python3 $R/bench.py --map $m --steps 50 --warmup 5 > $R/gpurun_out/bench7_${m}_prof.log 2>&1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof5_meshgen -- python3 $R/bench.py --map mesh --mesh-general --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/bench5_meshgen.log 2>&1
-echo done
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof7_meshgen -- python3 $R/bench.py --map mesh --mesh-general --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/bench7_meshgen.log 2>&1
+cd $R
+python bench.py > gpurun_out/bench7_mesh.json 2> gpurun_out/bench7_mesh.err
+python bench.py --map grid > gpurun_out/bench7_grid.json 2> gpurun_out/bench7_grid.err
+MCL_FORCE_COMM=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench7_mesh_rccl1.json 2> gpurun_out/bench7_rccl1.err
+wc -l gpurun_out/bench7_mesh.json gpurun_out/bench7_mesh_rccl1.json
+cut -c1-160 gpurun_out/bench7_mesh.json
