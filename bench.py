@@ -233,11 +233,13 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic,
                          'rays_per_s': round(P * B / (dom_ms * 1e-3), 1),
-                         'valu_issue_frac': (round(pmc['valu_insts_per_launch'] * 4.0 / (dom_ms * 1e-3 * 2.4e9 * 1024), 3)
-                                             if pmc.get('valu_insts_per_launch') and traffic else None),
-                         'note': 'the ray-cast is VALU-issue-bound, not HBM-bound (SURVEY 8d): valu_issue_frac = PMC '
-                                 'SQ_INSTS_VALU x 4 cycles / (kernel time x 1024 SIMDs x 2.4 GHz); streaming kernels '
-                                 'are listed in "kernels" with their own HBM fractions'},
+                         'valu_insts_per_ray': (round(pmc['valu_insts_per_launch'] * 64.0 / (P * B), 1)
+                                                if pmc.get('valu_insts_per_launch') and traffic else None),
+                         'valu_lane_utilisation': (round(pmc['valu_lane_utilisation'], 3)
+                                                   if pmc.get('valu_lane_utilisation') and traffic else None),
+                         'note': 'the ray-cast is VALU-issue-bound, not HBM-bound (SURVEY 8d): PMC SQ_INSTS_VALU wave-'
+                                 'instructions per ray-lane and the fraction of lanes active in them (profiles/'
+                                 'r01_traffic.json); streaming kernels are listed in "kernels" with their own HBM fractions'},
             'kernels': kernels,
             'pose_rmse_m': round(pose_rmse, 4),
         }

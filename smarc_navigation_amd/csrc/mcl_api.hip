@@ -853,6 +853,12 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   else
     LAUNCH_CAST(1);
 #undef LAUNCH_CAST
+  if (getenv("MCL_DEBUG_WORK")) {  // diagnostics: how many groups the fast kernel deferred
+    int cnt = 0;
+    hipMemcpyAsync(&cnt, a.work_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    hipStreamSynchronize(h->stream);
+    fprintf(stderr, "[mbes] deferred %d of %lld groups\n", cnt, ngroups);
+  }
   t_end(h);
   HIPCHK(h, hipGetLastError());
   return MCL_OK;

@@ -481,7 +481,9 @@ __device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int t
 template <int MAP, bool EXPECT_ONLY, int MODE>
 __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MIN_WAVES_MESH : MBES_MIN_WAVES_PER_SIMD))
     k_mbes_cast(MbesArgs a) {
-  __shared__ __attribute__((aligned(16))) float tile[MBES_TILE_FLOATS];
+  // general mesh tiles hold 8-byte cell words and run 3 workgroups per CU: give them 48 KiB
+  constexpr int TILE_FLOATS = MAP == 1 ? (MBES_TILE_FLOATS * 3) / 2 : MBES_TILE_FLOATS;
+  __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS];
   __shared__ float red[5][MBES_WAVES];  // umin, umax, vmin, vmax, zmax per wave
 
   const int lane = threadIdx.x & 63;
@@ -490,7 +492,7 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
   const float inv_res = (float)a.inv_res;
   // window limits: grid nodes nx x ny; mesh cells (nx-1) x (ny-1)
   const int lim_x = MAP != 1 ? a.nx - 1 : a.nx - 2, lim_y = MAP != 1 ? a.ny - 1 : a.ny - 2;
-  const int tile_cap = MAP != 1 ? MBES_TILE_FLOATS : MBES_TILE_FLOATS / 2;
+  const int tile_cap = MAP != 1 ? TILE_FLOATS : TILE_FLOATS / 2;
 
   const long long nwork = MODE == 1 ? (long long)*a.work_count : ngroups;
   for (long long it = blockIdx.x; it < nwork; it += gridDim.x) {
@@ -599,7 +601,8 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
     if (MODE == 0) {
       // block-uniform vote: every valid sensor must sit inside the (unclipped) tile with a cell of margin
       const float ul = (float)(P.um - (double)tx0), vl = (float)(P.vm - (double)ty0);
-      const bool inside = !valid || (ul >= 1.f && vl >= 1.f && ul <= (float)(tw - 2) && vl <= (float)(th - 2));
+      const int ncx = MAP == 1 ? tw : tw - 1, ncy = MAP == 1 ? th : th - 1;  // cells in the tile
+      const bool inside = !valid || (ul >= 1.f && vl >= 1.f && ul < (float)(ncx - 1) && vl < (float)(ncy - 1));
       if (lane == 0) red[4][w] = inside ? 1.f : 0.f;
       __syncthreads();
       float ok = red[4][lane & (MBES_WAVES - 1)];
