@@ -15,6 +15,7 @@
 #include "mcl_kernels.h"
 #include "mcl_mbes.h"
 #include "mcl_mesh.h"
+#include "mcl_mbes_profile.h"
 #include "mcl_resample_alt.h"
 #include "mcl_landmarks.h"
 
@@ -75,6 +76,7 @@ struct mcl_handle {
   int beams_cap = 0;
   std::vector<float> beam_cache;  // last uploaded angles
   int beam_lo = -1, beam_hi = -1;  // extreme-angle beams (footprint shortcut)
+  bool beams_sorted = false;
   float* grid = nullptr;
   int gnx = 0, gny = 0;
   double gox = 0, goy = 0, gres = 1;
@@ -740,6 +742,9 @@ int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, i
     const bool ok = finite && (double)beam_angles[hi] - (double)beam_angles[lo] < 3.0;  // span < pi
     h->beam_lo = ok ? lo : -1;
     h->beam_hi = ok ? hi : -1;
+    bool asc = finite;
+    for (int b = 1; b < B && asc; ++b) asc = beam_angles[b] >= beam_angles[b - 1];
+    h->beams_sorted = asc;
   }
   if (ranges)
     HIPCHK(h, hipMemcpyAsync(h->ranges_dev, ranges, sizeof(float) * (size_t)B, hipMemcpyHostToDevice, h->stream));
@@ -774,6 +779,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.beam_sc = h->beam_sc;
   a.ranges = with_ranges ? h->ranges_dev : nullptr;
   a.n_beams = B;
+  a.sorted = h->beams_sorted ? 1 : 0;
   a.b_lo = h->beam_lo;
   a.b_hi = h->beam_hi;
   a.inv_sigma = (float)(1.0 / sigma);
@@ -848,8 +854,22 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   } while (0)
   if (h->map_kind == 0)
     LAUNCH_CAST(0);
-  else if (h->mesh->heights && !h->force_general_mesh)
-    LAUNCH_CAST(2);
+  else if (h->mesh->heights && !h->force_general_mesh) {
+    // per-ray fast traversal by default; MCL_PROFILE=1 selects the experimental profile-marching kernel
+    // (exact and tested, but measured slower in round 1: 3.7 ms vs 2.9 ms at 1 M x 512 -- DESIGN.md 5c)
+    const char* p_env = getenv("MCL_PROFILE");
+    if (!(p_env && p_env[0] == '1')) {
+      LAUNCH_CAST(2);
+    } else {
+      if (with_ranges) {
+        k_mbes_profile<false><<<grid, MBES_THREADS, 0, h->stream>>>(a);
+        k_mbes_cast<2, false, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);
+      } else {
+        k_mbes_profile<true><<<grid, MBES_THREADS, 0, h->stream>>>(a);
+        k_mbes_cast<2, true, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);
+      }
+    }
+  }
   else
     LAUNCH_CAST(1);
 #undef LAUNCH_CAST

@@ -58,6 +58,7 @@ struct MbesArgs {
   const float2* beam_sc;  // (sin a_b, cos a_b)
   const float* ranges;    // measured
   int n_beams;
+  int sorted;             // 1: beam angles ascend with the beam index
   int b_lo, b_hi;         // indices of the extreme beam angles (span < pi), or -1: scan every beam for the footprint
   const float* grid;      // z[ix*ny + iy]
   int nx, ny;             // grid: nodes; mesh: cells + 1
