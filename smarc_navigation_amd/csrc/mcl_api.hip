@@ -817,7 +817,6 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.res = (float)h->gres;
     a.zmin_map = h->gzmin;
     a.zmax_map = h->gzmax;
-    a.chain = 1;  // a height grid is single-valued by construction
   } else {
     const MeshDev* m = h->mesh;
     a.mesh = mesh_args(m);
@@ -830,7 +829,6 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.res = (float)m->cs;
     a.zmin_map = m->zmin;
     a.zmax_map = m->zmax;
-    a.chain = h->mesh_heightfield ? 1 : 0;
   }
   const long long ngroups = (h->n + MBES_WAVES - 1) / MBES_WAVES;
   const int grid = (int)(ngroups < 4096 ? ngroups : 4096);

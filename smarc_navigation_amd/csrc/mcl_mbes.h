@@ -74,7 +74,6 @@ struct MbesArgs {
   int* worklist;          // group ids deferred by the fast kernel (capacity = number of groups)
   int* work_count;        // device counter, zeroed before every fast launch
   unsigned long long* stats;  // MBES_STATS builds: steps, exact tests, rays, retries
-  int chain;              // 1: map declared a height field (single-valued z(x,y)); reserved for profile marching
 };
 
 #ifdef MBES_STATS
