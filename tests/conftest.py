@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Built artefacts are git-ignored: in a fresh checkout compile libmcl_hip.so (hipcc cross-compiles
+    without a GPU) before the ABI tests look for it.  On the GPU box the prebuilt file travels along."""
+    import shutil
+    import subprocess
+    so = os.path.join(ROOT, 'smarc_navigation_amd', 'libmcl_hip.so')
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(so) and os.path.exists(hipcc):
+        subprocess.call(['make', '-C', os.path.join(ROOT, 'smarc_navigation_amd', 'csrc'), 'HIPCC=' + hipcc],
+                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
 def _has_gpu():
     try:
         import torch
