@@ -67,9 +67,9 @@ def attach_map(e, m):
         e.set_map_mesh(m['verts'], m['tris'], general=(a_mesh_general[0]))
 
 
-def make_ranges(engine_mod, m, stream, n_steps, beam_angles, sigma, r_max):
+def make_ranges(engine_mod, m, stream, n_steps, beam_angles, sigma, r_max, device=0):
     """Synthetic pings: expected ranges at the truth pose (one-particle engine on the GPU) + noise."""
-    e = engine_mod.Engine(1, rng_mode=engine_mod.RNG_REPLAY)
+    e = engine_mod.Engine(1, rng_mode=engine_mod.RNG_REPLAY, device=device)  # this rank's own GPU
     attach_map(e, m)
     rs = np.random.RandomState(4)
     out = np.zeros((n_steps, beam_angles.size), np.float32)
@@ -154,7 +154,7 @@ def main():
             os.dup2(saved, 1)
             os.close(saved)
     attach_map(e, m)
-    ranges = make_ranges(engine, m, stream, total_steps, ba, sigma, r_max)
+    ranges = make_ranges(engine, m, stream, total_steps, ba, sigma, r_max, device=local_rank)
     e.init_particles()
 
     def barrier():
