@@ -123,6 +123,8 @@ def main():
         a.gpus = world
     dist = None
     if world > 1:
+        # torch first: its bundled HIP runtime / RCCL are then the single copies in the process and
+        # libmcl_hip.so binds to them (loading the library first would map a second HIP runtime)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)
