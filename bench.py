@@ -80,9 +80,11 @@ def make_ranges(engine_mod, m, stream, n_steps, beam_angles, sigma, r_max, devic
     return out
 
 
-def cpu_baseline(m, stream, ranges, beam_angles, sigma, r_max, cov, n_full, n_sample):
-    """The oracle (C restatement, one host thread) on a bounded sample of the same workload."""
+def cpu_baseline(m, stream, ranges, beam_angles, sigma, r_max, cov, n_full, n_sample, threads, budget_s):
+    """The oracle (C restatement; its particle loops run on `threads` host threads) on a bounded
+    sample of the same workload."""
     from oracle import oracle as orc
+    threads = orc.set_threads(threads)
     amap = orc.Grid(m['z'], m['origin'], m['res']) if m['kind'] == 'grid' else orc.Mesh(m['verts'], m['tris'])
     n = n_sample
     soa = np.zeros((6, n))
@@ -104,13 +106,13 @@ def cpu_baseline(m, stream, ranges, beam_angles, sigma, r_max, cov, n_full, n_sa
         sq_err += (m6[0] - stream['truth'][k][0]) ** 2 + (m6[1] - stream['truth'][k][1]) ** 2
         steps += 1
         el = time.perf_counter() - t0
-        if el > 12.0 or steps >= min(len(ranges), 20):
+        if el > budget_s or steps >= min(len(ranges), 20):
             break
     per_step = el / steps
-    return dict(value=(n / float(n_full)) / per_step, unit='steps/s', cores=1, kind='port',
+    return dict(value=(n / float(n_full)) / per_step, unit='steps/s', cores=threads, kind='port',
                 pose_rmse_m=round(float(np.sqrt(sq_err / steps)), 4),
-                sample='%d particles x %d beams x %d steps of the same stream+map on 1 host thread (%.2f s/step), '
-                       'scaled linearly to %d particles' % (n, beam_angles.size, steps, per_step, n_full))
+                sample='%d particles x %d beams x %d steps of the same stream+map on %d host thread(s) (%.2f s/step), '
+                       'scaled linearly to %d particles' % (n, beam_angles.size, steps, threads, per_step, n_full))
 
 
 def main():
@@ -246,8 +248,14 @@ def main():
             'pose_rmse_m': round(pose_rmse, 4),
         }
         if world == 1 and not a.no_cpu_baseline:
+            # all host cores (the oracle's particle loops are OpenMP-parallel) and, beside it, one thread
             ns = a.cpu_particles or (8192 if m['kind'] == 'grid' else 4096)
-            out['cpu_baseline'] = cpu_baseline(m, stream, ranges, ba, sigma, r_max, cov, 1048576, ns)
+            cores = len(os.sched_getaffinity(0))
+            one = cpu_baseline(m, stream, ranges, ba, sigma, r_max, cov, 1048576, ns, 1, 8.0)
+            allc = cpu_baseline(m, stream, ranges, ba, sigma, r_max, cov, 1048576, ns * min(cores, 32), cores, 10.0)
+            allc['value_1thread'] = one['value']
+            allc['sample_1thread'] = one['sample']
+            out['cpu_baseline'] = allc
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -2,6 +2,9 @@
  * TEST INFRASTRUCTURE, NOT PRODUCT.  Build: make -C oracle  (gcc -O2 -ffp-contract=off).
  * Citations are relative to /root/reference/auv_particle_filter/scripts/. */
 #include "mcl_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -109,7 +112,20 @@ static void mat3_mul(const double A[9], const double B[9], double C[9]) {
 }
 
 /* ------------------------------------------------------------------ a2 add_noise */
+/* host threads used by the particle-parallel loops (add_noise, predict, native_normals, mbes_update);
+ * results do not depend on the count.  Returns the count in effect. */
+int orc_set_threads(int nthreads) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  return omp_get_max_threads();
+#else
+  (void)nthreads;
+  return 1;
+#endif
+}
+
 void orc_add_noise(int n, double* state, const double cov[6], const double* normals) {
+  #pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i)
     for (int c = 0; c < 6; ++c) ST(c, i) = ST(c, i) + sqrt(cov[c]) * normals[(size_t)i * 6 + c];
 }
@@ -129,6 +145,7 @@ void orc_predict(int n, double* state, const double v[3], double wz, const doubl
   const double Rx[9] = {1.0, 0.0, 0.0, 0.0, cr, -sr, 0.0, sr, cr};
   double M1[9];
   mat3_mul(Ry, Rx, M1);
+  #pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     double nz[6] = {0, 0, 0, 0, 0, 0};
     if (normals)
@@ -545,6 +562,7 @@ static void box_muller(uint32_t a, uint32_t b, double* n0, double* n1) {
 }
 
 void orc_native_normals(int n, int64_t gid0, uint64_t seed, uint32_t purpose, uint32_t step, double* normals) {
+  #pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     uint32_t gid = (uint32_t)(gid0 + i);
     uint32_t o[4];
@@ -860,6 +878,8 @@ void orc_mbes_update(int n, const double* state, const double m2o[16], const dou
   rot_rpy(sensor_off[3], sensor_off[4], sensor_off[5], Ro);
   double Rm[9] = {m2o[0], m2o[1], m2o[2], m2o[4], m2o[5], m2o[6], m2o[8], m2o[9], m2o[10]};
   const double lognorm = log(sigma * sqrt(2.0 * PI));
+  /* particles are independent: the loop is shared over the host threads (orc_set_threads) */
+#pragma omp parallel for schedule(dynamic, 8)
   for (int i = 0; i < n; ++i) {
     double Rp[9], Rmp[9], Rs[9];
     rot_rpy(ST(3, i), ST(4, i), ST(5, i), Rp);

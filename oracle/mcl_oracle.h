@@ -29,6 +29,7 @@ void orc_matrix_from_tf(const double t[3], const double q[4], double M[16]); /* 
 double orc_wrap_pi(double a);                                                 /* auv_particle.py:48 */
 
 /* ---- a2: Particle.add_noise (auv_particle.py:32-36). normals: n x 6, particle-major */
+int orc_set_threads(int nthreads);
 void orc_add_noise(int n, double* state, const double cov[6], const double* normals);
 /* ---- a4/a5: Particle.motion_pred + fullRotation (auv_particle.py:38-97). normals n x 6 or NULL */
 void orc_predict(int n, double* state, const double v[3], double wz, const double q[4], double z,

@@ -61,6 +61,7 @@ def _load():
         'orc_systematic_ncum': (None, [i, _u64p, u64, u64, i64, u64, _u32p]),
         'orc_indices_from_ncum': (None, [i64, _u32p, i64, i64, _i32p]),
         'orc_philox4x32': (None, [u32, u32, u32, u32, u32, u32, _u32p]),
+        'orc_set_threads': (C.c_int, [C.c_int]),
         'orc_native_normals': (None, [i, i64, u64, u32, u32, _f64p]),
         'orc_native_u53': (u64, [u64, u32]),
         'orc_ray_grid': (d, [C.POINTER(_Grid), _f64p, _f64p, d]),
@@ -255,6 +256,11 @@ def philox(c, k):
     out = np.zeros(4, np.uint32)
     _L.orc_philox4x32(c[0], c[1], c[2], c[3], k[0], k[1], out)
     return out
+
+
+def set_threads(nthreads):
+    """Host threads for the particle-parallel loops (0 = leave as is); returns the count in effect."""
+    return int(_L.orc_set_threads(int(nthreads)))
 
 
 def native_normals(n, gid0, seed, purpose, step):
