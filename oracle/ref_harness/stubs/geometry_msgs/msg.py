@@ -61,3 +61,16 @@ class TwistWithCovariance(object):
     def __init__(self):
         self.twist = Twist()
         self.covariance = [0.0] * 36
+
+
+class Transform(object):
+    def __init__(self):
+        self.translation = Vector3()
+        self.rotation = Quaternion()
+
+
+class TransformStamped(object):
+    def __init__(self):
+        self.header = _Header()
+        self.child_frame_id = ''
+        self.transform = Transform()

@@ -62,6 +62,10 @@ class Publisher(object):
 class Subscriber(object):
     def __init__(self, topic, typ, cb, queue_size=1):
         self.topic, self.cb = topic, cb
+        self.registered = True
+
+    def unregister(self):
+        self.registered = False
 
 
 class Timer(object):

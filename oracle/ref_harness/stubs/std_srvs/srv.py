@@ -1,2 +1,10 @@
 class Empty(object):
     pass
+
+
+class SetBool(object):
+    pass
+
+
+class SetBoolRequest(object):
+    pass

@@ -19,6 +19,12 @@ class TransformListener(object):
 
     def __init__(self):
         self.utm2map = None  # 4x4
+        self.frames = {}     # (target, source) -> (translation, quaternion) for lookupTransform
+
+    def lookupTransform(self, target, source, stamp):
+        if (target, source) not in self.frames:
+            raise LookupException()
+        return self.frames[(target, source)]
 
     def transformPoint(self, frame, pt):
         import numpy as np

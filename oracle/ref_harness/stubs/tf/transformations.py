@@ -104,3 +104,12 @@ def rotation_matrix(angle, direction, point=None):
     M = np.identity(4)
     M[:3, :3] = R
     return M
+
+
+def quaternion_multiply(quaternion1, quaternion0):
+    x0, y0, z0, w0 = quaternion0
+    x1, y1, z1, w1 = quaternion1
+    return np.array([x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0,
+                     -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0,
+                     x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0,
+                     -x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0])

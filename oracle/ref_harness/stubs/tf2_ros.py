@@ -9,3 +9,11 @@ class Buffer(object):
 class TransformListener(object):
     def __init__(self, buf):
         pass
+
+
+class StaticTransformBroadcaster(object):
+    def __init__(self):
+        self.sent = []
+
+    def sendTransform(self, ts):
+        self.sent.append(ts)

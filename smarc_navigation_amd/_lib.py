@@ -1,4 +1,4 @@
-"""ctypes loader for libmcl_hip.so (the C ABI in include/mcl.h).
+"""ctypes loader for libmcl_hip.so (the C ABI in include/mcl.h and include/mcl_dr.h).
 
 Fails loudly when the shared library is missing: there is no Python/CPU fallback for the hot
 path.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
@@ -31,11 +31,21 @@ class Odom(C.Structure):
                 ('z', C.c_double)]
 
 
+class DrConfig(C.Structure):
+    _fields_ = [('dvl_period', C.c_double), ('dr_period', C.c_double)]
+
+
+class DrOdom(C.Structure):
+    _fields_ = [('published', C.c_int32), ('used_dvl', C.c_int32), ('t_now', C.c_double), ('pos', C.c_double * 3),
+                ('q', C.c_double * 4), ('rpy', C.c_double * 3), ('lin_vel', C.c_double * 3),
+                ('ang_vel', C.c_double * 3)]
+
+
 class Timing(C.Structure):
     _fields_ = [('ms', C.c_double * 9), ('launches', C.c_int64 * 9)]
 
 
-# every symbol include/mcl.h declares: name -> (restype, argtypes)
+# every symbol include/mcl.h and include/mcl_dr.h declare: name -> (restype, argtypes)
 _vp, _i32, _i64, _d = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 SYMBOLS = {
     'mcl_abi_version': (C.c_int, []),
@@ -77,6 +87,18 @@ SYMBOLS = {
     'mcl_group_mean_cov': (C.c_int, [C.POINTER(_vp), _i32, _vp, _vp, _vp]),
     'mcl_timing_enable': (C.c_int, [_vp, _i32]),
     'mcl_timing_get': (C.c_int, [_vp, C.POINTER(Timing)]),
+    # include/mcl_dr.h: the dead-reckoning integrator (host only)
+    'mcl_dr_create': (C.c_int, [C.POINTER(DrConfig), C.POINTER(_vp)]),
+    'mcl_dr_destroy': (None, [_vp]),
+    'mcl_dr_heading': (C.c_int, [_vp, _vp]),
+    'mcl_dr_gps': (C.c_int, [_vp, _d, _d, C.c_int, _vp, C.POINTER(C.c_int), _vp, _vp]),
+    'mcl_dr_imu': (C.c_int, [_vp, _d, _vp, _vp]),
+    'mcl_dr_dvl': (C.c_int, [_vp, _d, _vp]),
+    'mcl_dr_depth': (C.c_int, [_vp, _d]),
+    'mcl_dr_thrust_cmd': (C.c_int, [_vp, _d]),
+    'mcl_dr_thrust': (C.c_int, [_vp, _d, _d]),
+    'mcl_dr_tick': (C.c_int, [_vp, C.POINTER(DrOdom)]),
+    'mcl_dr_to_odom': (C.c_int, [C.POINTER(DrOdom), _d, C.POINTER(Odom)]),
 }
 
 _lib = None

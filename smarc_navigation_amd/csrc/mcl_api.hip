@@ -163,21 +163,21 @@ void t_begin(mcl_handle* h, int k) {
     ev = h->ev_pool.back();
     h->ev_pool.pop_back();
   } else {
-    hipEventCreate(&ev.first);
-    hipEventCreate(&ev.second);
+    (void)hipEventCreate(&ev.first);
+    (void)hipEventCreate(&ev.second);
   }
-  hipEventRecord(ev.first, h->stream);
+  (void)hipEventRecord(ev.first, h->stream);
   h->regions.push_back(TimedRegion{ev.first, ev.second, k});
 }
 void t_end(mcl_handle* h) {
   if (!h->timing) return;
-  hipEventRecord(h->regions.back().b, h->stream);
+  (void)hipEventRecord(h->regions.back().b, h->stream);
 }
 void t_collect(mcl_handle* h) {
   for (auto& r : h->regions) {
     float ms = 0.f;
-    hipEventSynchronize(r.b);
-    hipEventElapsedTime(&ms, r.a, r.b);
+    (void)hipEventSynchronize(r.b);
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
     h->tacc.ms[r.k] += ms;
     h->tacc.launches[r.k] += 1;
     h->ev_pool.push_back({r.a, r.b});
@@ -716,8 +716,8 @@ void finish_mean_cov(const mcl_handle* h, double mean6[6], double* yaw_mean, dou
 // ------------------------------------------------------------------------------------------ MBES
 int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, int B) {
   if (B > h->beams_cap) {
-    if (h->beam_sc) hipFree(h->beam_sc);
-    if (h->ranges_dev) hipFree(h->ranges_dev);
+    if (h->beam_sc) (void)hipFree(h->beam_sc);
+    if (h->ranges_dev) (void)hipFree(h->ranges_dev);
     HIPCHK(h, hipMalloc(&h->beam_sc, sizeof(float2) * (size_t)B));
     HIPCHK(h, hipMalloc(&h->ranges_dev, sizeof(float) * (size_t)B));
     h->beams_cap = B;
@@ -873,8 +873,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
 #undef LAUNCH_CAST
   if (getenv("MCL_DEBUG_WORK")) {  // diagnostics: how many groups the fast kernel deferred
     int cnt = 0;
-    hipMemcpyAsync(&cnt, a.work_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
-    hipStreamSynchronize(h->stream);
+    (void)hipMemcpyAsync(&cnt, a.work_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    (void)hipStreamSynchronize(h->stream);
     fprintf(stderr, "[mbes] deferred %d of %lld groups\n", cnt, ngroups);
   }
   t_end(h);
@@ -922,6 +922,9 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
 }
 
 }  // namespace
+
+// dead-reckoning integrator (host only; uses euler_from_quat above)
+#include "mcl_dr_impl.h"
 
 // ============================================================================================ C ABI
 extern "C" {
@@ -1064,29 +1067,29 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
 
 int mcl_destroy(mcl_handle* h) {
   if (!h) return MCL_OK;
-  hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   t_collect(h);
   for (auto& e : h->ev_pool) {
-    hipEventDestroy(e.first);
-    hipEventDestroy(e.second);
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
   }
   if (h->comm2) ncclCommDestroy(h->comm2);
   if (h->comm) ncclCommDestroy(h->comm);
-  if (h->comm_stream) hipStreamDestroy(h->comm_stream);
-  if (h->ev_state_ready) hipEventDestroy(h->ev_state_ready);
-  if (h->ev_gather_done) hipEventDestroy(h->ev_gather_done);
+  if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+  if (h->ev_state_ready) (void)hipEventDestroy(h->ev_state_ready);
+  if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
                   h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev};
   for (void* b : bufs)
-    if (b) hipFree(b);
+    if (b) (void)hipFree(b);
   if (h->mesh) mesh_free(h->mesh);
   if (h->landmarks) landmarks_free(h->landmarks);
-  if (h->det_dev) hipFree(h->det_dev);
-  if (h->host_pin) hipHostFree(h->host_pin);
-  if (h->stream) hipStreamDestroy(h->stream);
+  if (h->det_dev) (void)hipFree(h->det_dev);
+  if (h->host_pin) (void)hipHostFree(h->host_pin);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return MCL_OK;
 }
@@ -1145,7 +1148,7 @@ int mcl_set_map_grid(mcl_handle* h, const float* z, int32_t nx, int32_t ny, doub
   if (!h || !z || nx < 2 || ny < 2 || !(res > 0.0)) return fail(h, MCL_ERR_INVALID, "set_map_grid: bad argument");
   RET_IF(set_device(h));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (h->grid) hipFree(h->grid);
+  if (h->grid) (void)hipFree(h->grid);
   h->grid = nullptr;
   const size_t cnt = (size_t)nx * (size_t)ny;
   HIPCHK(h, hipMalloc(&h->grid, sizeof(float) * cnt));
@@ -1215,7 +1218,7 @@ int mcl_mbes_expected(mcl_handle* h, int64_t first, int64_t count, const float* 
   RET_IF(upload_beams(h, nullptr, beam_angles, B));
   const size_t need = (size_t)count * (size_t)B;
   if (need > h->exp_cap) {
-    if (h->exp_dev) hipFree(h->exp_dev);
+    if (h->exp_dev) (void)hipFree(h->exp_dev);
     h->exp_dev = nullptr;
     HIPCHK(h, hipMalloc(&h->exp_dev, sizeof(float) * need));
     h->exp_cap = need;
@@ -1251,7 +1254,7 @@ int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, do
     return rc;
   }
   if (n_det > h->det_cap) {
-    if (h->det_dev) hipFree(h->det_dev);
+    if (h->det_dev) (void)hipFree(h->det_dev);
     h->det_dev = nullptr;
     HIPCHK(h, hipMalloc(&h->det_dev, sizeof(double) * 3 * (size_t)n_det));
     h->det_cap = n_det;

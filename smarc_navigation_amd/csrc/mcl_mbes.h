@@ -678,8 +678,7 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
     const float v0 = use == 1 ? (float)(P.vm - (double)ty0) : (float)P.vm;
     // lanes = consecutive beams (coherent: neighbouring lanes walk neighbouring cells)
     RayStats rs = {0, 0, 0, 0};
-    // wave-uniform choice: the fast traversal needs an unclipped tile and the sensor inside it
-    const bool fast = MODE == 0;  // MODE 0 reaches this point only with every wave eligible
+    // MODE 0 reaches this point only with every wave eligible for the fast traversal
     for (int b = lane; b < a.n_beams; b += 64) {
       const float2 sc = a.beam_sc[b];
       const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];

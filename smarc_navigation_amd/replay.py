@@ -10,6 +10,8 @@ RMSE between the PF mean pose and a reference track (the "pose RMSE vs ref" of t
 Stream file (np.savez): stamp[n], v[n,3], wz[n], q[n,4], z[n]  (odometry, /sam/dr/odom);
 optional gps_idx[k], gps_xy_utm[k,2]; optional mbes_idx[m], mbes_ranges[m,B], mbes_angles[B],
 mbes_range_max; optional dr_xyz[n,3] (dead-reckoning track), truth_xyz[n,3]; t0.
+A raw-sensor file (ev_t, ev_kind, ev_data as synth.raw_sensor_events makes them; optional gps_map,
+pressure_tf) is first run through the dead-reckoning integrator (--raw).
 
     python -m smarc_navigation_amd.replay stream.npz --particles 65536 [--map-grid map.npz] [--out traj.csv]
 """
@@ -32,6 +34,25 @@ def track_metrics(vec):
 def pose_rmse(est_xy, ref_xy):
     d = np.asarray(est_xy, dtype=np.float64) - np.asarray(ref_xy, dtype=np.float64)
     return float(np.sqrt(np.mean(np.sum(d * d, axis=1))))
+
+
+def odom_stream_from_raw(t, kind, data, gps_map=None, pressure_tf=None, dvl_period=0.2, dr_period=0.02):
+    """Raw IMU / DVL / depth / thruster events (synth.raw_sensor_events format) -> the odometry stream
+    `replay` consumes, through the dead-reckoning integrator (dr.py): one sample
+    per published timer tick, stamped with the tick's event time.  Also returns the map -> odom
+    transform the integrator fixed from the first usable GPS fix (4x4) for the filter's m2o."""
+    from . import dr, synth
+    from . import auv_pf as node
+    ticks, m2o = dr.replay_events(t, kind, data, gps_map=gps_map, pressure_tf=pressure_tf, dvl_period=dvl_period,
+                                  dr_period=dr_period)
+    tick_t = np.asarray(t)[np.asarray(kind) == synth.EV_TICK]
+    pub = ticks[:, 0] > 0
+    stream = dict(stamp=tick_t[pub], v=ticks[pub, 8:11], wz=ticks[pub, 13], q=ticks[pub, 4:8], z=ticks[pub, 3],
+                  dr_xyz=ticks[pub, 1:4])
+    if pub.any():
+        stream['t0'] = float(stream['stamp'][0]) - dr_period
+    m2o_mat = None if np.isnan(m2o).any() else node.matrix_from_tf(m2o[0:3], m2o[3:7])
+    return stream, m2o_mat
 
 
 def replay(stream, params=None, m2o=None, utm2map=None, grid=None, mesh=None, publish_every=5):
@@ -87,10 +108,18 @@ def main(argv=None):
     ap.add_argument('--map-grid', help='npz with z, origin, res')
     ap.add_argument('--out', help='CSV of the published mean pose')
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--raw', action='store_true', help='the file holds raw sensor events: integrate them first')
     a = ap.parse_args(argv)
     stream = dict(np.load(a.stream, allow_pickle=False))
+    m2o = None
+    if a.raw:
+        ptf = stream.get('pressure_tf')
+        if ptf is not None and np.isnan(ptf).any():
+            ptf = None
+        stream, m2o = odom_stream_from_raw(stream['ev_t'], stream['ev_kind'], stream['ev_data'],
+                                           gps_map=stream.get('gps_map'), pressure_tf=ptf)
     grid = dict(np.load(a.map_grid)) if a.map_grid else None
-    res = replay(stream, dict(particle_count=a.particles, seed=a.seed), grid=grid)
+    res = replay(stream, dict(particle_count=a.particles, seed=a.seed), m2o=m2o, grid=grid)
     if a.out:
         np.savetxt(a.out, np.column_stack([res['pub_idx'], res['pf_xyz']]), delimiter=',', header='step,x,y,z')
     print(json.dumps(res['summary']))

@@ -137,3 +137,69 @@ def beam_angles(n_beams, half_swath=math.pi / 3):
     if n_beams == 1:
         return np.zeros(1, dtype=np.float32)
     return np.linspace(-half_swath, half_swath, n_beams).astype(np.float32)
+
+
+# ---------------------------------------------------------------- raw sensor events for the DR integrator
+EV_IMU, EV_HEADING, EV_GPS, EV_DVL, EV_DEPTH, EV_THRUST, EV_THRUST_CMD, EV_TICK = range(8)
+
+
+def raw_sensor_events(duration=40.0, seed=11, scenario='auv', t0=50.0):
+    """Time-ordered raw sensor events for the dead-reckoning integrator (the callbacks of
+    sam_dead_reckoning/scripts/dr_node.py: stim_cb, sbg_cb, gps_cb, dvl_cb, depth_cb, thrust_cb,
+    thrust_cmd_cb, dr_timer).  Returns (t[n], kind[n] int32, data[n, 7]) with data columns:
+      EV_IMU: qx qy qz qw wx wy wz     EV_HEADING: qx qy qz qw     EV_GPS: x y (map frame)
+      EV_DVL: vx vy vz                 EV_DEPTH: z                 EV_THRUST: rpm1 rpm2
+      EV_THRUST_CMD: horizontal_radians                            EV_TICK: (none)
+    scenario 'auv': pressure sensor present, DVL from t0+1 s with outliers that trip the plausibility
+    gates and a 3 s dropout; 'surface': heading arrives after the first GPS fix, DVL starts late."""
+    rs = np.random.RandomState(seed)
+    ev = []
+
+    def add(t, kind, vals=()):
+        row = np.zeros(7)
+        row[:len(vals)] = vals
+        ev.append((t, kind, row))
+
+    surface = scenario == 'surface'
+    # ticks at 50 Hz, IMU at 100 Hz (offset so stamps never tie with ticks)
+    for k in range(int(duration / 0.02)):
+        add(t0 + 0.02 * k + 0.0101, EV_TICK)
+    for k in range(int(duration / 0.01)):
+        t = t0 + 0.01 * k + 0.0033
+        tt = t - t0
+        roll, pitch = 0.03 * math.sin(0.7 * tt), 0.05 * math.cos(0.4 * tt)
+        yaw = 0.3 + 0.2 * math.sin(0.15 * tt)
+        q = quat_from_rpy(roll, pitch, yaw)
+        w = (0.021 * math.cos(0.7 * tt), -0.02 * math.sin(0.4 * tt),
+             0.03 * math.cos(0.15 * tt) + 0.002 * rs.randn())
+        add(t, EV_IMU, (q[0], q[1], q[2], q[3], w[0], w[1], w[2]))
+    add(t0 + (2.5 if surface else 0.0507), EV_HEADING, tuple(quat_from_rpy(0.01, -0.02, 0.9)))
+    for k in range(5):
+        add(t0 + 0.5017 + 1.0 * k, EV_GPS, (12.5 + 0.1 * k, -7.25 - 0.1 * k))
+    dvl_start = 6.0 if surface else 1.0
+    k = 0
+    t = t0 + dvl_start + 0.0049
+    while t < t0 + duration:
+        tt = t - t0
+        if not (20.0 <= tt < 23.0):  # dropout: the motion model takes over
+            v = [1.0 + 0.05 * math.sin(0.1 * tt) + 0.01 * rs.randn(), 0.02 * math.sin(0.3 * tt) + 0.005 * rs.randn(),
+                 0.01 * rs.randn()]
+            if k % 17 == 5:
+                v[1] = 0.25      # |vy| gate
+            if k % 23 == 7:
+                v[0] = 1.7       # |vx| gate
+            if k % 29 == 11:
+                v[0] = -0.2      # reverse gate
+            add(t, EV_DVL, v)
+        k += 1
+        t += 0.2 + (0.013 if k % 7 == 0 else 0.0)  # an occasional late message trips the age gate
+    for k in range(int(duration / 0.1)):
+        tt = 0.1 * k + 0.0071
+        add(t0 + tt, EV_DEPTH, (-2.0 - 0.5 * math.sin(0.05 * tt) + 0.01 * rs.randn(),))
+        add(t0 + tt + 0.0013, EV_THRUST, (float(int(400 + 50 * math.sin(0.2 * tt))), float(int(380 + 40 * math.cos(0.1 * tt)))))
+    for k in range(int(duration / 0.5)):
+        tt = 0.5 * k + 0.0191
+        add(t0 + tt, EV_THRUST_CMD, (0.2 * math.sin(0.3 * tt),))  # beyond the 7 degree clip at the peaks
+    ev.sort(key=lambda e: (e[0], e[1]))
+    return (np.array([e[0] for e in ev]), np.array([e[1] for e in ev], dtype=np.int32),
+            np.stack([e[2] for e in ev]))

@@ -1,4 +1,4 @@
-"""CPU test: libmcl_hip.so loads without a GPU, exports every symbol include/mcl.h declares, the
+"""CPU test: libmcl_hip.so loads without a GPU, exports every symbol include/*.h declare, the
 ctypes table covers all of them, and the product path fails loudly when no device is present."""
 import ctypes
 import os
@@ -10,9 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    src = open(os.path.join(ROOT, 'include', 'mcl.h')).read()
-    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(mcl_[a-z0-9_]+)\s*\(', src)))
+    names = set()
+    for hdr in ('mcl.h', 'mcl_dr.h'):
+        src = open(os.path.join(ROOT, 'include', hdr)).read()
+        src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+        names |= set(re.findall(r'\b(mcl_[a-z0-9_]+)\s*\(', src))
+    return sorted(names)
 
 
 def test_header_symbols_exported_and_bound():

@@ -47,3 +47,34 @@ def test_replay_with_mbes_pings_tracks_the_truth():
     print(s)
     assert s['pf_rmse_vs_truth'] < 0.35
     assert abs(s['pf_distance'] - s['truth_distance']) < 1.0
+
+
+def test_raw_events_become_the_odometry_stream_the_filter_consumes():
+    """Host-only: raw IMU/DVL/depth events -> dead-reckoning integrator -> replay stream."""
+    t, k, d = synth.raw_sensor_events(duration=12.0, seed=4)
+    stream, m2o = rp.odom_stream_from_raw(t, k, d, pressure_tf=(0.3, 0.0, 0.05))
+    n = len(stream['stamp'])
+    assert n > 500 and stream['v'].shape == (n, 3) and stream['q'].shape == (n, 4)
+    assert np.all(np.diff(stream['stamp']) > 0)
+    assert m2o.shape == (4, 4) and m2o[0, 3] == 12.5 and m2o[1, 3] == -7.25
+    # DVL ticks carry the body-frame DVL velocity, the depth is the pressure reading
+    assert np.median(stream['v'][:, 0]) == pytest.approx(1.0, abs=0.1)
+    assert stream['z'].min() < -1.9
+    np.testing.assert_allclose(np.linalg.norm(stream['q'], axis=1), 1.0, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_raw_sensor_replay_without_fixes_follows_dead_reckoning():
+    """Raw events -> DR -> particle filter; with no GPS/MBES correction and small process noise the
+    filter's mean pose must stay on the dead-reckoning track (same motion model)."""
+    t, k, d = synth.raw_sensor_events(duration=20.0, seed=6)
+    stream, m2o = rp.odom_stream_from_raw(t, k, d, pressure_tf=(0.3, 0.0, 0.05))
+    out = rp.replay(stream, dict(particle_count=8192, init_covariance='[0.0, 0.0, 0.0, 0.0, 0.0, 0.0]',
+                                 motion_covariance='[0.000001, 0.000001, 0.0, 0.0, 0.0, 0.0]',
+                                 resampling_noise_covariance='[0.0, 0.0, 0.0, 0.0, 0.0, 0.0]', seed=3), m2o=m2o)
+    s = out['summary']
+    print(s)
+    # the filter integrates the yaw rate once per odometry sample (50 Hz), the integrator once per IMU
+    # sample (100 Hz): the tracks agree to discretisation, so compare path length and depth
+    assert abs(s['pf_distance'] - s['dr_distance']) < 0.05 * s['dr_distance'] + 0.1
+    assert np.allclose(out['pf_xyz'][:, 2], stream['dr_xyz'][out['pub_idx'], 2], atol=1e-9)
