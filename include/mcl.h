@@ -161,6 +161,16 @@ int mcl_mbes_expected(mcl_handle* h, int64_t first, int64_t count, const float* 
 int mcl_set_landmarks(mcl_handle* h, const double* xyz, int64_t n_landmarks);
 int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, double sigma, int32_t k,
                          double gate, const double sensor_offset[6], int32_t accumulate);
+/* Landmark update with a GLOBAL assignment per particle: the correspondence table
+ * of the reference's batch association (auv_ekf_slam/src/ekf_slam_core.cpp:172-178: distance if < gate,
+ * else 10000; :269-281: one new-landmark hypothesis per detection at cost new_mh_dist; :298-312: Munkres
+ * assignment) solved exactly for every particle; lw = -1/2 * optimal total - n_valid * lognorm.  A
+ * landmark explains at most one detection.  n_det <= 16; 1 <= k_cand <= 8 = nearest gated landmarks
+ * kept as candidates of a detection.  assign_out (optional, host): n_keep x n_det int32 for the first
+ * n_keep particles -- landmark index, -1 = new-landmark hypothesis, -2 = invalid (NaN) detection. */
+int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_det, double sigma, int32_t k_cand,
+                                double gate, double new_mh_dist, const double sensor_offset[6], int32_t accumulate,
+                                int32_t* assign_out, int64_t n_keep);
 
 /* ---- a8-a12 + a2: auv_pf.resample (auv_pf.py:169-198): normalise, resample, keep/lost/dupes
  * reassign, add_noise(resampling_noise_covariance).

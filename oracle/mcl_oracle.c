@@ -967,3 +967,142 @@ void orc_landmark_update(int n, const double* state, const double m2o[16], const
     lw[i] = acc - (double)nvalid * lognorm;
   }
 }
+
+/* ------------------------------------------------------------------ landmark update with a global
+ * (Hungarian) assignment -- SURVEY 8(f) rank 4.  The table and its constants follow the reference's
+ * batch association (auv_ekf_slam/src/ekf_slam_core.cpp:172-178 strict gate, 10000 = "infinite";
+ * :269-281 one new-landmark row per detection at cost new_mh_dist; :298-312 Munkres); the particle
+ * filter adaptation (known landmark positions, isotropic sigma, log-weight = -1/2 of the optimal
+ * total) is this build's own definition -> parity unpinned except for the solver, which is pinned
+ * to the reference's Munkres through oracle/_ref (tests/test_oracle_assign.py). */
+
+/* Dense rectangular assignment, n rows (each must be assigned) x m >= n columns (each used at most
+ * once), minimising the total; shortest augmenting paths with row/column potentials.  Returns the
+ * optimal total; col_of_row[r] = chosen column. */
+double orc_assign_dense(int n, int m, const double* cost, int* col_of_row) {
+  double* u = (double*)calloc((size_t)n + 1, sizeof(double));
+  double* v = (double*)calloc((size_t)m + 1, sizeof(double));
+  double* minv = (double*)malloc(((size_t)m + 1) * sizeof(double));
+  int* p = (int*)calloc((size_t)m + 1, sizeof(int));
+  int* way = (int*)calloc((size_t)m + 1, sizeof(int));
+  char* used = (char*)malloc((size_t)m + 1);
+  for (int i = 1; i <= n; ++i) {
+    p[0] = i;
+    int j0 = 0;
+    for (int j = 0; j <= m; ++j) {
+      minv[j] = INFINITY;
+      used[j] = 0;
+    }
+    do {
+      used[j0] = 1;
+      int i0 = p[j0], j1 = 0;
+      double delta = INFINITY;
+      for (int j = 1; j <= m; ++j)
+        if (!used[j]) {
+          double cur = cost[(size_t)(i0 - 1) * m + (j - 1)] - u[i0] - v[j];
+          if (cur < minv[j]) {
+            minv[j] = cur;
+            way[j] = j0;
+          }
+          if (minv[j] < delta) {
+            delta = minv[j];
+            j1 = j;
+          }
+        }
+      for (int j = 0; j <= m; ++j)
+        if (used[j]) {
+          u[p[j]] += delta;
+          v[j] -= delta;
+        } else {
+          minv[j] -= delta;
+        }
+      j0 = j1;
+    } while (p[j0] != 0);
+    do {
+      int j1 = way[j0];
+      p[j0] = p[j1];
+      j0 = j1;
+    } while (j0);
+  }
+  double total = 0.0;
+  for (int j = 1; j <= m; ++j)
+    if (p[j]) {
+      col_of_row[p[j] - 1] = j - 1;
+      total += cost[(size_t)(p[j] - 1) * m + (j - 1)];
+    }
+  free(u);
+  free(v);
+  free(minv);
+  free(p);
+  free(way);
+  free(used);
+  return total;
+}
+
+/* Brute force over ALL landmarks: per particle the dense table (valid detections) x (n_lm landmarks +
+ * one new-landmark column per detection).  k_cand: only the k_cand nearest landmarks inside the gate
+ * stay candidates of a detection (the others become 10000 like gated-out pairs).
+ * lw = -1/2 * optimal total - n_valid * lognorm.  assign_out (optional, n x n_det): landmark index,
+ * -1 = new-landmark hypothesis, -2 = invalid detection. */
+void orc_landmark_assign_update(int n, const double* state, const double m2o[16], const double sensor_off[6],
+                                const double* lm, int64_t n_lm, const double* det, int n_det, double sigma,
+                                int k_cand, double gate, double new_mh_dist, double* lw, int* assign_out) {
+  double Ro[9];
+  rot_rpy(sensor_off[3], sensor_off[4], sensor_off[5], Ro);
+  double Rm[9] = {m2o[0], m2o[1], m2o[2], m2o[4], m2o[5], m2o[6], m2o[8], m2o[9], m2o[10]};
+  const double lognorm = 1.5 * log(2.0 * PI) + 3.0 * log(sigma);
+  const int m = (int)n_lm + n_det;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int i = 0; i < n; ++i) {
+    double Rp[9], Rmp[9], Rs[9];
+    rot_rpy(ST(3, i), ST(4, i), ST(5, i), Rp);
+    mat3_mul(Rm, Rp, Rmp);
+    mat3_mul(Rmp, Ro, Rs);
+    double x = ST(0, i), y = ST(1, i), z = ST(2, i), o[3];
+    for (int r = 0; r < 3; ++r)
+      o[r] = (m2o[r * 4 + 0] * x + m2o[r * 4 + 1] * y + m2o[r * 4 + 2] * z + m2o[r * 4 + 3]) +
+             (Rmp[r * 3 + 0] * sensor_off[0] + Rmp[r * 3 + 1] * sensor_off[1] + Rmp[r * 3 + 2] * sensor_off[2]);
+    double* table = (double*)malloc((size_t)n_det * m * sizeof(double));
+    int* rows = (int*)malloc((size_t)n_det * sizeof(int));
+    int* col = (int*)malloc((size_t)n_det * sizeof(int));
+    double* kth = (double*)malloc((size_t)(k_cand > 0 ? k_cand : 1) * sizeof(double));
+    int nv = 0;
+    for (int d = 0; d < n_det; ++d) {
+      const double* zd = det + 3 * d;
+      if (assign_out) assign_out[(size_t)i * n_det + d] = -2;
+      if (!(zd[0] == zd[0] && zd[1] == zd[1] && zd[2] == zd[2])) continue;
+      double p[3];
+      for (int r = 0; r < 3; ++r) p[r] = o[r] + Rs[r * 3] * zd[0] + Rs[r * 3 + 1] * zd[1] + Rs[r * 3 + 2] * zd[2];
+      double* row = table + (size_t)nv * m;
+      for (int q = 0; q < k_cand; ++q) kth[q] = INFINITY;
+      for (int64_t j = 0; j < n_lm; ++j) {
+        double dx = p[0] - lm[3 * j], dy = p[1] - lm[3 * j + 1], dz = p[2] - lm[3 * j + 2];
+        double mh = (dx * dx + dy * dy + dz * dz) / (sigma * sigma);
+        row[j] = mh < gate ? mh : 10000.0;
+        if (mh < gate) {
+          double t = mh;
+          for (int q = 0; q < k_cand; ++q)
+            if (t < kth[q]) {
+              double s = kth[q];
+              kth[q] = t;
+              t = s;
+            }
+        }
+      }
+      /* keep the k_cand nearest only */
+      const double cut = kth[k_cand - 1];
+      for (int64_t j = 0; j < n_lm; ++j)
+        if (row[j] < 10000.0 && row[j] > cut) row[j] = 10000.0;
+      for (int e = 0; e < n_det; ++e) row[n_lm + e] = e == d ? new_mh_dist : 10000.0;
+      rows[nv++] = d;
+    }
+    double total = nv ? orc_assign_dense(nv, m, table, col) : 0.0;
+    if (assign_out)
+      for (int r = 0; r < nv; ++r) assign_out[(size_t)i * n_det + rows[r]] = col[r] < n_lm ? col[r] : -1;
+    lw[i] = -0.5 * total - (double)nv * lognorm;
+    free(table);
+    free(rows);
+    free(col);
+    free(kth);
+  }
+}

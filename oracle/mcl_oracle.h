@@ -111,6 +111,12 @@ void orc_mbes_update(int n, const double* state, const double m2o[16], const dou
 void orc_landmark_update(int n, const double* state, const double m2o[16], const double sensor_off[6],
                          const double* lm, int64_t n_lm, const double* det, int n_det, double sigma, int k,
                          double gate, double* lw);
+/* dense rectangular assignment (n rows assigned, m >= n columns); pinned to the reference Munkres via oracle/_ref */
+double orc_assign_dense(int n, int m, const double* cost, int* col_of_row);
+/* landmark update with a global assignment per particle (table as auv_ekf_slam/src/ekf_slam_core.cpp:172-312) */
+void orc_landmark_assign_update(int n, const double* state, const double m2o[16], const double sensor_off[6],
+                                const double* lm, int64_t n_lm, const double* det, int n_det, double sigma,
+                                int k_cand, double gate, double new_mh_dist, double* lw, int* assign_out);
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,8 @@ def _load():
         'orc_mesh_free': (None, [vp]),
         'orc_ray_mesh': (d, [vp, _f64p, _f64p, d]),
         'orc_landmark_update': (None, [i, _f64p, _f64p, _f64p, _f64p, i64, _f64p, i, d, i, d, _f64p]),
+        'orc_assign_dense': (d, [i, i, _f64p, _i32p]),
+        'orc_landmark_assign_update': (None, [i, _f64p, _f64p, _f64p, _f64p, i64, _f64p, i, d, i, d, d, _f64p, vp]),
         'orc_mbes_update': (None, [i, _f64p, _f64p, _f64p, i, vp, _f32p, vp, i, d, d, vp, vp]),
     }
     for name, (res, args) in sig.items():
@@ -327,3 +329,43 @@ def landmark_update(soa, m2o, sensor_off, landmarks, det, sigma, k=1, gate=11.34
     _L.orc_landmark_update(soa.shape[1], soa, _c(m2o).reshape(-1), _c(sensor_off), lm, lm.shape[0], dt,
                            dt.shape[0], float(sigma), int(k), float(gate), lw)
     return lw
+
+
+def assign_dense(cost):
+    """Optimal assignment of every ROW of cost[n, m] (n <= m) to a distinct column; returns
+    (col_of_row[n], total)."""
+    cost = _c(cost)
+    n, m = cost.shape
+    col = np.zeros(n, dtype=np.int32)
+    total = _L.orc_assign_dense(n, m, cost.reshape(-1), col)
+    return col, float(total)
+
+
+def landmark_assign_update(soa, m2o, sensor_off, landmarks, det, sigma, k_cand, gate, new_mh_dist, want_assign=False):
+    soa = _c(soa)
+    lm = _c(landmarks).reshape(-1, 3)
+    dt = _c(det).reshape(-1, 3)
+    lw = np.zeros(soa.shape[1])
+    asg = np.zeros((soa.shape[1], dt.shape[0]), dtype=np.int32) if want_assign else None
+    _L.orc_landmark_assign_update(soa.shape[1], soa, _c(m2o).reshape(-1), _c(sensor_off), lm, lm.shape[0], dt,
+                                  dt.shape[0], float(sigma), int(k_cand), float(gate), float(new_mh_dist), lw,
+                                  asg.ctypes.data if asg is not None else None)
+    return (lw, asg) if want_assign else lw
+
+
+_REF_MUNKRES = os.path.join(_HERE, '_ref', 'libref_munkres.so')
+
+
+def ref_munkres(cost):
+    """The REFERENCE's Munkres<double> (oracle/_ref, built from /root/reference/auv_ekf_slam/utils/munkres):
+    cost[rows, cols] as ekf_slam_core.cpp builds it (rows = landmarks, cols = measurements);
+    returns row_of_col[cols].  None if the reference build is not present."""
+    if not os.path.exists(_REF_MUNKRES):
+        return None
+    lib = C.CDLL(_REF_MUNKRES)
+    cost = _c(cost)
+    r, c = cost.shape
+    out = np.zeros(c, dtype=np.int32)
+    lib.ref_munkres_solve.argtypes = [C.c_int, C.c_int, _f64p, _i32p]
+    lib.ref_munkres_solve(r, c, cost.reshape(-1), out)
+    return out

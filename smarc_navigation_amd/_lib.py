@@ -65,6 +65,7 @@ SYMBOLS = {
     'mcl_mbes_expected': (C.c_int, [_vp, _i64, _i64, _vp, _i32, _d, _vp, _vp]),
     'mcl_set_landmarks': (C.c_int, [_vp, _vp, _i64]),
     'mcl_update_landmarks': (C.c_int, [_vp, _vp, _i32, _d, _i32, _d, _vp, _i32]),
+    'mcl_update_landmarks_assign': (C.c_int, [_vp, _vp, _i32, _d, _i32, _d, _d, _vp, _i32, _vp, _i64]),
     'mcl_resample': (C.c_int, [_vp, _vp, _i64, _vp]),
     'mcl_resample_prepare': (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     'mcl_mean_cov': (C.c_int, [_vp, _vp, _vp, _vp]),

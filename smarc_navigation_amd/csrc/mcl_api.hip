@@ -64,6 +64,7 @@ struct mcl_handle {
   float* exp_dev = nullptr;
   MbesPose* pose_dev = nullptr;
   int* mbes_worklist = nullptr;  // ngroups + 1 ints; [ngroups] is the counter
+  int* lm_worklist = nullptr;    // n + 1 ints; [n] is the counter (landmark assignment: particles with clashes)
   // alternative resamplers (lazily allocated)
   u64* cq = nullptr;       // inclusive scan of q
   u64* u53 = nullptr;      // uniforms as 53-bit integers
@@ -1081,7 +1082,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1290,6 +1291,90 @@ int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, do
   k_landmark_update<<<(unsigned)blocks, 256, 0, h->stream>>>(a);
   t_end(h);
   HIPCHK(h, hipGetLastError());
+  if (!accumulate) h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
+  h->have_lw = true;
+  h->residual_k = -1;
+  return MCL_OK;
+}
+
+int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_det, double sigma, int32_t k_cand,
+                                double gate, double new_mh_dist, const double sensor_offset[6], int32_t accumulate,
+                                int32_t* assign_out, int64_t n_keep) {
+  if (!h || !det_xyz || n_det < 1 || n_det > LM_SUB || !(sigma > 0.0) || k_cand < 1 || k_cand > LA_KC || !(gate > 0.0) ||
+      !(new_mh_dist >= 0.0) || n_keep < 0 || (n_keep > 0 && !assign_out))
+    return fail(h, MCL_ERR_INVALID, "update_landmarks_assign: bad argument (n_det <= 16, 1 <= k_cand <= 8)");
+  if (!h->landmarks) return fail(h, MCL_ERR_STATE, "update_landmarks_assign: no feature map (call mcl_set_landmarks first)");
+  if (accumulate && !h->have_lw) return fail(h, MCL_ERR_STATE, "update_landmarks_assign: nothing to accumulate onto");
+  RET_IF(set_device(h));
+  std::string err;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int rc = landmarks_build(h->landmarks, sigma * std::sqrt(gate), &err);
+  if (rc != MCL_OK) {
+    h->err = err;
+    return rc;
+  }
+  if (n_det > h->det_cap) {
+    if (h->det_dev) (void)hipFree(h->det_dev);
+    h->det_dev = nullptr;
+    HIPCHK(h, hipMalloc(&h->det_dev, sizeof(double) * 3 * (size_t)n_det));
+    h->det_cap = n_det;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->det_dev, det_xyz, sizeof(double) * 3 * (size_t)n_det, hipMemcpyHostToDevice, h->stream));
+  if (n_keep > h->n) n_keep = h->n;
+  int* asg_dev = nullptr;
+  if (n_keep > 0) HIPCHK(h, hipMalloc(&asg_dev, sizeof(int) * (size_t)n_keep * n_det));
+  static const double zero6[6] = {0, 0, 0, 0, 0, 0};
+  const double* so = sensor_offset ? sensor_offset : zero6;
+  LandmarkAssignArgs aa;
+  LandmarkArgs& a = aa.base;
+  for (int c = 0; c < 6; ++c) a.st[c] = h->state[h->cur] + (size_t)c * h->n;
+  a.n = h->n;
+  for (int q = 0; q < 12; ++q) a.m2o[q] = h->cfg.m2o[q];
+  for (int q = 0; q < 3; ++q) a.off_t[q] = so[q];
+  rot_rpy(so[3], so[4], so[5], a.off_R);
+  a.det = h->det_dev;
+  a.n_det = n_det;
+  a.lm = h->landmarks->lm;
+  a.cell_start = h->landmarks->cell_start;
+  a.gx = h->landmarks->gx;
+  a.gy = h->landmarks->gy;
+  a.x0 = h->landmarks->x0;
+  a.y0 = h->landmarks->y0;
+  a.inv_cs = 1.0 / h->landmarks->cs;
+  a.inv_s2 = 1.0 / (sigma * sigma);
+  a.gate = gate;
+  a.lognorm = 1.5 * std::log(2.0 * MCL_PI) + 3.0 * std::log(sigma);
+  a.k = k_cand;
+  a.accumulate = accumulate ? 1 : 0;
+  a.lw = h->lw;
+  aa.orig = h->landmarks->orig;
+  aa.new_mh = new_mh_dist;
+  aa.k_cand = k_cand;
+  aa.assign_out = asg_dev;
+  aa.n_keep = n_keep;
+  hipError_t le = hipSuccess;
+  if (!h->lm_worklist) le = hipMalloc(&h->lm_worklist, sizeof(int) * ((size_t)h->n + 1));
+  if (le == hipSuccess) {
+    aa.worklist = h->lm_worklist;
+    aa.work_count = h->lm_worklist + h->n;
+    le = hipMemsetAsync(aa.work_count, 0, sizeof(int), h->stream);
+  }
+  if (le == hipSuccess) {
+    t_begin(h, MCL_K_UPDATE_MBES);
+    long long blocks = (h->n + LA_PER_BLOCK - 1) / LA_PER_BLOCK;
+    if (blocks > 32768) blocks = 32768;
+    // every particle: conflict-free answer or worklist entry; then the solver over the worklist (its grid
+    // strides over the device-side count)
+    k_landmark_assign<false><<<(unsigned)blocks, LA_PER_BLOCK * LM_SUB, 0, h->stream>>>(aa);
+    k_landmark_assign<true><<<(unsigned)std::min<long long>(blocks, 2048), LA_PER_BLOCK * LM_SUB, 0, h->stream>>>(aa);
+    t_end(h);
+    le = hipGetLastError();
+  }
+  if (le == hipSuccess && n_keep > 0)
+    le = hipMemcpyAsync(assign_out, asg_dev, sizeof(int) * (size_t)n_keep * n_det, hipMemcpyDeviceToHost, h->stream);
+  if (le == hipSuccess && n_keep > 0) le = hipStreamSynchronize(h->stream);
+  if (asg_dev) (void)hipFree(asg_dev);
+  HIPCHK(h, le);
   if (!accumulate) h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
   h->have_lw = true;
   h->residual_k = -1;

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mcl.h"
@@ -127,10 +128,313 @@ __global__ void __launch_bounds__(256) k_landmark_update(LandmarkArgs a) {
   }
 }
 
+
+// sensor pose of particle i in the map frame (fp64): M = m2o * T(x,y,z) R(rpy) * T_off R_off
+__device__ __forceinline__ void landmark_sensor_pose(const LandmarkArgs& a, long long i, double Rs[9], double o[3]) {
+  const double x = a.st[0][i], y = a.st[1][i], z = a.st[2][i];
+  double sr, cr, sp, cp, sy, cy;
+  sincos(a.st[3][i], &sr, &cr);
+  sincos(a.st[4][i], &sp, &cp);
+  sincos(a.st[5][i], &sy, &cy);
+  const double Rp[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
+                        sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
+                        -sp,     cp * sr,                cp * cr};
+  double Rmp[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      Rmp[r * 3 + c] = a.m2o[r * 4 + 0] * Rp[c] + a.m2o[r * 4 + 1] * Rp[3 + c] + a.m2o[r * 4 + 2] * Rp[6 + c];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      Rs[r * 3 + c] = Rmp[r * 3 + 0] * a.off_R[c] + Rmp[r * 3 + 1] * a.off_R[3 + c] + Rmp[r * 3 + 2] * a.off_R[6 + c];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    o[r] = (a.m2o[r * 4 + 0] * x + a.m2o[r * 4 + 1] * y + a.m2o[r * 4 + 2] * z + a.m2o[r * 4 + 3]) +
+           (Rmp[r * 3 + 0] * a.off_t[0] + Rmp[r * 3 + 1] * a.off_t[1] + Rmp[r * 3 + 2] * a.off_t[2]);
+}
+
+// ------------------------------------------------------------------ global (Hungarian) assignment
+// SURVEY 8(f) rank 4.  Per particle the correspondence table of the reference's batch association
+// (auv_ekf_slam/src/ekf_slam_core.cpp:172-178: Mahalanobis distance if < gate else 10000; :269-281:
+// one new-landmark row per detection at cost new_mh_dist; :298-312: Munkres) is solved exactly:
+// lw = -1/2 (optimal total) - D_valid lognorm.  Every detection owns a private new-landmark column,
+// so the optimum never uses a 10000 entry and the table reduces to the gated pairs: a sparse
+// bipartite graph with <= k_cand + 1 edges per detection (k_cand <= 8 nearest gated landmarks).
+//   phase 1 (16 lanes per particle, one detection each): gated candidates from the landmark cell
+//            grid, sorted by distance;
+//   phase 2 (same lanes): shared landmarks get one column slot (first occurrence);
+//   phase 3 (lane 0 of the group): shortest-augmenting-path assignment with potentials on the sparse
+//            graph -- typically one relaxation per detection, conflicts cost a few more;
+//   phase 4 (16 lanes): each detection reads its matched edge, 16-lane sum.
+// Oracle: dense table over ALL landmarks + dense solver (orc_landmark_assign_update), the solver
+// itself pinned to the reference's Munkres.
+#define LA_KC 8
+#define LA_PER_BLOCK 8                    // particles per 128-thread block
+#define LA_COLS (LM_SUB + LM_SUB * LA_KC) // 16 private columns + 128 first-occurrence slots
+#define LA_START LA_COLS                  // virtual start column
+
+struct LandmarkAssignArgs {
+  LandmarkArgs base;
+  const u32* orig;       // cell-ordered slot -> caller's landmark index
+  double new_mh;
+  int k_cand;
+  int* assign_out;       // optional: first n_keep particles x n_det (landmark index, -1 new, -2 invalid)
+  long long n_keep;
+  int* worklist;         // particles whose cheapest edges clash (filled by the fast kernel)
+  int* work_count;
+};
+
+struct LaSharedFast {   // 560 B per particle: the fast kernel only exchanges candidate ids and choices
+  u32 cand_id[LM_SUB][LA_KC];
+  unsigned char ncand[LM_SUB];   // 255 = invalid detection
+  unsigned char choice[LM_SUB];
+};
+
+struct LaSharedFull {
+  double cand_cost[LM_SUB][LA_KC];
+  double v[LA_COLS + 1];
+  double minv[LA_COLS + 1];
+  double u[LM_SUB];
+  u32 cand_id[LM_SUB][LA_KC];
+  unsigned char cand_col[LM_SUB][LA_KC];
+  unsigned char ncand[LM_SUB];
+  unsigned char p[LA_COLS + 1];     // row + 1 matched to the column, 0 = free
+  unsigned char way[LA_COLS + 1];
+  unsigned char flag[LA_COLS + 1];  // bit 0 touched, bit 1 used
+  unsigned char list[LA_COLS + 1];  // touched columns of the current search
+};
+
+// FULL = false: phases 1, 2, 2b, 4 -- every particle; a particle whose detections' cheapest edges clash
+//               is appended to the worklist instead of being answered.
+// FULL = true : the worklist only, with the augmenting-path solver (phase 3).
+template <bool FULL>
+__global__ void __launch_bounds__(LA_PER_BLOCK * LM_SUB) k_landmark_assign(LandmarkAssignArgs aa) {
+  using Shared = typename std::conditional<FULL, LaSharedFull, LaSharedFast>::type;
+  __shared__ Shared sh[LA_PER_BLOCK];
+  const LandmarkArgs& a = aa.base;
+  const int sub = threadIdx.x & (LM_SUB - 1);
+  const int g = threadIdx.x / LM_SUB;
+  Shared& S = sh[g];
+  const double INF = __builtin_inf();
+  const long long total = FULL ? (long long)*aa.work_count : a.n;
+  const long long nblk = (total + LA_PER_BLOCK - 1) / LA_PER_BLOCK;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {  // block-uniform trip count
+    const long long slot = blk * LA_PER_BLOCK + g;
+    const bool live = slot < total;
+    const long long i = live ? (FULL ? (long long)aa.worklist[slot] : slot) : 0;
+    // ---- phase 1: candidates of detection `sub`, nearest first
+    double best[LA_KC];
+    u32 bid[LA_KC];
+#pragma unroll
+    for (int q = 0; q < LA_KC; ++q) {
+      best[q] = INF;
+      bid[q] = 0xffffffffu;
+    }
+    bool valid = false;
+    if (live && sub < a.n_det) {
+      const double zx = a.det[3 * sub], zy = a.det[3 * sub + 1], zz = a.det[3 * sub + 2];
+      valid = zx == zx && zy == zy && zz == zz;
+      if (valid) {
+        double Rs[9], o[3];
+        landmark_sensor_pose(a, i, Rs, o);
+        const double px = o[0] + Rs[0] * zx + Rs[1] * zy + Rs[2] * zz;
+        const double py = o[1] + Rs[3] * zx + Rs[4] * zy + Rs[5] * zz;
+        const double pz = o[2] + Rs[6] * zx + Rs[7] * zy + Rs[8] * zz;
+        const int cx = (int)floor((px - a.x0) * a.inv_cs), cyi = (int)floor((py - a.y0) * a.inv_cs);
+        for (int ix = max(cx - 1, 0); ix <= min(cx + 1, a.gx - 1); ++ix)
+          for (int iy = max(cyi - 1, 0); iy <= min(cyi + 1, a.gy - 1); ++iy) {
+            const size_t c = (size_t)ix * a.gy + iy;
+            for (u32 e = a.cell_start[c]; e < a.cell_start[c + 1]; ++e) {
+              const double dx = px - a.lm[3 * (size_t)e], dy = py - a.lm[3 * (size_t)e + 1], dz = pz - a.lm[3 * (size_t)e + 2];
+              double m = (dx * dx + dy * dy + dz * dz) * a.inv_s2;
+              if (m < a.gate) {  // strict, ekf_slam_core.cpp:173
+                u32 id = e;
+#pragma unroll
+                for (int q = 0; q < LA_KC; ++q) {
+                  if (m < best[q]) {
+                    const double t = best[q];
+                    const u32 ti = bid[q];
+                    best[q] = m;
+                    bid[q] = id;
+                    m = t;
+                    id = ti;
+                  }
+                }
+              }
+            }
+          }
+      }
+    }
+    int nc = 0;
+#pragma unroll
+    for (int q = 0; q < LA_KC; ++q) nc += (q < aa.k_cand && best[q] != INF) ? 1 : 0;
+    __syncthreads();  // previous iteration's shared state fully consumed
+#pragma unroll
+    for (int q = 0; q < LA_KC; ++q) {
+      S.cand_id[sub][q] = q < nc ? bid[q] : 0xffffffffu;
+      if constexpr (FULL) S.cand_cost[sub][q] = best[q];
+    }
+    S.ncand[sub] = valid ? (unsigned char)nc : (unsigned char)255;
+    if constexpr (FULL) {
+      S.u[sub] = 0.0;
+      for (int c = sub; c <= LA_COLS; c += LM_SUB) {
+        S.v[c] = 0.0;
+        S.p[c] = 0;
+        S.flag[c] = 0;
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: column slot of every candidate = its first occurrence over (row, rank); a shared
+    // landmark gets ONE column.  col[] stays in registers; the cheapest edge is found on the way.
+    int col[LA_KC];
+    double cmin = aa.new_mh;
+    int choice = valid ? sub : -1, choice_q = -1;
+#pragma unroll
+    for (int q = 0; q < LA_KC; ++q) {
+      col[q] = LM_SUB + sub * LA_KC + q;
+      if (q < nc) {
+        const u32 id = bid[q];
+        bool found = false;
+        for (int r = 0; r < sub && !found; ++r) {
+          const int ncr = S.ncand[r] == 255 ? 0 : S.ncand[r];
+          for (int t = 0; t < ncr; ++t)
+            if (S.cand_id[r][t] == id) {
+              col[q] = LM_SUB + r * LA_KC + t;
+              found = true;
+              break;
+            }
+        }
+        if (valid && best[q] < cmin) {
+          cmin = best[q];
+          choice = col[q];
+          choice_q = q;
+        }
+        if constexpr (FULL) S.cand_col[sub][q] = (unsigned char)col[q];
+      }
+    }
+    double cost = 0.0;
+    int nvalid = 0, asg = -2;
+    if constexpr (!FULL) {
+      // ---- phase 2b: if every detection's cheapest edge leads to a different column, those edges ARE
+      // the optimum (the sum of the row minima is a lower bound): the usual case on a sparse map
+      S.choice[sub] = (unsigned char)(choice < 0 ? 255 : choice);
+      __syncthreads();
+      int clash = 0;
+      if (choice >= 0)
+        for (int r = 0; r < LM_SUB; ++r) clash |= (r != sub && S.choice[r] == (unsigned char)choice) ? 1 : 0;
+#pragma unroll
+      for (int o2 = LM_SUB / 2; o2 > 0; o2 >>= 1) clash |= __shfl_xor(clash, o2, 64);
+      if (clash) {
+        if (sub == 0 && live) aa.worklist[atomicAdd(aa.work_count, 1)] = (int)i;
+        continue;  // uniform over the 16 lanes of the particle; the block-level barriers stay matched
+                   // because every thread still executes the same number of loop iterations
+      }
+      if (valid) {
+        nvalid = 1;
+        cost = cmin;
+        asg = choice_q < 0 ? -1 : (aa.assign_out ? (int)aa.orig[bid[choice_q]] : 0);
+      }
+    } else {
+      __syncthreads();
+      // ---- phase 3: sparse shortest-augmenting-path assignment, one lane per particle
+      if (sub == 0 && live) {
+        for (int i0row = 0; i0row < LM_SUB; ++i0row) {
+          if (S.ncand[i0row] == 255) continue;
+          int ntouched = 0;
+          int j0 = LA_START;
+          S.p[LA_START] = (unsigned char)(i0row + 1);
+          S.flag[LA_START] = 2;
+          for (;;) {
+            const int r = S.p[j0] - 1;
+            const double ur = S.u[r];
+            // relax the edges of row r: private new-landmark column, then its candidates
+            const int ne = 1 + S.ncand[r];
+            for (int e = 0; e < ne; ++e) {
+              const int j = e == 0 ? r : S.cand_col[r][e - 1];
+              const double c = e == 0 ? aa.new_mh : S.cand_cost[r][e - 1];
+              const unsigned char f = S.flag[j];
+              if (f & 2) continue;
+              const double cur = c - ur - S.v[j];
+              if (!(f & 1)) {
+                S.flag[j] = f | 1;
+                S.list[ntouched++] = (unsigned char)j;
+                S.minv[j] = INF;
+              }
+              if (cur < S.minv[j]) {
+                S.minv[j] = cur;
+                S.way[j] = (unsigned char)j0;
+              }
+            }
+            double delta = INF;
+            int j1 = -1;
+            for (int t = 0; t < ntouched; ++t) {
+              const int j = S.list[t];
+              if (!(S.flag[j] & 2) && S.minv[j] < delta) {
+                delta = S.minv[j];
+                j1 = j;
+              }
+            }
+            // potentials: rows of the used columns (incl. the start) go up, used columns go down
+            S.u[i0row] += delta;
+            for (int t = 0; t < ntouched; ++t) {
+              const int j = S.list[t];
+              if (S.flag[j] & 2) {
+                S.u[S.p[j] - 1] += delta;
+                S.v[j] -= delta;
+              } else {
+                S.minv[j] -= delta;
+              }
+            }
+            j0 = j1;
+            S.flag[j0] |= 2;
+            if (S.p[j0] == 0) break;
+          }
+          // augment along the alternating path back to the start
+          while (j0 != LA_START) {
+            const int j1 = S.way[j0];
+            S.p[j0] = S.p[j1];
+            j0 = j1;
+          }
+          for (int t = 0; t < ntouched; ++t) S.flag[S.list[t]] = 0;
+        }
+      }
+      __syncthreads();
+      // ---- phase 4: every detection reads its matched edge
+      if (live && valid) {
+        nvalid = 1;
+        asg = -1;
+        cost = aa.new_mh;
+        if (S.p[sub] != sub + 1) {
+#pragma unroll
+          for (int q = 0; q < LA_KC; ++q)
+            if (q < nc && S.p[col[q]] == sub + 1) {
+              cost = best[q];
+              asg = aa.assign_out ? (int)aa.orig[bid[q]] : 0;
+            }
+        }
+      }
+    }
+    if (aa.assign_out && live && i < aa.n_keep && sub < a.n_det) aa.assign_out[i * a.n_det + sub] = asg;
+#pragma unroll
+    for (int o2 = LM_SUB / 2; o2 > 0; o2 >>= 1) {
+      cost += __shfl_xor(cost, o2, 64);
+      nvalid += __shfl_xor(nvalid, o2, 64);
+    }
+    if (sub == 0 && live) {
+      const double val = -0.5 * cost - (double)nvalid * a.lognorm;
+      a.lw[i] = a.accumulate ? a.lw[i] + val : val;
+    }
+  }
+}
+
 struct LandmarkDev {
   std::vector<double> host_xyz;  // as given
   double* lm = nullptr;
   u32* cell_start = nullptr;
+  u32* orig = nullptr;      // cell-ordered slot -> index in the caller's landmark list
   int gx = 0, gy = 0;
   double x0 = 0, y0 = 0, cs = 0;
   double built_for = -1.0;  // gate radius the grid was built for
@@ -140,6 +444,7 @@ inline void landmarks_free(LandmarkDev* L) {
   if (!L) return;
   if (L->lm) (void)hipFree(L->lm);
   if (L->cell_start) (void)hipFree(L->cell_start);
+  if (L->orig) (void)hipFree(L->orig);
   delete L;
 }
 
@@ -173,22 +478,28 @@ inline int landmarks_build(LandmarkDev* L, double r, std::string* err) {
   for (size_t i = 0; i < n; ++i) start[cell(i) + 1]++;
   for (size_t c = 0; c < nc; ++c) start[c + 1] += start[c];
   std::vector<double> sorted(3 * std::max<size_t>(n, 1));
+  std::vector<u32> orig(std::max<size_t>(n, 1));
   for (size_t i = 0; i < n; ++i) {
     const size_t c = cell(i), r2 = start[c] + fill[c]++;
+    orig[r2] = (u32)i;
     sorted[3 * r2] = L->host_xyz[3 * i];
     sorted[3 * r2 + 1] = L->host_xyz[3 * i + 1];
     sorted[3 * r2 + 2] = L->host_xyz[3 * i + 2];
   }
   if (L->lm) (void)hipFree(L->lm);
   if (L->cell_start) (void)hipFree(L->cell_start);
+  if (L->orig) (void)hipFree(L->orig);
   L->lm = nullptr;
   L->cell_start = nullptr;
+  L->orig = nullptr;
   if (hipMalloc(&L->lm, sizeof(double) * sorted.size()) != hipSuccess ||
+      hipMalloc(&L->orig, sizeof(u32) * orig.size()) != hipSuccess ||
       hipMalloc(&L->cell_start, sizeof(u32) * (nc + 1)) != hipSuccess) {
     *err = "update_landmarks: device allocation failed";
     return MCL_ERR_ALLOC;
   }
   if (hipMemcpy(L->lm, sorted.data(), sizeof(double) * sorted.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(L->orig, orig.data(), sizeof(u32) * orig.size(), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(L->cell_start, start.data(), sizeof(u32) * (nc + 1), hipMemcpyHostToDevice) != hipSuccess) {
     *err = "update_landmarks: upload failed";
     return MCL_ERR_HIP;

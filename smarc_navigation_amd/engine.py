@@ -117,6 +117,17 @@ class Engine(object):
         self._ck(self.lib.mcl_update_landmarks(self.h, _ptr(d), d.shape[0], float(sigma), int(k), float(gate),
                                                _ptr(so), 1 if accumulate else 0))
 
+    def update_landmarks_assign(self, det_xyz, sigma, k_cand=8, gate=11.345, new_mh_dist=11.345, sensor_offset=None,
+                                accumulate=False, n_keep=0):
+        """Landmark update with a global (Hungarian) assignment per particle; returns the assignment of
+        the first n_keep particles (n_keep x n_det int32) or None."""
+        d, so = _f64(det_xyz), _f64(sensor_offset)
+        out = np.zeros((int(n_keep), d.shape[0]), dtype=np.int32) if n_keep else None
+        self._ck(self.lib.mcl_update_landmarks_assign(self.h, _ptr(d), d.shape[0], float(sigma), int(k_cand), float(gate),
+                                                      float(new_mh_dist), _ptr(so), 1 if accumulate else 0,
+                                                      out.ctypes.data if out is not None else None, int(n_keep)))
+        return out
+
     def resample(self, uniforms=None, normals=None):
         u = None if uniforms is None else _f64(np.atleast_1d(uniforms))
         nz = _f64(normals)
