@@ -80,6 +80,20 @@ def make_ranges(engine_mod, m, stream, n_steps, beam_angles, sigma, r_max, devic
     return out
 
 
+def host_cores():
+    """Host threads this process may really use: the affinity mask, capped by the cgroup CPU quota
+    (a container with `cpu.max = 1600000 100000` gets 16 CPUs of time however many it can see)."""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            cores = max(1, min(cores, int(-(-int(quota) // int(period)))))
+    except (IOError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(m, stream, ranges, beam_angles, sigma, r_max, cov, n_full, n_sample, threads, budget_s):
     """The oracle (C restatement; its particle loops run on `threads` host threads) on a bounded
     sample of the same workload."""
@@ -92,6 +106,7 @@ def cpu_baseline(m, stream, ranges, beam_angles, sigma, r_max, cov, n_full, n_sa
     t0 = time.perf_counter()
     steps = 0
     sq_err = 0.0
+    means = []
     while True:
         k = steps
         orc.predict(soa, stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'],
@@ -104,13 +119,14 @@ def cpu_baseline(m, stream, ranges, beam_angles, sigma, r_max, cov, n_full, n_sa
         orc.add_noise(soa, cov['resample_cov'], orc.native_normals(n, 0, 5, 2, k))
         m6, _, _ = orc.mean_cov(soa)
         sq_err += (m6[0] - stream['truth'][k][0]) ** 2 + (m6[1] - stream['truth'][k][1]) ** 2
+        means.append([m6[0], m6[1]])
         steps += 1
         el = time.perf_counter() - t0
         if el > budget_s or steps >= min(len(ranges), 20):
             break
     per_step = el / steps
     return dict(value=(n / float(n_full)) / per_step, unit='steps/s', cores=threads, kind='port',
-                pose_rmse_m=round(float(np.sqrt(sq_err / steps)), 4),
+                pose_rmse_m=round(float(np.sqrt(sq_err / steps)), 4), _means=np.array(means), _n=n,
                 sample='%d particles x %d beams x %d steps of the same stream+map on %d host thread(s) (%.2f s/step), '
                        'scaled linearly to %d particles' % (n, beam_angles.size, steps, threads, per_step, n_full))
 
@@ -250,11 +266,26 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             # all host cores (the oracle's particle loops are OpenMP-parallel) and, beside it, one thread
             ns = a.cpu_particles or (8192 if m['kind'] == 'grid' else 4096)
-            cores = len(os.sched_getaffinity(0))
+            cores = host_cores()
             one = cpu_baseline(m, stream, ranges, ba, sigma, r_max, cov, 1048576, ns, 1, 8.0)
             allc = cpu_baseline(m, stream, ranges, ba, sigma, r_max, cov, 1048576, ns * min(cores, 32), cores, 10.0)
             allc['value_1thread'] = one['value']
             allc['sample_1thread'] = one['sample']
+            # "pose RMSE vs ref": the same filter (same Philox draws, same stream and map) on the GPU at the
+            # oracle's sample size, mean (x, y) trajectory against the oracle's over the steps it ran
+            ref_xy, n_ref = allc.pop('_means'), allc.pop('_n')
+            one.pop('_means'), one.pop('_n')
+            g = engine.Engine(n_ref, seed=5, device=local_rank, **cov)
+            attach_map(g, m)
+            g.init_particles()
+            for k in range(len(ref_xy)):
+                g.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'],
+                            ranges[k], ba, sigma, r_max)
+            g.sync()
+            gh = g.mean_history(len(ref_xy))
+            g.close()
+            allc['pose_rmse_vs_oracle_m'] = float('%.3g' % np.sqrt(np.mean(np.sum((gh[:, :2] - ref_xy) ** 2, axis=1))))
+            out['pose_rmse_vs_oracle_m'] = allc['pose_rmse_vs_oracle_m']
             out['cpu_baseline'] = allc
         print(json.dumps(out))
     if dist is not None:
