@@ -257,9 +257,13 @@ def main():
                                                 if pmc.get('valu_insts_per_launch') and traffic else None),
                          'valu_lane_utilisation': (round(pmc['valu_lane_utilisation'], 3)
                                                    if pmc.get('valu_lane_utilisation') and traffic else None),
-                         'note': 'the ray-cast is VALU-issue-bound, not HBM-bound (SURVEY 8d): PMC SQ_INSTS_VALU wave-'
-                                 'instructions per ray-lane and the fraction of lanes active in them (profiles/'
-                                 'r01_traffic.json); streaming kernels are listed in "kernels" with their own HBM fractions'},
+                         # share of the chip's vector-issue slots: a wave64 VALU instruction occupies a SIMD-32
+                         # for 2 cycles (MI355X_MICROARCH.md "Wave scheduling"), 1024 SIMDs at 2.4 GHz
+                         'valu_issue_frac': (round(pmc['valu_insts_per_launch'] / (dom_ms * 1e-3) / (1024 * 2.4e9 / 2.0), 3)
+                                             if pmc.get('valu_insts_per_launch') and traffic else None),
+                         'note': 'the ray-cast is VALU-bound, not HBM-bound (SURVEY 8d): PMC SQ_INSTS_VALU wave-instructions '
+                                 'per ray-lane, the fraction of lanes active in them and the share of vector-issue '
+                                 'slots they fill (profiles/r01_traffic.json); streaming kernels are listed in "kernels" with their own HBM fractions'},
             'kernels': kernels,
             'pose_rmse_m': round(pose_rmse, 4),
         }
