@@ -1106,3 +1106,94 @@ void orc_landmark_assign_update(int n, const double* state, const double m2o[16]
     free(kth);
   }
 }
+
+/* ------------------------------------------------------------------ bathymetry map builder
+ * SELF-ORACLE for include/mcl_map.h (the rasterisation has no reference counterpart; the point cloud is
+ * the transform-and-concatenate of mbes_processors/mbes_mapper/src/mbes_receptor.cpp:64-107 with the
+ * beam geometry of mcl_update_mbes).  Same definition as the kernels: nearest node, round(z 2^20)
+ * accumulated in int64, mean, Jacobi hole filling in float with a fixed neighbour order. */
+void orc_gridmap_add_pings(int nx, int ny, double ox, double oy, double res, int64_t* sum, uint32_t* cnt,
+                           int64_t n_pings, const double* poses6, const float* ranges, const float* beam_angles,
+                           int B, double r_max, const double m2o[16], const double sensor_off[6], double* points_out) {
+  double Ro[9];
+  rot_rpy(sensor_off[3], sensor_off[4], sensor_off[5], Ro);
+  double Rm[9] = {m2o[0], m2o[1], m2o[2], m2o[4], m2o[5], m2o[6], m2o[8], m2o[9], m2o[10]};
+  const double inv_res = 1.0 / res;
+  const float rmaxf = (float)r_max;
+  for (int64_t p = 0; p < n_pings; ++p) {
+    const double* ps = poses6 + 6 * p;
+    double Rp[9], Rmp[9], Rs[9], o[3];
+    rot_rpy(ps[3], ps[4], ps[5], Rp);
+    mat3_mul(Rm, Rp, Rmp);
+    mat3_mul(Rmp, Ro, Rs);
+    for (int r = 0; r < 3; ++r)
+      o[r] = (m2o[r * 4 + 0] * ps[0] + m2o[r * 4 + 1] * ps[1] + m2o[r * 4 + 2] * ps[2] + m2o[r * 4 + 3]) +
+             (Rmp[r * 3 + 0] * sensor_off[0] + Rmp[r * 3 + 1] * sensor_off[1] + Rmp[r * 3 + 2] * sensor_off[2]);
+    for (int b = 0; b < B; ++b) {
+      const float rg = ranges[(size_t)p * B + b];
+      double x = NAN, y = NAN, z = NAN;
+      if (rg > 0.0f && rg < rmaxf) {
+        const float sa = (float)sin((double)beam_angles[b]), ca = (float)cos((double)beam_angles[b]);
+        const double dy = (double)rg * (double)sa, dz = -(double)rg * (double)ca;
+        x = o[0] + Rs[1] * dy + Rs[2] * dz;
+        y = o[1] + Rs[4] * dy + Rs[5] * dz;
+        z = o[2] + Rs[7] * dy + Rs[8] * dz;
+        const double fi = floor((x - ox) * inv_res + 0.5), fj = floor((y - oy) * inv_res + 0.5);
+        if (fi >= 0.0 && fj >= 0.0 && fi < (double)nx && fj < (double)ny) {
+          const size_t node = (size_t)fi * ny + (size_t)fj;
+          sum[node] += (int64_t)llrint(z * 1048576.0);
+          cnt[node] += 1u;
+        }
+      }
+      if (points_out) {
+        double* q = points_out + ((size_t)p * B + b) * 3;
+        q[0] = x;
+        q[1] = y;
+        q[2] = z;
+      }
+    }
+  }
+}
+
+int64_t orc_gridmap_finalize(int nx, int ny, const int64_t* sum, const uint32_t* cnt, int fill_passes, float* z_out) {
+  const size_t n = (size_t)nx * ny;
+  float* a = (float*)malloc(n * sizeof(float));
+  float* b = (float*)malloc(n * sizeof(float));
+  int64_t empty = 0;
+  for (size_t i = 0; i < n; ++i) {
+    a[i] = cnt[i] ? (float)(((double)sum[i] / 1048576.0) / (double)cnt[i]) : NAN;
+    empty += cnt[i] ? 0 : 1;
+  }
+  for (int p = 0; p < fill_passes && empty > 0; ++p) {
+    empty = 0;
+    for (int ix = 0; ix < nx; ++ix)
+      for (int iy = 0; iy < ny; ++iy) {
+        float v = a[(size_t)ix * ny + iy];
+        if (v != v) {
+          float s = 0.0f;
+          int k = 0;
+          for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy) {
+              const int jx = ix + dx, jy = iy + dy;
+              if ((dx || dy) && jx >= 0 && jy >= 0 && jx < nx && jy < ny) {
+                const float w = a[(size_t)jx * ny + jy];
+                if (w == w) {
+                  s += w;
+                  ++k;
+                }
+              }
+            }
+          if (k) v = s / (float)k;
+          empty += k ? 0 : 1;
+        }
+        b[(size_t)ix * ny + iy] = v;
+      }
+    float* t = a;
+    a = b;
+    b = t;
+  }
+  memcpy(z_out, a, n * sizeof(float));
+  free(a);
+  free(b);
+  return empty;
+}

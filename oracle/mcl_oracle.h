@@ -117,6 +117,11 @@ double orc_assign_dense(int n, int m, const double* cost, int* col_of_row);
 void orc_landmark_assign_update(int n, const double* state, const double m2o[16], const double sensor_off[6],
                                 const double* lm, int64_t n_lm, const double* det, int n_det, double sigma,
                                 int k_cand, double gate, double new_mh_dist, double* lw, int* assign_out);
+/* bathymetry map builder (self-oracle of include/mcl_map.h) */
+void orc_gridmap_add_pings(int nx, int ny, double ox, double oy, double res, int64_t* sum, uint32_t* cnt,
+                           int64_t n_pings, const double* poses6, const float* ranges, const float* beam_angles,
+                           int B, double r_max, const double m2o[16], const double sensor_off[6], double* points_out);
+int64_t orc_gridmap_finalize(int nx, int ny, const int64_t* sum, const uint32_t* cnt, int fill_passes, float* z_out);
 #ifdef __cplusplus
 }
 #endif

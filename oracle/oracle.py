@@ -72,6 +72,8 @@ def _load():
         'orc_landmark_update': (None, [i, _f64p, _f64p, _f64p, _f64p, i64, _f64p, i, d, i, d, _f64p]),
         'orc_assign_dense': (d, [i, i, _f64p, _i32p]),
         'orc_landmark_assign_update': (None, [i, _f64p, _f64p, _f64p, _f64p, i64, _f64p, i, d, i, d, d, _f64p, vp]),
+        'orc_gridmap_add_pings': (None, [i, i, d, d, d, vp, vp, i64, _f64p, _f32p, _f32p, i, d, _f64p, _f64p, vp]),
+        'orc_gridmap_finalize': (i64, [i, i, vp, vp, i, _f32p]),
         'orc_mbes_update': (None, [i, _f64p, _f64p, _f64p, i, vp, _f32p, vp, i, d, d, vp, vp]),
     }
     for name, (res, args) in sig.items():
@@ -369,3 +371,29 @@ def ref_munkres(cost):
     lib.ref_munkres_solve.argtypes = [C.c_int, C.c_int, _f64p, _i32p]
     lib.ref_munkres_solve(r, c, cost.reshape(-1), out)
     return out
+
+
+class GridMapBuilder(object):
+    """Self-oracle of include/mcl_map.h (fixed-point accumulators, order-free)."""
+
+    def __init__(self, nx, ny, origin, res):
+        self.nx, self.ny, self.origin, self.res = int(nx), int(ny), (float(origin[0]), float(origin[1])), float(res)
+        self.sum = np.zeros(self.nx * self.ny, dtype=np.int64)
+        self.cnt = np.zeros(self.nx * self.ny, dtype=np.uint32)
+
+    def add_pings(self, poses6, ranges, beam_angles, r_max, m2o=None, sensor_off=None, want_points=False):
+        poses6 = _c(poses6).reshape(-1, 6)
+        ranges = np.ascontiguousarray(ranges, dtype=np.float32).reshape(poses6.shape[0], -1)
+        ba = np.ascontiguousarray(beam_angles, dtype=np.float32)
+        m2o = _c(np.identity(4) if m2o is None else m2o).reshape(-1)
+        so = _c([0.0] * 6 if sensor_off is None else sensor_off)
+        pts = np.zeros((poses6.shape[0], ba.size, 3)) if want_points else None
+        _L.orc_gridmap_add_pings(self.nx, self.ny, self.origin[0], self.origin[1], self.res, self.sum.ctypes.data,
+                                 self.cnt.ctypes.data, poses6.shape[0], poses6.reshape(-1), ranges.reshape(-1), ba,
+                                 ba.size, float(r_max), m2o, so, pts.ctypes.data if pts is not None else None)
+        return pts
+
+    def finalize(self, fill_passes=0):
+        z = np.zeros(self.nx * self.ny, dtype=np.float32)
+        empty = _L.orc_gridmap_finalize(self.nx, self.ny, self.sum.ctypes.data, self.cnt.ctypes.data, int(fill_passes), z)
+        return z.reshape(self.nx, self.ny), int(empty)

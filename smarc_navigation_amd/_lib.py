@@ -1,4 +1,4 @@
-"""ctypes loader for libmcl_hip.so (the C ABI in include/mcl.h and include/mcl_dr.h).
+"""ctypes loader for libmcl_hip.so (the C ABI in include/mcl.h, mcl_dr.h and mcl_map.h).
 
 Fails loudly when the shared library is missing: there is no Python/CPU fallback for the hot
 path.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
@@ -45,7 +45,7 @@ class Timing(C.Structure):
     _fields_ = [('ms', C.c_double * 9), ('launches', C.c_int64 * 9)]
 
 
-# every symbol include/mcl.h and include/mcl_dr.h declare: name -> (restype, argtypes)
+# every symbol include/mcl.h, mcl_dr.h and mcl_map.h declare: name -> (restype, argtypes)
 _vp, _i32, _i64, _d = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 SYMBOLS = {
     'mcl_abi_version': (C.c_int, []),
@@ -100,6 +100,13 @@ SYMBOLS = {
     'mcl_dr_thrust': (C.c_int, [_vp, _d, _d]),
     'mcl_dr_tick': (C.c_int, [_vp, C.POINTER(DrOdom)]),
     'mcl_dr_to_odom': (C.c_int, [C.POINTER(DrOdom), _d, C.POINTER(Odom)]),
+    # include/mcl_map.h: the bathymetry map builder
+    'mcl_gridmap_create': (C.c_int, [_i32, _i32, _d, _d, _d, _i32, C.POINTER(_vp)]),
+    'mcl_gridmap_destroy': (None, [_vp]),
+    'mcl_gridmap_last_error': (C.c_char_p, [_vp]),
+    'mcl_gridmap_clear': (C.c_int, [_vp]),
+    'mcl_gridmap_add_pings': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i32, _d, _vp, _vp, _vp]),
+    'mcl_gridmap_finalize': (C.c_int, [_vp, _i32, _vp, C.POINTER(C.c_int64), _vp]),
 }
 
 _lib = None

@@ -926,6 +926,8 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
 
 // dead-reckoning integrator (host only; uses euler_from_quat above)
 #include "mcl_dr_impl.h"
+// bathymetry map builder (uses rot_rpy above)
+#include "mcl_gridmap.h"
 
 // ============================================================================================ C ABI
 extern "C" {

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     names = set()
-    for hdr in ('mcl.h', 'mcl_dr.h'):
+    for hdr in ('mcl.h', 'mcl_dr.h', 'mcl_map.h'):
         src = open(os.path.join(ROOT, 'include', hdr)).read()
         src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
         names |= set(re.findall(r'\b(mcl_[a-z0-9_]+)\s*\(', src))
