@@ -243,7 +243,7 @@ def main():
         dom_ms = tim[dom][0] / a.steps
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
         out = {
-            'metric': 'filter steps/sec at 1M particles x 512 MBES beams',
+            'metric': 'filter steps/sec at 1M particles x 512 MBES beams; pose RMSE vs ref',
             'value': round(value, 3), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64 state / f32 ray-cast', 'data': 'synthetic',
