@@ -20,12 +20,23 @@ struct NoiseArgs {
 };
 
 // 6 normals for particle gid (purpose 0 init / 2 resample-noise): two Philox blocks
+// Counter-based: a draw depends only on (gid, block, step, purpose, seed), so a pair whose two
+// covariances are zero is simply not evaluated (its products with sqrt(cov) = 0 are zero anyway);
+// the launch covariances leave (z, roll) out -- one fp64 log/sqrt/sincos less per particle.
 __device__ __forceinline__ void native_normals6(long long gid, const NoiseArgs& a, double z[6]) {
-  u32x4 o = philox4x32((u32)gid, 0u, a.step, a.purpose, a.k0, a.k1);
-  box_muller(o.x, o.y, z[0], z[1]);
-  box_muller(o.z, o.w, z[2], z[3]);
-  o = philox4x32((u32)gid, 1u, a.step, a.purpose, a.k0, a.k1);
-  box_muller(o.x, o.y, z[4], z[5]);
+  const bool p0 = a.sq[0] != 0.0 || a.sq[1] != 0.0, p1 = a.sq[2] != 0.0 || a.sq[3] != 0.0;
+  const bool p2 = a.sq[4] != 0.0 || a.sq[5] != 0.0;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) z[c] = 0.0;
+  if (p0 || p1) {
+    const u32x4 o = philox4x32((u32)gid, 0u, a.step, a.purpose, a.k0, a.k1);
+    if (p0) box_muller(o.x, o.y, z[0], z[1]);
+    if (p1) box_muller(o.z, o.w, z[2], z[3]);
+  }
+  if (p2) {
+    const u32x4 o = philox4x32((u32)gid, 1u, a.step, a.purpose, a.k0, a.k1);
+    box_muller(o.x, o.y, z[4], z[5]);
+  }
 }
 
 // ------------------------------------------------------------------ a2: Particle.add_noise
