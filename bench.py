@@ -6,42 +6,139 @@ per-beam ray-cast + Gaussian log-likelihood) -> weight normalisation -> systemat
 (+ keep/lost/dupes reassign + resampling noise) -> mean/covariance, on synthetic streams
 (SURVEY.md 8(d)), all inputs resident in HBM except the per-ping 512 ranges (2 KiB).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--map grid|mesh] [--particles P]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--map mesh|grid|mesh-general|mesh-tin]
+                    [--particles P] [--scaling weak|strong] [--total-particles T]
 
-N > 1: launched by torch.distributed.run, one rank per GPU.  Particles shard by contiguous
-global id (weak scaling: P particles per GPU); the data-path collectives are native RCCL calls
-inside libmcl_hip.so, torch.distributed (gloo) only carries the RCCL unique id and the timing
-barrier.  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU over RCCL.  Either an external launcher provides RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* (python -m torch.distributed.run ... bench.py --gpus N), or -- when WORLD_SIZE is
+unset -- this process spawns the N ranks itself (launch(): plain child processes created BEFORE anything
+here touches the GPU; the parent never imports torch or the engine) and relays rank 0's JSON line.
+A rank count that differs from --gpus is an error (exit 2), a rank that fails or a run that exceeds
+--launch-timeout ends every rank and exits non-zero: the bench never hangs and never silently measures
+fewer GPUs than asked.  Particles shard by contiguous global id; the data-path collectives are native
+RCCL calls inside libmcl_hip.so, torch.distributed (gloo) carries only the RCCL unique id and the timing
+barrier.  `rccl_ranks` in the output is an ncclAllReduce(sum) of 1 over the data-path communicator.
+
+--scaling weak (default): --particles per GPU (1 048 576: the metric's configuration on every GPU).
+--scaling strong: --total-particles (default 4 194 304 = BASELINE config 4) split over the GPUs.
+`value` counts 1 M-particle filter steps per second over the whole job (steps/s x total particles / 2^20),
+so at N = 1 with the default workload it is plain steps/s of the metric; `steps_per_s` and
+`ms_per_step` are the raw figures of the run.
 """
 import argparse
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = 'filter steps/sec at 1M particles x 512 MBES beams; pose RMSE vs ref'
+MIN_TIMED_STEPS = 200   # SURVEY 8(d): wall-clock over >= 200 steps, median + p95
+SIGMA, R_MAX = 0.2, 100.0
+COV = dict(init_cov=[2.0, 2.0, 0.0, 0.0, 0.0, 0.05], process_cov=[1e-4, 1e-4, 0.0, 0.0, 0.0, 1e-6],
+           resample_cov=[1e-3, 1e-3, 0.0, 0.0, 0.0, 1e-5])
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--particles', type=int, default=1048576, help='particles per GPU')
+    ap.add_argument('--particles', type=int, default=1048576, help='particles per GPU (weak scaling)')
+    ap.add_argument('--total-particles', type=int, default=4194304, help='total particles (strong scaling)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--beams', type=int, default=512)
-    ap.add_argument('--map', default='mesh', choices=['grid', 'mesh'])
+    ap.add_argument('--map', default='mesh', choices=['grid', 'mesh', 'mesh-general', 'mesh-tin'])
+    ap.add_argument('--mesh-general', action='store_true', help='same as --map mesh-general')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--mesh-general', action='store_true',
-                    help='do not use the structured-mesh path (detected for triangulated regular grids)')
+    ap.add_argument('--no-extra', action='store_true', help='skip the extra workload legs (N = 1 runs them by default)')
+    ap.add_argument('--only-main', action='store_true', help='same as --no-extra --no-cpu-baseline (profiling runs)')
     ap.add_argument('--cpu-particles', type=int, default=0, help='oracle sample size (0 = auto)')
-    return ap.parse_args()
+    ap.add_argument('--rmse-particles', type=int, default=0,
+                    help='particles of the GPU-vs-oracle trajectory comparison (0 = the oracle sample; 1048576 = metric size)')
+    ap.add_argument('--no-overlap', action='store_true', help='in-line state all-gather (no second communicator)')
+    ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-spawned ranks: wall-clock limit, seconds')
+    # launcher self-test (CPU, gloo): rendezvous + barrier + all-reduce only, no engine, no GPU
+    ap.add_argument('--dry-run', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--dry-run-fail-rank', type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument('--dry-run-hang-rank', type=int, default=-1, help=argparse.SUPPRESS)
+    a = ap.parse_args(argv)
+    if a.mesh_general:
+        a.map = 'mesh-general'
+    if a.only_main:
+        a.no_extra = a.no_cpu_baseline = True
+    return a
 
 
+# ------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(a, argv):
+    """Spawn a.gpus ranks of this script (fresh processes; nothing in this parent has touched the GPU)
+    and wait for them.  Rank 0 inherits stdout (the ONE JSON line); the other ranks' stdout goes to
+    stderr.  Returns the exit code: 0 only if every rank exited 0."""
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), MCL_BENCH_SPAWNED='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC only on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr, start_new_session=True))
+
+    def end_all():
+        for p in procs:  # exact process groups we created, never a pattern
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, 15)
+                except OSError:
+                    pass
+        t_end = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, 9)
+                except OSError:
+                    pass
+
+    deadline = time.time() + a.launch_timeout
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                sys.stderr.write('bench launcher: rank %d exited with code %d; ending the other ranks\n' % bad[0])
+                end_all()
+                return bad[0][1] if 0 < bad[0][1] < 256 else 1
+            if all(c == 0 for c in codes):
+                return 0
+            if time.time() > deadline:
+                sys.stderr.write('bench launcher: ranks still running after %.0f s; ending them\n' % a.launch_timeout)
+                end_all()
+                return 124
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        end_all()
+        return 130
+
+
+# ------------------------------------------------------------------------------------------ workloads
 def build_map(kind):
     from smarc_navigation_amd import synth
     if kind == 'grid':
@@ -51,30 +148,33 @@ def build_map(kind):
                     desc='512x512 fp32 height grid, 1 m cells')
     origin = (-64.0, -354.0)
     z = synth.bathymetry_grid(708, 708, 1.0, origin, seed=3)
-    verts, tris = synth.mesh_from_grid(z, 1.0, origin)
-    return dict(kind='mesh', z=z, origin=origin, res=1.0, verts=verts, tris=tris,
-                bytes=verts.nbytes + tris.nbytes,
-                desc='%d-triangle mesh (708x708 height field triangulated)' % tris.shape[0])
-
-
-a_mesh_general = [False]  # --mesh-general: force the triangle-record traversal (arbitrary soups)
+    if kind == 'mesh-tin':
+        verts, tris = synth.mesh_tin(z, 1.0, origin, seed=7)
+        desc = '%d-triangle irregular TIN (708x708 nodes jittered in xy, random diagonals)' % tris.shape[0]
+    else:
+        verts, tris = synth.mesh_from_grid(z, 1.0, origin)
+        desc = '%d-triangle mesh (708x708 height field triangulated)' % tris.shape[0]
+        if kind == 'mesh-general':
+            desc += ', general triangle-record traversal forced'
+    return dict(kind=kind, z=z, origin=origin, res=1.0, verts=verts, tris=tris, bytes=verts.nbytes + tris.nbytes, desc=desc)
 
 
 def attach_map(e, m):
     if m['kind'] == 'grid':
         e.set_map_grid(m['z'], m['origin'], m['res'])
     else:
-        e.set_map_mesh(m['verts'], m['tris'], general=(a_mesh_general[0]))
+        e.set_map_mesh(m['verts'], m['tris'], general=(m['kind'] == 'mesh-general'))
 
 
-def make_ranges(engine_mod, m, stream, n_steps, beam_angles, sigma, r_max, device=0):
-    """Synthetic pings: expected ranges at the truth pose (one-particle engine on the GPU) + noise."""
+def make_ranges(engine_mod, m, truth, beam_angles, sigma, r_max, device=0, seed=4):
+    """Synthetic pings: expected ranges at the truth poses (one-particle engine on the GPU) + noise."""
+    import numpy as np
     e = engine_mod.Engine(1, rng_mode=engine_mod.RNG_REPLAY, device=device)  # this rank's own GPU
     attach_map(e, m)
-    rs = np.random.RandomState(4)
-    out = np.zeros((n_steps, beam_angles.size), np.float32)
-    for k in range(n_steps):
-        e.set_particles(stream['truth'][k][:, None].copy())
+    rs = np.random.RandomState(seed)
+    out = np.zeros((len(truth), beam_angles.size), np.float32)
+    for k in range(len(truth)):
+        e.set_particles(truth[k][:, None].copy())
         out[k] = e.mbes_expected(0, 1, beam_angles, r_max)[0] + sigma * rs.randn(beam_angles.size)
     e.close()
     return out
@@ -94,9 +194,27 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(m, stream, ranges, beam_angles, sigma, r_max, cov, n_full, n_sample, threads, budget_s):
+def source_hash():
+    """Hash of the kernel sources the PMC figures in profiles/ were taken at: a stale profile is never
+    attached to a bench line of different kernels."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'smarc_navigation_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.h', '.hip')):
+            with open(os.path.join(d, name), 'rb') as f:
+                h.update(name.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
+def pctl(v, q):
+    import numpy as np
+    return float(np.percentile(np.asarray(v, dtype=np.float64), q))
+
+
+def cpu_baseline(m, stream, ranges, beam_angles, cov, n_full, n_sample, threads, budget_s, max_steps=20):
     """The oracle (C restatement; its particle loops run on `threads` host threads) on a bounded
     sample of the same workload."""
+    import numpy as np
     from oracle import oracle as orc
     threads = orc.set_threads(threads)
     amap = orc.Grid(m['z'], m['origin'], m['res']) if m['kind'] == 'grid' else orc.Mesh(m['verts'], m['tris'])
@@ -111,7 +229,7 @@ def cpu_baseline(m, stream, ranges, beam_angles, sigma, r_max, cov, n_full, n_sa
         k = steps
         orc.predict(soa, stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'],
                     cov['process_cov'], orc.native_normals(n, 0, 5, 1, k))
-        lw, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, amap, beam_angles, ranges[k], sigma, r_max,
+        lw, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, amap, beam_angles, ranges[k], SIGMA, R_MAX,
                                 want_expected=False)
         idx, ncum, q = orc.systematic_fixed(lw, 1, orc.native_u53(5, k))
         lost, dupes = orc.lost_dupes(idx)
@@ -122,7 +240,7 @@ def cpu_baseline(m, stream, ranges, beam_angles, sigma, r_max, cov, n_full, n_sa
         means.append([m6[0], m6[1]])
         steps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or steps >= min(len(ranges), 20):
+        if el > budget_s or steps >= min(len(ranges), max_steps):
             break
     per_step = el / steps
     return dict(value=(n / float(n_full)) / per_step, unit='steps/s', cores=threads, kind='port',
@@ -131,50 +249,191 @@ def cpu_baseline(m, stream, ranges, beam_angles, sigma, r_max, cov, n_full, n_sa
                        'scaled linearly to %d particles' % (n, beam_angles.size, steps, threads, per_step, n_full))
 
 
-def main():
-    a = parse()
-    a_mesh_general[0] = a.mesh_general
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != a.gpus and world > 1:
-        a.gpus = world
-    dist = None
-    if world > 1:
-        # torch first: its bundled HIP runtime / RCCL are then the single copies in the process and
-        # libmcl_hip.so binds to them (loading the library first would map a second HIP runtime)
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+def alg_bytes(P, B, map_bytes, world):
+    """Algorithmic (compulsory) HBM bytes per step of each phase."""
+    return {
+        'predict': 72.0 * P,
+        'update_mbes': 56.0 * P + 8.0 * B + map_bytes,
+        'normalise': 24.0 * P,
+        'scan': 28.0 * P,
+        'resample': 12.0 * P * world + 96.0 * P,
+        'mean_cov': 80.0 * P,
+    }
 
-    from smarc_navigation_amd import engine, synth
 
-    P, B = a.particles, a.beams
-    sigma, r_max = 0.2, 100.0
-    cov = dict(init_cov=[2.0, 2.0, 0.0, 0.0, 0.0, 0.05], process_cov=[1e-4, 1e-4, 0.0, 0.0, 0.0, 1e-6],
-               resample_cov=[1e-3, 1e-3, 0.0, 0.0, 0.0, 1e-5])
-    m = build_map(a.map)
-    total_steps = a.steps + a.warmup
-    stream = synth.odom_stream(total_steps)
+def kernel_table(tim, alg, steps):
+    kernels = {}
+    for name, (ms, cnt) in tim.items():
+        if cnt == 0:
+            continue
+        entry = dict(avg_ms=round(ms / cnt, 5), ms_per_step=round(ms / steps, 5), regions=int(cnt))
+        if name in alg and ms > 0:
+            gbs = alg[name] * steps / (ms * 1e-3) / 1e9
+            entry.update(alg_bytes_per_step=alg[name], achieved_gbs=round(gbs, 2), hbm_frac=round(gbs / HBM_PEAK_GBS, 5))
+        kernels[name] = entry
+    return kernels
+
+
+def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, resample=True, landmarks=None):
+    """One extra workload leg on a fresh engine: returns ms per step (wall, synchronised around the timed
+    block) and the per-phase HIP-event times.  resample=False: predict + MBES update only (the cloud
+    keeps its width); landmarks=(xyz, n_det): config 5 -- the landmark k-NN update accumulates onto the
+    MBES log-likelihood of the same ping."""
+    import numpy as np
+    from smarc_navigation_amd import synth
+    cov = cov or COV
+    total = steps + warmup
+    stream = synth.odom_stream(total, x0=x0)
     ba = synth.beam_angles(B)
+    ranges = make_ranges(engine, m, stream['truth'], ba, SIGMA, R_MAX, device=device)
+    e = engine.Engine(P, seed=5, device=device, **cov)
+    attach_map(e, m)
+    dets = None
+    if landmarks is not None:
+        lm_xyz, n_det = landmarks
+        e.set_landmarks(lm_xyz)
+        rs = np.random.RandomState(8)
+        dets = np.zeros((total, n_det, 3))
+        for k in range(total):
+            t = stream['truth'][k]
+            T = synth.rigid_matrix(*t)
+            d2 = np.sum((lm_xyz[:, :2] - t[:2]) ** 2, axis=1)
+            near = lm_xyz[np.argsort(d2)[:n_det]]
+            dets[k] = (near - T[:3, 3]).dot(T[:3, :3]) + 0.05 * rs.randn(n_det, 3)  # R^T (l - p): sensor frame
+    e.init_particles()
 
-    e = engine.Engine(P, seed=5, device=local_rank, rank=rank, world=world, n_global=P * world,
-                      global_offset=P * rank, **cov)
+    def step(k):
+        if resample and landmarks is None:
+            e.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'], ranges[k], ba,
+                        SIGMA, R_MAX)
+            return
+        e.predict(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'])
+        e.update_mbes(ranges[k], ba, SIGMA, R_MAX)
+        if landmarks is not None:
+            e.update_landmarks(dets[k], 0.3, k=4, gate=11.345, accumulate=True)
+        if resample:
+            e.resample()
+            e.mean_cov_async()
+
+    for k in range(warmup):
+        step(k)
+    e.sync()
+    e.timing_enable(True)
+    t0 = time.perf_counter()
+    for k in range(warmup, total):
+        step(k)
+    e.sync()
+    dt = time.perf_counter() - t0
+    tim = e.timing_get()
+    e.timing_enable(False)
+    e.close()
+    ms = 1e3 * dt / steps
+    out = dict(workload='%d particles x %d beams, %s%s%s' % (
+        P, B, m['desc'], '' if resample else ', predict + MBES update only (no resample: the cloud keeps its width)',
+        '' if landmarks is None else ', + %d detections x %d landmarks k-NN (k=4) per ping' % (landmarks[1], len(landmarks[0]))),
+        steps=steps, ms_per_step=round(ms, 4), steps_per_s=round(1e3 / ms, 2),
+        kernels={k: round(v[0] / steps, 5) for k, v in tim.items() if v[1]})
+    return out
+
+
+# ------------------------------------------------------------------------------------------ worker
+def dry_run(a, rank, world):
+    """Launcher self-test: rendezvous, barrier and a rank count over gloo -- no engine, no GPU."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if rank == a.dry_run_fail_rank:
+        sys.exit(7)
+    if rank == a.dry_run_hang_rank:
+        time.sleep(3600)
     if world > 1:
-        import torch
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        dist.barrier()
+        n = int(t[0])
+        dist.destroy_process_group()
+    else:
+        n = 1
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'n_gpus': world, 'gloo_ranks': n,
+                          'spawned_by_bench': os.environ.get('MCL_BENCH_SPAWNED') == '1'}))
+    return 0
+
+
+def setup_comm(e, engine, dist, rank, world, want_overlap):
+    """RCCL communicator(s) of the data path.  The overlapped state all-gather drives two communicators
+    on two streams; a self-test with a deadline runs that exact pattern first, and if any rank does not
+    complete it every rank aborts and re-initialises without the overlap (in-line gather).  A second
+    failure exits non-zero.  Never hangs: every wait has a deadline."""
+    import torch
+    overlap = want_overlap
+    for attempt in range(2):
         uid = [engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         # RCCL prints a version banner on stdout at communicator creation: keep stdout for the ONE JSON line
         sys.stdout.flush()
         saved = os.dup(1)
         os.dup2(2, 1)
+        ok = 1
         try:
-            e.comm_init(uid[0])
+            e.comm_init(uid[0], overlap=overlap)
+            e.comm_selftest(30000)
+        except engine.MclError as ex:
+            sys.stderr.write('rank %d: communicator self-test failed (%s)\n' % (rank, ex))
+            ok = 0
         finally:
+            sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
+        t = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t[0]) == 1:
+            ranks, has_overlap = e.comm_ranks()
+            return ranks, has_overlap
+        e.comm_shutdown(abort=True)
+        if not overlap:
+            break
+        overlap = False
+    sys.stderr.write('rank %d: no working RCCL communicator\n' % rank)
+    sys.exit(3)
+
+
+def worker(a, rank, world, local_rank):
+    import numpy as np
+    dist = None
+    if world > 1:
+        # torch first: its bundled HIP runtime / RCCL are then the single copies in the process and
+        # libmcl_hip.so binds to them (loading the library first would map a second HIP runtime)
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    from smarc_navigation_amd import engine, synth
+
+    B = a.beams
+    P = a.particles if a.scaling == 'weak' else a.total_particles // world
+    if a.scaling == 'strong' and P * world != a.total_particles:
+        sys.stderr.write('bench: --total-particles must be a multiple of the rank count\n')
+        sys.exit(2)
+    m = build_map(a.map)
+    nblocks = max(1, int(math.ceil(MIN_TIMED_STEPS / float(a.steps))))
+    nblocks = min(nblocks, max(1, (4000 - a.warmup) // a.steps))  # mcl_mean_history keeps 4096 results
+    total_steps = a.warmup + a.steps * nblocks
+    stream = synth.odom_stream(total_steps)
+    ba = synth.beam_angles(B)
+
+    e = engine.Engine(P, seed=5, device=local_rank, rank=rank, world=world, n_global=P * world,
+                      global_offset=P * rank, **COV)
+    rccl_ranks, has_overlap = 1, False
+    if world > 1:
+        rccl_ranks, has_overlap = setup_comm(e, engine, dist, rank, world, not a.no_overlap)
+        if rccl_ranks != world:
+            sys.stderr.write('rank %d: RCCL connected %d ranks, expected %d\n' % (rank, rccl_ranks, world))
+            sys.exit(4)
     attach_map(e, m)
-    ranges = make_ranges(engine, m, stream, total_steps, ba, sigma, r_max, device=local_rank)
+    ranges = make_ranges(engine, m, stream['truth'], ba, SIGMA, R_MAX, device=local_rank)
     e.init_particles()
 
     def barrier():
@@ -185,117 +444,185 @@ def main():
     def run(k0, k1):
         for k in range(k0, k1):
             e.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'],
-                        ranges[k], ba, sigma, r_max)
+                        ranges[k], ba, SIGMA, R_MAX)
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
 
     run(0, a.warmup)
     barrier()
+    # ---- the contract's timed region: EXACTLY --steps steps between two barrier + synchronize pairs
     e.timing_enable(True)
     t0 = time.perf_counter()
-    run(a.warmup, total_steps)
+    run(a.warmup, a.warmup + a.steps)
     barrier()
-    dt = time.perf_counter() - t0
+    dt = max_over_ranks(time.perf_counter() - t0)
     tim = e.timing_get()
     e.timing_enable(False)
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    # pose RMSE of the filter's mean (x, y) against the synthetic ground truth over the timed steps
-    hist = e.mean_history(a.steps)
+    # ---- the same block repeated until >= MIN_TIMED_STEPS steps are timed: median and p95 per block
+    block_ms = [1e3 * dt / a.steps]
+    for b in range(1, nblocks):
+        k0 = a.warmup + b * a.steps
+        t0 = time.perf_counter()
+        run(k0, k0 + a.steps)
+        barrier()
+        block_ms.append(1e3 * max_over_ranks(time.perf_counter() - t0) / a.steps)
+    # pose RMSE of the filter's mean (x, y) against the synthetic ground truth over every timed step
+    n_timed = a.steps * nblocks
+    hist = e.mean_history(n_timed)
     truth = stream['truth'][a.warmup:total_steps]
     pose_rmse = float(np.sqrt(np.mean((hist[:, 0] - truth[:, 0]) ** 2 + (hist[:, 1] - truth[:, 1]) ** 2)))
 
+    out = None
     if rank == 0:
         ms_per_step = 1e3 * dt / a.steps
-        value = world * a.steps / dt * (P / 1048576.0)
-        # per-kernel algorithmic HBM bytes per launch (DESIGN.md "Roofline accounting")
-        alg = {
-            'predict': 72.0 * P,
-            'update_mbes': 56.0 * P + 8.0 * B + m['bytes'],
-            'normalise': 24.0 * P,
-            'scan': 28.0 * P,
-            'resample': 12.0 * P * world + 96.0 * P,
-            'mean_cov': 80.0 * P,
-        }
-        kernels = {}
-        for name, (ms, cnt) in tim.items():
-            if cnt == 0:
-                continue
-            avg = ms / cnt
-            entry = dict(avg_ms=round(avg, 5), regions=int(cnt))
-            if name in alg and avg > 0:
-                per_launch = alg[name] * (a.steps / float(cnt)) if name != 'update_mbes' else alg[name]
-                gbs = alg[name] * a.steps / (ms * 1e-3) / 1e9
-                entry.update(alg_bytes_per_step=alg[name], achieved_gbs=round(gbs, 2),
-                             hbm_frac=round(gbs / HBM_PEAK_GBS, 5))
-            kernels[name] = entry
-        # PMC-measured HBM traffic of the dominant kernel (offline rocprofv3 passes, profiles/r01_traffic.json)
-        traffic, pmc = None, {}
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
-                pmc = json.load(f).get(m['kind'], {})
-            if P == 1048576 and B == 512 and world == 1:
-                traffic = pmc.get('traffic_bytes_per_launch')
-        except (IOError, ValueError):
-            pass
+        total_particles = P * world
+        value = a.steps / dt * (total_particles / 1048576.0)
+        alg = alg_bytes(P, B, m['bytes'], world)
+        kernels = kernel_table(tim, alg, a.steps)
         dom = max((k for k in kernels if k in alg), key=lambda k: tim[k][0])
         dom_ms = tim[dom][0] / a.steps
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
+        # PMC-measured HBM traffic of the dominant kernel: collected offline (counters cannot be read inside
+        # this run) by tools/pmc_summarise.py into profiles/r02_traffic.json, attached ONLY when that file was
+        # taken at the kernel sources this library was built from and at this workload
+        traffic, traffic_source, pmc = None, None, {}
+        src = source_hash()
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r02_traffic.json')) as f:
+                tj = json.load(f)
+            if tj.get('source_hash') == src and P == 1048576 and B == 512 and world == 1:
+                pmc = tj.get(m['kind'], {})
+                traffic = pmc.get('traffic_bytes_per_launch')
+                traffic_source = 'offline: profiles/r02_traffic.json (rocprofv3 --pmc passes, kernel sources %s)' % src
+            elif tj.get('source_hash') != src:
+                traffic_source = 'none: profiles/r02_traffic.json is for kernel sources %s, this library is %s' % (
+                    tj.get('source_hash'), src)
+        except (IOError, ValueError):
+            pass
+        streaming = [k for k in ('predict', 'normalise', 'scan', 'resample', 'mean_cov') if k in kernels]
         out = {
-            'metric': 'filter steps/sec at 1M particles x 512 MBES beams; pose RMSE vs ref',
+            'metric': METRIC,
             'value': round(value, 3), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': a.scaling,
             'vs_baseline': None, 'dtype': 'f64 state / f32 ray-cast', 'data': 'synthetic',
+            'steps_per_s': round(a.steps / dt, 3), 'particles_total': total_particles,
+            'rccl_ranks': rccl_ranks, 'overlapped_state_gather': bool(has_overlap),
+            'launcher': 'bench.py' if os.environ.get('MCL_BENCH_SPAWNED') == '1' else ('external' if world > 1 else 'none'),
+            'timed': {'blocks': nblocks, 'steps_per_block': a.steps, 'steps_total': n_timed,
+                      'ms_per_step_median': round(pctl(block_ms, 50), 4), 'ms_per_step_p95': round(pctl(block_ms, 95), 4),
+                      'ms_per_step_min': round(min(block_ms), 4), 'ms_per_step_max': round(max(block_ms), 4),
+                      'note': 'value/ms_per_step are the first block (exactly --steps steps); the block is repeated '
+                              'until >= %d steps are timed, each between barrier+synchronize pairs' % MIN_TIMED_STEPS},
             'config': {'workload': '%d particles/GPU x %d beams, %s, predict+MBES update+normalise+systematic '
                                    'resample+mean/cov per step' % (P, B, m['desc']),
                        'particles_per_gpu': P, 'beams': B, 'map': m['kind'], 'parallelism': 'particle-shard x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic,
+                         'traffic_source': traffic_source, 'kernel_source_hash': src,
                          'rays_per_s': round(P * B / (dom_ms * 1e-3), 1),
                          'valu_insts_per_ray': (round(pmc['valu_insts_per_launch'] * 64.0 / (P * B), 1)
-                                                if pmc.get('valu_insts_per_launch') and traffic else None),
+                                                if pmc.get('valu_insts_per_launch') else None),
                          'valu_lane_utilisation': (round(pmc['valu_lane_utilisation'], 3)
-                                                   if pmc.get('valu_lane_utilisation') and traffic else None),
+                                                   if pmc.get('valu_lane_utilisation') else None),
                          # share of the chip's vector-issue slots: a wave64 VALU instruction occupies a SIMD-32
                          # for 2 cycles (MI355X_MICROARCH.md "Wave scheduling"), 1024 SIMDs at 2.4 GHz
                          'valu_issue_frac': (round(pmc['valu_insts_per_launch'] / (dom_ms * 1e-3) / (1024 * 2.4e9 / 2.0), 3)
-                                             if pmc.get('valu_insts_per_launch') and traffic else None),
-                         'note': 'the ray-cast is VALU-bound, not HBM-bound (SURVEY 8d): PMC SQ_INSTS_VALU wave-instructions '
-                                 'per ray-lane, the fraction of lanes active in them and the share of vector-issue '
-                                 'slots they fill (profiles/r01_traffic.json); streaming kernels are listed in "kernels" with their own HBM fractions'},
+                                             if pmc.get('valu_insts_per_launch') else None),
+                         'streaming_ms_per_step': round(sum(kernels[k]['ms_per_step'] for k in streaming), 5),
+                         'note': 'the ray-cast is VALU-bound, not HBM-bound (SURVEY 8d); valu_* come from the offline PMC '
+                                 'passes named in traffic_source (null when that file does not match this library); '
+                                 'streaming kernels are listed in "kernels" with their own HBM fractions'},
             'kernels': kernels,
             'pose_rmse_m': round(pose_rmse, 4),
         }
-        if world == 1 and not a.no_cpu_baseline:
-            # all host cores (the oracle's particle loops are OpenMP-parallel) and, beside it, one thread
-            ns = a.cpu_particles or (8192 if m['kind'] == 'grid' else 4096)
-            cores = host_cores()
-            one = cpu_baseline(m, stream, ranges, ba, sigma, r_max, cov, 1048576, ns, 1, 8.0)
-            allc = cpu_baseline(m, stream, ranges, ba, sigma, r_max, cov, 1048576, ns * min(cores, 32), cores, 10.0)
-            allc['value_1thread'] = one['value']
-            allc['sample_1thread'] = one['sample']
-            # "pose RMSE vs ref": the same filter (same Philox draws, same stream and map) on the GPU at the
-            # oracle's sample size, mean (x, y) trajectory against the oracle's over the steps it ran
-            ref_xy, n_ref = allc.pop('_means'), allc.pop('_n')
-            one.pop('_means'), one.pop('_n')
-            g = engine.Engine(n_ref, seed=5, device=local_rank, **cov)
-            attach_map(g, m)
-            g.init_particles()
-            for k in range(len(ref_xy)):
-                g.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'],
-                            ranges[k], ba, sigma, r_max)
-            g.sync()
-            gh = g.mean_history(len(ref_xy))
-            g.close()
-            allc['pose_rmse_vs_oracle_m'] = float('%.3g' % np.sqrt(np.mean(np.sum((gh[:, :2] - ref_xy) ** 2, axis=1))))
-            out['pose_rmse_vs_oracle_m'] = allc['pose_rmse_vs_oracle_m']
-            out['cpu_baseline'] = allc
+    e.close()
+
+    # ---- N = 1: CPU baseline, trajectory RMSE against the oracle, extra workload legs
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # all host cores (the oracle's particle loops are OpenMP-parallel) and, beside it, one thread
+        ns = a.cpu_particles or (8192 if m['kind'] == 'grid' else 4096)
+        cores = host_cores()
+        one = cpu_baseline(m, stream, ranges, ba, COV, 1048576, ns, 1, 8.0)
+        allc = cpu_baseline(m, stream, ranges, ba, COV, 1048576, ns * min(cores, 32), cores, 10.0)
+        allc['value_1thread'] = one['value']
+        allc['sample_1thread'] = one['sample']
+        # "pose RMSE vs ref": the same filter (same Philox draws, same stream and map) on the GPU at the
+        # oracle's sample size, mean (x, y) trajectory against the oracle's over the steps it ran
+        ref_xy, n_ref = allc.pop('_means'), allc.pop('_n')
+        one.pop('_means'), one.pop('_n')
+        if a.rmse_particles and a.rmse_particles != n_ref:
+            big = cpu_baseline(m, stream, ranges, ba, COV, 1048576, a.rmse_particles, cores, 1e9, max_steps=10)
+            ref_xy, n_ref = big.pop('_means'), big.pop('_n')
+        g = engine.Engine(n_ref, seed=5, device=local_rank, **COV)
+        attach_map(g, m)
+        g.init_particles()
+        for k in range(len(ref_xy)):
+            g.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'],
+                        ranges[k], ba, SIGMA, R_MAX)
+        g.sync()
+        gh = g.mean_history(len(ref_xy))
+        g.close()
+        rm = float('%.3g' % np.sqrt(np.mean(np.sum((gh[:, :2] - ref_xy) ** 2, axis=1))))
+        out['pose_rmse_vs_oracle_m'] = rm
+        out['pose_rmse_vs_oracle_at'] = '%d particles x %d beams x %d steps (GPU filter vs oracle, same Philox draws)' % (
+            n_ref, B, len(ref_xy))
+        allc['pose_rmse_vs_oracle_m'] = rm
+        out['cpu_baseline'] = allc
+    if rank == 0 and world == 1 and not a.no_extra:
+        extra = {}
+        legs = []
+        mesh = m if a.map == 'mesh' else build_map('mesh')
+        if a.map != 'grid':
+            legs.append(('grid', dict(m=build_map('grid'), P=1048576, B=512, steps=30, warmup=5)))
+        if a.map != 'mesh-general':
+            mg = dict(mesh, kind='mesh-general', desc=mesh['desc'] + ', general triangle-record traversal forced')
+            legs.append(('mesh_general', dict(m=mg, P=1048576, B=512, steps=20, warmup=3)))
+        if a.map != 'mesh-tin':
+            legs.append(('mesh_tin', dict(m=build_map('mesh-tin'), P=1048576, B=512, steps=20, warmup=3)))
+        # global-localisation regime: sigma = 50 m cloud in the map interior, nothing collapses it
+        legs.append(('cloud_wide', dict(m=mesh, P=1048576, B=512, steps=10, warmup=2, x0=250.0, resample=False,
+                                        cov=dict(COV, init_cov=[2500.0, 2500.0, 0.0, 0.0, 0.0, 0.05]))))
+        legs.append(('cloud_converged_update_only', dict(m=mesh, P=1048576, B=512, steps=10, warmup=2, x0=250.0,
+                                                         resample=False)))
+        legs.append(('config2', dict(m=build_map('grid'), P=65536, B=256, steps=200, warmup=20)))
+        legs.append(('config4_shard', dict(m=mesh, P=524288, B=512, steps=30, warmup=5)))
+        legs.append(('config5_shard', dict(m=mesh, P=524288, B=512, steps=30, warmup=5,
+                                           landmarks=(synth.landmark_map(4096, (-64.0, -354.0, 643.0, 353.0)), 16))))
+        for name, kw in legs:
+            try:
+                extra[name] = run_leg(engine, name, kw.pop('m'), kw.pop('P'), kw.pop('B'), kw.pop('steps'), kw.pop('warmup'),
+                                      device=local_rank, **kw)
+            except Exception as ex:  # a failing leg must not cost the headline line
+                extra[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+        out['extra'] = extra
+    if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    e.close()
+    return 0
+
+
+def main():
+    a = parse()
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and a.gpus > 1:
+        sys.exit(launch(a, sys.argv[1:]))
+    world = int(env_world) if env_world is not None else 1
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        sys.stderr.write('bench: WORLD_SIZE=%d but --gpus %d: refusing to measure a different rank count\n' % (world, a.gpus))
+        sys.exit(2)
+    if a.dry_run:
+        sys.exit(dry_run(a, rank, world))
+    sys.exit(worker(a, rank, world, local_rank))
 
 
 if __name__ == '__main__':

@@ -183,6 +183,9 @@ int mcl_resample_prepare(mcl_handle* h, int64_t* n_uniforms);
 
 /* ---- a13: loc_loop/update_loc_pose (auv_pf.py:218-285) */
 int mcl_mean_cov(mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9]);
+/* the same evaluation queued on the handle's stream without waiting for it: the result lands in the
+ * pinned ring that mcl_last_mean_cov / mcl_mean_history read */
+int mcl_mean_cov_async(mcl_handle* h);
 /* PoseArray payload: n x 7 doubles (x,y,z,qx,qy,qz,qw), quaternion_from_euler per particle */
 int mcl_get_poses(mcl_handle* h, double* pose7);
 
@@ -216,6 +219,20 @@ int mcl_resample_indices(int32_t scheme, const double* weights, int64_t n, const
  * all-gather (shard totals, offspring CDF, ancestor states) */
 int mcl_comm_unique_id(char id[128]);
 int mcl_comm_init(mcl_handle* h, const char id[128]); /* MCL_COMM_RCCL: collective over all ranks */
+/* flags: MCL_COMM_NO_OVERLAP = no second communicator; the pre-resample state all-gather then runs
+ * in line on the handle's stream instead of under the measurement update (also: env MCL_NO_OVERLAP=1) */
+#define MCL_COMM_NO_OVERLAP 1u
+int mcl_comm_init_ex(mcl_handle* h, const char id[128], uint32_t flags);
+/* ranks = ncclAllReduce(sum) of 1 over the communicator (1 without one): the number of ranks RCCL really
+ * connected; overlap (optional) = 1 if the second communicator for the overlapped gather exists */
+int mcl_comm_ranks(mcl_handle* h, int32_t* ranks, int32_t* overlap);
+/* Runs the collective pattern of one mcl_step_mbes (state all-gather on the second communicator while the
+ * first one reduces and gathers) three times and waits for it with a deadline.  On a timeout BOTH
+ * communicators are aborted (ncclCommAbort) and MCL_ERR_COMM is returned -- the caller can then
+ * re-initialise with MCL_COMM_NO_OVERLAP under a fresh unique id, or exit: it never hangs. */
+int mcl_comm_selftest(mcl_handle* h, int32_t timeout_ms);
+/* destroy (abort = 0, after draining the streams) or abort the communicators; the handle stays usable */
+int mcl_comm_shutdown(mcl_handle* h, int32_t abort);
 /* MCL_COMM_LOCAL: all shards live in this process; the exchange steps are device copies.  The
  * sharded algorithm (and therefore every result bit) is the one the RCCL path runs. */
 int mcl_group_resample(mcl_handle** shards, int32_t n_shards, const double* uniforms, int64_t n_uniforms,

@@ -84,6 +84,11 @@ SYMBOLS = {
     'mcl_resample_indices': (C.c_int, [_i32, _vp, _i64, _vp, _i64, _i32, _vp]),
     'mcl_comm_unique_id': (C.c_int, [C.c_char_p]),
     'mcl_comm_init': (C.c_int, [_vp, C.c_char_p]),
+    'mcl_comm_init_ex': (C.c_int, [_vp, C.c_char_p, C.c_uint32]),
+    'mcl_comm_ranks': (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    'mcl_comm_selftest': (C.c_int, [_vp, _i32]),
+    'mcl_comm_shutdown': (C.c_int, [_vp, _i32]),
+    'mcl_mean_cov_async': (C.c_int, [_vp]),
     'mcl_group_resample': (C.c_int, [C.POINTER(_vp), _i32, _vp, _i64, C.POINTER(_vp)]),
     'mcl_group_mean_cov': (C.c_int, [C.POINTER(_vp), _i32, _vp, _vp, _vp]),
     'mcl_timing_enable': (C.c_int, [_vp, _i32]),

@@ -4,11 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mcl.h"
@@ -104,6 +106,18 @@ struct mcl_handle {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_state_ready = nullptr, ev_gather_done = nullptr;
   bool gather_inflight = false;
+  // environment switches, read once in mcl_create (never on the per-measurement path)
+  bool env_profile = false, env_debug_work = false, env_force_comm = false, env_no_overlap = false;
+  // pinned staging so that asynchronous uploads never read caller-owned pageable memory after the call returns
+  struct PinSlot {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;  // recorded after the async copy out of this slot
+    bool used = false;
+  } pin_ring[8];
+  unsigned pin_next = 0;
+  int* asg_dev = nullptr;  // landmark assignment output (cached, grown on demand)
+  size_t asg_cap = 0;
   std::string err;
 };
 
@@ -258,11 +272,39 @@ NoiseArgs noise_args(const mcl_handle* h, const double cov[6], uint32_t purpose,
   return a;
 }
 
+// Host -> device upload that honours "the caller owns every host buffer" (include/mcl.h): when the call
+// returns the caller may overwrite `src`.  Small payloads (ranges, detections, uniforms) are copied into a
+// ring of pinned slots and travel asynchronously; large ones (REPLAY normals: the parity path, not the
+// production path) are copied synchronously.
+int upload(mcl_handle* h, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return MCL_OK;
+  if (bytes > (1u << 20)) {
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MCL_OK;
+  }
+  mcl_handle::PinSlot& sl = h->pin_ring[h->pin_next++ % 8u];
+  if (sl.used) HIPCHK(h, hipEventSynchronize(sl.ev));
+  if (sl.cap < bytes) {
+    if (sl.p) (void)hipHostFree(sl.p);
+    sl.p = nullptr;
+    sl.cap = 0;
+    size_t cap = 4096;
+    while (cap < bytes) cap <<= 1;
+    HIPCHK(h, hipHostMalloc(&sl.p, cap, hipHostMallocDefault));
+    sl.cap = cap;
+  }
+  if (!sl.ev) HIPCHK(h, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+  memcpy(sl.p, src, bytes);
+  HIPCHK(h, hipMemcpyAsync(dst, sl.p, bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipEventRecord(sl.ev, h->stream));
+  sl.used = true;
+  return MCL_OK;
+}
+
 int upload_replay(mcl_handle* h, const double* normals) {
   if (!h->replay_dev) HIPCHK(h, hipMalloc(&h->replay_dev, sizeof(double) * 6 * (size_t)h->n));
-  HIPCHK(h, hipMemcpyAsync(h->replay_dev, normals, sizeof(double) * 6 * (size_t)h->n, hipMemcpyHostToDevice,
-                           h->stream));
-  return MCL_OK;
+  return upload(h, h->replay_dev, normals, sizeof(double) * 6 * (size_t)h->n);
 }
 
 int set_device(mcl_handle* h) {
@@ -409,6 +451,15 @@ int exchange_cdf_state(mcl_handle** sh, int ns) {
 
 // The pre-resample state is final once predict has run (updates only read it): send it on the
 // second communicator/stream so the 48 B x N_global all-gather overlaps the ray-cast.
+// an overlapped gather that will not be consumed (error return, state overwritten by the caller):
+// let it finish, then forget it, so the next resample gathers the state it actually resamples
+int cancel_state_gather(mcl_handle* h) {
+  if (!h->gather_inflight) return MCL_OK;
+  h->gather_inflight = false;
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather_done, 0));
+  return MCL_OK;
+}
+
 int start_state_gather(mcl_handle* h) {
   if (!h->comm2 || !h->state_glob) return MCL_OK;
   HIPCHK(h, hipEventRecord(h->ev_state_ready, h->stream));
@@ -530,7 +581,7 @@ int make_uniforms(mcl_handle* h, const double* uniforms, long long nu, long long
   const double* rp = nullptr;
   if (h->cfg.rng_mode == MCL_RNG_REPLAY) {
     if (!uniforms || nu < need) return fail(h, MCL_ERR_INVALID, "resample: not enough replay uniforms for this scheme");
-    HIPCHK(h, hipMemcpyAsync(h->uni_dev, uniforms, sizeof(double) * (size_t)need, hipMemcpyHostToDevice, h->stream));
+    RET_IF(upload(h, h->uni_dev, uniforms, sizeof(double) * (size_t)need));
     rp = h->uni_dev;
   }
   k_make_u53<<<grid_for(need), MCL_BLOCK, 0, h->stream>>>(rp, need, (u32)h->cfg.seed, (u32)(h->cfg.seed >> 32),
@@ -730,8 +781,7 @@ int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, i
       sc[b].x = (float)std::sin((double)beam_angles[b]);
       sc[b].y = (float)std::cos((double)beam_angles[b]);
     }
-    HIPCHK(h, hipMemcpyAsync(h->beam_sc, sc.data(), sizeof(float2) * (size_t)B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // sc is a local
+    RET_IF(upload(h, h->beam_sc, sc.data(), sizeof(float2) * (size_t)B));
     h->beam_cache.assign(beam_angles, beam_angles + B);
     int lo = 0, hi = 0;
     bool finite = true;
@@ -747,8 +797,7 @@ int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, i
     for (int b = 1; b < B && asc; ++b) asc = beam_angles[b] >= beam_angles[b - 1];
     h->beams_sorted = asc;
   }
-  if (ranges)
-    HIPCHK(h, hipMemcpyAsync(h->ranges_dev, ranges, sizeof(float) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+  if (ranges) RET_IF(upload(h, h->ranges_dev, ranges, sizeof(float) * (size_t)B));
   return MCL_OK;
 }
 
@@ -856,8 +905,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   else if (h->mesh->heights && !h->force_general_mesh) {
     // per-ray fast traversal by default; MCL_PROFILE=1 selects the experimental profile-marching kernel
     // (exact and tested, but measured slower in round 1: 3.7 ms vs 2.9 ms at 1 M x 512 -- DESIGN.md 5c)
-    const char* p_env = getenv("MCL_PROFILE");
-    if (!(p_env && p_env[0] == '1')) {
+    if (!h->env_profile) {
       LAUNCH_CAST(2);
     } else {
       if (with_ranges) {
@@ -872,7 +920,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   else
     LAUNCH_CAST(1);
 #undef LAUNCH_CAST
-  if (getenv("MCL_DEBUG_WORK")) {  // diagnostics: how many groups the fast kernel deferred
+  if (h->env_debug_work) {  // diagnostics: how many groups the fast kernel deferred
     int cnt = 0;
     (void)hipMemcpyAsync(&cnt, a.work_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
     (void)hipStreamSynchronize(h->stream);
@@ -1008,6 +1056,7 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
     return MCL_ERR_INVALID;
   }
   hipDeviceProp_t prop;
+  memset(&prop, 0, sizeof prop);
   if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
     g_create_err = std::string("mcl_create: device is not gfx950 (found ") + prop.gcnArchName + ")";
     return MCL_ERR_NO_DEVICE;
@@ -1021,6 +1070,16 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
   h->goff = h->world > 1 ? cfg->global_offset : 0;
   h->device = cfg->device;
   memset(&h->tacc, 0, sizeof h->tacc);
+  {
+    auto on = [](const char* name) {
+      const char* v = getenv(name);
+      return v && v[0] == '1';
+    };
+    h->env_profile = on("MCL_PROFILE");
+    h->env_debug_work = getenv("MCL_DEBUG_WORK") != nullptr;
+    h->env_force_comm = on("MCL_FORCE_COMM");
+    h->env_no_overlap = on("MCL_NO_OVERLAP");
+  }
   if (h->ng > 0xffffffffll || h->goff + h->n > h->ng || h->rank >= h->world) {
     g_create_err = "mcl_create: inconsistent shard geometry";
     delete h;
@@ -1079,6 +1138,7 @@ int mcl_destroy(mcl_handle* h) {
   }
   if (h->comm2) ncclCommDestroy(h->comm2);
   if (h->comm) ncclCommDestroy(h->comm);
+  h->comm2 = h->comm = nullptr;
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   if (h->ev_state_ready) (void)hipEventDestroy(h->ev_state_ready);
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
@@ -1092,6 +1152,11 @@ int mcl_destroy(mcl_handle* h) {
   if (h->landmarks) landmarks_free(h->landmarks);
   if (h->det_dev) (void)hipFree(h->det_dev);
   if (h->host_pin) (void)hipHostFree(h->host_pin);
+  for (auto& sl : h->pin_ring) {
+    if (sl.ev) (void)hipEventDestroy(sl.ev);
+    if (sl.p) (void)hipHostFree(sl.p);
+  }
+  if (h->asg_dev) (void)hipFree(h->asg_dev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return MCL_OK;
@@ -1106,6 +1171,7 @@ int mcl_init_particles(mcl_handle* h, const double* replay_normals) {
     RET_IF(upload_replay(h, replay_normals));
     rp = h->replay_dev;
   }
+  RET_IF(cancel_state_gather(h));
   NoiseArgs a = noise_args(h, h->cfg.init_cov, 0u, 0u);
   t_begin(h, MCL_K_NOISE);
   k_add_noise<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, rp, 1);
@@ -1120,6 +1186,7 @@ int mcl_init_particles(mcl_handle* h, const double* replay_normals) {
 int mcl_predict(mcl_handle* h, const mcl_odom* odom, double dt, const double* replay_normals) {
   if (!h || !odom) return MCL_ERR_INVALID;
   RET_IF(set_device(h));
+  RET_IF(cancel_state_gather(h));
   return do_predict(h, odom, dt, replay_normals);
 }
 
@@ -1249,12 +1316,19 @@ int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, do
   if (!h->landmarks) return fail(h, MCL_ERR_STATE, "update_landmarks: no feature map (call mcl_set_landmarks first)");
   if (accumulate && !h->have_lw) return fail(h, MCL_ERR_STATE, "update_landmarks: nothing to accumulate onto");
   RET_IF(set_device(h));
-  std::string err;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  int rc = landmarks_build(h->landmarks, sigma * std::sqrt(gate), &err);
-  if (rc != MCL_OK) {
-    h->err = err;
-    return rc;
+  {
+    // the cell grid depends on the gate radius only: rebuild (and drain the stream first -- the old
+    // arrays may still be read by a kernel in flight) only when it changes
+    const double radius = sigma * std::sqrt(gate);
+    if (!(h->landmarks->built_for == radius && h->landmarks->lm)) {
+      std::string err;
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      int rc = landmarks_build(h->landmarks, radius, &err);
+      if (rc != MCL_OK) {
+        h->err = err;
+        return rc;
+      }
+    }
   }
   if (n_det > h->det_cap) {
     if (h->det_dev) (void)hipFree(h->det_dev);
@@ -1262,7 +1336,7 @@ int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, do
     HIPCHK(h, hipMalloc(&h->det_dev, sizeof(double) * 3 * (size_t)n_det));
     h->det_cap = n_det;
   }
-  HIPCHK(h, hipMemcpyAsync(h->det_dev, det_xyz, sizeof(double) * 3 * (size_t)n_det, hipMemcpyHostToDevice, h->stream));
+  RET_IF(upload(h, h->det_dev, det_xyz, sizeof(double) * 3 * (size_t)n_det));
   static const double zero6[6] = {0, 0, 0, 0, 0, 0};
   const double* so = sensor_offset ? sensor_offset : zero6;
   LandmarkArgs a;
@@ -1308,12 +1382,19 @@ int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_
   if (!h->landmarks) return fail(h, MCL_ERR_STATE, "update_landmarks_assign: no feature map (call mcl_set_landmarks first)");
   if (accumulate && !h->have_lw) return fail(h, MCL_ERR_STATE, "update_landmarks_assign: nothing to accumulate onto");
   RET_IF(set_device(h));
-  std::string err;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  int rc = landmarks_build(h->landmarks, sigma * std::sqrt(gate), &err);
-  if (rc != MCL_OK) {
-    h->err = err;
-    return rc;
+  {
+    // the cell grid depends on the gate radius only: rebuild (and drain the stream first -- the old
+    // arrays may still be read by a kernel in flight) only when it changes
+    const double radius = sigma * std::sqrt(gate);
+    if (!(h->landmarks->built_for == radius && h->landmarks->lm)) {
+      std::string err;
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      int rc = landmarks_build(h->landmarks, radius, &err);
+      if (rc != MCL_OK) {
+        h->err = err;
+        return rc;
+      }
+    }
   }
   if (n_det > h->det_cap) {
     if (h->det_dev) (void)hipFree(h->det_dev);
@@ -1321,10 +1402,20 @@ int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_
     HIPCHK(h, hipMalloc(&h->det_dev, sizeof(double) * 3 * (size_t)n_det));
     h->det_cap = n_det;
   }
-  HIPCHK(h, hipMemcpyAsync(h->det_dev, det_xyz, sizeof(double) * 3 * (size_t)n_det, hipMemcpyHostToDevice, h->stream));
+  RET_IF(upload(h, h->det_dev, det_xyz, sizeof(double) * 3 * (size_t)n_det));
   if (n_keep > h->n) n_keep = h->n;
   int* asg_dev = nullptr;
-  if (n_keep > 0) HIPCHK(h, hipMalloc(&asg_dev, sizeof(int) * (size_t)n_keep * n_det));
+  if (n_keep > 0) {
+    const size_t need = (size_t)n_keep * (size_t)n_det;
+    if (need > h->asg_cap) {
+      if (h->asg_dev) (void)hipFree(h->asg_dev);
+      h->asg_dev = nullptr;
+      h->asg_cap = 0;
+      HIPCHK(h, hipMalloc(&h->asg_dev, sizeof(int) * need));
+      h->asg_cap = need;
+    }
+    asg_dev = h->asg_dev;
+  }
   static const double zero6[6] = {0, 0, 0, 0, 0, 0};
   const double* so = sensor_offset ? sensor_offset : zero6;
   LandmarkAssignArgs aa;
@@ -1375,7 +1466,6 @@ int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_
   if (le == hipSuccess && n_keep > 0)
     le = hipMemcpyAsync(assign_out, asg_dev, sizeof(int) * (size_t)n_keep * n_det, hipMemcpyDeviceToHost, h->stream);
   if (le == hipSuccess && n_keep > 0) le = hipStreamSynchronize(h->stream);
-  if (asg_dev) (void)hipFree(asg_dev);
   HIPCHK(h, le);
   if (!accumulate) h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
   h->have_lw = true;
@@ -1418,6 +1508,12 @@ int mcl_mean_cov(mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9
   HIPCHK(h, hipStreamSynchronize(h->stream));
   finish_mean_cov(h, mean6, yaw_mean, cov9);
   return MCL_OK;
+}
+
+int mcl_mean_cov_async(mcl_handle* h) {
+  if (!h) return MCL_ERR_INVALID;
+  if (h->world > 1 && !h->comm) return fail(h, MCL_ERR_STATE, "mean_cov: multi-shard handle needs a communicator");
+  return run_mean_cov_async(&h, 1);
 }
 
 int mcl_group_mean_cov(mcl_handle** shards, int32_t ns, double mean6[6], double* yaw_mean, double cov9[9]) {
@@ -1482,6 +1578,7 @@ int mcl_get_particles(mcl_handle* h, double* soa, double* w) {
 int mcl_set_particles(mcl_handle* h, const double* soa) {
   if (!h || !soa) return MCL_ERR_INVALID;
   RET_IF(set_device(h));
+  RET_IF(cancel_state_gather(h));
   HIPCHK(h, hipMemcpyAsync(h->state[h->cur], soa, sizeof(double) * 6 * (size_t)h->n, hipMemcpyHostToDevice,
                            h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1551,11 +1648,19 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
   if (!h || !odom || !ranges || !beam_angles) return MCL_ERR_INVALID;
   if (h->cfg.rng_mode != MCL_RNG_NATIVE) return fail(h, MCL_ERR_INVALID, "step_mbes: NATIVE rng only");
   if (h->world > 1 && !h->comm) return fail(h, MCL_ERR_STATE, "step_mbes: multi-shard handle needs mcl_comm_init");
+  if (B < 1 || !(sigma > 0.0) || !(r_max > 0.0)) return fail(h, MCL_ERR_INVALID, "step_mbes: bad argument");
+  if (h->map_kind < 0) return fail(h, MCL_ERR_STATE, "step_mbes: no map (call mcl_set_map_grid/mesh first)");
   RET_IF(set_device(h));
   RET_IF(do_predict(h, odom, dt, nullptr));
   RET_IF(start_state_gather(h));
-  RET_IF(upload_beams(h, ranges, beam_angles, B));
-  RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0));
+  int rc_u = upload_beams(h, ranges, beam_angles, B);
+  if (rc_u == MCL_OK) rc_u = launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0);
+  if (rc_u != MCL_OK) {
+    const std::string keep = h->err;
+    (void)cancel_state_gather(h);
+    h->err = keep;
+    return rc_u;
+  }
   h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
   h->have_lw = true;
   h->residual_k = -1;
@@ -1625,25 +1730,117 @@ int mcl_comm_unique_id(char id[128]) {
   return MCL_OK;
 }
 
-int mcl_comm_init(mcl_handle* h, const char id[128]) {
+namespace {
+// wait for an event with a deadline; 0 = done, 1 = timed out, negative = HIP error
+int wait_event_ms(hipEvent_t ev, int timeout_ms) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) return -1;
+    if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms)
+      return 1;
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
+void comm_teardown(mcl_handle* h, bool abort) {
+  if (h->comm2) (void)(abort ? ncclCommAbort(h->comm2) : ncclCommDestroy(h->comm2));
+  if (h->comm) (void)(abort ? ncclCommAbort(h->comm) : ncclCommDestroy(h->comm));
+  h->comm2 = nullptr;
+  h->comm = nullptr;
+  h->gather_inflight = false;
+}
+}  // namespace
+
+int mcl_comm_init_ex(mcl_handle* h, const char id[128], uint32_t flags) {
   if (!h || !id) return MCL_ERR_INVALID;
-  const char* force = getenv("MCL_FORCE_COMM");  // test hook: exercise the RCCL paths with one rank
-  if (h->world < 2 && !(force && force[0] == '1')) return MCL_OK;
+  if (h->world < 2 && !h->env_force_comm) return MCL_OK;  // MCL_FORCE_COMM=1: test hook, 1-rank communicator
+  if (h->comm) return fail(h, MCL_ERR_STATE, "comm_init: communicator exists (mcl_comm_shutdown first)");
   RET_IF(set_device(h));
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof uid);
   NCCLCHK(h, ncclCommInitRank(&h->comm, h->world, uid, h->rank));
   if (!h->state_glob) HIPCHK(h, hipMalloc(&h->state_glob, sizeof(double) * 6 * (size_t)h->ng));
   // second communicator + stream for the overlapped state all-gather; optional
-  const char* no_overlap = getenv("MCL_NO_OVERLAP");
-  if (!(no_overlap && no_overlap[0] == '1') && ncclCommSplit(h->comm, 0, h->rank, &h->comm2, nullptr) == ncclSuccess &&
-      h->comm2) {
-    HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_state_ready, hipEventDisableTiming));
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_gather_done, hipEventDisableTiming));
+  const bool overlap = !(flags & MCL_COMM_NO_OVERLAP) && !h->env_no_overlap;
+  if (overlap && ncclCommSplit(h->comm, 0, h->rank, &h->comm2, nullptr) == ncclSuccess && h->comm2) {
+    if (!h->comm_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    if (!h->ev_state_ready) HIPCHK(h, hipEventCreateWithFlags(&h->ev_state_ready, hipEventDisableTiming));
+    if (!h->ev_gather_done) HIPCHK(h, hipEventCreateWithFlags(&h->ev_gather_done, hipEventDisableTiming));
   } else {
     h->comm2 = nullptr;
   }
+  return MCL_OK;
+}
+
+int mcl_comm_init(mcl_handle* h, const char id[128]) { return mcl_comm_init_ex(h, id, 0u); }
+
+int mcl_comm_ranks(mcl_handle* h, int32_t* ranks, int32_t* overlap) {
+  if (!h || !ranks) return MCL_ERR_INVALID;
+  if (overlap) *overlap = h->comm2 ? 1 : 0;
+  if (!h->comm) {
+    *ranks = 1;
+    return MCL_OK;
+  }
+  RET_IF(set_device(h));
+  // every rank contributes 1: the sum is the number of ranks RCCL really connected
+  int* d = (int*)(h->totals + h->world);  // scratch word behind the shard totals
+  const int one = 1;
+  HIPCHK(h, hipMemcpyAsync(d, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  NCCLCHK(h, ncclAllReduce(d, d, 1, ncclInt32, ncclSum, h->comm, h->stream));
+  int got = 0;
+  HIPCHK(h, hipMemcpyAsync(&got, d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *ranks = got;
+  return MCL_OK;
+}
+
+int mcl_comm_selftest(mcl_handle* h, int32_t timeout_ms) {
+  if (!h) return MCL_ERR_INVALID;
+  if (!h->comm) return MCL_OK;
+  if (timeout_ms < 1) timeout_ms = 1;
+  RET_IF(set_device(h));
+  // the exact concurrency pattern of mcl_step_mbes: the 6-array state all-gather on the second
+  // communicator/stream while the first communicator runs its all-reduce + all-gathers, three rounds
+  hipEvent_t done = nullptr;
+  HIPCHK(h, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  int rc = MCL_OK;
+  for (int round = 0; round < 3 && rc == MCL_OK; ++round) {
+    rc = start_state_gather(h);
+    if (rc != MCL_OK) break;
+    ncclResult_t e = ncclAllReduce(h->scal + 24, h->scal + 24, 1, ncclDouble, ncclMax, h->comm, h->stream);
+    if (e == ncclSuccess) e = ncclAllGather(h->totals + h->rank, h->totals, 1, ncclUint64, h->comm, h->stream);
+    if (e == ncclSuccess)
+      e = ncclAllGather(h->ncum + h->goff, h->ncum, (size_t)h->n, ncclUint32, h->comm, h->stream);
+    if (e != ncclSuccess) {
+      h->err = std::string("comm_selftest: ") + ncclGetErrorString(e);
+      rc = MCL_ERR_COMM;
+      break;
+    }
+    if (h->gather_inflight) {
+      (void)hipStreamWaitEvent(h->stream, h->ev_gather_done, 0);
+      h->gather_inflight = false;
+    }
+    (void)hipEventRecord(done, h->stream);
+    const int w = wait_event_ms(done, timeout_ms);
+    if (w != 0) {
+      h->err = w > 0 ? "comm_selftest: collectives did not complete before the deadline (communicators aborted)"
+                     : "comm_selftest: HIP error while waiting";
+      comm_teardown(h, true);
+      rc = MCL_ERR_COMM;
+    }
+  }
+  (void)hipEventDestroy(done);
+  return rc;
+}
+
+int mcl_comm_shutdown(mcl_handle* h, int32_t abort) {
+  if (!h) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  if (!abort && h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!abort && h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+  comm_teardown(h, abort != 0);
   return MCL_OK;
 }
 

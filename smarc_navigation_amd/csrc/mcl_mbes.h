@@ -360,9 +360,11 @@ __device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int t
   const float fu = floorf(pu), fv = floorf(pv);
   int ix = (int)fu, iy = (int)fv;
   const float adu = fabsf(fast_rcp(du)), adv = fabsf(fast_rcp(dv));  // +inf for an axis-parallel ray
-  // distance to the next cell border along each axis; 0 * inf = NaN is ignored by min / fails <=
-  float tnx = fmaf(du > 0.f ? (fu + 1.f) - pu : pu - fu, adu, t_lo);
-  float tny = fmaf(dv > 0.f ? (fv + 1.f) - pv : pv - fv, adv, t_lo);
+  // distance to the next cell border along each axis.  An axis-parallel ray that starts exactly on a
+  // grid line gives 0 * inf = NaN: minNum(NaN, inf) = inf turns it into "never crosses" (a NaN here would
+  // fail every `tnx <= tny` test and march the other axis forever)
+  float tnx = fminf(fmaf(du > 0.f ? (fu + 1.f) - pu : pu - fu, adu, t_lo), INF);
+  float tny = fminf(fmaf(dv > 0.f ? (fv + 1.f) - pv : pv - fv, adv, t_lo), INF);
   const int sx = du > 0.f ? 1 : -1, sy = dv > 0.f ? 1 : -1;
   const int dax = sx * th;
   int addr = ix * th + iy;

@@ -143,6 +143,10 @@ class Engine(object):
         self._ck(self.lib.mcl_mean_cov(self.h, _ptr(mean), _ptr(yaw), _ptr(cov)))
         return mean, float(yaw[0]), cov
 
+    def mean_cov_async(self):
+        """queue mean/cov on the stream without waiting; read it later with last_mean_cov / mean_history"""
+        self._ck(self.lib.mcl_mean_cov_async(self.h))
+
     def last_mean_cov(self):
         mean, yaw, cov = np.zeros(6), np.zeros(1), np.zeros(9)
         self._ck(self.lib.mcl_last_mean_cov(self.h, _ptr(mean), _ptr(yaw), _ptr(cov)))
@@ -206,8 +210,20 @@ class Engine(object):
         self._ck(self.lib.mcl_sync(self.h))
 
     # ---- multi-GPU
-    def comm_init(self, uid_bytes):
-        self._ck(self.lib.mcl_comm_init(self.h, uid_bytes))
+    def comm_init(self, uid_bytes, overlap=True):
+        self._ck(self.lib.mcl_comm_init_ex(self.h, uid_bytes, 0 if overlap else 1))
+
+    def comm_ranks(self):
+        """(ranks RCCL connected = all-reduce(sum) of 1, overlapped-gather communicator present)"""
+        r, o = C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.mcl_comm_ranks(self.h, C.byref(r), C.byref(o)))
+        return int(r.value), bool(o.value)
+
+    def comm_selftest(self, timeout_ms=20000):
+        self._ck(self.lib.mcl_comm_selftest(self.h, int(timeout_ms)))
+
+    def comm_shutdown(self, abort=False):
+        self._ck(self.lib.mcl_comm_shutdown(self.h, 1 if abort else 0))
 
     # ---- instrumentation
     def timing_enable(self, on=True):

@@ -131,6 +131,48 @@ def mesh_from_grid(z, res, origin):
     return verts, tris
 
 
+def mesh_tin(z, res, origin, seed=7, jitter=0.25):
+    """An irregular TIN over the same terrain: every interior node of the height grid is moved in xy by
+    up to +-jitter*res (uniform; border nodes stay, so the footprint is unchanged), its height is the
+    bilinear height of the grid at the new position, and every cell is split along a random diagonal.
+    jitter <= 0.25 keeps every quad convex, so the triangles tile the plane without overlap.  The
+    vertices no longer sit on a lattice: this is NOT a triangulated regular grid."""
+    nx, ny = z.shape
+    rs = np.random.RandomState(seed)
+    ix, iy = np.meshgrid(np.arange(nx, dtype=np.float64), np.arange(ny, dtype=np.float64), indexing='ij')
+    ju = (rs.rand(nx, ny) * 2.0 - 1.0) * jitter
+    jv = (rs.rand(nx, ny) * 2.0 - 1.0) * jitter
+    ju[0, :] = ju[-1, :] = 0.0
+    ju[:, 0] = ju[:, -1] = 0.0
+    jv[0, :] = jv[-1, :] = 0.0
+    jv[:, 0] = jv[:, -1] = 0.0
+    u, v = ix + ju, iy + jv
+    i0 = np.clip(np.floor(u).astype(int), 0, nx - 2)
+    j0 = np.clip(np.floor(v).astype(int), 0, ny - 2)
+    fu, fv = u - i0, v - j0
+    zd = z.astype(np.float64)
+    h = (zd[i0, j0] * (1 - fu) * (1 - fv) + zd[i0 + 1, j0] * fu * (1 - fv) +
+         zd[i0, j0 + 1] * (1 - fu) * fv + zd[i0 + 1, j0 + 1] * fu * fv)
+    verts = np.stack([origin[0] + res * u, origin[1] + res * v, h], axis=-1).reshape(-1, 3).astype(np.float32)
+    cx, cy = np.meshgrid(np.arange(nx - 1), np.arange(ny - 1), indexing='ij')
+    v00 = (cx * ny + cy).reshape(-1)
+    v10, v01, v11 = v00 + ny, v00 + 1, v00 + ny + 1
+    d = rs.rand(v00.size) < 0.5
+    t1 = np.where(d[:, None], np.stack([v00, v10, v11], axis=1), np.stack([v00, v10, v01], axis=1))
+    t2 = np.where(d[:, None], np.stack([v00, v11, v01], axis=1), np.stack([v10, v11, v01], axis=1))
+    tris = np.concatenate([t1, t2], axis=0).astype(np.uint32)
+    return verts, tris
+
+
+def landmark_map(n=4096, extent=(-64.0, -256.0, 448.0, 256.0), z_range=(-24.0, -16.0), seed=6):
+    """Feature map of BASELINE config 5: n landmarks uniform over the map (seed 6)."""
+    rs = np.random.RandomState(seed)
+    x = extent[0] + (extent[2] - extent[0]) * rs.rand(n)
+    y = extent[1] + (extent[3] - extent[1]) * rs.rand(n)
+    zz = z_range[0] + (z_range[1] - z_range[0]) * rs.rand(n)
+    return np.stack([x, y, zz], axis=1)
+
+
 def beam_angles(n_beams, half_swath=math.pi / 3):
     """LaserScan-style fan: angle_min=-half_swath, equal increments, inclusive of +half_swath
     (mbes_processors/mbes_toy_processor/src/toy_mbes_manipulator.cpp:69-73 geometry)."""

@@ -351,3 +351,44 @@ def test_profile_marching_kernel_matches_oracle(eng, orc, monkeypatch):
     lw_ref, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, orc.Mesh(verts, tris), ba, ranges, 0.2, 80.0)
     d = np.abs(e.get_log_weights() - lw_ref)
     assert np.all((d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref)))
+
+
+@pytest.mark.parametrize('kind', ['grid', 'mesh', 'mesh_general'])
+@pytest.mark.parametrize('positive', [False, True])
+def test_axis_parallel_nadir_beam_from_a_grid_line(kind, positive, eng, orc):
+    """yaw = roll = 0, pitch != 0 and a beam at angle exactly 0 give a ray with dv == 0 exactly; with the
+    sensor exactly on a y grid line the distance to the next y border is 0 * inf.  That NaN used to
+    march the traversal out of the LDS tile (wrong ranges on a negative-depth map, a hang on a
+    positive-height map).  The same set-up turned by 90 degrees (du == 0 on an x grid line) rides along."""
+    nx = ny = 96
+    origin = (-48.0, -48.0)
+    z = synth.bathymetry_grid(nx, ny, 1.0, origin, seed=11)
+    sensor_z = -3.0
+    if positive:
+        z = (z + 60.0).astype(np.float32)  # heights 35..45 m, sensor above them
+        sensor_z = 70.0
+    n = 8
+    soa = np.zeros((6, n))
+    soa[0] = [0.0, 3.0, -5.0, 7.25, 0.0, 2.0, -4.0, 1.5]      # x
+    soa[1] = [0.0, -7.0, 12.0, 4.0, 0.5, 3.0, -6.0, 9.0]      # y: integers = on a grid line (origin is integer)
+    soa[2] = sensor_z
+    soa[4] = [0.15, -0.2, 0.05, 0.3, 0.15, 0.0, 0.0, 0.0]     # pitch
+    soa[5] = [0.0, 0.0, 0.0, 0.0, 0.0, np.pi / 2, -np.pi / 2, np.pi]  # exact quarter turns
+    B = 65
+    ba = synth.beam_angles(B, np.pi / 3)
+    assert ba[B // 2] == 0.0
+    e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    if kind == 'grid':
+        e.set_map_grid(z, origin, 1.0)
+        ref_map = orc.Grid(z, origin, 1.0)
+    else:
+        verts, tris = synth.mesh_from_grid(z, 1.0, origin)
+        e.set_map_mesh(verts, tris, general=(kind == 'mesh_general'))
+        ref_map = orc.Mesh(verts, tris)
+    got = e.mbes_expected(0, n, ba, 120.0)
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, ref_map, ba, None, 0.2, 120.0)
+    err = np.abs(got - ref)
+    print('%s positive=%s: max range error %.3e, nadir-beam error %.3e' % (kind, positive, err.max(), err[:, B // 2].max()))
+    assert ref[:, B // 2].max() < 100.0
+    assert err.max() <= 1e-3

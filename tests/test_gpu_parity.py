@@ -330,6 +330,11 @@ def test_rccl_paths_with_one_rank_match_plain_filter(eng, monkeypatch):
         monkeypatch.setenv('MCL_NO_OVERLAP', no_overlap)
         e = eng.Engine(n, **cov)
         e.comm_init(eng.comm_unique_id())
+        # the communicator really exists (an all-reduce(sum) of 1 counts its ranks), the second one only
+        # with the overlap on; the deadline self-test runs the step's two-communicator pattern
+        ranks, overlap = e.comm_ranks()
+        assert ranks == 1 and overlap == (force == '1' and no_overlap == '0')
+        e.comm_selftest(20000)
         e.set_map_grid(z, origin, 1.0)
         e.init_particles()
         for k in range(4):
@@ -340,6 +345,42 @@ def test_rccl_paths_with_one_rank_match_plain_filter(eng, monkeypatch):
     for st, mean in results[1:]:
         assert np.array_equal(st, results[0][0])
         np.testing.assert_allclose(mean, results[0][1], rtol=1e-13, atol=1e-13)
+
+
+def test_comm_shutdown_and_reinit_without_overlap(eng, monkeypatch):
+    """The fall-back bench.py takes when the overlap self-test fails: abort both communicators,
+    re-initialise under a fresh id with MCL_COMM_NO_OVERLAP, same results.  Also: a step that fails after
+    the overlapped gather was started (no map) must not leave a stale gather behind."""
+    from smarc_navigation_amd import synth
+    from oracle import oracle as orc
+    monkeypatch.setenv('MCL_FORCE_COMM', '1')
+    n, B = 8192, 64
+    origin = (-64.0, -64.0)
+    z = synth.bathymetry_grid(128, 128, 1.0, origin, seed=3)
+    ba = synth.beam_angles(B)
+    cov = dict(init_cov=[1, 1, 0, 0, 0, 0.01], process_cov=[1e-3, 1e-3, 0, 0, 0, 1e-5],
+               resample_cov=[0.01, 0.01, 0, 0, 0, 1e-4], seed=22)
+    q = orc.quat_from_euler(0.0, 0.0, 0.1)
+    ranges = np.full(B, 21.0, np.float32)
+    out = []
+    for reinit in (False, True):
+        e = eng.Engine(n, **cov)
+        e.comm_init(eng.comm_unique_id())
+        if reinit:
+            e.comm_shutdown(abort=True)
+            assert e.comm_ranks() == (1, False)
+            e.comm_init(eng.comm_unique_id(), overlap=False)
+            assert e.comm_ranks() == (1, False)
+        e.init_particles()
+        with pytest.raises(eng.MclError):  # no map yet: refused before anything is queued
+            e.step_mbes([1.0, 0.0, 0.0], 0.02, q, -2.0, 0.02, ranges, ba, 0.5, 80.0)
+        e.set_map_grid(z, origin, 1.0)
+        for k in range(3):
+            e.step_mbes([1.0, 0.0, 0.0], 0.02, q, -2.0, 0.02, ranges, ba, 0.5, 80.0)
+        e.sync()
+        out.append(e.get_particles())
+        e.close()
+    assert np.array_equal(out[0], out[1])
 
 
 def test_rccl_single_rank_world1_smoke(eng):
