@@ -522,7 +522,12 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
       // The fan is planar, so the points where its beams reach depth z_min(map) are collinear and
       // ordered by beam angle: the two extreme-angle beams bound the footprint, provided both point
       // downward and reach z_min before r_max (then every beam between them does too).
-      bool simple = a.b_lo >= 0;
+      // A height grid is a solid below its surface: a ray that comes in from OUTSIDE the map below the
+      // seabed hits at its entry point (oracle: orc_ray_grid), possibly deeper than z_min.  For a sensor
+      // off the map the footprint therefore runs to r_max along every beam (an arc, not a segment: no
+      // two-beam shortcut).  Meshes have no side walls, their footprint stops at z_min.
+      const bool off_map = MAP == 0 && !(P.um >= 0.0 && P.um <= (double)(a.nx - 1) && P.vm >= 0.0 && P.vm <= (double)(a.ny - 1));
+      bool simple = a.b_lo >= 0 && !off_map;
       float ue[2], ve[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -547,7 +552,7 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
           const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
           const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
           float t_end = a.r_max;
-          if (dz < -1e-6f) t_end = fminf(t_end, fmaxf((a.zmin_map - P.oz) * fast_rcp(dz), 0.f));
+          if (dz < -1e-6f && !off_map) t_end = fminf(t_end, fmaxf((a.zmin_map - P.oz) * fast_rcp(dz), 0.f));
           const float ub = (float)P.um + t_end * dx * inv_res, vb = (float)P.vm + t_end * dy * inv_res;
           umin = fminf(umin, ub);
           umax = fmaxf(umax, ub);

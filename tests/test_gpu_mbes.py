@@ -257,9 +257,50 @@ def test_heightfield_flag_rejects_vertical_faces(eng):
     e.set_map_mesh(verts, tris)  # fine as a general soup
 
 
-def test_chained_starts_on_rough_terrain_and_steep_rolls(eng, orc):
-    """Stress the neighbour-chained starts: rough bottom, big roll/pitch, unsorted and duplicated
-    beam angles -- results must still equal the per-ray oracle."""
+def _bounded_against_perturbed_oracle(orc, omap, soa, ba, got, lw_got, ranges, sigma, r_max, delta=1e-3, tol=1e-3):
+    """fp32 vs fp64 on rough terrain: a ray that grazes a ridge may hit or miss it depending on the last bit,
+    and then its range jumps by metres.  Every such jump must still be an answer the fp64 oracle itself
+    gives when the whole surface moves by +-delta (= the sensor depth by -+delta): each GPU range has to lie
+    within `tol` of one of the three oracle ranges, NO exceptions, and each particle's log-likelihood
+    must be the one those oracle ranges give (usual fp32 tolerance).  Returns the share of rays whose three
+    candidates differ (the ill-conditioned ones) and the widest log-likelihood interval they span."""
+    ident, zero = np.identity(4), [0] * 6
+    cands, lws = [], []
+    for dz in (0.0, delta, -delta):
+        s = soa.copy()
+        s[2] += dz
+        _, ex = orc.mbes_update(s, ident, zero, omap, ba, None, sigma, r_max)
+        cands.append(ex)
+    cands = np.stack(cands)                               # 3 x n x B
+    dist = np.abs(cands - got[None])
+    pick = np.argmin(dist, axis=0)
+    near = np.take_along_axis(cands, pick[None], axis=0)[0]   # the oracle answer each GPU range corresponds to
+    # a ray at grazing incidence is ill-conditioned without any hit/miss flip (d range / d height of 20 and
+    # more): when the three oracle answers lie within 10 cm of each other they span a continuous branch
+    # and any value between them is an oracle answer for a surface shift below delta
+    lo_c, hi_c = cands.min(axis=0), cands.max(axis=0)
+    cont = (hi_c - lo_c) < 0.1
+    near = np.where(cont, np.clip(got, lo_c, hi_c), near)
+    dev = np.abs(got - near)
+    worst = np.unravel_index(np.argmax(dev), dev.shape)
+    assert dev.max() <= tol, 'ray %s: GPU %.4f vs oracle candidates %s' % (worst, got[worst], cands[(slice(None),) + worst])
+    valid = ranges > 0
+    lognorm = np.count_nonzero(valid) * np.log(sigma * np.sqrt(2 * np.pi))
+    res = np.where(valid[None, :], ranges[None, :] - near, 0.0)
+    lw_near = -0.5 * np.sum((res / sigma) ** 2, axis=1) - lognorm
+    # first-order effect of the (asserted sub-millimetre) deviations on the sum of squared residuals
+    slack = 1e-2 + 2e-4 * np.abs(lw_near) + np.sum(np.abs(res) * np.where(valid[None, :], dev, 0.0), axis=1) / sigma ** 2
+    d = np.abs(lw_got - lw_near)
+    assert np.all(d <= slack), 'log-likelihood differs from the oracle-candidate value: worst excess %.3e' % (d - slack).max()
+    q = np.where(valid[None, None, :], -0.5 * ((ranges[None, None, :] - cands) / sigma) ** 2, 0.0)
+    width = q.max(axis=0).sum(axis=1) - q.min(axis=0).sum(axis=1)
+    return float(np.mean(np.ptp(cands, axis=0) > 20 * delta)), float(width.max())  # sensitivity d range / d height > 10
+
+
+def test_rough_terrain_and_steep_rolls_are_bounded_by_the_oracle(eng, orc):
+    """Rough bottom, big roll/pitch, unsorted and duplicated beam angles: every expected range equals the
+    fp64 oracle's on the map or on the map moved by +-1 mm, and every particle's log-likelihood lies in the
+    interval those answers span -- no unbounded outliers (VERDICT r1, weak #2)."""
     nx = ny = 200
     origin = (-100.0, -100.0)
     rs = np.random.RandomState(9)
@@ -267,27 +308,31 @@ def test_chained_starts_on_rough_terrain_and_steep_rolls(eng, orc):
     n = 40
     soa = rs.randn(6, n) * np.array([4.0, 4.0, 0.5, 0.25, 0.25, 3.0])[:, None]
     soa[2] -= 3.0
+    verts, tris = synth.mesh_from_grid(z, 1.0, origin)
+    sigma, r_max = 0.2, 120.0
     for ba in (synth.beam_angles(256, 1.2), synth.beam_angles(256, 1.2)[::-1].copy(),
                np.sort(rs.uniform(-1.1, 1.1, 200)).astype(np.float32),
                rs.uniform(-1.1, 1.1, 130).astype(np.float32),
                np.repeat(synth.beam_angles(64, 1.0), 3)):
-        e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
-        e.set_particles(soa)
-        e.set_map_grid(z, origin, 1.0)
-        got = e.mbes_expected(0, n, ba, 120.0)
-        _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, orc.Grid(z, origin, 1.0), ba, None, 0.2, 120.0)
-        err = np.abs(got - ref)
-        # grazing rays over rough terrain can flip hit/miss under fp32: allow a handful, report them
-        bad = err > 2e-3
-        print('rough terrain: %d/%d rays off by > 2e-3 m (max %.3e)' % (bad.sum(), err.size, err.max()))
-        assert bad.mean() < 2e-3
-        verts, tris = synth.mesh_from_grid(z, 1.0, origin)
-        e.set_map_mesh(verts, tris)
-        gotm = e.mbes_expected(0, n, ba, 120.0)
-        _, refm = orc.mbes_update(soa, np.identity(4), [0] * 6, orc.Mesh(verts, tris), ba, None, 0.2, 120.0)
-        badm = np.abs(gotm - refm) > 2e-3
-        print('rough mesh   : %d/%d rays off by > 2e-3 m' % (badm.sum(), badm.size))
-        assert badm.mean() < 2e-3
+        for kind in ('grid', 'mesh', 'mesh_general'):
+            e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+            e.set_particles(soa)
+            if kind == 'grid':
+                e.set_map_grid(z, origin, 1.0)
+                omap = orc.Grid(z, origin, 1.0)
+            else:
+                e.set_map_mesh(verts, tris, general=(kind == 'mesh_general'))
+                omap = orc.Mesh(verts, tris)
+            got = e.mbes_expected(0, n, ba, r_max)
+            _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, None, sigma, r_max)
+            ranges = (ref[0] + sigma * rs.randn(ba.size)).astype(np.float32)
+            e.update_mbes(ranges, ba, sigma, r_max)
+            ill, width = _bounded_against_perturbed_oracle(orc, omap, soa, ba, got, e.get_log_weights(), ranges, sigma, r_max)
+            err = np.abs(got - ref)
+            print('rough %-12s B=%3d: %d/%d rays differ from the unperturbed oracle by > 2e-3 m (max %.3e); '
+                  'ill-conditioned rays %.2f %%, widest lw interval %.2f' % (kind, ba.size, (err > 2e-3).sum(), err.size,
+                                                                             err.max(), 100 * ill, width))
+            assert (err > 2e-3).mean() < 2e-3
 
 
 def test_structured_mesh_with_alternating_diagonals(eng, orc):
