@@ -18,10 +18,19 @@
 #include "mcl_mbes.h"
 #include "mcl_mesh.h"
 #include "mcl_mbes_profile.h"
+#include "mcl_resample.h"
 #include "mcl_resample_alt.h"
 #include "mcl_landmarks.h"
 
 #define MEAN_RING 4096
+#define RING_STRIDE 20  // doubles per mean/cov result: 16 payload + [16] format tag
+// control block layout (bytes)
+#define CTRL_SLOTS 0                       // MCL_MAX_SLOTS u64
+#define CTRL_WORK (8 * MCL_MAX_SLOTS)      // int: groups deferred by the fast MBES kernel
+#define CTRL_T_QUANT (CTRL_WORK + 8)       // u32 tickets, self-resetting
+#define CTRL_T_EXPAND (CTRL_WORK + 12)
+#define CTRL_T_GATHER (CTRL_WORK + 16)
+#define CTRL_BYTES 1024
 
 namespace {
 
@@ -48,7 +57,14 @@ struct mcl_handle {
   double* wnorm = nullptr;       // n (lazily)
   u64* q = nullptr;              // n fixed-point weights
   u32* ncum = nullptr;           // ng offspring CDF (global)
-  u32* zcum = nullptr;           // ng lost-slot ranks (global)
+  u32* zcum = nullptr;           // ng scratch (generic keep/lost/dupes of the explicit-index schemes)
+  u32* zr = nullptr;             // n: rank of a lost slot among the lost slots, or ZR_SURVIVOR
+  u32* dupes32 = nullptr;        // ng: dupes[k] = ancestor copied into the k-th lost slot
+  u64* desc = nullptr;           // ntiles_glob look-back descriptors
+  unsigned char* ctrl = nullptr; // control block: max-lw slots | MBES work counter | kernel tickets (CTRL_* offsets)
+  u32 epoch = 0;                 // look-back epoch (one per k_cdf_expand launch)
+  bool max_valid = false;        // the slots hold max lw of the current log-weights
+  bool pose_ready = false;       // pose_dev already holds the records of the current state (fused predict)
   u64* tile64 = nullptr;
   u32* tile32 = nullptr;
   long long ntiles_loc = 0, ntiles_glob = 0;
@@ -316,12 +332,24 @@ int set_device(mcl_handle* h) {
 // resample pipeline, written over a set of shards so that the RCCL path (one shard per process)
 // and the LOCAL test group (several shards in one process) execute the same phases.
 // ------------------------------------------------------------------------------------------
+u64* ctrl_slots(mcl_handle* h) { return (u64*)(h->ctrl + CTRL_SLOTS); }
+u32* ctrl_u32(mcl_handle* h, int off) { return (u32*)(h->ctrl + off); }
+
+// max lw into the slots (unless the update kernel that wrote lw already did it)
+int ensure_max_slots(mcl_handle* h) {
+  if (h->max_valid) return MCL_OK;
+  HIPCHK(h, hipMemsetAsync(h->ctrl + CTRL_SLOTS, 0, 8 * MCL_MAX_SLOTS, h->stream));
+  k_max_slots<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->lw, h->n, ctrl_slots(h));
+  HIPCHK(h, hipGetLastError());
+  h->max_valid = true;
+  return MCL_OK;
+}
+// scal[0] = local max lw (the value the shard exchange reduces)
 int phase_local_max(mcl_handle* h) {
   RET_IF(set_device(h));
   t_begin(h, MCL_K_NORMALISE);
-  const int g = grid_for(h->n);
-  k_max_partial<<<g, MCL_BLOCK, 0, h->stream>>>(h->lw, h->n, h->part);
-  k_max_final<<<1, 1024, 0, h->stream>>>(h->part, g, h->scal);
+  RET_IF(ensure_max_slots(h));
+  k_max_finish<<<1, 64, 0, h->stream>>>(ctrl_slots(h), h->scal);
   t_end(h);
   HIPCHK(h, hipGetLastError());
   return MCL_OK;
@@ -353,16 +381,31 @@ int exchange_max(mcl_handle** sh, int ns) {
   return MCL_OK;
 }
 
-int phase_quantise(mcl_handle* h) {
+// fixed-point weights, tile sums, exclusive tile offsets and the shard total in ONE launch.
+// from_slots: single shard -- the kernel reads the maximum straight from the slots (no k_max_finish)
+// fused_next: k_cdf_expand<true> follows and adds the tile sums up itself (no tile scan launch)
+int phase_quantise(mcl_handle* h, bool from_slots, bool fused_next = false) {
   RET_IF(set_device(h));
   const double scale = std::ldexp(1.0, 63 - ceil_log2(h->ng));
   t_begin(h, MCL_K_NORMALISE);
-  k_q_tile_sums<<<grid_tiles(h->ntiles_loc), MCL_BLOCK, 0, h->stream>>>(h->lw, h->n, h->scal, h->weight_mode,
-                                                                        scale, h->q, h->tile64);
+  if (from_slots) RET_IF(ensure_max_slots(h));
+  QuantArgs a;
+  a.lw = h->lw;
+  a.n = h->n;
+  a.slots = from_slots ? ctrl_slots(h) : nullptr;
+  a.m_lw = h->scal;
+  a.mode = h->weight_mode;
+  a.scale = scale;
+  a.q = h->q;
+  a.tile_sum = h->tile64;
+  k_quantise_tiles<<<(unsigned)h->ntiles_loc, MCL_BLOCK, 0, h->stream>>>(a);
   t_end(h);
-  t_begin(h, MCL_K_SCAN);
-  k_scan_tile_sums<u64><<<1, 1024, 0, h->stream>>>(h->tile64, h->ntiles_loc, h->totals + h->rank);
-  t_end(h);
+  if (!fused_next) {
+    // sharded / explicit-position schemes: exclusive tile offsets and the shard total as separate arrays
+    t_begin(h, MCL_K_SCAN);
+    k_scan_tile_sums<u64><<<1, 1024, 0, h->stream>>>(h->tile64, h->ntiles_loc, h->totals + h->rank);
+    t_end(h);
+  }
   HIPCHK(h, hipGetLastError());
   return MCL_OK;
 }
@@ -474,30 +517,69 @@ int start_state_gather(mcl_handle* h) {
   return MCL_OK;
 }
 
-int phase_reassign(mcl_handle* h, const double* replay_normals) {
+// lost-slot ranks + dupes list.  fused_cdf: single shard, the offspring CDF is computed in the same pass
+int phase_expand(mcl_handle* h, bool fused_cdf, uint64_t u53) {
+  RET_IF(set_device(h));
+  ExpandArgs a;
+  memset(&a, 0, sizeof a);
+  a.q = h->q;
+  a.tile_sum = h->tile64;
+  a.n_fine = h->ntiles_loc;
+  a.n_global_u = (u64)h->ng;
+  a.u53 = u53;
+  a.total_out = h->totals + h->rank;
+  a.ncum = h->ncum;
+  a.n = h->ng;
+  a.own0 = h->goff;
+  a.own_n = h->n;
+  a.zr = h->zr;
+  a.dupes = h->dupes32;
+  a.desc = h->desc;
+  a.ticket = ctrl_u32(h, CTRL_T_EXPAND);
+  a.epoch = ++h->epoch;
+  const unsigned grid = (unsigned)((h->ng + RS_TILE - 1) / RS_TILE);
+  t_begin(h, fused_cdf ? MCL_K_SCAN : MCL_K_RESAMPLE);
+  if (fused_cdf)
+    k_cdf_expand<true><<<grid, RS_BLOCK, 0, h->stream>>>(a);
+  else
+    k_cdf_expand<false><<<grid, RS_BLOCK, 0, h->stream>>>(a);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+
+// reassign gather + resampling noise (+ the sums of update_loc_pose of the new state when with_moments)
+int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments) {
   RET_IF(set_device(h));
   if (replay_normals) RET_IF(upload_replay(h, replay_normals));
-  t_begin(h, MCL_K_RESAMPLE);
-  k_zero_tile_sums<<<grid_tiles(h->ntiles_glob), MCL_BLOCK, 0, h->stream>>>(h->ncum, h->ng, h->tile32);
-  k_scan_tile_sums<u32><<<1, 1024, 0, h->stream>>>(h->tile32, h->ntiles_glob, h->tile32 + h->ntiles_glob);
-  k_zero_scan<<<grid_tiles(h->ntiles_glob), MCL_BLOCK, 0, h->stream>>>(h->ncum, h->ng, h->tile32, h->zcum);
-  ReassignArgs a;
+  GatherArgs a;
   const bool multi = h->world > 1 || (h->comm && h->state_glob);
   a.src = multi ? state_ptrs(h->state_glob, h->ng) : state_ptrs(h->state[h->cur], h->n);
   a.dst = state_ptrs(h->state[h->cur ^ 1], h->n);
   a.n = h->n;
-  a.n_global = h->ng;
   a.goff = h->goff;
+  a.zr = h->zr;
+  a.dupes = h->dupes32;
   a.nz = noise_args(h, h->cfg.resample_cov, 2u, h->step_resample);
   a.add_noise = 1;
-  k_reassign_noise<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(a, h->ncum, h->zcum,
-                                                               replay_normals ? h->replay_dev : nullptr);
+  a.part = h->part;
+  a.sums_out = h->scal + 32;
+  a.ticket = ctrl_u32(h, CTRL_T_GATHER);
+  const double* rp = replay_normals ? h->replay_dev : nullptr;
+  t_begin(h, MCL_K_RESAMPLE);
+  long long gg = (h->n + (long long)RS_BLOCK * 4 - 1) / ((long long)RS_BLOCK * 4);
+  gg = gg < 1 ? 1 : (gg > GATHER_MAX_GRID ? GATHER_MAX_GRID : gg);
+  if (with_moments)
+    k_resample_gather<true><<<(unsigned)gg, RS_BLOCK, 0, h->stream>>>(a, rp);
+  else
+    k_resample_gather<false><<<(unsigned)gg, RS_BLOCK, 0, h->stream>>>(a, rp);
   t_end(h);
   HIPCHK(h, hipGetLastError());
   h->cur ^= 1;
   h->step_resample++;
   h->have_cdf = true;
   h->have_lw = false;
+  h->pose_ready = false;
   return MCL_OK;
 }
 
@@ -605,8 +687,7 @@ int alt_indices(mcl_handle* h, const double* uniforms, long long nu) {
     }
     t_end(h);
   } else {
-    RET_IF(phase_local_max(h));
-    RET_IF(phase_quantise(h));
+    RET_IF(phase_quantise(h, true));
     RET_IF(make_uniforms(h, uniforms, nu, h->n));
     t_begin(h, MCL_K_SCAN);
     k_u64_scan<<<grid_tiles(h->ntiles_loc), MCL_BLOCK, 0, h->stream>>>(h->q, h->n, h->tile64, h->cq);
@@ -653,7 +734,7 @@ int run_resample_alt(mcl_handle* h, const double* uniforms, long long nu, const 
 }
 
 int run_resample(mcl_handle** sh, int ns, const double* uniforms, long long nu,
-                 const double* const* replay_normals) {
+                 const double* const* replay_normals, bool with_moments = false) {
   mcl_handle* h0 = sh[0];
   for (int s = 0; s < ns; ++s) {
     if (!sh[s]->have_lw) return fail(sh[s], MCL_ERR_STATE, "resample: no weights (call an update first)");
@@ -671,15 +752,25 @@ int run_resample(mcl_handle** sh, int ns, const double* uniforms, long long nu,
   } else {
     u53 = native_u53(h0->cfg.seed, h0->step_resample);
   }
+  // one shard (and few enough tiles for every k_cdf_expand block to add their sums up itself):
+  // max from the slots -> quantise -> CDF + expansion -> gather, three launches
+  const bool single = ns == 1 && h0->world == 1 && !h0->comm && h0->ntiles_loc <= 8192;
+  if (single) {
+    RET_IF(phase_quantise(h0, true, true));
+    RET_IF(phase_expand(h0, true, u53));
+    return phase_gather(h0, (replay_normals && h0->cfg.rng_mode == MCL_RNG_REPLAY) ? replay_normals[0] : nullptr,
+                        with_moments);
+  }
   for (int s = 0; s < ns; ++s) RET_IF(phase_local_max(sh[s]));
   RET_IF(exchange_max(sh, ns));
-  for (int s = 0; s < ns; ++s) RET_IF(phase_quantise(sh[s]));
+  for (int s = 0; s < ns; ++s) RET_IF(phase_quantise(sh[s], false));
   RET_IF(exchange_totals(sh, ns));
   for (int s = 0; s < ns; ++s) RET_IF(phase_cdf(sh[s], u53));
   RET_IF(exchange_cdf_state(sh, ns));
+  for (int s = 0; s < ns; ++s) RET_IF(phase_expand(sh[s], false, 0));
   for (int s = 0; s < ns; ++s)
-    RET_IF(phase_reassign(sh[s], (replay_normals && sh[s]->cfg.rng_mode == MCL_RNG_REPLAY) ? replay_normals[s]
-                                                                                          : nullptr));
+    RET_IF(phase_gather(sh[s], (replay_normals && sh[s]->cfg.rng_mode == MCL_RNG_REPLAY) ? replay_normals[s] : nullptr,
+                        with_moments));
   return MCL_OK;
 }
 
@@ -739,30 +830,63 @@ int run_mean_cov_async(mcl_handle** sh, int ns) {
   for (int s = 0; s < ns; ++s) {
     mcl_handle* h = sh[s];
     RET_IF(set_device(h));
-    HIPCHK(h, hipMemcpyAsync(h->host_pin + 16 * (h->mean_count % MEAN_RING), h->scal + 8, sizeof(double) * 14,
-                             hipMemcpyDeviceToHost, h->stream));
+    double* slot = h->host_pin + RING_STRIDE * (h->mean_count % MEAN_RING);
+    slot[16] = 0.0;  // format 0: [0..6] sums of the 6 components + wrapped yaw, [8..13] centred second-moment sums
+    HIPCHK(h, hipMemcpyAsync(slot, h->scal + 8, sizeof(double) * 14, hipMemcpyDeviceToHost, h->stream));
     h->mean_count++;
     h->have_meancov = true;
   }
   return MCL_OK;
 }
-// host_pin layout: [0..6] sums7, [7] pad, [8..13] cov sums6
+// the sums k_resample_gather<true> left in scal[32..47]: reduce over the shards, queue the copy to the ring
+int collect_fused_moments(mcl_handle** sh, int ns) {
+  RET_IF(exchange_sums(sh, ns, 32, MOM_COUNT));
+  for (int s = 0; s < ns; ++s) {
+    mcl_handle* h = sh[s];
+    RET_IF(set_device(h));
+    double* slot = h->host_pin + RING_STRIDE * (h->mean_count % MEAN_RING);
+    slot[16] = 1.0;  // format 1: 13 sums about the shift in [13..15] (mcl_resample.h, k_resample_gather)
+    t_begin(h, MCL_K_MEAN_COV);
+    HIPCHK(h, hipMemcpyAsync(slot, h->scal + 32, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
+    t_end(h);
+    h->mean_count++;
+    h->have_meancov = true;
+  }
+  return MCL_OK;
+}
+// ring entry -> mean pose, arithmetic mean of the wrapped yaw, covariance as auv_pf.py:238-252 lays it out
 void finish_mean_cov(const mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9], long long which = -1) {
   const double N = (double)h->ng;
   if (which < 0) which = h->mean_count - 1;
-  const double* p = h->host_pin + 16 * (which % MEAN_RING);
-  for (int c = 0; c < 6; ++c) mean6[c] = p[c] / N;
+  const double* p = h->host_pin + RING_STRIDE * (which % MEAN_RING);
+  double c[6];
+  if (p[16] == 0.0) {
+    for (int k = 0; k < 6; ++k) mean6[k] = p[k] / N;
+    for (int k = 0; k < 6; ++k) c[k] = p[8 + k] / N;
+  } else {
+    // d = x - shift:  mean = shift + sum(d)/N ;  cov_ab = sum(d_a d_b)/N - (sum d_a / N)(sum d_b / N)
+    const double m0 = p[0] / N, m1 = p[1] / N, m2 = p[2] / N;
+    mean6[0] = p[13] + m0;
+    mean6[1] = p[14] + m1;
+    mean6[2] = p[15] + m2;
+    for (int k = 3; k < 6; ++k) mean6[k] = p[k] / N;
+    c[0] = p[7] / N - m0 * m0;
+    c[1] = p[8] / N - m1 * m1;
+    c[2] = p[9] / N - m2 * m2;
+    c[3] = p[10] / N - m0 * m1;
+    c[4] = p[11] / N - m0 * m2;
+    c[5] = p[12] / N - m1 * m2;
+  }
   if (yaw_mean) *yaw_mean = p[6] / N;
-  const double* c = p + 8;
-  cov9[0] = c[0] / N;
-  cov9[1] = c[3] / N;
-  cov9[2] = c[4] / N;
-  cov9[3] = c[3] / N;  // only [1,0] mirrored (auv_pf.py:246)
-  cov9[4] = c[1] / N;
-  cov9[5] = c[5] / N;
+  cov9[0] = c[0];
+  cov9[1] = c[3];
+  cov9[2] = c[4];
+  cov9[3] = c[3];  // only [1,0] mirrored (auv_pf.py:246)
+  cov9[4] = c[1];
+  cov9[5] = c[5];
   cov9[6] = 0.0;
   cov9[7] = 0.0;
-  cov9[8] = c[2] / N;
+  cov9[8] = c[2];
 }
 
 // ------------------------------------------------------------------------------------------ MBES
@@ -816,7 +940,8 @@ void rot_rpy(double roll, double pitch, double yaw, double R[9]) {
 }
 
 int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max, const double sensor_offset[6],
-                double* lw_out, float* exp_out, long long exp_first, long long exp_count) {
+                double* lw_out, float* exp_out, long long exp_first, long long exp_count, bool pose_done = false,
+                MbesArgs* args_only = nullptr) {
   if (h->map_kind < 0) return fail(h, MCL_ERR_STATE, "update_mbes: no map (call mcl_set_map_grid/mesh first)");
   static const double zero6[6] = {0, 0, 0, 0, 0, 0};
   const double* so = sensor_offset ? sensor_offset : zero6;
@@ -884,10 +1009,21 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   const int grid = (int)(ngroups < 4096 ? ngroups : 4096);
   if (!h->mbes_worklist) HIPCHK(h, hipMalloc(&h->mbes_worklist, sizeof(int) * (size_t)(ngroups + 1)));
   a.worklist = h->mbes_worklist;
-  a.work_count = h->mbes_worklist + ngroups;
+  a.work_count = (int*)(h->ctrl + CTRL_WORK);
+  // the cast kernels leave max lw in the control block's slots: the normalisation needs no reduction pass
+  a.max_slots = (with_ranges && lw_out == h->lw) ? ctrl_slots(h) : nullptr;
+  if (args_only) {
+    *args_only = a;
+    return MCL_OK;
+  }
   t_begin(h, MCL_K_UPDATE_MBES);
-  HIPCHK(h, hipMemsetAsync(a.work_count, 0, sizeof(int), h->stream));
-  k_mbes_pose<<<grid_for(h->n), 256, 0, h->stream>>>(a);
+  if (a.max_slots) {
+    HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_WORK + sizeof(int), h->stream));  // slots + work counter
+    h->max_valid = true;
+  } else {
+    HIPCHK(h, hipMemsetAsync(a.work_count, 0, sizeof(int), h->stream));
+  }
+  if (!pose_done) k_mbes_pose<<<grid_for(h->n), 256, 0, h->stream>>>(a);
   // fast kernel over every group, then the general kernel over the few groups it deferred
   const int ggrid = (int)(ngroups < 512 ? ngroups : 512);
 #define LAUNCH_CAST(MAPV)                                                          \
@@ -931,7 +1067,11 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   return MCL_OK;
 }
 
-int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* replay_normals) {
+// pose_for: when given (fused step, NATIVE rng) the kernel also writes the MBES pose records of the new
+// state; *pose_written tells the caller whether it did (a dt <= 0 step leaves the state untouched)
+int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* replay_normals,
+               const MbesArgs* pose_for = nullptr, bool* pose_written = nullptr) {
+  if (pose_written) *pose_written = false;
   if (!(dt > 0.0)) return MCL_OK;  // auv_pf.py:205 gate
   double rpy[3];
   euler_from_quat(od->q, rpy);
@@ -963,7 +1103,20 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
   if (h->cfg.rng_mode == MCL_RNG_REPLAY && !rp) {
     // noise-free: feed zeros through the native branch with sq = 0
   }
-  k_predict<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, rp);
+  if (pose_for && !rp && h->cfg.rng_mode == MCL_RNG_NATIVE) {
+    PoseXform T;
+    for (int k = 0; k < 12; ++k) T.m2o[k] = pose_for->m2o[k];
+    for (int k = 0; k < 3; ++k) T.off_t[k] = pose_for->off_t[k];
+    for (int k = 0; k < 9; ++k) T.off_R[k] = pose_for->off_R[k];
+    T.ox = pose_for->ox;
+    T.oy = pose_for->oy;
+    T.inv_res = pose_for->inv_res;
+    k_predict_pose<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, T,
+                                                               pose_for->pose);
+    if (pose_written) *pose_written = true;
+  } else {
+    k_predict<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, rp);
+  }
   t_end(h);
   HIPCHK(h, hipGetLastError());
   h->step_predict++;
@@ -1115,12 +1268,18 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
   h->ntiles_glob = (h->ng + MCL_SCAN_TILE - 1) / MCL_SCAN_TILE;
   CREATE_CHK(hipMalloc(&h->tile64, sizeof(u64) * (size_t)(h->ntiles_loc + 1)));
   CREATE_CHK(hipMalloc(&h->tile32, sizeof(u32) * (size_t)(h->ntiles_glob + 1)));
-  CREATE_CHK(hipMalloc(&h->part, sizeof(double) * 7 * MCL_MAX_GRID));
-  CREATE_CHK(hipMalloc(&h->scal, sizeof(double) * 32));
-  CREATE_CHK(hipMemsetAsync(h->scal, 0, sizeof(double) * 32, h->stream));
+  CREATE_CHK(hipMalloc(&h->part, sizeof(double) * MOM_COUNT * MCL_MAX_GRID));
+  CREATE_CHK(hipMalloc(&h->scal, sizeof(double) * 64));
+  CREATE_CHK(hipMemsetAsync(h->scal, 0, sizeof(double) * 64, h->stream));
+  CREATE_CHK(hipMalloc(&h->zr, sizeof(u32) * n));
+  CREATE_CHK(hipMalloc(&h->dupes32, sizeof(u32) * ng));
+  CREATE_CHK(hipMalloc(&h->desc, sizeof(u64) * (size_t)(h->ntiles_glob + 1)));
+  CREATE_CHK(hipMemsetAsync(h->desc, 0, sizeof(u64) * (size_t)(h->ntiles_glob + 1), h->stream));
+  CREATE_CHK(hipMalloc(&h->ctrl, CTRL_BYTES));
+  CREATE_CHK(hipMemsetAsync(h->ctrl, 0, CTRL_BYTES, h->stream));
   CREATE_CHK(hipMalloc(&h->totals, sizeof(u64) * (size_t)(h->world + 1)));
   CREATE_CHK(hipMemsetAsync(h->totals, 0, sizeof(u64) * (size_t)(h->world + 1), h->stream));
-  CREATE_CHK(hipHostMalloc(&h->host_pin, sizeof(double) * 16 * MEAN_RING, hipHostMallocDefault));
+  CREATE_CHK(hipHostMalloc(&h->host_pin, sizeof(double) * RING_STRIDE * MEAN_RING, hipHostMallocDefault));
   CREATE_CHK(hipStreamSynchronize(h->stream));
 #undef CREATE_CHK
   *out = h;
@@ -1142,7 +1301,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   if (h->ev_state_ready) (void)hipEventDestroy(h->ev_state_ready);
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
-  void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum,
+  void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
                   h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev};
@@ -1210,6 +1369,7 @@ int mcl_update_gps(mcl_handle* h, double gx_map, double gy_map) {
   HIPCHK(h, hipGetLastError());
   h->weight_mode = MCL_WEIGHT_LINEAR_FLOOR;
   h->have_lw = true;
+  h->max_valid = false;
   h->residual_k = -1;
   return MCL_OK;
 }
@@ -1369,6 +1529,7 @@ int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, do
   HIPCHK(h, hipGetLastError());
   if (!accumulate) h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
   h->have_lw = true;
+  h->max_valid = false;
   h->residual_k = -1;
   return MCL_OK;
 }
@@ -1469,6 +1630,7 @@ int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_
   HIPCHK(h, le);
   if (!accumulate) h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
   h->have_lw = true;
+  h->max_valid = false;
   h->residual_k = -1;
   return MCL_OK;
 }
@@ -1600,6 +1762,7 @@ int mcl_set_log_weights(mcl_handle* h, const double* lw, int32_t weight_mode) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->weight_mode = weight_mode;
   h->have_lw = true;
+  h->max_valid = false;
   h->residual_k = -1;
   return MCL_OK;
 }
@@ -1651,10 +1814,14 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
   if (B < 1 || !(sigma > 0.0) || !(r_max > 0.0)) return fail(h, MCL_ERR_INVALID, "step_mbes: bad argument");
   if (h->map_kind < 0) return fail(h, MCL_ERR_STATE, "step_mbes: no map (call mcl_set_map_grid/mesh first)");
   RET_IF(set_device(h));
-  RET_IF(do_predict(h, odom, dt, nullptr));
+  // predict writes the MBES pose records of the new state in the same pass (the map and sensor offset are known here)
+  MbesArgs pa;
+  RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, false, &pa));
+  bool pose_done = false;
+  RET_IF(do_predict(h, odom, dt, nullptr, &pa, &pose_done));
   RET_IF(start_state_gather(h));
   int rc_u = upload_beams(h, ranges, beam_angles, B);
-  if (rc_u == MCL_OK) rc_u = launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0);
+  if (rc_u == MCL_OK) rc_u = launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, pose_done);
   if (rc_u != MCL_OK) {
     const std::string keep = h->err;
     (void)cancel_state_gather(h);
@@ -1664,8 +1831,12 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
   h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
   h->have_lw = true;
   h->residual_k = -1;
-  RET_IF(run_resample(&h, 1, nullptr, 0, nullptr));
-  RET_IF(run_mean_cov_async(&h, 1));
+  // resample; the gather pass also accumulates the sums of update_loc_pose of the new state
+  RET_IF(run_resample(&h, 1, nullptr, 0, nullptr, h->cfg.resample_scheme == MCL_RESAMPLE_SYSTEMATIC));
+  if (h->cfg.resample_scheme == MCL_RESAMPLE_SYSTEMATIC)
+    RET_IF(collect_fused_moments(&h, 1));
+  else
+    RET_IF(run_mean_cov_async(&h, 1));
   return MCL_OK;
 }
 
@@ -1701,8 +1872,7 @@ int mcl_resample_indices(int32_t scheme, const double* weights, int64_t n, const
       rc = MCL_ERR_INVALID;
     } else {
       uint64_t u53 = (uint64_t)std::floor(uniforms[0] * 9007199254740992.0);
-      rc = phase_local_max(h);
-      if (rc == MCL_OK) rc = phase_quantise(h);
+      rc = phase_quantise(h, true);
       if (rc == MCL_OK) rc = phase_cdf(h, u53);
       if (rc == MCL_OK) {
         h->have_cdf = true;

@@ -78,6 +78,45 @@ __device__ __forceinline__ T block_max(T v, T* sh, T lowest) {
   return r;
 }
 
+// ---------------------------------------------------------------- order-preserving keys, agent-scope words
+// double -> u64 with the same ordering (NaN excluded by the callers); key 0 is below every value and
+// stands for "no value yet" (decodes to -inf).  Lets a max over doubles be an integer atomicMax.
+__device__ __forceinline__ u64 ordered_key(double x) {
+  const u64 b = (u64)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ordered_value(u64 k) {
+  if (k == 0ull) return -__builtin_inf();
+  const u64 b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+#define MCL_MAX_SLOTS 64
+// relaxed agent-scope accesses (global_load/store ... sc1): L2-served, never a stale per-CU L1 line.
+// One naturally aligned 8-byte word written by ONE store is its own hand-off granule (value + tag):
+// no fence is needed to read it from another CU (MI355X_MICROARCH.md, inter-workgroup visibility).
+__device__ __forceinline__ u64 load_agent(const u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_agent(u64* p, u64 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// max over the slots an update kernel filled (one wave; every lane gets the result)
+__device__ __forceinline__ double max_from_slots(const u64* slots) {
+  u64 k = slots[threadIdx.x & 63];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 w = __shfl_xor(k, o, MCL_WAVE);
+    k = w > k ? w : k;
+  }
+  return ordered_value(k);
+}
+
 // ---------------------------------------------------------------- scalar math
 // (a + pi) % (2 pi) - pi with Python's floored modulo (auv_particle.py:48, auv_pf.py:229)
 __device__ __forceinline__ double wrap_pi(double a) {

@@ -5,7 +5,7 @@
 #include "mcl_device.h"
 
 #define MCL_BLOCK 256
-#define MCL_SCAN_ITEMS 8
+#define MCL_SCAN_ITEMS 4
 #define MCL_SCAN_TILE (MCL_BLOCK * MCL_SCAN_ITEMS)
 #define MCL_MAX_GRID 2048
 

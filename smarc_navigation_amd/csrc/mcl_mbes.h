@@ -17,6 +17,7 @@
 #include <hip/hip_fp16.h>
 
 #include "mcl_device.h"
+#include "mcl_kernels.h"
 
 #ifndef MBES_WAVES
 #define MBES_WAVES 8                         // particles per workgroup
@@ -68,6 +69,7 @@ struct MbesArgs {
   float inv_sigma, r_max;
   double lognorm;         // log(sigma sqrt(2 pi))
   double* lw;             // out: log-likelihood per particle
+  u64* max_slots;         // out: running maximum of lw (ordered keys, MCL_MAX_SLOTS words), or nullptr
   float* exp_out;         // out (EXPECT_ONLY): expected ranges [(i-exp_first)*B + b]
   long long exp_first, exp_count;
   MeshArgs mesh;
@@ -96,40 +98,93 @@ __device__ __forceinline__ double uniform_f64(double x) {
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-// ------------------------------------------------------------------ pose pre-kernel
+// ------------------------------------------------------------------ pose record
+// sensor pose in the map = m2o * T(x,y,z) R(rpy) * T_off R_off, origin in map cell units
+struct PoseXform {
+  double m2o[12];
+  double off_t[3];
+  double off_R[9];
+  double ox, oy, inv_res;
+};
+__device__ __forceinline__ MbesPose make_pose(const PoseXform& T, double x, double y, double z, double sr, double cr,
+                                              double sp, double cp, double sy, double cy) {
+  const double Rp[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
+                        sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
+                        -sp,     cp * sr,                cp * cr};
+  double Rmp[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      Rmp[r * 3 + c] = T.m2o[r * 4 + 0] * Rp[c] + T.m2o[r * 4 + 1] * Rp[3 + c] + T.m2o[r * 4 + 2] * Rp[6 + c];
+  double o[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    o[r] = (T.m2o[r * 4 + 0] * x + T.m2o[r * 4 + 1] * y + T.m2o[r * 4 + 2] * z + T.m2o[r * 4 + 3]) +
+           (Rmp[r * 3 + 0] * T.off_t[0] + Rmp[r * 3 + 1] * T.off_t[1] + Rmp[r * 3 + 2] * T.off_t[2]);
+  MbesPose P;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    P.c1[r] = (float)(Rmp[r * 3 + 0] * T.off_R[1] + Rmp[r * 3 + 1] * T.off_R[4] + Rmp[r * 3 + 2] * T.off_R[7]);
+    P.c2[r] = (float)(Rmp[r * 3 + 0] * T.off_R[2] + Rmp[r * 3 + 1] * T.off_R[5] + Rmp[r * 3 + 2] * T.off_R[8]);
+  }
+  P.um = (o[0] - T.ox) * T.inv_res;
+  P.vm = (o[1] - T.oy) * T.inv_res;
+  P.oz = (float)o[2];
+  P.pad = 0.f;
+  return P;
+}
+__device__ __forceinline__ PoseXform pose_xform(const MbesArgs& a) {
+  PoseXform T;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T.m2o[k] = a.m2o[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) T.off_t[k] = a.off_t[k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) T.off_R[k] = a.off_R[k];
+  T.ox = a.ox;
+  T.oy = a.oy;
+  T.inv_res = a.inv_res;
+  return T;
+}
+// stand-alone pose kernel (mcl_update_mbes / mcl_mbes_expected on an arbitrary state)
 __global__ void __launch_bounds__(256) k_mbes_pose(MbesArgs a) {
+  const PoseXform T = pose_xform(a);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < a.n;
        i += (long long)gridDim.x * blockDim.x) {
-    const double x = a.st[0][i], y = a.st[1][i], z = a.st[2][i];
     double sr, cr, sp, cp, sy, cy;
     sincos(a.st[3][i], &sr, &cr);
     sincos(a.st[4][i], &sp, &cp);
     sincos(a.st[5][i], &sy, &cy);
-    const double Rp[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
-                          sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
-                          -sp,     cp * sr,                cp * cr};
-    double Rmp[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        Rmp[r * 3 + c] = a.m2o[r * 4 + 0] * Rp[c] + a.m2o[r * 4 + 1] * Rp[3 + c] + a.m2o[r * 4 + 2] * Rp[6 + c];
-    double o[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-      o[r] = (a.m2o[r * 4 + 0] * x + a.m2o[r * 4 + 1] * y + a.m2o[r * 4 + 2] * z + a.m2o[r * 4 + 3]) +
-             (Rmp[r * 3 + 0] * a.off_t[0] + Rmp[r * 3 + 1] * a.off_t[1] + Rmp[r * 3 + 2] * a.off_t[2]);
-    MbesPose P;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      P.c1[r] = (float)(Rmp[r * 3 + 0] * a.off_R[1] + Rmp[r * 3 + 1] * a.off_R[4] + Rmp[r * 3 + 2] * a.off_R[7]);
-      P.c2[r] = (float)(Rmp[r * 3 + 0] * a.off_R[2] + Rmp[r * 3 + 1] * a.off_R[5] + Rmp[r * 3 + 2] * a.off_R[8]);
-    }
-    P.um = (o[0] - a.ox) * a.inv_res;
-    P.vm = (o[1] - a.oy) * a.inv_res;
-    P.oz = (float)o[2];
-    P.pad = 0.f;
-    a.pose[i] = P;
+    a.pose[i] = make_pose(T, a.st[0][i], a.st[1][i], a.st[2][i], sr, cr, sp, cp, sy, cy);
+  }
+}
+// motion_pred (mcl_kernels.h:k_predict) and the pose record of the state it has just written, in one pass
+// (the fused step: the measurement update that follows would re-read all six components).  Same arithmetic
+// as k_predict followed by k_mbes_pose, bit for bit: roll and pitch are the odometry's for every particle.
+__global__ void __launch_bounds__(MCL_BLOCK) k_predict_pose(StatePtrs s, long long n, PredictArgs a, PoseXform T,
+                                                            MbesPose* __restrict__ pose) {
+  double sr, cr, sp, cp;
+  sincos(a.roll, &sr, &cr);
+  sincos(a.pitch, &sp, &cp);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    u32x4 o = philox4x32((u32)(a.nz.gid0 + i), 0u, a.nz.step, 1u, a.nz.k0, a.nz.k1);
+    double n0, n1, n5, unused;
+    box_muller(o.x, o.y, n0, n1);
+    box_muller(o.z, o.w, n5, unused);
+    const double yaw_t = wrap_pi(s.c[5][i] + a.wzdt + a.nz.sq[5] * n5);
+    double sy, cy;
+    sincos(yaw_t, &sy, &cy);
+    const double x = s.c[0][i] + ((cy * a.m0 - sy * a.m1) + a.nz.sq[0] * n0);
+    const double y = s.c[1][i] + ((sy * a.m0 + cy * a.m1) + a.nz.sq[1] * n1);
+    s.c[0][i] = x;
+    s.c[1][i] = y;
+    s.c[2][i] = a.z;
+    s.c[3][i] = a.roll;
+    s.c[4][i] = a.pitch;
+    s.c[5][i] = yaw_t;
+    pose[i] = make_pose(T, x, y, a.z, sr, cr, sp, cp, sy, cy);
   }
 }
 
@@ -497,6 +552,7 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
   const int tile_cap = MAP != 1 ? TILE_FLOATS : TILE_FLOATS / 2;
 
   const long long nwork = MODE == 1 ? (long long)*a.work_count : ngroups;
+  double wmax = -__builtin_inf();  // lane 0: largest log-likelihood this wave has written
   for (long long it = blockIdx.x; it < nwork; it += gridDim.x) {
     const long long grp = MODE == 1 ? (long long)a.worklist[it] : it;
     const long long i = grp * MBES_WAVES + w;
@@ -635,7 +691,11 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
             }
             const double accd0 = wave_sum((double)acc0);
             const int nvs = wave_sum(nv0);
-            if (lane == 0) a.lw[i] = -0.5 * accd0 - (double)nvs * a.lognorm;
+            if (lane == 0) {
+              const double v = -0.5 * accd0 - (double)nvs * a.lognorm;
+              a.lw[i] = v;
+              wmax = v > wmax ? v : wmax;
+            }
           }
         }
         continue;  // uniform for the whole workgroup
@@ -741,7 +801,14 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
     if (!EXPECT_ONLY) {
       const double accd = wave_sum((double)acc);
       const int nv = wave_sum(nvalid);
-      if (lane == 0) a.lw[i] = -0.5 * accd - (double)nv * a.lognorm;
+      if (lane == 0) {
+        const double v = -0.5 * accd - (double)nv * a.lognorm;
+        a.lw[i] = v;
+        wmax = v > wmax ? v : wmax;  // NaN never wins
+      }
     }
   }
+  // the normalisation needs max lw: one atomic per wave on an order-preserving key, spread over the slots
+  if (!EXPECT_ONLY && lane == 0 && a.max_slots && wmax > -__builtin_inf())
+    atomicMax((unsigned long long*)&a.max_slots[(blockIdx.x * MBES_WAVES + w) & (MCL_MAX_SLOTS - 1)], ordered_key(wmax));
 }

@@ -1,0 +1,373 @@
+// mcl_resample.h -- the systematic resample as three streaming kernels (gfx950, wave64):
+//
+//   k_quantise_tiles   lw -> fixed-point weights q + per-tile sums; the block that finishes LAST scans the
+//                      tile sums (exclusive offsets + total) -- no separate scan launch.
+//   k_cdf_expand       q -> offspring CDF ncum (exact integer arithmetic); zero-offspring
+//                      flags and their global ranks by a single-pass DECOUPLED LOOK-BACK scan over the
+//                      tiles; every lost slot learns its rank, every ancestor with surplus copies writes
+//                      its index into the dupes list at the ranks it owns.  keep/lost/dupes of
+//                      auv_pf.py:183-190 without a search: dupes[k] is written, not looked up.
+//   k_resample_gather  dst[i] = src[i] (survivor) or src[dupes[rank_i]] (lost slot) + add_noise
+//                      (auv_pf.py:191-198), and -- for the fused step -- the 13 sums of
+//                      update_loc_pose (auv_pf.py:218-252) of the NEW state in the same pass, taken about
+//                      a shift (the pre-resample state of global particle 0) so that the centred moments
+//                      keep full precision; the last block adds the per-block partials in block order.
+//
+// Inter-block hand-offs follow MI355X_MICROARCH.md ("inter-workgroup visibility"): a tile descriptor is ONE
+// naturally aligned 8-byte word {epoch:30 | status:2 | value:32} written by ONE relaxed agent-scope store
+// and read by relaxed agent-scope loads (sc1: served by L2, never a stale L1 line), so it needs no fence;
+// the "last block" of the gather publishes its 13 partial sums with one write-through store, drains it
+// (s_waitcnt vmcnt(0)) and draws a ticket; the block that draws the last one acquires and adds them up.
+// Tiles are handed out by a ticket counter, so a block only ever waits for tiles that are already running;
+// blocks are 1024 threads so that 1 M particles need only 256 tickets (returning atomics on one word
+// serialise in L2 at ~88 per microsecond).
+#pragma once
+#include "mcl_kernels.h"
+
+// ------------------------------------------------------------------ max log-weight into slots
+__global__ void __launch_bounds__(MCL_BLOCK) k_max_slots(const double* __restrict__ v, long long n,
+                                                         u64* __restrict__ slots) {
+  __shared__ double sh[16];
+  double m = -__builtin_inf();
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const double x = v[i];
+    m = (x > m) ? x : m;  // NaN never wins
+  }
+  m = block_max(m, sh, -__builtin_inf());
+  if (threadIdx.x == 0) atomicMax((unsigned long long*)&slots[blockIdx.x & (MCL_MAX_SLOTS - 1)], ordered_key(m));
+}
+__global__ void __launch_bounds__(64) k_max_finish(const u64* __restrict__ slots, double* __restrict__ out) {
+  const double m = max_from_slots(slots);
+  if (threadIdx.x == 0) out[0] = m;
+}
+
+// ------------------------------------------------------------------ K1: quantise + tile sums
+// One returning atomic on ONE word costs ~11 ns (the L2 serialises them: ~88 per microsecond), so a
+// "last block done" ticket per 256-thread block would cost more than this whole kernel at 1 M particles.
+// K1 therefore only writes one sum per tile of MCL_SCAN_TILE particles; whoever needs a prefix of them
+// (k_cdf_expand, one 1024-thread block per 4 tiles) adds the few hundred sums up itself.
+struct QuantArgs {
+  const double* lw;
+  long long n;
+  const u64* slots;    // max-log-weight slots filled by the update kernel, or nullptr: read m_lw[0]
+  const double* m_lw;  // the (all-reduced) maximum
+  int mode;
+  double scale;
+  u64* q;
+  u64* tile_sum;   // gridDim.x entries
+};
+__global__ void __launch_bounds__(MCL_BLOCK) k_quantise_tiles(QuantArgs a) {
+  __shared__ u64 sh[16];
+  const double m = a.slots ? max_from_slots(a.slots) : a.m_lw[0];
+  const long long tile = blockIdx.x;  // the grid is exactly the number of tiles
+  const long long base = tile * MCL_SCAN_TILE;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < MCL_SCAN_ITEMS; ++k) {
+    const long long i = base + (long long)k * MCL_BLOCK + threadIdx.x;
+    if (i < a.n) {
+      const u64 qi = quantise_weight(a.lw[i], m, a.mode, a.scale);
+      a.q[i] = qi;
+      acc += qi;
+    }
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) a.tile_sum[tile] = acc;
+}
+
+// ------------------------------------------------------------------ decoupled look-back (u32 sums)
+#define DESC_AGG 1ull
+#define DESC_PREFIX 2ull
+__device__ __forceinline__ u32 wave_sum_all(u32 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, MCL_WAVE);
+  return v;
+}
+// Called by ONE full wave.  Publishes this tile's aggregate, returns the sum of all earlier tiles.
+__device__ __forceinline__ u32 scan_lookback(u64* desc, long long tile, u32 agg, u32 epoch) {
+  const int lane = threadIdx.x & 63;
+  const u64 ep = (u64)(epoch & 0x3fffffffu);
+  const u64 tag = ep << 34;
+  if (tile == 0) {
+    if (lane == 0) store_agent(&desc[0], tag | (DESC_PREFIX << 32) | (u64)agg);
+    return 0u;
+  }
+  if (lane == 0) store_agent(&desc[tile], tag | (DESC_AGG << 32) | (u64)agg);
+  u32 excl = 0u;
+  long long p = tile - 1;  // nearest predecessor not yet accounted for; lane l looks at p - l
+  for (;;) {
+    const long long idx = p - lane;
+    const u64 d = idx >= 0 ? load_agent(&desc[idx]) : (tag | (DESC_PREFIX << 32));  // before tile 0: prefix 0
+    const u32 st = (u32)(d >> 32) & 3u;
+    const bool valid = (d >> 34) == ep && st != 0u;
+    const unsigned long long vmask = __ballot(valid), pmask = __ballot(valid && st == (u32)DESC_PREFIX);
+    const int first_invalid = (~vmask) ? __ffsll((long long)~vmask) - 1 : 64;
+    const int first_pref = pmask ? __ffsll((long long)pmask) - 1 : 64;
+    if (first_pref < first_invalid) {  // an inclusive prefix within the valid run: done
+      excl += wave_sum_all(lane <= first_pref ? (u32)d : 0u);
+      break;
+    }
+    if (first_invalid == 0) {  // the nearest predecessor has not published yet
+      __builtin_amdgcn_s_sleep(2);
+      continue;
+    }
+    excl += wave_sum_all(lane < first_invalid ? (u32)d : 0u);
+    p -= first_invalid;
+  }
+  if (lane == 0) store_agent(&desc[tile], tag | (DESC_PREFIX << 32) | (u64)(excl + agg));
+  return excl;
+}
+
+// ------------------------------------------------------------------ K2: CDF + lost ranks + dupes list
+#define RS_BLOCK 1024                       // 16 waves: one block per CU, <= 256 tickets at 1 M particles
+#define RS_ITEMS MCL_SCAN_ITEMS
+#define RS_TILE (RS_BLOCK * RS_ITEMS)
+#define RS_FINE (RS_TILE / MCL_SCAN_TILE)   // K1 tiles per K2 tile
+#define EXP_HEAVY 24   // an ancestor with more surplus copies than this is expanded by the whole block
+#define EXP_LIST 192
+#define ZR_SURVIVOR 0xffffffffu
+struct ExpandArgs {
+  const u64* q;          // FROM_Q: fixed-point weights of this (single) shard
+  const u64* tile_sum;   // FROM_Q: the sums k_quantise_tiles wrote, n_fine entries
+  long long n_fine;
+  u64 n_global_u, u53;   // FROM_Q
+  u64* total_out;        // FROM_Q: block 0 leaves the total weight here
+  u32* ncum;             // FROM_Q: out; else in: the all-gathered global offspring CDF
+  long long n;           // elements scanned (always the GLOBAL particle count)
+  long long own0, own_n; // global index range of the slots this shard owns
+  u32* zr;               // own_n: rank among the lost slots, or ZR_SURVIVOR
+  u32* dupes;            // n: dupes[k] = ancestor whose copy the k-th lost slot receives
+  u64* desc;             // one descriptor per tile
+  u32* ticket;           // zero before the launch, left zero
+  u32 epoch;             // differs from launch to launch: stale descriptors are never valid
+};
+template <bool FROM_Q>
+__global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
+  __shared__ u64 sh64[16];
+  __shared__ u64 shb[16];
+  __shared__ u32 sh32[16];
+  __shared__ u32 snc[RS_TILE];
+  __shared__ u32 heavy[EXP_LIST][3];
+  __shared__ u32 tile_sh, zex_sh, agg_sh, heavy_n;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) {
+    const u32 t = atomicAdd(a.ticket, 1u);
+    tile_sh = t;
+    heavy_n = 0u;
+    if (t == gridDim.x - 1u) atomicExch(a.ticket, 0u);  // every ticket of this launch has been drawn
+  }
+  __syncthreads();
+  const long long tile = tile_sh;
+  const long long base = tile * RS_TILE + (long long)tid * RS_ITEMS;
+  u32 nc[RS_ITEMS];
+  u32 prev_tile = 0u;  // offspring CDF just before this tile
+  if (FROM_Q) {
+    // weight before this tile and total weight: every block adds the K1 tile sums up itself
+    u64 pre = 0ull, tot = 0ull;
+    const long long fine0 = tile * RS_FINE;
+    for (long long i = tid; i < a.n_fine; i += RS_BLOCK) {
+      const u64 v = a.tile_sum[i];
+      tot += v;
+      pre += i < fine0 ? v : 0ull;
+    }
+    pre = wave_sum(pre);
+    tot = wave_sum(tot);
+    if (lane == 0) {
+      sh64[w] = pre;
+      shb[w] = tot;
+    }
+    __syncthreads();
+    u64 off = 0ull, T = 0ull;
+#pragma unroll
+    for (int k = 0; k < RS_BLOCK / 64; ++k) {
+      off += sh64[k];
+      T += shb[k];
+    }
+    __syncthreads();  // sh64 is reused by the scan below
+    if (blockIdx.x == 0 && tid == 0) a.total_out[0] = T;
+    u64 v[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) v[k] = (base + k < a.n) ? a.q[base + k] : 0ull;
+    tile_scan_blocked(v, sh64);
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+      nc[k] = 0u;
+      if (base + k < a.n) {
+        u64 quo, rem;
+        muldiv_u64(v[k] + off, a.n_global_u, T, quo, rem);
+        nc[k] = (u32)quo + (shl53_gt_mul(rem, a.u53, T) ? 1u : 0u);
+        a.ncum[base + k] = nc[k];
+      }
+    }
+    if (off != 0ull) {
+      u64 quo, rem;
+      muldiv_u64(off, a.n_global_u, T, quo, rem);
+      prev_tile = (u32)quo + (shl53_gt_mul(rem, a.u53, T) ? 1u : 0u);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) nc[k] = (base + k < a.n) ? a.ncum[base + k] : 0u;
+    if (tile > 0) prev_tile = a.ncum[tile * RS_TILE - 1];
+  }
+  // ---- offspring counts need the left neighbour: through LDS
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k) snc[tid * RS_ITEMS + k] = nc[k];
+  __syncthreads();
+  const u32 prev = tid == 0 ? prev_tile : snc[tid * RS_ITEMS - 1];
+  u32 z[RS_ITEMS], zs[RS_ITEMS];
+  {
+    u32 cp = prev;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+      const bool in = base + k < a.n;
+      z[k] = (in && nc[k] == cp) ? 1u : 0u;
+      zs[k] = z[k];
+      if (in) cp = nc[k];
+    }
+  }
+  tile_scan_blocked(zs, sh32);  // inclusive, within the tile
+  if (tid == RS_BLOCK - 1) agg_sh = zs[RS_ITEMS - 1];
+  __syncthreads();
+  if (w == 0) {
+    const u32 zex = scan_lookback(a.desc, tile, agg_sh, a.epoch);
+    if (tid == 0) zex_sh = zex;
+  }
+  __syncthreads();
+  const u32 zex = zex_sh;
+  // ---- ranks of the lost slots; dupes entries of the ancestors with surplus copies
+  {
+    u32 cp = prev;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+      const long long j = base + k;
+      if (j < a.n) {
+        const u32 zc = zex + zs[k];  // zero-offspring slots in [0, j]
+        const u32 c = nc[k] - cp;
+        cp = nc[k];
+        if (j >= a.own0 && j < a.own0 + a.own_n) a.zr[j - a.own0] = z[k] ? zc - 1u : ZR_SURVIVOR;
+        if (c > 1u) {
+          // cumulative surplus before j:  E_{j-1} = ncum_{j-1} - j + zcum_{j-1}   (mod 2^32, the result is >= 0)
+          const u32 s = c - 1u, e0 = (nc[k] - c) - (u32)j + zc;
+          if (s <= EXP_HEAVY) {
+            for (u32 r = 0; r < s; ++r) a.dupes[e0 + r] = (u32)j;
+          } else {
+            const u32 slot = atomicAdd(&heavy_n, 1u);
+            if (slot < EXP_LIST) {
+              heavy[slot][0] = (u32)j;
+              heavy[slot][1] = e0;
+              heavy[slot][2] = s;
+            } else {
+              for (u32 r = 0; r < s; ++r) a.dupes[e0 + r] = (u32)j;
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const u32 hn = heavy_n < EXP_LIST ? heavy_n : EXP_LIST;
+  for (u32 h = 0; h < hn; ++h) {
+    const u32 j = heavy[h][0], e0 = heavy[h][1], s = heavy[h][2];
+    for (u32 r = tid; r < s; r += RS_BLOCK) a.dupes[e0 + r] = j;
+  }
+}
+
+// ------------------------------------------------------------------ K3: gather + noise (+ fused moments)
+#define MOM_COUNT 13   // sum d(x,y,z), sum roll, pitch, yaw, sum wrap(yaw), sum dxx dyy dzz dxy dxz dyz
+#define GATHER_MAX_GRID 512
+struct GatherArgs {
+  StatePtrs src;  // pre-resample state, GLOBAL indexing (state_glob when sharded)
+  StatePtrs dst;  // this shard's slice of the new state
+  long long n, goff;
+  const u32* zr;
+  const u32* dupes;
+  NoiseArgs nz;
+  int add_noise;
+  double* part;      // MOMENTS: [MOM_COUNT][gridDim.x] per-block partial sums
+  double* sums_out;  // MOMENTS: 13 sums followed by the 3 shifts
+  u32* ticket;       // MOMENTS: zero before the launch, left zero
+};
+template <bool MOMENTS>
+__global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, const double* __restrict__ replay) {
+  __shared__ double red[MOM_COUNT][RS_BLOCK / 64];
+  __shared__ u32 last_sh;
+  double acc[MOM_COUNT];
+  double shift[3] = {0.0, 0.0, 0.0};
+  if (MOMENTS) {
+#pragma unroll
+    for (int c = 0; c < MOM_COUNT; ++c) acc[c] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) shift[c] = a.src.c[c][0];  // a member of the cloud, the same on every shard
+  }
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < a.n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long g = a.goff + i;
+    const u32 r = a.zr[i];
+    const long long src = r == ZR_SURVIVOR ? g : (long long)a.dupes[r];
+    double z[6] = {0, 0, 0, 0, 0, 0};
+    if (a.add_noise) {
+      if (replay) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) z[c] = replay[i * 6 + c];
+      } else {
+        native_normals6(g, a.nz, z);
+      }
+    }
+    double v[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      v[c] = a.src.c[c][src] + a.nz.sq[c] * z[c];
+      a.dst.c[c][i] = v[c];
+    }
+    if (MOMENTS) {
+      const double dx = v[0] - shift[0], dy = v[1] - shift[1], dz = v[2] - shift[2];
+      acc[0] += dx;
+      acc[1] += dy;
+      acc[2] += dz;
+      acc[3] += v[3];
+      acc[4] += v[4];
+      acc[5] += v[5];
+      acc[6] += wrap_pi(v[5]);
+      acc[7] += dx * dx;
+      acc[8] += dy * dy;
+      acc[9] += dz * dz;
+      acc[10] += dx * dy;
+      acc[11] += dx * dz;
+      acc[12] += dy * dz;
+    }
+  }
+  if (!MOMENTS) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < MOM_COUNT; ++c) {
+    const double s = wave_sum(acc[c]);
+    if (lane == 0) red[c][w] = s;
+  }
+  __syncthreads();
+  if (w == 0) {
+    // wave 0: lanes 0..12 publish this block's 13 partial sums (ONE write-through store instruction), drain it,
+    // then lane 0 draws the ticket -- no release fence: only these words are read inside the launch
+    if (lane < MOM_COUNT) {
+      double s = 0.0;
+      for (int k = 0; k < RS_BLOCK / 64; ++k) s += red[lane][k];
+      store_agent(&a.part[(size_t)lane * gridDim.x + blockIdx.x], s);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) last_sh = (atomicAdd(a.ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last_sh) return;
+  // ---- the last block adds the partials in a fixed order (the result does not depend on which block is last):
+  // wave c takes component c, lane l the blocks l, l + 64, ...; then the fixed shuffle tree
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  if (w < MOM_COUNT) {
+    double s = 0.0;
+    for (unsigned b = lane; b < gridDim.x; b += 64) s += load_agent(&a.part[(size_t)w * gridDim.x + b]);
+    s = wave_sum(s);
+    if (lane == 0) a.sums_out[w] = s;
+  }
+  if (threadIdx.x < 3) a.sums_out[MOM_COUNT + threadIdx.x] = shift[threadIdx.x];
+  if (threadIdx.x == 0) *a.ticket = 0u;
+}

@@ -392,3 +392,77 @@ def test_rccl_single_rank_world1_smoke(eng):
     e.init_particles()
     e.update_gps(0, 0)
     e.resample()
+
+
+def test_fused_step_equals_separate_calls_bitwise(eng):
+    """mcl_step_mbes (predict + pose records in one kernel, max lw from the cast epilogue, the sums of
+    update_loc_pose inside the resample gather) against the same step made of the separate ABI calls:
+    particles bit for bit, mean / covariance to rounding (one-pass shifted sums vs two passes)."""
+    from smarc_navigation_amd import synth
+    from oracle import oracle as orc
+    n, B = 30000, 96
+    origin = (-64.0, -64.0)
+    z = synth.bathymetry_grid(128, 128, 1.0, origin, seed=3)
+    ba = synth.beam_angles(B)
+    cov = dict(init_cov=[1, 1, 0, 0, 0, 0.01], process_cov=[1e-3, 1e-3, 0, 0, 0, 1e-5],
+               resample_cov=[0.01, 0.01, 0, 0, 0, 1e-4], seed=31)
+    m2o = synth.rigid_matrix(0.5, -1.0, 0.0, 0.0, 0.0, 0.1)
+    off = [0.2, 0.0, -0.1, 0.0, 0.01, 0.02]
+    stream = synth.odom_stream(5)
+    one = eng.Engine(1, rng_mode=eng.RNG_REPLAY, m2o=m2o)
+    one.set_map_grid(z, origin, 1.0)
+    a, b = eng.Engine(n, m2o=m2o, **cov), eng.Engine(n, m2o=m2o, **cov)
+    for e in (a, b):
+        e.set_map_grid(z, origin, 1.0)
+        e.init_particles()
+    for k in range(4):
+        one.set_particles(stream['truth'][k][:, None].copy())
+        ranges = one.mbes_expected(0, 1, ba, 80.0, off)[0]
+        a.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'], ranges, ba, 0.3, 80.0, off)
+        ma = a.last_mean_cov()
+        b.predict(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'])
+        b.update_mbes(ranges, ba, 0.3, 80.0, off)
+        b.resample()
+        mb = b.mean_cov()
+        assert np.array_equal(a.get_particles(), b.get_particles()), k
+        assert np.array_equal(a.last_indices(), b.last_indices())
+        np.testing.assert_allclose(ma[0], mb[0], rtol=0, atol=1e-12)
+        assert abs(ma[1] - mb[1]) <= 1e-12
+        np.testing.assert_allclose(ma[2], mb[2], rtol=1e-9, atol=1e-15)
+        # and both are the oracle's mean/cov of that state
+        m6, yaw, c9 = orc.mean_cov(a.get_particles())
+        np.testing.assert_allclose(ma[0], m6, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(ma[2], c9, rtol=1e-8, atol=1e-15)
+
+
+@pytest.mark.parametrize('n,heavy,where', [(65536, 150, 'first_tile'), (65536, 1, 'one'), (300000, 40, 'spread'),
+                                           (2048 * 3 + 5, 2, 'tile_edges')])
+def test_expansion_of_heavy_ancestors_matches_list_semantics(eng, n, heavy, where):
+    """Ancestors with many copies: more than EXP_HEAVY surplus copies go through the block-cooperative list,
+    more than EXP_LIST of them in one tile overflow it; one particle holding all the weight; heavy
+    ancestors sitting on tile borders.  keep/lost/dupes must equal the reference's list semantics."""
+    from oracle import oracle as orc
+    rs = np.random.RandomState(5)
+    lw = np.full(n, -800.0)
+    if where == 'first_tile':
+        idx = np.arange(heavy) * 3
+    elif where == 'one':
+        idx = np.array([n // 2 + 17])
+    elif where == 'tile_edges':
+        idx = np.array([2047, 2048])
+    else:
+        idx = np.sort(rs.choice(n, heavy, replace=False))
+    lw[idx] = rs.uniform(-1.0, 0.0, idx.size)
+    soa = rs.randn(6, n)
+    e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_log_weights(lw, eng.WEIGHT_LOG_SHIFT)
+    u = 0.37
+    e.resample(uniforms=[u], normals=np.zeros((n, 6)))
+    ref_idx, _, _ = orc.systematic_fixed(lw, 1, orc.u_to_u53(u))
+    assert np.array_equal(e.last_indices(), ref_idx)
+    lost, dupes = orc.lost_dupes(ref_idx)
+    assert lost.size >= n - idx.size - 1
+    ref = soa.copy()
+    orc.reassign(ref, lost, dupes)
+    assert np.array_equal(e.get_particles(), ref)
