@@ -74,6 +74,8 @@ struct mcl_handle {
   int* idx = nullptr;         // n (lazily)
   double* replay_dev = nullptr;
   double* pose7 = nullptr;
+  double* host_pin_dev = nullptr;  // device-side address of host_pin (kernels write results into the ring directly)
+  bool moments_direct = false;
   double* host_pin = nullptr;  // pinned ring: MEAN_RING entries of 16 doubles (sums7, pad, cov-sums6, pad2)
   long long mean_count = 0;     // number of mean/cov results produced so far
   // MBES
@@ -564,10 +566,21 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   a.add_noise = 1;
   a.part = h->part;
   a.sums_out = h->scal + 32;
+  if (with_moments && !multi && h->host_pin_dev) {
+    // single shard: the last block writes the sums straight into the pinned ring entry (no copy command);
+    // the host reads it only after synchronising the stream
+    double* slot = h->host_pin + RING_STRIDE * (h->mean_count % MEAN_RING);
+    slot[16] = 1.0;
+    a.sums_out = h->host_pin_dev + RING_STRIDE * (h->mean_count % MEAN_RING);
+    h->moments_direct = true;
+  } else {
+    h->moments_direct = false;
+  }
   a.ticket = ctrl_u32(h, CTRL_T_GATHER);
   const double* rp = replay_normals ? h->replay_dev : nullptr;
   t_begin(h, MCL_K_RESAMPLE);
-  long long gg = (h->n + (long long)RS_BLOCK * 4 - 1) / ((long long)RS_BLOCK * 4);
+  // one particle per thread up to 256 blocks (= 256 tickets), grid-stride beyond
+  long long gg = (h->n + RS_BLOCK - 1) / RS_BLOCK;
   gg = gg < 1 ? 1 : (gg > GATHER_MAX_GRID ? GATHER_MAX_GRID : gg);
   if (with_moments)
     k_resample_gather<true><<<(unsigned)gg, RS_BLOCK, 0, h->stream>>>(a, rp);
@@ -840,6 +853,11 @@ int run_mean_cov_async(mcl_handle** sh, int ns) {
 }
 // the sums k_resample_gather<true> left in scal[32..47]: reduce over the shards, queue the copy to the ring
 int collect_fused_moments(mcl_handle** sh, int ns) {
+  if (ns == 1 && sh[0]->moments_direct) {
+    sh[0]->mean_count++;
+    sh[0]->have_meancov = true;
+    return MCL_OK;
+  }
   RET_IF(exchange_sums(sh, ns, 32, MOM_COUNT));
   for (int s = 0; s < ns; ++s) {
     mcl_handle* h = sh[s];
@@ -1280,6 +1298,7 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
   CREATE_CHK(hipMalloc(&h->totals, sizeof(u64) * (size_t)(h->world + 1)));
   CREATE_CHK(hipMemsetAsync(h->totals, 0, sizeof(u64) * (size_t)(h->world + 1), h->stream));
   CREATE_CHK(hipHostMalloc(&h->host_pin, sizeof(double) * RING_STRIDE * MEAN_RING, hipHostMallocDefault));
+  if (hipHostGetDevicePointer((void**)&h->host_pin_dev, h->host_pin, 0) != hipSuccess) h->host_pin_dev = nullptr;
   CREATE_CHK(hipStreamSynchronize(h->stream));
 #undef CREATE_CHK
   *out = h;

@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
 
 // ------------------------------------------------------------------ K3: gather + noise (+ fused moments)
 #define MOM_COUNT 13   // sum d(x,y,z), sum roll, pitch, yaw, sum wrap(yaw), sum dxx dyy dzz dxy dxz dyz
-#define GATHER_MAX_GRID 512
+#define GATHER_MAX_GRID 256
 struct GatherArgs {
   StatePtrs src;  // pre-resample state, GLOBAL indexing (state_glob when sharded)
   StatePtrs dst;  // this shard's slice of the new state
