@@ -17,7 +17,6 @@
 #include "mcl_kernels.h"
 #include "mcl_mbes.h"
 #include "mcl_mesh.h"
-#include "mcl_mbes_profile.h"
 #include "mcl_resample.h"
 #include "mcl_resample_alt.h"
 #include "mcl_landmarks.h"
@@ -83,6 +82,7 @@ struct mcl_handle {
   float* ranges_dev = nullptr;
   float* exp_dev = nullptr;
   MbesPose* pose_dev = nullptr;
+  MbesGroup* mbes_groups = nullptr;  // one record per group of MBES_WAVES particles
   int* mbes_worklist = nullptr;  // ngroups + 1 ints; [ngroups] is the counter
   int* lm_worklist = nullptr;    // n + 1 ints; [n] is the counter (landmark assignment: particles with clashes)
   // alternative resamplers (lazily allocated)
@@ -125,7 +125,7 @@ struct mcl_handle {
   hipEvent_t ev_state_ready = nullptr, ev_gather_done = nullptr;
   bool gather_inflight = false;
   // environment switches, read once in mcl_create (never on the per-measurement path)
-  bool env_profile = false, env_debug_work = false, env_force_comm = false, env_no_overlap = false;
+  bool env_debug_work = false, env_force_comm = false, env_no_overlap = false;
   // pinned staging so that asynchronous uploads never read caller-owned pageable memory after the call returns
   struct PinSlot {
     void* p = nullptr;
@@ -986,6 +986,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.pose = h->pose_dev;
   memset(&a.mesh, 0, sizeof a.mesh);
   a.stats = nullptr;
+  a.diag_mode = 0;
 #ifdef MBES_STATS
   {
     static unsigned long long* g_stats = nullptr;
@@ -1022,58 +1023,68 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.res = (float)m->cs;
     a.zmin_map = m->zmin;
     a.zmax_map = m->zmax;
+    a.diag_mode = m->diag_mode;
   }
   const long long ngroups = (h->n + MBES_WAVES - 1) / MBES_WAVES;
   const int grid = (int)(ngroups < 4096 ? ngroups : 4096);
   if (!h->mbes_worklist) HIPCHK(h, hipMalloc(&h->mbes_worklist, sizeof(int) * (size_t)(ngroups + 1)));
+  if (!h->mbes_groups) HIPCHK(h, hipMalloc(&h->mbes_groups, sizeof(MbesGroup) * (size_t)ngroups));
   a.worklist = h->mbes_worklist;
+  a.groups = h->mbes_groups;
   a.work_count = (int*)(h->ctrl + CTRL_WORK);
   // the cast kernels leave max lw in the control block's slots: the normalisation needs no reduction pass
   a.max_slots = (with_ranges && lw_out == h->lw) ? ctrl_slots(h) : nullptr;
+  // height grids and structured meshes: the pose kernel classifies the groups, k_mbes_fast casts the
+  // eligible ones, k_mbes_cast<.,.,1> the worklist; triangle-record meshes keep the two-mode kernel
+  const bool lean = h->map_kind == 0 || (h->mesh->heights && !h->force_general_mesh);
   if (args_only) {
     *args_only = a;
     return MCL_OK;
   }
   t_begin(h, MCL_K_UPDATE_MBES);
-  if (a.max_slots) {
-    HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_WORK + sizeof(int), h->stream));  // slots + work counter
-    h->max_valid = true;
-  } else {
-    HIPCHK(h, hipMemsetAsync(a.work_count, 0, sizeof(int), h->stream));
+  if (!pose_done) {
+    // (the fused predict has already reset the control block and written poses, group records and worklist)
+    if (a.max_slots)
+      HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_WORK + sizeof(int), h->stream));  // slots + work counter
+    else
+      HIPCHK(h, hipMemsetAsync(a.work_count, 0, sizeof(int), h->stream));
+    if (lean)
+      k_mbes_pose<true><<<grid_for(h->n), 256, 0, h->stream>>>(a);
+    else
+      k_mbes_pose<false><<<grid_for(h->n), 256, 0, h->stream>>>(a);
   }
-  if (!pose_done) k_mbes_pose<<<grid_for(h->n), 256, 0, h->stream>>>(a);
-  // fast kernel over every group, then the general kernel over the few groups it deferred
+  if (a.max_slots) h->max_valid = true;
   const int ggrid = (int)(ngroups < 512 ? ngroups : 512);
-#define LAUNCH_CAST(MAPV)                                                          \
+#define LAUNCH_LEAN(SURFV, MAPV)                                                   \
   do {                                                                             \
     if (with_ranges) {                                                             \
-      k_mbes_cast<MAPV, false, 0><<<grid, MBES_THREADS, 0, h->stream>>>(a);        \
+      k_mbes_fast<SURFV, false><<<grid, MBES_THREADS, 0, h->stream>>>(a);          \
       k_mbes_cast<MAPV, false, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);       \
     } else {                                                                       \
-      k_mbes_cast<MAPV, true, 0><<<grid, MBES_THREADS, 0, h->stream>>>(a);         \
+      k_mbes_fast<SURFV, true><<<grid, MBES_THREADS, 0, h->stream>>>(a);           \
       k_mbes_cast<MAPV, true, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);        \
     }                                                                              \
   } while (0)
-  if (h->map_kind == 0)
-    LAUNCH_CAST(0);
-  else if (h->mesh->heights && !h->force_general_mesh) {
-    // per-ray fast traversal by default; MCL_PROFILE=1 selects the experimental profile-marching kernel
-    // (exact and tested, but measured slower in round 1: 3.7 ms vs 2.9 ms at 1 M x 512 -- DESIGN.md 5c)
-    if (!h->env_profile) {
-      LAUNCH_CAST(2);
+  if (h->map_kind == 0) {
+    LAUNCH_LEAN(0, 0);
+  } else if (lean) {
+    if (a.diag_mode == 1)
+      LAUNCH_LEAN(2, 2);
+    else if (a.diag_mode == 2)
+      LAUNCH_LEAN(3, 2);
+    else
+      LAUNCH_LEAN(1, 2);
+  } else {
+    // fast traversal over every group, then the general traversal over the few groups it deferred
+    if (with_ranges) {
+      k_mbes_cast<1, false, 0><<<grid, MBES_THREADS, 0, h->stream>>>(a);
+      k_mbes_cast<1, false, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);
     } else {
-      if (with_ranges) {
-        k_mbes_profile<false><<<grid, MBES_THREADS, 0, h->stream>>>(a);
-        k_mbes_cast<2, false, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);
-      } else {
-        k_mbes_profile<true><<<grid, MBES_THREADS, 0, h->stream>>>(a);
-        k_mbes_cast<2, true, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);
-      }
+      k_mbes_cast<1, true, 0><<<grid, MBES_THREADS, 0, h->stream>>>(a);
+      k_mbes_cast<1, true, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);
     }
   }
-  else
-    LAUNCH_CAST(1);
-#undef LAUNCH_CAST
+#undef LAUNCH_LEAN
   if (h->env_debug_work) {  // diagnostics: how many groups the fast kernel deferred
     int cnt = 0;
     (void)hipMemcpyAsync(&cnt, a.work_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
@@ -1122,15 +1133,13 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
     // noise-free: feed zeros through the native branch with sq = 0
   }
   if (pose_for && !rp && h->cfg.rng_mode == MCL_RNG_NATIVE) {
-    PoseXform T;
-    for (int k = 0; k < 12; ++k) T.m2o[k] = pose_for->m2o[k];
-    for (int k = 0; k < 3; ++k) T.off_t[k] = pose_for->off_t[k];
-    for (int k = 0; k < 9; ++k) T.off_R[k] = pose_for->off_R[k];
-    T.ox = pose_for->ox;
-    T.oy = pose_for->oy;
-    T.inv_res = pose_for->inv_res;
-    k_predict_pose<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, T,
-                                                               pose_for->pose);
+    // reset the slots + work counter first: the kernel appends the deferred groups to the worklist
+    HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_WORK + sizeof(int), h->stream));
+    const bool lean = h->map_kind == 0 || (h->mesh->heights && !h->force_general_mesh);
+    if (lean)
+      k_predict_pose<true><<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, *pose_for);
+    else
+      k_predict_pose<false><<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, *pose_for);
     if (pose_written) *pose_written = true;
   } else {
     k_predict<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, rp);
@@ -1246,7 +1255,6 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
       const char* v = getenv(name);
       return v && v[0] == '1';
     };
-    h->env_profile = on("MCL_PROFILE");
     h->env_debug_work = getenv("MCL_DEBUG_WORK") != nullptr;
     h->env_force_comm = on("MCL_FORCE_COMM");
     h->env_no_overlap = on("MCL_NO_OVERLAP");
@@ -1322,7 +1330,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1834,13 +1842,14 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
   if (h->map_kind < 0) return fail(h, MCL_ERR_STATE, "step_mbes: no map (call mcl_set_map_grid/mesh first)");
   RET_IF(set_device(h));
   // predict writes the MBES pose records of the new state in the same pass (the map and sensor offset are known here)
+  // (the beam table first: the group classification in that kernel follows the two extreme beams)
+  RET_IF(upload_beams(h, ranges, beam_angles, B));
   MbesArgs pa;
   RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, false, &pa));
   bool pose_done = false;
   RET_IF(do_predict(h, odom, dt, nullptr, &pa, &pose_done));
   RET_IF(start_state_gather(h));
-  int rc_u = upload_beams(h, ranges, beam_angles, B);
-  if (rc_u == MCL_OK) rc_u = launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, pose_done);
+  int rc_u = launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, pose_done);
   if (rc_u != MCL_OK) {
     const std::string keep = h->err;
     (void)cancel_state_gather(h);

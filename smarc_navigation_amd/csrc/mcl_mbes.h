@@ -40,6 +40,14 @@ struct MbesPose {   // 48 B
   float pad;
 };
 
+// Tile window of one group of MBES_WAVES consecutive particles, decided once per group by the pose kernel
+// (one thread per particle, 8-lane shuffles) instead of by every wave of the cast kernel.
+struct MbesGroup {   // 32 B
+  int tx0, ty0, tw, th;  // window origin and size: nodes (grid / structured mesh)
+  int fast;              // 1: k_mbes_fast casts this group; 0: it is on the worklist of the general kernel
+  int pad[3];
+};
+
 struct MeshArgs {
   const float4* tri;       // 3 float4 per (cell, triangle) record, plane form (mcl_mesh.h)
   const float4* tri_mt;    // Moller-Trumbore records for near-vertical triangles (or nullptr)
@@ -66,6 +74,7 @@ struct MbesArgs {
   double ox, oy, inv_res;
   float res;
   float zmin_map, zmax_map;
+  int diag_mode;          // structured mesh: 1 = every cell split along 00-11, 2 = along 10-01, 0 = per-cell bit
   float inv_sigma, r_max;
   double lognorm;         // log(sigma sqrt(2 pi))
   double* lw;             // out: log-likelihood per particle
@@ -73,6 +82,7 @@ struct MbesArgs {
   float* exp_out;         // out (EXPECT_ONLY): expected ranges [(i-exp_first)*B + b]
   long long exp_first, exp_count;
   MeshArgs mesh;
+  struct MbesGroup* groups;  // one record per group of MBES_WAVES particles (written by the pose kernels)
   int* worklist;          // group ids deferred by the fast kernel (capacity = number of groups)
   int* work_count;        // device counter, zeroed before every fast launch
   unsigned long long* stats;  // MBES_STATS builds: steps, exact tests, rays, retries
@@ -147,44 +157,134 @@ __device__ __forceinline__ PoseXform pose_xform(const MbesArgs& a) {
   T.inv_res = a.inv_res;
   return T;
 }
+// Group classification for the fast cast kernel (height grids and structured meshes).  Called by every
+// lane of a wave with the pose record of "its" particle (lanes 8k..8k+7 = one group).  The footprint of a
+// fan is bounded by its two extreme-angle beams followed down to z_min(map) (planar fan: the end points of
+// all beams at that depth are collinear and ordered by angle); a group is FAST when all its fans have such
+// a footprint, the bounding window is not clipped by the map border, fits the LDS tile and contains every
+// sensor with a cell of margin.  Everything else goes on the worklist of the general kernel.
+__device__ __forceinline__ void classify_group(const MbesArgs& a, const MbesPose& P, bool valid, long long i) {
+  const int lane = threadIdx.x & 63;
+  const float inv_res = (float)a.inv_res;
+  float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = umin, vmax = umax;
+  bool simple = true;
+  if (valid) {
+    umin = umax = (float)P.um;
+    vmin = vmax = (float)P.vm;
+    simple = a.b_lo >= 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float2 sc = a.beam_sc[k == 0 ? max(a.b_lo, 0) : max(a.b_hi, 0)];
+      const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
+      const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
+      const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
+      const float t_end = fmaxf((a.zmin_map - P.oz) * fast_rcp(dz), 0.f);
+      simple = simple & (dz < -1e-4f) & (t_end <= a.r_max);
+      const float ue = (float)P.um + t_end * dx * inv_res, ve = (float)P.vm + t_end * dy * inv_res;
+      umin = fminf(umin, ue);
+      umax = fmaxf(umax, ue);
+      vmin = fminf(vmin, ve);
+      vmax = fmaxf(vmax, ve);
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < MBES_WAVES; o <<= 1) {
+    umin = fminf(umin, __shfl_xor(umin, o, 64));
+    umax = fmaxf(umax, __shfl_xor(umax, o, 64));
+    vmin = fminf(vmin, __shfl_xor(vmin, o, 64));
+    vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+  }
+  const int lim_x = a.nx - 1, lim_y = a.ny - 1;
+  const int wx0 = (int)floorf(umin) - 1, wy0 = (int)floorf(vmin) - 1;
+  const int wx1 = (int)floorf(umax) + 2, wy1 = (int)floorf(vmax) + 2;
+  const bool clipped = wx0 < 0 || wy0 < 0 || wx1 > lim_x || wy1 > lim_y;
+  const int tx0 = max(wx0, 0), ty0 = max(wy0, 0);
+  const int tw = min(wx1, lim_x) - tx0 + 1, th = min(wy1, lim_y) - ty0 + 1;
+  const bool fits = tw >= 2 && th >= 2 && (long long)tw * th <= MBES_TILE_FLOATS;
+  const float ul = (float)(P.um - (double)tx0), vl = (float)(P.vm - (double)ty0);
+  const bool inside = !valid || (ul >= 1.f && vl >= 1.f && ul < (float)(tw - 2) && vl < (float)(th - 2));
+  const unsigned long long okm = __ballot(inside && simple);
+  const unsigned grp_bits = (unsigned)(okm >> (lane & ~(MBES_WAVES - 1))) & ((1u << MBES_WAVES) - 1u);
+  const bool fast = (umin <= umax) && !clipped && fits && grp_bits == ((1u << MBES_WAVES) - 1u);
+  const bool leader = (lane & (MBES_WAVES - 1)) == 0 && valid;
+  if (leader) {
+    MbesGroup G;
+    G.tx0 = tx0;
+    G.ty0 = ty0;
+    G.tw = tw;
+    G.th = th;
+    G.fast = fast ? 1 : 0;
+    G.pad[0] = G.pad[1] = G.pad[2] = 0;
+    a.groups[i / MBES_WAVES] = G;
+  }
+  // one atomic per wave: the leaders of its deferred groups take consecutive worklist slots
+  const unsigned long long dm = __ballot(leader && !fast);
+  if (dm) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(a.work_count, (int)__popcll(dm));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (leader && !fast) a.worklist[base + (int)__popcll(dm & ((1ull << lane) - 1ull))] = (int)(i / MBES_WAVES);
+  }
+}
+
 // stand-alone pose kernel (mcl_update_mbes / mcl_mbes_expected on an arbitrary state)
+template <bool CLASSIFY>
 __global__ void __launch_bounds__(256) k_mbes_pose(MbesArgs a) {
   const PoseXform T = pose_xform(a);
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < a.n;
+  const long long n_pad = (a.n + 63) & ~63ll;  // whole waves take part in the group shuffles
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_pad;
        i += (long long)gridDim.x * blockDim.x) {
-    double sr, cr, sp, cp, sy, cy;
-    sincos(a.st[3][i], &sr, &cr);
-    sincos(a.st[4][i], &sp, &cp);
-    sincos(a.st[5][i], &sy, &cy);
-    a.pose[i] = make_pose(T, a.st[0][i], a.st[1][i], a.st[2][i], sr, cr, sp, cp, sy, cy);
+    const bool valid = i < a.n;
+    MbesPose P;
+    P.um = P.vm = 0.0;
+    P.oz = 0.f;
+    if (valid) {
+      double sr, cr, sp, cp, sy, cy;
+      sincos(a.st[3][i], &sr, &cr);
+      sincos(a.st[4][i], &sp, &cp);
+      sincos(a.st[5][i], &sy, &cy);
+      P = make_pose(T, a.st[0][i], a.st[1][i], a.st[2][i], sr, cr, sp, cp, sy, cy);
+      a.pose[i] = P;
+    }
+    if (CLASSIFY) classify_group(a, P, valid, i);
   }
 }
 // motion_pred (mcl_kernels.h:k_predict) and the pose record of the state it has just written, in one pass
 // (the fused step: the measurement update that follows would re-read all six components).  Same arithmetic
 // as k_predict followed by k_mbes_pose, bit for bit: roll and pitch are the odometry's for every particle.
-__global__ void __launch_bounds__(MCL_BLOCK) k_predict_pose(StatePtrs s, long long n, PredictArgs a, PoseXform T,
-                                                            MbesPose* __restrict__ pose) {
+template <bool CLASSIFY>
+__global__ void __launch_bounds__(MCL_BLOCK) k_predict_pose(StatePtrs s, long long n, PredictArgs a, MbesArgs m) {
+  const PoseXform T = pose_xform(m);
   double sr, cr, sp, cp;
   sincos(a.roll, &sr, &cr);
   sincos(a.pitch, &sp, &cp);
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+  const long long n_pad = (n + 63) & ~63ll;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_pad;
        i += (long long)gridDim.x * blockDim.x) {
-    u32x4 o = philox4x32((u32)(a.nz.gid0 + i), 0u, a.nz.step, 1u, a.nz.k0, a.nz.k1);
-    double n0, n1, n5, unused;
-    box_muller(o.x, o.y, n0, n1);
-    box_muller(o.z, o.w, n5, unused);
-    const double yaw_t = wrap_pi(s.c[5][i] + a.wzdt + a.nz.sq[5] * n5);
-    double sy, cy;
-    sincos(yaw_t, &sy, &cy);
-    const double x = s.c[0][i] + ((cy * a.m0 - sy * a.m1) + a.nz.sq[0] * n0);
-    const double y = s.c[1][i] + ((sy * a.m0 + cy * a.m1) + a.nz.sq[1] * n1);
-    s.c[0][i] = x;
-    s.c[1][i] = y;
-    s.c[2][i] = a.z;
-    s.c[3][i] = a.roll;
-    s.c[4][i] = a.pitch;
-    s.c[5][i] = yaw_t;
-    pose[i] = make_pose(T, x, y, a.z, sr, cr, sp, cp, sy, cy);
+    const bool valid = i < n;
+    MbesPose P;
+    P.um = P.vm = 0.0;
+    P.oz = 0.f;
+    if (valid) {
+      u32x4 o = philox4x32((u32)(a.nz.gid0 + i), 0u, a.nz.step, 1u, a.nz.k0, a.nz.k1);
+      double n0, n1, n5, unused;
+      box_muller(o.x, o.y, n0, n1);
+      box_muller(o.z, o.w, n5, unused);
+      const double yaw_t = wrap_pi(s.c[5][i] + a.wzdt + a.nz.sq[5] * n5);
+      double sy, cy;
+      sincos(yaw_t, &sy, &cy);
+      const double x = s.c[0][i] + ((cy * a.m0 - sy * a.m1) + a.nz.sq[0] * n0);
+      const double y = s.c[1][i] + ((sy * a.m0 + cy * a.m1) + a.nz.sq[1] * n1);
+      s.c[0][i] = x;
+      s.c[1][i] = y;
+      s.c[2][i] = a.z;
+      s.c[3][i] = a.roll;
+      s.c[4][i] = a.pitch;
+      s.c[5][i] = yaw_t;
+      P = make_pose(T, x, y, a.z, sr, cr, sp, cp, sy, cy);
+      m.pose[i] = P;
+    }
+    if (CLASSIFY) classify_group(m, P, valid, i);
   }
 }
 
@@ -530,6 +630,159 @@ __device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int t
   return r_max;
 }
 
+// ------------------------------------------------------------------ clearance traversal (LDS tile)
+// Same preconditions as cast_fast.  ONE loop, no separate exact test: the ray is followed cell by cell in
+// its own "forward" frame (a', b' grow along the ray in both axes, F00 is the corner it enters by, F11 the
+// one it leaves by), carrying the clearance g = z_ray - h at the cell border it has just crossed.  Heights
+// along cell EDGES are linear for bilinear patches and for either triangulation, so g at the exit point is
+// two corner reads and a lerp, and g at the entry of the next cell is the same number (continuity).
+//   SURF 1..3 (a cell = two triangles): along the ray h is piecewise linear with one kink where the ray
+//     crosses the cell's diagonal, so the first hit is the first sign change of g over
+//     {entry, diagonal crossing, exit} and the range follows by linear interpolation -- exact.
+//     SURF 1: the diagonal of a cell is the LSB of its (0,0) corner height (mixed meshes);
+//     SURF 2 / 3: every cell is split along 00-11 / 10-01 (no bit to read, heights untouched).
+//   SURF 0 (bilinear patch): g is a quadratic in t between the borders, g(tau) = g_in + B tau + K tau^2 with
+//     K = -(twist) cu cv dt^2: a sign change at the exit, or both ends above and a real root inside (grazing).
+// ~41 VALU + 4 LDS reads per cell for the triangulated surfaces, against 25 per cell + 76 per exact
+// two-plane test before; the wave executes max-over-lanes CELLS only, there is no second divergent phase.
+template <int SURF>
+__device__ __forceinline__ float cast_clear(const float* __restrict__ tile, int th, const MbesArgs& a, float u0, float v0,
+                                            float oz, float du, float dv, float dz, float zmax, float r_max) {
+  const float INF = __builtin_inff();
+  const float rdz = fast_rcp(dz);
+  float t_lo = 0.f, t1 = r_max;
+  if (dz < 0.f) {
+    if (oz > zmax) t_lo = fmaxf((zmax - oz) * rdz - 1e-3f, 0.f);  // skip the water column above the tile
+    t1 = fminf(r_max, (a.zmin_map - oz) * rdz + 1e-2f);           // below every node beyond this
+  }
+  const bool px = du > 0.f, py = dv > 0.f;
+  const float cu = fabsf(du), cv = fabsf(dv);                        // cells per metre along each axis
+  const float iu = fabsf(fast_rcp(du)), iv = fabsf(fast_rcp(dv));    // metres per cell (+inf: axis-parallel)
+  const float fu = floorf(fmaf(t_lo, du, u0)), fv = floorf(fmaf(t_lo, dv, v0));
+  // forward-frame coordinates of the ray at parameter t inside the current cell: a' = A0 + t cu, b' = B0 + t cv
+  float A0 = px ? u0 - fu : (fu + 1.f) - u0;
+  float B0 = py ? v0 - fv : (fv + 1.f) - v0;
+  // parameter at which the ray reaches a' = 1 / b' = 1 (0 * inf = NaN -> "never": see cast_fast)
+  float tnx = fminf((1.f - A0) * iu, INF), tny = fminf((1.f - B0) * iv, INF);
+  // LDS BYTE offsets: F00 = entry corner, F10 / F01 one node on along x / y, F11 the exit corner
+  const char* base = (const char*)tile;
+  const int oxb = (px ? th : -th) * 4, oyb = py ? 4 : -4, oxyb = oxb + oyb;
+  int a00 = (__mul24((int)fu + (px ? 0 : 1), th) + (int)fv + (py ? 0 : 1)) * 4;  // tile indices fit 24 bits
+#define TILE_AT(off) (*(const float*)(base + (off)))
+  // diagonal of a cell in the forward frame: mirroring ONE axis turns a 00-11 split into a 10-01 split
+  const bool flip = px != py;
+  bool fd = SURF == 2 ? flip : !flip;       // true: the cell is split along F10-F01 (SURF 1: re-read per cell)
+  const int kcb = (px ? 0 : -th * 4) + (py ? 0 : -4);  // SURF 1: the canonical (0,0) corner relative to F00
+  if (SURF == 1) fd = ((__float_as_uint(TILE_AT(a00 + kcb)) & 1u) != 0u) != flip;
+  float t_in = t_lo, g_in;
+  {
+    // clearance at the start point (inside the start cell)
+    const float F00 = TILE_AT(a00), F01 = TILE_AT(a00 + oyb), F10 = TILE_AT(a00 + oxb), F11 = TILE_AT(a00 + oxyb);
+    const float as = fmaf(t_lo, cu, A0), bs = fmaf(t_lo, cv, B0);
+    float h;
+    if (SURF == 0) {
+      const float h0 = fmaf(as, F10 - F00, F00), h1 = fmaf(as, F11 - F01, F01);
+      h = fmaf(bs, h1 - h0, h0);
+    } else {
+      // fd false: triangles (F00,F10,F11) below the diagonal b' = a', (F00,F01,F11) above it
+      // fd true : triangles (F00,F10,F01) where a' + b' <= 1, (F10,F11,F01) beyond
+      const bool lower = (fd & (as + bs <= 1.f)) | (!fd & (bs <= as));
+      const float sa = lower ? F10 - F00 : F11 - F01;
+      const float sb = (lower == fd) ? F01 - F00 : F11 - F10;
+      const float hc = (fd & !lower) ? (F10 + F01) - F11 : F00;
+      h = fmaf(bs, sb, fmaf(as, sa, hc));
+    }
+    g_in = fmaf(t_lo, dz, oz) - h;
+    if (SURF == 0 && !(t_lo > 0.f) && g_in <= 0.f) return 0.f;  // the sensor itself is at or below the seabed
+    // a vertical ray never leaves its cell: the surface under it is the height just evaluated
+    if (!(tnx < INF) & !(tny < INF)) return (dz < 0.f && g_in > 0.f) ? fminf(t_lo - g_in * rdz, r_max) : r_max;
+  }
+  // per-ray constants of the diagonal crossing  t_d = (ck - A0 + sB B0) * inv_sel:
+  //   fd: a' + b' = 1 -> (1 - A0 - B0) / (cu + cv)      !fd: a' = b' -> (B0 - A0) / (cu - cv)
+  // and of the two nodes the diagonal joins (P0 at a' = 0 ... P1 at a' = 1 along it)
+  float ck = fd ? 1.f : 0.f, sB = fd ? -1.f : 1.f, inv_sel = fast_rcp(fd ? cu + cv : cu - cv);
+  int kP0 = fd ? oyb : 0, kP1 = fd ? oxb : oxyb;
+  const float cucv = cu * cv;
+  float t_out, g_out, t_d = 0.f, g_d = 0.f, kq = 0.f;
+  bool in = false, hit;
+  for (;;) {
+    const bool stepx = tnx <= tny;
+    const int aE = a00 + (stepx ? oxb : oyb);  // the node next to F00 on the edge the ray leaves by = next cell's F00
+    // always to the cell's exit edge (never cut at t1: the clearance is evaluated ON the edge); a hit beyond
+    // r_max is discarded at the end, and the cell that contains t1 still lies inside the tile
+    t_out = stepx ? tnx : tny;
+    const float f = fmaf(t_out, stepx ? cv : cu, stepx ? B0 : A0);  // position along that edge, it ends in F11
+    const float F11 = TILE_AT(a00 + oxyb);
+    if (SURF == 0) {
+      const float F00 = TILE_AT(a00), F01 = TILE_AT(a00 + oyb), F10 = TILE_AT(a00 + oxb);
+      const float E0 = stepx ? F10 : F01;
+      g_out = fmaf(t_out, dz, oz) - fmaf(f, F11 - E0, E0);
+      const float dt = t_out - t_in;
+      kq = -(((F11 - F01) - (F10 - F00)) * cucv) * (dt * dt);
+      // a sign change at the exit, or both ends above and a real root inside (K > 0: the patch bulges up to the ray).
+      // With B = g_out - g_in - K < 0 the smaller root is 2 g_in / (sqrt(disc) - B) and sqrt(disc) <= -B, so it
+      // can only be < 1 if g_out < K: that one compare keeps the grazing test out of the common path
+      // (the branch is wave-uniform: taken only when some lane is that close to the surface)
+      hit = (g_out > 0.f) != (g_in > 0.f);
+      const bool maybe = (!hit) & (g_out < kq);
+      if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
+        const float Bq = (g_out - g_in) - kq;
+        const float disc = fmaf(Bq, Bq, -4.f * kq * g_in);
+        if (maybe & (Bq < 0.f) & (disc >= 0.f)) hit = 2.f * g_in < fast_sqrt(disc) - Bq;
+      }
+    } else {
+      if (SURF == 1) {
+        fd = ((__float_as_uint(TILE_AT(a00 + kcb)) & 1u) != 0u) != flip;
+        ck = fd ? 1.f : 0.f;
+        sB = fd ? -1.f : 1.f;
+        inv_sel = fast_rcp(fd ? cu + cv : cu - cv);
+        kP0 = fd ? oyb : 0;
+        kP1 = fd ? oxb : oxyb;
+      }
+      const float E0 = TILE_AT(aE), P0 = TILE_AT(a00 + kP0), P1 = TILE_AT(a00 + kP1);
+      g_out = fmaf(t_out, dz, oz) - fmaf(f, F11 - E0, E0);
+      t_d = fmaf(sB, B0, ck - A0) * inv_sel;
+      in = (t_d > t_in) & (t_d < t_out);  // NaN / inf: the ray does not cross the diagonal inside the cell
+      g_d = fmaf(t_d, dz, oz) - fmaf(fmaf(t_d, cu, A0), P1 - P0, P0);
+      const bool c_i = g_in > 0.f, c_d = g_d > 0.f, c_o = g_out > 0.f;
+      const bool x1 = in & (c_d != c_i);  // sign change on the first piece
+      hit = x1 | ((c_o != c_i) != x1);    // or on the last one: c_o != (in ? c_d : c_i), as lane-mask XORs
+    }
+    if (hit | !(t_out < t1)) break;
+    a00 = aE;
+    A0 -= stepx ? 1.f : 0.f;
+    B0 -= stepx ? 0.f : 1.f;
+    tnx += stepx ? iu : 0.f;
+    tny += stepx ? 0.f : iv;
+    t_in = t_out;
+    g_in = g_out;
+  }
+#undef TILE_AT
+  if (!hit) return r_max;
+  float root;
+  if (SURF == 0) {
+    // smallest root in [0, 1] of K tau^2 + B tau + g_in = 0
+    const float Bq = (g_out - g_in) - kq;
+    const float disc = fmaxf(fmaf(Bq, Bq, -4.f * kq * g_in), 0.f);
+    const float sq = fast_sqrt(disc);
+    const float qv = -0.5f * (Bq + (Bq >= 0.f ? sq : -sq));
+    const float r1 = g_in * fast_rcp(qv), r2 = qv * fast_rcp(kq);  // r2 = inf / NaN on a planar patch
+    const float c1 = (r1 >= -1e-4f && r1 <= 1.0001f) ? r1 : INF, c2 = (r2 >= -1e-4f && r2 <= 1.0001f) ? r2 : INF;
+    float tau = fminf(c1, c2);
+    if (!(tau < INF)) tau = g_in * fast_rcp(g_in - g_out);  // rounding pushed both just outside: the chord
+    root = fmaf(fminf(fmaxf(tau, 0.f), 1.f), t_out - t_in, t_in);
+  } else {
+    // the piece of the cell in which g changes sign: [t_in, t_d], [t_d, t_out] or the whole cell
+    const bool first = in & ((g_d > 0.f) != (g_in > 0.f));
+    const bool from_in = first | !in;
+    const float ta = from_in ? t_in : t_d, ga = from_in ? g_in : g_d;
+    const float tb = first ? t_d : t_out, gb = first ? g_d : g_out;
+    root = fmaf(ga * fast_rcp(ga - gb), tb - ta, ta);
+    root = fminf(fmaxf(root, ta), tb);
+  }
+  return root <= r_max ? fmaxf(root, 0.f) : r_max;
+}
+
 // ------------------------------------------------------------------ the cast kernel
 // MODE 0: fast traversal only -- a workgroup whose tile is clipped by the map border, does not fit LDS
 //         or whose sensors are not inside it appends its group id to a.worklist and returns; this
@@ -756,7 +1009,18 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
       float e;
       bool below;
       if (MODE == 0) {
+#ifdef MBES_OLD_FAST
         e = cast_fast<MAP>(tile, th, tw, a, tx0, ty0, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max, rs);
+#else
+        if (MAP == 0)
+          e = cast_clear<0>(tile, th, a, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max);
+        else if (MAP == 2)
+          e = a.diag_mode == 1 ? cast_clear<2>(tile, th, a, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max)
+            : a.diag_mode == 2 ? cast_clear<3>(tile, th, a, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max)
+                               : cast_clear<1>(tile, th, a, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max);
+        else
+          e = cast_fast<MAP>(tile, th, tw, a, tx0, ty0, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max, rs);
+#endif
       } else if (MAP == 2) {
         // structured mesh off the fast path (map border, wide cloud): general mesh march on global memory
         e = use < 0 ? a.r_max
@@ -798,6 +1062,85 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
       }
     }
 #endif
+    if (!EXPECT_ONLY) {
+      const double accd = wave_sum((double)acc);
+      const int nv = wave_sum(nvalid);
+      if (lane == 0) {
+        const double v = -0.5 * accd - (double)nv * a.lognorm;
+        a.lw[i] = v;
+        wmax = v > wmax ? v : wmax;  // NaN never wins
+      }
+    }
+  }
+  // the normalisation needs max lw: one atomic per wave on an order-preserving key, spread over the slots
+  if (!EXPECT_ONLY && lane == 0 && a.max_slots && wmax > -__builtin_inf())
+    atomicMax((unsigned long long*)&a.max_slots[(blockIdx.x * MBES_WAVES + w) & (MCL_MAX_SLOTS - 1)], ordered_key(wmax));
+}
+
+// ------------------------------------------------------------------ the fast cast kernel
+// Height grids (MAP 0) and structured meshes (MAP 2).  One wavefront per particle, lanes = consecutive
+// beams, MBES_WAVES particles per workgroup share one LDS tile.  Everything that is decided per GROUP (tile
+// window, eligibility) was decided by the pose kernel (classify_group) and arrives as one 32-byte record
+// through scalar loads; what is left per group is the staging of the tile and its maximum height.
+// SURF: the surface cast_clear follows -- 0 bilinear grid, 1 triangulated with a per-cell diagonal bit,
+// 2 / 3 triangulated with every cell split along 00-11 / 10-01.
+template <int SURF, bool EXPECT_ONLY>
+__global__ void __launch_bounds__(MBES_THREADS, MBES_MIN_WAVES_PER_SIMD) k_mbes_fast(MbesArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[MBES_TILE_FLOATS];
+  __shared__ float red[MBES_WAVES];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long ngroups = (a.n + MBES_WAVES - 1) / MBES_WAVES;
+  const float inv_res = (float)a.inv_res;
+  double wmax = -__builtin_inf();  // lane 0: largest log-likelihood this wave has written
+  for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const MbesGroup G = a.groups[grp];  // uniform address: scalar loads
+    if (!G.fast) continue;              // on the general kernel's worklist
+    const int tx0 = G.tx0, ty0 = G.ty0, tw = G.tw, th = G.th;
+    const long long i = grp * MBES_WAVES + w;
+    const bool valid = i < a.n;
+    __syncthreads();  // the previous group's tile and red[] are fully consumed
+    // ---- stage the tile (rows to waves, columns to lanes: coalesced along iy) and its maximum height
+    float m = -__builtin_inff();
+    for (int ix = w; ix < tw; ix += MBES_WAVES) {
+      const float* src = a.grid + (size_t)(tx0 + ix) * a.ny + ty0;
+      for (int iy = lane; iy < th; iy += 64) {
+        const float h = src[iy];
+        tile[ix * th + iy] = h;
+        m = fmaxf(m, h);
+      }
+    }
+    m = wave_max(m);
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    float zmax = red[lane & (MBES_WAVES - 1)];
+#pragma unroll
+    for (int o = MBES_WAVES / 2; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o, 64));
+    zmax = uniform_f32(zmax);
+    if (!valid) continue;
+    // the pose record is wave-uniform (scalar loads)
+    const MbesPose P = a.pose[i];
+    const float u0 = (float)(P.um - (double)tx0), v0 = (float)(P.vm - (double)ty0);
+    float acc = 0.f;
+    int nvalid = 0;
+    for (int b = lane; b < a.n_beams; b += 64) {
+      const float2 sc = a.beam_sc[b];
+      const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
+      const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
+      const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
+      const float e = cast_clear<SURF>(tile, th, a, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max);
+      if (EXPECT_ONLY) {
+        if (i >= a.exp_first && i < a.exp_first + a.exp_count)
+          a.exp_out[(size_t)(i - a.exp_first) * a.n_beams + b] = e;
+      } else {
+        const float rm = a.ranges[b];
+        if (rm > 0.f) {  // NaN fails the test
+          const float d = (rm - e) * a.inv_sigma;
+          acc += d * d;
+          ++nvalid;
+        }
+      }
+    }
     if (!EXPECT_ONLY) {
       const double accd = wave_sum((double)acc);
       const int nv = wave_sum(nvalid);

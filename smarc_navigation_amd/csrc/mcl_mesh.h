@@ -30,6 +30,7 @@ struct MeshDev {
   // structured mesh (a triangulated regular height grid): node heights, diagonal bit in the LSB
   float* heights = nullptr;  // (gx+1)*(gy+1), or nullptr if the mesh is not structured
   size_t n_vertical = 0;  // triangles whose xy projection is degenerate (cannot be a height field)
+  int diag_mode = 0;      // structured: 1 = every cell split along 00-11, 2 = along 10-01, 0 = mixed (LSB per cell)
 };
 
 inline void mesh_free(MeshDev* m) {
@@ -307,14 +308,18 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
         if (seen[c] != 3) ok = false;
     }
     if (ok) {
-      for (size_t ix = 0; ix < nnx; ++ix)
-        for (size_t iy = 0; iy < nny; ++iy) {
-          u32 b;
-          memcpy(&b, &hts[ix * nny + iy], 4);
-          const u32 dbit = (ix < (size_t)m->gx && iy < (size_t)m->gy) ? diag[ix * m->gy + iy] : 0u;
-          b = (b & ~1u) | dbit;  // the cell's diagonal rides in the LSB of its (0,0) corner height
-          memcpy(&hts[ix * nny + iy], &b, 4);
-        }
+      size_t n1 = 0;
+      for (size_t c = 0; c < nc; ++c) n1 += diag[c];
+      m->diag_mode = n1 == 0 ? 1 : (n1 == nc ? 2 : 0);
+      if (m->diag_mode == 0)  // mixed: the cell's diagonal rides in the LSB of its (0,0) corner height (a 1-ulp change)
+        for (size_t ix = 0; ix < nnx; ++ix)
+          for (size_t iy = 0; iy < nny; ++iy) {
+            u32 b;
+            memcpy(&b, &hts[ix * nny + iy], 4);
+            const u32 dbit = (ix < (size_t)m->gx && iy < (size_t)m->gy) ? diag[ix * m->gy + iy] : 0u;
+            b = (b & ~1u) | dbit;
+            memcpy(&hts[ix * nny + iy], &b, 4);
+          }
       if (hipMalloc(&m->heights, sizeof(float) * hts.size()) != hipSuccess ||
           hipMemcpy(m->heights, hts.data(), sizeof(float) * hts.size(), hipMemcpyHostToDevice) != hipSuccess) {
         *err = "set_map_mesh: device allocation failed";

@@ -374,29 +374,6 @@ def test_structured_mesh_with_alternating_diagonals(eng, orc):
     assert np.abs(got2 - got).max() <= 1e-3
 
 
-def test_profile_marching_kernel_matches_oracle(eng, orc, monkeypatch):
-    """MCL_PROFILE=1 selects the experimental profile-marching kernel for structured meshes (the fan
-    plane's exact intersection polyline + in-plane beam queries): same answers."""
-    monkeypatch.setenv('MCL_PROFILE', '1')
-    n = 200
-    z, origin, verts, tris, soa = _mesh_scene(n)
-    soa[3] *= 0.3   # keep the fan planes near vertical so that the groups are eligible
-    soa[4] *= 0.3
-    ba = synth.beam_angles(512)
-    e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
-    e.set_particles(soa)
-    e.set_map_mesh(verts, tris)
-    got = e.mbes_expected(0, n, ba, 80.0)
-    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, orc.Mesh(verts, tris), ba, None, 0.2, 80.0)
-    err = np.abs(got - ref)
-    print('profile marching: max range error %.3e' % err.max())
-    assert err.max() <= 1e-3
-    ranges = (ref[0] + 0.05).astype(np.float32)
-    e.update_mbes(ranges, ba, 0.2, 80.0)
-    lw_ref, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, orc.Mesh(verts, tris), ba, ranges, 0.2, 80.0)
-    d = np.abs(e.get_log_weights() - lw_ref)
-    assert np.all((d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref)))
-
 
 @pytest.mark.parametrize('kind', ['grid', 'mesh', 'mesh_general'])
 @pytest.mark.parametrize('positive', [False, True])
