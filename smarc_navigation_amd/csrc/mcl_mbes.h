@@ -32,6 +32,9 @@
 #ifndef MBES_TILE_FLOATS
 #define MBES_TILE_FLOATS 8192                // 32 KiB tile in LDS
 #endif
+#ifndef MBES_TILE_MARGIN
+#define MBES_TILE_MARGIN 0                   // nodes staged around a group's window (A/B: a margin re-uses tiles more often but raises the tile maximum the rays start from -- measured slower)
+#endif
 
 struct MbesPose {   // 48 B
   double um, vm;    // sensor origin in GLOBAL cell units (fp64: precise before the tile shift)
@@ -1093,30 +1096,53 @@ __global__ void __launch_bounds__(MBES_THREADS, MBES_MIN_WAVES_PER_SIMD) k_mbes_
   const long long ngroups = (a.n + MBES_WAVES - 1) / MBES_WAVES;
   const float inv_res = (float)a.inv_res;
   double wmax = -__builtin_inf();  // lane 0: largest log-likelihood this wave has written
+  // the staged tile: origin, size (cw == 0: none yet) and maximum height.  Consecutive groups of a converged
+  // cloud have (nearly) the same window, so the tile is staged with a margin and re-used for as long as the
+  // next group's window lies inside it -- no staging, no barrier, the waves of the workgroup drift freely.
+  int cx0 = 0, cy0 = 0, cw = 0, ch = 0;
+  float zmax = 0.f;
   for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const MbesGroup G = a.groups[grp];  // uniform address: scalar loads
     if (!G.fast) continue;              // on the general kernel's worklist
-    const int tx0 = G.tx0, ty0 = G.ty0, tw = G.tw, th = G.th;
     const long long i = grp * MBES_WAVES + w;
     const bool valid = i < a.n;
-    __syncthreads();  // the previous group's tile and red[] are fully consumed
-    // ---- stage the tile (rows to waves, columns to lanes: coalesced along iy) and its maximum height
-    float m = -__builtin_inff();
-    for (int ix = w; ix < tw; ix += MBES_WAVES) {
-      const float* src = a.grid + (size_t)(tx0 + ix) * a.ny + ty0;
-      for (int iy = lane; iy < th; iy += 64) {
-        const float h = src[iy];
-        tile[ix * th + iy] = h;
-        m = fmaxf(m, h);
+    const bool inside = G.tx0 >= cx0 && G.ty0 >= cy0 && G.tx0 + G.tw <= cx0 + cw && G.ty0 + G.th <= cy0 + ch;
+    if (!inside) {  // uniform over the workgroup (G, c* are the same in every wave)
+      // window + margin, clipped to the map; without the margin if that does not fit the LDS tile
+      int mg = MBES_TILE_MARGIN;
+      int ex0, ey0, ew, eh;
+      for (;;) {
+        ex0 = max(G.tx0 - mg, 0);
+        ey0 = max(G.ty0 - mg, 0);
+        ew = min(G.tx0 + G.tw + mg, a.nx) - ex0;
+        eh = min(G.ty0 + G.th + mg, a.ny) - ey0;
+        if (mg == 0 || ew * eh <= MBES_TILE_FLOATS) break;
+        mg >>= 1;
       }
-    }
-    m = wave_max(m);
-    if (lane == 0) red[w] = m;
-    __syncthreads();
-    float zmax = red[lane & (MBES_WAVES - 1)];
+      cx0 = ex0;
+      cy0 = ey0;
+      cw = ew;
+      ch = eh;
+      __syncthreads();  // every wave is done with the previous tile
+      // rows to waves, columns to lanes (coalesced along iy); the tile's maximum height on the way
+      float m = -__builtin_inff();
+      for (int ix = w; ix < cw; ix += MBES_WAVES) {
+        const float* src = a.grid + (size_t)(cx0 + ix) * a.ny + cy0;
+        for (int iy = lane; iy < ch; iy += 64) {
+          const float h = src[iy];
+          tile[ix * ch + iy] = h;
+          m = fmaxf(m, h);
+        }
+      }
+      m = wave_max(m);
+      if (lane == 0) red[w] = m;
+      __syncthreads();
+      float mm = red[lane & (MBES_WAVES - 1)];
 #pragma unroll
-    for (int o = MBES_WAVES / 2; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o, 64));
-    zmax = uniform_f32(zmax);
+      for (int o = MBES_WAVES / 2; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+      zmax = uniform_f32(mm);
+    }
+    const int tx0 = cx0, ty0 = cy0, th = ch;
     if (!valid) continue;
     // the pose record is wave-uniform (scalar loads)
     const MbesPose P = a.pose[i];
