@@ -166,10 +166,10 @@ def attach_map(e, m):
         e.set_map_mesh(m['verts'], m['tris'], general=(m['kind'] == 'mesh-general'))
 
 
-def make_ranges(engine_mod, m, truth, beam_angles, sigma, r_max, device=0, seed=4):
+def make_ranges(engine_mod, m, truth, beam_angles, sigma, r_max, device=0, seed=4, m2o=None):
     """Synthetic pings: expected ranges at the truth poses (one-particle engine on the GPU) + noise."""
     import numpy as np
-    e = engine_mod.Engine(1, rng_mode=engine_mod.RNG_REPLAY, device=device)  # this rank's own GPU
+    e = engine_mod.Engine(1, rng_mode=engine_mod.RNG_REPLAY, device=device, m2o=m2o)  # this rank's own GPU
     attach_map(e, m)
     rs = np.random.RandomState(seed)
     out = np.zeros((len(truth), beam_angles.size), np.float32)
@@ -274,7 +274,7 @@ def kernel_table(tim, alg, steps):
     return kernels
 
 
-def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, resample=True, landmarks=None):
+def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, resample=True, landmarks=None, m2o=None):
     """One extra workload leg on a fresh engine: returns ms per step (wall, synchronised around the timed
     block) and the per-phase HIP-event times.  resample=False: predict + MBES update only (the cloud
     keeps its width); landmarks=(xyz, n_det): config 5 -- the landmark k-NN update accumulates onto the
@@ -285,8 +285,8 @@ def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, re
     total = steps + warmup
     stream = synth.odom_stream(total, x0=x0)
     ba = synth.beam_angles(B)
-    ranges = make_ranges(engine, m, stream['truth'], ba, SIGMA, R_MAX, device=device)
-    e = engine.Engine(P, seed=5, device=device, **cov)
+    ranges = make_ranges(engine, m, stream['truth'], ba, SIGMA, R_MAX, device=device, m2o=m2o)
+    e = engine.Engine(P, seed=5, device=device, m2o=m2o, **cov)
     attach_map(e, m)
     dets = None
     if landmarks is not None:
@@ -584,11 +584,16 @@ def worker(a, rank, world, local_rank):
             legs.append(('mesh_general', dict(m=mg, P=1048576, B=512, steps=20, warmup=3)))
         if a.map != 'mesh-tin':
             legs.append(('mesh_tin', dict(m=build_map('mesh-tin'), P=1048576, B=512, steps=20, warmup=3)))
-        # global-localisation regime: sigma = 50 m cloud in the map interior, nothing collapses it
-        legs.append(('cloud_wide', dict(m=mesh, P=1048576, B=512, steps=10, warmup=2, x0=250.0, resample=False,
-                                        cov=dict(COV, init_cov=[2500.0, 2500.0, 0.0, 0.0, 0.0, 0.05]))))
-        legs.append(('cloud_converged_update_only', dict(m=mesh, P=1048576, B=512, steps=10, warmup=2, x0=250.0,
-                                                         resample=False)))
+        # global-localisation regime: sigma = 50 m cloud that nothing collapses (no resample).  Particles are
+        # initialised around the odom origin (auv_particle.py:24), so the map <- odom transform puts that
+        # origin 250 m inside the map; 'cloud_wide_at_border' leaves it 64 m from the western border, where
+        # a tenth of the cloud is off the map and its groups take the general kernel
+        shift = synth.rigid_matrix(250.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+        wide = dict(COV, init_cov=[2500.0, 2500.0, 0.0, 0.0, 0.0, 0.05])
+        legs.append(('cloud_wide', dict(m=mesh, P=1048576, B=512, steps=10, warmup=3, resample=False, cov=wide, m2o=shift)))
+        legs.append(('cloud_wide_at_border', dict(m=mesh, P=1048576, B=512, steps=10, warmup=3, resample=False, cov=wide)))
+        legs.append(('cloud_converged_update_only', dict(m=mesh, P=1048576, B=512, steps=10, warmup=3, resample=False,
+                                                         m2o=shift)))
         legs.append(('config2', dict(m=build_map('grid'), P=65536, B=256, steps=200, warmup=20)))
         legs.append(('config4_shard', dict(m=mesh, P=524288, B=512, steps=30, warmup=5)))
         legs.append(('config5_shard', dict(m=mesh, P=524288, B=512, steps=30, warmup=5,

@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -83,6 +87,13 @@ struct mcl_handle {
   float* exp_dev = nullptr;
   MbesPose* pose_dev = nullptr;
   MbesGroup* mbes_groups = nullptr;  // one record per group of MBES_WAVES particles
+  // visiting order for dispersed clouds: Morton keys, radix sort (rocPRIM), permutation
+  u32 *sort_keys = nullptr, *sort_keys_out = nullptr, *sort_idx = nullptr, *mbes_perm = nullptr;
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  int* work_host = nullptr;     // pinned: [0] groups the natural order deferred in the last update (read one call late)
+  bool sort_visits = false;     // the next update visits the particles in Morton order
+  int env_sort = -1;            // MCL_SORT_VISITS=0/1 forces the decision (tests, A/B)
   int* mbes_worklist = nullptr;  // ngroups + 1 ints; [ngroups] is the counter
   int* lm_worklist = nullptr;    // n + 1 ints; [n] is the counter (landmark assignment: particles with clashes)
   // alternative resamplers (lazily allocated)
@@ -986,6 +997,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.pose = h->pose_dev;
   memset(&a.mesh, 0, sizeof a.mesh);
   a.stats = nullptr;
+  a.perm = nullptr;
   a.diag_mode = 0;
 #ifdef MBES_STATS
   {
@@ -1054,6 +1066,38 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       k_mbes_pose<false><<<grid_for(h->n), 256, 0, h->stream>>>(a);
   }
   if (a.max_slots) h->max_valid = true;
+  a.perm = nullptr;
+  if (lean) {
+    // Dispersed cloud?  The natural-order classification has just counted the groups without a common tile.
+    // That count travels to the host asynchronously and is read one call late (no synchronisation): when the
+    // previous update deferred more than 1/16 of its groups, this one visits the particles in Morton order.
+    if (!h->work_host) {
+      HIPCHK(h, hipHostMalloc(&h->work_host, 64, hipHostMallocDefault));
+      h->work_host[0] = 0;
+    }
+    const bool sort_now = h->env_sort >= 0 ? h->env_sort == 1 : h->sort_visits;
+    h->sort_visits = (long long)h->work_host[0] * 16 > ngroups;
+    HIPCHK(h, hipMemcpyAsync(h->work_host, a.work_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (sort_now && h->n > MBES_WAVES) {
+      const size_t n = (size_t)h->n;
+      if (!h->sort_keys) {
+        HIPCHK(h, hipMalloc(&h->sort_keys, sizeof(u32) * n));
+        HIPCHK(h, hipMalloc(&h->sort_keys_out, sizeof(u32) * n));
+        HIPCHK(h, hipMalloc(&h->sort_idx, sizeof(u32) * n));
+        HIPCHK(h, hipMalloc(&h->mbes_perm, sizeof(u32) * n));
+        HIPCHK(h, rocprim::radix_sort_pairs(nullptr, h->sort_tmp_bytes, h->sort_keys, h->sort_keys_out, h->sort_idx,
+                                            h->mbes_perm, n, 0, 24, h->stream));
+        HIPCHK(h, hipMalloc(&h->sort_tmp, h->sort_tmp_bytes));
+      }
+      k_mbes_keys<<<grid_for(h->n), 256, 0, h->stream>>>(a, h->sort_keys, h->sort_idx);
+      // stable LSD radix sort of (key, slot) pairs: the visiting order is deterministic
+      HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp, h->sort_tmp_bytes, h->sort_keys, h->sort_keys_out, h->sort_idx,
+                                          h->mbes_perm, n, 0, 24, h->stream));
+      a.perm = h->mbes_perm;
+      HIPCHK(h, hipMemsetAsync(a.work_count, 0, sizeof(int), h->stream));
+      k_mbes_classify<<<grid_for(h->n), 256, 0, h->stream>>>(a);
+    }
+  }
   const int ggrid = (int)(ngroups < 512 ? ngroups : 512);
 #define LAUNCH_LEAN(SURFV, MAPV)                                                   \
   do {                                                                             \
@@ -1090,6 +1134,21 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     (void)hipMemcpyAsync(&cnt, a.work_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
     (void)hipStreamSynchronize(h->stream);
     fprintf(stderr, "[mbes] deferred %d of %lld groups\n", cnt, ngroups);
+    if (lean && cnt > 0) {
+      std::vector<MbesGroup> g((size_t)ngroups);
+      (void)hipMemcpy(g.data(), h->mbes_groups, sizeof(MbesGroup) * (size_t)ngroups, hipMemcpyDeviceToHost);
+      long long why[32] = {0}, area = 0, na = 0;
+      for (const MbesGroup& G : g)
+        if (!G.fast) {
+          why[G.why & 31]++;
+          area += (long long)G.tw * G.th;
+          ++na;
+        }
+      fprintf(stderr, "[mbes] why:");
+      for (int k = 0; k < 32; ++k)
+        if (why[k]) fprintf(stderr, " %d:%lld", k, why[k]);
+      fprintf(stderr, "  mean window of deferred groups %lld nodes\n", na ? area / na : 0);
+    }
   }
   t_end(h);
   HIPCHK(h, hipGetLastError());
@@ -1256,6 +1315,7 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
       return v && v[0] == '1';
     };
     h->env_debug_work = getenv("MCL_DEBUG_WORK") != nullptr;
+    if (const char* sv = getenv("MCL_SORT_VISITS")) h->env_sort = sv[0] == '1' ? 1 : 0;
     h->env_force_comm = on("MCL_FORCE_COMM");
     h->env_no_overlap = on("MCL_NO_OVERLAP");
   }
@@ -1330,7 +1390,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1338,6 +1398,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->landmarks) landmarks_free(h->landmarks);
   if (h->det_dev) (void)hipFree(h->det_dev);
   if (h->host_pin) (void)hipHostFree(h->host_pin);
+  if (h->work_host) (void)hipHostFree(h->work_host);
   for (auto& sl : h->pin_ring) {
     if (sl.ev) (void)hipEventDestroy(sl.ev);
     if (sl.p) (void)hipHostFree(sl.p);

@@ -32,6 +32,12 @@
 #ifndef MBES_TILE_FLOATS
 #define MBES_TILE_FLOATS 8192                // 32 KiB tile in LDS
 #endif
+#ifndef MBES_DIR_BINS
+#define MBES_DIR_BINS 16                     // fan-direction bins of the Morton visiting order (<= 16: 4 key bits)
+#endif
+#ifndef MBES_DIR_BINS
+#define MBES_DIR_BINS 16                     // fan-direction bins of the Morton visiting order (<= 16: 4 key bits)
+#endif
 #ifndef MBES_TILE_MARGIN
 #define MBES_TILE_MARGIN 0                   // nodes staged around a group's window (A/B: a margin re-uses tiles more often but raises the tile maximum the rays start from -- measured slower)
 #endif
@@ -48,7 +54,9 @@ struct MbesPose {   // 48 B
 struct MbesGroup {   // 32 B
   int tx0, ty0, tw, th;  // window origin and size: nodes (grid / structured mesh)
   int fast;              // 1: k_mbes_fast casts this group; 0: it is on the worklist of the general kernel
-  int pad[3];
+  int why;               // diagnostics (MCL_DEBUG_WORK): 1 no two-beam footprint, 2 clipped by the map border,
+                         // 4 window larger than the LDS tile, 8 a sensor outside the window, 16 no valid fan
+  int pad[2];
 };
 
 struct MeshArgs {
@@ -85,6 +93,7 @@ struct MbesArgs {
   float* exp_out;         // out (EXPECT_ONLY): expected ranges [(i-exp_first)*B + b]
   long long exp_first, exp_count;
   MeshArgs mesh;
+  const u32* perm;        // visiting order: wave j of the cast kernels works on particle perm[j] (nullptr: j)
   struct MbesGroup* groups;  // one record per group of MBES_WAVES particles (written by the pose kernels)
   int* worklist;          // group ids deferred by the fast kernel (capacity = number of groups)
   int* work_count;        // device counter, zeroed before every fast launch
@@ -210,6 +219,8 @@ __device__ __forceinline__ void classify_group(const MbesArgs& a, const MbesPose
   const unsigned grp_bits = (unsigned)(okm >> (lane & ~(MBES_WAVES - 1))) & ((1u << MBES_WAVES) - 1u);
   const bool fast = (umin <= umax) && !clipped && fits && grp_bits == ((1u << MBES_WAVES) - 1u);
   const bool leader = (lane & (MBES_WAVES - 1)) == 0 && valid;
+  const unsigned long long sm = __ballot(simple), im = __ballot(inside);  // (diagnostics)
+  const unsigned gm = (1u << MBES_WAVES) - 1u;
   if (leader) {
     MbesGroup G;
     G.tx0 = tx0;
@@ -217,7 +228,9 @@ __device__ __forceinline__ void classify_group(const MbesArgs& a, const MbesPose
     G.tw = tw;
     G.th = th;
     G.fast = fast ? 1 : 0;
-    G.pad[0] = G.pad[1] = G.pad[2] = 0;
+    G.why = ((((unsigned)(sm >> (lane & ~(MBES_WAVES - 1))) & gm) != gm) ? 1 : 0) | (clipped ? 2 : 0) | (fits ? 0 : 4) |
+            ((((unsigned)(im >> (lane & ~(MBES_WAVES - 1))) & gm) != gm) ? 8 : 0) | ((umin <= umax) ? 0 : 16);
+    G.pad[0] = G.pad[1] = 0;
     a.groups[i / MBES_WAVES] = G;
   }
   // one atomic per wave: the leaders of its deferred groups take consecutive worklist slots
@@ -288,6 +301,53 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_predict_pose(StatePtrs s, long lo
       m.pose[i] = P;
     }
     if (CLASSIFY) classify_group(m, P, valid, i);
+  }
+}
+
+// ---- spatially coherent visiting order (dispersed clouds: global localisation, before the filter converges)
+// A group of MBES_WAVES particles shares one LDS tile only if their fans are neighbours.  When the natural
+// (slot) order leaves many groups without a common tile, the particles are VISITED in the order of a Morton
+// key of their map cell under a bin of the fan direction; state slots are untouched, so keep/lost/dupes and
+// every RNG draw (keyed by the slot's global id) are unaffected.
+__device__ __forceinline__ u32 morton_spread10(u32 v) {
+  v &= 0x3ffu;
+  v = (v | (v << 8)) & 0x00ff00ffu;
+  v = (v | (v << 4)) & 0x0f0f0f0fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+__global__ void __launch_bounds__(256) k_mbes_keys(MbesArgs a, u32* __restrict__ keys, u32* __restrict__ idx) {
+  // finest block size for which the map fits 1024 x 1024 blocks (1 cell up to 1023 cells a side)
+  int sh = 0;
+  while (((a.nx > a.ny ? a.nx : a.ny) >> sh) > 1023) ++sh;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < a.n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const MbesPose P = a.pose[i];
+    u32 key = 0xffffffu;  // off the map (or NaN): visited last
+    if (P.um >= 0.0 && P.um < (double)a.nx && P.vm >= 0.0 && P.vm < (double)a.ny) {
+      // MBES_DIR_BINS bins of the fan's direction in the map (a line: modulo pi) above the Morton code of the
+      // cell, so that a group's fans are parallel as well as close: their common window stays a narrow strip
+      const float ang = atan2f(P.c1[1], P.c1[0]);  // (-pi, pi]
+      int bin = (int)floorf((ang < 0.f ? ang + 3.14159265f : ang) * ((float)MBES_DIR_BINS / 3.14159265f));
+      bin = bin < 0 ? 0 : (bin > MBES_DIR_BINS - 1 ? MBES_DIR_BINS - 1 : bin);
+      key = ((u32)bin << 20) | morton_spread10((u32)P.um >> sh) | (morton_spread10((u32)P.vm >> sh) << 1);
+    }
+    keys[i] = key;
+    idx[i] = (u32)i;
+  }
+}
+// group records and worklist for the visiting order a.perm (same decision as in the pose kernels)
+__global__ void __launch_bounds__(256) k_mbes_classify(MbesArgs a) {
+  const long long n_pad = (a.n + 63) & ~63ll;
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < n_pad;
+       j += (long long)gridDim.x * blockDim.x) {
+    const bool valid = j < a.n;
+    MbesPose P;
+    P.um = P.vm = 0.0;
+    P.oz = 0.f;
+    if (valid) P = a.pose[a.perm[j]];
+    classify_group(a, P, valid, j);
   }
 }
 
@@ -811,8 +871,9 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
   double wmax = -__builtin_inf();  // lane 0: largest log-likelihood this wave has written
   for (long long it = blockIdx.x; it < nwork; it += gridDim.x) {
     const long long grp = MODE == 1 ? (long long)a.worklist[it] : it;
-    const long long i = grp * MBES_WAVES + w;
-    const bool valid = i < a.n;
+    const long long j = grp * MBES_WAVES + w;  // position in the visiting order
+    const bool valid = j < a.n;
+    const long long i = (valid && a.perm) ? (long long)a.perm[j] : j;  // the particle
     MbesPose P;
     if (valid) {
       // the record is wave-uniform: pin it in SGPRs (frees ~11 VGPRs per lane)
@@ -1104,8 +1165,9 @@ __global__ void __launch_bounds__(MBES_THREADS, MBES_MIN_WAVES_PER_SIMD) k_mbes_
   for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const MbesGroup G = a.groups[grp];  // uniform address: scalar loads
     if (!G.fast) continue;              // on the general kernel's worklist
-    const long long i = grp * MBES_WAVES + w;
-    const bool valid = i < a.n;
+    const long long j = grp * MBES_WAVES + w;  // position in the visiting order
+    const bool valid = j < a.n;
+    const long long i = (valid && a.perm) ? (long long)a.perm[j] : j;  // the particle
     const bool inside = G.tx0 >= cx0 && G.ty0 >= cy0 && G.tx0 + G.tw <= cx0 + cw && G.ty0 + G.th <= cy0 + ch;
     if (!inside) {  // uniform over the workgroup (G, c* are the same in every wave)
       // window + margin, clipped to the map; without the margin if that does not fit the LDS tile

@@ -414,3 +414,46 @@ def test_axis_parallel_nadir_beam_from_a_grid_line(kind, positive, eng, orc):
     print('%s positive=%s: max range error %.3e, nadir-beam error %.3e' % (kind, positive, err.max(), err[:, B // 2].max()))
     assert ref[:, B // 2].max() < 100.0
     assert err.max() <= 1e-3
+
+
+@pytest.mark.parametrize('kind', ['grid', 'mesh'])
+def test_morton_visiting_order_for_dispersed_clouds(kind, eng, orc, monkeypatch):
+    """A sigma = 60 m cloud in slot order has no two neighbours in a group; visited in Morton order of the map
+    cell (MCL_SORT_VISITS=1 forces it, the library switches by itself one update after it sees many deferred
+    groups) the same particles share LDS tiles.  The results must not depend on the visiting order beyond
+    fp32 rounding, and both must match the oracle."""
+    n, B = 20000, 256
+    origin = (-64.0, -256.0)
+    z = synth.bathymetry_grid(512, 512, 1.0, origin, seed=3)
+    rs = np.random.RandomState(21)
+    soa = rs.randn(6, n) * np.array([60.0, 60.0, 0.0, 0.02, 0.02, 3.0])[:, None]
+    soa[0] += 190.0
+    soa[2] = -2.5
+    ba = synth.beam_angles(B)
+    if kind == 'grid':
+        omap = orc.Grid(z, origin, 1.0)
+    else:
+        verts, tris = synth.mesh_from_grid(z, 1.0, origin)
+        omap = orc.Mesh(verts, tris)
+    truth = np.array([[190.0], [0.0], [-2.5], [0.0], [0.0], [0.1]])
+    _, ex = orc.mbes_update(truth, np.identity(4), [0] * 6, omap, ba, None, 0.2, 100.0)
+    ranges = ex[0].astype(np.float32)
+    lw_ref, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, ranges, 0.2, 100.0)
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('MCL_SORT_VISITS', mode)
+        e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+        e.set_particles(soa)
+        if kind == 'grid':
+            e.set_map_grid(z, origin, 1.0)
+        else:
+            e.set_map_mesh(verts, tris)
+        e.update_mbes(ranges, ba, 0.2, 100.0)
+        out[mode] = e.get_log_weights()
+        d = np.abs(out[mode] - lw_ref)
+        bad = ~((d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref)))
+        print('%s sort=%s: max |dlw| %.3e, outside tolerance %d of %d' % (kind, mode, d.max(), bad.sum(), n))
+        assert bad.sum() <= n // 500
+        e.close()
+    dd = np.abs(out['0'] - out['1'])
+    assert np.all((dd <= 2e-2) | (dd <= 4e-4 * np.abs(lw_ref)) | (np.abs(out['0'] - lw_ref) > 1e-2))
