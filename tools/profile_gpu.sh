@@ -12,10 +12,10 @@ for m in mesh grid; do
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_${m}_write -- python3 $R/bench.py --map $m --steps 4 --warmup 1 --only-main > /dev/null 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY --output-format csv -d $O/pmc_${m}_sq -- python3 $R/bench.py --map $m --steps 4 --warmup 1 --only-main > /dev/null 2>&1
 done
-cd $R && python3 tools/pmc_summarise.py $O $O/traffic.json > /dev/null 2>&1
+cd $R && python3 tools/pmc_summarise.py $O $O/traffic.json > $O/summarise.log 2>&1
 # keep only what is small enough to travel back: the stats CSVs, the dominant kernel's counter rows, the summary
 find $O -name "*kernel_stats.csv" | head
 for f in $(find $O -name "*counter_collection.csv"); do grep -E "Correlation_Id|k_mbes_fast" $f > $f.mbes; rm $f; done
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O
-cat $O/traffic.json | head -60
+head -c 1500 $O/traffic.json
