@@ -42,7 +42,8 @@ enum mcl_resample_scheme {
   MCL_RESAMPLE_SYSTEMATIC = 0, /* resampling.py:135-168 -- the GPU production scheme */
   MCL_RESAMPLE_RESIDUAL = 1,   /* resampling.py:27-76   -- what auv_pf.py:182 calls */
   MCL_RESAMPLE_STRATIFIED = 2, /* resampling.py:80-114 */
-  MCL_RESAMPLE_MULTINOMIAL = 3 /* resampling.py:171-194 */
+  MCL_RESAMPLE_MULTINOMIAL = 3,/* resampling.py:171-194 */
+  MCL_RESAMPLE_NAIVE = 4       /* resampling.py:116-131 -- systematic positions, `>` instead of `<`; sharded like it */
 };
 
 enum mcl_rng_mode {

@@ -672,7 +672,8 @@ int residual_prepare(mcl_handle* h) {
 long long uniforms_needed(mcl_handle* h, int* rc) {
   *rc = MCL_OK;
   switch (h->cfg.resample_scheme) {
-    case MCL_RESAMPLE_SYSTEMATIC: return 1;
+    case MCL_RESAMPLE_SYSTEMATIC:
+    case MCL_RESAMPLE_NAIVE: return 1;
     case MCL_RESAMPLE_STRATIFIED:
     case MCL_RESAMPLE_MULTINOMIAL: return h->n;
     case MCL_RESAMPLE_RESIDUAL:
@@ -762,7 +763,7 @@ int run_resample(mcl_handle** sh, int ns, const double* uniforms, long long nu,
   mcl_handle* h0 = sh[0];
   for (int s = 0; s < ns; ++s) {
     if (!sh[s]->have_lw) return fail(sh[s], MCL_ERR_STATE, "resample: no weights (call an update first)");
-    if (sh[s]->cfg.resample_scheme != MCL_RESAMPLE_SYSTEMATIC) {
+    if (sh[s]->cfg.resample_scheme != MCL_RESAMPLE_SYSTEMATIC && sh[s]->cfg.resample_scheme != MCL_RESAMPLE_NAIVE) {
       if (ns > 1 || sh[s]->world > 1)
         return fail(sh[s], MCL_ERR_UNSUPPORTED, "resample: only the systematic scheme is sharded across GPUs");
       return run_resample_alt(sh[s], uniforms, nu, replay_normals ? replay_normals[0] : nullptr);
@@ -776,6 +777,7 @@ int run_resample(mcl_handle** sh, int ns, const double* uniforms, long long nu,
   } else {
     u53 = native_u53(h0->cfg.seed, h0->step_resample);
   }
+  if (h0->cfg.resample_scheme == MCL_RESAMPLE_NAIVE) u53 |= MCL_U53_NAIVE;  // ">=" at the CDF edges (mcl_device.h)
   // one shard (and few enough tiles for every k_cdf_expand block to add their sums up itself):
   // max from the slots -> quantise -> CDF + expansion -> gather, three launches
   const bool single = ns == 1 && h0->world == 1 && !h0->comm && h0->ntiles_loc <= 8192;
@@ -1921,8 +1923,9 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
   h->have_lw = true;
   h->residual_k = -1;
   // resample; the gather pass also accumulates the sums of update_loc_pose of the new state
-  RET_IF(run_resample(&h, 1, nullptr, 0, nullptr, h->cfg.resample_scheme == MCL_RESAMPLE_SYSTEMATIC));
-  if (h->cfg.resample_scheme == MCL_RESAMPLE_SYSTEMATIC)
+  const bool sys = h->cfg.resample_scheme == MCL_RESAMPLE_SYSTEMATIC || h->cfg.resample_scheme == MCL_RESAMPLE_NAIVE;
+  RET_IF(run_resample(&h, 1, nullptr, 0, nullptr, sys));
+  if (sys)
     RET_IF(collect_fused_moments(&h, 1));
   else
     RET_IF(run_mean_cov_async(&h, 1));
@@ -1950,7 +1953,7 @@ int mcl_resample_indices(int32_t scheme, const double* weights, int64_t n, const
   if (rc != MCL_OK) return rc;
   rc = mcl_set_log_weights(h, weights, MCL_WEIGHT_LINEAR);
   if (rc == MCL_OK) {
-    if (scheme != MCL_RESAMPLE_SYSTEMATIC) {
+    if (scheme != MCL_RESAMPLE_SYSTEMATIC && scheme != MCL_RESAMPLE_NAIVE) {
       int64_t need = 0;
       rc = mcl_resample_prepare(h, &need);
       if (rc == MCL_OK) rc = alt_indices(h, uniforms, n_uniforms);
@@ -1961,6 +1964,7 @@ int mcl_resample_indices(int32_t scheme, const double* weights, int64_t n, const
       rc = MCL_ERR_INVALID;
     } else {
       uint64_t u53 = (uint64_t)std::floor(uniforms[0] * 9007199254740992.0);
+      if (scheme == MCL_RESAMPLE_NAIVE) u53 |= MCL_U53_NAIVE;
       rc = phase_quantise(h, true);
       if (rc == MCL_OK) rc = phase_cdf(h, u53);
       if (rc == MCL_OK) {

@@ -221,9 +221,14 @@ __device__ __forceinline__ void muldiv_u64(u64 C, u64 N, u64 T, u64& quo, u64& r
   quo = a;
   rem = r_lo;
 }
-// (r << 53) > U * T   for r < T <= 2^64-1, U < 2^53
+// (r << 53) > U * T   for r < T <= 2^64-1, U < 2^53.  Bit 63 of U selects ">=" instead of ">": that is the
+// only difference between naive_resample (resampling.py:116-131: `while resample_id > cdf[ind]`, i.e. the
+// first j with cdf_j >= pos) and systematic_resample (:161-167: the first j with pos < cs_j).
+#define MCL_U53_NAIVE (1ull << 63)
 __device__ __forceinline__ bool shl53_gt_mul(u64 r, u64 U, u64 T) {
+  const bool or_equal = (U >> 63) != 0ull;
+  U &= ~MCL_U53_NAIVE;
   const u64 l_hi = r >> 11, l_lo = r << 53;
   const u64 m_lo = U * T, m_hi = __umul64hi(U, T);
-  return l_hi > m_hi || (l_hi == m_hi && l_lo > m_lo);
+  return l_hi > m_hi || (l_hi == m_hi && (or_equal ? l_lo >= m_lo : l_lo > m_lo));
 }

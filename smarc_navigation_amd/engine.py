@@ -7,7 +7,7 @@ import numpy as np
 from . import _lib
 from ._lib import Config, Odom, Timing, MclError  # noqa: F401
 
-SYSTEMATIC, RESIDUAL, STRATIFIED, MULTINOMIAL = 0, 1, 2, 3
+SYSTEMATIC, RESIDUAL, STRATIFIED, MULTINOMIAL, NAIVE = 0, 1, 2, 3, 4
 RNG_NATIVE, RNG_REPLAY = 0, 1
 WEIGHT_LINEAR_FLOOR, WEIGHT_LOG_SHIFT, WEIGHT_LINEAR = 0, 1, 2
 

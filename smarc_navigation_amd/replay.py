@@ -3,9 +3,10 @@
 
 Replays a recorded input stream (own .npz format, no rosbag dependency) through the node class
 (smarc_navigation_amd/auv_pf.py: the same callbacks the rospy wrapper registers) and scores the
-result the way the reference's visual_tools.py does at shutdown (finish_hld, visual_tools.py:61-76:
-path length of the GPS / DR / PF tracks and the norm of each track's final position), plus the
-RMSE between the PF mean pose and a reference track (the "pose RMSE vs ref" of the metric).
+result the way the reference's visual_tools.py does: time-synchronised (GPS, DR, PF) samples accumulated per
+callback (odom_cb, visual_tools.py:27-37,80-110), the two error series it plots (:127,:135) and its shutdown
+summary (finish_hld :61-76: path length of the three tracks and the norm of each track's final position),
+plus the RMSE between the PF mean pose and a reference track (the "pose RMSE vs ref" of the metric).
 
 Stream file (np.savez): stamp[n], v[n,3], wz[n], q[n,4], z[n]  (odometry, /sam/dr/odom);
 optional gps_idx[k], gps_xy_utm[k,2]; optional mbes_idx[m], mbes_ranges[m,B], mbes_angles[B],
@@ -29,6 +30,87 @@ def track_metrics(vec):
         dist += np.linalg.norm(vec[:, i] - vec[:, i - 1])
     final = float(np.linalg.norm(vec[:, -1])) if vec.shape[1] else 0.0
     return float(dist), final
+
+
+class ApproximateTimeSync(object):
+    """The time synchroniser visual_tools.py:27-37 relies on: ros_comm's message_filters
+    ApproximateTimeSynchronizer (Python implementation, ROS melodic / noetic 1.14-1.16; a third-party
+    dependency, not part of the reference repository), restated from its published algorithm:
+    every topic keeps the last `queue_size` messages by stamp; when a message arrives, the other topics'
+    stamps within `slop` of it are collected, sorted by distance, and the first combination (itertools
+    product order: nearest candidates first) whose span is < slop and whose messages are all still queued
+    is delivered and removed.  add(topic_index, stamp, msg) returns the delivered tuple or None."""
+
+    def __init__(self, n_topics, queue_size, slop):
+        self.queues = [dict() for _ in range(n_topics)]
+        self.queue_size, self.slop = int(queue_size), float(slop)
+
+    def add(self, index, stamp, msg):
+        import itertools
+        q = self.queues[index]
+        q[stamp] = msg
+        while len(q) > self.queue_size:
+            del q[min(q)]
+        others = self.queues[:index] + self.queues[index + 1:]
+        cands = []
+        for oq in others:
+            ts = sorted(((s, abs(s - stamp)) for s in oq if abs(s - stamp) <= self.slop), key=lambda x: x[1])
+            if not ts:
+                return None
+            cands.append([s for s, _ in ts])
+        for vv in itertools.product(*cands):
+            vv = list(vv)
+            vv.insert(index, stamp)
+            if (max(vv) - min(vv)) < self.slop and all(t in qq for qq, t in zip(self.queues, vv)):
+                out = tuple(qq[t] for qq, t in zip(self.queues, vv))
+                for qq, t in zip(self.queues, vv):
+                    del qq[t]
+                return out
+        return None
+
+
+class DRStats(object):
+    """Mirror of visual_tools.py's DRStatsVisualization (the reference's evaluation node): GPS fix (utm),
+    dead-reckoning odometry and PF odometry, time-synchronised (queue 20, slop 20 s, :27-37), accumulated per
+    sample (odom_cb :80-110: the fix is transformed utm -> odom frame with z = 0; the three 3 x k arrays START
+    with a zero column, :48-50), scored at shutdown (finish_hld :61-76) and as the two error series the node
+    plots (visualize :127,:135).  `utm2odom`: 4x4, or None while the transform is unavailable (the triple
+    is then dropped like the node drops it, :108-109)."""
+
+    def __init__(self, queue_size=20, slop=20.0):
+        self.sync = ApproximateTimeSync(3, queue_size, slop)
+        self.filter_cnt = 1
+        self.gps_odom_vec = np.zeros((3, 1))
+        self.dr_odom_vec = np.zeros((3, 1))
+        self.pf_odom_vec = np.zeros((3, 1))
+        self.utm2odom = None
+
+    def odom_cb(self, gps_xyz_utm, dr_xyz, pf_xyz):
+        if self.utm2odom is None:
+            return False
+        g = np.asarray(self.utm2odom, dtype=np.float64).dot([gps_xyz_utm[0], gps_xyz_utm[1], 0.0, 1.0])[:3]
+        self.gps_odom_vec = np.hstack((self.gps_odom_vec, g.reshape((3, 1))))
+        self.dr_odom_vec = np.hstack((self.dr_odom_vec, np.asarray(dr_xyz, dtype=np.float64).reshape((3, 1))))
+        self.pf_odom_vec = np.hstack((self.pf_odom_vec, np.asarray(pf_xyz, dtype=np.float64).reshape((3, 1))))
+        self.filter_cnt += 1
+        return True
+
+    def add(self, topic, stamp, xyz):
+        """topic: 0 gps (utm), 1 dead reckoning, 2 particle filter; runs odom_cb on every synchronised triple"""
+        hit = self.sync.add(topic, float(stamp), np.asarray(xyz, dtype=np.float64))
+        return self.odom_cb(*hit) if hit is not None else False
+
+    def error_series(self):
+        """|gps - pf| and |gps - dr| per accumulated sample (visual_tools.py:127,:135)"""
+        return (np.linalg.norm(self.gps_odom_vec - self.pf_odom_vec, axis=0),
+                np.linalg.norm(self.gps_odom_vec - self.dr_odom_vec, axis=0))
+
+    def finish_hld(self):
+        """the six numbers the node prints at shutdown (visual_tools.py:61-76)"""
+        out = {}
+        for name, vec in (('GPS', self.gps_odom_vec), ('DR', self.dr_odom_vec), ('PF', self.pf_odom_vec)):
+            out[name + ' distance'], out[name + ' final error'] = track_metrics(vec)
+        return out
 
 
 def pose_rmse(est_xy, ref_xy):
@@ -70,8 +152,17 @@ def replay(stream, params=None, m2o=None, utm2map=None, grid=None, mesh=None, pu
     gps_at = {int(k): j for j, k in enumerate(stream['gps_idx'])} if 'gps_idx' in stream else {}
     mbes_at = {int(k): j for j, k in enumerate(stream['mbes_idx'])} if 'mbes_idx' in stream else {}
     pub_idx, pf_xyz = [], []
+    stats = DRStats() if ('gps_idx' in stream and 'dr_xyz' in stream) else None
+    if stats is not None:
+        # visual_tools transforms the fix into the odom frame: (map <- odom)^-1 (map <- utm)
+        u2m = np.identity(4) if utm2map is None else np.asarray(utm2map, dtype=np.float64)
+        stats.utm2odom = np.linalg.inv(np.identity(4) if m2o is None else np.asarray(m2o, dtype=np.float64)).dot(u2m)
     for k in range(n):
         pf.odom_callback(msgs.odometry_from_stream(stream, k))
+        if stats is not None:
+            stats.add(1, stream['stamp'][k], stream['dr_xyz'][k])
+            if k in gps_at:
+                stats.add(0, stream['stamp'][k], list(stream['gps_xy_utm'][gps_at[k]]) + [0.0])
         if k in gps_at:
             g = msgs.Odometry()
             g.pose.pose.position.x = float(stream['gps_xy_utm'][gps_at[k]][0])
@@ -89,6 +180,8 @@ def replay(stream, params=None, m2o=None, utm2map=None, grid=None, mesh=None, pu
             p = tr.odom_corrected[-1].pose.pose.position
             pub_idx.append(k)
             pf_xyz.append([p.x, p.y, p.z])
+            if stats is not None:
+                stats.add(2, stream['stamp'][k], [p.x, p.y, p.z])
     pf_xyz = np.array(pf_xyz)
     summary = {}
     summary['pf_distance'], summary['pf_final'] = track_metrics(pf_xyz.T)
@@ -98,7 +191,12 @@ def replay(stream, params=None, m2o=None, utm2map=None, grid=None, mesh=None, pu
             tag = name.split('_')[0]
             summary[tag + '_distance'], summary[tag + '_final'] = track_metrics(ref.T)
             summary['pf_rmse_vs_' + tag] = pose_rmse(pf_xyz[:, :2], ref[:, :2])
-    return dict(pf_xyz=pf_xyz, pub_idx=np.array(pub_idx), summary=summary)
+    out = dict(pf_xyz=pf_xyz, pub_idx=np.array(pub_idx), summary=summary)
+    if stats is not None:
+        out['stats'] = stats
+        out['err_gps_pf'], out['err_gps_dr'] = stats.error_series()
+        summary['visual_tools'] = stats.finish_hld()
+    return out
 
 
 def main(argv=None):

@@ -10,6 +10,13 @@ from numpy.random import random
 from . import engine as _engine
 
 
+def naive_resample(weights):
+    """resampling.py:116-131: base positions i/N plus ONE np.random.uniform(0, 1/N) draw (= random()/N),
+    first index whose cumulative weight is >= the position.  Returns a list like the reference."""
+    w = np.asarray(weights, dtype=np.float64)
+    return _engine.resample_indices(w, random(), _engine.NAIVE).tolist()
+
+
 def systematic_resample(weights):
     w = np.asarray(weights, dtype=np.float64)
     return _engine.resample_indices(w, random(), _engine.SYSTEMATIC)

@@ -65,7 +65,7 @@ def test_resampling_mirror_matches_reference_under_seeded_numpy():
         w, seed = g[tag + '_w'], int(g[tag + '_seed'])
         if w.size > 4096:
             continue
-        for fn in ('systematic_resample', 'stratified_resample', 'multinomial_resample', 'residual_resample'):
+        for fn in ('systematic_resample', 'stratified_resample', 'multinomial_resample', 'residual_resample', 'naive_resample'):
             key = tag + '_' + fn
             if key not in g:
                 continue
@@ -73,7 +73,7 @@ def test_resampling_mirror_matches_reference_under_seeded_numpy():
             idx = getattr(resampling, fn)(w.copy())
             assert np.array_equal(idx, g[key]), key
             checked += 1
-    assert checked >= 100
+    assert checked >= 130
 
 
 def test_covariance_string_parser_matches_reference_quirk():

@@ -104,7 +104,7 @@ def test_trajectory_replay_residual_node_as_written(eng):
 
 
 def test_all_resampler_kats_vs_reference(eng):
-    """stratified / multinomial / residual golden vectors (resampling.py) through the GPU."""
+    """stratified / multinomial / residual / naive golden vectors (resampling.py) through the GPU."""
     g = helpers.load('resampling_kat')
     counts = {}
     for tag in g['cases']:
@@ -112,7 +112,7 @@ def test_all_resampler_kats_vs_reference(eng):
         n = w.size
         seed = int(g[tag + '_seed'])
         for name, scheme in (('stratified_resample', eng.STRATIFIED), ('multinomial_resample', eng.MULTINOMIAL),
-                             ('residual_resample', eng.RESIDUAL)):
+                             ('residual_resample', eng.RESIDUAL), ('naive_resample', eng.NAIVE)):
             key = tag + '_' + name
             if key not in g:
                 continue

@@ -144,3 +144,66 @@ def test_survey_map_localise_round_trip():
     mean, _, _ = f.mean_cov()
     assert abs(mean[0] - poses[k, 0]) < 0.25 and abs(mean[1] - poses[k, 1]) < 0.25
     f.close()
+
+
+def test_fuse_swath_follows_pclfuser_and_pcd_round_trip(tmp_path):
+    """Host restatement of mbes_receptor.cpp:64-107: middle ping's pose = submap frame, every ping moved by
+    T_submap<-map * T_map<-base_t, cloud stored with the submap pose as VIEWPOINT.  No GPU."""
+    from smarc_navigation_amd import gridmap, synth
+    rs = np.random.RandomState(3)
+    n = 5
+    poses = np.column_stack([np.linspace(0, 4, n), 0.3 * rs.randn(n), -2 + 0.1 * rs.randn(n), 0.02 * rs.randn(n),
+                             0.03 * rs.randn(n), 0.2 + 0.05 * rs.randn(n)])
+    pts_map = [rs.randn(7, 3) * [1, 10, 0.2] + [p[0], p[1], -20.0] for p in poses]     # truth in the map
+    pts_base = [(pm - synth.rigid_matrix(*p)[:3, 3]).dot(synth.rigid_matrix(*p)[:3, :3]) for pm, p in zip(pts_map, poses)]
+    sm = gridmap.fuse_swath(pts_base, poses, index=3)
+    assert sm['frame_id'] == 'submap_3_frame' and sm['points'].shape == (35, 3)
+    T = sm['T_map_submap']
+    np.testing.assert_allclose(T, synth.rigid_matrix(*poses[2]), atol=1e-12)            # (5 - 1) / 2 = ping 2
+    back = sm['points'].astype(np.float64).dot(T[:3, :3].T) + T[:3, 3]
+    np.testing.assert_allclose(back, np.concatenate(pts_map), atol=2e-5)                 # float32 cloud
+    # quaternion of the stored orientation reproduces the rotation
+    x, y, z, w = sm['quat']
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    np.testing.assert_allclose(R, T[:3, :3], atol=1e-12)
+    path = str(tmp_path / 'submap_3_frame.pdc')
+    gridmap.save_pcd_ascii(path, sm)
+    rd = gridmap.load_pcd_ascii(path)
+    assert rd['n'] == 35
+    np.testing.assert_array_equal(rd['points'], sm['points'])
+    np.testing.assert_allclose(rd['origin'], sm['origin'], rtol=1e-8)
+    np.testing.assert_allclose(rd['quat'], sm['quat'], rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_submap_builder_windows_pings_on_the_gpu(tmp_path):
+    """N-ping windowing with the points produced by the GPU kernel in the submap frame == the host pclFuser
+    restatement on the same pings."""
+    from smarc_navigation_amd import gridmap, synth
+    B, meas = 64, 4
+    ba = synth.beam_angles(B)
+    stream = synth.odom_stream(10 * 50)
+    poses = stream['truth'][49::50][:10]
+    rs = np.random.RandomState(2)
+    ranges = (18.0 / np.cos(ba)[None, :] + 0.05 * rs.randn(10, B)).astype(np.float32)
+    ranges[3, 5] = 0.0
+    sb = gridmap.SubmapBuilder(meas, ba, 80.0)
+    got = [sb.add_ping(p, r) for p, r in zip(poses, ranges)]
+    assert [g is not None for g in got] == [False, False, False, True, False, False, False, True, False, False]
+    assert len(sb.submaps) == 2
+    for k, sm in enumerate(sb.submaps):
+        sl = slice(k * meas, (k + 1) * meas)
+        # the same pings as points in their own base frames (beam b looks along (0, sin a, -cos a))
+        pts_base = []
+        for r in ranges[sl]:
+            ok = r > 0
+            pts_base.append(np.column_stack([np.zeros(B), np.sin(ba) * r, -np.cos(ba) * r])[ok])
+        ref = gridmap.fuse_swath(pts_base, poses[sl], index=k)
+        assert sm['frame_id'] == ref['frame_id'] and sm['points'].shape == ref['points'].shape
+        np.testing.assert_allclose(sm['points'], ref['points'], atol=2e-5)
+        np.testing.assert_allclose(sm['origin'], ref['origin'], atol=1e-12)
+    paths = sb.save(str(tmp_path))
+    assert [p.split('/')[-1] for p in paths] == ['submap_0_frame.pdc', 'submap_1_frame.pdc']
+    assert gridmap.load_pcd_ascii(paths[1])['n'] == sb.submaps[1]['points'].shape[0]

@@ -78,3 +78,48 @@ def test_raw_sensor_replay_without_fixes_follows_dead_reckoning():
     # sample (100 Hz): the tracks agree to discretisation, so compare path length and depth
     assert abs(s['pf_distance'] - s['dr_distance']) < 0.05 * s['dr_distance'] + 0.1
     assert np.allclose(out['pf_xyz'][:, 2], stream['dr_xyz'][out['pub_idx'], 2], atol=1e-9)
+
+
+def test_drstats_mirror_matches_the_reference_node():
+    """DRStats against visual_tools.py itself (golden: oracle/ref_harness/gen_golden_stats.py ran the
+    reference's odom_cb / finish_hld on synchronised triples, three of them without tf)."""
+    from tests import helpers
+    from smarc_navigation_amd import replay
+    g = helpers.load('visual_tools_stats')
+    st = replay.DRStats()
+    dropped = set(int(k) for k in g['dropped'])
+    for k in range(g['dr'].shape[0]):
+        st.utm2odom = None if k in dropped else g['utm2odom']
+        assert st.odom_cb(g['gps_utm'][k], g['dr'][k], g['pf'][k]) == (k not in dropped)
+    assert st.filter_cnt == int(g['filter_cnt'])
+    np.testing.assert_allclose(st.gps_odom_vec, g['gps_odom_vec'], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(st.dr_odom_vec, g['dr_odom_vec'])
+    np.testing.assert_array_equal(st.pf_odom_vec, g['pf_odom_vec'])
+    e_pf, e_dr = st.error_series()
+    np.testing.assert_allclose(e_pf, g['err_pf'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(e_dr, g['err_dr'], rtol=0, atol=1e-9)
+    fin = st.finish_hld()
+    for name, val in zip(g['printed_names'], g['printed_values']):
+        assert abs(fin[str(name)] - float(val)) <= 1e-9 * max(1.0, abs(float(val))), name
+
+
+def test_approximate_time_sync_follows_message_filters():
+    from smarc_navigation_amd.replay import ApproximateTimeSync
+    s = ApproximateTimeSync(3, queue_size=3, slop=0.5)
+    assert s.add(0, 10.0, 'g10') is None
+    assert s.add(1, 10.1, 'd10') is None
+    assert s.add(2, 10.2, 'p10') == ('g10', 'd10', 'p10')     # span 0.2 < slop
+    assert s.add(2, 10.25, 'p10b') is None                       # its partners were consumed
+    assert s.add(0, 11.0, 'g11') is None
+    assert s.add(1, 11.6, 'd11') is None                         # 0.6 from g11: outside the slop of every gps message
+    assert s.add(1, 11.2, 'd11b') is None                        # pf still missing within slop (10.25 is 0.95 away)
+    assert s.add(2, 11.3, 'p11') == ('g11', 'd11b', 'p11')      # nearest partners first: d11b (0.1) before d11 (0.3)
+    # queue_size: the oldest stamps fall out
+    for k in range(5):
+        s.add(0, 20.0 + k, 'g%d' % k)
+    assert sorted(s.queues[0]) == [22.0, 23.0, 24.0]
+    # span test is strict (< slop)
+    t = ApproximateTimeSync(2, 5, 1.0)
+    t.add(0, 1.0, 'a')
+    assert t.add(1, 2.0, 'b') is None
+    assert t.add(1, 1.9, 'c') == ('a', 'c')
