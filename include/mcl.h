@@ -160,6 +160,15 @@ int mcl_mbes_expected(mcl_handle* h, int64_t first, int64_t count, const float* 
  * 1 <= k <= 4; gate = chi-square threshold on |p - l|^2 / sigma^2; accumulate != 0 adds the
  * log-likelihood to the one an earlier update left (e.g. MBES ranges + landmarks of one ping). */
 int mcl_set_landmarks(mcl_handle* h, const double* xyz, int64_t n_landmarks);
+/* Mahalanobis association as in the reference's EKF-SLAM (auv_ekf_slam/src/ekf_slam_core.cpp:160-178,
+ * correspondence_obj_mbes.cpp:26-35,110-120): innovation nu = z - R^T (l - o) in the SENSOR frame,
+ * S = H Sigma H^T + Q, d_m = nu^T S^-1 nu gated against `gate`.  A particle is a pose hypothesis, so of the EKF's
+ * covariance only the landmark's own 3x3 block Sigma_j remains and H is R^T: S = R^T Sigma_j R + Q.
+ * cov6: n_landmarks x 6 (xx xy xz yy yz zz, MAP frame) or NULL = exact map; Q6: measurement covariance in the
+ * sensor frame or NULL = sigma^2 I of the update call.  Both NULL switches back to the isotropic distance.
+ * Affects mcl_update_landmarks (k-NN: each term weighted by 1/sqrt(det S)) and mcl_update_landmarks_assign
+ * (table entries d_m as in the reference). */
+int mcl_set_landmark_noise(mcl_handle* h, const double* cov6, const double Q6[6]);
 int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, double sigma, int32_t k,
                          double gate, const double sensor_offset[6], int32_t accumulate);
 /* Landmark update with a GLOBAL assignment per particle: the correspondence table
@@ -167,7 +176,11 @@ int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, do
  * else 10000; :269-281: one new-landmark hypothesis per detection at cost new_mh_dist; :298-312: Munkres
  * assignment) solved exactly for every particle; lw = -1/2 * optimal total - n_valid * lognorm.  A
  * landmark explains at most one detection.  n_det <= 16; 1 <= k_cand <= 8 = nearest gated landmarks
- * kept as candidates of a detection.  assign_out (optional, host): n_keep x n_det int32 for the first
+ * kept as candidates of a detection: when MORE than k_cand landmarks lie inside a detection's gate the farther
+ * ones are dropped before the assignment, so on maps that dense the optimum can differ from the one over the
+ * full table (part of the definition: the oracle applies the same rule; tests/test_gpu_landmark_assign.py
+ * ::test_dense_cluster...).  With mcl_set_landmark_noise the table entries are the reference's Mahalanobis
+ * distances.  assign_out (optional, host): n_keep x n_det int32 for the first
  * n_keep particles -- landmark index, -1 = new-landmark hypothesis, -2 = invalid (NaN) detection. */
 int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_det, double sigma, int32_t k_cand,
                                 double gate, double new_mh_dist, const double sensor_offset[6], int32_t accumulate,

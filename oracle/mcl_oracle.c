@@ -1197,3 +1197,174 @@ int64_t orc_gridmap_finalize(int nx, int ny, const int64_t* sum, const uint32_t*
   free(b);
   return empty;
 }
+
+/* ---- Mahalanobis association the reference's way (auv_ekf_slam/src/ekf_slam_core.cpp:135-178,
+ * correspondence_obj_mbes.cpp:26-35 measModel, :110-116 computeMHLDistance, :118-120 computeNu), for a pose
+ * hypothesis (particle): the landmark goes into the SENSOR frame, z_hat = R^T (l - o); nu = z - z_hat;
+ * S = H Sigma H^T + Q with H = R^T (the landmark block of the reference's H_t_, :97-107) and Sigma = the landmark's
+ * own 3x3 covariance; d_m = nu^T S^-1 nu.  lmcov: n_lm x 6 (xx xy xz yy yz zz, map frame) or NULL; Q6 or NULL
+ * (sigma^2 I).  Returns d_m, *logdet = log det S. */
+static double maha_sensor_frame(const double Rs[9], const double o[3], const double* l, const double* zd, const double* cov6,
+                                const double Q[6], double* logdet) {
+  double dl[3] = {l[0] - o[0], l[1] - o[1], l[2] - o[2]}, nu[3];
+  for (int r = 0; r < 3; ++r) nu[r] = zd[r] - (Rs[r] * dl[0] + Rs[3 + r] * dl[1] + Rs[6 + r] * dl[2]); /* R^T */
+  double S[9] = {Q[0], Q[1], Q[2], Q[1], Q[3], Q[4], Q[2], Q[4], Q[5]};
+  if (cov6) {
+    const double C[9] = {cov6[0], cov6[1], cov6[2], cov6[1], cov6[3], cov6[4], cov6[2], cov6[4], cov6[5]};
+    double T[9]; /* T = R^T C */
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) T[r * 3 + c] = Rs[r] * C[c] + Rs[3 + r] * C[3 + c] + Rs[6 + r] * C[6 + c];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) S[r * 3 + c] += T[r * 3] * Rs[c] + T[r * 3 + 1] * Rs[3 + c] + T[r * 3 + 2] * Rs[6 + c];
+  }
+  /* solve S x = nu by Gaussian elimination with partial pivoting; det on the way */
+  double A[3][4] = {{S[0], S[1], S[2], nu[0]}, {S[3], S[4], S[5], nu[1]}, {S[6], S[7], S[8], nu[2]}};
+  double det = 1.0;
+  for (int c = 0; c < 3; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 3; ++r)
+      if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+    if (piv != c) {
+      for (int k = 0; k < 4; ++k) {
+        double t = A[c][k];
+        A[c][k] = A[piv][k];
+        A[piv][k] = t;
+      }
+      det = -det;
+    }
+    det *= A[c][c];
+    for (int r = c + 1; r < 3; ++r) {
+      double f = A[r][c] / A[c][c];
+      for (int k = c; k < 4; ++k) A[r][k] -= f * A[c][k];
+    }
+  }
+  double x[3];
+  for (int r = 2; r >= 0; --r) {
+    double t = A[r][3];
+    for (int k = r + 1; k < 3; ++k) t -= A[r][k] * x[k];
+    x[r] = t / A[r][r];
+  }
+  *logdet = log(det);
+  return nu[0] * x[0] + nu[1] * x[1] + nu[2] * x[2];
+}
+static void sensor_pose_of(const double* state, int n, int i, const double m2o[16], const double sensor_off[6], double Rs[9],
+                           double o[3]) {
+  double Ro[9], Rp[9], Rmp[9];
+  rot_rpy(sensor_off[3], sensor_off[4], sensor_off[5], Ro);
+  double Rm[9] = {m2o[0], m2o[1], m2o[2], m2o[4], m2o[5], m2o[6], m2o[8], m2o[9], m2o[10]};
+  rot_rpy(ST(3, i), ST(4, i), ST(5, i), Rp);
+  mat3_mul(Rm, Rp, Rmp);
+  mat3_mul(Rmp, Ro, Rs);
+  double x = ST(0, i), y = ST(1, i), z = ST(2, i);
+  for (int r = 0; r < 3; ++r)
+    o[r] = (m2o[r * 4 + 0] * x + m2o[r * 4 + 1] * y + m2o[r * 4 + 2] * z + m2o[r * 4 + 3]) +
+           (Rmp[r * 3 + 0] * sensor_off[0] + Rmp[r * 3 + 1] * sensor_off[1] + Rmp[r * 3 + 2] * sensor_off[2]);
+}
+static double det_sym6(const double Q[6]) {
+  return Q[0] * (Q[3] * Q[5] - Q[4] * Q[4]) - Q[1] * (Q[1] * Q[5] - Q[4] * Q[2]) + Q[2] * (Q[1] * Q[4] - Q[3] * Q[2]);
+}
+/* k-NN update with Mahalanobis distances: lw_d = log sum_k exp(-d_k/2) / sqrt((2 pi)^3 det S_k) over the k nearest
+ * inside the gate, or -gate/2 - 1/2 log((2 pi)^3 det Q) if none. */
+void orc_landmark_update_maha(int n, const double* state, const double m2o[16], const double sensor_off[6], const double* lm,
+                              const double* lmcov, int64_t n_lm, const double* det, int n_det, double sigma, const double* Q6,
+                              int k, double gate, double* lw) {
+  double Q[6] = {sigma * sigma, 0, 0, sigma * sigma, 0, sigma * sigma};
+  if (Q6) memcpy(Q, Q6, sizeof Q);
+  const double ldq = log(det_sym6(Q));
+  for (int i = 0; i < n; ++i) {
+    double Rs[9], o[3];
+    sensor_pose_of(state, n, i, m2o, sensor_off, Rs, o);
+    double acc = 0.0;
+    for (int d = 0; d < n_det; ++d) {
+      const double* zd = det + 3 * d;
+      if (!(zd[0] == zd[0] && zd[1] == zd[1] && zd[2] == zd[2])) continue;
+      double best[8], bld[8];
+      for (int q = 0; q < k; ++q) best[q] = INFINITY, bld[q] = 0.0;
+      for (int64_t j = 0; j < n_lm; ++j) {
+        double ld, m = maha_sensor_frame(Rs, o, lm + 3 * j, zd, lmcov ? lmcov + 6 * j : NULL, Q, &ld);
+        if (m <= gate)
+          for (int q = 0; q < k; ++q)
+            if (m < best[q]) {
+              double t = best[q], tl = bld[q];
+              best[q] = m;
+              bld[q] = ld;
+              m = t;
+              ld = tl;
+            }
+      }
+      double lwd;
+      if (best[0] == INFINITY) {
+        lwd = -0.5 * gate - 0.5 * ldq;
+      } else {
+        double e0 = -0.5 * (best[0] + bld[0]), s = 0.0;
+        for (int q = 0; q < k; ++q)
+          if (best[q] != INFINITY) s += exp(-0.5 * (best[q] + bld[q]) - e0);
+        lwd = e0 + log(s);
+      }
+      acc += lwd - 1.5 * log(2.0 * PI);
+    }
+    lw[i] = acc;
+  }
+}
+/* global assignment with the reference's table (ekf_slam_core.cpp:172-178: d_m if < gate else 10000; :269-281 one
+ * new-landmark row per detection at new_mh_dist; :298-312 Munkres); table_out (optional): the (n_lm + n_det) x n_det
+ * table of particle 0 in the reference's layout corresp_table(j, i) (landmark rows, detection columns), invalid
+ * detections dropped, so that the reference's own Munkres can be run on it. */
+void orc_landmark_assign_update_maha(int n, const double* state, const double m2o[16], const double sensor_off[6],
+                                     const double* lm, const double* lmcov, int64_t n_lm, const double* det, int n_det,
+                                     double sigma, const double* Q6, int k_cand, double gate, double new_mh_dist, double* lw,
+                                     int* assign_out, double* table_out) {
+  double Q[6] = {sigma * sigma, 0, 0, sigma * sigma, 0, sigma * sigma};
+  if (Q6) memcpy(Q, Q6, sizeof Q);
+  const double lognorm = 1.5 * log(2.0 * PI) + 0.5 * log(det_sym6(Q));
+  const int m = (int)n_lm + n_det;
+  for (int i = 0; i < n; ++i) {
+    double Rs[9], o[3];
+    sensor_pose_of(state, n, i, m2o, sensor_off, Rs, o);
+    double* table = (double*)malloc((size_t)n_det * m * sizeof(double));
+    int* rows = (int*)malloc((size_t)n_det * sizeof(int));
+    int* col = (int*)malloc((size_t)n_det * sizeof(int));
+    double* kth = (double*)malloc((size_t)(k_cand > 0 ? k_cand : 1) * sizeof(double));
+    int nv = 0;
+    for (int d = 0; d < n_det; ++d) {
+      const double* zd = det + 3 * d;
+      if (assign_out) assign_out[(size_t)i * n_det + d] = -2;
+      if (!(zd[0] == zd[0] && zd[1] == zd[1] && zd[2] == zd[2])) continue;
+      double* row = table + (size_t)nv * m;
+      for (int q = 0; q < k_cand; ++q) kth[q] = INFINITY;
+      for (int64_t j = 0; j < n_lm; ++j) {
+        double ld, mh = maha_sensor_frame(Rs, o, lm + 3 * j, zd, lmcov ? lmcov + 6 * j : NULL, Q, &ld);
+        row[j] = mh < gate ? mh : 10000.0;
+        if (mh < gate) {
+          double t = mh;
+          for (int q = 0; q < k_cand; ++q)
+            if (t < kth[q]) {
+              double s2 = kth[q];
+              kth[q] = t;
+              t = s2;
+            }
+        }
+      }
+      const double cut = kth[k_cand - 1]; /* the GPU keeps the k_cand nearest gated landmarks of a detection */
+      for (int64_t j = 0; j < n_lm; ++j)
+        if (row[j] < 10000.0 && row[j] > cut) row[j] = 10000.0;
+      for (int e = 0; e < n_det; ++e) row[n_lm + e] = e == d ? new_mh_dist : 10000.0;
+      rows[nv++] = d;
+    }
+    if (i == 0 && table_out) {
+      /* reference layout: corresp_table(j, c), j over landmarks then the new-landmark rows of the VALID detections */
+      for (int c = 0; c < nv; ++c) {
+        for (int64_t j = 0; j < n_lm; ++j) table_out[(size_t)j * nv + c] = table[(size_t)c * m + j];
+        for (int e = 0; e < nv; ++e) table_out[(size_t)(n_lm + e) * nv + c] = e == c ? new_mh_dist : 10000.0;
+      }
+    }
+    double total = nv ? orc_assign_dense(nv, m, table, col) : 0.0;
+    if (assign_out)
+      for (int r = 0; r < nv; ++r) assign_out[(size_t)i * n_det + rows[r]] = col[r] < n_lm ? col[r] : -1;
+    lw[i] = -0.5 * total - (double)nv * lognorm;
+    free(table);
+    free(rows);
+    free(col);
+    free(kth);
+  }
+}

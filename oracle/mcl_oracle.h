@@ -117,6 +117,14 @@ double orc_assign_dense(int n, int m, const double* cost, int* col_of_row);
 void orc_landmark_assign_update(int n, const double* state, const double m2o[16], const double sensor_off[6],
                                 const double* lm, int64_t n_lm, const double* det, int n_det, double sigma,
                                 int k_cand, double gate, double new_mh_dist, double* lw, int* assign_out);
+/* Mahalanobis association the reference's way (sensor-frame innovation, S = R^T Sigma_j R + Q; ekf_slam_core.cpp:135-178) */
+void orc_landmark_update_maha(int n, const double* state, const double m2o[16], const double sensor_off[6], const double* lm,
+                              const double* lmcov, int64_t n_lm, const double* det, int n_det, double sigma, const double* Q6,
+                              int k, double gate, double* lw);
+void orc_landmark_assign_update_maha(int n, const double* state, const double m2o[16], const double sensor_off[6],
+                                     const double* lm, const double* lmcov, int64_t n_lm, const double* det, int n_det,
+                                     double sigma, const double* Q6, int k_cand, double gate, double new_mh_dist, double* lw,
+                                     int* assign_out, double* table_out);
 /* bathymetry map builder (self-oracle of include/mcl_map.h) */
 void orc_gridmap_add_pings(int nx, int ny, double ox, double oy, double res, int64_t* sum, uint32_t* cnt,
                            int64_t n_pings, const double* poses6, const float* ranges, const float* beam_angles,

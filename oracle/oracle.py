@@ -72,6 +72,8 @@ def _load():
         'orc_landmark_update': (None, [i, _f64p, _f64p, _f64p, _f64p, i64, _f64p, i, d, i, d, _f64p]),
         'orc_assign_dense': (d, [i, i, _f64p, _i32p]),
         'orc_landmark_assign_update': (None, [i, _f64p, _f64p, _f64p, _f64p, i64, _f64p, i, d, i, d, d, _f64p, vp]),
+        'orc_landmark_update_maha': (None, [i, _f64p, _f64p, _f64p, _f64p, vp, i64, _f64p, i, d, vp, i, d, _f64p]),
+        'orc_landmark_assign_update_maha': (None, [i, _f64p, _f64p, _f64p, _f64p, vp, i64, _f64p, i, d, vp, i, d, d, _f64p, vp, vp]),
         'orc_gridmap_add_pings': (None, [i, i, d, d, d, vp, vp, i64, _f64p, _f32p, _f32p, i, d, _f64p, _f64p, vp]),
         'orc_gridmap_finalize': (i64, [i, i, vp, vp, i, _f32p]),
         'orc_mbes_update': (None, [i, _f64p, _f64p, _f64p, i, vp, _f32p, vp, i, d, d, vp, vp]),
@@ -331,6 +333,44 @@ def landmark_update(soa, m2o, sensor_off, landmarks, det, sigma, k=1, gate=11.34
     _L.orc_landmark_update(soa.shape[1], soa, _c(m2o).reshape(-1), _c(sensor_off), lm, lm.shape[0], dt,
                            dt.shape[0], float(sigma), int(k), float(gate), lw)
     return lw
+
+
+def landmark_update_maha(soa, m2o, sensor_off, landmarks, det, sigma, k=1, gate=11.345, lmcov=None, Q6=None):
+    """k-NN update with the reference's Mahalanobis distance (sensor-frame innovation, S = R^T Sigma_j R + Q)"""
+    soa, lm, dt = _c(soa), _c(landmarks), _c(det)
+    cov = None if lmcov is None else _c(lmcov)
+    q = None if Q6 is None else _c(Q6)
+    lw = np.zeros(soa.shape[1])
+    _L.orc_landmark_update_maha(soa.shape[1], soa, _c(m2o).reshape(-1), _c(sensor_off), lm,
+                                cov.ctypes.data if cov is not None else None, lm.shape[0], dt, dt.shape[0], float(sigma),
+                                q.ctypes.data if q is not None else None, int(k), float(gate), lw)
+    return lw
+
+
+def landmark_assign_update_maha(soa, m2o, sensor_off, landmarks, det, sigma, k_cand, gate, new_mh_dist, lmcov=None, Q6=None,
+                                want_assign=False, want_table=False):
+    """global assignment on the reference's Mahalanobis table; want_table: also the (n_lm + D_valid) x D_valid table of
+    particle 0 in the reference's own layout (ekf_slam_core.cpp:248-281), for its own Munkres"""
+    soa = _c(soa)
+    lm = _c(landmarks).reshape(-1, 3)
+    dt = _c(det).reshape(-1, 3)
+    cov = None if lmcov is None else _c(lmcov)
+    q = None if Q6 is None else _c(Q6)
+    lw = np.zeros(soa.shape[1])
+    asg = np.zeros((soa.shape[1], dt.shape[0]), dtype=np.int32) if want_assign else None
+    nv = int(np.sum(~np.isnan(dt).any(axis=1)))
+    tab = np.zeros((lm.shape[0] + nv, nv)) if want_table else None
+    _L.orc_landmark_assign_update_maha(soa.shape[1], soa, _c(m2o).reshape(-1), _c(sensor_off), lm,
+                                       cov.ctypes.data if cov is not None else None, lm.shape[0], dt, dt.shape[0],
+                                       float(sigma), q.ctypes.data if q is not None else None, int(k_cand), float(gate),
+                                       float(new_mh_dist), lw, asg.ctypes.data if asg is not None else None,
+                                       tab.ctypes.data if tab is not None else None)
+    out = [lw]
+    if want_assign:
+        out.append(asg)
+    if want_table:
+        out.append(tab)
+    return out[0] if len(out) == 1 else tuple(out)
 
 
 def assign_dense(cost):

@@ -64,6 +64,7 @@ SYMBOLS = {
     'mcl_update_mbes': (C.c_int, [_vp, _vp, _vp, _i32, _d, _d, _vp]),
     'mcl_mbes_expected': (C.c_int, [_vp, _i64, _i64, _vp, _i32, _d, _vp, _vp]),
     'mcl_set_landmarks': (C.c_int, [_vp, _vp, _i64]),
+    'mcl_set_landmark_noise': (C.c_int, [_vp, _vp, _vp]),
     'mcl_update_landmarks': (C.c_int, [_vp, _vp, _i32, _d, _i32, _d, _vp, _i32]),
     'mcl_update_landmarks_assign': (C.c_int, [_vp, _vp, _i32, _d, _i32, _d, _d, _vp, _i32, _vp, _i64]),
     'mcl_resample': (C.c_int, [_vp, _vp, _i64, _vp]),

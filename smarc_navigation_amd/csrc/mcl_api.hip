@@ -1559,6 +1559,69 @@ int mcl_set_landmarks(mcl_handle* h, const double* xyz, int64_t n_landmarks) {
   return MCL_OK;
 }
 
+namespace {
+// largest eigenvalue bound of a symmetric 3x3 (xx xy xz yy yz zz): Gershgorin
+double sym3_lam_bound(const double* s) {
+  const double r0 = s[0] + std::fabs(s[1]) + std::fabs(s[2]), r1 = s[3] + std::fabs(s[1]) + std::fabs(s[4]),
+               r2 = s[5] + std::fabs(s[2]) + std::fabs(s[4]);
+  return std::max(r0, std::max(r1, r2));
+}
+double sym3_det(const double* s) {
+  return s[0] * (s[3] * s[5] - s[4] * s[4]) - s[1] * (s[1] * s[5] - s[4] * s[2]) + s[2] * (s[1] * s[4] - s[3] * s[2]);
+}
+// measurement covariance of this update: the Q of mcl_set_landmark_noise, else sigma^2 I
+void landmark_q(const LandmarkDev* L, double sigma, double Q[6]) {
+  if (L->have_q) {
+    for (int k = 0; k < 6; ++k) Q[k] = L->Q[k];
+  } else {
+    Q[0] = Q[3] = Q[5] = sigma * sigma;
+    Q[1] = Q[2] = Q[4] = 0.0;
+  }
+}
+// every landmark inside the gate lies within this distance of the detection: d^2 >= |nu|^2 / lambda_max(S)
+double landmark_gate_radius(const LandmarkDev* L, double sigma, double gate) {
+  if (!L->maha) return sigma * std::sqrt(gate);
+  double Q[6];
+  landmark_q(L, sigma, Q);
+  return std::sqrt(gate * (L->lam_cov_max + sym3_lam_bound(Q)));
+}
+void landmark_noise_args(const LandmarkDev* L, double sigma, LandmarkArgs& a) {
+  a.maha = L->maha ? 1 : 0;
+  a.lmcov = L->lmcov;
+  landmark_q(L, sigma, a.Q);
+  a.logdet_q = std::log(sym3_det(a.Q));
+  a.lognorm = 1.5 * std::log(2.0 * MCL_PI) + 0.5 * a.logdet_q;  // isotropic: 3/2 log 2pi + 3 log sigma
+}
+}  // namespace
+
+int mcl_set_landmark_noise(mcl_handle* h, const double* cov6, const double Q6[6]) {
+  if (!h) return MCL_ERR_INVALID;
+  if (!h->landmarks) return fail(h, MCL_ERR_STATE, "set_landmark_noise: no feature map (call mcl_set_landmarks first)");
+  RET_IF(set_device(h));
+  LandmarkDev* L = h->landmarks;
+  const size_t n = L->host_xyz.size() / 3;
+  L->host_cov.clear();
+  L->lam_cov_max = 0.0;
+  if (cov6) {
+    for (size_t i = 0; i < n; ++i) {
+      const double* s = cov6 + 6 * i;
+      if (!(s[0] >= 0.0 && s[3] >= 0.0 && s[5] >= 0.0) || !(sym3_det(s) >= 0.0))
+        return fail(h, MCL_ERR_INVALID, "set_landmark_noise: landmark covariance not positive semi-definite");
+      L->lam_cov_max = std::max(L->lam_cov_max, sym3_lam_bound(s));
+    }
+    L->host_cov.assign(cov6, cov6 + 6 * n);
+  }
+  L->have_q = Q6 != nullptr;
+  if (Q6) {
+    if (!(sym3_det(Q6) > 0.0) || !(Q6[0] > 0.0)) return fail(h, MCL_ERR_INVALID, "set_landmark_noise: Q must be positive definite");
+    for (int k = 0; k < 6; ++k) L->Q[k] = Q6[k];
+  }
+  L->maha = cov6 != nullptr || Q6 != nullptr;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  L->built_for = -1.0;  // the covariances travel with the next grid build
+  return MCL_OK;
+}
+
 int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, double sigma, int32_t k, double gate,
                          const double sensor_offset[6], int32_t accumulate) {
   if (!h || !det_xyz || n_det < 1 || !(sigma > 0.0) || k < 1 || k > LM_MAX_K || !(gate > 0.0))
@@ -1569,7 +1632,7 @@ int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, do
   {
     // the cell grid depends on the gate radius only: rebuild (and drain the stream first -- the old
     // arrays may still be read by a kernel in flight) only when it changes
-    const double radius = sigma * std::sqrt(gate);
+    const double radius = landmark_gate_radius(h->landmarks, sigma, gate);
     if (!(h->landmarks->built_for == radius && h->landmarks->lm)) {
       std::string err;
       HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1606,7 +1669,7 @@ int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, do
   a.inv_cs = 1.0 / h->landmarks->cs;
   a.inv_s2 = 1.0 / (sigma * sigma);
   a.gate = gate;
-  a.lognorm = 1.5 * std::log(2.0 * MCL_PI) + 3.0 * std::log(sigma);
+  landmark_noise_args(h->landmarks, sigma, a);
   a.k = k;
   a.accumulate = accumulate ? 1 : 0;
   a.lw = h->lw;
@@ -1636,7 +1699,7 @@ int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_
   {
     // the cell grid depends on the gate radius only: rebuild (and drain the stream first -- the old
     // arrays may still be read by a kernel in flight) only when it changes
-    const double radius = sigma * std::sqrt(gate);
+    const double radius = landmark_gate_radius(h->landmarks, sigma, gate);
     if (!(h->landmarks->built_for == radius && h->landmarks->lm)) {
       std::string err;
       HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1687,7 +1750,7 @@ int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_
   a.inv_cs = 1.0 / h->landmarks->cs;
   a.inv_s2 = 1.0 / (sigma * sigma);
   a.gate = gate;
-  a.lognorm = 1.5 * std::log(2.0 * MCL_PI) + 3.0 * std::log(sigma);
+  landmark_noise_args(h->landmarks, sigma, a);
   a.k = k_cand;
   a.accumulate = accumulate ? 1 : 0;
   a.lw = h->lw;

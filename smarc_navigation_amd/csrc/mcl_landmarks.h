@@ -36,11 +36,60 @@ struct LandmarkArgs {
   const u32* cell_start;  // gx*gy + 1
   int gx, gy;
   double x0, y0, inv_cs;
-  double inv_s2, gate, lognorm;  // lognorm = 3/2 log(2 pi) + 3 log(sigma)
+  double inv_s2, gate, lognorm;  // lognorm = 3/2 log(2 pi) + 3 log(sigma)  (Mahalanobis mode: + 1/2 log det Q)
+  // Mahalanobis mode (mcl_set_landmark_noise): per-landmark position covariance (cell order, 6 doubles: xx xy xz
+  // yy yz zz, or nullptr = none) and the sensor-frame measurement covariance Q
+  int maha;
+  const double* lmcov;
+  double Q[6];
+  double logdet_q;               // log det Q
   int k;
   int accumulate;         // add to lw instead of overwriting
   double* lw;
 };
+
+// Cost of pairing a detection (already mapped to p = o + R z in the map frame) with landmark slot e, and
+// log det of its innovation covariance.
+//   isotropic:   |p - l|^2 / sigma^2,  S = sigma^2 I
+//   Mahalanobis: the reference's d_m = nu^T S^-1 nu with nu = z - R^T (l - o) in the SENSOR frame and
+//                S = H Sigma H^T + Q (auv_ekf_slam/src/ekf_slam_core.cpp:160-162, correspondence_obj_mbes.cpp:
+//                26-35,110-120).  A particle is a pose hypothesis, so the robot block of the EKF covariance is
+//                gone and H is the landmark block R^T: S = R^T Sigma_j R + Q.  Evaluated in the map frame, where
+//                it is the same number:  (p - l)^T (Sigma_j + R Q R^T)^-1 (p - l).   Qm = R Q R^T per particle.
+__device__ __forceinline__ void landmark_qm(const LandmarkArgs& a, const double Rs[9], double Qm[6]) {
+  // T = R Q (Q symmetric: xx xy xz yy yz zz), Qm = T R^T
+  const double q[9] = {a.Q[0], a.Q[1], a.Q[2], a.Q[1], a.Q[3], a.Q[4], a.Q[2], a.Q[4], a.Q[5]};
+  double T[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) T[r * 3 + c] = Rs[r * 3] * q[c] + Rs[r * 3 + 1] * q[3 + c] + Rs[r * 3 + 2] * q[6 + c];
+  const int ij[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int r = ij[k][0], c = ij[k][1];
+    Qm[k] = T[r * 3] * Rs[c * 3] + T[r * 3 + 1] * Rs[c * 3 + 1] + T[r * 3 + 2] * Rs[c * 3 + 2];
+  }
+}
+__device__ __forceinline__ double landmark_pair_cost(const LandmarkArgs& a, const double Qm[6], double px, double py,
+                                                     double pz, u32 e, double* logdet) {
+  const double dx = px - a.lm[3 * (size_t)e], dy = py - a.lm[3 * (size_t)e + 1], dz = pz - a.lm[3 * (size_t)e + 2];
+  if (!a.maha) {
+    *logdet = 0.0;  // constant: folded into lognorm
+    return (dx * dx + dy * dy + dz * dz) * a.inv_s2;
+  }
+  double s[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) s[k] = Qm[k] + (a.lmcov ? a.lmcov[6 * (size_t)e + k] : 0.0);
+  // symmetric 3x3 inverse by cofactors
+  const double c00 = s[3] * s[5] - s[4] * s[4], c01 = s[2] * s[4] - s[1] * s[5], c02 = s[1] * s[4] - s[2] * s[3];
+  const double det = s[0] * c00 + s[1] * c01 + s[2] * c02;
+  const double c11 = s[0] * s[5] - s[2] * s[2], c12 = s[1] * s[2] - s[0] * s[4], c22 = s[0] * s[3] - s[1] * s[1];
+  const double quad = dx * (c00 * dx + c01 * dy + c02 * dz) + dy * (c01 * dx + c11 * dy + c12 * dz) +
+                      dz * (c02 * dx + c12 * dy + c22 * dz);
+  *logdet = log(det) - a.logdet_q;  // relative to Q's: lognorm carries 1/2 log det Q
+  return quad / det;
+}
 
 __global__ void __launch_bounds__(256) k_landmark_update(LandmarkArgs a) {
   const int sub = threadIdx.x & (LM_SUB - 1);
@@ -70,6 +119,8 @@ __global__ void __launch_bounds__(256) k_landmark_update(LandmarkArgs a) {
     for (int r = 0; r < 3; ++r)
       o[r] = (a.m2o[r * 4 + 0] * x + a.m2o[r * 4 + 1] * y + a.m2o[r * 4 + 2] * z + a.m2o[r * 4 + 3]) +
              (Rmp[r * 3 + 0] * a.off_t[0] + Rmp[r * 3 + 1] * a.off_t[1] + Rmp[r * 3 + 2] * a.off_t[2]);
+    double Qm[6] = {0, 0, 0, 0, 0, 0};
+    if (a.maha) landmark_qm(a, Rs, Qm);
     double acc = 0.0;
     int nvalid = 0;
     for (int d = sub; d < a.n_det; d += LM_SUB) {
@@ -78,24 +129,29 @@ __global__ void __launch_bounds__(256) k_landmark_update(LandmarkArgs a) {
       const double px = o[0] + Rs[0] * zx + Rs[1] * zy + Rs[2] * zz;
       const double py = o[1] + Rs[3] * zx + Rs[4] * zy + Rs[5] * zz;
       const double pz = o[2] + Rs[6] * zx + Rs[7] * zy + Rs[8] * zz;
-      double best[LM_MAX_K];
+      double best[LM_MAX_K], bld[LM_MAX_K];
 #pragma unroll
-      for (int q = 0; q < LM_MAX_K; ++q) best[q] = __builtin_inf();
+      for (int q = 0; q < LM_MAX_K; ++q) {
+        best[q] = __builtin_inf();
+        bld[q] = 0.0;
+      }
       const int cx = (int)floor((px - a.x0) * a.inv_cs), cyi = (int)floor((py - a.y0) * a.inv_cs);
       for (int ix = max(cx - 1, 0); ix <= min(cx + 1, a.gx - 1); ++ix)
         for (int iy = max(cyi - 1, 0); iy <= min(cyi + 1, a.gy - 1); ++iy) {
           const size_t c = (size_t)ix * a.gy + iy;
           for (u32 e = a.cell_start[c]; e < a.cell_start[c + 1]; ++e) {
-            const double dx = px - a.lm[3 * (size_t)e], dy = py - a.lm[3 * (size_t)e + 1], dz = pz - a.lm[3 * (size_t)e + 2];
-            double m = (dx * dx + dy * dy + dz * dz) * a.inv_s2;
+            double ld;
+            double m = landmark_pair_cost(a, Qm, px, py, pz, e, &ld);
             if (m <= a.gate) {
               // insert into the sorted k-best list
 #pragma unroll
               for (int q = 0; q < LM_MAX_K; ++q) {
                 if (m < best[q]) {
-                  const double t = best[q];
+                  const double t = best[q], tl = bld[q];
                   best[q] = m;
+                  bld[q] = ld;
                   m = t;
+                  ld = tl;
                 }
               }
             }
@@ -105,12 +161,13 @@ __global__ void __launch_bounds__(256) k_landmark_update(LandmarkArgs a) {
       if (best[0] == __builtin_inf()) {
         lwd = -0.5 * a.gate;
       } else {
-        // log-sum-exp over the k nearest inside the gate, anchored at the nearest
+        // log sum_k exp(-d_k^2 / 2) / sqrt(det S_k / det Q) over the k nearest inside the gate, anchored at the nearest
+        const double e0 = -0.5 * (best[0] + bld[0]);
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < LM_MAX_K; ++q)
-          if (q < a.k && best[q] != __builtin_inf()) s += exp(-0.5 * (best[q] - best[0]));
-        lwd = -0.5 * best[0] + log(s);
+          if (q < a.k && best[q] != __builtin_inf()) s += exp(-0.5 * (best[q] + bld[q]) - e0);
+        lwd = e0 + log(s);
       }
       acc += lwd;
       ++nvalid;
@@ -243,13 +300,15 @@ __global__ void __launch_bounds__(LA_PER_BLOCK * LM_SUB) k_landmark_assign(Landm
         const double px = o[0] + Rs[0] * zx + Rs[1] * zy + Rs[2] * zz;
         const double py = o[1] + Rs[3] * zx + Rs[4] * zy + Rs[5] * zz;
         const double pz = o[2] + Rs[6] * zx + Rs[7] * zy + Rs[8] * zz;
+        double Qm[6] = {0, 0, 0, 0, 0, 0};
+        if (a.maha) landmark_qm(a, Rs, Qm);
         const int cx = (int)floor((px - a.x0) * a.inv_cs), cyi = (int)floor((py - a.y0) * a.inv_cs);
         for (int ix = max(cx - 1, 0); ix <= min(cx + 1, a.gx - 1); ++ix)
           for (int iy = max(cyi - 1, 0); iy <= min(cyi + 1, a.gy - 1); ++iy) {
             const size_t c = (size_t)ix * a.gy + iy;
             for (u32 e = a.cell_start[c]; e < a.cell_start[c + 1]; ++e) {
-              const double dx = px - a.lm[3 * (size_t)e], dy = py - a.lm[3 * (size_t)e + 1], dz = pz - a.lm[3 * (size_t)e + 2];
-              double m = (dx * dx + dy * dy + dz * dz) * a.inv_s2;
+              double ld_unused;
+              double m = landmark_pair_cost(a, Qm, px, py, pz, e, &ld_unused);
               if (m < a.gate) {  // strict, ekf_slam_core.cpp:173
                 u32 id = e;
 #pragma unroll
@@ -438,6 +497,12 @@ struct LandmarkDev {
   int gx = 0, gy = 0;
   double x0 = 0, y0 = 0, cs = 0;
   double built_for = -1.0;  // gate radius the grid was built for
+  // Mahalanobis mode (mcl_set_landmark_noise)
+  std::vector<double> host_cov;  // n x 6 as given, or empty
+  double* lmcov = nullptr;       // cell order
+  bool maha = false, have_q = false;
+  double Q[6] = {0, 0, 0, 0, 0, 0};
+  double lam_cov_max = 0.0;      // largest eigenvalue over the landmark covariances (bound: Gershgorin)
 };
 
 inline void landmarks_free(LandmarkDev* L) {
@@ -445,6 +510,7 @@ inline void landmarks_free(LandmarkDev* L) {
   if (L->lm) (void)hipFree(L->lm);
   if (L->cell_start) (void)hipFree(L->cell_start);
   if (L->orig) (void)hipFree(L->orig);
+  if (L->lmcov) (void)hipFree(L->lmcov);
   delete L;
 }
 
@@ -503,6 +569,18 @@ inline int landmarks_build(LandmarkDev* L, double r, std::string* err) {
       hipMemcpy(L->cell_start, start.data(), sizeof(u32) * (nc + 1), hipMemcpyHostToDevice) != hipSuccess) {
     *err = "update_landmarks: upload failed";
     return MCL_ERR_HIP;
+  }
+  if (L->lmcov) (void)hipFree(L->lmcov);
+  L->lmcov = nullptr;
+  if (!L->host_cov.empty()) {
+    std::vector<double> sc(6 * std::max<size_t>(n, 1));
+    for (size_t r2 = 0; r2 < n; ++r2)
+      for (int k = 0; k < 6; ++k) sc[6 * r2 + k] = L->host_cov[6 * (size_t)orig[r2] + k];
+    if (hipMalloc(&L->lmcov, sizeof(double) * sc.size()) != hipSuccess ||
+        hipMemcpy(L->lmcov, sc.data(), sizeof(double) * sc.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      *err = "update_landmarks: covariance upload failed";
+      return MCL_ERR_ALLOC;
+    }
   }
   L->built_for = r;
   return MCL_OK;

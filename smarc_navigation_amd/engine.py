@@ -112,6 +112,12 @@ class Engine(object):
         a = _f64(xyz)
         self._ck(self.lib.mcl_set_landmarks(self.h, _ptr(a), a.shape[0]))
 
+    def set_landmark_noise(self, cov6=None, Q6=None):
+        """Mahalanobis association: per-landmark covariance (n x 6: xx xy xz yy yz zz, map frame) and / or the
+        sensor-frame measurement covariance Q (6); both None = isotropic sigma again."""
+        c, q = _f64(cov6), _f64(Q6)
+        self._ck(self.lib.mcl_set_landmark_noise(self.h, _ptr(c), _ptr(q)))
+
     def update_landmarks(self, det_xyz, sigma, k=1, gate=11.345, sensor_offset=None, accumulate=False):
         d, so = _f64(det_xyz), _f64(sensor_offset)
         self._ck(self.lib.mcl_update_landmarks(self.h, _ptr(d), d.shape[0], float(sigma), int(k), float(gate),

@@ -137,3 +137,75 @@ def test_full_filter_step_with_assignment_localises():
     mean, _, _ = e.mean_cov()
     assert abs(mean[0] - truth[0]) < 0.1 and abs(mean[1] - truth[1]) < 0.1
     e.close()
+
+
+def _maha_scene(seed, n=3000, n_lm=400, n_det=10, dense=False):
+    rs = np.random.RandomState(seed)
+    span = 6.0 if dense else 25.0
+    lm = np.column_stack([rs.uniform(-span, span, n_lm), rs.uniform(-span, span, n_lm), -20 + rs.randn(n_lm)])
+    cov = np.zeros((n_lm, 6))
+    for j in range(n_lm):
+        A = rs.randn(3, 3) * np.array([0.4, 0.2, 0.1])
+        S = A.dot(A.T) + 0.01 * np.identity(3)
+        cov[j] = [S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]]
+    Aq = rs.randn(3, 3) * 0.15
+    Q = Aq.dot(Aq.T) + 0.02 * np.identity(3)
+    Q6 = np.array([Q[0, 0], Q[0, 1], Q[0, 2], Q[1, 1], Q[1, 2], Q[2, 2]])
+    soa = rs.randn(6, n) * np.array([1.0, 1.0, 0.1, 0.03, 0.03, 0.2])[:, None]
+    soa[2] -= 2.0
+    m2o = synth.rigid_matrix(0.5, -0.25, 0.0, 0.0, 0.0, 0.1)
+    off = [0.2, 0.0, -0.1, 0.0, 0.02, 0.05]
+    near = np.argsort(np.sum(lm[:, :2] ** 2, axis=1))[:n_det]
+    det = (lm[near] - [0.5, -0.25, -2.0]) + 0.3 * rs.randn(n_det, 3)
+    det[1] = np.nan
+    return soa, m2o, off, lm, cov, Q6, det
+
+
+@pytest.mark.parametrize('with_cov,with_q', [(True, True), (False, True), (True, False)])
+def test_mahalanobis_knn_and_assignment_match_oracle(with_cov, with_q):
+    """mcl_set_landmark_noise: per-landmark covariance and sensor-frame Q.  The kernels evaluate the distance
+    in the map frame with cofactors, the oracle the reference's way in the sensor frame with Gaussian
+    elimination: the same numbers to 1e-9."""
+    from smarc_navigation_amd import engine as eng
+    from oracle import oracle as orc
+    soa, m2o, off, lm, cov, Q6, det = _maha_scene(5)
+    e = eng.Engine(soa.shape[1], m2o=m2o, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_landmarks(lm)
+    e.set_landmark_noise(cov if with_cov else None, Q6 if with_q else None)
+    kw = dict(lmcov=cov if with_cov else None, Q6=Q6 if with_q else None)
+    for k in (1, 3):
+        e.update_landmarks(det, 0.3, k=k, gate=11.345, sensor_offset=off)
+        ref = orc.landmark_update_maha(soa, m2o, off, lm, det, 0.3, k, 11.345, **kw)
+        np.testing.assert_allclose(e.get_log_weights(), ref, rtol=1e-9, atol=1e-9)
+    asg = e.update_landmarks_assign(det, 0.3, k_cand=8, gate=11.345, new_mh_dist=9.0, sensor_offset=off, n_keep=200)
+    ref, ref_asg = orc.landmark_assign_update_maha(soa, m2o, off, lm, det, 0.3, 8, 11.345, 9.0, want_assign=True, **kw)
+    np.testing.assert_allclose(e.get_log_weights(), ref, rtol=1e-9, atol=1e-9)
+    same = np.mean(asg == ref_asg[:200])
+    assert same > 0.98  # ties between equal-cost optima may be broken differently
+    # back to the isotropic distance
+    e.set_landmark_noise(None, None)
+    e.update_landmarks(det, 0.3, k=2, gate=11.345, sensor_offset=off)
+    np.testing.assert_allclose(e.get_log_weights(), orc.landmark_update(soa, m2o, off, lm, det, 0.3, 2, 11.345), rtol=1e-9, atol=1e-9)
+
+
+def test_dense_cluster_more_gated_landmarks_than_candidates():
+    """with more than k_cand landmarks inside the gate of a detection the sparse graph keeps only the
+    k_cand nearest; that truncation is part of the definition (mcl.h) and the oracle applies the same rule, so
+    the GPU must still reproduce it exactly on a map dense enough that every detection has > 8 gated landmarks."""
+    from smarc_navigation_amd import engine as eng
+    from oracle import oracle as orc
+    soa, m2o, off, lm, cov, Q6, det = _maha_scene(7, n=1500, n_lm=600, dense=True)
+    e = eng.Engine(soa.shape[1], m2o=m2o, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_landmarks(lm)
+    e.set_landmark_noise(cov, Q6)
+    # how many landmarks are gated per detection (particle 0): the premise of the test
+    _, _, tab = orc.landmark_assign_update_maha(soa[:, :1].copy(), m2o, off, lm, det, 0.3, 600, 11.345, 9.0, lmcov=cov, Q6=Q6,
+                                                want_assign=True, want_table=True)
+    gated = (tab[:600] < 10000.0).sum(axis=0)
+    print('gated landmarks per detection:', gated)
+    assert gated.max() > 8
+    e.update_landmarks_assign(det, 0.3, k_cand=8, gate=11.345, new_mh_dist=9.0, sensor_offset=off)
+    ref = orc.landmark_assign_update_maha(soa, m2o, off, lm, det, 0.3, 8, 11.345, 9.0, lmcov=cov, Q6=Q6)
+    np.testing.assert_allclose(e.get_log_weights(), ref, rtol=1e-9, atol=1e-9)
