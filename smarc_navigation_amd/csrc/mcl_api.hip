@@ -999,6 +999,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.pose = h->pose_dev;
   memset(&a.mesh, 0, sizeof a.mesh);
   a.stats = nullptr;
+  a.cells = 0;
   a.perm = nullptr;
   a.diag_mode = 0;
 #ifdef MBES_STATS
@@ -1038,6 +1039,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.zmin_map = m->zmin;
     a.zmax_map = m->zmax;
     a.diag_mode = m->diag_mode;
+    a.cells = (m->heights && !h->force_general_mesh) ? 0 : 1;
   }
   const long long ngroups = (h->n + MBES_WAVES - 1) / MBES_WAVES;
   const int grid = (int)(ngroups < 4096 ? ngroups : 4096);
@@ -1050,7 +1052,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.max_slots = (with_ranges && lw_out == h->lw) ? ctrl_slots(h) : nullptr;
   // height grids and structured meshes: the pose kernel classifies the groups, k_mbes_fast casts the
   // eligible ones, k_mbes_cast<.,.,1> the worklist; triangle-record meshes keep the two-mode kernel
-  const bool lean = h->map_kind == 0 || (h->mesh->heights && !h->force_general_mesh);
+  const bool lean = true;  // every map kind: the pose kernel classifies the groups
+  const bool structured = h->map_kind == 1 && h->mesh->heights && !h->force_general_mesh;
   if (args_only) {
     *args_only = a;
     return MCL_OK;
@@ -1113,7 +1116,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   } while (0)
   if (h->map_kind == 0) {
     LAUNCH_LEAN(0, 0);
-  } else if (lean) {
+  } else if (structured) {
     if (a.diag_mode == 1)
       LAUNCH_LEAN(2, 2);
     else if (a.diag_mode == 2)
@@ -1121,14 +1124,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     else
       LAUNCH_LEAN(1, 2);
   } else {
-    // fast traversal over every group, then the general traversal over the few groups it deferred
-    if (with_ranges) {
-      k_mbes_cast<1, false, 0><<<grid, MBES_THREADS, 0, h->stream>>>(a);
-      k_mbes_cast<1, false, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);
-    } else {
-      k_mbes_cast<1, true, 0><<<grid, MBES_THREADS, 0, h->stream>>>(a);
-      k_mbes_cast<1, true, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);
-    }
+    LAUNCH_LEAN(4, 1);  // triangle records: cell-word tiles
   }
 #undef LAUNCH_LEAN
   if (h->env_debug_work) {  // diagnostics: how many groups the fast kernel deferred
@@ -1196,7 +1192,7 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
   if (pose_for && !rp && h->cfg.rng_mode == MCL_RNG_NATIVE) {
     // reset the slots + work counter first: the kernel appends the deferred groups to the worklist
     HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_WORK + sizeof(int), h->stream));
-    const bool lean = h->map_kind == 0 || (h->mesh->heights && !h->force_general_mesh);
+    const bool lean = true;
     if (lean)
       k_predict_pose<true><<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, *pose_for);
     else

@@ -85,6 +85,7 @@ struct MbesArgs {
   double ox, oy, inv_res;
   float res;
   float zmin_map, zmax_map;
+  int cells;              // 1: the LDS tile holds per-CELL words (triangle-record meshes), windows are cell ranges
   int diag_mode;          // structured mesh: 1 = every cell split along 00-11, 2 = along 10-01, 0 = per-cell bit
   float inv_sigma, r_max;
   double lognorm;         // log(sigma sqrt(2 pi))
@@ -206,15 +207,19 @@ __device__ __forceinline__ void classify_group(const MbesArgs& a, const MbesPose
     vmin = fminf(vmin, __shfl_xor(vmin, o, 64));
     vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
   }
-  const int lim_x = a.nx - 1, lim_y = a.ny - 1;
+  // node windows (grid, structured mesh): nx x ny nodes, + 2 so that the far corner of the last cell is inside;
+  // cell windows (triangle records): (nx - 1) x (ny - 1) cells, 8-byte words, 6144 of them in the 48 KiB tile
+  const int cz = a.cells ? 1 : 0;
+  const int lim_x = a.nx - 1 - cz, lim_y = a.ny - 1 - cz;
   const int wx0 = (int)floorf(umin) - 1, wy0 = (int)floorf(vmin) - 1;
-  const int wx1 = (int)floorf(umax) + 2, wy1 = (int)floorf(vmax) + 2;
+  const int wx1 = (int)floorf(umax) + 2 - cz, wy1 = (int)floorf(vmax) + 2 - cz;
   const bool clipped = wx0 < 0 || wy0 < 0 || wx1 > lim_x || wy1 > lim_y;
   const int tx0 = max(wx0, 0), ty0 = max(wy0, 0);
   const int tw = min(wx1, lim_x) - tx0 + 1, th = min(wy1, lim_y) - ty0 + 1;
-  const bool fits = tw >= 2 && th >= 2 && (long long)tw * th <= MBES_TILE_FLOATS;
+  const bool fits = tw >= 2 - cz && th >= 2 - cz && (long long)tw * th <= (cz ? (MBES_TILE_FLOATS * 3) / 4 : MBES_TILE_FLOATS);
   const float ul = (float)(P.um - (double)tx0), vl = (float)(P.vm - (double)ty0);
-  const bool inside = !valid || (ul >= 1.f && vl >= 1.f && ul < (float)(tw - 2) && vl < (float)(th - 2));
+  const int ncx = tw - 1 + cz, ncy = th - 1 + cz;  // cells in the window
+  const bool inside = !valid || (ul >= 1.f && vl >= 1.f && ul < (float)(ncx - 1) && vl < (float)(ncy - 1));
   const unsigned long long okm = __ballot(inside && simple);
   const unsigned grp_bits = (unsigned)(okm >> (lane & ~(MBES_WAVES - 1))) & ((1u << MBES_WAVES) - 1u);
   const bool fast = (umin <= umax) && !clipped && fits && grp_bits == ((1u << MBES_WAVES) - 1u);
@@ -1148,9 +1153,14 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
 // through scalar loads; what is left per group is the staging of the tile and its maximum height.
 // SURF: the surface cast_clear follows -- 0 bilinear grid, 1 triangulated with a per-cell diagonal bit,
 // 2 / 3 triangulated with every cell split along 00-11 / 10-01.
+// SURF 4: arbitrary triangle soups -- the tile holds the 8-byte cell words (conservative z-range, record range)
+// of mcl_mesh.h, the traversal is cast_fast<1> (cell march on the z-ranges + plane-form triangle records from L2).
 template <int SURF, bool EXPECT_ONLY>
-__global__ void __launch_bounds__(MBES_THREADS, MBES_MIN_WAVES_PER_SIMD) k_mbes_fast(MbesArgs a) {
-  __shared__ __attribute__((aligned(16))) float tile[MBES_TILE_FLOATS];
+__global__ void __launch_bounds__(MBES_THREADS, SURF == 4 ? MBES_MIN_WAVES_MESH : MBES_MIN_WAVES_PER_SIMD) k_mbes_fast(MbesArgs a) {
+  constexpr bool CELLS = SURF == 4;
+  constexpr int TILE_WORDS = CELLS ? (MBES_TILE_FLOATS * 3) / 2 : MBES_TILE_FLOATS;  // 48 KiB of cell words / 32 KiB of heights
+  constexpr int TILE_CAP = CELLS ? TILE_WORDS / 2 : TILE_WORDS;
+  __shared__ __attribute__((aligned(16))) float tile[TILE_WORDS];
   __shared__ float red[MBES_WAVES];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1176,9 +1186,9 @@ __global__ void __launch_bounds__(MBES_THREADS, MBES_MIN_WAVES_PER_SIMD) k_mbes_
       for (;;) {
         ex0 = max(G.tx0 - mg, 0);
         ey0 = max(G.ty0 - mg, 0);
-        ew = min(G.tx0 + G.tw + mg, a.nx) - ex0;
-        eh = min(G.ty0 + G.th + mg, a.ny) - ey0;
-        if (mg == 0 || ew * eh <= MBES_TILE_FLOATS) break;
+        ew = min(G.tx0 + G.tw + mg, a.nx - (CELLS ? 1 : 0)) - ex0;
+        eh = min(G.ty0 + G.th + mg, a.ny - (CELLS ? 1 : 0)) - ey0;
+        if (mg == 0 || ew * eh <= TILE_CAP) break;
         mg >>= 1;
       }
       cx0 = ex0;
@@ -1188,12 +1198,26 @@ __global__ void __launch_bounds__(MBES_THREADS, MBES_MIN_WAVES_PER_SIMD) k_mbes_
       __syncthreads();  // every wave is done with the previous tile
       // rows to waves, columns to lanes (coalesced along iy); the tile's maximum height on the way
       float m = -__builtin_inff();
-      for (int ix = w; ix < cw; ix += MBES_WAVES) {
-        const float* src = a.grid + (size_t)(cx0 + ix) * a.ny + cy0;
-        for (int iy = lane; iy < ch; iy += 64) {
-          const float h = src[iy];
-          tile[ix * ch + iy] = h;
-          m = fmaxf(m, h);
+      if (!CELLS) {
+        for (int ix = w; ix < cw; ix += MBES_WAVES) {
+          const float* src = a.grid + (size_t)(cx0 + ix) * a.ny + cy0;
+          for (int iy = lane; iy < ch; iy += 64) {
+            const float h = src[iy];
+            tile[ix * ch + iy] = h;
+            m = fmaxf(m, h);
+          }
+        }
+      } else {
+        uint2* t2 = (uint2*)tile;
+        for (int ix = w; ix < cw; ix += MBES_WAVES) {
+          const uint2* src = a.mesh.cell_info + (size_t)(cx0 + ix) * a.mesh.gy + cy0;
+          for (int iy = lane; iy < ch; iy += 64) {
+            const uint2 ci = src[iy];
+            t2[ix * ch + iy] = ci;
+            float czlo, czhi;
+            cell_zrange(ci.x, czlo, czhi);
+            m = fmaxf(m, czhi);
+          }
         }
       }
       m = wave_max(m);
@@ -1216,7 +1240,13 @@ __global__ void __launch_bounds__(MBES_THREADS, MBES_MIN_WAVES_PER_SIMD) k_mbes_
       const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
       const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
       const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
-      const float e = cast_clear<SURF>(tile, th, a, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max);
+      float e;
+      if (CELLS) {
+        RayStats rs = {0, 0, 0, 0};
+        e = cast_fast<1>(tile, th, cw, a, tx0, ty0, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max, rs);
+      } else {
+        e = cast_clear<(CELLS ? 0 : SURF)>(tile, th, a, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max);
+      }
       if (EXPECT_ONLY) {
         if (i >= a.exp_first && i < a.exp_first + a.exp_count)
           a.exp_out[(size_t)(i - a.exp_first) * a.n_beams + b] = e;

@@ -144,12 +144,42 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
     a1 = std::min(std::max(a1, a0), m->gx - 1);
     b1 = std::min(std::max(b1, b0), m->gy - 1);
   };
+  // exact binning: a triangle is recorded in a cell only if its xy projection really overlaps the cell
+  // (separating-axis test: the cell's axes are covered by cell_range, the triangle's three edge normals here).
+  // On an irregular TIN the bbox of a triangle touches up to 3 x 3 cells but the triangle itself only 2-3:
+  // ~10 -> ~4 records per cell.
+  auto overlaps = [&](int64_t k, int a, int b) {
+    const double e = 1e-7 * cs;
+    const double bx0 = m->x0 + a * cs + e, bx1 = m->x0 + (a + 1) * cs - e, by0 = m->y0 + b * cs + e, by1 = m->y0 + (b + 1) * cs - e;
+    double px[3], py[3];
+    for (int c = 0; c < 3; ++c) {
+      px[c] = verts[3 * (size_t)tris[3 * k + c]];
+      py[c] = verts[3 * (size_t)tris[3 * k + c] + 1];
+    }
+    for (int c = 0; c < 3; ++c) {
+      const int d = (c + 1) % 3, o = (c + 2) % 3;
+      const double nx = -(py[d] - py[c]), ny = px[d] - px[c];  // normal of edge c -> d
+      double side = nx * (px[o] - px[c]) + ny * (py[o] - py[c]);  // the third vertex is on this side
+      if (side == 0.0) continue;                                   // degenerate projection: bbox binning decides
+      const double sgn = side > 0.0 ? 1.0 : -1.0;
+      // the box corner farthest towards the triangle's side
+      const double cxm = (nx * sgn > 0.0) ? bx1 : bx0, cym = (ny * sgn > 0.0) ? by1 : by0;
+      if (sgn * (nx * (cxm - px[c]) + ny * (cym - py[c])) < 0.0) return false;  // the whole box is outside this edge
+    }
+    return true;
+  };
   std::vector<u32> start(nc + 1, 0u);
   for (int64_t k = 0; k < nt; ++k) {
     int a0, a1, b0, b1;
     cell_range(k, a0, a1, b0, b1);
+    bool any = false;
     for (int a = a0; a <= a1; ++a)
-      for (int b = b0; b <= b1; ++b) start[(size_t)a * m->gy + b + 1]++;
+      for (int b = b0; b <= b1; ++b)
+        if (overlaps(k, a, b)) {
+          start[(size_t)a * m->gy + b + 1]++;
+          any = true;
+        }
+    if (!any) start[(size_t)a0 * m->gy + b0 + 1]++;  // (a sliver thinner than the tolerance: keep it somewhere)
   }
   for (size_t c = 0; c < nc; ++c) {
     if ((uint64_t)start[c + 1] + start[c] > 0xffffffffull) {
@@ -192,8 +222,12 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
     const double nlen = std::sqrt(nx * nx + ny * ny + nz * nz);
     const bool vertical = std::fabs(nz) <= 1e-4 * nlen;
     if (vertical && (tz1 - tz0) > 1e-6) m->n_vertical++;
+    bool any_cell = false;
+    for (int a = a0; a <= a1; ++a)
+      for (int b = b0; b <= b1; ++b) any_cell = any_cell || overlaps(k, a, b);
     for (int a = a0; a <= a1; ++a)
       for (int b = b0; b <= b1; ++b) {
+        if (any_cell ? !overlaps(k, a, b) : !(a == a0 && b == b0)) continue;
         const size_t c = (size_t)a * m->gy + b;
         const size_t r = 3 * ((size_t)start[c] + fill[c]++);
         const double cx = m->x0 + a * cs, cy = m->y0 + b * cs;
