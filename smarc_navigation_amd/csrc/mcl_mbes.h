@@ -725,13 +725,16 @@ __device__ __forceinline__ float cast_clear(const float* __restrict__ tile, int 
   }
   const bool px = du > 0.f, py = dv > 0.f;
   const float cu = fabsf(du), cv = fabsf(dv);                        // cells per metre along each axis
-  const float iu = fabsf(fast_rcp(du)), iv = fabsf(fast_rcp(dv));    // metres per cell (+inf: axis-parallel)
+  // metres per cell; an axis-parallel ray gets a huge FINITE value: 0 * 1e30 = 0, so nothing below can turn into
+  // a NaN (0 * inf marched the other axis forever) and a vertical ray simply "leaves" its cell at
+  // t ~ 1e30, where the linear interpolation of the clearance still returns g_in / |dz|
+  const float iu = fminf(fabsf(fast_rcp(du)), 1e30f), iv = fminf(fabsf(fast_rcp(dv)), 1e30f);
   const float fu = floorf(fmaf(t_lo, du, u0)), fv = floorf(fmaf(t_lo, dv, v0));
   // forward-frame coordinates of the ray at parameter t inside the current cell: a' = A0 + t cu, b' = B0 + t cv
   float A0 = px ? u0 - fu : (fu + 1.f) - u0;
   float B0 = py ? v0 - fv : (fv + 1.f) - v0;
-  // parameter at which the ray reaches a' = 1 / b' = 1 (0 * inf = NaN -> "never": see cast_fast)
-  float tnx = fminf((1.f - A0) * iu, INF), tny = fminf((1.f - B0) * iv, INF);
+  // parameter at which the ray reaches a' = 1 / b' = 1
+  float tnx = (1.f - A0) * iu, tny = (1.f - B0) * iv;
   // LDS BYTE offsets: F00 = entry corner, F10 / F01 one node on along x / y, F11 the exit corner
   const char* base = (const char*)tile;
   const int oxb = (px ? th : -th) * 4, oyb = py ? 4 : -4, oxyb = oxb + oyb;
@@ -742,28 +745,40 @@ __device__ __forceinline__ float cast_clear(const float* __restrict__ tile, int 
   bool fd = SURF == 2 ? flip : !flip;       // true: the cell is split along F10-F01 (SURF 1: re-read per cell)
   const int kcb = (px ? 0 : -th * 4) + (py ? 0 : -4);  // SURF 1: the canonical (0,0) corner relative to F00
   if (SURF == 1) fd = ((__float_as_uint(TILE_AT(a00 + kcb)) & 1u) != 0u) != flip;
-  float t_in = t_lo, g_in;
+  // The march starts on the border by which the ray ENTERED the start cell (the later of its two previous
+  // crossings): the clearance there is an edge lerp like every other one.  Only when that point lies behind
+  // the sensor (the sensor is inside the start cell) the surface is evaluated under the start point itself.
+  float t_in, g_in;
   {
-    // clearance at the start point (inside the start cell)
-    const float F00 = TILE_AT(a00), F01 = TILE_AT(a00 + oyb), F10 = TILE_AT(a00 + oxb), F11 = TILE_AT(a00 + oxyb);
-    const float as = fmaf(t_lo, cu, A0), bs = fmaf(t_lo, cv, B0);
-    float h;
-    if (SURF == 0) {
-      const float h0 = fmaf(as, F10 - F00, F00), h1 = fmaf(as, F11 - F01, F01);
-      h = fmaf(bs, h1 - h0, h0);
+    const float tpx = tnx - iu, tpy = tny - iv;
+    const bool via_x = tpx >= tpy;
+    const float t_s = via_x ? tpx : tpy;
+    if (t_s >= 0.f) {
+      // entered through a' = 0 (via_x: nodes F00 .. F01, coordinate b') or b' = 0 (nodes F00 .. F10, coordinate a')
+      const float F00 = TILE_AT(a00), Fn = TILE_AT(a00 + (via_x ? oyb : oxb));
+      const float f = fmaf(t_s, via_x ? cv : cu, via_x ? B0 : A0);
+      t_in = t_s;
+      g_in = fmaf(t_s, dz, oz) - fmaf(f, Fn - F00, F00);
     } else {
-      // fd false: triangles (F00,F10,F11) below the diagonal b' = a', (F00,F01,F11) above it
-      // fd true : triangles (F00,F10,F01) where a' + b' <= 1, (F10,F11,F01) beyond
-      const bool lower = (fd & (as + bs <= 1.f)) | (!fd & (bs <= as));
-      const float sa = lower ? F10 - F00 : F11 - F01;
-      const float sb = (lower == fd) ? F01 - F00 : F11 - F10;
-      const float hc = (fd & !lower) ? (F10 + F01) - F11 : F00;
-      h = fmaf(bs, sb, fmaf(as, sa, hc));
+      const float F00 = TILE_AT(a00), F01 = TILE_AT(a00 + oyb), F10 = TILE_AT(a00 + oxb), F11 = TILE_AT(a00 + oxyb);
+      const float as = fmaf(t_lo, cu, A0), bs = fmaf(t_lo, cv, B0);
+      float h;
+      if (SURF == 0) {
+        const float h0 = fmaf(as, F10 - F00, F00), h1 = fmaf(as, F11 - F01, F01);
+        h = fmaf(bs, h1 - h0, h0);
+      } else {
+        // fd false: triangles (F00,F10,F11) below the diagonal b' = a', (F00,F01,F11) above it
+        // fd true : triangles (F00,F10,F01) where a' + b' <= 1, (F10,F11,F01) beyond
+        const bool lower = (fd & (as + bs <= 1.f)) | (!fd & (bs <= as));
+        const float sa = lower ? F10 - F00 : F11 - F01;
+        const float sb = (lower == fd) ? F01 - F00 : F11 - F10;
+        const float hc = (fd & !lower) ? (F10 + F01) - F11 : F00;
+        h = fmaf(bs, sb, fmaf(as, sa, hc));
+      }
+      t_in = t_lo;
+      g_in = fmaf(t_lo, dz, oz) - h;
+      if (SURF == 0 && !(t_lo > 0.f) && g_in <= 0.f) return 0.f;  // the sensor itself is at or below the seabed
     }
-    g_in = fmaf(t_lo, dz, oz) - h;
-    if (SURF == 0 && !(t_lo > 0.f) && g_in <= 0.f) return 0.f;  // the sensor itself is at or below the seabed
-    // a vertical ray never leaves its cell: the surface under it is the height just evaluated
-    if (!(tnx < INF) & !(tny < INF)) return (dz < 0.f && g_in > 0.f) ? fminf(t_lo - g_in * rdz, r_max) : r_max;
   }
   // per-ray constants of the diagonal crossing  t_d = (ck - A0 + sB B0) * inv_sel:
   //   fd: a' + b' = 1 -> (1 - A0 - B0) / (cu + cv)      !fd: a' = b' -> (B0 - A0) / (cu - cv)
