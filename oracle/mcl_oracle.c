@@ -552,15 +552,74 @@ void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t
   out[3] = c3;
 }
 
+/* Deterministic log / sincos of the NATIVE Box-Muller draws: the same fma sequences as mcl_device.h
+ * (det_log, det_sincos2pi), so CPU and GPU normals agree bit for bit. */
+double orc_det_log(double x) {
+  uint64_t bits;
+  memcpy(&bits, &x, 8);
+  int64_t e = (int64_t)(bits >> 52) - 1023;
+  uint64_t mb = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+  double m;
+  memcpy(&m, &mb, 8);
+  if (m > 1.41421356237309514547) {
+    m *= 0.5;
+    e += 1;
+  }
+  const double s = (m - 1.0) / (m + 1.0);
+  const double s2 = s * s;
+  double p = 1.0 / 23.0;
+  p = fma(p, s2, 1.0 / 21.0);
+  p = fma(p, s2, 1.0 / 19.0);
+  p = fma(p, s2, 1.0 / 17.0);
+  p = fma(p, s2, 1.0 / 15.0);
+  p = fma(p, s2, 1.0 / 13.0);
+  p = fma(p, s2, 1.0 / 11.0);
+  p = fma(p, s2, 1.0 / 9.0);
+  p = fma(p, s2, 1.0 / 7.0);
+  p = fma(p, s2, 1.0 / 5.0);
+  p = fma(p, s2, 1.0 / 3.0);
+  p = fma(p, s2, 1.0);
+  const double lm = 2.0 * s * p;
+  const double ed = (double)e;
+  return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
+}
+void orc_det_sincos2pi(double u, double* sn, double* cs) {
+  const double k = rint(u * 4.0);
+  const double r = fma(-k, 0.25, u);
+  const double th = r * 6.28318530717958647693;
+  const double t2 = th * th;
+  double ps = -1.0 / 355687428096000.0;
+  ps = fma(ps, t2, 1.0 / 1307674368000.0);
+  ps = fma(ps, t2, -1.0 / 6227020800.0);
+  ps = fma(ps, t2, 1.0 / 39916800.0);
+  ps = fma(ps, t2, -1.0 / 362880.0);
+  ps = fma(ps, t2, 1.0 / 5040.0);
+  ps = fma(ps, t2, -1.0 / 120.0);
+  ps = fma(ps, t2, 1.0 / 6.0);
+  const double s0 = fma(-(th * t2), ps, th);
+  double pc = 1.0 / 6402373705728000.0;
+  pc = fma(pc, t2, -1.0 / 20922789888000.0);
+  pc = fma(pc, t2, 1.0 / 87178291200.0);
+  pc = fma(pc, t2, -1.0 / 479001600.0);
+  pc = fma(pc, t2, 1.0 / 3628800.0);
+  pc = fma(pc, t2, -1.0 / 40320.0);
+  pc = fma(pc, t2, 1.0 / 720.0);
+  pc = fma(pc, t2, -1.0 / 24.0);
+  pc = fma(pc, t2, 0.5);
+  const double c0 = fma(-t2, pc, 1.0);
+  const int q = (int)k & 3;
+  *sn = q == 0 ? s0 : (q == 1 ? c0 : (q == 2 ? -s0 : -c0));
+  *cs = q == 0 ? c0 : (q == 1 ? -s0 : (q == 2 ? -c0 : s0));
+}
 static void box_muller(uint32_t a, uint32_t b, double* n0, double* n1) {
   double u1 = ((double)a + 0.5) * (1.0 / 4294967296.0);
   double u2 = ((double)b + 0.5) * (1.0 / 4294967296.0);
-  double r = sqrt(-2.0 * log(u1));
-  double t = 2.0 * PI * u2;
-  *n0 = r * cos(t);
-  *n1 = r * sin(t);
+  double r = sqrt(-2.0 * orc_det_log(u1));
+  double sn, cs;
+  orc_det_sincos2pi(u2, &sn, &cs);
+  *n0 = r * cs;
+  *n1 = r * sn;
 }
-
 void orc_native_normals(int n, int64_t gid0, uint64_t seed, uint32_t purpose, uint32_t step, double* normals) {
   #pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {

@@ -117,6 +117,9 @@ double orc_assign_dense(int n, int m, const double* cost, int* col_of_row);
 void orc_landmark_assign_update(int n, const double* state, const double m2o[16], const double sensor_off[6],
                                 const double* lm, int64_t n_lm, const double* det, int n_det, double sigma,
                                 int k_cand, double gate, double new_mh_dist, double* lw, int* assign_out);
+/* deterministic log / sin-cos(2 pi u) of the NATIVE Box-Muller draws (== mcl_device.h det_log / det_sincos2pi) */
+double orc_det_log(double x);
+void orc_det_sincos2pi(double u, double* sn, double* cs);
 /* Mahalanobis association the reference's way (sensor-frame innovation, S = R^T Sigma_j R + Q; ekf_slam_core.cpp:135-178) */
 void orc_landmark_update_maha(int n, const double* state, const double m2o[16], const double sensor_off[6], const double* lm,
                               const double* lmcov, int64_t n_lm, const double* det, int n_det, double sigma, const double* Q6,

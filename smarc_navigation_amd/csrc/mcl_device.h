@@ -181,12 +181,73 @@ __device__ __forceinline__ u32x4 philox4x32(u32 c0, u32 c1, u32 c2, u32 c3, u32 
   }
   return u32x4{c0, c1, c2, c3};
 }
+// Deterministic log and sin/cos for the Box-Muller draws: fixed sequences of fma / mul / div / rint / bit ops,
+// written identically in oracle/mcl_oracle.c (orc_det_log, orc_det_sincos2pi), so the NATIVE normals agree
+// bit for bit between CPU and GPU -- and cost a fraction of ocml's log / sincos (whose large-argument paths
+// and special cases these draws never need).  Accuracy: < 3e-16 relative (log), < 2e-16 absolute (sin, cos).
+__device__ __forceinline__ double det_log(double x) {  // x a positive normal number
+#pragma clang fp contract(off)
+  const u64 bits = (u64)__double_as_longlong(x);
+  long long e = (long long)(bits >> 52) - 1023;
+  double m = __longlong_as_double((long long)((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull));  // [1, 2)
+  if (m > 1.41421356237309514547) {
+    m *= 0.5;
+    e += 1;
+  }
+  const double s = (m - 1.0) / (m + 1.0);  // |s| <= 0.1716
+  const double s2 = s * s;
+  double p = 1.0 / 23.0;                   // atanh series: log m = 2 s (1 + s2/3 + s2^2/5 + ...)
+  p = __builtin_fma(p, s2, 1.0 / 21.0);
+  p = __builtin_fma(p, s2, 1.0 / 19.0);
+  p = __builtin_fma(p, s2, 1.0 / 17.0);
+  p = __builtin_fma(p, s2, 1.0 / 15.0);
+  p = __builtin_fma(p, s2, 1.0 / 13.0);
+  p = __builtin_fma(p, s2, 1.0 / 11.0);
+  p = __builtin_fma(p, s2, 1.0 / 9.0);
+  p = __builtin_fma(p, s2, 1.0 / 7.0);
+  p = __builtin_fma(p, s2, 1.0 / 5.0);
+  p = __builtin_fma(p, s2, 1.0 / 3.0);
+  p = __builtin_fma(p, s2, 1.0);
+  const double lm = 2.0 * s * p;
+  const double ed = (double)e;
+  return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lm));
+}
+// sin and cos of 2 pi u for u in [0, 1]
+__device__ __forceinline__ void det_sincos2pi(double u, double& sn, double& cs) {
+#pragma clang fp contract(off)
+  const double k = __builtin_rint(u * 4.0);          // quarter turns, 0 .. 4
+  const double r = __builtin_fma(-k, 0.25, u);       // exact: |r| <= 1/8
+  const double th = r * 6.28318530717958647693;      // |th| <= pi/4
+  const double t2 = th * th;
+  double ps = -1.0 / 355687428096000.0;              // sin: th (1 - t2/3! + ... - t2^8/17!)
+  ps = __builtin_fma(ps, t2, 1.0 / 1307674368000.0);
+  ps = __builtin_fma(ps, t2, -1.0 / 6227020800.0);
+  ps = __builtin_fma(ps, t2, 1.0 / 39916800.0);
+  ps = __builtin_fma(ps, t2, -1.0 / 362880.0);
+  ps = __builtin_fma(ps, t2, 1.0 / 5040.0);
+  ps = __builtin_fma(ps, t2, -1.0 / 120.0);
+  ps = __builtin_fma(ps, t2, 1.0 / 6.0);
+  const double s0 = __builtin_fma(-(th * t2), ps, th);
+  double pc = 1.0 / 6402373705728000.0;              // cos: 1 - t2/2! + ... + t2^9/18!
+  pc = __builtin_fma(pc, t2, -1.0 / 20922789888000.0);
+  pc = __builtin_fma(pc, t2, 1.0 / 87178291200.0);
+  pc = __builtin_fma(pc, t2, -1.0 / 479001600.0);
+  pc = __builtin_fma(pc, t2, 1.0 / 3628800.0);
+  pc = __builtin_fma(pc, t2, -1.0 / 40320.0);
+  pc = __builtin_fma(pc, t2, 1.0 / 720.0);
+  pc = __builtin_fma(pc, t2, -1.0 / 24.0);
+  pc = __builtin_fma(pc, t2, 0.5);
+  const double c0 = __builtin_fma(-t2, pc, 1.0);
+  const int q = (int)k & 3;
+  sn = q == 0 ? s0 : (q == 1 ? c0 : (q == 2 ? -s0 : -c0));
+  cs = q == 0 ? c0 : (q == 1 ? -s0 : (q == 2 ? -c0 : s0));
+}
 __device__ __forceinline__ void box_muller(u32 a, u32 b, double& n0, double& n1) {
   double u1 = ((double)a + 0.5) * (1.0 / 4294967296.0);
   double u2 = ((double)b + 0.5) * (1.0 / 4294967296.0);
-  double r = sqrt(-2.0 * log(u1));
+  double r = sqrt(-2.0 * det_log(u1));   // IEEE sqrt: correctly rounded on both sides
   double s, c;
-  sincos(2.0 * MCL_PI * u2, &s, &c);
+  det_sincos2pi(u2, s, c);
   n0 = r * c;
   n1 = r * s;
 }
