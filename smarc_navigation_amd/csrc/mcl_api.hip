@@ -20,6 +20,7 @@
 #include "../../include/mcl.h"
 #include "mcl_kernels.h"
 #include "mcl_mbes.h"
+#include "mcl_sweep.h"
 #include "mcl_mesh.h"
 #include "mcl_resample.h"
 #include "mcl_resample_alt.h"
@@ -30,6 +31,7 @@
 // control block layout (bytes)
 #define CTRL_SLOTS 0                       // MCL_MAX_SLOTS u64
 #define CTRL_WORK (8 * MCL_MAX_SLOTS)      // int: groups deferred by the fast MBES kernel
+#define CTRL_DEFER (CTRL_WORK + 4)         // int: particles the fan sweep handed to the general kernel
 #define CTRL_T_QUANT (CTRL_WORK + 8)       // u32 tickets, self-resetting
 #define CTRL_T_EXPAND (CTRL_WORK + 12)
 #define CTRL_T_GATHER (CTRL_WORK + 16)
@@ -109,6 +111,18 @@ struct mcl_handle {
   std::vector<float> beam_cache;  // last uploaded angles
   int beam_lo = -1, beam_hi = -1;  // extreme-angle beams (footprint shortcut)
   bool beams_sorted = false;
+  // fan sweep (mcl_sweep.h)
+  std::vector<float> ranges_host;   // last uploaded ranges (the sweep's beam table is built from them)
+  bool sweep_angles_ok = false;     // ascending, finite, |a| <= 85 degrees
+  int b_split = 0;
+  float4* sweep_beams = nullptr;
+  float* sweep_tail = nullptr;
+  int sweep_cap = 0;
+  u32* defer_idx = nullptr;
+  int env_sweep = -1;               // MCL_SWEEP=0/1 forces the decision (tests, A/B)
+  bool sweep_now = false;           // decided by the first launch_mbes call of an update
+  bool sweep_bad = false;           // the last sweep handed over more than 1/16 of the particles
+  int sweep_nvalid = 0;
   float* grid = nullptr;
   int gnx = 0, gny = 0;
   double gox = 0, goy = 0, gres = 1;
@@ -951,8 +965,55 @@ int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, i
     bool asc = finite;
     for (int b = 1; b < B && asc; ++b) asc = beam_angles[b] >= beam_angles[b - 1];
     h->beams_sorted = asc;
+    // the fan sweep walks outward from the nadir on either side: ascending angles, all within 85 degrees of it
+    h->sweep_angles_ok = asc && B <= 2048 && beam_angles[0] >= -1.4835f && beam_angles[B - 1] <= 1.4835f;
+    h->b_split = 0;
+    while (h->b_split < B && beam_angles[h->b_split] < 0.f) ++h->b_split;
   }
-  if (ranges) RET_IF(upload(h, h->ranges_dev, ranges, sizeof(float) * (size_t)B));
+  if (ranges) {
+    RET_IF(upload(h, h->ranges_dev, ranges, sizeof(float) * (size_t)B));
+    h->ranges_host.assign(ranges, ranges + B);
+  } else {
+    h->ranges_host.clear();
+  }
+  return MCL_OK;
+}
+
+// beam table of the fan sweep: side-signed tangent, secant, measured range, weight; and per beam the sum of the
+// squared normalised residuals against r_max over the beams from it to the end of its side (mcl_sweep.h)
+int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max) {
+  if (B > h->sweep_cap) {
+    if (h->sweep_beams) (void)hipFree(h->sweep_beams);
+    if (h->sweep_tail) (void)hipFree(h->sweep_tail);
+    HIPCHK(h, hipMalloc(&h->sweep_beams, sizeof(float4) * (size_t)B));
+    HIPCHK(h, hipMalloc(&h->sweep_tail, sizeof(float) * (size_t)B));
+    h->sweep_cap = B;
+  }
+  std::vector<float4> tb((size_t)B);
+  std::vector<float> tail((size_t)B, 0.f);
+  const float inv_sigma = (float)(1.0 / sigma), rmaxf = (float)r_max;
+  int nvalid = 0;
+  for (int b = 0; b < B; ++b) {
+    const double ang = (double)h->beam_cache[b];
+    const float rm = (with_ranges && (int)h->ranges_host.size() == B) ? h->ranges_host[b] : 0.f;
+    const bool valid = rm > 0.f;  // NaN fails the test (as in the cast kernels)
+    nvalid += valid ? 1 : 0;
+    tb[b].x = (float)(std::tan(ang) * (b < h->b_split ? -1.0 : 1.0));
+    tb[b].y = (float)(1.0 / std::cos(ang));
+    tb[b].z = valid ? rm : 0.f;
+    tb[b].w = valid ? inv_sigma : 0.f;
+  }
+  auto miss = [&](int b) {
+    const float d = (tb[b].z - rmaxf) * tb[b].w;
+    return d * d;
+  };
+  float run = 0.f;
+  for (int b = B - 1; b >= h->b_split; --b) tail[b] = (run += miss(b));
+  run = 0.f;
+  for (int b = 0; b < h->b_split; ++b) tail[b] = (run += miss(b));
+  h->sweep_nvalid = nvalid;
+  RET_IF(upload(h, h->sweep_beams, tb.data(), sizeof(float4) * (size_t)B));
+  RET_IF(upload(h, h->sweep_tail, tail.data(), sizeof(float) * (size_t)B));
   return MCL_OK;
 }
 
@@ -968,6 +1029,25 @@ void rot_rpy(double roll, double pitch, double yaw, double R[9]) {
   R[6] = -sp;
   R[7] = cp * sr;
   R[8] = cp * cr;
+}
+
+// Morton visiting order of the particles' pose records (k_mbes_keys): h->mbes_perm
+int sort_visiting_order(mcl_handle* h, const MbesArgs& a) {
+  const size_t n = (size_t)h->n;
+  if (!h->sort_keys) {
+    HIPCHK(h, hipMalloc(&h->sort_keys, sizeof(u32) * n));
+    HIPCHK(h, hipMalloc(&h->sort_keys_out, sizeof(u32) * n));
+    HIPCHK(h, hipMalloc(&h->sort_idx, sizeof(u32) * n));
+    HIPCHK(h, hipMalloc(&h->mbes_perm, sizeof(u32) * n));
+    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, h->sort_tmp_bytes, h->sort_keys, h->sort_keys_out, h->sort_idx,
+                                        h->mbes_perm, n, 0, 24, h->stream));
+    HIPCHK(h, hipMalloc(&h->sort_tmp, h->sort_tmp_bytes));
+  }
+  k_mbes_keys<<<grid_for(h->n), 256, 0, h->stream>>>(a, h->sort_keys, h->sort_idx);
+  // stable LSD radix sort of (key, slot) pairs: the visiting order is deterministic
+  HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp, h->sort_tmp_bytes, h->sort_keys, h->sort_keys_out, h->sort_idx,
+                                      h->mbes_perm, n, 0, 24, h->stream));
+  return MCL_OK;
 }
 
 int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max, const double sensor_offset[6],
@@ -1002,6 +1082,14 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.cells = 0;
   a.perm = nullptr;
   a.diag_mode = 0;
+  a.sweep_beams = nullptr;
+  a.sweep_tail = nullptr;
+  a.b_split = 0;
+  a.sweep_nvalid = 0;
+  a.sweep_c2z_min = 2.f;
+  a.defer_idx = nullptr;
+  a.defer_count = (int*)(h->ctrl + CTRL_DEFER);
+  a.n_dev = nullptr;
 #ifdef MBES_STATS
   {
     static unsigned long long* g_stats = nullptr;
@@ -1054,6 +1142,25 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   // eligible ones, k_mbes_cast<.,.,1> the worklist; triangle-record meshes keep the two-mode kernel
   const bool lean = true;  // every map kind: the pose kernel classifies the groups
   const bool structured = h->map_kind == 1 && h->mesh->heights && !h->force_general_mesh;
+  // ---- fan sweep (mcl_sweep.h): regularly triangulated meshes, ascending beam angles.  The fan plane may lean
+  // from the vertical only as far as the steepest triangle allows (tan(tilt) * slope < 1, with a margin).
+  if (!pose_done) {
+    bool sweep = structured && (a.diag_mode == 1 || a.diag_mode == 2) && h->sweep_angles_ok && h->env_sweep != 0 &&
+                 h->n < (1ll << 31);
+    h->sweep_now = sweep;
+    if (sweep) RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max));
+  }
+  const bool sweep = h->sweep_now;
+  if (sweep) {
+    if (!h->defer_idx) HIPCHK(h, hipMalloc(&h->defer_idx, sizeof(u32) * (size_t)h->n));
+    a.sweep_beams = h->sweep_beams;
+    a.sweep_tail = h->sweep_tail;
+    a.b_split = h->b_split;
+    a.sweep_nvalid = h->sweep_nvalid;
+    const double tan_lim = std::min(std::tan(35.0 * MCL_PI / 180.0), 0.8 / std::max(h->mesh->slope_max, 1e-9));
+    a.sweep_c2z_min = (float)(1.0 / std::sqrt(1.0 + tan_lim * tan_lim));
+    a.defer_idx = h->defer_idx;
+  }
   if (args_only) {
     *args_only = a;
     return MCL_OK;
@@ -1062,16 +1169,71 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   if (!pose_done) {
     // (the fused predict has already reset the control block and written poses, group records and worklist)
     if (a.max_slots)
-      HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_WORK + sizeof(int), h->stream));  // slots + work counter
+      HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_DEFER + sizeof(int), h->stream));  // slots + work and hand-over counters
     else
-      HIPCHK(h, hipMemsetAsync(a.work_count, 0, sizeof(int), h->stream));
-    if (lean)
+      HIPCHK(h, hipMemsetAsync(a.work_count, 0, 2 * sizeof(int), h->stream));
+    if (lean && !sweep)
       k_mbes_pose<true><<<grid_for(h->n), 256, 0, h->stream>>>(a);
     else
       k_mbes_pose<false><<<grid_for(h->n), 256, 0, h->stream>>>(a);
   }
   if (a.max_slots) h->max_valid = true;
   a.perm = nullptr;
+  if (sweep) {
+    if (!h->work_host) {
+      HIPCHK(h, hipHostMalloc(&h->work_host, 64, hipHostMallocDefault));
+      h->work_host[0] = 0;
+      h->work_host[1] = 0;
+    }
+    // The hand-over count of the previous sweep, read one call late (no synchronisation).  When it was large (a
+    // cloud on the map border, a fan too tilted for the terrain) the particles are visited in Morton order: the
+    // hand-over list inherits it wave by wave, so the groups of eight the cast kernels form from it share tiles.
+    const bool sort_now = h->env_sort >= 0 ? h->env_sort == 1 : h->sweep_bad;
+    h->sweep_bad = (long long)h->work_host[1] * 16 > h->n;
+    if (sort_now && h->n > MBES_WAVES) {
+      RET_IF(sort_visiting_order(h, a));
+      a.perm = h->mbes_perm;
+    }
+    const int sgrid = (int)((2 * h->n + SWEEP_THREADS - 1) / SWEEP_THREADS);
+    const size_t lds = (size_t)B * (sizeof(float4) + sizeof(float));
+    // what the sweep hands over is cast the old way, in the order of the hand-over list: group records and
+    // worklist (k_mbes_classify), the fast kernel, the general kernel -- all three read the count on the device
+    MbesArgs d = a;
+    d.perm = h->defer_idx;
+    d.n_dev = a.defer_count;
+    const int cgrid = (int)std::min<long long>(grid_for(h->n), 1024);
+    const int fgrid = (int)std::min<long long>(ngroups, 2048);
+    const int dgrid = (int)std::min<long long>(ngroups, 512);
+#define LAUNCH_SWEEP(SURFV)                                                              \
+  do {                                                                                   \
+    if (with_ranges) {                                                                   \
+      k_mbes_sweep<SURFV, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);           \
+      k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
+      k_mbes_fast<SURFV, false><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);               \
+      k_mbes_cast<2, false, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);                \
+    } else {                                                                             \
+      k_mbes_sweep<SURFV, true><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);            \
+      k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
+      k_mbes_fast<SURFV, true><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);                \
+      k_mbes_cast<2, true, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);                 \
+    }                                                                                    \
+  } while (0)
+    if (a.diag_mode == 1)
+      LAUNCH_SWEEP(2);
+    else
+      LAUNCH_SWEEP(3);
+#undef LAUNCH_SWEEP
+    HIPCHK(h, hipMemcpyAsync(h->work_host + 1, a.defer_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (h->env_debug_work) {
+      int cnt = 0;
+      (void)hipMemcpyAsync(&cnt, a.defer_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+      (void)hipStreamSynchronize(h->stream);
+      fprintf(stderr, "[mbes] sweep handed over %d of %lld particles\n", cnt, (long long)h->n);
+    }
+    t_end(h);
+    HIPCHK(h, hipGetLastError());
+    return MCL_OK;
+  }
   if (lean) {
     // Dispersed cloud?  The natural-order classification has just counted the groups without a common tile.
     // That count travels to the host asynchronously and is read one call late (no synchronisation): when the
@@ -1079,25 +1241,13 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     if (!h->work_host) {
       HIPCHK(h, hipHostMalloc(&h->work_host, 64, hipHostMallocDefault));
       h->work_host[0] = 0;
+      h->work_host[1] = 0;
     }
     const bool sort_now = h->env_sort >= 0 ? h->env_sort == 1 : h->sort_visits;
     h->sort_visits = (long long)h->work_host[0] * 16 > ngroups;
     HIPCHK(h, hipMemcpyAsync(h->work_host, a.work_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (sort_now && h->n > MBES_WAVES) {
-      const size_t n = (size_t)h->n;
-      if (!h->sort_keys) {
-        HIPCHK(h, hipMalloc(&h->sort_keys, sizeof(u32) * n));
-        HIPCHK(h, hipMalloc(&h->sort_keys_out, sizeof(u32) * n));
-        HIPCHK(h, hipMalloc(&h->sort_idx, sizeof(u32) * n));
-        HIPCHK(h, hipMalloc(&h->mbes_perm, sizeof(u32) * n));
-        HIPCHK(h, rocprim::radix_sort_pairs(nullptr, h->sort_tmp_bytes, h->sort_keys, h->sort_keys_out, h->sort_idx,
-                                            h->mbes_perm, n, 0, 24, h->stream));
-        HIPCHK(h, hipMalloc(&h->sort_tmp, h->sort_tmp_bytes));
-      }
-      k_mbes_keys<<<grid_for(h->n), 256, 0, h->stream>>>(a, h->sort_keys, h->sort_idx);
-      // stable LSD radix sort of (key, slot) pairs: the visiting order is deterministic
-      HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp, h->sort_tmp_bytes, h->sort_keys, h->sort_keys_out, h->sort_idx,
-                                          h->mbes_perm, n, 0, 24, h->stream));
+      RET_IF(sort_visiting_order(h, a));
       a.perm = h->mbes_perm;
       HIPCHK(h, hipMemsetAsync(a.work_count, 0, sizeof(int), h->stream));
       k_mbes_classify<<<grid_for(h->n), 256, 0, h->stream>>>(a);
@@ -1191,8 +1341,8 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
   }
   if (pose_for && !rp && h->cfg.rng_mode == MCL_RNG_NATIVE) {
     // reset the slots + work counter first: the kernel appends the deferred groups to the worklist
-    HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_WORK + sizeof(int), h->stream));
-    const bool lean = true;
+    HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_DEFER + sizeof(int), h->stream));
+    const bool lean = !pose_for->sweep_beams;  // the fan sweep needs no group records
     if (lean)
       k_predict_pose<true><<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, *pose_for);
     else
@@ -1314,6 +1464,7 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
     };
     h->env_debug_work = getenv("MCL_DEBUG_WORK") != nullptr;
     if (const char* sv = getenv("MCL_SORT_VISITS")) h->env_sort = sv[0] == '1' ? 1 : 0;
+    if (const char* sv = getenv("MCL_SWEEP")) h->env_sweep = sv[0] == '1' ? 1 : 0;
     h->env_force_comm = on("MCL_FORCE_COMM");
     h->env_no_overlap = on("MCL_NO_OVERLAP");
   }
@@ -1388,7 +1539,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_beams, h->sweep_tail, h->defer_idx, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);

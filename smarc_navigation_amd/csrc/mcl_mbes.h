@@ -99,7 +99,17 @@ struct MbesArgs {
   int* worklist;          // group ids deferred by the fast kernel (capacity = number of groups)
   int* work_count;        // device counter, zeroed before every fast launch
   unsigned long long* stats;  // MBES_STATS builds: steps, exact tests, rays, retries
+  // fan sweep (mcl_sweep.h): regularly triangulated meshes, ascending beam angles
+  const float4* sweep_beams;  // per beam: side-signed tan a, 1 / cos a, measured range, weight (inv_sigma, or 0: invalid)
+  const float* sweep_tail;    // per beam: sum of ((range - r_max) * weight)^2 over this beam and the ones beyond it on its side
+  int b_split;                // first beam with a >= 0: beams [b_split, B) sweep outward on the + side, [0, b_split) on the - side
+  int sweep_nvalid;           // beams with a valid measured range
+  float sweep_c2z_min;        // cos of the largest fan-plane tilt the sweep accepts (terrain slope bound, mcl_api.hip)
+  u32* defer_idx;             // particles the sweep hands over: the visiting order (perm) of the cast kernels that follow it
+  int* defer_count;           // device counter, zeroed with the control block
+  const int* n_dev;           // when set, the classify / cast kernels visit *n_dev entries of perm instead of a.n
 };
+__device__ __forceinline__ long long mbes_count(const MbesArgs& a) { return a.n_dev ? (long long)*a.n_dev : a.n; }
 
 #ifdef MBES_STATS
 #define STAT_INC(v) (++(v))
@@ -344,10 +354,11 @@ __global__ void __launch_bounds__(256) k_mbes_keys(MbesArgs a, u32* __restrict__
 }
 // group records and worklist for the visiting order a.perm (same decision as in the pose kernels)
 __global__ void __launch_bounds__(256) k_mbes_classify(MbesArgs a) {
-  const long long n_pad = (a.n + 63) & ~63ll;
+  const long long n = mbes_count(a);
+  const long long n_pad = (n + 63) & ~63ll;
   for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < n_pad;
        j += (long long)gridDim.x * blockDim.x) {
-    const bool valid = j < a.n;
+    const bool valid = j < n;
     MbesPose P;
     P.um = P.vm = 0.0;
     P.oz = 0.f;
@@ -881,19 +892,21 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
 
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long long ngroups = (a.n + MBES_WAVES - 1) / MBES_WAVES;
+  const long long ngroups = (mbes_count(a) + MBES_WAVES - 1) / MBES_WAVES;
   const float inv_res = (float)a.inv_res;
   // window limits: grid nodes nx x ny; mesh cells (nx-1) x (ny-1)
   const int lim_x = MAP != 1 ? a.nx - 1 : a.nx - 2, lim_y = MAP != 1 ? a.ny - 1 : a.ny - 2;
   const int tile_cap = MAP != 1 ? TILE_FLOATS : TILE_FLOATS / 2;
 
+  const long long n_eff = mbes_count(a);
+  const u32* perm = a.perm;
   const long long nwork = MODE == 1 ? (long long)*a.work_count : ngroups;
   double wmax = -__builtin_inf();  // lane 0: largest log-likelihood this wave has written
   for (long long it = blockIdx.x; it < nwork; it += gridDim.x) {
     const long long grp = MODE == 1 ? (long long)a.worklist[it] : it;
     const long long j = grp * MBES_WAVES + w;  // position in the visiting order
-    const bool valid = j < a.n;
-    const long long i = (valid && a.perm) ? (long long)a.perm[j] : j;  // the particle
+    const bool valid = j < n_eff;
+    const long long i = (valid && perm) ? (long long)perm[j] : j;  // the particle
     MbesPose P;
     if (valid) {
       // the record is wave-uniform: pin it in SGPRs (frees ~11 VGPRs per lane)
@@ -1106,7 +1119,7 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MI
           e = cast_fast<MAP>(tile, th, tw, a, tx0, ty0, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max, rs);
 #endif
       } else if (MAP == 2) {
-        // structured mesh off the fast path (map border, wide cloud): general mesh march on global memory
+        // structured mesh off the fast path (map border, wide cloud, sweep hand-overs): general mesh march on global memory
         e = use < 0 ? a.r_max
                     : cast_ray<1, false>(a.mesh.cell_info, a.mesh.gy, a, 0, 0, a.mesh.gx, a.mesh.gy, (float)P.um,
                                          (float)P.vm, P.oz, dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
@@ -1179,7 +1192,8 @@ __global__ void __launch_bounds__(MBES_THREADS, SURF == 4 ? MBES_MIN_WAVES_MESH 
   __shared__ float red[MBES_WAVES];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long long ngroups = (a.n + MBES_WAVES - 1) / MBES_WAVES;
+  const long long n_eff = mbes_count(a);
+  const long long ngroups = (n_eff + MBES_WAVES - 1) / MBES_WAVES;
   const float inv_res = (float)a.inv_res;
   double wmax = -__builtin_inf();  // lane 0: largest log-likelihood this wave has written
   // the staged tile: origin, size (cw == 0: none yet) and maximum height.  Consecutive groups of a converged
@@ -1191,7 +1205,7 @@ __global__ void __launch_bounds__(MBES_THREADS, SURF == 4 ? MBES_MIN_WAVES_MESH 
     const MbesGroup G = a.groups[grp];  // uniform address: scalar loads
     if (!G.fast) continue;              // on the general kernel's worklist
     const long long j = grp * MBES_WAVES + w;  // position in the visiting order
-    const bool valid = j < a.n;
+    const bool valid = j < n_eff;
     const long long i = (valid && a.perm) ? (long long)a.perm[j] : j;  // the particle
     const bool inside = G.tx0 >= cx0 && G.ty0 >= cy0 && G.tx0 + G.tw <= cx0 + cw && G.ty0 + G.th <= cy0 + ch;
     if (!inside) {  // uniform over the workgroup (G, c* are the same in every wave)

@@ -31,6 +31,7 @@ struct MeshDev {
   float* heights = nullptr;  // (gx+1)*(gy+1), or nullptr if the mesh is not structured
   size_t n_vertical = 0;  // triangles whose xy projection is degenerate (cannot be a height field)
   int diag_mode = 0;      // structured: 1 = every cell split along 00-11, 2 = along 10-01, 0 = mixed (LSB per cell)
+  double slope_max = 0;   // structured: steepest triangle, |grad h| (the fan sweep's tilt bound, mcl_sweep.h)
 };
 
 inline void mesh_free(MeshDev* m) {
@@ -354,6 +355,20 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
             b = (b & ~1u) | dbit;
             memcpy(&hts[ix * nny + iy], &b, 4);
           }
+      // steepest triangle: the two triangles of a cell take their x slope from one x edge and their y slope from
+      // one y edge of the cell, in the four combinations either triangulation can produce
+      {
+        double g2 = 0.0;
+        for (size_t ix = 0; ix + 1 < nnx; ++ix)
+          for (size_t iy = 0; iy + 1 < nny; ++iy) {
+            const double h00 = hts[ix * nny + iy], h10 = hts[(ix + 1) * nny + iy], h01 = hts[ix * nny + iy + 1],
+                         h11 = hts[(ix + 1) * nny + iy + 1];
+            const double ax = std::max(std::fabs(h10 - h00), std::fabs(h11 - h01));
+            const double ay = std::max(std::fabs(h01 - h00), std::fabs(h11 - h10));
+            g2 = std::max(g2, ax * ax + ay * ay);
+          }
+        m->slope_max = std::sqrt(g2) / cs;
+      }
       if (hipMalloc(&m->heights, sizeof(float) * hts.size()) != hipSuccess ||
           hipMemcpy(m->heights, hts.data(), sizeof(float) * hts.size(), hipMemcpyHostToDevice) != hipSuccess) {
         *err = "set_map_mesh: device allocation failed";
