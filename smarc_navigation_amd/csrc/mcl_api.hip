@@ -2317,6 +2317,18 @@ int mcl_comm_shutdown(mcl_handle* h, int32_t abort) {
   return MCL_OK;
 }
 
+int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64_t* deferred_groups) {
+  if (!h) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int cnt[2] = {0, 0};
+  HIPCHK(h, hipMemcpy(cnt, h->ctrl + CTRL_WORK, sizeof cnt, hipMemcpyDeviceToHost));
+  if (path) *path = h->sweep_now ? 1 : 0;
+  if (handed_over) *handed_over = h->sweep_now ? cnt[1] : 0;
+  if (deferred_groups) *deferred_groups = cnt[0];
+  return MCL_OK;
+}
+
 int mcl_timing_enable(mcl_handle* h, int32_t on) {
   if (!h) return MCL_ERR_INVALID;
   RET_IF(set_device(h));

@@ -70,7 +70,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   const int pstep = side ? -1 : 1, pend = side ? -1 : B;
   const bool none = ptr == pend;
   // ---- how far out can the walk go?  The outermost beam of the side is below every node once it reaches z_min
-  float s_stop = a.r_max;
+  float s_stop = none ? 0.f : a.r_max;  // (a side without beams only takes part in the nadir cast)
   if (!none) {
     const float2 sc = a.beam_sc[side ? 0 : B - 1];
     const float dz_e = sc.x * P.c1[2] - sc.y * c2z;

@@ -235,6 +235,12 @@ class Engine(object):
     def timing_enable(self, on=True):
         self._ck(self.lib.mcl_timing_enable(self.h, 1 if on else 0))
 
+    def mbes_last_path(self):
+        """(path, handed_over, deferred_groups) of the last MBES update: path 1 = fan sweep, 0 = ray traversal."""
+        p, ho, dg = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        self._ck(self.lib.mcl_mbes_last_path(self.h, C.byref(p), C.byref(ho), C.byref(dg)))
+        return int(p.value), int(ho.value), int(dg.value)
+
     def timing_get(self):
         t = Timing()
         self._ck(self.lib.mcl_timing_get(self.h, C.byref(t)))

@@ -115,9 +115,9 @@ def bathymetry_grid(nx=512, ny=512, res=1.0, origin=(-64.0, -256.0), seed=3, dep
     return np.ascontiguousarray(z, dtype=np.float32)
 
 
-def mesh_from_grid(z, res, origin):
+def mesh_from_grid(z, res, origin, diagonal='00-11'):
     """Triangulate a height grid: verts[nv,3] fp32, tris[nt,3] uint32; 2 triangles per cell,
-    split along the (ix,iy)-(ix+1,iy+1) diagonal."""
+    split along the (ix,iy)-(ix+1,iy+1) diagonal ('00-11') or the (ix+1,iy)-(ix,iy+1) one ('10-01')."""
     nx, ny = z.shape
     ix, iy = np.meshgrid(np.arange(nx), np.arange(ny), indexing='ij')
     verts = np.stack([origin[0] + res * ix, origin[1] + res * iy, z], axis=-1)
@@ -126,8 +126,12 @@ def mesh_from_grid(z, res, origin):
     v10 = v00 + ny
     v01 = v00 + 1
     v11 = v00 + ny + 1
-    tris = np.concatenate([np.stack([v00, v10, v11], axis=1),
-                           np.stack([v00, v11, v01], axis=1)], axis=0).astype(np.uint32)
+    if diagonal == '10-01':
+        tris = np.concatenate([np.stack([v00, v10, v01], axis=1),
+                               np.stack([v10, v11, v01], axis=1)], axis=0).astype(np.uint32)
+    else:
+        tris = np.concatenate([np.stack([v00, v10, v11], axis=1),
+                               np.stack([v00, v11, v01], axis=1)], axis=0).astype(np.uint32)
     return verts, tris
 
 
