@@ -1146,7 +1146,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   // from the vertical only as far as the steepest triangle allows (tan(tilt) * slope < 1, with a margin).
   if (!pose_done) {
     bool sweep = structured && (a.diag_mode == 1 || a.diag_mode == 2) && h->sweep_angles_ok && h->env_sweep != 0 &&
-                 h->n < (1ll << 31);
+                 h->n < (1ll << 31) && (long long)a.nx * a.ny < (1ll << 31);
     h->sweep_now = sweep;
     if (sweep) RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max));
   }
@@ -1194,16 +1194,21 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       RET_IF(sort_visiting_order(h, a));
       a.perm = h->mbes_perm;
     }
-    const int sgrid = (int)((2 * h->n + SWEEP_THREADS - 1) / SWEEP_THREADS);
-    const size_t lds = (size_t)B * (sizeof(float4) + sizeof(float));
+    // (expected ranges of a few particles: only their lanes are launched)
+    const long long n_lanes = 2 * ((!with_ranges && !a.perm) ? std::max<long long>(std::min<long long>(exp_count, h->n - exp_first), 1) : h->n);
+    const int sgrid = (int)((n_lanes + SWEEP_THREADS - 1) / SWEEP_THREADS);
+    const size_t lds = (size_t)(B + 2) * sizeof(float4) + (size_t)B * sizeof(float);
     // what the sweep hands over is cast the old way, in the order of the hand-over list: group records and
     // worklist (k_mbes_classify), the fast kernel, the general kernel -- all three read the count on the device
     MbesArgs d = a;
     d.perm = h->defer_idx;
     d.n_dev = a.defer_count;
-    const int cgrid = (int)std::min<long long>(grid_for(h->n), 1024);
-    const int fgrid = (int)std::min<long long>(ngroups, 2048);
-    const int dgrid = (int)std::min<long long>(ngroups, 512);
+    // (their loops are grid-stride: the grids only set the parallelism.  After an update that handed nothing over
+    //  they are launched small -- three empty 2048-workgroup launches cost 15 us, 2.5 % of the update)
+    const bool few = h->work_host[1] == 0;
+    const int cgrid = (int)std::min<long long>(grid_for(h->n), few ? 32 : 1024);
+    const int fgrid = (int)std::min<long long>(ngroups, few ? 64 : 2048);
+    const int dgrid = (int)std::min<long long>(ngroups, few ? 64 : 512);
 #define LAUNCH_SWEEP(SURFV)                                                              \
   do {                                                                                   \
     if (with_ranges) {                                                                   \

@@ -95,6 +95,8 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   }
   if (!pre) SWEEP_FAIL(1);
   const float* __restrict__ gp = a.grid + ((size_t)I0 * ny + J0);  // node (I0, J0); every access below is inside the footprint
+  const float* __restrict__ grid = a.grid;
+  const int g0 = I0 * ny + J0, g_hi = nx * ny - 1;  // (maps below 2^31 nodes: checked on the host)
   // ---- nadir hit: the ordinary clearance traversal on the global height array
   const float r0 = cast_clear<SURF>(gp, ny, a, ul, vl, oz, -P.c2[0] * inv_res, -P.c2[1] * inv_res, -c2z, a.zmax_map, a.r_max);
   if (!(r0 < a.r_max)) SWEEP_FAIL(5);
@@ -165,22 +167,23 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     t_cur = far_m ? tm : tn;
     s_prev = far_m ? sn : sm;
     t_prev = far_m ? tn : tm;
+    if (!(t_cur > 0.f)) SWEEP_FAIL(8);
   }
   // ---- walk outward, merging the beam table against the polyline
-  const int i_lo = -I0, i_hi = nx - 1 - I0, j_lo = -J0, j_hi = ny - 1 - J0;
   float acc = 0.f;
   bool ok = true;
   const int max_steps = (int)(3.f * (s_stop + 4.f * res) * inv_res) + 16;
   int step = 0;
+  float4 bm = sbeam[ptr];  // the next beam to resolve stays in registers across segments: a vertex it passes beyond costs no LDS read
   for (;;) {
     // the third node of the triangle across (A, Bn): its height load is in flight while the beams are resolved
     const int Nk = (int)((unsigned)A.P + (unsigned)Bn.P - (unsigned)C);
     const int nj = __builtin_amdgcn_sbfe(Nk, 0, 16), ni = (Nk - nj) >> 16;
     // (the footprint test keeps a sane walk inside the map; the clamp keeps a NaN-driven one from reading outside it)
-    const float hN = gp[min(max(ni, i_lo), i_hi) * ny + min(max(nj, j_lo), j_hi)];
+    const float hN = grid[(unsigned)min(max(g0 + ni * ny + nj, 0), g_hi)];
     const float dts = t_cur - t_prev;
-    while (ptr != pend) {
-      const float4 bm = sbeam[ptr];
+    for (;;) {
+      // (no `ptr != pend` test: the record beyond the last beam has tan a = +inf and t_cur > 0, so e_cur = -inf)
       const float e_cur = fmaf(-bm.x, t_cur, s_cur);
       if (!(e_cur >= 0.f)) break;  // the beam passes beyond this vertex
       const float e_prev = fmaf(-bm.x, t_prev, s_prev);
@@ -195,6 +198,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
         acc = fmaf(dd, dd, acc);
       }
       ptr += pstep;
+      bm = sbeam[ptr];  // (one sentinel record on either end of the table)
     }
     if (ptr == pend) break;
     if (s_cur > s_stop) break;  // every beam left misses inside r_max (tail below)
@@ -221,6 +225,10 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     t_prev = t_cur;
     s_cur = fmaf(lam, Bn.s - A.s, A.s);
     t_cur = fmaf(lam, Bn.t - A.t, A.t);
+    if (!(t_cur > 0.f)) {  // the seabed rises above the sensor's own horizon: not for the sweep (see the sentinel records)
+      ok = false;
+      break;
+    }
   }
   if (ok && ptr != pend) {
     if (EXPECT_ONLY) {
@@ -244,16 +252,19 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
 template <int SURF, bool EXPECT_ONLY>
 __global__ void __launch_bounds__(SWEEP_THREADS, SWEEP_MIN_WAVES) k_mbes_sweep(MbesArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sweep_lds[];
-  float4* sbeam = (float4*)sweep_lds;
-  float* stail = (float*)(sbeam + a.n_beams);
+  float4* sbeam = (float4*)sweep_lds + 1;  // records -1 and n_beams exist (read, never used)
+  float* stail = (float*)(sbeam + a.n_beams + 1);
   for (int b = threadIdx.x; b < a.n_beams; b += SWEEP_THREADS) {
     sbeam[b] = a.sweep_beams[b];
     stail[b] = a.sweep_tail[b];
   }
+  if (threadIdx.x == 0) sbeam[-1] = sbeam[a.n_beams] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);  // "never reached"
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const long long gid = blockIdx.x * (long long)SWEEP_THREADS + threadIdx.x;
-  const long long j = gid >> 1;  // position in the visiting order; lanes 2k, 2k+1 = the two sides of one particle
+  // position in the visiting order; lanes 2k, 2k+1 = the two sides of one particle.  (Expected ranges in the natural
+  // order: the grid only covers the particles asked for.)
+  const long long j = (gid >> 1) + ((EXPECT_ONLY && !a.perm) ? a.exp_first : 0);
   const int side = (int)(gid & 1);
   const bool valid = j < a.n;
   const long long i = (valid && a.perm) ? (long long)a.perm[j] : j;

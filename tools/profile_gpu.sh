@@ -15,7 +15,7 @@ done
 cd $R && python3 tools/pmc_summarise.py $O $O/traffic.json > $O/summarise.log 2>&1
 # keep only what is small enough to travel back: the stats CSVs, the dominant kernel's counter rows, the summary
 find $O -name "*kernel_stats.csv" | head
-for f in $(find $O -name "*counter_collection.csv"); do grep -E "Correlation_Id|k_mbes_fast" $f > $f.mbes; rm $f; done
+for f in $(find $O -name "*counter_collection.csv"); do grep -E "Correlation_Id|k_mbes_fast|k_mbes_sweep" $f > $f.mbes; rm $f; done
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O
 head -c 1500 $O/traffic.json
