@@ -261,6 +261,15 @@ def alg_bytes(P, B, map_bytes, world):
     }
 
 
+def mbes_path(e, P):
+    """Which kernels cast the last MBES update (mcl_mbes_last_path): the fan sweep (regularly triangulated
+    meshes) or the ray traversal, and how much of the cloud the first stage passed on to the general kernels."""
+    path, handed, deferred = e.mbes_last_path()
+    return {'algorithm': 'fan sweep (mcl_sweep.h: k_mbes_sweep)' if path == 1 else 'ray traversal (mcl_mbes.h: k_mbes_fast)',
+            'particles_handed_to_traversal': handed if path == 1 else None,
+            'groups_deferred_to_general_kernel': deferred, 'of_particles': P}
+
+
 def kernel_table(tim, alg, steps):
     kernels = {}
     for name, (ms, cnt) in tim.items():
@@ -326,9 +335,10 @@ def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, re
     dt = time.perf_counter() - t0
     tim = e.timing_get()
     e.timing_enable(False)
+    path = mbes_path(e, P)
     e.close()
     ms = 1e3 * dt / steps
-    out = dict(workload='%d particles x %d beams, %s%s%s' % (
+    out = dict(mbes_path=path, workload='%d particles x %d beams, %s%s%s' % (
         P, B, m['desc'], '' if resample else ', predict + MBES update only (no resample: the cloud keeps its width)',
         '' if landmarks is None else ', + %d detections x %d landmarks k-NN (k=4) per ping' % (landmarks[1], len(landmarks[0]))),
         steps=steps, ms_per_step=round(ms, 4), steps_per_s=round(1e3 / ms, 2),
@@ -481,6 +491,7 @@ def worker(a, rank, world, local_rank):
     if rank == 0:
         ms_per_step = 1e3 * dt / a.steps
         total_particles = P * world
+        path_main = mbes_path(e, P)
         value = a.steps / dt * (total_particles / 1048576.0)
         alg = alg_bytes(P, B, m['bytes'], world)
         kernels = kernel_table(tim, alg, a.steps)
@@ -534,8 +545,11 @@ def worker(a, rank, world, local_rank):
                          'valu_issue_frac': (round(pmc['valu_insts_per_launch'] / (dom_ms * 1e-3) / (1024 * 2.4e9 / 2.0), 3)
                                              if pmc.get('valu_insts_per_launch') else None),
                          'streaming_ms_per_step': round(sum(kernels[k]['ms_per_step'] for k in streaming), 5),
-                         'note': 'the ray-cast is VALU-bound, not HBM-bound (SURVEY 8d); valu_* come from the offline PMC '
-                                 'passes named in traffic_source (null when that file does not match this library); '
+                         'mbes_path': path_main,
+                         'note': 'the MBES update is bound by vector / LDS issue, not by HBM (SURVEY 8d): its compulsory '
+                                 'traffic is 56 B per particle + the map; valu_* come from the offline PMC '
+                                 'passes named in traffic_source (null when that file does not match this library), '
+                                 'valu_insts_per_ray = wave instructions x 64 / (particles x beams); '
                                  'streaming kernels are listed in "kernels" with their own HBM fractions'},
             'kernels': kernels,
             'pose_rmse_m': round(pose_rmse, 4),

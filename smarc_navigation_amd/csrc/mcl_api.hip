@@ -127,6 +127,7 @@ struct mcl_handle {
   int gnx = 0, gny = 0;
   double gox = 0, goy = 0, gres = 1;
   float gzmin = 0, gzmax = 0;
+  double gslope_max = 0;       // steepest patch gradient of the height grid (the fan sweep's tilt bound)
   MeshDev* mesh = nullptr;
   LandmarkDev* landmarks = nullptr;
   double* det_dev = nullptr;
@@ -1145,7 +1146,12 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   // ---- fan sweep (mcl_sweep.h): regularly triangulated meshes, ascending beam angles.  The fan plane may lean
   // from the vertical only as far as the steepest triangle allows (tan(tilt) * slope < 1, with a margin).
   if (!pose_done) {
-    bool sweep = structured && (a.diag_mode == 1 || a.diag_mode == 2) && h->sweep_angles_ok && h->env_sweep != 0 &&
+    // (one lane per particle side: below ~16 k particles (meshes; ~100 k on height grids, whose per-beam work is
+    //  heavier) the sweep cannot fill the chip and the wave-per-particle traversal is faster -- measured at 32 k ...
+    //  1 M; MCL_SWEEP=1 forces it)
+    const long long sweep_min_n = h->env_sweep == 1 ? 1 : (h->map_kind == 0 ? 98304 : 16384);
+    bool sweep = ((structured && (a.diag_mode == 1 || a.diag_mode == 2)) || h->map_kind == 0) && h->sweep_angles_ok && h->env_sweep != 0 &&
+                 h->n >= sweep_min_n &&
                  h->n < (1ll << 31) && (long long)a.nx * a.ny < (1ll << 31);
     h->sweep_now = sweep;
     if (sweep) RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max));
@@ -1157,7 +1163,9 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.sweep_tail = h->sweep_tail;
     a.b_split = h->b_split;
     a.sweep_nvalid = h->sweep_nvalid;
-    const double tan_lim = std::min(std::tan(35.0 * MCL_PI / 180.0), 0.8 / std::max(h->mesh->slope_max, 1e-9));
+    // (grids: 0.45 -- below 0.5 the plane function cannot change sign around a cell's four corners, mcl_sweep.h)
+    const double slope_max = h->map_kind == 0 ? h->gslope_max : h->mesh->slope_max;
+    const double tan_lim = std::min(std::tan(35.0 * MCL_PI / 180.0), (h->map_kind == 0 ? 0.45 : 0.8) / std::max(slope_max, 1e-9));
     a.sweep_c2z_min = (float)(1.0 / std::sqrt(1.0 + tan_lim * tan_lim));
     a.defer_idx = h->defer_idx;
   }
@@ -1209,24 +1217,26 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     const int cgrid = (int)std::min<long long>(grid_for(h->n), few ? 32 : 1024);
     const int fgrid = (int)std::min<long long>(ngroups, few ? 64 : 2048);
     const int dgrid = (int)std::min<long long>(ngroups, few ? 64 : 512);
-#define LAUNCH_SWEEP(SURFV)                                                              \
+#define LAUNCH_SWEEP(SURFV, MAPV)                                                        \
   do {                                                                                   \
     if (with_ranges) {                                                                   \
       k_mbes_sweep<SURFV, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);           \
       k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
       k_mbes_fast<SURFV, false><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);               \
-      k_mbes_cast<2, false, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);                \
+      k_mbes_cast<MAPV, false, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);             \
     } else {                                                                             \
       k_mbes_sweep<SURFV, true><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);            \
       k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
       k_mbes_fast<SURFV, true><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);                \
-      k_mbes_cast<2, true, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);                 \
+      k_mbes_cast<MAPV, true, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);              \
     }                                                                                    \
   } while (0)
-    if (a.diag_mode == 1)
-      LAUNCH_SWEEP(2);
+    if (h->map_kind == 0)
+      LAUNCH_SWEEP(0, 0);
+    else if (a.diag_mode == 1)
+      LAUNCH_SWEEP(2, 2);
     else
-      LAUNCH_SWEEP(3);
+      LAUNCH_SWEEP(3, 2);
 #undef LAUNCH_SWEEP
     HIPCHK(h, hipMemcpyAsync(h->work_host + 1, a.defer_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (h->env_debug_work) {
@@ -1637,6 +1647,20 @@ int mcl_set_map_grid(mcl_handle* h, const float* z, int32_t nx, int32_t ny, doub
   h->gres = res;
   h->gzmin = mn;
   h->gzmax = mx;
+  {
+    // steepest gradient of a bilinear patch: its x slope lies between those of the cell's two x edges, its y slope
+    // between those of the two y edges
+    double g2 = 0.0;
+    for (int ix = 0; ix + 1 < nx; ++ix)
+      for (int iy = 0; iy + 1 < ny; ++iy) {
+        const size_t k = (size_t)ix * ny + iy;
+        const double h00 = z[k], h01 = z[k + 1], h10 = z[k + ny], h11 = z[k + ny + 1];
+        const double ax = std::max(std::fabs(h10 - h00), std::fabs(h11 - h01));
+        const double ay = std::max(std::fabs(h01 - h00), std::fabs(h11 - h10));
+        g2 = std::max(g2, ax * ax + ay * ay);
+      }
+    h->gslope_max = std::sqrt(g2) / res;
+  }
   h->map_kind = 0;
   return MCL_OK;
 }

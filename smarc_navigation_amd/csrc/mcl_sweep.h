@@ -27,19 +27,14 @@
 #ifndef SWEEP_THREADS
 #define SWEEP_THREADS 256
 #endif
+#ifndef SWEEP_MIN_WAVES_GRID
+#define SWEEP_MIN_WAVES_GRID 6   // height grids carry the conic of the current cell as well (<= 80 VGPRs)
+#endif
 #ifndef SWEEP_MIN_WAVES
 #define SWEEP_MIN_WAVES 8   // waves per SIMD the register budget is held to (<= 64 VGPRs)
 #endif
 
-#ifdef SWEEP_DEBUG
-#define SWEEP_FAIL(code)                                      \
-  do {                                                        \
-    if (EXPECT_ONLY && side == 1) exp_row[19] = (float)(code); \
-    return false;                                             \
-  } while (0)
-#else
-#define SWEEP_FAIL(code) return false
-#endif
+#define SWEEP_FAIL(code) return false  // (code: which test declined -- for a debugger)
 
 struct SweepNode {
   int P;        // lattice coordinates relative to the sensor's cell, packed i * 65536 + j (j signed)
@@ -48,6 +43,15 @@ struct SweepNode {
 };
 
 // SURF 2: every cell split along 00-11; SURF 3: along 10-01.
+// SURF 0: a height GRID (bilinear patches).  The walk is the same -- along cell edges a bilinear patch is linear, so
+//   the points where the fan plane crosses CELL edges are exact, and walking the 00-11 triangulation of the node
+//   values of the plane function visits them in order (the plane function is bilinear in a cell; its zero set joins
+//   the same pairs of edge crossings as that of the triangulated values unless the four corner signs alternate,
+//   which the tilt bound for grids excludes: tan(tilt) * slope < 0.45).  Crossings of the auxiliary diagonals are
+//   passed over.  Between two consecutive cell-edge crossings the slice is an arc of a conic inside ONE cell: a beam
+//   whose angle they bracket meets the surface in that cell, at a root of the bilinear-patch quadratic of the oracle
+//   (orc_ray_grid); a beam that passes just beyond the far crossing may still graze the arc -- bounded by the patch's
+//   twist -- and is then tested against the same quadratic.
 // Returns false when the particle has to go to the general kernel.  acc: sum over this side's beams of
 // ((range - expected) * weight)^2; EXPECT_ONLY: expected ranges to exp_row[b] instead.
 template <int SURF, bool EXPECT_ONLY>
@@ -96,10 +100,11 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   if (!pre) SWEEP_FAIL(1);
   const float* __restrict__ gp = a.grid + ((size_t)I0 * ny + J0);  // node (I0, J0); every access below is inside the footprint
   const float* __restrict__ grid = a.grid;
-  const int g0 = I0 * ny + J0, g_hi = nx * ny - 1;  // (maps below 2^31 nodes: checked on the host)
+  const int g0i = I0 * ny + J0, g_hi = nx * ny - 1;  // (maps below 2^31 nodes: checked on the host)
   // ---- nadir hit: the ordinary clearance traversal on the global height array
   const float r0 = cast_clear<SURF>(gp, ny, a, ul, vl, oz, -P.c2[0] * inv_res, -P.c2[1] * inv_res, -c2z, a.zmax_map, a.r_max);
   if (!(r0 < a.r_max)) SWEEP_FAIL(5);
+  if (SURF == 0 && !(r0 > 0.f)) SWEEP_FAIL(9);  // the sensor is at or below the seabed (a grid is solid underneath)
   if (none) return true;
   // ---- plane and in-plane coordinates as affine functions of (i, j, h): lattice coordinates relative to (I0, J0)
   const float nx_ = P.c1[1] * P.c2[2] - P.c1[2] * P.c2[1], ny_ = P.c1[2] * P.c2[0] - P.c1[0] * P.c2[2],
@@ -120,18 +125,17 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   };
   // ---- the triangle under the nadir hit
   SweepNode A, Bn;
-  int C;
+  int C, start_i, start_j;
   float s_prev, t_prev, s_cur, t_cur;
-#ifdef SWEEP_DEBUG
-  float dbg[6] = {0, 0, 0, 0, 0, 0};
-#endif
   {
     const float uh = fmaf(r0, -P.c2[0] * inv_res, ul), vh = fmaf(r0, -P.c2[1] * inv_res, vl);
     const float cfi = floorf(uh), cfj = floorf(vh);
     const float fu = uh - cfi, fv = vh - cfj;
     const int c00 = (int)cfi * 65536 + (int)cfj;
+    start_i = (int)cfi;
+    start_j = (int)cfj;
     int k0, k1, k2;
-    if (SURF == 2) {
+    if (SURF == 2 || SURF == 0) {
       const bool lower = fv <= fu;  // (00, 10, 11) : (00, 11, 01)
       k0 = c00;
       k1 = lower ? c00 + 65536 : c00 + 65537;
@@ -159,9 +163,6 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     const bool pl = NL.d > 0.f;
     A = pl ? NF : NL;   // A: d <= 0, Bn: d > 0
     Bn = pl ? NL : NF;
-#ifdef SWEEP_DEBUG
-    dbg[0] = sm; dbg[1] = tm; dbg[2] = sn; dbg[3] = tn; dbg[4] = (float)L; dbg[5] = NL.d;
-#endif
     C = far_m ? NN.P : NM.P;
     s_cur = far_m ? sm : sn;
     t_cur = far_m ? tm : tn;
@@ -175,30 +176,116 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   const int max_steps = (int)(3.f * (s_stop + 4.f * res) * inv_res) + 16;
   int step = 0;
   float4 bm = sbeam[ptr];  // the next beam to resolve stays in registers across segments: a vertex it passes beyond costs no LDS read
+  // SURF 0: does the current / previous vertex lie on a cell edge (and not on an auxiliary diagonal)?
+  const auto on_cell_edge = [](int Pa, int Pb) { const int dP = Pa - Pb; return !(dP == 65537 || dP == -65537); };
+  bool cur_edge = SURF != 0 || on_cell_edge(A.P, Bn.P), prev_edge = false;
+  float hp00 = 0.f, hp01 = 0.f, hp10 = 0.f, hp11 = 0.f;  // SURF 0: corner heights of the cell the walk is in
+  if (SURF == 0) {
+    const unsigned gs = (unsigned)min(max(g0i + start_i * ny + start_j, 0), g_hi - ny - 1);
+    hp00 = grid[gs];
+    hp01 = grid[gs + 1];
+    hp10 = grid[gs + ny];
+    hp11 = grid[gs + ny + 1];
+  }
+  const float rc2z = fast_rcp(c2z);
+  // (s, t) -> cells: u = ul + ax s + bx t, v = vl + ay s + by t
+  const float ax = sg * P.c1[0] * inv_res, ay = sg * P.c1[1] * inv_res, bx = -P.c2[0] * inv_res, by = -P.c2[1] * inv_res;
   for (;;) {
     // the third node of the triangle across (A, Bn): its height load is in flight while the beams are resolved
     const int Nk = (int)((unsigned)A.P + (unsigned)Bn.P - (unsigned)C);
     const int nj = __builtin_amdgcn_sbfe(Nk, 0, 16), ni = (Nk - nj) >> 16;
     // (the footprint test keeps a sane walk inside the map; the clamp keeps a NaN-driven one from reading outside it)
-    const float hN = grid[(unsigned)min(max(g0 + ni * ny + nj, 0), g_hi)];
+    const float hN = grid[(unsigned)min(max(g0i + ni * ny + nj, 0), g_hi)];
     const float dts = t_cur - t_prev;
-    for (;;) {
-      // (no `ptr != pend` test: the record beyond the last beam has tan a = +inf and t_cur > 0, so e_cur = -inf)
-      const float e_cur = fmaf(-bm.x, t_cur, s_cur);
-      if (!(e_cur >= 0.f)) break;  // the beam passes beyond this vertex
-      const float e_prev = fmaf(-bm.x, t_prev, s_prev);
-      // crossing of the half line s = t tan a with the segment: e changes sign (<= 0 at prev, >= 0 at cur)
-      const float lam = fmaxf(fminf(e_prev * fast_rcp(e_prev - e_cur), 1.f), 0.f);
-      const float tau = fmaf(lam, dts, t_prev);
-      const float r = fminf(tau * bm.y, a.r_max);  // range = t / cos a; beyond r_max (or NaN): r_max
-      if (EXPECT_ONLY) {
-        exp_row[ptr] = r;
-      } else {
-        const float dd = (bm.z - r) * bm.w;
-        acc = fmaf(dd, dd, acc);
+    if (cur_edge) {
+      // SURF 0: the patch of the cell the arc (prev -> cur) lies in = the cell of the triangle (A, Bn, C)
+      // In the fan plane the clearance z - h(u, v) over this cell is a conic in (s, t),
+      //   G = g0 + g1 s + g2 t + g3 s^2 + g4 s t + g5 t^2   (u, v, z are affine in (s, t), h is bilinear),
+      // and along beam s = t tan a it is the quadratic  g0 + (g1 T + g2) t + (g3 T^2 + g4 T + g5) t^2  -- the same
+      // polynomial as the oracle's ray / patch quadratic (orc_ray_grid), with tau = t.
+      float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, kb = 0.f, uc = 0.f, vc = 0.f;
+      if (SURF == 0) {
+        const int ja = __builtin_amdgcn_sbfe(A.P, 0, 16), ia = (A.P - ja) >> 16;
+        const int jb = __builtin_amdgcn_sbfe(Bn.P, 0, 16), ib = (Bn.P - jb) >> 16;
+        const int jc = __builtin_amdgcn_sbfe(C, 0, 16), ic = (C - jc) >> 16;
+        const int i0 = min(ia, min(ib, ic)), j0 = min(ja, min(jb, jc));
+        // (hp: the corner heights of this cell, loaded one cell edge ago)
+        const float pB = hp10 - hp00, pC = hp01 - hp00, pD = (hp00 - hp10) - (hp01 - hp11);
+        uc = ul - (float)i0;
+        vc = vl - (float)j0;
+        // u = uc + ax s + bx t, v = vc + ay s + by t (cells), z = oz + sz s + tz t
+        g0 = oz - fmaf(pD * uc, vc, fmaf(pC, vc, fmaf(pB, uc, hp00)));
+        g1 = sz - fmaf(pD, fmaf(uc, ay, vc * ax), fmaf(pC, ay, pB * ax));
+        g2 = tz - fmaf(pD, fmaf(uc, by, vc * bx), fmaf(pC, by, pB * bx));
+        g3 = -pD * (ax * ay);
+        g4 = -pD * fmaf(ax, by, ay * bx);
+        g5 = -pD * (bx * by);
+        // how far (in e = s - t tan a, per unit tan a) the arc can bulge beyond its chord: along the chord the
+        // clearance is -twist * du * dv * l (1 - l) <= |twist du dv| / 4, and moving along -c2 changes the clearance
+        // at a rate of at least c2z (1 - slope tan(tilt)) >= 0.55 c2z
+        const float ds = s_cur - s_prev;
+        const float cu = prev_edge ? fmaf(ax, ds, bx * dts) : 1.f, cv = prev_edge ? fmaf(ay, ds, by * dts) : 1.f;
+        kb = 0.46f * fabsf(pD * cu * cv) * rc2z + 1e-6f;
+        // the corner heights of the NEXT cell (the one across this edge: the cell of (A, Bn, N)) are in flight
+        // while this arc's beams are resolved
+        const int i1 = min(ia, min(ib, ni)), j1 = min(ja, min(jb, nj));
+        const unsigned gn = (unsigned)min(max(g0i + i1 * ny + j1, 0), g_hi - ny - 1);
+        hp00 = grid[gn];
+        hp01 = grid[gn + 1];
+        hp10 = grid[gn + ny];
+        hp11 = grid[gn + ny + 1];
       }
-      ptr += pstep;
-      bm = sbeam[ptr];  // (one sentinel record on either end of the table)
+      for (;;) {
+        // (no `ptr != pend` test: the record beyond the last beam has tan a = +inf and t_cur > 0, so e_cur = -inf)
+        const float e_cur = fmaf(-bm.x, t_cur, s_cur);
+        const float e_prev = fmaf(-bm.x, t_prev, s_prev);
+        bool graze = false;
+        if (!(e_cur >= 0.f)) {  // the beam passes beyond this vertex
+          if (SURF != 0) break;
+          if (!(fmaxf(e_cur, e_prev) + bm.x * kb >= 0.f)) break;  // ... by more than the arc can bulge (sentinel: NaN)
+          graze = true;
+        }
+        // crossing of the half line s = t tan a with the chord: e changes sign (<= 0 at prev, >= 0 at cur)
+        const float lam = fmaxf(fminf(e_prev * fast_rcp(e_prev - e_cur), 1.f), 0.f);
+        float tau = fmaf(lam, dts, t_prev);
+        if (SURF == 0) {
+          const float q1 = fmaf(g1, bm.x, g2), q2 = fmaf(fmaf(g3, bm.x, g4), bm.x, g5);
+          // the root next to the chord's estimate: one Newton step (the estimate is off by at most the arc's bulge, a
+          // few millimetres on smooth terrain), accepted when the residual confirms it to 3e-5 m.  On strongly twisted
+          // patches, or where the beam meets the seabed at a shallow angle (two close roots: Newton stalls), the closed
+          // form takes over (wave-uniform branch)
+          const float f0 = fmaf(fmaf(q2, tau, q1), tau, g0), fp = fmaf(2.f * q2, tau, q1);
+          float tn = fmaf(-f0, fast_rcp(fp), tau);
+          const float fr = fmaf(fmaf(q2, tn, q1), tn, g0);
+          const bool exact = graze | !(fabsf(fr) <= 3e-5f * fabsf(fp));
+          if (__builtin_amdgcn_ballot_w64(exact) != 0ull) {
+            if (exact) {
+              const float disc = fmaf(q1, q1, -4.f * q2 * g0);
+              const float sq = fast_sqrt(fmaxf(disc, 0.f));
+              const float qq = -0.5f * (q1 + (q1 >= 0.f ? sq : -sq));
+              const float r1 = g0 * fast_rcp(qq), r2 = qq * fast_rcp(q2);  // r2 = inf / NaN on a planar patch
+              const float lo = fminf(r1, r2), hi = fmaxf(r1, r2);
+              const float du = fmaf(ax, bm.x, bx), dv = fmaf(ay, bm.x, by);  // cells per unit t along the beam
+              // a root counts if its point lies in this cell (the arc is the only piece of the slice there)
+              const float EPS = 2e-4f;
+              const bool vlo = (disc >= 0.f) & (lo > 0.f) & (fabsf(fmaf(du, lo, uc) - 0.5f) <= 0.5f + EPS) & (fabsf(fmaf(dv, lo, vc) - 0.5f) <= 0.5f + EPS);
+              const bool vhi = (disc >= 0.f) & (hi > 0.f) & (fabsf(fmaf(du, hi, uc) - 0.5f) <= 0.5f + EPS) & (fabsf(fmaf(dv, hi, vc) - 0.5f) <= 0.5f + EPS);
+              if (graze & !(vlo | vhi)) break;  // a beam beyond the far vertex that passes over the arc: not in this cell
+              tn = vlo ? lo : (vhi ? hi : tau);  // (neither, bracketed: rounding at the cell border -- the chord)
+            }
+          }
+          tau = tn;
+        }
+        const float r = fminf(tau * bm.y, a.r_max);  // range = t / cos a; beyond r_max (or NaN): r_max
+        if (EXPECT_ONLY) {
+          exp_row[ptr] = r;
+        } else {
+          const float dd = (bm.z - r) * bm.w;
+          acc = fmaf(dd, dd, acc);
+        }
+        ptr += pstep;
+        bm = sbeam[ptr];  // (one sentinel record on either end of the table)
+      }
     }
     if (ptr == pend) break;
     if (s_cur > s_stop) break;  // every beam left misses inside r_max (tail below)
@@ -221,10 +308,14 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     Bn.s = pos ? sN : Bn.s;
     Bn.t = pos ? tN : Bn.t;
     const float lam = A.d * fast_rcp(A.d - Bn.d);
-    s_prev = s_cur;
-    t_prev = t_cur;
+    if (cur_edge) {  // (SURF 0: a diagonal crossing is not a vertex of the slice)
+      s_prev = s_cur;
+      t_prev = t_cur;
+      prev_edge = true;
+    }
     s_cur = fmaf(lam, Bn.s - A.s, A.s);
     t_cur = fmaf(lam, Bn.t - A.t, A.t);
+    if (SURF == 0) cur_edge = on_cell_edge(A.P, Bn.P);
     if (!(t_cur > 0.f)) {  // the seabed rises above the sensor's own horizon: not for the sweep (see the sentinel records)
       ok = false;
       break;
@@ -237,20 +328,12 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
       acc += stail[ptr];
     }
   }
-#ifdef SWEEP_DEBUG
-  if (EXPECT_ONLY && side == 1) {
-    exp_row[0] = r0; exp_row[1] = s_prev; exp_row[2] = t_prev; exp_row[3] = s_cur; exp_row[4] = t_cur;
-    exp_row[5] = A.d; exp_row[6] = Bn.d; exp_row[7] = (float)step; exp_row[8] = (float)ptr; exp_row[9] = s_stop;
-    exp_row[10] = (float)max_steps; exp_row[11] = ok ? 1.f : 0.f; exp_row[12] = dbg[0]; exp_row[13] = dbg[1];
-    exp_row[14] = dbg[2]; exp_row[15] = dbg[3]; exp_row[16] = dbg[4]; exp_row[17] = dbg[5];
-  }
-#endif
   acc_out = acc;
   return ok;
 }
 
 template <int SURF, bool EXPECT_ONLY>
-__global__ void __launch_bounds__(SWEEP_THREADS, SWEEP_MIN_WAVES) k_mbes_sweep(MbesArgs a) {
+__global__ void __launch_bounds__(SWEEP_THREADS, SURF == 0 ? SWEEP_MIN_WAVES_GRID : SWEEP_MIN_WAVES) k_mbes_sweep(MbesArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sweep_lds[];
   float4* sbeam = (float4*)sweep_lds + 1;  // records -1 and n_beams exist (read, never used)
   float* stail = (float*)(sbeam + a.n_beams + 1);
@@ -279,23 +362,11 @@ __global__ void __launch_bounds__(SWEEP_THREADS, SWEEP_MIN_WAVES) k_mbes_sweep(M
     const MbesPose P = a.pose[i];
     ok = sweep_side<SURF, EXPECT_ONLY>(a, P, sbeam, stail, side, exp_row, acc);
   }
-#ifdef SWEEP_PRINTF
-  if (EXPECT_ONLY && work) printf("sweep i=%lld side=%d ok=%d acc=%g\n", i, side, (int)ok, (double)acc);
-#endif
   // both sides of a particle agree on its fate (the exchange is NOT under `ok &&`: every lane takes part in it)
   const int ok_i = ok ? 1 : 0;
   const int ok_other = __shfl_xor(ok_i, 1, 64);
   const bool ok2 = (ok_i != 0) & (ok_other != 0);
-#ifdef SWEEP_DEBUG
-  if (EXPECT_ONLY && work && side == 0) {
-    exp_row[20] = ok ? 1.f : 0.f;
-    exp_row[21] = (float)ok_other;
-  }
-#endif
   const double acc2 = (double)acc + (double)__shfl_xor(acc, 1, 64);
-#ifdef SWEEP_DEBUG2
-  if (EXPECT_ONLY && work) exp_row[side ? a.n_beams - 1 : a.n_beams - 2] = 500.f + 10.f * ok_i + ok_other;
-#endif
   const bool writer = work && side == 0;
   double v = -__builtin_inf();
   if (writer && ok2 && !EXPECT_ONLY) {

@@ -12,6 +12,13 @@ from smarc_navigation_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _force_sweep(monkeypatch):
+    """The library only sweeps clouds large enough to fill the chip (16 k particles on meshes, 98 k on grids);
+    MCL_SWEEP=1 (read at mcl_create) forces it for the small clouds the oracle can check ray by ray."""
+    monkeypatch.setenv('MCL_SWEEP', '1')
+
+
 @pytest.fixture(scope='module')
 def orc():
     from oracle import oracle
@@ -39,9 +46,7 @@ def _cloud(n, seed, spread, centre):
 
 def _engine(eng, soa, verts, tris, monkeypatch=None, sweep=None, **kw):
     if monkeypatch is not None:
-        if sweep is None:
-            monkeypatch.delenv('MCL_SWEEP', raising=False)
-        else:
+        if sweep is not None:
             monkeypatch.setenv('MCL_SWEEP', '1' if sweep else '0')
     e = eng.Engine(soa.shape[1], rng_mode=eng.RNG_REPLAY, **kw)
     e.set_particles(soa)
@@ -267,3 +272,83 @@ def test_fused_step_with_sweep_matches_separate_calls(eng):
         assert e.mbes_last_path()[0] == 1
         res.append(e.get_particles())
     assert np.array_equal(res[0], res[1])
+
+
+# ------------------------------------------------------------------ height grids (bilinear patches): SURF 0
+@pytest.mark.parametrize('n,B', [(512, 512), (33, 100), (5, 1)])
+def test_grid_sweep_expected_ranges_and_logweights_vs_oracle(n, B, eng, orc):
+    z, origin = _terrain(seed=21)
+    soa = _cloud(n, 3, (4.0, 4.0, 0.3, 0.06, 0.06, 3.0), (5.0, 8.0, -2.0))
+    m2o = synth.rigid_matrix(1.5, -0.5, 0.0, 0.0, 0.0, 0.3)
+    off = [0.3, -0.1, -0.2, 0.01, -0.02, 0.05]
+    ba = synth.beam_angles(B)
+    e = eng.Engine(n, m2o=m2o, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_map_grid(z, origin, 1.0)
+    g = orc.Grid(z, origin, 1.0)
+    got = e.mbes_expected(0, n, ba, 80.0, off)
+    assert e.mbes_last_path()[:2] == (1, 0)
+    _, ref = orc.mbes_update(soa, m2o, off, g, ba, None, 0.2, 80.0)
+    err = np.abs(got - ref)
+    print('grid sweep: max |expected range error| = %.3e m over %d rays' % (err.max(), err.size))
+    assert err.max() <= 1e-3
+    ranges = (ref[0] + 0.2 * np.random.RandomState(1).randn(B)).astype(np.float32)
+    if B > 8:
+        ranges[::7] = 0.0
+        ranges[3] = np.nan
+    e.update_mbes(ranges, ba, 0.2, 80.0, off)
+    assert e.mbes_last_path()[:2] == (1, 0)
+    lw_ref, _ = orc.mbes_update(soa, m2o, off, g, ba, ranges, 0.2, 80.0)
+    rel = np.abs(e.get_log_weights() - lw_ref) / np.maximum(1.0, np.abs(lw_ref))
+    assert rel.max() <= 2e-4
+
+
+def test_grid_sweep_on_twisted_patches_and_grazing_beams(eng, orc, monkeypatch):
+    """Rough terrain: patches with centimetres-to-decimetres of twist, beams that graze crests.  Sweep, traversal
+    kernels and oracle agree ray by ray (a beam grazing a crest may flip between crest and shadow: isolated rays)."""
+    z, origin = _terrain(seed=22, fbm_amp=3.0, swell=4.0)
+    n, B = 1024, 400
+    soa = _cloud(n, 5, (6.0, 6.0, 0.4, 0.05, 0.05, 3.0), (0.0, 0.0, -6.0))
+    ba = synth.beam_angles(B, 1.35)   # out to 77 degrees: shallow incidence, shadows behind every bump
+    g = orc.Grid(z, origin, 1.0)
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, g, ba, None, 0.2, 90.0)
+    res = {}
+    for sweep in (True, False):
+        monkeypatch.setenv('MCL_SWEEP', '1' if sweep else '0')
+        e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+        e.set_particles(soa)
+        e.set_map_grid(z, origin, 1.0)
+        res[sweep] = (e.mbes_expected(0, n, ba, 90.0), e.mbes_last_path())
+    assert res[True][1][0] == 1 and res[False][1][0] == 0
+    print('rough grid: sweep handed over %d of %d' % (res[True][1][1], n))
+    assert res[True][1][1] < n   # (steep terrain: the tilt bound hands the more tilted fans over)
+    for name, got in (('sweep', res[True][0]), ('traversal', res[False][0])):
+        err = np.abs(got - ref)
+        bad = (err > 1e-3).sum()
+        print('rough grid, %s: %d of %d rays differ by more than 1e-3 m (max %.3e)' % (name, bad, err.size, err.max()))
+        assert bad <= max(4, err.size // 20000)
+    jumps = np.abs(np.diff(ref, axis=1)) > 1.0
+    assert jumps.sum() > 50   # the scene really has shadow boundaries
+
+
+def test_grid_ridge_occlusion_and_short_r_max(eng, orc):
+    nx, ny = 160, 160
+    origin = (-80.0, -80.0)
+    x = origin[0] + np.arange(nx)[:, None] + 0.0 * np.arange(ny)[None, :]
+    y = origin[1] + np.arange(ny)[None, :] + 0.0 * np.arange(nx)[:, None]
+    z = (-30.0 + 0.3 * np.sin(x / 5.0) * np.cos(y / 7.0) + 9.0 * np.exp(-((y - 14.0) / 2.5) ** 2)).astype(np.float32)
+    n, B = 64, 512
+    soa = _cloud(n, 2, (2.0, 1.0, 0.2, 0.03, 0.03, 0.05), (0.0, 0.0, -12.0))
+    ba = synth.beam_angles(B, 1.25)
+    g = orc.Grid(z, origin, 1.0)
+    for r_max in (100.0, 24.0):
+        e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+        e.set_particles(soa)
+        e.set_map_grid(z, origin, 1.0)
+        got = e.mbes_expected(0, n, ba, r_max)
+        assert e.mbes_last_path()[0] == 1
+        _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, g, ba, None, 0.2, r_max)
+        err = np.abs(got - ref)
+        flips = (err > 1e-3).sum()
+        print('grid ridge r_max %.0f: %d of %d rays differ (max %.3e)' % (r_max, flips, err.size, err.max()))
+        assert flips <= max(2, err.size // 5000)
