@@ -86,6 +86,8 @@ struct mcl_handle {
   // MBES
   float2* beam_sc = nullptr;
   float* ranges_dev = nullptr;
+  const float* ranges_ptr = nullptr;  // where the ranges of this update are on the device (ranges_dev, or beside the sweep's beam table)
+  bool ranges_pending = false;
   float* exp_dev = nullptr;
   MbesPose* pose_dev = nullptr;
   MbesGroup* mbes_groups = nullptr;  // one record per group of MBES_WAVES particles
@@ -971,11 +973,13 @@ int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, i
     h->b_split = 0;
     while (h->b_split < B && beam_angles[h->b_split] < 0.f) ++h->b_split;
   }
+  // (the ranges travel with the first launch_mbes of the update: in one copy with the sweep's beam table, or alone)
   if (ranges) {
-    RET_IF(upload(h, h->ranges_dev, ranges, sizeof(float) * (size_t)B));
     h->ranges_host.assign(ranges, ranges + B);
+    h->ranges_pending = true;
   } else {
     h->ranges_host.clear();
+    h->ranges_pending = false;
   }
   return MCL_OK;
 }
@@ -983,15 +987,19 @@ int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, i
 // beam table of the fan sweep: side-signed tangent, secant, measured range, weight; and per beam the sum of the
 // squared normalised residuals against r_max over the beams from it to the end of its side (mcl_sweep.h)
 int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max) {
+  // one device block, one copy per update: B records | B tail sums | B measured ranges (for the traversal kernels
+  // that take the hand-overs)
   if (B > h->sweep_cap) {
     if (h->sweep_beams) (void)hipFree(h->sweep_beams);
-    if (h->sweep_tail) (void)hipFree(h->sweep_tail);
-    HIPCHK(h, hipMalloc(&h->sweep_beams, sizeof(float4) * (size_t)B));
-    HIPCHK(h, hipMalloc(&h->sweep_tail, sizeof(float) * (size_t)B));
+    HIPCHK(h, hipMalloc(&h->sweep_beams, (sizeof(float4) + 2 * sizeof(float)) * (size_t)B));
     h->sweep_cap = B;
   }
-  std::vector<float4> tb((size_t)B);
-  std::vector<float> tail((size_t)B, 0.f);
+  h->sweep_tail = (float*)(h->sweep_beams + B);
+  std::vector<float> blk((size_t)B * 6);
+  float4* tb = (float4*)blk.data();
+  float* tail = blk.data() + (size_t)B * 4;
+  float* rng = tail + B;
+  for (int b = 0; b < B; ++b) tail[b] = 0.f;
   const float inv_sigma = (float)(1.0 / sigma), rmaxf = (float)r_max;
   int nvalid = 0;
   for (int b = 0; b < B; ++b) {
@@ -1003,6 +1011,7 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
     tb[b].y = (float)(1.0 / std::cos(ang));
     tb[b].z = valid ? rm : 0.f;
     tb[b].w = valid ? inv_sigma : 0.f;
+    rng[b] = rm;
   }
   auto miss = [&](int b) {
     const float d = (tb[b].z - rmaxf) * tb[b].w;
@@ -1013,8 +1022,9 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
   run = 0.f;
   for (int b = 0; b < h->b_split; ++b) tail[b] = (run += miss(b));
   h->sweep_nvalid = nvalid;
-  RET_IF(upload(h, h->sweep_beams, tb.data(), sizeof(float4) * (size_t)B));
-  RET_IF(upload(h, h->sweep_tail, tail.data(), sizeof(float) * (size_t)B));
+  RET_IF(upload(h, h->sweep_beams, blk.data(), sizeof(float) * blk.size()));
+  h->ranges_ptr = h->sweep_tail + B;
+  h->ranges_pending = false;
   return MCL_OK;
 }
 
@@ -1064,7 +1074,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   for (int k = 0; k < 3; ++k) a.off_t[k] = so[k];
   rot_rpy(so[3], so[4], so[5], a.off_R);
   a.beam_sc = h->beam_sc;
-  a.ranges = with_ranges ? h->ranges_dev : nullptr;
+  a.ranges = nullptr;  // (set below, once the ranges are on the device)
   a.n_beams = B;
   a.sorted = h->beams_sorted ? 1 : 0;
   a.b_lo = h->beam_lo;
@@ -1091,6 +1101,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.defer_idx = nullptr;
   a.defer_count = (int*)(h->ctrl + CTRL_DEFER);
   a.n_dev = nullptr;
+  a.host_count = nullptr;
 #ifdef MBES_STATS
   {
     static unsigned long long* g_stats = nullptr;
@@ -1154,8 +1165,15 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
                  h->n >= sweep_min_n &&
                  h->n < (1ll << 31) && (long long)a.nx * a.ny < (1ll << 31);
     h->sweep_now = sweep;
-    if (sweep) RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max));
+    if (sweep) {
+      RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max));
+    } else if (with_ranges && h->ranges_pending) {
+      RET_IF(upload(h, h->ranges_dev, h->ranges_host.data(), sizeof(float) * (size_t)B));
+      h->ranges_ptr = h->ranges_dev;
+      h->ranges_pending = false;
+    }
   }
+  a.ranges = with_ranges ? h->ranges_ptr : nullptr;
   const bool sweep = h->sweep_now;
   if (sweep) {
     if (!h->defer_idx) HIPCHK(h, hipMalloc(&h->defer_idx, sizeof(u32) * (size_t)h->n));
@@ -1211,6 +1229,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     MbesArgs d = a;
     d.perm = h->defer_idx;
     d.n_dev = a.defer_count;
+    d.host_count = h->work_host + 1;  // (pinned: the classify kernel stores the count there, no copy on the stream)
     // (their loops are grid-stride: the grids only set the parallelism.  After an update that handed nothing over
     //  they are launched small -- three empty 2048-workgroup launches cost 15 us, 2.5 % of the update)
     const bool few = h->work_host[1] == 0;
@@ -1238,7 +1257,6 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     else
       LAUNCH_SWEEP(3, 2);
 #undef LAUNCH_SWEEP
-    HIPCHK(h, hipMemcpyAsync(h->work_host + 1, a.defer_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (h->env_debug_work) {
       int cnt = 0;
       (void)hipMemcpyAsync(&cnt, a.defer_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
@@ -1554,7 +1572,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_beams, h->sweep_tail, h->defer_idx, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_beams, h->defer_idx, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);

@@ -108,6 +108,7 @@ struct MbesArgs {
   u32* defer_idx;             // particles the sweep hands over: the visiting order (perm) of the cast kernels that follow it
   int* defer_count;           // device counter, zeroed with the control block
   const int* n_dev;           // when set, the classify / cast kernels visit *n_dev entries of perm instead of a.n
+  int* host_count;            // pinned host word (or nullptr): k_mbes_classify leaves the hand-over count there
 };
 __device__ __forceinline__ long long mbes_count(const MbesArgs& a) { return a.n_dev ? (long long)*a.n_dev : a.n; }
 
@@ -355,6 +356,7 @@ __global__ void __launch_bounds__(256) k_mbes_keys(MbesArgs a, u32* __restrict__
 // group records and worklist for the visiting order a.perm (same decision as in the pose kernels)
 __global__ void __launch_bounds__(256) k_mbes_classify(MbesArgs a) {
   const long long n = mbes_count(a);
+  if (a.host_count && blockIdx.x == 0 && threadIdx.x == 0) *a.host_count = (int)n;  // (read by the host one update late)
   const long long n_pad = (n + 63) & ~63ll;
   for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < n_pad;
        j += (long long)gridDim.x * blockDim.x) {

@@ -3,7 +3,7 @@
 
     python tools/pmc_summarise.py <dir with pmc_<map>_{fetch,write,sq}/.../*_counter_collection.csv> [out.json]
 
-Per map kind (mesh: the fan sweep k_mbes_sweep; grid: k_mbes_fast) and for the dominant MBES kernel: mean FETCH_SIZE / WRITE_SIZE per dispatch (KB),
+Per map kind (the fan sweep k_mbes_sweep: <2,false> on the mesh, <0,false> on the grid) and for the dominant MBES kernel: mean FETCH_SIZE / WRITE_SIZE per dispatch (KB),
 HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes (gfx950 reports half of a wide
 streaming read: MI355X_MICROARCH.md, HBM section; calibrated in round 1 on k_predict), VALU
 wave-instructions per launch, VALU lane utilisation (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)) and
@@ -41,10 +41,10 @@ def main():
     d = sys.argv[1]
     out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'profiles', 'r02_traffic.json')
     res = {'_how': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (three separate passes) on '
-                   '`python3 bench.py --map <m> --steps 4 --warmup 1 --only-main`, dominant kernel k_mbes_sweep<2,false> (mesh) / k_mbes_fast<0,false> (grid), '
+                   '`python3 bench.py --map <m> --steps 4 --warmup 1 --only-main`, dominant kernel k_mbes_sweep<2,false> (mesh) / k_mbes_sweep<0,false> (grid), '
                    'mean over dispatches; KB -> bytes x1024; FETCH_SIZE doubled (gfx950 reports half of a wide streaming read)',
            '_round': 2, 'source_hash': bench.source_hash()}
-    for kind, prefix in (('mesh', 'void k_mbes_sweep<2, false>'), ('grid', 'void k_mbes_fast<0, false>')):
+    for kind, prefix in (('mesh', 'void k_mbes_sweep<2, false>'), ('grid', 'void k_mbes_sweep<0, false>')):
         e = {}
         f, nf = mean_counter(d, 'pmc_%s_fetch' % kind, prefix, 'FETCH_SIZE')
         w, nw = mean_counter(d, 'pmc_%s_write' % kind, prefix, 'WRITE_SIZE')
