@@ -28,11 +28,19 @@ def _engine_with_map(eng, g, general=False):
     return e, n
 
 
-@pytest.mark.parametrize('name,general', [('mbes_grid_interior', False), ('mbes_grid_rough', False),
-                                          ('mbes_grid_border', False), ('mbes_mesh_regular', False),
-                                          ('mbes_mesh_regular', True), ('mbes_mesh_tin', False)])
-def test_gpu_expected_ranges_and_loglik_match_independent_golden(name, general, eng):
+@pytest.mark.parametrize('name,general,sweep', [('mbes_grid_interior', False, False), ('mbes_grid_rough', False, False),
+                                                ('mbes_grid_border', False, False), ('mbes_mesh_regular', False, False),
+                                                ('mbes_mesh_regular', True, False), ('mbes_mesh_tin', False, False),
+                                                # the fan sweep (mcl_sweep.h), forced for these small pose sets
+                                                ('mbes_mesh_regular', False, True), ('mbes_grid_interior', False, True),
+                                                ('mbes_grid_rough', False, True), ('mbes_grid_border', False, True),
+                                                # ... and on maps wide enough for the whole swath (gen_golden_mbes.py --sweep)
+                                                ('mbes_mesh_sweep', False, True), ('mbes_mesh_sweep_d2', False, True),
+                                                ('mbes_grid_sweep', False, True), ('mbes_grid_sweep_rough', False, True),
+                                                ('mbes_mesh_sweep', False, False), ('mbes_grid_sweep_rough', False, False)])
+def test_gpu_expected_ranges_and_loglik_match_independent_golden(name, general, sweep, eng, monkeypatch):
     g = helpers.load(name)
+    monkeypatch.setenv('MCL_SWEEP', '1' if sweep else '0')
     e, n = _engine_with_map(eng, g, general)
     r_max, sigma = float(g['r_max']), float(g['sigma'])
     got = e.mbes_expected(0, n, g['beam_angles'], r_max, g['sensor_offset'])
@@ -41,6 +49,14 @@ def test_gpu_expected_ranges_and_loglik_match_independent_golden(name, general, 
     print('%s%s: max |range error| %.3e m over %d unambiguous rays (%d at r_max)' % (
         name, ' (general path)' if general else '', err[ok].max(), int(ok.sum()), int((g['expected'] >= r_max)[ok].sum())))
     assert err[ok].max() <= 1e-3
+    path, handed, _ = e.mbes_last_path()
+    assert path == (1 if sweep else 0)
+    if sweep:
+        print('   fan sweep: %d of %d poses handed to the traversal kernels' % (handed, n))
+        # (small maps / rough terrain: the sweep declines, the result is checked either way; the *_sweep maps are
+        #  wide enough for every pose, the rough one may lose the more tilted ones to the slope bound)
+        assert handed < n or name not in ('mbes_grid_interior', 'mbes_grid_sweep_rough')
+        assert handed == 0 or name not in ('mbes_mesh_sweep', 'mbes_mesh_sweep_d2', 'mbes_grid_sweep')
     e.update_mbes(g['ranges'], g['beam_angles'], sigma, r_max, g['sensor_offset'])
     lw = e.get_log_weights()
     fin = np.isfinite(g['lw'])
