@@ -155,7 +155,7 @@ def build_map(kind):
         verts, tris = synth.mesh_from_grid(z, 1.0, origin)
         desc = '%d-triangle mesh (708x708 height field triangulated)' % tris.shape[0]
         if kind == 'mesh-general':
-            desc += ', general triangle-record traversal forced'
+            desc += ', treated as an arbitrary triangle mesh (MCL_MESH_GENERAL: no structured-mesh detection)'
     return dict(kind=kind, z=z, origin=origin, res=1.0, verts=verts, tris=tris, bytes=verts.nbytes + tris.nbytes, desc=desc)
 
 
@@ -594,7 +594,7 @@ def worker(a, rank, world, local_rank):
         if a.map != 'grid':
             legs.append(('grid', dict(m=build_map('grid'), P=1048576, B=512, steps=30, warmup=5)))
         if a.map != 'mesh-general':
-            mg = dict(mesh, kind='mesh-general', desc=mesh['desc'] + ', general triangle-record traversal forced')
+            mg = dict(mesh, kind='mesh-general', desc=mesh['desc'] + ', treated as an arbitrary triangle mesh (MCL_MESH_GENERAL: no structured-mesh detection)')
             legs.append(('mesh_general', dict(m=mg, P=1048576, B=512, steps=20, warmup=3)))
         if a.map != 'mesh-tin':
             legs.append(('mesh_tin', dict(m=build_map('mesh-tin'), P=1048576, B=512, steps=20, warmup=3)))

@@ -24,7 +24,7 @@ auv_ekf_localization/src/correspondence_obj.cpp:80-97; LaserScan beam geometry
 mbes_processors/mbes_toy_processor/src/toy_mbes_manipulator.cpp:69-73.
 
 Re-run:  python oracle/ref_harness/gen_golden_mbes.py      (writes tests/golden/mbes_*.npz, landmarks_knn.npz)
-         python oracle/ref_harness/gen_golden_mbes.py --sweep   (round 2: mbes_*_sweep*.npz, maps wide enough for the fan sweep)
+         python oracle/ref_harness/gen_golden_mbes.py --sweep [names]   (round 2: mbes_*_sweep*.npz, maps wide enough for the fan sweep)
 """
 import os
 import sys
@@ -234,9 +234,12 @@ def make_case(name, kind, amap, m2o, poses, off6, n_beams, half_swath, sigma, r_
         name, exp.size, int(ok.sum()), int((exp >= r_max).sum()), int(np.isfinite(lw).sum()), len(poses)))
 
 
-def sweep_cases():
+def sweep_cases(only=()):
     """Round 2: cases sized for the fan sweep (smarc_navigation_amd/csrc/mcl_sweep.h) -- maps wide enough for the
     whole swath, so that the sweep really casts these poses instead of handing them to the traversal kernels."""
+    def case(name, *args):  # (every case draws its poses from the shared stream whether it is written or not)
+        if not only or name in only:
+            make_case(name, *args)
     rs = np.random.RandomState(4321)
     m2o = synth.rigid_matrix(1.5, -2.0, 0.3, 0.0, 0.0, 0.25)
     off = [0.3, -0.1, -0.2, 0.01, -0.02, 0.05]
@@ -244,19 +247,23 @@ def sweep_cases():
     z = synth.bathymetry_grid(144, 144, 1.0, origin, seed=31)
     for name, diag in (('mbes_mesh_sweep', '00-11'), ('mbes_mesh_sweep_d2', '10-01')):
         verts, tris = synth.mesh_from_grid(z, 1.0, origin, diagonal=diag)
-        make_case(name, 'mesh', dict(verts=verts, tris=tris), m2o,
+        case(name, 'mesh', dict(verts=verts, tris=tris), m2o,
                   poses_over(rs, 12, (1.0, -2.0, -2.0), (2.5, 2.5, 0.3, 0.06, 0.06, 3.0)), off, 64, np.pi / 3, 0.2, 80.0, 7)
-    make_case('mbes_grid_sweep', 'grid', dict(z=z, origin=origin, res=1.0), m2o,
+    case('mbes_grid_sweep', 'grid', dict(z=z, origin=origin, res=1.0), m2o,
               poses_over(rs, 12, (-1.0, 2.0, -2.0), (2.5, 2.5, 0.3, 0.06, 0.06, 3.0)), off, 64, np.pi / 3, 0.2, 80.0, 8)
+    # an irregular TIN over the same terrain (jittered vertices, random diagonals): the sweep walks it by adjacency
+    vt, tt = synth.mesh_tin(z, 1.0, origin, seed=9)
+    case('mbes_tin_sweep', 'mesh', dict(verts=vt, tris=tt), m2o,
+              poses_over(rs, 12, (0.0, 1.0, -2.0), (2.5, 2.5, 0.3, 0.06, 0.06, 3.0)), off, 64, np.pi / 3, 0.2, 80.0, 10)
     # stronger relief (x3): twisted patches, steeper triangles, shadows; moderate tilt so the slope bound holds
     zr = (-20.0 + 3.0 * (z.astype(np.float64) + 20.0)).astype(np.float32)
-    make_case('mbes_grid_sweep_rough', 'grid', dict(z=zr, origin=origin, res=1.0), np.identity(4),
+    case('mbes_grid_sweep_rough', 'grid', dict(z=zr, origin=origin, res=1.0), np.identity(4),
               poses_over(rs, 12, (0.0, 0.0, -1.0), (3.0, 3.0, 0.4, 0.03, 0.03, 3.0)), [0.0] * 6, 72, 1.15, 0.2, 90.0, 9)
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == '--sweep':
-        sweep_cases()
+        sweep_cases(sys.argv[2:])
         return
     rs = np.random.RandomState(1234)
     m2o = synth.rigid_matrix(1.5, -2.0, 0.3, 0.0, 0.0, 0.25)

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/mcl.h"
@@ -31,7 +32,14 @@ struct MeshDev {
   float* heights = nullptr;  // (gx+1)*(gy+1), or nullptr if the mesh is not structured
   size_t n_vertical = 0;  // triangles whose xy projection is degenerate (cannot be a height field)
   int diag_mode = 0;      // structured: 1 = every cell split along 00-11, 2 = along 10-01, 0 = mixed (LSB per cell)
-  double slope_max = 0;   // structured: steepest triangle, |grad h| (the fan sweep's tilt bound, mcl_sweep.h)
+  double slope_max = 0;   // steepest triangle, |grad h| (the fan sweep's tilt bound, mcl_sweep.h)
+  // triangle adjacency for the fan sweep over an arbitrary height-field TIN (mcl_sweep.h: sweep_side_tin):
+  // per triangle two uint4 {v0, v1, v2, -} {neighbour across v0v1, v1v2, v2v0 (0xffffffff: mesh border), -},
+  // per vertex one float4 (x, y, z, -).  tin_ok: every edge has at most two triangles and their third vertices lie
+  // on opposite sides of it in the xy projection (no fold: the mesh is a height field), no vertical triangle.
+  uint4* tin_tri = nullptr;
+  float4* tin_vert = nullptr;
+  bool tin_ok = false;
 };
 
 inline void mesh_free(MeshDev* m) {
@@ -41,6 +49,8 @@ inline void mesh_free(MeshDev* m) {
   if (m->cell_info) (void)hipFree(m->cell_info);
   if (m->tri_mt) (void)hipFree(m->tri_mt);
   if (m->heights) (void)hipFree(m->heights);
+  if (m->tin_tri) (void)hipFree(m->tin_tri);
+  if (m->tin_vert) (void)hipFree(m->tin_vert);
   delete m;
 }
 
@@ -239,7 +249,10 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
           const double det = ax * by - ay * bx;
           rec[r + 0] = make_float4((float)px, (float)py, (float)pd, 0.f);
           rec[r + 1] = make_float4((float)lx, (float)ly, (float)(by / det), (float)(-bx / det));
-          rec[r + 2] = make_float4((float)(-ay / det), (float)(ax / det), 0.f, 0.f);
+          float tid;  // (the source triangle's index rides in the record's spare word: sweep_side_tin's start)
+          const u32 k32 = (u32)k;
+          memcpy(&tid, &k32, 4);
+          rec[r + 2] = make_float4((float)(-ay / det), (float)(ax / det), tid, 0.f);
         } else {
           rec[r + 0] = make_float4(0.f, 0.f, 0.f, 1.f);  // flag: use the Moller-Trumbore record
           rec[r + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -278,6 +291,67 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
     *err = "set_map_mesh: upload failed";
     mesh_free(m);
     return MCL_ERR_HIP;
+  }
+  // ---- triangle adjacency (fan sweep over a TIN): edge -> the (at most two) triangles on it
+  if (!any_vertical && nt < (1ll << 31) && nv < (1ll << 31)) {
+    bool ok = true;
+    std::unordered_map<uint64_t, int64_t> edge_first;  // undirected edge -> 3 * triangle + local edge of the first owner
+    edge_first.reserve((size_t)nt * 2);
+    std::vector<uint4> tt(2 * (size_t)nt);
+    double g2 = 0.0;
+    for (int64_t k = 0; k < nt && ok; ++k) {
+      const u32 v[3] = {tris[3 * k], tris[3 * k + 1], tris[3 * k + 2]};
+      tt[2 * k] = make_uint4(v[0], v[1], v[2], 0u);
+      tt[2 * k + 1] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0u);
+      if (v[0] == v[1] || v[1] == v[2] || v[0] == v[2]) ok = false;
+      // slope of the triangle's plane
+      const float* p0 = verts + 3 * (size_t)v[0];
+      const float* p1 = verts + 3 * (size_t)v[1];
+      const float* p2 = verts + 3 * (size_t)v[2];
+      const double ax = (double)p1[0] - p0[0], ay = (double)p1[1] - p0[1], az = (double)p1[2] - p0[2];
+      const double bx = (double)p2[0] - p0[0], by = (double)p2[1] - p0[1], bz = (double)p2[2] - p0[2];
+      const double nz = ax * by - ay * bx, nx = ay * bz - az * by, ny = az * bx - ax * bz;
+      if (nz == 0.0) ok = false; else g2 = std::max(g2, (nx * nx + ny * ny) / (nz * nz));
+    }
+    for (int64_t k = 0; k < nt && ok; ++k)
+      for (int e = 0; e < 3 && ok; ++e) {
+        const u32 a = tris[3 * k + e], b = tris[3 * k + (e + 1) % 3];
+        const uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+        auto it = edge_first.find(key);
+        if (it == edge_first.end()) {
+          edge_first.emplace(key, 3 * k + e);
+        } else if (it->second < 0) {
+          ok = false;  // a third triangle on this edge
+        } else {
+          const int64_t k2 = it->second / 3;
+          const int e2 = (int)(it->second % 3);
+          // the two third vertices must lie on opposite sides of the edge in the xy projection (no fold)
+          const float* pa = verts + 3 * (size_t)a;
+          const float* pb = verts + 3 * (size_t)b;
+          const float* pc = verts + 3 * (size_t)tris[3 * k + (e + 2) % 3];
+          const float* pd = verts + 3 * (size_t)tris[3 * k2 + (e2 + 2) % 3];
+          const double ex = (double)pb[0] - pa[0], ey = (double)pb[1] - pa[1];
+          const double sc = ex * ((double)pc[1] - pa[1]) - ey * ((double)pc[0] - pa[0]);
+          const double sd = ex * ((double)pd[1] - pa[1]) - ey * ((double)pd[0] - pa[0]);
+          if (!(sc * sd < 0.0)) ok = false;
+          u32* nb1 = &tt[2 * k + 1].x;
+          u32* nb2 = &tt[2 * k2 + 1].x;
+          nb1[e] = (u32)k2;
+          nb2[e2] = (u32)k;
+          it->second = -1;
+        }
+      }
+    if (ok) {
+      std::vector<float4> vv((size_t)nv);
+      for (int64_t i = 0; i < nv; ++i) vv[i] = make_float4(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2], 0.f);
+      if (hipMalloc(&m->tin_tri, sizeof(uint4) * tt.size()) == hipSuccess &&
+          hipMalloc(&m->tin_vert, sizeof(float4) * vv.size()) == hipSuccess &&
+          hipMemcpy(m->tin_tri, tt.data(), sizeof(uint4) * tt.size(), hipMemcpyHostToDevice) == hipSuccess &&
+          hipMemcpy(m->tin_vert, vv.data(), sizeof(float4) * vv.size(), hipMemcpyHostToDevice) == hipSuccess) {
+        m->tin_ok = true;
+        m->slope_max = std::sqrt(g2);
+      }
+    }
   }
   // ---- structured-mesh detection: is this exactly a regular height grid with every cell split into
   // two triangles along one of its diagonals?  Then node heights + one diagonal bit per cell describe
@@ -390,5 +464,9 @@ inline MeshArgs mesh_args(const MeshDev* m) {
   ma.gx = m->gx;
   ma.gy = m->gy;
   ma.cs = (float)m->cs;
+  ma.tin_tri = m->tin_tri;
+  ma.tin_vert = m->tin_vert;
+  ma.x0 = m->x0;
+  ma.y0 = m->y0;
   return ma;
 }

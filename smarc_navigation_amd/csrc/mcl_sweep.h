@@ -332,8 +332,232 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   return ok;
 }
 
+// ------------------------------------------------------------------ arbitrary height-field TINs (SURF 5)
+// The same sweep without the lattice: the triangle across an edge comes from the adjacency table built by
+// mesh_build (mcl_mesh.h: two uint4 per triangle -- vertex ids, neighbour ids), nodes are vertex records (x, y, z).
+// Per step: the neighbour's record (32 B), the one vertex of it that is not on the shared edge (16 B, dependent),
+// plane function and in-plane coordinates from map-frame coordinates (the subtraction of the sensor position is done
+// in fp64: vertices are fp32 inputs, the sensor is not).  The walk ends at a mesh border (hand-over).
+// The start triangle: the (cell, triangle) records of mcl_mesh.h carry their source triangle's index in a spare word.
+__device__ __forceinline__ float tin_nadir(const MbesArgs& a, int I0, int J0, float ul, float vl, float oz, float dx, float dy,
+                                           float dz, u32& tri_id) {
+  // the near-vertical ray O + t (dx, dy, dz), cell by cell through the cell grid (cells of a.mesh.cs metres)
+  const MeshArgs& ma = a.mesh;
+  const float cs = ma.cs, ics = 1.f / cs;
+  const float du = dx * ics, dv = dy * ics;
+  const float rdz = fast_rcp(dz);
+  float t = oz > a.zmax_map ? fmaxf((a.zmax_map - oz) * rdz - 1e-3f, 0.f) : 0.f;
+  const float t1 = fminf(a.r_max, (a.zmin_map - oz) * rdz + 1e-2f);
+  const float pu = fmaf(t, du, ul), pv = fmaf(t, dv, vl);
+  int ci = (int)floorf(pu), cj = (int)floorf(pv);
+  const int sx = du > 0.f ? 1 : -1, sy = dv > 0.f ? 1 : -1;
+  const float adu = fminf(fabsf(fast_rcp(du)), 1e30f), adv = fminf(fabsf(fast_rcp(dv)), 1e30f);
+  float tnx = t + (du > 0.f ? (float)(ci + 1) - pu : pu - (float)ci) * adu;
+  float tny = t + (dv > 0.f ? (float)(cj + 1) - pv : pv - (float)cj) * adv;
+  tri_id = 0xffffffffu;
+  for (int guard = 0; guard < 64; ++guard) {
+    const float t_out = fminf(fminf(tnx, tny), t1);
+    const int gi = min(max(I0 + ci, 0), ma.gx - 1), gj = min(max(J0 + cj, 0), ma.gy - 1);
+    const size_t c = (size_t)gi * ma.gy + gj;
+    const u32 rs = ma.cell_start[c], re = ma.cell_start[c + 1];
+    const float olx = (ul - (float)ci) * cs, oly = (vl - (float)cj) * cs;
+    float best = __builtin_inff();
+    for (u32 k = rs; k < re; ++k) {
+      const float4 r0 = ma.tri[3 * (size_t)k], r1 = ma.tri[3 * (size_t)k + 1], r2 = ma.tri[3 * (size_t)k + 2];
+      const float den = fmaf(r0.x, dx, fmaf(r0.y, dy, dz));
+      const float th = (r0.z - fmaf(r0.x, olx, fmaf(r0.y, oly, oz))) * fast_rcp(den);
+      const float hx = fmaf(th, dx, olx) - r1.x, hy = fmaf(th, dy, oly) - r1.y;
+      const float bu = fmaf(r1.z, hx, r1.w * hy), bv = fmaf(r2.x, hx, r2.y * hy);
+      const float EPS = 2e-5f;
+      if (bu >= -EPS && bv >= -EPS && bu + bv <= 1.f + EPS && th >= 0.f && th <= t_out + 1e-4f && th < best) {
+        best = th;
+        tri_id = __float_as_uint(r2.z);
+      }
+    }
+    if (best < __builtin_inff()) return fminf(best, a.r_max);
+    if (!(t_out < t1)) break;
+    const bool stepx = tnx <= tny;
+    ci += stepx ? sx : 0;
+    cj += stepx ? 0 : sy;
+    tnx += stepx ? adu : 0.f;
+    tny += stepx ? 0.f : adv;
+  }
+  return a.r_max;
+}
+
+template <bool EXPECT_ONLY>
+__device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose& P, const float4* __restrict__ sbeam,
+                                               const float* __restrict__ stail, int side, float* __restrict__ exp_row,
+                                               float& acc_out) {
+  acc_out = 0.f;
+  const MeshArgs& ma = a.mesh;
+  const int nx = a.nx, ny = a.ny, B = a.n_beams;  // (cells + 1 of the cell grid: the mesh's bounding box)
+  bool pre = P.um >= 1.0 && P.um < (double)(nx - 2) && P.vm >= 1.0 && P.vm < (double)(ny - 2);
+  const float c2z = P.c2[2];
+  pre = pre & (c2z >= a.sweep_c2z_min);
+  const double fum = pre ? floor(P.um) : 1.0, fvm = pre ? floor(P.vm) : 1.0;
+  const int I0 = (int)fum, J0 = (int)fvm;
+  const float ul = (float)(P.um - fum), vl = (float)(P.vm - fvm);
+  const float res = a.res, inv_res = (float)a.inv_res, oz = P.oz;
+  const float sg = side ? -1.f : 1.f;
+  int ptr = side ? a.b_split - 1 : a.b_split;
+  const int pstep = side ? -1 : 1, pend = side ? -1 : B;
+  const bool none = ptr == pend;
+  float s_stop = none ? 0.f : a.r_max;
+  if (!none) {
+    const float2 sc = a.beam_sc[side ? 0 : B - 1];
+    const float dz_e = sc.x * P.c1[2] - sc.y * c2z;
+    if (dz_e < -1e-4f) s_stop = fminf(s_stop, (a.zmin_map - oz) * fast_rcp(dz_e) * fabsf(sc.x));
+  }
+  s_stop += 2.f * res;
+  {
+    // (same footprint test as sweep_side, against the mesh's bounding box; holes and ragged borders end the walk)
+    const float rc = fast_rcp(c2z);
+    const float sl = fabsf(P.c1[2]) * (s_stop + 2.f * res);
+    const float t_hi = ((oz - a.zmin_map) + sl) * rc + res, t_lo = fminf(((oz - a.zmax_map) - sl) * rc - res, 0.f);
+    const float s_lo = -2.f * res, s_hi = s_stop + 2.f * res;
+    const float ax = sg * P.c1[0] * inv_res, ay = sg * P.c1[1] * inv_res, bx = -P.c2[0] * inv_res, by = -P.c2[1] * inv_res;
+    const float ux0 = fminf(s_lo * ax, s_hi * ax) + fminf(t_lo * bx, t_hi * bx);
+    const float ux1 = fmaxf(s_lo * ax, s_hi * ax) + fmaxf(t_lo * bx, t_hi * bx);
+    const float vy0 = fminf(s_lo * ay, s_hi * ay) + fminf(t_lo * by, t_hi * by);
+    const float vy1 = fmaxf(s_lo * ay, s_hi * ay) + fmaxf(t_lo * by, t_hi * by);
+    const float fi0 = (float)I0, fj0 = (float)J0;
+    pre = pre & (fi0 + ux0 >= 1.f) & (fi0 + ux1 <= (float)(nx - 2)) & (fj0 + vy0 >= 1.f) & (fj0 + vy1 <= (float)(ny - 2));
+  }
+  if (!pre) return false;
+  u32 T = 0xffffffffu;
+  const float r0 = tin_nadir(a, I0, J0, ul, vl, oz, -P.c2[0], -P.c2[1], -c2z, T);
+  if (!(r0 < a.r_max) || T == 0xffffffffu) return false;
+  if (none) return true;
+  // plane and in-plane coordinates from (x - Ox, y - Oy, z - Oz) in metres
+  const double Ox = ma.x0 + P.um * (double)ma.cs, Oy = ma.y0 + P.vm * (double)ma.cs;
+  const float nx_ = P.c1[1] * P.c2[2] - P.c1[2] * P.c2[1], ny_ = P.c1[2] * P.c2[0] - P.c1[0] * P.c2[2],
+              nz_ = P.c1[0] * P.c2[1] - P.c1[1] * P.c2[0];
+  const float su = sg * P.c1[0], sv = sg * P.c1[1], sz = sg * P.c1[2];
+  const float tu = -P.c2[0], tv = -P.c2[1], tz = -c2z;
+  struct TinNode {
+    u32 id;
+    float d, s, t;
+  };
+  // (member-wise: a select between whole structs goes through scratch)
+  const auto sel = [](bool c, const TinNode& x, const TinNode& y) {
+    TinNode r;
+    r.id = c ? x.id : y.id;
+    r.d = c ? x.d : y.d;
+    r.s = c ? x.s : y.s;
+    r.t = c ? x.t : y.t;
+    return r;
+  };
+  auto node = [&](u32 vid) {
+    const float4 v = ma.tin_vert[vid];
+    const float rx = (float)((double)v.x - Ox), ry = (float)((double)v.y - Oy), rz = v.z - oz;
+    TinNode N;
+    N.id = vid;
+    N.d = fmaf(nx_, rx, fmaf(ny_, ry, nz_ * rz));
+    N.s = fmaf(su, rx, fmaf(sv, ry, sz * rz));
+    N.t = fmaf(tu, rx, fmaf(tv, ry, tz * rz));
+    return N;
+  };
+  TinNode A, Bn;
+  u32 nb;  // the triangle across the current exit edge
+  float s_prev, t_prev, s_cur, t_cur;
+  {
+    const uint4 tv3 = ma.tin_tri[2 * (size_t)T], tn3 = ma.tin_tri[2 * (size_t)T + 1];
+    const TinNode N0 = node(tv3.x), N1 = node(tv3.y), N2 = node(tv3.z);
+    const bool p0b = N0.d > 0.f, p1b = N1.d > 0.f, p2b = N2.d > 0.f;
+    if (p0b == p1b && p1b == p2b) return false;
+    const int L = (p0b != p1b && p0b != p2b) ? 0 : ((p1b != p0b && p1b != p2b) ? 1 : 2);
+    // local vertices L, L+1, L+2; the plane crosses edge L (vL, vL+1) and edge L+2 (vL+2, vL)
+    const TinNode NL = sel(L == 0, N0, sel(L == 1, N1, N2));
+    const TinNode NM = sel(L == 0, N1, sel(L == 1, N2, N0));  // vL+1
+    const TinNode NN = sel(L == 0, N2, sel(L == 1, N0, N1));  // vL+2
+    const u32 nbM = L == 0 ? tn3.x : (L == 1 ? tn3.y : tn3.z);  // across edge L
+    const u32 nbN = L == 0 ? tn3.z : (L == 1 ? tn3.x : tn3.y);  // across edge L+2
+    const float lm = NL.d * fast_rcp(NL.d - NM.d), ln = NL.d * fast_rcp(NL.d - NN.d);
+    const float sm = fmaf(lm, NM.s - NL.s, NL.s), tm = fmaf(lm, NM.t - NL.t, NL.t);
+    const float sn = fmaf(ln, NN.s - NL.s, NL.s), tn = fmaf(ln, NN.t - NL.t, NL.t);
+    if (!(sm != sn)) return false;
+    const bool far_m = sm > sn;
+    const TinNode NF = sel(far_m, NM, NN);
+    const bool pl = NL.d > 0.f;
+    A = sel(pl, NF, NL);   // A: d <= 0, Bn: d > 0
+    Bn = sel(pl, NL, NF);
+    nb = far_m ? nbM : nbN;
+    s_cur = far_m ? sm : sn;
+    t_cur = far_m ? tm : tn;
+    s_prev = far_m ? sn : sm;
+    t_prev = far_m ? tn : tm;
+    if (!(t_cur > 0.f)) return false;
+  }
+  float acc = 0.f;
+  bool ok = true;
+  const int max_steps = (int)(6.f * (s_stop + 4.f * res) * inv_res) + 64;  // (triangles may be much smaller than a cell)
+  int step = 0;
+  float4 bm = sbeam[ptr];
+  for (;;) {
+    // the neighbour's record is in flight while the beams are resolved
+    const bool border = nb == 0xffffffffu;
+    const size_t tq = border ? 0 : (size_t)nb;
+    const uint4 tv3 = ma.tin_tri[2 * tq], tn3 = ma.tin_tri[2 * tq + 1];
+    const float dts = t_cur - t_prev;
+    for (;;) {
+      const float e_cur = fmaf(-bm.x, t_cur, s_cur);
+      if (!(e_cur >= 0.f)) break;
+      const float e_prev = fmaf(-bm.x, t_prev, s_prev);
+      const float lam = fmaxf(fminf(e_prev * fast_rcp(e_prev - e_cur), 1.f), 0.f);
+      const float tau = fmaf(lam, dts, t_prev);
+      const float r = fminf(tau * bm.y, a.r_max);
+      if (EXPECT_ONLY) {
+        exp_row[ptr] = r;
+      } else {
+        const float dd = (bm.z - r) * bm.w;
+        acc = fmaf(dd, dd, acc);
+      }
+      ptr += pstep;
+      bm = sbeam[ptr];
+    }
+    if (ptr == pend) break;
+    if (s_cur > s_stop) break;
+    if (border || ++step > max_steps) {  // the slice runs off the mesh (a hole, a ragged border): not for the sweep
+      ok = false;
+      break;
+    }
+    // the vertex of the neighbour that is not on the shared edge, and the vertex after it (orientation)
+    const int m = (tv3.x != A.id && tv3.x != Bn.id) ? 0 : ((tv3.y != A.id && tv3.y != Bn.id) ? 1 : 2);
+    const u32 vidN = m == 0 ? tv3.x : (m == 1 ? tv3.y : tv3.z);
+    const u32 nextv = m == 0 ? tv3.y : (m == 1 ? tv3.z : tv3.x);
+    const u32 nb_m = m == 0 ? tn3.x : (m == 1 ? tn3.y : tn3.z);   // across edge m = (N, next)
+    const u32 nb_p = m == 0 ? tn3.z : (m == 1 ? tn3.x : tn3.y);   // across edge m+2 = (previous, N)
+    const TinNode N = node(vidN);
+    const bool pos = N.d > 0.f;
+    // pos: N replaces Bn, the exit edge is (A, N); else N replaces A, the exit edge is (N, Bn)
+    const u32 keep = pos ? A.id : Bn.id;
+    nb = nextv == keep ? nb_m : nb_p;
+    A = sel(pos, A, N);
+    Bn = sel(pos, N, Bn);
+    const float lam = A.d * fast_rcp(A.d - Bn.d);
+    s_prev = s_cur;
+    t_prev = t_cur;
+    s_cur = fmaf(lam, Bn.s - A.s, A.s);
+    t_cur = fmaf(lam, Bn.t - A.t, A.t);
+    if (!(t_cur > 0.f)) {
+      ok = false;
+      break;
+    }
+  }
+  if (ok && ptr != pend) {
+    if (EXPECT_ONLY) {
+      for (; ptr != pend; ptr += pstep) exp_row[ptr] = a.r_max;
+    } else {
+      acc += stail[ptr];
+    }
+  }
+  acc_out = acc;
+  return ok;
+}
+
 template <int SURF, bool EXPECT_ONLY>
-__global__ void __launch_bounds__(SWEEP_THREADS, SURF == 0 ? SWEEP_MIN_WAVES_GRID : SWEEP_MIN_WAVES) k_mbes_sweep(MbesArgs a) {
+__global__ void __launch_bounds__(SWEEP_THREADS, (SURF == 0 || SURF == 5) ? SWEEP_MIN_WAVES_GRID : SWEEP_MIN_WAVES) k_mbes_sweep(MbesArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sweep_lds[];
   float4* sbeam = (float4*)sweep_lds + 1;  // records -1 and n_beams exist (read, never used)
   float* stail = (float*)(sbeam + a.n_beams + 1);
@@ -360,7 +584,10 @@ __global__ void __launch_bounds__(SWEEP_THREADS, SURF == 0 ? SWEEP_MIN_WAVES_GRI
   float acc = 0.f;
   if (work) {
     const MbesPose P = a.pose[i];
-    ok = sweep_side<SURF, EXPECT_ONLY>(a, P, sbeam, stail, side, exp_row, acc);
+    if (SURF == 5)
+      ok = sweep_side_tin<EXPECT_ONLY>(a, P, sbeam, stail, side, exp_row, acc);
+    else
+      ok = sweep_side<(SURF == 5 ? 2 : SURF), EXPECT_ONLY>(a, P, sbeam, stail, side, exp_row, acc);
   }
   // both sides of a particle agree on its fate (the exchange is NOT under `ok &&`: every lane takes part in it)
   const int ok_i = ok ? 1 : 0;

@@ -37,6 +37,7 @@ def _engine_with_map(eng, g, general=False):
                                                 # ... and on maps wide enough for the whole swath (gen_golden_mbes.py --sweep)
                                                 ('mbes_mesh_sweep', False, True), ('mbes_mesh_sweep_d2', False, True),
                                                 ('mbes_grid_sweep', False, True), ('mbes_grid_sweep_rough', False, True),
+                                                ('mbes_tin_sweep', False, True), ('mbes_tin_sweep', False, False),
                                                 ('mbes_mesh_sweep', False, False), ('mbes_grid_sweep_rough', False, False)])
 def test_gpu_expected_ranges_and_loglik_match_independent_golden(name, general, sweep, eng, monkeypatch):
     g = helpers.load(name)
@@ -56,7 +57,7 @@ def test_gpu_expected_ranges_and_loglik_match_independent_golden(name, general, 
         # (small maps / rough terrain: the sweep declines, the result is checked either way; the *_sweep maps are
         #  wide enough for every pose, the rough one may lose the more tilted ones to the slope bound)
         assert handed < n or name not in ('mbes_grid_interior', 'mbes_grid_sweep_rough')
-        assert handed == 0 or name not in ('mbes_mesh_sweep', 'mbes_mesh_sweep_d2', 'mbes_grid_sweep')
+        assert handed == 0 or name not in ('mbes_mesh_sweep', 'mbes_mesh_sweep_d2', 'mbes_grid_sweep', 'mbes_tin_sweep')
     e.update_mbes(g['ranges'], g['beam_angles'], sigma, r_max, g['sensor_offset'])
     lw = e.get_log_weights()
     fin = np.isfinite(g['lw'])

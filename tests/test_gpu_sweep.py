@@ -352,3 +352,58 @@ def test_grid_ridge_occlusion_and_short_r_max(eng, orc):
         flips = (err > 1e-3).sum()
         print('grid ridge r_max %.0f: %d of %d rays differ (max %.3e)' % (r_max, flips, err.size, err.max()))
         assert flips <= max(2, err.size // 5000)
+
+
+# ------------------------------------------------------------------ arbitrary height-field TINs: SURF 5 (adjacency walk)
+@pytest.mark.parametrize('n,B', [(512, 512), (40, 33)])
+def test_tin_sweep_expected_ranges_and_logweights_vs_oracle(n, B, eng, orc):
+    z, origin = _terrain(seed=31)
+    verts, tris = synth.mesh_tin(z, 1.0, origin, seed=4)
+    soa = _cloud(n, 3, (4.0, 4.0, 0.3, 0.06, 0.06, 3.0), (5.0, 8.0, -2.0))
+    m2o = synth.rigid_matrix(1.5, -0.5, 0.0, 0.0, 0.0, 0.3)
+    off = [0.3, -0.1, -0.2, 0.01, -0.02, 0.05]
+    ba = synth.beam_angles(B)
+    e = eng.Engine(n, m2o=m2o, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_map_mesh(verts, tris)
+    mesh = orc.Mesh(verts, tris)
+    got = e.mbes_expected(0, n, ba, 80.0, off)
+    assert e.mbes_last_path()[:2] == (1, 0)
+    _, ref = orc.mbes_update(soa, m2o, off, mesh, ba, None, 0.2, 80.0)
+    err = np.abs(got - ref)
+    print('TIN sweep: max |expected range error| = %.3e m over %d rays' % (err.max(), err.size))
+    assert err.max() <= 1e-3
+    ranges = (ref[0] + 0.2 * np.random.RandomState(1).randn(B)).astype(np.float32)
+    ranges[::7] = 0.0
+    e.update_mbes(ranges, ba, 0.2, 80.0, off)
+    assert e.mbes_last_path()[:2] == (1, 0)
+    lw_ref, _ = orc.mbes_update(soa, m2o, off, mesh, ba, ranges, 0.2, 80.0)
+    rel = np.abs(e.get_log_weights() - lw_ref) / np.maximum(1.0, np.abs(lw_ref))
+    assert rel.max() <= 2e-4
+
+
+def test_tin_with_holes_hands_over_and_folded_mesh_is_not_swept(eng, orc):
+    """A TIN with triangles missing: a slice that runs into a hole ends the walk, the particle goes to the traversal
+    kernels.  A mesh with a triangle listed twice (three faces on an edge) has no usable adjacency: traversal only."""
+    z, origin = _terrain(seed=32)
+    verts, tris = synth.mesh_tin(z, 1.0, origin, seed=5)
+    rs = np.random.RandomState(7)
+    keep = np.ones(len(tris), bool)
+    keep[rs.choice(len(tris), 400, replace=False)] = False     # 1 % of the triangles removed: holes
+    n, B = 256, 128
+    soa = _cloud(n, 6, (5.0, 5.0, 0.3, 0.05, 0.05, 3.0), (0.0, 0.0, -2.0))
+    ba = synth.beam_angles(B)
+    holes = np.ascontiguousarray(tris[keep])
+    e = _engine(eng, soa, verts, holes)
+    got = e.mbes_expected(0, n, ba, 80.0)
+    path, handed, _ = e.mbes_last_path()
+    print('TIN with holes: handed over %d of %d' % (handed, n))
+    assert path == 1 and 0 < handed
+    mesh = orc.Mesh(verts, holes)
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, mesh, ba, None, 0.2, 80.0)
+    err = np.abs(got - ref)
+    assert (err > 1e-3).sum() <= 2, err.max()
+    dup = np.ascontiguousarray(np.concatenate([tris, tris[:1]], axis=0))
+    e2 = _engine(eng, soa, verts, dup)
+    e2.mbes_expected(0, n, ba, 80.0)
+    assert e2.mbes_last_path()[0] == 0

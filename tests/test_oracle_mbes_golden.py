@@ -9,7 +9,7 @@ import pytest
 from tests import helpers
 
 GRID_CASES = ['mbes_grid_interior', 'mbes_grid_rough', 'mbes_grid_border', 'mbes_grid_sweep', 'mbes_grid_sweep_rough']
-MESH_CASES = ['mbes_mesh_regular', 'mbes_mesh_tin', 'mbes_mesh_sweep', 'mbes_mesh_sweep_d2']
+MESH_CASES = ['mbes_mesh_regular', 'mbes_mesh_tin', 'mbes_mesh_sweep', 'mbes_mesh_sweep_d2', 'mbes_tin_sweep']
 
 
 @pytest.fixture(scope='module')
