@@ -1161,7 +1161,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     //  heavier) the sweep cannot fill the chip and the wave-per-particle traversal is faster -- measured at 32 k ...
     //  1 M; MCL_SWEEP=1 forces it)
     const long long sweep_min_n = h->env_sweep == 1 ? 1 : (h->map_kind == 0 ? 98304 : 16384);
-    const bool tin = h->map_kind == 1 && !structured && h->mesh->tin_ok;  // a height-field TIN with adjacency
+    // a height-field TIN with adjacency -- also a triangulated height grid whose cells are split along mixed diagonals
+    const bool tin = h->map_kind == 1 && h->mesh->tin_ok && (!structured || a.diag_mode == 0);
     bool sweep = ((structured && (a.diag_mode == 1 || a.diag_mode == 2)) || h->map_kind == 0 || tin) && h->sweep_angles_ok && h->env_sweep != 0 &&
                  h->n >= sweep_min_n &&
                  h->n < (1ll << 31) && (long long)a.nx * a.ny < (1ll << 31);
@@ -1251,24 +1252,26 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       k_mbes_cast<MAPV, true, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);              \
     }                                                                                    \
   } while (0)
-#define LAUNCH_SWEEP_TIN()                                                               \
+#define LAUNCH_SWEEP_TIN(SURFV, MAPV)                                                    \
   do {                                                                                   \
     if (with_ranges) {                                                                   \
       k_mbes_sweep<5, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);               \
       k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
-      k_mbes_fast<4, false><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);                   \
-      k_mbes_cast<1, false, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);                \
+      k_mbes_fast<SURFV, false><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);               \
+      k_mbes_cast<MAPV, false, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);             \
     } else {                                                                             \
       k_mbes_sweep<5, true><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);                \
       k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
-      k_mbes_fast<4, true><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);                    \
-      k_mbes_cast<1, true, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);                 \
+      k_mbes_fast<SURFV, true><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);                \
+      k_mbes_cast<MAPV, true, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);              \
     }                                                                                    \
   } while (0)
     if (h->map_kind == 0)
       LAUNCH_SWEEP(0, 0);
     else if (!structured)
-      LAUNCH_SWEEP_TIN();
+      LAUNCH_SWEEP_TIN(4, 1);   // hand-overs: triangle records
+    else if (a.diag_mode == 0)
+      LAUNCH_SWEEP_TIN(1, 2);   // hand-overs: node heights with the per-cell diagonal bit
     else if (a.diag_mode == 1)
       LAUNCH_SWEEP(2, 2);
     else

@@ -407,3 +407,33 @@ def test_tin_with_holes_hands_over_and_folded_mesh_is_not_swept(eng, orc):
     e2 = _engine(eng, soa, verts, dup)
     e2.mbes_expected(0, n, ba, 80.0)
     assert e2.mbes_last_path()[0] == 0
+
+
+def test_alternating_diagonals_go_through_the_adjacency_sweep(eng, orc):
+    """A triangulated height grid whose cells are split along either diagonal (checkerboard), triangles listed in
+    shuffled order and rotated: no lattice reflection applies, the sweep walks it by adjacency like any TIN."""
+    nx, ny = 150, 140
+    origin = (-75.0, -70.0)
+    z = synth.bathymetry_grid(nx, ny, 1.0, origin, seed=12, fbm_amp=1.0)
+    ixg, iyg = np.meshgrid(np.arange(nx), np.arange(ny), indexing='ij')
+    verts = np.stack([origin[0] + ixg, origin[1] + iyg, z], axis=-1).reshape(-1, 3).astype(np.float32)
+    v00 = (ixg[:-1, :-1] * ny + iyg[:-1, :-1]).reshape(-1)
+    v10, v01, v11 = v00 + ny, v00 + 1, v00 + ny + 1
+    even = ((ixg[:-1, :-1] + iyg[:-1, :-1]) % 2 == 0).reshape(-1)
+    t1 = np.where(even[:, None], np.stack([v00, v10, v11], 1), np.stack([v00, v10, v01], 1))
+    t2 = np.where(even[:, None], np.stack([v00, v11, v01], 1), np.stack([v10, v11, v01], 1))
+    tris = np.concatenate([t1, t2]).astype(np.uint32)
+    rs = np.random.RandomState(1)
+    tris = tris[rs.permutation(tris.shape[0])]
+    roll = rs.randint(3, size=tris.shape[0])
+    tris = np.ascontiguousarray(np.stack([tris[np.arange(len(tris)), (k + roll) % 3] for k in range(3)], axis=1))
+    n, B = 200, 200
+    soa = _cloud(n, 1, (3.0, 3.0, 0.3, 0.06, 0.06, 3.0), (0.0, 0.0, -2.0))
+    ba = synth.beam_angles(B, 1.0)
+    e = _engine(eng, soa, verts, tris)
+    got = e.mbes_expected(0, n, ba, 80.0)
+    assert e.mbes_last_path()[:2] == (1, 0)
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, orc.Mesh(verts, tris), ba, None, 0.2, 80.0)
+    err = np.abs(got - ref)
+    print('alternating diagonals through the adjacency sweep: max range error %.3e' % err.max())
+    assert err.max() <= 1e-3
