@@ -152,6 +152,10 @@ struct mcl_handle {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_state_ready = nullptr, ev_gather_done = nullptr;
   bool gather_inflight = false;
+  // z, roll, pitch of every particle are the odometry's right after motion_pred: the exchange leaves them out
+  bool uni_valid = false;       // true from a predict until the state is written by anything else
+  double uni_val[3] = {0, 0, 0};
+  unsigned gather_uni_mask = 0; // components the last state exchange skipped (phase_gather substitutes uni_val)
   // environment switches, read once in mcl_create (never on the per-measurement path)
   bool env_debug_work = false, env_force_comm = false, env_no_overlap = false;
   // pinned staging so that asynchronous uploads never read caller-owned pageable memory after the call returns
@@ -493,11 +497,13 @@ int exchange_cdf_state(mcl_handle** sh, int ns) {
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather_done, 0));
         h->gather_inflight = false;
       } else {
+        h->gather_uni_mask = h->uni_valid ? 0x1cu : 0u;  // z, roll, pitch: the same on every particle of every shard
         NCCLCHK(h, ncclGroupStart());
         NCCLCHK(h, ncclAllGather(h->ncum + h->goff, h->ncum, (size_t)h->n, ncclUint32, h->comm, h->stream));
         for (int c = 0; c < 6; ++c)
-          NCCLCHK(h, ncclAllGather(h->state[h->cur] + (size_t)c * h->n, h->state_glob + (size_t)c * h->ng,
-                                   (size_t)h->n, ncclDouble, h->comm, h->stream));
+          if (!((h->gather_uni_mask >> c) & 1u))
+            NCCLCHK(h, ncclAllGather(h->state[h->cur] + (size_t)c * h->n, h->state_glob + (size_t)c * h->ng,
+                                     (size_t)h->n, ncclDouble, h->comm, h->stream));
         NCCLCHK(h, ncclGroupEnd());
       }
       t_end(h);
@@ -507,6 +513,7 @@ int exchange_cdf_state(mcl_handle** sh, int ns) {
   for (int s = 0; s < ns; ++s) HIPCHK(sh[s], hipStreamSynchronize(sh[s]->stream));
   for (int d = 0; d < ns; ++d) {
     mcl_handle* D = sh[d];
+    D->gather_uni_mask = 0u;  // (LOCAL groups copy everything)
     RET_IF(set_device(D));
     for (int s = 0; s < ns; ++s) {
       mcl_handle* S = sh[s];
@@ -537,10 +544,13 @@ int start_state_gather(mcl_handle* h) {
   if (!h->comm2 || !h->state_glob) return MCL_OK;
   HIPCHK(h, hipEventRecord(h->ev_state_ready, h->stream));
   HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_state_ready, 0));
+  // 24 B instead of 48 B per particle of the GLOBAL cloud when z, roll, pitch are the odometry's on every particle
+  h->gather_uni_mask = h->uni_valid ? 0x1cu : 0u;
   NCCLCHK(h, ncclGroupStart());
   for (int c = 0; c < 6; ++c)
-    NCCLCHK(h, ncclAllGather(h->state[h->cur] + (size_t)c * h->n, h->state_glob + (size_t)c * h->ng, (size_t)h->n,
-                             ncclDouble, h->comm2, h->comm_stream));
+    if (!((h->gather_uni_mask >> c) & 1u))
+      NCCLCHK(h, ncclAllGather(h->state[h->cur] + (size_t)c * h->n, h->state_glob + (size_t)c * h->ng, (size_t)h->n,
+                               ncclDouble, h->comm2, h->comm_stream));
   NCCLCHK(h, ncclGroupEnd());
   HIPCHK(h, hipEventRecord(h->ev_gather_done, h->comm_stream));
   h->gather_inflight = true;
@@ -594,6 +604,8 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   a.add_noise = 1;
   a.part = h->part;
   a.sums_out = h->scal + 32;
+  a.uni_mask = multi ? h->gather_uni_mask : 0u;
+  for (int c = 0; c < 6; ++c) a.uni[c] = (c >= 2 && c <= 4) ? h->uni_val[c - 2] : 0.0;
   if (with_moments && !multi && h->host_pin_dev) {
     // single shard: the last block writes the sums straight into the pinned ring entry (no copy command);
     // the host reads it only after synchronising the stream
@@ -617,6 +629,8 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   t_end(h);
   HIPCHK(h, hipGetLastError());
   h->cur ^= 1;
+  h->uni_valid = false;  // (the new state carries resampling noise)
+  h->gather_uni_mask = 0u;
   h->step_resample++;
   h->have_cdf = true;
   h->have_lw = false;
@@ -745,6 +759,7 @@ int alt_indices(mcl_handle* h, const double* uniforms, long long nu) {
   return MCL_OK;
 }
 int run_resample_alt(mcl_handle* h, const double* uniforms, long long nu, const double* replay_normals) {
+  h->uni_valid = false;  // (single shard only: no exchange; the new state carries resampling noise)
   RET_IF(alt_indices(h, uniforms, nu));
   // keep/lost/dupes for an arbitrary ancestor vector (auv_pf.py:183-198) + noise
   if (replay_normals) RET_IF(upload_replay(h, replay_normals));
@@ -1408,6 +1423,11 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
   t_end(h);
   HIPCHK(h, hipGetLastError());
   h->step_predict++;
+  // every particle now holds the odometry's depth, roll and pitch (both kernels store these three constants)
+  h->uni_valid = true;
+  h->uni_val[0] = a.z;
+  h->uni_val[1] = a.roll;
+  h->uni_val[2] = a.pitch;
   return MCL_OK;
 }
 
@@ -1622,6 +1642,7 @@ int mcl_init_particles(mcl_handle* h, const double* replay_normals) {
     rp = h->replay_dev;
   }
   RET_IF(cancel_state_gather(h));
+  h->uni_valid = false;
   NoiseArgs a = noise_args(h, h->cfg.init_cov, 0u, 0u);
   t_begin(h, MCL_K_NOISE);
   k_add_noise<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, rp, 1);
@@ -2109,6 +2130,7 @@ int mcl_set_particles(mcl_handle* h, const double* soa) {
   if (!h || !soa) return MCL_ERR_INVALID;
   RET_IF(set_device(h));
   RET_IF(cancel_state_gather(h));
+  h->uni_valid = false;
   HIPCHK(h, hipMemcpyAsync(h->state[h->cur], soa, sizeof(double) * 6 * (size_t)h->n, hipMemcpyHostToDevice,
                            h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));

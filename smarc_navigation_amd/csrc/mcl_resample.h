@@ -287,6 +287,10 @@ struct GatherArgs {
   double* part;      // MOMENTS: [MOM_COUNT][gridDim.x] per-block partial sums
   double* sums_out;  // MOMENTS: 13 sums followed by the 3 shifts
   u32* ticket;       // MOMENTS: zero before the launch, left zero
+  // components the exchange did not gather because every particle of the cloud holds the same value (z, roll,
+  // pitch straight after motion_pred: auv_particle.py:55-57,70): bit c set -> src.c[c] is not read, uni[c] is the value
+  unsigned uni_mask;
+  double uni[6];
 };
 template <bool MOMENTS>
 __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, const double* __restrict__ replay) {
@@ -298,7 +302,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
 #pragma unroll
     for (int c = 0; c < MOM_COUNT; ++c) acc[c] = 0.0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) shift[c] = a.src.c[c][0];  // a member of the cloud, the same on every shard
+    for (int c = 0; c < 3; ++c) shift[c] = ((a.uni_mask >> c) & 1u) ? a.uni[c] : a.src.c[c][0];  // a member of the cloud, the same on every shard
   }
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < a.n;
        i += (long long)gridDim.x * blockDim.x) {
@@ -317,7 +321,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
     double v[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      v[c] = a.src.c[c][src] + a.nz.sq[c] * z[c];
+      v[c] = (((a.uni_mask >> c) & 1u) ? a.uni[c] : a.src.c[c][src]) + a.nz.sq[c] * z[c];
       a.dst.c[c][i] = v[c];
     }
     if (MOMENTS) {

@@ -347,6 +347,52 @@ def test_rccl_paths_with_one_rank_match_plain_filter(eng, monkeypatch):
         np.testing.assert_allclose(mean, results[0][1], rtol=1e-13, atol=1e-13)
 
 
+@pytest.mark.parametrize('fused', [True, False])
+def test_state_exchange_leaves_out_the_components_predict_made_uniform(fused, eng, monkeypatch):
+    """After motion_pred every particle holds the odometry's depth, roll and pitch, so the pre-resample state
+    exchange only gathers x, y, yaw (24 B instead of 48 B per particle of the global cloud) and the gather kernel
+    substitutes the three constants -- bit for bit the plain filter, with resampling noise on ALL six components,
+    a rolled and pitched vehicle, and a resample that does NOT follow a predict (set_particles: full exchange)."""
+    from smarc_navigation_amd import synth
+    from oracle import oracle as orc
+    n, B = 16384, 64
+    origin = (-64.0, -64.0)
+    z = synth.bathymetry_grid(128, 128, 1.0, origin, seed=3)
+    ba = synth.beam_angles(B)
+    cov = dict(init_cov=[1, 1, 0.04, 0.0025, 0.0025, 0.01], process_cov=[1e-3, 1e-3, 0, 0, 0, 1e-5],
+               resample_cov=[0.01, 0.01, 0.0025, 1e-4, 1e-4, 1e-4], seed=22)
+    q = orc.quat_from_euler(0.03, -0.05, 0.1)
+    ranges = np.full(B, 21.0, np.float32)
+    results = []
+    for force, no_overlap in (('0', '0'), ('1', '0'), ('1', '1')):
+        monkeypatch.setenv('MCL_FORCE_COMM', force)
+        monkeypatch.setenv('MCL_NO_OVERLAP', no_overlap)
+        e = eng.Engine(n, **cov)
+        e.comm_init(eng.comm_unique_id())
+        e.set_map_grid(z, origin, 1.0)
+        e.init_particles()
+        for k in range(3):
+            if fused:
+                e.step_mbes([1.0, 0.0, 0.0], 0.02, q, -2.0 - 0.1 * k, 0.02, ranges, ba, 0.5, 80.0)
+            else:
+                e.predict([1.0, 0.0, 0.0], 0.02, q, -2.0 - 0.1 * k, 0.02)
+                e.update_mbes(ranges, ba, 0.5, 80.0)
+                e.resample()
+        st1 = e.get_particles()
+        # a resample that does not follow a predict: nothing is uniform, everything is exchanged
+        soa = st1.copy()
+        soa[2] += np.linspace(0.0, 1.0, n)
+        e.set_particles(soa)
+        e.update_mbes(ranges, ba, 0.5, 80.0)
+        e.resample()
+        results.append((st1, e.get_particles()))
+        e.close()
+    for st1, st2 in results[1:]:
+        assert np.array_equal(st1, results[0][0])
+        assert np.array_equal(st2, results[0][1])
+    assert np.ptp(results[0][1][2]) > 0.2   # the second resample really carried distinct depths
+
+
 def test_comm_shutdown_and_reinit_without_overlap(eng, monkeypatch):
     """The fall-back bench.py takes when the overlap self-test fails: abort both communicators,
     re-initialise under a fresh id with MCL_COMM_NO_OVERLAP, same results.  Also: a step that fails after
