@@ -1179,7 +1179,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     // a height-field TIN with adjacency -- also a triangulated height grid whose cells are split along mixed diagonals
     const bool tin = h->map_kind == 1 && h->mesh->tin_ok && (!structured || a.diag_mode == 0);
     bool sweep = ((structured && (a.diag_mode == 1 || a.diag_mode == 2)) || h->map_kind == 0 || tin) && h->sweep_angles_ok && h->env_sweep != 0 &&
-                 h->n >= sweep_min_n &&
+                 h->ng >= sweep_min_n &&  // (the GLOBAL count: every shard of a cloud takes the same path, results do not depend on the GPU count)
                  h->n < (1ll << 31) && (long long)a.nx * a.ny < (1ll << 31);
     h->sweep_now = sweep;
     if (sweep) {

@@ -437,3 +437,39 @@ def test_alternating_diagonals_go_through_the_adjacency_sweep(eng, orc):
     err = np.abs(got - ref)
     print('alternating diagonals through the adjacency sweep: max range error %.3e' % err.max())
     assert err.max() <= 1e-3
+
+
+def test_sharded_sweep_is_bitwise_the_unsharded_one(eng, monkeypatch):
+    """The sweep casts every particle with its own two lanes -- no tiles, no groups -- so its log-likelihoods do not
+    depend on where a particle sits in the launch, and the path is chosen by the GLOBAL particle count: 4 shards of
+    8 192 (below the sweep's threshold on their own) reproduce the 32 768-particle filter bit for bit, MBES update,
+    resample indices and states."""
+    monkeypatch.delenv('MCL_SWEEP', raising=False)   # the library's own choice
+    z, origin = _terrain(seed=41)
+    verts, tris = synth.mesh_from_grid(z, 1.0, origin)
+    shards, n = 4, 32768
+    cov = dict(init_cov=[1.0, 1.0, 0, 0, 0, 0.01], process_cov=[1e-3, 1e-3, 0, 0, 0, 1e-5],
+               resample_cov=[0.01, 0.01, 0, 0, 0, 1e-4], seed=7)
+    one = eng.Engine(n, **cov)
+    many = [eng.Engine(n // shards, rank=r, world=shards, n_global=n, global_offset=r * (n // shards), **cov)
+            for r in range(shards)]
+    B = 96
+    ba = synth.beam_angles(B)
+    ranges = np.full(B, 24.0, np.float32)
+    from oracle import oracle as orc
+    q = orc.quat_from_euler(0.01, 0.02, 0.3)
+    for e in [one] + many:
+        e.set_map_mesh(verts, tris)
+        e.init_particles()
+    for step in range(3):
+        for e in [one] + many:
+            e.predict([1.0, 0.05, 0.0], 0.02, q, -2.0, 0.02)
+            e.update_mbes(ranges, ba, 0.4, 80.0)
+            assert e.mbes_last_path()[:2] == (1, 0)
+        lw1 = one.get_log_weights()
+        lwm = np.concatenate([e.get_log_weights() for e in many])
+        assert np.array_equal(lw1, lwm), step
+        one.resample()
+        eng.group_resample(many)
+        assert np.array_equal(one.last_indices(), np.concatenate([e.last_indices() for e in many]))
+        assert np.array_equal(one.get_particles(), np.concatenate([e.get_particles() for e in many], axis=1)), step
