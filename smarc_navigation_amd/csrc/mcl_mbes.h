@@ -1,18 +1,19 @@
-// mcl_mbes.h -- MBES measurement update: per-particle, per-beam ray-cast against the bathymetric
-// map -> expected ranges -> Gaussian log-likelihood (north_star; no reference symbol).
+// mcl_mbes.h -- MBES measurement update by RAY TRAVERSAL: per-particle, per-beam ray-cast against the bathymetric
+// map -> expected ranges -> Gaussian log-likelihood (north_star; no reference symbol).  Since round 2 the
+// default on regular meshes, height grids and height-field TINs is the fan sweep (mcl_sweep.h); these kernels cast
+// what the sweep does not cover (triangle soups with vertical faces / folds / non-manifold edges, unsorted beam tables,
+// small clouds) and the particles it hands over.  Shared by both: the pose records, MbesArgs, cast_clear.
 //
-// Two kernels per update:
-//   k_mbes_pose : one thread per particle, fp64 -> sensor pose record (origin in map cell units,
-//                 two columns of R_map_sensor) in HBM (48 B/particle).
-//   k_mbes_cast : one WAVEFRONT per particle, lanes = consecutive beams (a fan is coherent:
-//                 neighbouring lanes walk neighbouring cells).  A workgroup of MBES_WAVES particles
-//                 reduces the footprint of its fans, stages the bounding map tile into LDS once
-//                 (heights for a grid, per-cell z-ranges for a mesh), then every ray runs a
-//                 "while-while" traversal in fp32 tile-local coordinates: a cheap 2-D DDA loop that
-//                 only looks for the next candidate cell (LDS reject test), and a reconverged exact
-//                 test (bilinear-patch quadratic / Moller-Trumbore on the cell's triangle records).
-// Bound: VALU issue + LDS reads (rocprof: VALU pipe ~87 % busy); compulsory HBM traffic is only
-// 48 B + 8 B per particle plus the map tile reads (L2-resident).
+//   k_mbes_pose / k_predict_pose : one thread per particle, fp64 -> sensor pose record (origin in map cell units,
+//                 two columns of R_map_sensor) in HBM (48 B/particle); <true>: also the tile window and fast-path
+//                 eligibility of every group of MBES_WAVES particles (classify_group).
+//   k_mbes_fast : one WAVEFRONT per particle, lanes = consecutive beams (a fan is coherent: neighbouring lanes walk
+//                 neighbouring cells), MBES_WAVES particles per workgroup share one LDS tile (heights; cell words for
+//                 triangle records); the ray follows the surface's clearance cell by cell (cast_clear).
+//   k_mbes_cast : the general kernel -- groups whose window is clipped by the map border or larger than LDS, sensors
+//                 off the map, global-memory march (cast_ray), triangle records (records_hit).
+// Bound: VALU issue + LDS reads; compulsory HBM traffic is only 48 B + 8 B per particle plus the map tile reads
+// (L2-resident).
 #pragma once
 #include <hip/hip_fp16.h>
 

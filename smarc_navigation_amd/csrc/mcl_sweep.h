@@ -1,4 +1,6 @@
-// mcl_sweep.h -- MBES update on a regularly triangulated height mesh WITHOUT a traversal per ray: the fan sweep.
+// mcl_sweep.h -- MBES update WITHOUT a traversal per ray: the fan sweep.  Three surfaces: regularly triangulated
+// height meshes (lattice walk, SURF 2 / 3), height grids with bilinear patches (SURF 0) and arbitrary height-field
+// TINs (adjacency walk, SURF 5: sweep_side_tin below).  The idea, for a triangulated surface:
 //
 // The beams of one ping lie in one plane through the sensor (D_b = sin a_b c1 - cos a_b c2, mcl_mbes.h), so all
 // 512 expected ranges of a particle are intersections of rays from ONE point with ONE curve: the slice of the
