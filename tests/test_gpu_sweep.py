@@ -473,3 +473,53 @@ def test_sharded_sweep_is_bitwise_the_unsharded_one(eng, monkeypatch):
         eng.group_resample(many)
         assert np.array_equal(one.last_indices(), np.concatenate([e.last_indices() for e in many]))
         assert np.array_equal(one.get_particles(), np.concatenate([e.get_particles() for e in many], axis=1)), step
+
+
+@pytest.mark.parametrize('seed', range(18))
+def test_sweep_fuzz_against_the_oracle(seed, eng, orc):
+    """Random scenes: map kind (regular mesh of either diagonal, height grid, TIN), resolution, relief, vehicle
+    attitude, sensor offset, map<-odom transform, swath, beam count, r_max.  Every ray the sweep casts (and every
+    one it hands over) equals the fp64 oracle's within 1e-3 m, up to isolated grazing rays."""
+    rs = np.random.RandomState(1000 + seed)
+    kind = ('mesh', 'mesh2', 'grid', 'tin')[seed % 4]
+    res = float(rs.choice([0.5, 1.0, 2.0]))
+    nx, ny = int(150 / res) + rs.randint(0, 30), int(150 / res) + rs.randint(0, 30)
+    origin = (-0.5 * nx * res + rs.uniform(-5, 5), -0.5 * ny * res + rs.uniform(-5, 5))
+    z = synth.bathymetry_grid(nx, ny, res, origin, seed=seed, depth=-rs.uniform(12.0, 35.0),
+                              swell=rs.uniform(0.0, 4.0), fbm_amp=rs.uniform(0.1, 1.5))
+    n = 192
+    B = int(rs.choice([7, 64, 257]))
+    tilt = rs.choice([0.0, 0.03, 0.12])
+    soa = _cloud(n, seed, (6.0, 6.0, 0.5, tilt, tilt, 3.0), (rs.uniform(-8, 8), rs.uniform(-8, 8), -rs.uniform(0.5, 6.0)))
+    m2o = synth.rigid_matrix(rs.uniform(-3, 3), rs.uniform(-3, 3), rs.uniform(-0.5, 0.5), 0.0, 0.0, rs.uniform(-3, 3))
+    off = [rs.uniform(-0.5, 0.5), rs.uniform(-0.5, 0.5), rs.uniform(-0.3, 0.3), rs.uniform(-0.05, 0.05), rs.uniform(-0.05, 0.05), rs.uniform(-0.2, 0.2)]
+    ba = synth.beam_angles(B, rs.uniform(0.6, 1.3))
+    r_max = float(rs.choice([40.0, 80.0, 150.0]))
+    e = eng.Engine(n, m2o=m2o, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    if kind == 'grid':
+        e.set_map_grid(z, origin, res)
+        omap = orc.Grid(z, origin, res)
+    else:
+        if kind == 'tin':
+            verts, tris = synth.mesh_tin(z, res, origin, seed=seed)
+        else:
+            verts, tris = synth.mesh_from_grid(z, res, origin, diagonal='00-11' if kind == 'mesh' else '10-01')
+        e.set_map_mesh(verts, tris)
+        omap = orc.Mesh(verts, tris)
+    got = e.mbes_expected(0, n, ba, r_max, off)
+    path, handed, _ = e.mbes_last_path()
+    assert path == 1
+    _, ref = orc.mbes_update(soa, m2o, off, omap, ba, None, 0.2, r_max)
+    err = np.abs(got - ref)
+    bad = int((err > 1e-3).sum())
+    print('fuzz %d %s res %.1f B %d tilt %.2f r_max %.0f: handed over %d/%d, max err %.2e, rays off %d/%d' % (
+        seed, kind, res, B, tilt, r_max, handed, n, err.max(), bad, err.size))
+    assert bad <= max(1, err.size // 5000)
+    ranges = (ref[rs.randint(n)] + 0.2 * rs.randn(B)).astype(np.float32)
+    ranges[rs.randint(B)] = 0.0
+    e.update_mbes(ranges, ba, 0.2, r_max, off)
+    lw_ref, _ = orc.mbes_update(soa, m2o, off, omap, ba, ranges, 0.2, r_max)
+    d = np.abs(e.get_log_weights() - lw_ref)
+    okm = (d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref))
+    assert (~okm).sum() <= (1 if bad else 0) + n // 100
