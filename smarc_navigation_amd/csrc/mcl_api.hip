@@ -31,10 +31,11 @@
 // control block layout (bytes)
 #define CTRL_SLOTS 0                       // MCL_MAX_SLOTS u64
 #define CTRL_WORK (8 * MCL_MAX_SLOTS)      // int: groups deferred by the fast MBES kernel
-#define CTRL_DEFER (CTRL_WORK + 4)         // int: particles the fan sweep handed to the general kernel
-#define CTRL_T_QUANT (CTRL_WORK + 8)       // u32 tickets, self-resetting
-#define CTRL_T_EXPAND (CTRL_WORK + 12)
-#define CTRL_T_GATHER (CTRL_WORK + 16)
+#define CTRL_DEFER (CTRL_WORK + 4)         // int: particles the first sweep pass declined
+#define CTRL_DEFER2 (CTRL_WORK + 8)        // int: particles the bounds-checked second pass handed to the traversal kernels
+#define CTRL_T_QUANT (CTRL_WORK + 12)      // u32 tickets, self-resetting
+#define CTRL_T_EXPAND (CTRL_WORK + 16)
+#define CTRL_T_GATHER (CTRL_WORK + 20)
 #define CTRL_BYTES 1024
 
 namespace {
@@ -121,9 +122,11 @@ struct mcl_handle {
   float* sweep_tail = nullptr;
   int sweep_cap = 0;
   u32* defer_idx = nullptr;
+  u32* defer_idx2 = nullptr;        // what the bounds-checked second pass hands on
   int env_sweep = -1;               // MCL_SWEEP=0/1 forces the decision (tests, A/B)
   bool sweep_now = false;           // decided by the first launch_mbes call of an update
   bool sweep_bad = false;           // the last sweep handed over more than 1/16 of the particles
+  bool sweep_two_pass = false;      // lattice maps: a bounds-checked second pass precedes the traversal kernels
   int sweep_nvalid = 0;
   float* grid = nullptr;
   int gnx = 0, gny = 0;
@@ -1194,6 +1197,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   const bool sweep = h->sweep_now;
   if (sweep) {
     if (!h->defer_idx) HIPCHK(h, hipMalloc(&h->defer_idx, sizeof(u32) * (size_t)h->n));
+    if (!h->defer_idx2) HIPCHK(h, hipMalloc(&h->defer_idx2, sizeof(u32) * (size_t)h->n));
     a.sweep_beams = h->sweep_beams;
     a.sweep_tail = h->sweep_tail;
     a.b_split = h->b_split;
@@ -1212,9 +1216,9 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   if (!pose_done) {
     // (the fused predict has already reset the control block and written poses, group records and worklist)
     if (a.max_slots)
-      HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_DEFER + sizeof(int), h->stream));  // slots + work and hand-over counters
+      HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_DEFER2 + sizeof(int), h->stream));  // slots + work and hand-over counters
     else
-      HIPCHK(h, hipMemsetAsync(a.work_count, 0, 2 * sizeof(int), h->stream));
+      HIPCHK(h, hipMemsetAsync(a.work_count, 0, 3 * sizeof(int), h->stream));
     if (lean && !sweep)
       k_mbes_pose<true><<<grid_for(h->n), 256, 0, h->stream>>>(a);
     else
@@ -1227,6 +1231,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       HIPCHK(h, hipHostMalloc(&h->work_host, 64, hipHostMallocDefault));
       h->work_host[0] = 0;
       h->work_host[1] = 0;
+      h->work_host[2] = 0;
     }
     // The hand-over count of the previous sweep, read one call late (no synchronisation).  When it was large (a
     // cloud on the map border, a fan too tilted for the terrain) the particles are visited in Morton order: the
@@ -1241,27 +1246,40 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     const long long n_lanes = 2 * ((!with_ranges && !a.perm) ? std::max<long long>(std::min<long long>(exp_count, h->n - exp_first), 1) : h->n);
     const int sgrid = (int)((n_lanes + SWEEP_THREADS - 1) / SWEEP_THREADS);
     const size_t lds = (size_t)(B + 2) * sizeof(float4) + (size_t)B * sizeof(float);
-    // what the sweep hands over is cast the old way, in the order of the hand-over list: group records and
-    // worklist (k_mbes_classify), the fast kernel, the general kernel -- all three read the count on the device
-    MbesArgs d = a;
-    d.perm = h->defer_idx;
-    d.n_dev = a.defer_count;
+    // What the first pass declines goes through a second, bounds-checked pass (lattice maps: a slice that leaves the
+    // map ends there), and what that one declines is cast the old way, in the order of its hand-over list: group
+    // records and worklist (k_mbes_classify), the fast kernel, the general kernel.  All of them read the length of
+    // their list on the device.
+    const bool lattice = h->map_kind == 0 || (structured && a.diag_mode != 0);
+    h->sweep_two_pass = lattice;
+    MbesArgs c = a;   // second pass
+    c.perm = h->defer_idx;
+    c.n_dev = a.defer_count;
+    c.defer_idx = h->defer_idx2;
+    c.defer_count = (int*)(h->ctrl + CTRL_DEFER2);
+    c.host_count = h->work_host + 2;
+    MbesArgs d = a;   // traversal kernels
+    d.perm = lattice ? h->defer_idx2 : h->defer_idx;
+    d.n_dev = lattice ? c.defer_count : a.defer_count;
     d.host_count = h->work_host + 1;  // (pinned: the classify kernel stores the count there, no copy on the stream)
     // (their loops are grid-stride: the grids only set the parallelism.  After an update that handed nothing over
     //  they are launched small -- three empty 2048-workgroup launches cost 15 us, 2.5 % of the update)
-    const bool few = h->work_host[1] == 0;
+    const bool few = h->work_host[1] == 0, few2 = h->work_host[2] == 0;
     const int cgrid = (int)std::min<long long>(grid_for(h->n), few ? 32 : 1024);
     const int fgrid = (int)std::min<long long>(ngroups, few ? 64 : 2048);
     const int dgrid = (int)std::min<long long>(ngroups, few ? 64 : 512);
+    const int s2grid = (int)std::min<long long>(sgrid, few2 ? 32 : 4096);
 #define LAUNCH_SWEEP(SURFV, MAPV)                                                        \
   do {                                                                                   \
     if (with_ranges) {                                                                   \
-      k_mbes_sweep<SURFV, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);           \
+      k_mbes_sweep<SURFV, false, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);    \
+      k_mbes_sweep<SURFV, false, true><<<s2grid, SWEEP_THREADS, lds, h->stream>>>(c);    \
       k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
       k_mbes_fast<SURFV, false><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);               \
       k_mbes_cast<MAPV, false, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);             \
     } else {                                                                             \
-      k_mbes_sweep<SURFV, true><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);            \
+      k_mbes_sweep<SURFV, true, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);     \
+      k_mbes_sweep<SURFV, true, true><<<s2grid, SWEEP_THREADS, lds, h->stream>>>(c);     \
       k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
       k_mbes_fast<SURFV, true><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);                \
       k_mbes_cast<MAPV, true, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);              \
@@ -1311,6 +1329,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       HIPCHK(h, hipHostMalloc(&h->work_host, 64, hipHostMallocDefault));
       h->work_host[0] = 0;
       h->work_host[1] = 0;
+      h->work_host[2] = 0;
     }
     const bool sort_now = h->env_sort >= 0 ? h->env_sort == 1 : h->sort_visits;
     h->sort_visits = (long long)h->work_host[0] * 16 > ngroups;
@@ -1410,7 +1429,7 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
   }
   if (pose_for && !rp && h->cfg.rng_mode == MCL_RNG_NATIVE) {
     // reset the slots + work counter first: the kernel appends the deferred groups to the worklist
-    HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_DEFER + sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_DEFER2 + sizeof(int), h->stream));
     const bool lean = !pose_for->sweep_beams;  // the fan sweep needs no group records
     if (lean)
       k_predict_pose<true><<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, *pose_for);
@@ -1613,7 +1632,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_beams, h->defer_idx, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_beams, h->defer_idx, h->defer_idx2, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -2411,10 +2430,10 @@ int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64
   if (!h) return MCL_ERR_INVALID;
   RET_IF(set_device(h));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  int cnt[2] = {0, 0};
+  int cnt[3] = {0, 0, 0};  // deferred groups, declined by the first sweep pass, declined by the second
   HIPCHK(h, hipMemcpy(cnt, h->ctrl + CTRL_WORK, sizeof cnt, hipMemcpyDeviceToHost));
   if (path) *path = h->sweep_now ? 1 : 0;
-  if (handed_over) *handed_over = h->sweep_now ? cnt[1] : 0;
+  if (handed_over) *handed_over = h->sweep_now ? (h->sweep_two_pass ? cnt[2] : cnt[1]) : 0;
   if (deferred_groups) *deferred_groups = cnt[0];
   return MCL_OK;
 }

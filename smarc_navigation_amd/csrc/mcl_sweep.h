@@ -30,7 +30,7 @@
 #define SWEEP_THREADS 256
 #endif
 #ifndef SWEEP_MIN_WAVES_GRID
-#define SWEEP_MIN_WAVES_GRID 6   // height grids carry the conic of the current cell as well (<= 80 VGPRs)
+#define SWEEP_MIN_WAVES_GRID 6   // height grids carry the conic of the current cell as well (<= 80 VGPRs); so does the bounds-checked second pass
 #endif
 #ifndef SWEEP_MIN_WAVES
 #define SWEEP_MIN_WAVES 8   // waves per SIMD the register budget is held to (<= 64 VGPRs)
@@ -56,7 +56,13 @@ struct SweepNode {
 //   twist -- and is then tested against the same quadratic.
 // Returns false when the particle has to go to the general kernel.  acc: sum over this side's beams of
 // ((range - expected) * weight)^2; EXPECT_ONLY: expected ranges to exp_row[b] instead.
-template <int SURF, bool EXPECT_ONLY>
+// CHECKED (second pass, over what the first one declined): the footprint need not lie inside the map -- every node is
+//   tested against the map's bounds, and a slice that leaves the map ENDS there: the beams left return r_max (a mesh
+//   has no side walls; a ray from inside a grid never re-enters it).  That conclusion needs the slice to cross the
+//   border line once: the fan plane is vertical (a straight track), or the track meets the border at more than ~64
+//   degrees (|cos| >= 0.9: with the tilt bound the border's trace in the fan plane is then steeper than the slice).
+//   Anything else goes on to the traversal kernels.
+template <int SURF, bool EXPECT_ONLY, bool CHECKED = false>
 __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P, const float4* __restrict__ sbeam,
                                            const float* __restrict__ stail, int side, float* __restrict__ exp_row,
                                            float& acc_out) {
@@ -96,7 +102,14 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     const float vy0 = fminf(s_lo * ay, s_hi * ay) + fminf(t_lo * by, t_hi * by);
     const float vy1 = fmaxf(s_lo * ay, s_hi * ay) + fmaxf(t_lo * by, t_hi * by);
     const float fi0 = (float)I0, fj0 = (float)J0;
-    pre = pre & (fi0 + ux0 >= 3.f) & (fi0 + ux1 <= (float)(nx - 5)) & (fj0 + vy0 >= 3.f) & (fj0 + vy1 <= (float)(ny - 5));
+    if (!CHECKED) {
+      pre = pre & (fi0 + ux0 >= 3.f) & (fi0 + ux1 <= (float)(nx - 5)) & (fj0 + vy0 >= 3.f) & (fj0 + vy1 <= (float)(ny - 5));
+    } else {
+      // only the nadir ray (cast below without bounds tests) has to stay inside: t in [t_lo, t_hi] along -c2
+      const float n0 = fminf(t_lo * bx, t_hi * bx), n1 = fmaxf(t_lo * bx, t_hi * bx);
+      const float m0 = fminf(t_lo * by, t_hi * by), m1 = fmaxf(t_lo * by, t_hi * by);
+      pre = pre & (fi0 + n0 >= 3.f) & (fi0 + n1 <= (float)(nx - 5)) & (fj0 + m0 >= 3.f) & (fj0 + m1 <= (float)(ny - 5));
+    }
     pre = pre & (s_hi * fmaxf(fabsf(ax), fabsf(ay)) + fmaxf(-t_lo, t_hi) * fmaxf(fabsf(bx), fabsf(by)) < 30000.f);  // packed coordinates
   }
   if (!pre) SWEEP_FAIL(1);
@@ -198,6 +211,8 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     const int nj = __builtin_amdgcn_sbfe(Nk, 0, 16), ni = (Nk - nj) >> 16;
     // (the footprint test keeps a sane walk inside the map; the clamp keeps a NaN-driven one from reading outside it)
     const float hN = grid[(unsigned)min(max(g0i + ni * ny + nj, 0), g_hi)];
+    // CHECKED: is that node on the map at all?  (if not, the slice leaves the map through the edge it stands on)
+    const bool off_x = CHECKED && (unsigned)(I0 + ni) >= (unsigned)nx, off_y = CHECKED && (unsigned)(J0 + nj) >= (unsigned)ny;
     const float dts = t_cur - t_prev;
     if (cur_edge) {
       // SURF 0: the patch of the cell the arc (prev -> cur) lies in = the cell of the triangle (A, Bn, C)
@@ -291,6 +306,13 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     }
     if (ptr == pend) break;
     if (s_cur > s_stop) break;  // every beam left misses inside r_max (tail below)
+    if (CHECKED && (off_x | off_y)) {
+      // the slice ends at the map border: final if it cannot come back (see the comment at the top)
+      const float cxy = fast_rcp(fast_sqrt(fmaf(P.c1[0], P.c1[0], P.c1[1] * P.c1[1])));
+      const bool transversal = (off_x & !off_y & (fabsf(P.c1[0]) * cxy >= 0.9f)) | (off_y & !off_x & (fabsf(P.c1[1]) * cxy >= 0.9f));
+      ok = (c2z >= 0.9999999f) | transversal;
+      break;  // (ok: the beams left get r_max through the tail below)
+    }
     if (++step > max_steps) {
       ok = false;
       break;
@@ -558,24 +580,15 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   return ok;
 }
 
-template <int SURF, bool EXPECT_ONLY>
-__global__ void __launch_bounds__(SWEEP_THREADS, (SURF == 0 || SURF == 5) ? SWEEP_MIN_WAVES_GRID : SWEEP_MIN_WAVES) k_mbes_sweep(MbesArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char sweep_lds[];
-  float4* sbeam = (float4*)sweep_lds + 1;  // records -1 and n_beams exist (read, never used)
-  float* stail = (float*)(sbeam + a.n_beams + 1);
-  for (int b = threadIdx.x; b < a.n_beams; b += SWEEP_THREADS) {
-    sbeam[b] = a.sweep_beams[b];
-    stail[b] = a.sweep_tail[b];
-  }
-  if (threadIdx.x == 0) sbeam[-1] = sbeam[a.n_beams] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);  // "never reached"
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const long long gid = blockIdx.x * (long long)SWEEP_THREADS + threadIdx.x;
+// one particle side: cast, agree with the other side's lane, write lw or hand the particle over; returns lw (or -inf)
+template <int SURF, bool EXPECT_ONLY, bool CHECKED>
+__device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long gid, long long n, const float4* sbeam,
+                                             const float* stail, int lane) {
   // position in the visiting order; lanes 2k, 2k+1 = the two sides of one particle.  (Expected ranges in the natural
   // order: the grid only covers the particles asked for.)
   const long long j = (gid >> 1) + ((EXPECT_ONLY && !a.perm) ? a.exp_first : 0);
   const int side = (int)(gid & 1);
-  const bool valid = j < a.n;
+  const bool valid = j < n;
   const long long i = (valid && a.perm) ? (long long)a.perm[j] : j;
   bool ok = true, work = valid;
   float* exp_row = nullptr;
@@ -589,7 +602,7 @@ __global__ void __launch_bounds__(SWEEP_THREADS, (SURF == 0 || SURF == 5) ? SWEE
     if (SURF == 5)
       ok = sweep_side_tin<EXPECT_ONLY>(a, P, sbeam, stail, side, exp_row, acc);
     else
-      ok = sweep_side<(SURF == 5 ? 2 : SURF), EXPECT_ONLY>(a, P, sbeam, stail, side, exp_row, acc);
+      ok = sweep_side<(SURF == 5 ? 2 : SURF), EXPECT_ONLY, CHECKED>(a, P, sbeam, stail, side, exp_row, acc);
   }
   // both sides of a particle agree on its fate (the exchange is NOT under `ok &&`: every lane takes part in it)
   const int ok_i = ok ? 1 : 0;
@@ -610,10 +623,40 @@ __global__ void __launch_bounds__(SWEEP_THREADS, (SURF == 0 || SURF == 5) ? SWEE
     base = __builtin_amdgcn_readfirstlane(base);
     if (writer && !ok2) a.defer_idx[base + (int)__popcll(dm & ((1ull << lane) - 1ull))] = (u32)i;
   }
+  return v == v ? v : -__builtin_inf();  // NaN never wins the maximum
+}
+
+template <int SURF, bool EXPECT_ONLY, bool CHECKED = false>
+__global__ void __launch_bounds__(SWEEP_THREADS, (SURF == 0 || SURF == 5) ? SWEEP_MIN_WAVES_GRID : (CHECKED ? 6 : SWEEP_MIN_WAVES)) k_mbes_sweep(MbesArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sweep_lds[];
+  float4* sbeam = (float4*)sweep_lds + 1;  // records -1 and n_beams exist (read, never used)
+  float* stail = (float*)(sbeam + a.n_beams + 1);
+  const long long n = mbes_count(a);  // (CHECKED pass: the length of the first pass's hand-over list, read here)
+  if (CHECKED && a.host_count && blockIdx.x == 0 && threadIdx.x == 0) *a.host_count = (int)n;
+  if (CHECKED && n == 0) return;
+  for (int b = threadIdx.x; b < a.n_beams; b += SWEEP_THREADS) {
+    sbeam[b] = a.sweep_beams[b];
+    stail[b] = a.sweep_tail[b];
+  }
+  if (threadIdx.x == 0) sbeam[-1] = sbeam[a.n_beams] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);  // "never reached"
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const long long gid0 = blockIdx.x * (long long)SWEEP_THREADS + threadIdx.x;
+  double vmax;
+  if (!CHECKED) {
+    // the first pass is launched with one lane per particle side
+    vmax = sweep_lane<SURF, EXPECT_ONLY, false>(a, gid0, n, sbeam, stail, lane);
+  } else {
+    // the CHECKED pass strides over the first pass's list (whole waves: the lanes exchange verdicts)
+    vmax = -__builtin_inf();
+    for (long long gid = gid0; (gid >> 1) < ((n + 31) & ~31ll); gid += (long long)gridDim.x * SWEEP_THREADS) {
+      const double v = sweep_lane<SURF, EXPECT_ONLY, true>(a, gid, n, sbeam, stail, lane);
+      vmax = v > vmax ? v : vmax;
+    }
+  }
   if (!EXPECT_ONLY && a.max_slots) {
     // the normalisation needs max lw: one atomic per wave on an order-preserving key
-    if (!(v == v)) v = -__builtin_inf();  // NaN never wins
-    const double m = wave_max(v);
+    const double m = wave_max(vmax);
     if (lane == 0 && m > -__builtin_inf())
       atomicMax((unsigned long long*)&a.max_slots[(blockIdx.x * (SWEEP_THREADS / 64) + (threadIdx.x >> 6)) & (MCL_MAX_SLOTS - 1)],
                 ordered_key(m));
