@@ -1116,6 +1116,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.b_split = 0;
   a.sweep_nvalid = 0;
   a.sweep_c2z_min = 2.f;
+  a.sweep_slope = 0.f;
   a.defer_idx = nullptr;
   a.defer_count = (int*)(h->ctrl + CTRL_DEFER);
   a.n_dev = nullptr;
@@ -1206,6 +1207,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     const double slope_max = h->map_kind == 0 ? h->gslope_max : h->mesh->slope_max;
     const double tan_lim = std::min(std::tan(35.0 * MCL_PI / 180.0), (h->map_kind == 0 ? 0.45 : 0.8) / std::max(slope_max, 1e-9));
     a.sweep_c2z_min = (float)(1.0 / std::sqrt(1.0 + tan_lim * tan_lim));
+    a.sweep_slope = (float)slope_max;
     a.defer_idx = h->defer_idx;
   }
   if (args_only) {

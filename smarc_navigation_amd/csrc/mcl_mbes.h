@@ -109,6 +109,7 @@ struct MbesArgs {
   int b_split;                // first beam with a >= 0: beams [b_split, B) sweep outward on the + side, [0, b_split) on the - side
   int sweep_nvalid;           // beams with a valid measured range
   float sweep_c2z_min;        // cos of the largest fan-plane tilt the sweep accepts (terrain slope bound, mcl_api.hip)
+  float sweep_slope;          // the map's steepest slope |grad h| (second pass: may a slice end at the map border?)
   u32* defer_idx;             // particles the sweep hands over: the visiting order (perm) of the cast kernels that follow it
   int* defer_count;           // device counter, zeroed with the control block
   const int* n_dev;           // when set, the classify / cast kernels visit *n_dev entries of perm instead of a.n

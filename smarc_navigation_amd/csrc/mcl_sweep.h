@@ -59,9 +59,10 @@ struct SweepNode {
 // CHECKED (second pass, over what the first one declined): the footprint need not lie inside the map -- every node is
 //   tested against the map's bounds, and a slice that leaves the map ENDS there: the beams left return r_max (a mesh
 //   has no side walls; a ray from inside a grid never re-enters it).  That conclusion needs the slice to cross the
-//   border line once: the fan plane is vertical (a straight track), or the track meets the border at more than ~64
-//   degrees (|cos| >= 0.9: with the tilt bound the border's trace in the fan plane is then steeper than the slice).
-//   Anything else goes on to the traversal kernels.
+//   border line once: the border's trace in the fan plane must be steeper than the slice can be, which the fan's
+//   tilt, the map's steepest slope and the angle between fan and border decide (see the test in the walk); a level
+//   vehicle always qualifies, a tilted fan slanting along the border over steep terrain goes on to the traversal
+//   kernels, like everything else the second pass declines.
 template <int SURF, bool EXPECT_ONLY, bool CHECKED = false>
 __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P, const float4* __restrict__ sbeam,
                                            const float* __restrict__ stail, int side, float* __restrict__ exp_row,
@@ -307,10 +308,12 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     if (ptr == pend) break;
     if (s_cur > s_stop) break;  // every beam left misses inside r_max (tail below)
     if (CHECKED && (off_x | off_y)) {
-      // the slice ends at the map border: final if it cannot come back (see the comment at the top)
-      const float cxy = fast_rcp(fast_sqrt(fmaf(P.c1[0], P.c1[0], P.c1[1] * P.c1[1])));
-      const bool transversal = (off_x & !off_y & (fabsf(P.c1[0]) * cxy >= 0.9f)) | (off_y & !off_x & (fabsf(P.c1[1]) * cxy >= 0.9f));
-      ok = (c2z >= 0.9999999f) | transversal;
+      // The slice ends at the map border: final if it cannot come back.  In plane coordinates the border x = x_b is
+      // the line s = s_L + k t with |k| <= sin(tilt) / |c1x|, the slice is t = f(s) with
+      // |f'| <= (slope + sin(tilt)) / (cos(tilt) - slope sin(tilt)); they meet once if |k f'| < 1 (0.9 here).
+      const float sb = fast_sqrt(fmaxf(1.f - c2z * c2z, 0.f));
+      const float lhs = sb * (a.sweep_slope + sb), rhs = 0.9f * (c2z - a.sweep_slope * sb);
+      ok = (off_x != off_y) & (lhs < rhs * fabsf(off_x ? P.c1[0] : P.c1[1]));
       break;  // (ok: the beams left get r_max through the tail below)
     }
     if (++step > max_steps) {

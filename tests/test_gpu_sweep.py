@@ -157,24 +157,23 @@ def test_fans_reaching_over_the_map_border(kind, eng, orc):
 
 
 def test_second_pass_only_ends_a_slice_where_it_cannot_come_back(eng, orc):
-    """A tilted fan running almost PARALLEL to the border it reaches: the track is curved (tilt x relief) and could
-    cross the border line more than once, so the second pass declines and the traversal kernels cast the particle;
-    a vertical fan, or one that meets the border squarely, is ended there.  Either way the ranges are the oracle's."""
-    z, origin = _terrain(nx=160, ny=150, origin=(-80.0, -75.0), seed=17, fbm_amp=1.0)
+    """A strongly tilted fan slanting ALONG the border it reaches, over steep terrain: the track is curved (tilt x
+    relief) and could cross the border line more than once, so the second pass declines and the traversal kernels
+    cast the particle; a level fan, or one that meets the border squarely, is ended there.  Either way the ranges are
+    the oracle's."""
+    z, origin = _terrain(nx=160, ny=150, origin=(-80.0, -75.0), seed=17, fbm_amp=2.0, swell=4.0)
     verts, tris = synth.mesh_from_grid(z, 1.0, origin)
     n, B = 192, 128
-    soa = _cloud(n, 4, (2.0, 2.0, 0.3, 0.0, 0.0, 0.0), (70.0, 0.0, -2.0))   # 9 m from the +x border (x = 79)
-    soa[5] = np.where(np.arange(n) % 2 == 0, np.pi / 2 + 0.15, 0.35)     # even: heading +y (fan along x: meets the border squarely); odd: fan 20 degrees off the border line
-    soa[3] = 0.06 * np.sin(np.arange(n))                                  # rolled and pitched: not a vertical fan
-    soa[4] = 0.05
-    soa[3, :16] = 0.0
-    soa[4, :16] = 0.0                                                     # a few level ones
+    soa = _cloud(n, 4, (0.5, 2.0, 0.3, 0.0, 0.0, 0.0), (75.0, 0.0, -2.0))   # 4 m from the +x border (x = 79)
+    soa[5] = np.where(np.arange(n) % 2 == 0, np.pi / 2 + 0.15, 0.12)     # even: heading +y (fan along x: meets the border squarely); odd: fan 7 degrees off the border line
+    soa[3] = np.where(np.arange(n) % 2 == 0, 0.03, 0.2)                  # the slanting ones are rolled by 11 degrees
+    soa[4] = 0.02
     ba = synth.beam_angles(B, 1.25)
     e = _engine(eng, soa, verts, tris)
     got = e.mbes_expected(0, n, ba, 90.0)
     path, handed, _ = e.mbes_last_path()
     print('handed over %d of %d' % (handed, n))
-    assert path == 1 and n // 4 < handed < 3 * n // 4    # the tilted, slanting ones (odd, beyond the first 16)
+    assert path == 1 and n // 4 < handed < 3 * n // 4    # the rolled, slanting ones
     _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, orc.Mesh(verts, tris), ba, None, 0.2, 90.0)
     assert (ref == 90.0).mean() > 0.05
     err = np.abs(got - ref)
