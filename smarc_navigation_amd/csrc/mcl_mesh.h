@@ -34,7 +34,8 @@ struct MeshDev {
   int diag_mode = 0;      // structured: 1 = every cell split along 00-11, 2 = along 10-01, 0 = mixed (LSB per cell)
   double slope_max = 0;   // steepest triangle, |grad h| (the fan sweep's tilt bound, mcl_sweep.h)
   // triangle adjacency for the fan sweep over an arbitrary height-field TIN (mcl_sweep.h: sweep_side_tin):
-  // per triangle two uint4 {v0, v1, v2, -} {neighbour across v0v1, v1v2, v2v0 (0xffffffff: mesh border), -},
+  // per triangle two uint4 {v0, v1, v2, -} {neighbour across v0v1, v1v2, v2v0 (0xffffffff: hole / ragged border,
+  // 0xfffffff0 / 0xfffffff1: the map's outer x / y border), -},
   // per vertex one float4 (x, y, z, -).  tin_ok: every edge has at most two triangles and their third vertices lie
   // on opposite sides of it in the xy projection (no fold: the mesh is a height field), no vertical triangle.
   uint4* tin_tri = nullptr;
@@ -342,6 +343,24 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
         }
       }
     if (ok) {
+      // an edge without a second triangle: on the OUTER border of a rectangular map (both ends on the same side of
+      // the bounding box: 0xfffffff0 for an x side, 0xfffffff1 for a y side -- a slice that leaves there cannot
+      // come back, mcl_sweep.h) or anywhere else (a hole, a ragged outline: 0xffffffff)
+      const double eb = 1e-6 * std::max(1.0, std::max(xmax - xmin, ymax - ymin));
+      for (int64_t k = 0; k < nt; ++k) {
+        u32* nb = &tt[2 * k + 1].x;
+        for (int e = 0; e < 3; ++e) {
+          if (nb[e] != 0xffffffffu) continue;
+          const float* pa = verts + 3 * (size_t)tris[3 * k + e];
+          const float* pb = verts + 3 * (size_t)tris[3 * k + (e + 1) % 3];
+          const bool on_x = (std::fabs(pa[0] - xmin) <= eb && std::fabs(pb[0] - xmin) <= eb) ||
+                            (std::fabs(pa[0] - xmax) <= eb && std::fabs(pb[0] - xmax) <= eb);
+          const bool on_y = (std::fabs(pa[1] - ymin) <= eb && std::fabs(pb[1] - ymin) <= eb) ||
+                            (std::fabs(pa[1] - ymax) <= eb && std::fabs(pb[1] - ymax) <= eb);
+          if (on_x) nb[e] = 0xfffffff0u;
+          else if (on_y) nb[e] = 0xfffffff1u;
+        }
+      }
       std::vector<float4> vv((size_t)nv);
       for (int64_t i = 0; i < nv; ++i) vv[i] = make_float4(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2], 0.f);
       if (hipMalloc(&m->tin_tri, sizeof(uint4) * tt.size()) == hipSuccess &&

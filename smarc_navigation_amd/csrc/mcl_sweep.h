@@ -364,7 +364,8 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
 // mesh_build (mcl_mesh.h: two uint4 per triangle -- vertex ids, neighbour ids), nodes are vertex records (x, y, z).
 // Per step: the neighbour's record (32 B), the one vertex of it that is not on the shared edge (16 B, dependent),
 // plane function and in-plane coordinates from map-frame coordinates (the subtraction of the sensor position is done
-// in fp64: vertices are fp32 inputs, the sensor is not).  The walk ends at a mesh border (hand-over).
+// in fp64: vertices are fp32 inputs, the sensor is not).  The walk ends at a mesh border: the map's outer border (the
+// beams left return r_max, under the rule of the second pass above) or a hole / ragged outline (hand-over).
 // The start triangle: the (cell, triangle) records of mcl_mesh.h carry their source triangle's index in a spare word.
 __device__ __forceinline__ float tin_nadir(const MbesArgs& a, int I0, int J0, float ul, float vl, float oz, float dx, float dy,
                                            float dz, u32& tri_id) {
@@ -419,7 +420,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   acc_out = 0.f;
   const MeshArgs& ma = a.mesh;
   const int nx = a.nx, ny = a.ny, B = a.n_beams;  // (cells + 1 of the cell grid: the mesh's bounding box)
-  bool pre = P.um >= 1.0 && P.um < (double)(nx - 2) && P.vm >= 1.0 && P.vm < (double)(ny - 2);
+  bool pre = P.um >= 0.0 && P.um < (double)(nx - 1) && P.vm >= 0.0 && P.vm < (double)(ny - 1);  // (NaN: false)
   const float c2z = P.c2[2];
   pre = pre & (c2z >= a.sweep_c2z_min);
   const double fum = pre ? floor(P.um) : 1.0, fvm = pre ? floor(P.vm) : 1.0;
@@ -437,20 +438,8 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     if (dz_e < -1e-4f) s_stop = fminf(s_stop, (a.zmin_map - oz) * fast_rcp(dz_e) * fabsf(sc.x));
   }
   s_stop += 2.f * res;
-  {
-    // (same footprint test as sweep_side, against the mesh's bounding box; holes and ragged borders end the walk)
-    const float rc = fast_rcp(c2z);
-    const float sl = fabsf(P.c1[2]) * (s_stop + 2.f * res);
-    const float t_hi = ((oz - a.zmin_map) + sl) * rc + res, t_lo = fminf(((oz - a.zmax_map) - sl) * rc - res, 0.f);
-    const float s_lo = -2.f * res, s_hi = s_stop + 2.f * res;
-    const float ax = sg * P.c1[0] * inv_res, ay = sg * P.c1[1] * inv_res, bx = -P.c2[0] * inv_res, by = -P.c2[1] * inv_res;
-    const float ux0 = fminf(s_lo * ax, s_hi * ax) + fminf(t_lo * bx, t_hi * bx);
-    const float ux1 = fmaxf(s_lo * ax, s_hi * ax) + fmaxf(t_lo * bx, t_hi * bx);
-    const float vy0 = fminf(s_lo * ay, s_hi * ay) + fminf(t_lo * by, t_hi * by);
-    const float vy1 = fmaxf(s_lo * ay, s_hi * ay) + fmaxf(t_lo * by, t_hi * by);
-    const float fi0 = (float)I0, fj0 = (float)J0;
-    pre = pre & (fi0 + ux0 >= 1.f) & (fi0 + ux1 <= (float)(nx - 2)) & (fj0 + vy0 >= 1.f) & (fj0 + vy1 <= (float)(ny - 2));
-  }
+  // (no footprint test: the walk goes from triangle to triangle through the adjacency table and ends at the mesh's
+  //  border -- at the OUTER border of a rectangular map for good, under the rule of sweep_side's second pass)
   if (!pre) return false;
   u32 T = 0xffffffffu;
   const float r0 = tin_nadir(a, I0, J0, ul, vl, oz, -P.c2[0], -P.c2[1], -c2z, T);
@@ -523,7 +512,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   float4 bm = sbeam[ptr];
   for (;;) {
     // the neighbour's record is in flight while the beams are resolved
-    const bool border = nb == 0xffffffffu;
+    const bool border = nb >= 0xfffffff0u;
     const size_t tq = border ? 0 : (size_t)nb;
     const uint4 tv3 = ma.tin_tri[2 * tq], tn3 = ma.tin_tri[2 * tq + 1];
     const float dts = t_cur - t_prev;
@@ -545,7 +534,15 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     }
     if (ptr == pend) break;
     if (s_cur > s_stop) break;
-    if (border || ++step > max_steps) {  // the slice runs off the mesh (a hole, a ragged border): not for the sweep
+    if (border) {
+      // the slice runs off the mesh.  Through the map's outer border: final if it cannot come back (same bound as in
+      // sweep_side's second pass); through a hole or a ragged outline: not for the sweep
+      const float sb = fast_sqrt(fmaxf(1.f - c2z * c2z, 0.f));
+      const float lhs = sb * (a.sweep_slope + sb), rhs = 0.9f * (c2z - a.sweep_slope * sb);
+      ok = (nb != 0xffffffffu) & (lhs < rhs * fabsf(nb == 0xfffffff0u ? P.c1[0] : P.c1[1]));
+      break;  // (ok: the beams left get r_max through the tail below)
+    }
+    if (++step > max_steps) {
       ok = false;
       break;
     }
