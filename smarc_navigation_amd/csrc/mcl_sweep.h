@@ -385,7 +385,8 @@ __device__ __forceinline__ float tin_nadir(const MbesArgs& a, int I0, int J0, fl
   tri_id = 0xffffffffu;
   for (int guard = 0; guard < 64; ++guard) {
     const float t_out = fminf(fminf(tnx, tny), t1);
-    const int gi = min(max(I0 + ci, 0), ma.gx - 1), gj = min(max(J0 + cj, 0), ma.gy - 1);
+    const int gi = I0 + ci, gj = J0 + cj;
+    if ((unsigned)gi >= (unsigned)ma.gx || (unsigned)gj >= (unsigned)ma.gy) break;  // the nadir ray leaves the map: no start
     const size_t c = (size_t)gi * ma.gy + gj;
     const u32 rs = ma.cell_start[c], re = ma.cell_start[c + 1];
     const float olx = (ul - (float)ci) * cs, oly = (vl - (float)cj) * cs;
