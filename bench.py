@@ -283,7 +283,8 @@ def kernel_table(tim, alg, steps):
     return kernels
 
 
-def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, resample=True, landmarks=None, m2o=None):
+def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, resample=True, landmarks=None, m2o=None,
+            rccl_1rank=False):
     """One extra workload leg on a fresh engine: returns ms per step (wall, synchronised around the timed
     block) and the per-phase HIP-event times.  resample=False: predict + MBES update only (the cloud
     keeps its width); landmarks=(xyz, n_det): config 5 -- the landmark k-NN update accumulates onto the
@@ -295,7 +296,19 @@ def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, re
     stream = synth.odom_stream(total, x0=x0)
     ba = synth.beam_angles(B)
     ranges = make_ranges(engine, m, stream['truth'], ba, SIGMA, R_MAX, device=device, m2o=m2o)
-    e = engine.Engine(P, seed=5, device=device, m2o=m2o, **cov)
+    if rccl_1rank:
+        # the SHARDED pipeline on one GPU: a 1-rank RCCL communicator (MCL_FORCE_COMM, read at mcl_create) makes the
+        # step run its exchange phases -- max all-reduce, totals / CDF all-gathers, the state gather on the second
+        # communicator under the MBES update, moments all-reduce -- with nobody to talk to
+        os.environ['MCL_FORCE_COMM'] = '1'
+    try:
+        e = engine.Engine(P, seed=5, device=device, m2o=m2o, **cov)
+        if rccl_1rank:
+            with stdout_to_stderr():
+                e.comm_init(engine.comm_unique_id())
+    finally:
+        if rccl_1rank:
+            del os.environ['MCL_FORCE_COMM']
     attach_map(e, m)
     dets = None
     if landmarks is not None:
@@ -371,6 +384,29 @@ def dry_run(a, rank, world):
     return 0
 
 
+class stdout_to_stderr(object):
+    """RCCL prints a version banner on the C stdout at communicator creation (buffered: it would come out at exit,
+    after the JSON line).  Inside this block fd 1 is stderr, and the C stdio buffers are flushed before fd 1 is
+    given back, so stdout stays reserved for the ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def setup_comm(e, engine, dist, rank, world, want_overlap):
     """RCCL communicator(s) of the data path.  The overlapped state all-gather drives two communicators
     on two streams; a self-test with a deadline runs that exact pattern first, and if any rank does not
@@ -381,21 +417,14 @@ def setup_comm(e, engine, dist, rank, world, want_overlap):
     for attempt in range(2):
         uid = [engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        # RCCL prints a version banner on stdout at communicator creation: keep stdout for the ONE JSON line
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
         ok = 1
-        try:
-            e.comm_init(uid[0], overlap=overlap)
-            e.comm_selftest(30000)
-        except engine.MclError as ex:
-            sys.stderr.write('rank %d: communicator self-test failed (%s)\n' % (rank, ex))
-            ok = 0
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        with stdout_to_stderr():
+            try:
+                e.comm_init(uid[0], overlap=overlap)
+                e.comm_selftest(30000)
+            except engine.MclError as ex:
+                sys.stderr.write('rank %d: communicator self-test failed (%s)\n' % (rank, ex))
+                ok = 0
         t = torch.tensor([ok], dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if int(t[0]) == 1:
@@ -610,6 +639,7 @@ def worker(a, rank, world, local_rank):
                                                          m2o=shift)))
         legs.append(('config2', dict(m=build_map('grid'), P=65536, B=256, steps=200, warmup=20)))
         legs.append(('config4_shard', dict(m=mesh, P=524288, B=512, steps=30, warmup=5)))
+        legs.append(('config4_shard_rccl_1rank', dict(m=mesh, P=524288, B=512, steps=30, warmup=5, rccl_1rank=True)))
         legs.append(('config5_shard', dict(m=mesh, P=524288, B=512, steps=30, warmup=5,
                                            landmarks=(synth.landmark_map(4096, (-64.0, -354.0, 643.0, 353.0)), 16))))
         for name, kw in legs:
