@@ -140,9 +140,13 @@ int mcl_set_map_mesh(mcl_handle* h, const float* verts, int64_t nv, const uint32
  * bathymetric surface is).  It enables neighbour-chained ray starts; a mesh with
  * overhangs must NOT set it -- results would be wrong for occluded beams. */
 #define MCL_MESH_HEIGHTFIELD 1u
-/* MCL_MESH_GENERAL: do not use the structured-mesh fast path even when the mesh is detected to be a
- * triangulated regular height grid (testing / A-B runs of the general triangle-record traversal) */
+/* MCL_MESH_GENERAL: cast this mesh with the general triangle-record traversal only -- no structured-mesh fast
+ * path even when the mesh is detected to be a triangulated regular height grid, and no fan sweep by adjacency
+ * (testing / A-B runs of the kernels that serve arbitrary triangle soups) */
 #define MCL_MESH_GENERAL 2u
+/* MCL_MESH_UNSTRUCTURED: no structured-mesh detection, but the fan sweep by triangle adjacency is still used when
+ * mesh_build proves the mesh a single-valued height field (A-B runs of the adjacency walk on a regular mesh) */
+#define MCL_MESH_UNSTRUCTURED 4u
 int mcl_set_map_mesh_ex(mcl_handle* h, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt,
                         uint32_t flags);
 /* ranges[b] <= 0 or NaN marks an invalid beam; beam b looks along (0, sin a_b, -cos a_b) in the
@@ -230,7 +234,11 @@ int mcl_resample_indices(int32_t scheme, const double* weights, int64_t n, const
                          int64_t n_uniforms, int32_t device, int32_t* out);
 
 /* ---- multi-GPU: particles shard by contiguous global id; RCCL all-reduce (max log-w),
- * all-gather (shard totals, offspring CDF, ancestor states) */
+ * all-gather (shard totals, offspring CDF, ancestor states).
+ * PRECONDITION: every rank is given the SAME inputs per step (odometry message, ping, dt).  motion_pred leaves the
+ * odometry's depth, roll and pitch on every particle (auv_particle.py:55-57,70), and a resample that directly follows
+ * a predict does not ship those three components between shards: a copied particle takes them from the receiving
+ * rank's own odometry.  Ranks fed different odometry would silently disagree on z, roll, pitch of copied particles. */
 int mcl_comm_unique_id(char id[128]);
 int mcl_comm_init(mcl_handle* h, const char id[128]); /* MCL_COMM_RCCL: collective over all ranks */
 /* flags: MCL_COMM_NO_OVERLAP = no second communicator; the pre-resample state all-gather then runs

@@ -96,8 +96,13 @@ struct mcl_handle {
   u32 *sort_keys = nullptr, *sort_keys_out = nullptr, *sort_idx = nullptr, *mbes_perm = nullptr;
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
-  int* work_host = nullptr;     // pinned: [0] groups the natural order deferred in the last update (read one call late)
-  bool sort_visits = false;     // the next update visits the particles in Morton order
+  // pinned ring of 4 slots x 4 ints, one slot per MBES update: [0] groups the natural-order classification deferred,
+  // [1] particles the sweep handed to the traversal kernels, [2] particles its first pass declined.  An update reads
+  // the slot of the update TWO before it, after waiting for that update's event (long since complete when the host
+  // runs ahead): the visiting-order and grid-size decisions are a function of the filter's history, never of timing.
+  int* work_host = nullptr;
+  hipEvent_t ev_upd[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned long long upd_seq = 0;
   int env_sort = -1;            // MCL_SORT_VISITS=0/1 forces the decision (tests, A/B)
   int* mbes_worklist = nullptr;  // ngroups + 1 ints; [ngroups] is the counter
   int* lm_worklist = nullptr;    // n + 1 ints; [n] is the counter (landmark assignment: particles with clashes)
@@ -125,7 +130,6 @@ struct mcl_handle {
   u32* defer_idx2 = nullptr;        // what the bounds-checked second pass hands on
   int env_sweep = -1;               // MCL_SWEEP=0/1 forces the decision (tests, A/B)
   bool sweep_now = false;           // decided by the first launch_mbes call of an update
-  bool sweep_bad = false;           // the last sweep handed over more than 1/16 of the particles
   bool sweep_two_pass = false;      // lattice maps: a bounds-checked second pass precedes the traversal kernels
   int sweep_nvalid = 0;
   float* grid = nullptr;
@@ -139,7 +143,8 @@ struct mcl_handle {
   int det_cap = 0;
   int map_kind = -1;  // 0 grid, 1 mesh
   bool mesh_heightfield = false;
-  bool force_general_mesh = false;  // MCL_MESH_GENERAL: keep the triangle-record path even if structured
+  bool force_general_mesh = false;  // MCL_MESH_GENERAL / MCL_MESH_UNSTRUCTURED: no structured-mesh fast path
+  bool mesh_no_sweep = false;       // MCL_MESH_GENERAL: triangle-record traversal only (no adjacency sweep either)
   // bookkeeping
   int weight_mode = 0;
   bool have_lw = false, have_cdf = false, have_meancov = false;
@@ -1181,7 +1186,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     //  1 M; MCL_SWEEP=1 forces it)
     const long long sweep_min_n = h->env_sweep == 1 ? 1 : (h->map_kind == 0 ? 98304 : 16384);
     // a height-field TIN with adjacency -- also a triangulated height grid whose cells are split along mixed diagonals
-    const bool tin = h->map_kind == 1 && h->mesh->tin_ok && (!structured || a.diag_mode == 0);
+    // (tin_ok: mesh_build has PROVEN the mesh single-valued over (x, y) -- adjacency, fold and pairwise overlap tests)
+    const bool tin = h->map_kind == 1 && h->mesh->tin_ok && !h->mesh_no_sweep && (!structured || a.diag_mode == 0);
     bool sweep = ((structured && (a.diag_mode == 1 || a.diag_mode == 2)) || h->map_kind == 0 || tin) && h->sweep_angles_ok && h->env_sweep != 0 &&
                  h->ng >= sweep_min_n &&  // (the GLOBAL count: every shard of a cloud takes the same path, results do not depend on the GPU count)
                  h->n < (1ll << 31) && (long long)a.nx * a.ny < (1ll << 31);
@@ -1214,6 +1220,27 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     *args_only = a;
     return MCL_OK;
   }
+  // ---- counters of the update two before this one (deterministic lag, see mcl_handle::work_host)
+  if (!h->work_host) {
+    HIPCHK(h, hipHostMalloc(&h->work_host, 64, hipHostMallocDefault));
+    memset(h->work_host, 0, 64);
+    for (int k = 0; k < 4; ++k) HIPCHK(h, hipEventCreateWithFlags(&h->ev_upd[k], hipEventDisableTiming));
+  }
+  static const int wh_zero[4] = {0, 0, 0, 0};
+  const int* wh_prev = wh_zero;
+  if (h->upd_seq >= 2) {
+    HIPCHK(h, hipEventSynchronize(h->ev_upd[(h->upd_seq - 2) & 3]));
+    wh_prev = h->work_host + 4 * ((h->upd_seq - 2) & 3);
+  }
+  int* wh_cur = h->work_host + 4 * (h->upd_seq & 3);  // (its last user, four updates ago, finished before the event above)
+  wh_cur[0] = wh_cur[1] = wh_cur[2] = wh_cur[3] = 0;
+  struct SeqGuard {  // whatever path returns: this update's kernels are behind its event
+    mcl_handle* h;
+    ~SeqGuard() {
+      (void)hipEventRecord(h->ev_upd[h->upd_seq & 3], h->stream);
+      h->upd_seq++;
+    }
+  } seq_guard{h};
   t_begin(h, MCL_K_UPDATE_MBES);
   if (!pose_done) {
     // (the fused predict has already reset the control block and written poses, group records and worklist)
@@ -1229,17 +1256,10 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   if (a.max_slots) h->max_valid = true;
   a.perm = nullptr;
   if (sweep) {
-    if (!h->work_host) {
-      HIPCHK(h, hipHostMalloc(&h->work_host, 64, hipHostMallocDefault));
-      h->work_host[0] = 0;
-      h->work_host[1] = 0;
-      h->work_host[2] = 0;
-    }
-    // The hand-over count of the previous sweep, read one call late (no synchronisation).  When it was large (a
-    // cloud on the map border, a fan too tilted for the terrain) the particles are visited in Morton order: the
-    // hand-over list inherits it wave by wave, so the groups of eight the cast kernels form from it share tiles.
-    const bool sort_now = h->env_sort >= 0 ? h->env_sort == 1 : h->sweep_bad;
-    h->sweep_bad = (long long)h->work_host[1] * 16 > h->n;
+    // The hand-over count of the sweep two updates ago (see work_host).  When it was large (a cloud on the map
+    // border, a fan too tilted for the terrain) the particles are visited in Morton order: the hand-over list
+    // inherits it wave by wave, so the groups of eight the cast kernels form from it share tiles.
+    const bool sort_now = h->env_sort >= 0 ? h->env_sort == 1 : (long long)wh_prev[1] * 16 > h->n;
     if (sort_now && h->n > MBES_WAVES) {
       RET_IF(sort_visiting_order(h, a));
       a.perm = h->mbes_perm;
@@ -1259,14 +1279,14 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     c.n_dev = a.defer_count;
     c.defer_idx = h->defer_idx2;
     c.defer_count = (int*)(h->ctrl + CTRL_DEFER2);
-    c.host_count = h->work_host + 2;
+    c.host_count = wh_cur + 2;
     MbesArgs d = a;   // traversal kernels
     d.perm = lattice ? h->defer_idx2 : h->defer_idx;
     d.n_dev = lattice ? c.defer_count : a.defer_count;
-    d.host_count = h->work_host + 1;  // (pinned: the classify kernel stores the count there, no copy on the stream)
+    d.host_count = wh_cur + 1;  // (pinned: the classify kernel stores the count there, no copy on the stream)
     // (their loops are grid-stride: the grids only set the parallelism.  After an update that handed nothing over
     //  they are launched small -- three empty 2048-workgroup launches cost 15 us, 2.5 % of the update)
-    const bool few = h->work_host[1] == 0, few2 = h->work_host[2] == 0;
+    const bool few = wh_prev[1] == 0, few2 = wh_prev[2] == 0;
     const int cgrid = (int)std::min<long long>(grid_for(h->n), few ? 32 : 1024);
     const int fgrid = (int)std::min<long long>(ngroups, few ? 64 : 2048);
     const int dgrid = (int)std::min<long long>(ngroups, few ? 64 : 512);
@@ -1327,15 +1347,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     // Dispersed cloud?  The natural-order classification has just counted the groups without a common tile.
     // That count travels to the host asynchronously and is read one call late (no synchronisation): when the
     // previous update deferred more than 1/16 of its groups, this one visits the particles in Morton order.
-    if (!h->work_host) {
-      HIPCHK(h, hipHostMalloc(&h->work_host, 64, hipHostMallocDefault));
-      h->work_host[0] = 0;
-      h->work_host[1] = 0;
-      h->work_host[2] = 0;
-    }
-    const bool sort_now = h->env_sort >= 0 ? h->env_sort == 1 : h->sort_visits;
-    h->sort_visits = (long long)h->work_host[0] * 16 > ngroups;
-    HIPCHK(h, hipMemcpyAsync(h->work_host, a.work_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    const bool sort_now = h->env_sort >= 0 ? h->env_sort == 1 : (long long)wh_prev[0] * 16 > ngroups;
+    HIPCHK(h, hipMemcpyAsync(wh_cur, a.work_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (sort_now && h->n > MBES_WAVES) {
       RET_IF(sort_visiting_order(h, a));
       a.perm = h->mbes_perm;
@@ -1643,6 +1656,8 @@ int mcl_destroy(mcl_handle* h) {
   if (h->det_dev) (void)hipFree(h->det_dev);
   if (h->host_pin) (void)hipHostFree(h->host_pin);
   if (h->work_host) (void)hipHostFree(h->work_host);
+  for (auto& e : h->ev_upd)
+    if (e) (void)hipEventDestroy(e);
   for (auto& sl : h->pin_ring) {
     if (sl.ev) (void)hipEventDestroy(sl.ev);
     if (sl.p) (void)hipHostFree(sl.p);
@@ -1765,7 +1780,8 @@ int mcl_set_map_mesh_ex(mcl_handle* h, const float* verts, int64_t nv, const uin
   }
   h->map_kind = 1;
   h->mesh_heightfield = (flags & MCL_MESH_HEIGHTFIELD) != 0;
-  h->force_general_mesh = (flags & MCL_MESH_GENERAL) != 0;
+  h->force_general_mesh = (flags & (MCL_MESH_GENERAL | MCL_MESH_UNSTRUCTURED)) != 0;
+  h->mesh_no_sweep = (flags & MCL_MESH_GENERAL) != 0;
   if (h->mesh_heightfield && h->mesh->n_vertical > 0) {
     h->err = "set_map_mesh: MCL_MESH_HEIGHTFIELD declared but the mesh has vertical faces";
     h->mesh_heightfield = false;

@@ -210,6 +210,7 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
   std::vector<float4> rec(3 * std::max<size_t>(m->n_records, 1)), rec_mt;
   std::vector<float2> cz(nc, make_float2(INFINITY, -INFINITY));
   std::vector<u32> fill(nc, 0u);
+  std::vector<u32> rec_tri(std::max<size_t>(m->n_records, 1), 0u);  // source triangle of every record (overlap test below)
   bool any_vertical = false;
   for (int64_t k = 0; k < nt && !any_vertical; ++k) {
     const float* v0 = verts + 3 * (size_t)tris[3 * k];
@@ -242,6 +243,7 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
         if (any_cell ? !overlaps(k, a, b) : !(a == a0 && b == b0)) continue;
         const size_t c = (size_t)a * m->gy + b;
         const size_t r = 3 * ((size_t)start[c] + fill[c]++);
+        rec_tri[r / 3] = (u32)k;
         const double cx = m->x0 + a * cs, cy = m->y0 + b * cs;
         const double lx = v0[0] - cx, ly = v0[1] - cy;  // v0 relative to the cell corner
         if (!vertical) {
@@ -342,6 +344,55 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
           it->second = -1;
         }
       }
+    // ---- GLOBAL single-valuedness.  The edge tests above are local: two sheets that overlap in xy without sharing an
+    // edge (a seabed and a wreck floating above it) pass them, and a walk by adjacency would never meet the upper
+    // sheet.  Two triangles whose xy projections overlap with positive area are both recorded in some common cell
+    // (exact binning above), so it is enough to test the pairs of every cell: separating-axis test on the six edge
+    // normals; projections that merely touch (shared edge or vertex) count as separated.
+    if (ok) {
+      const double eps = 1e-9 * cs * cs;
+      auto proj_overlap = [&](u32 ka, u32 kb) {
+        double P[2][3][2];
+        const u32 kk[2] = {ka, kb};
+        for (int t = 0; t < 2; ++t)
+          for (int c = 0; c < 3; ++c) {
+            P[t][c][0] = verts[3 * (size_t)tris[3 * (size_t)kk[t] + c]];
+            P[t][c][1] = verts[3 * (size_t)tris[3 * (size_t)kk[t] + c] + 1];
+          }
+        for (int t = 0; t < 2; ++t)
+          for (int c = 0; c < 3; ++c) {
+            const int d = (c + 1) % 3;
+            double ax = -(P[t][d][1] - P[t][c][1]), ay = P[t][d][0] - P[t][c][0];
+            const double len = std::sqrt(ax * ax + ay * ay);
+            if (!(len > 0.0)) continue;
+            ax /= len;
+            ay /= len;
+            double lo[2], hi[2];
+            for (int u = 0; u < 2; ++u) {
+              lo[u] = INFINITY;
+              hi[u] = -INFINITY;
+              for (int q = 0; q < 3; ++q) {
+                const double pr = ax * P[u][q][0] + ay * P[u][q][1];
+                lo[u] = std::min(lo[u], pr);
+                hi[u] = std::max(hi[u], pr);
+              }
+            }
+            // (eps is an area; the axis is a unit vector, so compare lengths against eps / cs)
+            if (hi[0] <= lo[1] + eps / cs || hi[1] <= lo[0] + eps / cs) return false;  // separated (or touching)
+          }
+        return true;
+      };
+      for (size_t c = 0; c < nc && ok; ++c) {
+        const u32 rs = start[c], re = start[c + 1];
+        if (re - rs > 256u) {  // pathological pile-up in one cell: not worth proving anything
+          ok = false;
+          break;
+        }
+        for (u32 i = rs; i < re && ok; ++i)
+          for (u32 j = i + 1; j < re && ok; ++j)
+            if (rec_tri[i] != rec_tri[j] && proj_overlap(rec_tri[i], rec_tri[j])) ok = false;
+      }
+    }
     if (ok) {
       // an edge without a second triangle: on the OUTER border of a rectangular map (both ends on the same side of
       // the bounding box: 0xfffffff0 for an x side, 0xfffffff1 for a y side -- a slice that leaves there cannot

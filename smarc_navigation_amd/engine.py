@@ -91,11 +91,12 @@ class Engine(object):
         self._ck(self.lib.mcl_set_map_grid(self.h, _ptr(z), z.shape[0], z.shape[1], float(origin[0]),
                                            float(origin[1]), float(res)))
 
-    def set_map_mesh(self, verts, tris, heightfield=False, general=False):
+    def set_map_mesh(self, verts, tris, heightfield=False, general=False, unstructured=False):
         v = _f32(verts)
         t = np.ascontiguousarray(tris, dtype=np.uint32)
         self._ck(self.lib.mcl_set_map_mesh_ex(self.h, _ptr(v), v.shape[0], _ptr(t), t.shape[0],
-                                              (1 if heightfield else 0) | (2 if general else 0)))
+                                              (1 if heightfield else 0) | (2 if general else 0) |
+                                              (4 if unstructured else 0)))
 
     def update_mbes(self, ranges, beam_angles, sigma, r_max, sensor_offset=None):
         r, a, so = _f32(ranges), _f32(beam_angles), _f64(sensor_offset)

@@ -418,7 +418,7 @@ def test_tin_sweep_expected_ranges_and_logweights_vs_oracle(n, B, eng, orc):
     assert rel.max() <= 2e-4
 
 
-def test_tin_with_holes_hands_over_and_folded_mesh_is_not_swept(eng, orc):
+def test_tin_with_holes_hands_over_and_folded_mesh_is_not_swept(eng, orc, monkeypatch):
     """A TIN with triangles missing: a slice that runs into a hole ends the walk, the particle goes to the traversal
     kernels.  A mesh with a triangle listed twice (three faces on an edge) has no usable adjacency: traversal only."""
     z, origin = _terrain(seed=32)
@@ -438,11 +438,55 @@ def test_tin_with_holes_hands_over_and_folded_mesh_is_not_swept(eng, orc):
     mesh = orc.Mesh(verts, holes)
     _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, mesh, ba, None, 0.2, 80.0)
     err = np.abs(got - ref)
-    assert (err > 1e-3).sum() <= 2, err.max()
+    bad = err > 1e-3
+    assert bad.sum() <= 2, err.max()
+    # a ray that grazes the rim of a hole may pass through it in one arithmetic and hit the rim in the other: such a
+    # ray is accepted only if the traversal kernels (independent fp32 code) return what the sweep returned -- a sweep
+    # that mis-cast a hand-over (r_max instead of a hit) would disagree with both
+    if bad.any():
+        monkeypatch.setenv('MCL_SWEEP', '0')
+        e0 = _engine(eng, soa, verts, holes)
+        got0 = e0.mbes_expected(0, n, ba, 80.0)
+        assert e0.mbes_last_path()[0] == 0
+        monkeypatch.delenv('MCL_SWEEP')
+        assert np.abs(got - got0)[bad].max() <= 1e-3, (err[bad], np.abs(got - got0)[bad])
     dup = np.ascontiguousarray(np.concatenate([tris, tris[:1]], axis=0))
     e2 = _engine(eng, soa, verts, dup)
     e2.mbes_expected(0, n, ba, 80.0)
     assert e2.mbes_last_path()[0] == 0
+
+
+def test_two_sheets_overlapping_in_xy_are_not_swept(eng, orc, monkeypatch):
+    """a seabed plus a second sheet floating above part of it (a wreck deck).  Every local test of the
+    adjacency build passes (each sheet is edge-manifold and fold-free) but the mesh is not single-valued over (x, y):
+    a walk by adjacency from the nadir triangle would never meet the other sheet.  mesh_build proves global
+    single-valuedness (pairwise xy-overlap test per cell) before it allows the sweep, so this map is cast by the
+    traversal kernels -- at a cloud size where a TIN would otherwise be swept -- and matches the oracle's nearest hit."""
+    monkeypatch.delenv('MCL_SWEEP', raising=False)
+    z, origin = _terrain(seed=33)
+    verts, tris = synth.mesh_tin(z, 1.0, origin, seed=6)
+    # the deck: a 12 m x 10 m jittered sheet 6 m above the seabed, under the vehicle's port swath
+    dz, dorigin = np.full((13, 11), float(z.mean()) + 6.0), (-6.0, 3.0)
+    dverts, dtris = synth.mesh_tin(dz, 1.0, dorigin, seed=7)
+    v2 = np.concatenate([verts, dverts]).astype(np.float32)
+    t2 = np.concatenate([tris, dtris + len(verts)]).astype(np.uint32)
+    n, B = 16384, 64
+    soa = _cloud(n, 8, (1.5, 1.5, 0.1, 0.02, 0.02, 0.3), (0.0, 0.0, -2.0))
+    ba = synth.beam_angles(B)
+    e = _engine(eng, soa, v2, t2)
+    got = e.mbes_expected(0, 512, ba, 80.0)
+    assert e.mbes_last_path()[0] == 0, 'a two-sheet mesh must not go through the adjacency sweep'
+    sub = np.ascontiguousarray(soa[:, :512])
+    _, ref = orc.mbes_update(sub, np.identity(4), [0] * 6, orc.Mesh(v2, t2), ba, None, 0.2, 80.0)
+    err = np.abs(got - ref)
+    # the deck really occludes: many rays end on it, well short of the seabed below
+    _, ref1 = orc.mbes_update(sub, np.identity(4), [0] * 6, orc.Mesh(verts, tris), ba, None, 0.2, 80.0)
+    assert (ref1 - ref > 3.0).mean() > 0.05
+    assert (err > 1e-3).sum() <= max(2, err.size // 5000), err.max()
+    # the same seabed alone IS swept at this size
+    e1 = _engine(eng, soa, verts, tris)
+    e1.mbes_expected(0, 8, ba, 80.0)
+    assert e1.mbes_last_path()[0] == 1
 
 
 def test_alternating_diagonals_go_through_the_adjacency_sweep(eng, orc):
