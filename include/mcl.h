@@ -261,6 +261,21 @@ int mcl_group_resample(mcl_handle** shards, int32_t n_shards, const double* unif
                        const double* const* replay_normals /* per shard, or NULL */);
 int mcl_group_mean_cov(mcl_handle** shards, int32_t n_shards, double mean6[6], double* yaw_mean,
                        double cov9[9]);
+/* mcl_step_mbes over a LOCAL group: every shard runs the fused predict + MBES update, then the sharded resample
+ * (+ moments) -- phase for phase what N ranks under RCCL execute, so a 4 M-particle BASELINE config 4 step can be
+ * checked bit for bit against the unsharded filter on one GPU.  The result is read with mcl_last_mean_cov(shards[0]). */
+int mcl_group_step_mbes(mcl_handle** shards, int32_t n_shards, const mcl_odom* odom, double dt, const float* ranges,
+                        const float* beam_angles, int32_t n_beams, double sigma, double r_max,
+                        const double sensor_offset[6]);
+/* Resample exchange between shards.  Default: O(n) per rank -- every shard expands its own slice of the
+ * offspring CDF, the shards all-gather two integers each (lost slots L_r, surplus copies S_r), and rank q sends rank r
+ * exactly the surplus copies whose positions in the global dupes order fall into r's lost ranks (ncclSend / ncclRecv in
+ * one group; one host synchronisation per resample to learn the sizes).  MCL_EXCHANGE=allgather (environment, read in
+ * mcl_create) selects the all-gather of CDF + state of rounds 1-2.  Results are bit-identical.
+ * After an O(n) exchange a shard holds only its own slice of the offspring CDF: mcl_get_last_indices and
+ * mcl_get_last_offspring_cdf all-gather it on demand -- under RCCL that is a COLLECTIVE call (every rank makes it).
+ * mcl_exchange_stats: particle states this shard sent to peers and lost slots it filled, summed since the last reset. */
+int mcl_exchange_stats(mcl_handle* h, int64_t* states_sent, int64_t* lost_slots, int32_t reset);
 
 /* ---- instrumentation */
 int mcl_timing_enable(mcl_handle* h, int32_t on);

@@ -164,6 +164,19 @@ struct mcl_handle {
   bool uni_valid = false;       // true from a predict until the state is written by anything else
   double uni_val[3] = {0, 0, 0};
   unsigned gather_uni_mask = 0; // components the last state exchange skipped (phase_gather substitutes uni_val)
+  // O(n)-per-rank resample exchange: hand-over records {L | S << 32, x0, y0, z0} of every shard,
+  // surplus copies packed for the peers, copies received for this shard's lost slots
+  bool exch_allgather = false;   // MCL_EXCHANGE=allgather: the all-gather exchange of rounds 1-2 instead
+  u64* lsx = nullptr;            // device, world x 4 words
+  u64* lsx_host = nullptr;       // pinned, world x 4 words
+  double* xsend = nullptr;       // 6 x xsend_cap
+  size_t xsend_cap = 0;
+  double* xrecv = nullptr;       // 6 x n
+  std::vector<u32> ex_L, ex_S;   // per shard, filled by exchange_ls
+  std::vector<u32> ex_Lpre, ex_Spre;
+  unsigned long long ex_sent = 0, ex_lost = 0;  // particle states sent to peers / lost slots, summed over the resamples
+  bool cdf_global = false;       // ncum holds the GLOBAL offspring CDF (else only this shard's slice)
+  std::vector<mcl_handle*> group;  // LOCAL group this shard was last resampled in (lazy CDF all-gather)
   // environment switches, read once in mcl_create (never on the per-measurement path)
   bool env_debug_work = false, env_force_comm = false, env_no_overlap = false;
   // pinned staging so that asynchronous uploads never read caller-owned pageable memory after the call returns
@@ -596,13 +609,215 @@ int phase_expand(mcl_handle* h, bool fused_cdf, uint64_t u53) {
   return MCL_OK;
 }
 
+// ---- O(n)-per-rank exchange -------------------------------------------------------------------------------
+// CDF, lost ranks and dupes list of THIS shard only (k_cdf_expand<true> over the shard, global weight offsets from the
+// all-gathered totals); leaves the shard's hand-over record in lsx[rank]
+int phase_expand_local(mcl_handle* h, uint64_t u53) {
+  RET_IF(set_device(h));
+  if (!h->lsx) {
+    HIPCHK(h, hipMalloc(&h->lsx, sizeof(u64) * 4 * (size_t)h->world));
+    HIPCHK(h, hipHostMalloc(&h->lsx_host, sizeof(u64) * 4 * (size_t)h->world, hipHostMallocDefault));
+  }
+  ExpandArgs a;
+  memset(&a, 0, sizeof a);
+  a.q = h->q;
+  a.tile_sum = h->tile64;  // exclusive offsets (k_scan_tile_sums)
+  a.n_fine = h->ntiles_loc;
+  a.n_global_u = (u64)h->ng;
+  a.u53 = u53;
+  a.total_out = h->totals + h->world;  // (unused in this mode)
+  a.ncum = h->ncum + h->goff;
+  a.n = h->n;
+  a.own0 = 0;
+  a.own_n = h->n;
+  a.zr = h->zr;
+  a.dupes = h->dupes32;
+  a.desc = h->desc;
+  a.ticket = ctrl_u32(h, CTRL_T_EXPAND);
+  a.epoch = ++h->epoch;
+  a.totals = h->totals;
+  a.rank = h->rank;
+  a.world = h->world;
+  a.ls_out = h->lsx + 4 * (size_t)h->rank;
+  for (int c = 0; c < 3; ++c) a.p0[c] = h->state[h->cur] + (size_t)c * h->n;
+  const unsigned grid = (unsigned)((h->n + RS_TILE - 1) / RS_TILE);
+  t_begin(h, MCL_K_SCAN);
+  k_cdf_expand<true><<<grid, RS_BLOCK, 0, h->stream>>>(a);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  h->cdf_global = h->world == 1;
+  return MCL_OK;
+}
+
+// every shard learns {L, S} of every shard (and the position of global particle 0); the host needs them to size the
+// point-to-point transfers: ONE stream synchronisation per resample
+int exchange_ls(mcl_handle** sh, int ns) {
+  const int world = sh[0]->world;
+  if (ns == 1) {
+    mcl_handle* h = sh[0];
+    t_begin(h, MCL_K_COMM);
+    if (h->comm && world > 1)
+      NCCLCHK(h, ncclAllGather(h->lsx + 4 * (size_t)h->rank, h->lsx, 4, ncclUint64, h->comm, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->lsx_host, h->lsx, sizeof(u64) * 4 * (size_t)world, hipMemcpyDeviceToHost, h->stream));
+    t_end(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  } else {
+    for (int s = 0; s < ns; ++s) {
+      mcl_handle* h = sh[s];
+      RET_IF(set_device(h));
+      HIPCHK(h, hipMemcpyAsync(h->lsx_host + 4 * (size_t)s, h->lsx + 4 * (size_t)s, sizeof(u64) * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    for (int s = 0; s < ns; ++s) HIPCHK(sh[s], hipStreamSynchronize(sh[s]->stream));
+    for (int d = 0; d < ns; ++d) {
+      for (int s = 0; s < ns; ++s)
+        if (s != d) memcpy(sh[d]->lsx_host + 4 * (size_t)s, sh[s]->lsx_host + 4 * (size_t)s, sizeof(u64) * 4);
+      RET_IF(set_device(sh[d]));
+      HIPCHK(sh[d], hipMemcpyAsync(sh[d]->lsx, sh[d]->lsx_host, sizeof(u64) * 4 * (size_t)ns, hipMemcpyHostToDevice, sh[d]->stream));
+    }
+  }
+  for (int s = 0; s < ns; ++s) {
+    mcl_handle* h = sh[s];
+    h->ex_L.assign(world, 0u);
+    h->ex_S.assign(world, 0u);
+    h->ex_Lpre.assign(world + 1, 0u);
+    h->ex_Spre.assign(world + 1, 0u);
+    for (int r = 0; r < world; ++r) {
+      h->ex_L[r] = (u32)(h->lsx_host[4 * (size_t)r] & 0xffffffffull);
+      h->ex_S[r] = (u32)(h->lsx_host[4 * (size_t)r] >> 32);
+      h->ex_Lpre[r + 1] = h->ex_Lpre[r] + h->ex_L[r];
+      h->ex_Spre[r + 1] = h->ex_Spre[r] + h->ex_S[r];
+    }
+    if (h->ex_Lpre[world] != h->ex_Spre[world])
+      return fail(h, MCL_ERR_COMM, "resample exchange: lost slots and surplus copies of the shards do not add up (ranks fed different inputs?)");
+  }
+  return MCL_OK;
+}
+
+// surplus copies into the send buffer (own lost slots: straight into the receive buffer)
+int phase_pack(mcl_handle* h) {
+  RET_IF(set_device(h));
+  const u32 S = h->ex_S[h->rank];
+  if (!h->xrecv) HIPCHK(h, hipMalloc(&h->xrecv, sizeof(double) * 6 * (size_t)h->n));
+  if ((size_t)S > h->xsend_cap) {
+    if (h->xsend) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      (void)hipFree(h->xsend);
+      h->xsend = nullptr;
+    }
+    size_t cap = std::max<size_t>((size_t)S + (size_t)S / 4, 4096);
+    HIPCHK(h, hipMalloc(&h->xsend, sizeof(double) * 6 * cap));
+    h->xsend_cap = cap;
+  }
+  h->gather_uni_mask = h->uni_valid ? 0x1cu : 0u;  // z, roll, pitch: the same on every particle of every shard
+  if (S == 0) return MCL_OK;
+  PackArgs a;
+  a.src = state_ptrs(h->state[h->cur], h->n);
+  a.dupes = h->dupes32;
+  a.S = S;
+  a.Spre = h->ex_Spre[h->rank];
+  a.Lpre = h->ex_Lpre[h->rank];
+  a.L = h->ex_L[h->rank];
+  a.uni_mask = h->gather_uni_mask;
+  a.send = state_ptrs(h->xsend, (long long)h->xsend_cap);
+  a.recv = state_ptrs(h->xrecv, h->n);
+  t_begin(h, MCL_K_RESAMPLE);
+  k_pack_dupes<<<grid_for(S), MCL_BLOCK, 0, h->stream>>>(a);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+
+// the range of global dupes positions that shard `from` holds and shard `to` needs: [lo, hi)
+void ex_range(const mcl_handle* h, int from, int to, u32& lo, u32& hi) {
+  lo = std::max(h->ex_Spre[from], h->ex_Lpre[to]);
+  hi = std::min(h->ex_Spre[from + 1], h->ex_Lpre[to + 1]);
+  if (hi < lo) hi = lo;
+}
+
+int exchange_dupes(mcl_handle** sh, int ns) {
+  if (ns == 1) {
+    mcl_handle* h = sh[0];
+    h->ex_lost += h->ex_L[h->rank];
+    if (!h->comm || h->world == 1) return MCL_OK;
+    const int q = h->rank;
+    t_begin(h, MCL_K_COMM);
+    NCCLCHK(h, ncclGroupStart());
+    for (int r = 0; r < h->world; ++r) {
+      if (r == q) continue;
+      u32 lo, hi;
+      ex_range(h, q, r, lo, hi);  // what I hold and r needs
+      if (hi > lo) {
+        h->ex_sent += hi - lo;
+        for (int c = 0; c < 6; ++c)
+          if (!((h->gather_uni_mask >> c) & 1u))
+            NCCLCHK(h, ncclSend(h->xsend + (size_t)c * h->xsend_cap + (lo - h->ex_Spre[q]), (size_t)(hi - lo), ncclDouble, r, h->comm, h->stream));
+      }
+      ex_range(h, r, q, lo, hi);  // what r holds and I need
+      if (hi > lo)
+        for (int c = 0; c < 6; ++c)
+          if (!((h->gather_uni_mask >> c) & 1u))
+            NCCLCHK(h, ncclRecv(h->xrecv + (size_t)c * h->n + (lo - h->ex_Lpre[q]), (size_t)(hi - lo), ncclDouble, r, h->comm, h->stream));
+    }
+    NCCLCHK(h, ncclGroupEnd());
+    t_end(h);
+    return MCL_OK;
+  }
+  // LOCAL group: the same ranges as device copies (after every shard has packed)
+  for (int s = 0; s < ns; ++s) HIPCHK(sh[s], hipStreamSynchronize(sh[s]->stream));
+  for (int d = 0; d < ns; ++d) {
+    mcl_handle* D = sh[d];
+    RET_IF(set_device(D));
+    D->ex_lost += D->ex_L[d];
+    for (int s = 0; s < ns; ++s) {
+      if (s == d) continue;
+      mcl_handle* S = sh[s];
+      u32 lo, hi;
+      ex_range(D, s, d, lo, hi);
+      if (hi <= lo) continue;
+      S->ex_sent += hi - lo;
+      for (int c = 0; c < 6; ++c)
+        if (!((D->gather_uni_mask >> c) & 1u))
+          HIPCHK(D, hipMemcpyAsync(D->xrecv + (size_t)c * D->n + (lo - D->ex_Lpre[d]),
+                                   S->xsend + (size_t)c * S->xsend_cap + (lo - S->ex_Spre[s]),
+                                   sizeof(double) * (size_t)(hi - lo), hipMemcpyDefault, D->stream));
+    }
+  }
+  for (int d = 0; d < ns; ++d) HIPCHK(sh[d], hipStreamSynchronize(sh[d]->stream));
+  return MCL_OK;
+}
+
+// the global offspring CDF on demand (mcl_get_last_indices / mcl_get_last_offspring_cdf after an O(n) exchange, which
+// leaves only the shard's own slice): RCCL -- a COLLECTIVE all-gather, every rank must make the call; LOCAL group --
+// copies from the peers' slices
+int ensure_global_cdf(mcl_handle* h) {
+  if (h->cdf_global || h->world == 1) return MCL_OK;
+  RET_IF(set_device(h));
+  if (h->comm) {
+    NCCLCHK(h, ncclAllGather(h->ncum + h->goff, h->ncum, (size_t)h->n, ncclUint32, h->comm, h->stream));
+  } else if ((int)h->group.size() == h->world) {
+    for (mcl_handle* S : h->group) {
+      if (S == h) continue;
+      HIPCHK(S, hipStreamSynchronize(S->stream));
+      HIPCHK(h, hipMemcpyAsync(h->ncum + S->goff, S->ncum + S->goff, sizeof(u32) * (size_t)S->n, hipMemcpyDefault, h->stream));
+    }
+  } else {
+    return fail(h, MCL_ERR_STATE, "the global offspring CDF needs the communicator or the LOCAL group of the last resample");
+  }
+  h->cdf_global = true;
+  return MCL_OK;
+}
+
 // reassign gather + resampling noise (+ the sums of update_loc_pose of the new state when with_moments)
 int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments) {
   RET_IF(set_device(h));
   if (replay_normals) RET_IF(upload_replay(h, replay_normals));
   GatherArgs a;
-  const bool multi = h->world > 1 || (h->comm && h->state_glob);
-  a.src = multi ? state_ptrs(h->state_glob, h->ng) : state_ptrs(h->state[h->cur], h->n);
+  const bool multi = h->world > 1 || h->comm;
+  const bool p2p = multi && !h->exch_allgather;
+  a.src = (multi && !p2p) ? state_ptrs(h->state_glob, h->ng) : state_ptrs(h->state[h->cur], h->n);
+  a.recv_mode = p2p ? 1 : 0;
+  a.recv = p2p ? state_ptrs(h->xrecv, h->n) : a.src;
+  a.shift_dev = p2p ? (const double*)(h->lsx + 1) : nullptr;
   a.dst = state_ptrs(h->state[h->cur ^ 1], h->n);
   a.n = h->n;
   a.goff = h->goff;
@@ -822,17 +1037,36 @@ int run_resample(mcl_handle** sh, int ns, const double* uniforms, long long nu,
   // max from the slots -> quantise -> CDF + expansion -> gather, three launches
   const bool single = ns == 1 && h0->world == 1 && !h0->comm && h0->ntiles_loc <= 8192;
   if (single) {
+    h0->cdf_global = true;
+    h0->group.clear();
     RET_IF(phase_quantise(h0, true, true));
     RET_IF(phase_expand(h0, true, u53));
     return phase_gather(h0, (replay_normals && h0->cfg.rng_mode == MCL_RNG_REPLAY) ? replay_normals[0] : nullptr,
                         with_moments);
   }
-  for (int s = 0; s < ns; ++s) RET_IF(phase_local_max(sh[s]));
+  for (int s = 0; s < ns; ++s) {
+    sh[s]->group.assign(sh, sh + ns);
+    if (ns == 1) sh[s]->group.clear();
+    RET_IF(phase_local_max(sh[s]));
+  }
   RET_IF(exchange_max(sh, ns));
   for (int s = 0; s < ns; ++s) RET_IF(phase_quantise(sh[s], false));
   RET_IF(exchange_totals(sh, ns));
+  if (!h0->exch_allgather) {
+    // O(n) per rank: every shard expands its OWN slice, the shards exchange two integers each, and only
+    // the surplus copies whose global positions fall into a peer's lost ranks cross a link
+    for (int s = 0; s < ns; ++s) RET_IF(phase_expand_local(sh[s], u53));
+    RET_IF(exchange_ls(sh, ns));
+    for (int s = 0; s < ns; ++s) RET_IF(phase_pack(sh[s]));
+    RET_IF(exchange_dupes(sh, ns));
+    for (int s = 0; s < ns; ++s)
+      RET_IF(phase_gather(sh[s], (replay_normals && sh[s]->cfg.rng_mode == MCL_RNG_REPLAY) ? replay_normals[s] : nullptr,
+                          with_moments));
+    return MCL_OK;
+  }
   for (int s = 0; s < ns; ++s) RET_IF(phase_cdf(sh[s], u53));
   RET_IF(exchange_cdf_state(sh, ns));
+  for (int s = 0; s < ns; ++s) sh[s]->cdf_global = true;
   for (int s = 0; s < ns; ++s) RET_IF(phase_expand(sh[s], false, 0));
   for (int s = 0; s < ns; ++s)
     RET_IF(phase_gather(sh[s], (replay_normals && sh[s]->cfg.rng_mode == MCL_RNG_REPLAY) ? replay_normals[s] : nullptr,
@@ -1574,6 +1808,7 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
     if (const char* sv = getenv("MCL_SORT_VISITS")) h->env_sort = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_SWEEP")) h->env_sweep = sv[0] == '1' ? 1 : 0;
     h->env_force_comm = on("MCL_FORCE_COMM");
+    if (const char* ex = getenv("MCL_EXCHANGE")) h->exch_allgather = strcmp(ex, "allgather") == 0;
     h->env_no_overlap = on("MCL_NO_OVERLAP");
   }
   if (h->ng > 0xffffffffll || h->goff + h->n > h->ng || h->rank >= h->world) {
@@ -1602,7 +1837,7 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
   CREATE_CHK(hipMalloc(&h->state[1], sizeof(double) * 6 * n));
   CREATE_CHK(hipMemsetAsync(h->state[0], 0, sizeof(double) * 6 * n, h->stream));
   CREATE_CHK(hipMemsetAsync(h->state[1], 0, sizeof(double) * 6 * n, h->stream));
-  if (h->world > 1) CREATE_CHK(hipMalloc(&h->state_glob, sizeof(double) * 6 * ng));
+  if (h->world > 1 && h->exch_allgather) CREATE_CHK(hipMalloc(&h->state_glob, sizeof(double) * 6 * ng));
   CREATE_CHK(hipMalloc(&h->lw, sizeof(double) * n));
   CREATE_CHK(hipMalloc(&h->q, sizeof(u64) * n));
   CREATE_CHK(hipMalloc(&h->ncum, sizeof(u32) * ng));
@@ -1648,13 +1883,14 @@ int mcl_destroy(mcl_handle* h) {
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
                   h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_beams, h->defer_idx, h->defer_idx2, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
-                  h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev};
+                  h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev, h->lsx, h->xsend, h->xrecv};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (h->mesh) mesh_free(h->mesh);
   if (h->landmarks) landmarks_free(h->landmarks);
   if (h->det_dev) (void)hipFree(h->det_dev);
   if (h->host_pin) (void)hipHostFree(h->host_pin);
+  if (h->lsx_host) (void)hipHostFree(h->lsx_host);
   if (h->work_host) (void)hipHostFree(h->work_host);
   for (auto& e : h->ev_upd)
     if (e) (void)hipEventDestroy(e);
@@ -2199,6 +2435,7 @@ int mcl_get_last_indices(mcl_handle* h, int32_t* idx) {
   if (!h->have_cdf && !h->idx_explicit) return fail(h, MCL_ERR_STATE, "get_last_indices: no resample yet");
   RET_IF(set_device(h));
   if (!h->idx) HIPCHK(h, hipMalloc(&h->idx, sizeof(int) * (size_t)h->n));
+  if (!h->idx_explicit) RET_IF(ensure_global_cdf(h));
   if (!h->idx_explicit) {
     k_indices<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->ncum, h->ng, h->goff, h->n, h->idx);
     HIPCHK(h, hipGetLastError());
@@ -2212,6 +2449,7 @@ int mcl_get_last_offspring_cdf(mcl_handle* h, uint32_t* ncum) {
   if (!h || !ncum) return MCL_ERR_INVALID;
   if (!h->have_cdf) return fail(h, MCL_ERR_STATE, "get_last_offspring_cdf: no resample yet");
   RET_IF(set_device(h));
+  RET_IF(ensure_global_cdf(h));
   HIPCHK(h, hipMemcpyAsync(ncum, h->ncum, sizeof(u32) * (size_t)h->ng, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MCL_OK;
@@ -2269,6 +2507,43 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
   return MCL_OK;
 }
 
+int mcl_group_step_mbes(mcl_handle** shards, int32_t ns, const mcl_odom* odom, double dt, const float* ranges,
+                        const float* beam_angles, int32_t B, double sigma, double r_max, const double sensor_offset[6]) {
+  if (!shards || ns < 1 || !odom || !ranges || !beam_angles) return MCL_ERR_INVALID;
+  for (int s = 0; s < ns; ++s)
+    if (!shards[s] || shards[s]->world != ns || shards[s]->rank != s)
+      return fail(shards[0], MCL_ERR_INVALID, "group_step_mbes: shards must be ranks 0..n-1 of one world");
+  if (B < 1 || !(sigma > 0.0) || !(r_max > 0.0)) return fail(shards[0], MCL_ERR_INVALID, "group_step_mbes: bad argument");
+  for (int s = 0; s < ns; ++s) {
+    mcl_handle* h = shards[s];
+    if (h->cfg.rng_mode != MCL_RNG_NATIVE) return fail(h, MCL_ERR_INVALID, "group_step_mbes: NATIVE rng only");
+    if (h->map_kind < 0) return fail(h, MCL_ERR_STATE, "group_step_mbes: no map (call mcl_set_map_grid/mesh first)");
+    if (h->cfg.resample_scheme != MCL_RESAMPLE_SYSTEMATIC && h->cfg.resample_scheme != MCL_RESAMPLE_NAIVE)
+      return fail(h, MCL_ERR_UNSUPPORTED, "group_step_mbes: only the systematic scheme is sharded");
+    RET_IF(set_device(h));
+    // the same fused front half as mcl_step_mbes: predict writes the pose records, the sweep leaves max lw in the slots
+    RET_IF(upload_beams(h, ranges, beam_angles, B));
+    MbesArgs pa;
+    RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, false, &pa));
+    bool pose_done = false;
+    RET_IF(do_predict(h, odom, dt, nullptr, &pa, &pose_done));
+    RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, pose_done));
+    h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
+    h->have_lw = true;
+    h->residual_k = -1;
+  }
+  RET_IF(run_resample(shards, ns, nullptr, 0, nullptr, true));
+  return collect_fused_moments(shards, ns);
+}
+
+int mcl_exchange_stats(mcl_handle* h, int64_t* states_sent, int64_t* lost_slots, int32_t reset) {
+  if (!h) return MCL_ERR_INVALID;
+  if (states_sent) *states_sent = (int64_t)h->ex_sent;
+  if (lost_slots) *lost_slots = (int64_t)h->ex_lost;
+  if (reset) h->ex_sent = h->ex_lost = 0;
+  return MCL_OK;
+}
+
 int mcl_sync(mcl_handle* h) {
   if (!h) return MCL_ERR_INVALID;
   RET_IF(set_device(h));
@@ -2306,6 +2581,7 @@ int mcl_resample_indices(int32_t scheme, const double* weights, int64_t n, const
       if (rc == MCL_OK) rc = phase_cdf(h, u53);
       if (rc == MCL_OK) {
         h->have_cdf = true;
+        h->cdf_global = true;
         rc = mcl_get_last_indices(h, out);
       }
       if (rc != MCL_OK) g_create_err = h->err;
@@ -2360,9 +2636,10 @@ int mcl_comm_init_ex(mcl_handle* h, const char id[128], uint32_t flags) {
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof uid);
   NCCLCHK(h, ncclCommInitRank(&h->comm, h->world, uid, h->rank));
-  if (!h->state_glob) HIPCHK(h, hipMalloc(&h->state_glob, sizeof(double) * 6 * (size_t)h->ng));
-  // second communicator + stream for the overlapped state all-gather; optional
-  const bool overlap = !(flags & MCL_COMM_NO_OVERLAP) && !h->env_no_overlap;
+  if (h->exch_allgather && !h->state_glob) HIPCHK(h, hipMalloc(&h->state_glob, sizeof(double) * 6 * (size_t)h->ng));
+  // second communicator + stream for the overlapped state all-gather (MCL_EXCHANGE=allgather only: the O(n)
+  // exchange ships a few per cent of a shard and has nothing worth hiding); optional
+  const bool overlap = h->exch_allgather && !(flags & MCL_COMM_NO_OVERLAP) && !h->env_no_overlap;
   if (overlap && ncclCommSplit(h->comm, 0, h->rank, &h->comm2, nullptr) == ncclSuccess && h->comm2) {
     if (!h->comm_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     if (!h->ev_state_ready) HIPCHK(h, hipEventCreateWithFlags(&h->ev_state_ready, hipEventDisableTiming));
@@ -2411,8 +2688,21 @@ int mcl_comm_selftest(mcl_handle* h, int32_t timeout_ms) {
     if (rc != MCL_OK) break;
     ncclResult_t e = ncclAllReduce(h->scal + 24, h->scal + 24, 1, ncclDouble, ncclMax, h->comm, h->stream);
     if (e == ncclSuccess) e = ncclAllGather(h->totals + h->rank, h->totals, 1, ncclUint64, h->comm, h->stream);
-    if (e == ncclSuccess)
+    if (e == ncclSuccess && h->exch_allgather)
       e = ncclAllGather(h->ncum + h->goff, h->ncum, (size_t)h->n, ncclUint32, h->comm, h->stream);
+    if (e == ncclSuccess && !h->exch_allgather && h->world > 1) {
+      // the O(n) exchange's pattern: the hand-over records all-gathered, then grouped point-to-point transfers
+      // (here: one word to the next rank, one from the previous)
+      if (!h->lsx) {
+        HIPCHK(h, hipMalloc(&h->lsx, sizeof(u64) * 4 * (size_t)h->world));
+        HIPCHK(h, hipHostMalloc(&h->lsx_host, sizeof(u64) * 4 * (size_t)h->world, hipHostMallocDefault));
+      }
+      e = ncclAllGather(h->lsx + 4 * (size_t)h->rank, h->lsx, 4, ncclUint64, h->comm, h->stream);
+      if (e == ncclSuccess) e = ncclGroupStart();
+      if (e == ncclSuccess) e = ncclSend(h->totals + h->rank, 1, ncclUint64, (h->rank + 1) % h->world, h->comm, h->stream);
+      if (e == ncclSuccess) e = ncclRecv(h->totals + h->world, 1, ncclUint64, (h->rank + h->world - 1) % h->world, h->comm, h->stream);
+      if (e == ncclSuccess) e = ncclGroupEnd();
+    }
     if (e != ncclSuccess) {
       h->err = std::string("comm_selftest: ") + ncclGetErrorString(e);
       rc = MCL_ERR_COMM;

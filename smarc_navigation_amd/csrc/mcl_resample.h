@@ -141,6 +141,15 @@ struct ExpandArgs {
   u64* desc;             // one descriptor per tile
   u32* ticket;           // zero before the launch, left zero
   u32 epoch;             // differs from launch to launch: stale descriptors are never valid
+  // FROM_Q over ONE SHARD of a sharded cloud (the O(n)-per-rank exchange): `totals` = the all-gathered
+  // shard totals (the weight before this shard and the global total come from them), `tile_sum` then holds the
+  // EXCLUSIVE tile offsets k_scan_tile_sums left; ranks (zr) and the dupes list are LOCAL to the shard -- positions
+  // in the shard's own list of lost slots / surplus copies -- and the block of the last tile leaves in `ls_out`
+  // {L = lost slots, S = surplus copies} of the shard and the position of its particle 0 (the moments' shift)
+  const u64* totals;
+  int rank, world;
+  u64* ls_out;           // 4 words: L | S << 32, then x, y, z of local particle 0 as doubles
+  const double* p0[3];
 };
 template <bool FROM_Q>
 __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
@@ -162,30 +171,47 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
   const long long base = tile * RS_TILE + (long long)tid * RS_ITEMS;
   u32 nc[RS_ITEMS];
   u32 prev_tile = 0u;  // offspring CDF just before this tile
+  u32 nc_start = 0u;   // ... and just before the scanned range (non-zero only for a later shard of a sharded cloud)
   if (FROM_Q) {
-    // weight before this tile and total weight: every block adds the K1 tile sums up itself
-    u64 pre = 0ull, tot = 0ull;
     const long long fine0 = tile * RS_FINE;
-    for (long long i = tid; i < a.n_fine; i += RS_BLOCK) {
-      const u64 v = a.tile_sum[i];
-      tot += v;
-      pre += i < fine0 ? v : 0ull;
-    }
-    pre = wave_sum(pre);
-    tot = wave_sum(tot);
-    if (lane == 0) {
-      sh64[w] = pre;
-      shb[w] = tot;
-    }
-    __syncthreads();
     u64 off = 0ull, T = 0ull;
+    if (a.totals) {
+      // one shard of several: the weight before the shard and the global total from the all-gathered shard totals
+      u64 shard_off = 0ull;
+      for (int r = 0; r < a.world; ++r) {
+        const u64 t = a.totals[r];
+        shard_off += r < a.rank ? t : 0ull;
+        T += t;
+      }
+      off = shard_off + a.tile_sum[fine0];
+      if (shard_off != 0ull) {
+        u64 quo, rem;
+        muldiv_u64(shard_off, a.n_global_u, T, quo, rem);
+        nc_start = (u32)quo + (shl53_gt_mul(rem, a.u53, T) ? 1u : 0u);
+      }
+    } else {
+      // weight before this tile and total weight: every block adds the K1 tile sums up itself
+      u64 pre = 0ull, tot = 0ull;
+      for (long long i = tid; i < a.n_fine; i += RS_BLOCK) {
+        const u64 v = a.tile_sum[i];
+        tot += v;
+        pre += i < fine0 ? v : 0ull;
+      }
+      pre = wave_sum(pre);
+      tot = wave_sum(tot);
+      if (lane == 0) {
+        sh64[w] = pre;
+        shb[w] = tot;
+      }
+      __syncthreads();
 #pragma unroll
-    for (int k = 0; k < RS_BLOCK / 64; ++k) {
-      off += sh64[k];
-      T += shb[k];
+      for (int k = 0; k < RS_BLOCK / 64; ++k) {
+        off += sh64[k];
+        T += shb[k];
+      }
+      __syncthreads();  // sh64 is reused by the scan below
+      if (blockIdx.x == 0 && tid == 0) a.total_out[0] = T;
     }
-    __syncthreads();  // sh64 is reused by the scan below
-    if (blockIdx.x == 0 && tid == 0) a.total_out[0] = T;
     u64 v[RS_ITEMS];
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; ++k) v[k] = (base + k < a.n) ? a.q[base + k] : 0ull;
@@ -200,6 +226,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
         a.ncum[base + k] = nc[k];
       }
     }
+    prev_tile = nc_start;
     if (off != 0ull) {
       u64 quo, rem;
       muldiv_u64(off, a.n_global_u, T, quo, rem);
@@ -235,6 +262,14 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
   }
   __syncthreads();
   const u32 zex = zex_sh;
+  if (FROM_Q && a.ls_out && tile == (long long)gridDim.x - 1 && tid == 0) {
+    // the shard's hand-over record: lost slots, surplus copies (= offspring of the shard - slots + lost), particle 0
+    const u32 L = zex + agg_sh;
+    const u32 S = (snc[(a.n - 1) - tile * RS_TILE] - nc_start) - (u32)a.n + L;
+    a.ls_out[0] = (u64)L | ((u64)S << 32);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.ls_out[1 + c] = (u64)__double_as_longlong(a.p0[c][0]);
+  }
   // ---- ranks of the lost slots; dupes entries of the ancestors with surplus copies
   {
     u32 cp = prev;
@@ -248,7 +283,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
         if (j >= a.own0 && j < a.own0 + a.own_n) a.zr[j - a.own0] = z[k] ? zc - 1u : ZR_SURVIVOR;
         if (c > 1u) {
           // cumulative surplus before j:  E_{j-1} = ncum_{j-1} - j + zcum_{j-1}   (mod 2^32, the result is >= 0)
-          const u32 s = c - 1u, e0 = (nc[k] - c) - (u32)j + zc;
+          const u32 s = c - 1u, e0 = ((nc[k] - c) - nc_start) - (u32)j + zc;
           if (s <= EXP_HEAVY) {
             for (u32 r = 0; r < s; ++r) a.dupes[e0 + r] = (u32)j;
           } else {
@@ -273,6 +308,36 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ O(n) exchange: pack the surplus copies
+// Surplus copy p of this shard (p-th entry of its local dupes list) has position Spre + p in the GLOBAL dupes order;
+// the lost slot of global rank k takes the copy at position k.  Copies whose position falls into this shard's own
+// lost ranks [Lpre, Lpre + L) go straight into its receive buffer, the others into the send buffer, from which the
+// host sends each peer the contiguous range that intersects the peer's lost ranks.
+struct PackArgs {
+  StatePtrs src;       // this shard's pre-resample state
+  const u32* dupes;    // local ancestor index of every surplus copy
+  u32 S, Spre, Lpre, L;
+  unsigned uni_mask;   // components that are not shipped (the same value on every particle of the cloud)
+  StatePtrs send;      // [c][S]
+  StatePtrs recv;      // [c][L]
+};
+__global__ void __launch_bounds__(MCL_BLOCK) k_pack_dupes(PackArgs a) {
+  for (u32 p = blockIdx.x * MCL_BLOCK + threadIdx.x; p < a.S; p += gridDim.x * MCL_BLOCK) {
+    const u32 anc = a.dupes[p];
+    const u32 g = a.Spre + p;
+    const bool self = g >= a.Lpre && g - a.Lpre < a.L;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+      if (!((a.uni_mask >> c) & 1u)) {
+        const double v = a.src.c[c][anc];
+        if (self)
+          a.recv.c[c][g - a.Lpre] = v;
+        else
+          a.send.c[c][p] = v;
+      }
+  }
+}
+
 // ------------------------------------------------------------------ K3: gather + noise (+ fused moments)
 #define MOM_COUNT 13   // sum d(x,y,z), sum roll, pitch, yaw, sum wrap(yaw), sum dxx dyy dzz dxy dxz dyz
 #define GATHER_MAX_GRID 256
@@ -291,6 +356,12 @@ struct GatherArgs {
   // pitch straight after motion_pred: auv_particle.py:55-57,70): bit c set -> src.c[c] is not read, uni[c] is the value
   unsigned uni_mask;
   double uni[6];
+  // O(n) exchange: src is this shard's OWN pre-resample state (local indexing), zr holds LOCAL lost ranks and a lost
+  // slot reads recv.c[c][rank]; shift_dev = the position of global particle 0 (every rank has it from the hand-over
+  // records).  recv_mode 0: the look-up through the dupes list into src (single shard / all-gathered state).
+  int recv_mode;
+  StatePtrs recv;
+  const double* shift_dev;
 };
 template <bool MOMENTS>
 __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, const double* __restrict__ replay) {
@@ -302,13 +373,16 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
 #pragma unroll
     for (int c = 0; c < MOM_COUNT; ++c) acc[c] = 0.0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) shift[c] = ((a.uni_mask >> c) & 1u) ? a.uni[c] : a.src.c[c][0];  // a member of the cloud, the same on every shard
+    for (int c = 0; c < 3; ++c)  // a member of the cloud, the same on every shard
+      shift[c] = a.recv_mode ? a.shift_dev[c] : (((a.uni_mask >> c) & 1u) ? a.uni[c] : a.src.c[c][0]);
   }
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < a.n;
        i += (long long)gridDim.x * blockDim.x) {
     const long long g = a.goff + i;
     const u32 r = a.zr[i];
-    const long long src = r == ZR_SURVIVOR ? g : (long long)a.dupes[r];
+    const bool surv = r == ZR_SURVIVOR;
+    const long long src = a.recv_mode ? (surv ? i : (long long)r) : (surv ? g : (long long)a.dupes[r]);
+    const bool from_recv = a.recv_mode && !surv;
     double z[6] = {0, 0, 0, 0, 0, 0};
     if (a.add_noise) {
       if (replay) {
@@ -321,7 +395,8 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
     double v[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      v[c] = (((a.uni_mask >> c) & 1u) ? a.uni[c] : a.src.c[c][src]) + a.nz.sq[c] * z[c];
+      const double* from = from_recv ? a.recv.c[c] : a.src.c[c];
+      v[c] = (((a.uni_mask >> c) & 1u) ? a.uni[c] : from[src]) + a.nz.sq[c] * z[c];
       a.dst.c[c][i] = v[c];
     }
     if (MOMENTS) {

@@ -232,6 +232,12 @@ class Engine(object):
     def comm_shutdown(self, abort=False):
         self._ck(self.lib.mcl_comm_shutdown(self.h, 1 if abort else 0))
 
+    def exchange_stats(self, reset=False):
+        """(particle states sent to peers, lost slots filled) by the sharded resamples since the last reset"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._ck(self.lib.mcl_exchange_stats(self.h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return int(a.value), int(b.value)
+
     # ---- instrumentation
     def timing_enable(self, on=True):
         self._ck(self.lib.mcl_timing_enable(self.h, 1 if on else 0))
@@ -266,6 +272,18 @@ def group_resample(engines, uniforms=None, normals_per_shard=None):
         keep = [_f64(a) for a in normals_per_shard]
         nzp = (C.c_void_p * ns)(*[a.ctypes.data for a in keep])
     _lib.check(lib.mcl_group_resample(hs, ns, _ptr(u), 0 if u is None else u.size, nzp), engines[0].h)
+
+
+def group_step_mbes(engines, v, wz, q, z, dt, ranges, beam_angles, sigma, r_max, sensor_offset=None):
+    """one fused step of a LOCAL group of shards (mcl_group_step_mbes); read the result with
+    engines[0].last_mean_cov()"""
+    lib = _lib.load()
+    ns = len(engines)
+    hs = (C.c_void_p * ns)(*[e.h for e in engines])
+    od = make_odom(v, wz, q, z)
+    r, a, so = _f32(ranges), _f32(beam_angles), _f64(sensor_offset)
+    _lib.check(lib.mcl_group_step_mbes(hs, ns, C.byref(od), float(dt), _ptr(r), _ptr(a), a.size, float(sigma),
+                                       float(r_max), _ptr(so)), engines[0].h)
 
 
 def group_mean_cov(engines):

@@ -13,6 +13,20 @@ from smarc_navigation_amd import synth
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
+def host_threads():
+    """Host threads worth giving the oracle's OpenMP loops: the affinity mask capped by the cgroup CPU quota (the GPU
+    box shows 256 hardware threads but grants 16 CPUs of time; oversubscribing them is slower)."""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            cores = max(1, min(cores, int(-(-int(quota) // int(period)))))
+    except (IOError, ValueError):
+        pass
+    return cores
+
+
 def load(name):
     return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
 

@@ -280,9 +280,16 @@ def test_mean_cov_and_poses_match_oracle(eng, orc):
         np.testing.assert_allclose(poses[i, 3:], orc.quat_from_euler(soa[3, i], soa[4, i], soa[5, i]), atol=1e-14)
 
 
-@pytest.mark.parametrize('shards', [2, 4])
-def test_sharded_equals_unsharded_bitwise(shards, eng):
-    """particle shards + exchange steps give bit-identical states and indices."""
+@pytest.mark.parametrize('exchange', ['p2p', 'allgather'])
+@pytest.mark.parametrize('shards', [2, 4, 8])
+def test_sharded_equals_unsharded_bitwise(shards, exchange, eng, monkeypatch):
+    """particle shards + exchange steps give bit-identical states and indices -- with the O(n)-per-rank
+    exchange (every shard expands its own CDF slice, only surplus copies that fill a PEER's lost slots move) and with
+    the all-gather exchange of rounds 1-2 (MCL_EXCHANGE=allgather)."""
+    if exchange == 'allgather':
+        monkeypatch.setenv('MCL_EXCHANGE', 'allgather')
+    else:
+        monkeypatch.delenv('MCL_EXCHANGE', raising=False)
     n = 8192 * shards
     cov = dict(init_cov=[2, 2, 0, 0, 0, 0.05], process_cov=[1e-3, 1e-3, 0, 0, 0, 1e-5],
                resample_cov=[0.01, 0.01, 0, 0, 0, 1e-4], meas_std=2.0, seed=99)
@@ -304,6 +311,12 @@ def test_sharded_equals_unsharded_bitwise(shards, eng):
         assert np.array_equal(full, parts), step
         assert np.array_equal(one.last_indices(), np.concatenate([e.last_indices() for e in many]))
         assert np.array_equal(one.last_offspring_cdf(), many[0].last_offspring_cdf())
+        assert np.array_equal(one.last_offspring_cdf(), many[-1].last_offspring_cdf())
+    if exchange == 'p2p':
+        sent = sum(e.exchange_stats()[0] for e in many)
+        lost = sum(e.exchange_stats()[1] for e in many)
+        print('%d shards: %d of %d copied particles crossed a shard border' % (shards, sent, lost))
+        assert 0 < sent < lost   # something moved between shards, most copies stayed at home
     m1 = one.mean_cov()
     m2 = eng.group_mean_cov(many)
     np.testing.assert_allclose(m1[0], m2[0], rtol=1e-13, atol=1e-13)
@@ -325,15 +338,16 @@ def test_rccl_paths_with_one_rank_match_plain_filter(eng, monkeypatch):
     q = orc.quat_from_euler(0.0, 0.0, 0.1)
     ranges = np.full(B, 21.0, np.float32)
     results = []
-    for force, no_overlap in (('0', '0'), ('1', '0'), ('1', '1')):
+    for force, no_overlap, exchange in (('0', '0', 'p2p'), ('1', '0', 'p2p'), ('1', '0', 'allgather'), ('1', '1', 'allgather')):
         monkeypatch.setenv('MCL_FORCE_COMM', force)
         monkeypatch.setenv('MCL_NO_OVERLAP', no_overlap)
+        monkeypatch.setenv('MCL_EXCHANGE', exchange)
         e = eng.Engine(n, **cov)
         e.comm_init(eng.comm_unique_id())
         # the communicator really exists (an all-reduce(sum) of 1 counts its ranks), the second one only
-        # with the overlap on; the deadline self-test runs the step's two-communicator pattern
+        # with the all-gather exchange and the overlap on; the deadline self-test runs the step's collective pattern
         ranks, overlap = e.comm_ranks()
-        assert ranks == 1 and overlap == (force == '1' and no_overlap == '0')
+        assert ranks == 1 and overlap == (force == '1' and no_overlap == '0' and exchange == 'allgather')
         e.comm_selftest(20000)
         e.set_map_grid(z, origin, 1.0)
         e.init_particles()
@@ -364,9 +378,10 @@ def test_state_exchange_leaves_out_the_components_predict_made_uniform(fused, en
     q = orc.quat_from_euler(0.03, -0.05, 0.1)
     ranges = np.full(B, 21.0, np.float32)
     results = []
-    for force, no_overlap in (('0', '0'), ('1', '0'), ('1', '1')):
+    for force, no_overlap, exchange in (('0', '0', 'p2p'), ('1', '0', 'p2p'), ('1', '0', 'allgather'), ('1', '1', 'allgather')):
         monkeypatch.setenv('MCL_FORCE_COMM', force)
         monkeypatch.setenv('MCL_NO_OVERLAP', no_overlap)
+        monkeypatch.setenv('MCL_EXCHANGE', exchange)
         e = eng.Engine(n, **cov)
         e.comm_init(eng.comm_unique_id())
         e.set_map_grid(z, origin, 1.0)
@@ -400,6 +415,7 @@ def test_comm_shutdown_and_reinit_without_overlap(eng, monkeypatch):
     from smarc_navigation_amd import synth
     from oracle import oracle as orc
     monkeypatch.setenv('MCL_FORCE_COMM', '1')
+    monkeypatch.setenv('MCL_EXCHANGE', 'allgather')   # (the exchange that has a second communicator to lose)
     n, B = 8192, 64
     origin = (-64.0, -64.0)
     z = synth.bathymetry_grid(128, 128, 1.0, origin, seed=3)
