@@ -1,7 +1,11 @@
-"""world_size-2 CPU test (gloo): the particle-sharded resample algorithm -- local weights,
-all-reduce(max), shard totals all-gather, offspring-CDF all-gather, state all-gather, per-slot
-reassign -- gives bit-identical particles to the unsharded filter.  Compute is the oracle (no GPU
-here); the exchange pattern is exactly the one libmcl_hip.so runs over RCCL."""
+"""world_size-2 (and 3) CPU tests (gloo): the particle-sharded resample algorithm gives bit-identical particles to
+the unsharded filter, in both exchange patterns libmcl_hip.so runs over RCCL:
+  * all-gather: local weights, all-reduce(max), shard totals all-gather, offspring-CDF all-gather, state all-gather,
+    per-slot reassign (MCL_EXCHANGE=allgather);
+  * O(n) per rank (default): every shard expands its OWN CDF slice, the shards all-gather {lost slots, surplus
+    copies}, and rank q sends rank r exactly the surplus copies whose positions in the global dupes order fall into
+    r's lost ranks (point-to-point).
+Compute is the oracle (no GPU here)."""
 import os
 import socket
 
@@ -70,6 +74,95 @@ def _worker(rank, world, port, n, seed, ret):
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
+
+
+def _worker_p2p(rank, world, port, n, seed, spread, ret):
+    """The O(n)-per-rank exchange: mcl_api.hip phase_expand_local / exchange_ls / phase_pack / exchange_dupes."""
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(seed)
+        lw_all = -0.5 * (rs.randn(n) * spread) ** 2 - 40.0
+        if spread > 3.0:
+            lw_all[: n // world] += 6.0   # the weight sits in shard 0: its surplus copies fill the other shards
+        soa_all = rs.randn(6, n)
+        u53 = orc.u_to_u53(rs.random_sample())
+        nl = n // world
+        sl = slice(rank * nl, (rank + 1) * nl)
+        lw, soa = lw_all[sl].copy(), np.ascontiguousarray(soa_all[:, sl])
+        m = torch.tensor([float(np.max(lw))], dtype=torch.float64)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        q, tot = orc.fixed_weights_shard(lw, 1, n, float(m[0]))
+        tl = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([np.uint64(tot).astype(np.int64)], dtype=torch.int64))
+        totals = [int(np.int64(t[0]).astype(np.uint64)) for t in tl]
+        T, off = sum(totals), sum(totals[:rank])
+        # ---- local expansion: the shard's own CDF slice, the CDF value just before the shard
+        ncum_loc = orc.systematic_ncum(q, u53, off, T, n).astype(np.int64)
+        nc_start = int(orc.systematic_ncum(np.zeros(1, np.uint64), u53, off, T, n)[0]) if off else 0
+        c = np.diff(np.concatenate([[nc_start], ncum_loc]))
+        lost_local = np.nonzero(c == 0)[0]
+        dupes_local = np.repeat(np.arange(nl), np.maximum(c - 1, 0))   # ancestors ascending, c - 1 copies each
+        L, S = lost_local.size, dupes_local.size
+        assert S == (int(ncum_loc[-1]) - nc_start) - nl + L
+        # ---- hand-over records
+        gl = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(gl, torch.tensor([L, S], dtype=torch.int64))
+        Ls, Ss = [int(g[0]) for g in gl], [int(g[1]) for g in gl]
+        assert sum(Ls) == sum(Ss)
+        Lpre, Spre = np.concatenate([[0], np.cumsum(Ls)]), np.concatenate([[0], np.cumsum(Ss)])
+        send = np.ascontiguousarray(soa[:, dupes_local])   # packed surplus copies, position Spre[rank] + p
+        recv = np.full((6, L), np.nan)
+
+        def rng(frm, to):
+            lo, hi = max(Spre[frm], Lpre[to]), min(Spre[frm + 1], Lpre[to + 1])
+            return int(lo), int(max(hi, lo))
+        lo, hi = rng(rank, rank)
+        recv[:, lo - Lpre[rank]:hi - Lpre[rank]] = send[:, lo - Spre[rank]:hi - Spre[rank]]
+        reqs, bufs, sent = [], [], 0
+        for r in range(world):
+            if r == rank:
+                continue
+            lo, hi = rng(rank, r)
+            if hi > lo:
+                t = torch.from_numpy(np.ascontiguousarray(send[:, lo - Spre[rank]:hi - Spre[rank]]))
+                reqs.append(dist.isend(t, r))
+                sent += hi - lo
+            lo, hi = rng(r, rank)
+            if hi > lo:
+                t = torch.zeros(6, hi - lo, dtype=torch.float64)
+                reqs.append(dist.irecv(t, r))
+                bufs.append((lo, hi, t))
+        for rq in reqs:
+            rq.wait()
+        for lo, hi, t in bufs:
+            recv[:, lo - Lpre[rank]:hi - Lpre[rank]] = t.numpy()
+        mine = soa.copy()
+        mine[:, lost_local] = recv
+        ref, idx_ref, ncum_ref = _unsharded(lw_all, soa_all, u53, 1)
+        ok = np.array_equal(mine, ref[:, sl]) and np.array_equal(ncum_loc.astype(np.uint32), ncum_ref[sl])
+        ret[rank] = (bool(ok), int(sent), int(L))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n,spread', [(2, 4096, 2.5), (2, 20000, 2.5), (3, 6000, 2.5), (2, 8192, 4.0), (3, 9000, 4.0)])
+def test_sharded_resample_o_n_exchange_gloo(world, n, spread):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_p2p, args=(world, port, n, 23, spread, ret), nprocs=world, join=True)
+        out = dict(ret)
+    assert all(out[r][0] for r in range(world)), out
+    sent, lost = sum(v[1] for v in out.values()), sum(v[2] for v in out.values())
+    assert 0 < sent < lost   # copies crossed shard borders; far fewer than were made
+    if spread > 3.0:
+        assert out[0][1] > 0.3 * lost   # the heavy shard fed the others
 
 
 @pytest.mark.parametrize('n', [4096, 20000])
