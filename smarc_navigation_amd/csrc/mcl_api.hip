@@ -123,6 +123,7 @@ struct mcl_handle {
   std::vector<float> ranges_host;   // last uploaded ranges (the sweep's beam table is built from them)
   bool sweep_angles_ok = false;     // ascending, finite, |a| <= 85 degrees
   int b_split = 0;
+  float sweep_tan0[4] = {0.f, 0.f, 0.f, 0.f};
   float4* sweep_beams = nullptr;
   float* sweep_tail = nullptr;
   int sweep_cap = 0;
@@ -1257,28 +1258,37 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
   float* tail = blk.data() + (size_t)B * 4;
   float* rng = tail + B;
   for (int b = 0; b < B; ++b) tail[b] = 0.f;
-  const float inv_sigma = (float)(1.0 / sigma), rmaxf = (float)r_max;
+  const float rmaxf = (float)r_max;
   int nvalid = 0;
   for (int b = 0; b < B; ++b) {
     const double ang = (double)h->beam_cache[b];
     const float rm = (with_ranges && (int)h->ranges_host.size() == B) ? h->ranges_host[b] : 0.f;
     const bool valid = rm > 0.f;  // NaN fails the test (as in the cast kernels)
     nvalid += valid ? 1 : 0;
-    tb[b].x = (float)(std::tan(ang) * (b < h->b_split ? -1.0 : 1.0));
-    tb[b].y = (float)(1.0 / std::cos(ang));
-    tb[b].z = valid ? rm : 0.f;
-    tb[b].w = valid ? inv_sigma : 0.f;
+    // the residual's constants: (range_b - r) w with r = min(t / cos a, r_max) is max(z w - t (w / cos a), (z - r_max) w);
+    // an invalid beam has all three zero.  Expected-range calls (no measured ranges) keep 1 / cos a in .y
+    const double sec = 1.0 / std::cos(ang);
+    // .x: the side-signed tangent of the beam SWEEP_TAN_AHEAD places further out on this beam's side (mcl_sweep.h)
+    {
+      const int nb = b < h->b_split ? b - SWEEP_TAN_AHEAD : b + SWEEP_TAN_AHEAD;
+      tb[b].x = (nb < 0 || nb >= B) ? INFINITY : (float)(std::tan((double)h->beam_cache[nb]) * (b < h->b_split ? -1.0 : 1.0));
+    }
+    tb[b].y = with_ranges ? (valid ? (float)(sec / sigma) : 0.f) : (float)sec;
+    tb[b].z = valid ? (float)((double)rm / sigma) : 0.f;
+    tb[b].w = valid ? (float)(((double)rm - (double)rmaxf) / sigma) : 0.f;
     rng[b] = rm;
   }
-  auto miss = [&](int b) {
-    const float d = (tb[b].z - rmaxf) * tb[b].w;
-    return d * d;
-  };
+  auto miss = [&](int b) { return tb[b].w * tb[b].w; };
   float run = 0.f;
   for (int b = B - 1; b >= h->b_split; --b) tail[b] = (run += miss(b));
   run = 0.f;
   for (int b = 0; b < h->b_split; ++b) tail[b] = (run += miss(b));
   h->sweep_nvalid = nvalid;
+  for (int k = 0; k < 2; ++k) {
+    const int bp = h->b_split + k, bm = h->b_split - 1 - k;
+    h->sweep_tan0[2 * k] = bp < B ? (float)std::tan((double)h->beam_cache[bp]) : INFINITY;
+    h->sweep_tan0[2 * k + 1] = bm >= 0 ? (float)(-std::tan((double)h->beam_cache[bm])) : INFINITY;
+  }
   RET_IF(upload(h, h->sweep_beams, blk.data(), sizeof(float) * blk.size()));
   h->ranges_ptr = h->sweep_tail + B;
   h->ranges_pending = false;
@@ -1354,6 +1364,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.sweep_tail = nullptr;
   a.b_split = 0;
   a.sweep_nvalid = 0;
+  for (int k = 0; k < 4; ++k) a.sweep_tan0[k] = INFINITY;
   a.sweep_c2z_min = 2.f;
   a.sweep_slope = 0.f;
   a.defer_idx = nullptr;
@@ -1424,7 +1435,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     const bool tin = h->map_kind == 1 && h->mesh->tin_ok && !h->mesh_no_sweep && (!structured || a.diag_mode == 0);
     bool sweep = ((structured && (a.diag_mode == 1 || a.diag_mode == 2)) || h->map_kind == 0 || tin) && h->sweep_angles_ok && h->env_sweep != 0 &&
                  h->ng >= sweep_min_n &&  // (the GLOBAL count: every shard of a cloud takes the same path, results do not depend on the GPU count)
-                 h->n < (1ll << 31) && (long long)a.nx * a.ny < (1ll << 31);
+                 h->n < (1ll << 31) && (long long)a.nx * a.ny < (1ll << 30) && a.ny < (1 << 21);
     h->sweep_now = sweep;
     if (sweep) {
       RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max));
@@ -1443,6 +1454,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.sweep_tail = h->sweep_tail;
     a.b_split = h->b_split;
     a.sweep_nvalid = h->sweep_nvalid;
+    for (int k = 0; k < 4; ++k) a.sweep_tan0[k] = h->sweep_tan0[k];
     // (grids: 0.45 -- below 0.5 the plane function cannot change sign around a cell's four corners, mcl_sweep.h)
     const double slope_max = h->map_kind == 0 ? h->gslope_max : h->mesh->slope_max;
     const double tan_lim = std::min(std::tan(35.0 * MCL_PI / 180.0), (h->map_kind == 0 ? 0.45 : 0.8) / std::max(slope_max, 1e-9));

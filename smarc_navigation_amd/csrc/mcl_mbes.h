@@ -104,7 +104,8 @@ struct MbesArgs {
   int* work_count;        // device counter, zeroed before every fast launch
   unsigned long long* stats;  // MBES_STATS builds: steps, exact tests, rays, retries
   // fan sweep (mcl_sweep.h): regularly triangulated meshes, ascending beam angles
-  const float4* sweep_beams;  // per beam: side-signed tan a, 1 / cos a, measured range, weight (inv_sigma, or 0: invalid)
+  const float4* sweep_beams;  // per beam: side-signed tan of the beam SWEEP_TAN_AHEAD places further out on its side (+inf beyond the last), w / cos a, z w, (z - r_max) w  (z measured range, w = 1 / sigma; invalid beam: zeros; expected-range calls: .y = 1 / cos a)
+  float sweep_tan0[4];        // side-signed tan of the first beam of the + / - side, then of the second one (+inf: no such beam)
   const float* sweep_tail;    // per beam: sum of ((range - r_max) * weight)^2 over this beam and the ones beyond it on its side
   int b_split;                // first beam with a >= 0: beams [b_split, B) sweep outward on the + side, [0, b_split) on the - side
   int sweep_nvalid;           // beams with a valid measured range

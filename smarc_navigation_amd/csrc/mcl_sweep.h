@@ -37,6 +37,20 @@
 #endif
 
 #define SWEEP_FAIL(code) return false  // (code: which test declined -- for a debugger)
+#ifndef SWEEP_TAN_AHEAD
+#define SWEEP_TAN_AHEAD 2   // record b carries the tangent of the beam this many places further out on its side
+#endif
+#ifndef SWEEP_SCHED_BARRIER
+#define SWEEP_SCHED_BARRIER 1
+#endif
+
+// v_max_f32 as the hardware does it (IEEE maxNum: a NaN operand loses).  fmaxf() adds a canonicalising v_max(x, x) in
+// front of every operand that comes out of memory -- one more instruction in a 12-instruction loop.
+__device__ __forceinline__ float hw_max(float x, float y) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
 
 struct SweepNode {
   int P;        // lattice coordinates relative to the sensor's cell, packed i * 65536 + j (j signed)
@@ -116,7 +130,10 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   if (!pre) SWEEP_FAIL(1);
   const float* __restrict__ gp = a.grid + ((size_t)I0 * ny + J0);  // node (I0, J0); every access below is inside the footprint
   const float* __restrict__ grid = a.grid;
-  const int g0i = I0 * ny + J0, g_hi = nx * ny - 1;  // (maps below 2^31 nodes: checked on the host)
+  const int g0i = I0 * ny + J0, g_hi = nx * ny - 1;  // (maps below 2^30 nodes: checked on the host)
+  // the height array as a raw buffer (stride 0, num_records in bytes): out-of-range reads return 0
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.grid, 0, nx * ny * 4, 0x00020000);
+  const int ny4 = ny * 4, g0b = g0i * 4;
   // ---- nadir hit: the ordinary clearance traversal on the global height array
   const float r0 = cast_clear<SURF>(gp, ny, a, ul, vl, oz, -P.c2[0] * inv_res, -P.c2[1] * inv_res, -c2z, a.zmax_map, a.r_max);
   if (!(r0 < a.r_max)) SWEEP_FAIL(5);
@@ -191,7 +208,15 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   bool ok = true;
   const int max_steps = (int)(3.f * (s_stop + 4.f * res) * inv_res) + 16;
   int step = 0;
-  float4 bm = sbeam[ptr];  // the next beam to resolve stays in registers across segments: a vertex it passes beyond costs no LDS read
+  // the next beam to resolve stays in registers across segments (a vertex it passes beyond costs no LDS read), the one
+  // after it is already on its way from LDS: the table is walked by pointer, one add per beam
+  // (record b carries the tangent of the NEXT beam of its side in .x: the decision to leave the merge loop never waits
+  //  for the record that has just been requested)
+  const float4* bp = sbeam + ptr;
+  const float4* const bp_end = sbeam + pend;
+  float tcur = side ? a.sweep_tan0[1] : a.sweep_tan0[0];   // tan of the pending beam (side-signed)
+  float tnext = side ? a.sweep_tan0[3] : a.sweep_tan0[2];  // ... and of the one after it (SWEEP_TAN_AHEAD 2)
+  float4 bm = bp[0];
   // SURF 0: does the current / previous vertex lie on a cell edge (and not on an auxiliary diagonal)?
   const auto on_cell_edge = [](int Pa, int Pb) { const int dP = Pa - Pb; return !(dP == 65537 || dP == -65537); };
   bool cur_edge = SURF != 0 || on_cell_edge(A.P, Bn.P), prev_edge = false;
@@ -206,15 +231,19 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   const float rc2z = fast_rcp(c2z);
   // (s, t) -> cells: u = ul + ax s + bx t, v = vl + ay s + by t
   const float ax = sg * P.c1[0] * inv_res, ay = sg * P.c1[1] * inv_res, bx = -P.c2[0] * inv_res, by = -P.c2[1] * inv_res;
-  for (;;) {
+  // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the next triangle.
+  // Returns true when the walk is over (all beams resolved, stop distance, map border, failure).
+  const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc) -> bool {
     // the third node of the triangle across (A, Bn): its height load is in flight while the beams are resolved
     const int Nk = (int)((unsigned)A.P + (unsigned)Bn.P - (unsigned)C);
     const int nj = __builtin_amdgcn_sbfe(Nk, 0, 16), ni = (Nk - nj) >> 16;
-    // (the footprint test keeps a sane walk inside the map; the clamp keeps a NaN-driven one from reading outside it)
-    const float hN = grid[(unsigned)min(max(g0i + ni * ny + nj, 0), g_hi)];
+    // (the footprint test keeps a sane walk inside the map; a NaN-driven one is stopped by the buffer's own range check:
+    //  a raw buffer load beyond num_records returns 0 -- no clamp, no 64-bit address arithmetic.  |ni| < 30000 and
+    //  4 ny < 2^23 -- checked on the host --: the full-rate 24-bit multiply)
+    const float hN = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(ni, ny4) + ((nj << 2) + g0b), 0, 0));
     // CHECKED: is that node on the map at all?  (if not, the slice leaves the map through the edge it stands on)
     const bool off_x = CHECKED && (unsigned)(I0 + ni) >= (unsigned)nx, off_y = CHECKED && (unsigned)(J0 + nj) >= (unsigned)ny;
-    const float dts = t_cur - t_prev;
+    const float dts = tc - tp;
     if (cur_edge) {
       // SURF 0: the patch of the cell the arc (prev -> cur) lies in = the cell of the triangle (A, Bn, C)
       // In the fan plane the clearance z - h(u, v) over this cell is a conic in (s, t),
@@ -241,7 +270,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
         // how far (in e = s - t tan a, per unit tan a) the arc can bulge beyond its chord: along the chord the
         // clearance is -twist * du * dv * l (1 - l) <= |twist du dv| / 4, and moving along -c2 changes the clearance
         // at a rate of at least c2z (1 - slope tan(tilt)) >= 0.55 c2z
-        const float ds = s_cur - s_prev;
+        const float ds = sc - sp;
         const float cu = prev_edge ? fmaf(ax, ds, bx * dts) : 1.f, cv = prev_edge ? fmaf(ay, ds, by * dts) : 1.f;
         kb = 0.46f * fabsf(pD * cu * cv) * rc2z + 1e-6f;
         // the corner heights of the NEXT cell (the one across this edge: the cell of (A, Bn, N)) are in flight
@@ -253,21 +282,20 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
         hp10 = grid[gn + ny];
         hp11 = grid[gn + ny + 1];
       }
-      for (;;) {
-        // (no `ptr != pend` test: the record beyond the last beam has tan a = +inf and t_cur > 0, so e_cur = -inf)
-        const float e_cur = fmaf(-bm.x, t_cur, s_cur);
-        const float e_prev = fmaf(-bm.x, t_prev, s_prev);
-        bool graze = false;
-        if (!(e_cur >= 0.f)) {  // the beam passes beyond this vertex
-          if (SURF != 0) break;
-          if (!(fmaxf(e_cur, e_prev) + bm.x * kb >= 0.f)) break;  // ... by more than the arc can bulge (sentinel: NaN)
-          graze = true;
-        }
-        // crossing of the half line s = t tan a with the chord: e changes sign (<= 0 at prev, >= 0 at cur)
-        const float lam = fmaxf(fminf(e_prev * fast_rcp(e_prev - e_cur), 1.f), 0.f);
-        float tau = fmaf(lam, dts, t_prev);
+      // (no end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0, so e_cur = -inf.  The
+      //  loop is rotated: e_cur of the NEXT beam is formed at the end of the body, one compare decides)
+      float e_cur = fmaf(-tcur, tc, sc);
+      // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes sign:
+      // <= 0 at prev, >= 0 at cur), SURF 0: refined on the patch; then on to the next beam of the table
+      const auto resolve = [&](bool graze) -> bool {
+        const float e_prev = fmaf(-tcur, tp, sp);
+        const float lam = __builtin_amdgcn_fmed3f(e_prev * fast_rcp(e_prev - e_cur), 0.f, 1.f);
+        float tau = fmaf(lam, dts, tp);
+#if SWEEP_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);   // (the record's fields are first needed below: the wait for it belongs here)
+#endif
         if (SURF == 0) {
-          const float q1 = fmaf(g1, bm.x, g2), q2 = fmaf(fmaf(g3, bm.x, g4), bm.x, g5);
+          const float q1 = fmaf(g1, tcur, g2), q2 = fmaf(fmaf(g3, tcur, g4), tcur, g5);
           // the root next to the chord's estimate: one Newton step (the estimate is off by at most the arc's bulge, a
           // few millimetres on smooth terrain), accepted when the residual confirms it to 3e-5 m.  On strongly twisted
           // patches, or where the beam meets the seabed at a shallow angle (two close roots: Newton stalls), the closed
@@ -283,30 +311,53 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
               const float qq = -0.5f * (q1 + (q1 >= 0.f ? sq : -sq));
               const float r1 = g0 * fast_rcp(qq), r2 = qq * fast_rcp(q2);  // r2 = inf / NaN on a planar patch
               const float lo = fminf(r1, r2), hi = fmaxf(r1, r2);
-              const float du = fmaf(ax, bm.x, bx), dv = fmaf(ay, bm.x, by);  // cells per unit t along the beam
+              const float du = fmaf(ax, tcur, bx), dv = fmaf(ay, tcur, by);  // cells per unit t along the beam
               // a root counts if its point lies in this cell (the arc is the only piece of the slice there)
               const float EPS = 2e-4f;
               const bool vlo = (disc >= 0.f) & (lo > 0.f) & (fabsf(fmaf(du, lo, uc) - 0.5f) <= 0.5f + EPS) & (fabsf(fmaf(dv, lo, vc) - 0.5f) <= 0.5f + EPS);
               const bool vhi = (disc >= 0.f) & (hi > 0.f) & (fabsf(fmaf(du, hi, uc) - 0.5f) <= 0.5f + EPS) & (fabsf(fmaf(dv, hi, vc) - 0.5f) <= 0.5f + EPS);
-              if (graze & !(vlo | vhi)) break;  // a beam beyond the far vertex that passes over the arc: not in this cell
+              if (graze & !(vlo | vhi)) return false;  // a beam beyond the far vertex that passes over the arc: not in this cell
               tn = vlo ? lo : (vhi ? hi : tau);  // (neither, bracketed: rounding at the cell border -- the chord)
             }
           }
           tau = tn;
         }
-        const float r = fminf(tau * bm.y, a.r_max);  // range = t / cos a; beyond r_max (or NaN): r_max
+        // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants (mcl_api.hip:
+        // upload_sweep_beams): (range_b - r) w = max(z w - t (w / cos a), (z - r_max) w)
         if (EXPECT_ONLY) {
-          exp_row[ptr] = r;
+          exp_row[bp - sbeam] = fminf(tau * bm.y, a.r_max);
         } else {
-          const float dd = (bm.z - r) * bm.w;
+          const float dd = hw_max(fmaf(-tau, bm.y, bm.z), bm.w);
           acc = fmaf(dd, dd, acc);
         }
-        ptr += pstep;
-        bm = sbeam[ptr];  // (one sentinel record on either end of the table)
+#if SWEEP_TAN_AHEAD == 2
+        tcur = tnext;
+        tnext = bm.x;
+#else
+        tcur = bm.x;
+#endif
+        bp += pstep;
+        bm = bp[0];   // (needed a handful of instructions into the next iteration -- not by its loop test)
+        e_cur = fmaf(-tcur, tc, sc);
+        return true;
+      };
+      // (no end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0, so e_cur = -inf)
+      if (SURF != 0) {
+        while (e_cur >= 0.f) resolve(false);   // until the pending beam passes beyond this vertex
+      } else {
+        for (;;) {
+          bool graze = false;
+          if (!(e_cur >= 0.f)) {  // the beam passes beyond this vertex ...
+            const float e_prev_g = fmaf(-tcur, tp, sp);
+            if (!(fmaxf(e_cur, e_prev_g) + tcur * kb >= 0.f)) break;  // ... by more than the arc can bulge (sentinel: NaN)
+            graze = true;
+          }
+          if (!resolve(graze)) break;
+        }
       }
     }
-    if (ptr == pend) break;
-    if (s_cur > s_stop) break;  // every beam left misses inside r_max (tail below)
+    if (bp == bp_end) return true;
+    if (sc > s_stop) return true;  // every beam left misses inside r_max (tail below)
     if (CHECKED && (off_x | off_y)) {
       // The slice ends at the map border: final if it cannot come back.  In plane coordinates the border x = x_b is
       // the line s = s_L + k t with |k| <= sin(tilt) / |c1x|, the slice is t = f(s) with
@@ -314,11 +365,11 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
       const float sb = fast_sqrt(fmaxf(1.f - c2z * c2z, 0.f));
       const float lhs = sb * (a.sweep_slope + sb), rhs = 0.9f * (c2z - a.sweep_slope * sb);
       ok = (off_x != off_y) & (lhs < rhs * fabsf(off_x ? P.c1[0] : P.c1[1]));
-      break;  // (ok: the beams left get r_max through the tail below)
+      return true;  // (ok: the beams left get r_max through the tail below)
     }
     if (++step > max_steps) {
       ok = false;
-      break;
+      return true;
     }
     const float fi = (float)ni, fj = (float)nj;
     const float dN = fmaf(pu, fi, fmaf(pv, fj, fmaf(pz, hN, p0)));
@@ -335,20 +386,39 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     Bn.s = pos ? sN : Bn.s;
     Bn.t = pos ? tN : Bn.t;
     const float lam = A.d * fast_rcp(A.d - Bn.d);
-    if (cur_edge) {  // (SURF 0: a diagonal crossing is not a vertex of the slice)
-      s_prev = s_cur;
-      t_prev = t_cur;
-      prev_edge = true;
+    const float s_new = fmaf(lam, Bn.s - A.s, A.s), t_new = fmaf(lam, Bn.t - A.t, A.t);
+    if (SURF != 0) {
+      // lattice meshes: every crossing is a vertex of the slice.  The new vertex takes the place of the one before
+      // last and the CALLER swaps the roles (the walk loop is unrolled by two): no register shuffling per step
+      sp = s_new;
+      tp = t_new;
+    } else {
+      if (cur_edge) {  // (a diagonal crossing is not a vertex of the slice)
+        sp = sc;
+        tp = tc;
+        prev_edge = true;
+      }
+      sc = s_new;
+      tc = t_new;
+      cur_edge = on_cell_edge(A.P, Bn.P);
     }
-    s_cur = fmaf(lam, Bn.s - A.s, A.s);
-    t_cur = fmaf(lam, Bn.t - A.t, A.t);
-    if (SURF == 0) cur_edge = on_cell_edge(A.P, Bn.P);
-    if (!(t_cur > 0.f)) {  // the seabed rises above the sensor's own horizon: not for the sweep (see the sentinel records)
+    if (!(t_new > 0.f)) {  // the seabed rises above the sensor's own horizon: not for the sweep (see the sentinel records)
       ok = false;
-      break;
+      return true;
+    }
+    return false;
+  };
+  if (SURF != 0) {
+    for (;;) {
+      if (walk_step(s_prev, t_prev, s_cur, t_cur)) break;
+      if (walk_step(s_cur, t_cur, s_prev, t_prev)) break;
+    }
+  } else {
+    while (!walk_step(s_prev, t_prev, s_cur, t_cur)) {
     }
   }
-  if (ok && ptr != pend) {
+  if (ok && bp != bp_end) {
+    ptr = (int)(bp - sbeam);
     if (EXPECT_ONLY) {
       for (; ptr != pend; ptr += pstep) exp_row[ptr] = a.r_max;
     } else {
@@ -510,30 +580,42 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   bool ok = true;
   const int max_steps = (int)(6.f * (s_stop + 4.f * res) * inv_res) + 64;  // (triangles may be much smaller than a cell)
   int step = 0;
-  float4 bm = sbeam[ptr];
+  const float4* bp = sbeam + ptr;
+  const float4* const bp_end = sbeam + pend;
+  float tcur = side ? a.sweep_tan0[1] : a.sweep_tan0[0];
+  float tnext = side ? a.sweep_tan0[3] : a.sweep_tan0[2];
+  float4 bm = bp[0];
   for (;;) {
     // the neighbour's record is in flight while the beams are resolved
     const bool border = nb >= 0xfffffff0u;
     const size_t tq = border ? 0 : (size_t)nb;
     const uint4 tv3 = ma.tin_tri[2 * tq], tn3 = ma.tin_tri[2 * tq + 1];
     const float dts = t_cur - t_prev;
-    for (;;) {
-      const float e_cur = fmaf(-bm.x, t_cur, s_cur);
-      if (!(e_cur >= 0.f)) break;
-      const float e_prev = fmaf(-bm.x, t_prev, s_prev);
-      const float lam = fmaxf(fminf(e_prev * fast_rcp(e_prev - e_cur), 1.f), 0.f);
+    float e_cur = fmaf(-tcur, t_cur, s_cur);
+    while (e_cur >= 0.f) {
+      const float e_prev = fmaf(-tcur, t_prev, s_prev);
+      const float lam = __builtin_amdgcn_fmed3f(e_prev * fast_rcp(e_prev - e_cur), 0.f, 1.f);
       const float tau = fmaf(lam, dts, t_prev);
-      const float r = fminf(tau * bm.y, a.r_max);
+#if SWEEP_SCHED_BARRIER
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       if (EXPECT_ONLY) {
-        exp_row[ptr] = r;
+        exp_row[bp - sbeam] = fminf(tau * bm.y, a.r_max);
       } else {
-        const float dd = (bm.z - r) * bm.w;
+        const float dd = hw_max(fmaf(-tau, bm.y, bm.z), bm.w);
         acc = fmaf(dd, dd, acc);
       }
-      ptr += pstep;
-      bm = sbeam[ptr];
+#if SWEEP_TAN_AHEAD == 2
+      tcur = tnext;
+      tnext = bm.x;
+#else
+      tcur = bm.x;
+#endif
+      bp += pstep;
+      bm = bp[0];
+      e_cur = fmaf(-tcur, t_cur, s_cur);
     }
-    if (ptr == pend) break;
+    if (bp == bp_end) break;
     if (s_cur > s_stop) break;
     if (border) {
       // the slice runs off the mesh.  Through the map's outer border: final if it cannot come back (same bound as in
@@ -570,7 +652,8 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
       break;
     }
   }
-  if (ok && ptr != pend) {
+  if (ok && bp != bp_end) {
+    ptr = (int)(bp - sbeam);
     if (EXPECT_ONLY) {
       for (; ptr != pend; ptr += pstep) exp_row[ptr] = a.r_max;
     } else {
@@ -581,14 +664,22 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   return ok;
 }
 
-// one particle side: cast, agree with the other side's lane, write lw or hand the particle over; returns lw (or -inf)
+// Work layout: a WAVE holds 64 particles' lanes of ONE side -- waves 2k and 2k+1 of a workgroup are the + and - sides
+// of the same 64 particles.  The lanes of a wave then walk alike whenever the cloud is coherent (a converged filter:
+// neighbouring slots are centimetres apart), so the merge loop's trip count -- the maximum over the wave of the beams
+// per segment -- is close to every lane's own count; with the two sides of a particle in neighbouring lanes (round 2)
+// every wave mixed two unrelated walks.  The two sides meet through LDS.
+#define SWEEP_PARTICLES (SWEEP_THREADS / 2)   // particles per workgroup
+
+// one particle side: cast; the + side's lane then combines both verdicts, writes lw or hands the particle over.
+// j0: position of the workgroup's first particle in the visiting order.  Returns lw (or -inf) in the + side's lanes.
 template <int SURF, bool EXPECT_ONLY, bool CHECKED>
-__device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long gid, long long n, const float4* sbeam,
-                                             const float* stail, int lane) {
-  // position in the visiting order; lanes 2k, 2k+1 = the two sides of one particle.  (Expected ranges in the natural
-  // order: the grid only covers the particles asked for.)
-  const long long j = (gid >> 1) + ((EXPECT_ONLY && !a.perm) ? a.exp_first : 0);
-  const int side = (int)(gid & 1);
+__device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, long long n, const float4* sbeam,
+                                             const float* stail, float* xacc, int* xok) {
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: scalar registers)
+  const int side = w & 1, pl = (w >> 1) * 64 + lane;   // particle within the workgroup
+  // (expected ranges in the natural order: the grid only covers the particles asked for)
+  const long long j = j0 + pl + ((EXPECT_ONLY && !a.perm) ? a.exp_first : 0);
   const bool valid = j < n;
   const long long i = (valid && a.perm) ? (long long)a.perm[j] : j;
   bool ok = true, work = valid;
@@ -605,24 +696,28 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long gid, l
     else
       ok = sweep_side<(SURF == 5 ? 2 : SURF), EXPECT_ONLY, CHECKED>(a, P, sbeam, stail, side, exp_row, acc);
   }
-  // both sides of a particle agree on its fate (the exchange is NOT under `ok &&`: every lane takes part in it)
-  const int ok_i = ok ? 1 : 0;
-  const int ok_other = __shfl_xor(ok_i, 1, 64);
-  const bool ok2 = (ok_i != 0) & (ok_other != 0);
-  const double acc2 = (double)acc + (double)__shfl_xor(acc, 1, 64);
-  const bool writer = work && side == 0;
-  double v = -__builtin_inf();
-  if (writer && ok2 && !EXPECT_ONLY) {
-    v = -0.5 * acc2 - (double)a.sweep_nvalid * a.lognorm;
-    a.lw[i] = v;
+  // both sides of a particle agree on its fate: the - side leaves its verdict and sum in LDS (every lane takes part)
+  if (side) {
+    xacc[pl] = acc;
+    xok[pl] = ok ? 1 : 0;
   }
-  // hand-overs: one atomic per wave
-  const unsigned long long dm = __ballot(writer && !ok2);
-  if (dm) {
-    int base = 0;
-    if (lane == 0) base = atomicAdd(a.defer_count, (int)__popcll(dm));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (writer && !ok2) a.defer_idx[base + (int)__popcll(dm & ((1ull << lane) - 1ull))] = (u32)i;
+  __syncthreads();
+  double v = -__builtin_inf();
+  if (!side) {
+    const bool ok2 = ok & (xok[pl] != 0);
+    const double acc2 = (double)acc + (double)xacc[pl];
+    if (work && ok2 && !EXPECT_ONLY) {
+      v = -0.5 * acc2 - (double)a.sweep_nvalid * a.lognorm;
+      a.lw[i] = v;
+    }
+    // hand-overs: one atomic per wave
+    const unsigned long long dm = __ballot(work && !ok2);
+    if (dm) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(a.defer_count, (int)__popcll(dm));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (work && !ok2) a.defer_idx[base + (int)__popcll(dm & ((1ull << lane) - 1ull))] = (u32)i;
+    }
   }
   return v == v ? v : -__builtin_inf();  // NaN never wins the maximum
 }
@@ -630,6 +725,8 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long gid, l
 template <int SURF, bool EXPECT_ONLY, bool CHECKED = false>
 __global__ void __launch_bounds__(SWEEP_THREADS, (SURF == 0 || SURF == 5) ? SWEEP_MIN_WAVES_GRID : (CHECKED ? 6 : SWEEP_MIN_WAVES)) k_mbes_sweep(MbesArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sweep_lds[];
+  __shared__ float xacc[SWEEP_PARTICLES];
+  __shared__ int xok[SWEEP_PARTICLES];
   float4* sbeam = (float4*)sweep_lds + 1;  // records -1 and n_beams exist (read, never used)
   float* stail = (float*)(sbeam + a.n_beams + 1);
   const long long n = mbes_count(a);  // (CHECKED pass: the length of the first pass's hand-over list, read here)
@@ -641,24 +738,23 @@ __global__ void __launch_bounds__(SWEEP_THREADS, (SURF == 0 || SURF == 5) ? SWEE
   }
   if (threadIdx.x == 0) sbeam[-1] = sbeam[a.n_beams] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);  // "never reached"
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const long long gid0 = blockIdx.x * (long long)SWEEP_THREADS + threadIdx.x;
   double vmax;
   if (!CHECKED) {
     // the first pass is launched with one lane per particle side
-    vmax = sweep_lane<SURF, EXPECT_ONLY, false>(a, gid0, n, sbeam, stail, lane);
+    vmax = sweep_lane<SURF, EXPECT_ONLY, false>(a, blockIdx.x * (long long)SWEEP_PARTICLES, n, sbeam, stail, xacc, xok);
   } else {
-    // the CHECKED pass strides over the first pass's list (whole waves: the lanes exchange verdicts)
+    // the CHECKED pass strides over the first pass's list, a workgroup's worth of particles at a time
     vmax = -__builtin_inf();
-    for (long long gid = gid0; (gid >> 1) < ((n + 31) & ~31ll); gid += (long long)gridDim.x * SWEEP_THREADS) {
-      const double v = sweep_lane<SURF, EXPECT_ONLY, true>(a, gid, n, sbeam, stail, lane);
+    for (long long j0 = blockIdx.x * (long long)SWEEP_PARTICLES; j0 < n; j0 += (long long)gridDim.x * SWEEP_PARTICLES) {
+      const double v = sweep_lane<SURF, EXPECT_ONLY, true>(a, j0, n, sbeam, stail, xacc, xok);
       vmax = v > vmax ? v : vmax;
+      __syncthreads();  // (xacc / xok are rewritten by the next round)
     }
   }
-  if (!EXPECT_ONLY && a.max_slots) {
-    // the normalisation needs max lw: one atomic per wave on an order-preserving key
+  if (!EXPECT_ONLY && a.max_slots && !((threadIdx.x >> 6) & 1)) {
+    // the normalisation needs max lw: one atomic per (+ side) wave on an order-preserving key
     const double m = wave_max(vmax);
-    if (lane == 0 && m > -__builtin_inf())
+    if ((threadIdx.x & 63) == 0 && m > -__builtin_inf())
       atomicMax((unsigned long long*)&a.max_slots[(blockIdx.x * (SWEEP_THREADS / 64) + (threadIdx.x >> 6)) & (MCL_MAX_SLOTS - 1)],
                 ordered_key(m));
   }

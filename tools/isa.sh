@@ -6,7 +6,7 @@ set -e
 OUT=${1:-/tmp/isa}
 mkdir -p "$OUT"
 cd "$(dirname "$0")/../smarc_navigation_amd/csrc"
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S -o "$OUT/mcl.s" mcl_api.hip \
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -fno-slp-vectorize -S -o "$OUT/mcl.s" mcl_api.hip \
   -Rpass-analysis=kernel-resource-usage 2> "$OUT/res.txt" ${ISA_FLAGS}
 python3 - "$OUT" <<'PY'
 import re, sys, subprocess
