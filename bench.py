@@ -55,7 +55,7 @@ def parse(argv=None):
     ap.add_argument('--total-particles', type=int, default=4194304, help='total particles (strong scaling)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--beams', type=int, default=512)
-    ap.add_argument('--map', default='mesh', choices=['grid', 'mesh', 'mesh-general', 'mesh-tin'])
+    ap.add_argument('--map', default='mesh', choices=['grid', 'mesh', 'mesh-general', 'mesh-adjacency', 'mesh-tin'])
     ap.add_argument('--mesh-general', action='store_true', help='same as --map mesh-general')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the extra workload legs (N = 1 runs them by default)')
@@ -144,7 +144,7 @@ def build_map(kind):
     if kind == 'grid':
         origin = (-64.0, -256.0)
         z = synth.bathymetry_grid(512, 512, 1.0, origin, seed=3)
-        return dict(kind='grid', z=z, origin=origin, res=1.0, bytes=z.nbytes,
+        return dict(kind='grid', z=z, origin=origin, res=1.0, bytes=z.nbytes, bytes_what='512 x 512 fp32 heights',
                     desc='512x512 fp32 height grid, 1 m cells')
     origin = (-64.0, -354.0)
     z = synth.bathymetry_grid(708, 708, 1.0, origin, seed=3)
@@ -155,15 +155,28 @@ def build_map(kind):
         verts, tris = synth.mesh_from_grid(z, 1.0, origin)
         desc = '%d-triangle mesh (708x708 height field triangulated)' % tris.shape[0]
         if kind == 'mesh-general':
-            desc += ', treated as an arbitrary triangle mesh (MCL_MESH_GENERAL: no structured-mesh detection)'
-    return dict(kind=kind, z=z, origin=origin, res=1.0, verts=verts, tris=tris, bytes=verts.nbytes + tris.nbytes, desc=desc)
+            desc += ', cast as an arbitrary triangle soup (MCL_MESH_GENERAL: triangle-record traversal only)'
+        if kind == 'mesh-adjacency':
+            desc += ', swept by triangle adjacency (MCL_MESH_UNSTRUCTURED: no structured-mesh detection)'
+    # the bytes the chosen path is REQUIRED to read per ping (M), not the size of the input arrays:
+    # structured mesh -> the node heights; adjacency sweep -> 32 B per triangle + 16 B per vertex; triangle-record
+    # traversal -> 48 B per (cell, triangle) record (at least one per triangle) + 8 B per cell
+    nt, nv = tris.shape[0], verts.shape[0]
+    if kind == 'mesh':
+        mb, what = 4 * z.size, '708 x 708 fp32 node heights (structured mesh: no triangle records are read)'
+    elif kind in ('mesh-tin', 'mesh-adjacency'):
+        mb, what = 32 * nt + 16 * nv, '32 B adjacency record per triangle + 16 B per vertex'
+    else:
+        mb, what = 48 * nt + 8 * (nt // 2), '>= 48 B plane record per triangle + 8 B per cell'
+    return dict(kind=kind, z=z, origin=origin, res=1.0, verts=verts, tris=tris, bytes=mb, bytes_what=what, desc=desc)
 
 
 def attach_map(e, m):
     if m['kind'] == 'grid':
         e.set_map_grid(m['z'], m['origin'], m['res'])
     else:
-        e.set_map_mesh(m['verts'], m['tris'], general=(m['kind'] == 'mesh-general'))
+        e.set_map_mesh(m['verts'], m['tris'], general=(m['kind'] == 'mesh-general'),
+                       unstructured=(m['kind'] == 'mesh-adjacency'))
 
 
 def make_ranges(engine_mod, m, truth, beam_angles, sigma, r_max, device=0, seed=4, m2o=None):
@@ -266,6 +279,7 @@ def mbes_path(e, P):
     meshes) or the ray traversal, and how much of the cloud the first stage passed on to the general kernels."""
     path, handed, deferred = e.mbes_last_path()
     return {'algorithm': 'fan sweep (mcl_sweep.h: k_mbes_sweep)' if path == 1 else 'ray traversal (mcl_mbes.h: k_mbes_fast)',
+            'dominant_launch': 'k_mbes_sweep<SURF,false,false> (first pass)' if path == 1 else 'k_mbes_fast<SURF,false>',
             'particles_handed_to_traversal': handed if path == 1 else None,
             'groups_deferred_to_general_kernel': deferred, 'of_particles': P}
 
@@ -284,7 +298,7 @@ def kernel_table(tim, alg, steps):
 
 
 def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, resample=True, landmarks=None, m2o=None,
-            rccl_1rank=False):
+            rccl_1rank=False, sigma=None):
     """One extra workload leg on a fresh engine: returns ms per step (wall, synchronised around the timed
     block) and the per-phase HIP-event times.  resample=False: predict + MBES update only (the cloud
     keeps its width); landmarks=(xyz, n_det): config 5 -- the landmark k-NN update accumulates onto the
@@ -292,6 +306,7 @@ def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, re
     import numpy as np
     from smarc_navigation_amd import synth
     cov = cov or COV
+    sig = sigma or SIGMA   # the likelihood's sigma (the simulated pings keep SIGMA of range noise)
     total = steps + warmup
     stream = synth.odom_stream(total, x0=x0)
     ba = synth.beam_angles(B)
@@ -327,10 +342,10 @@ def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, re
     def step(k):
         if resample and landmarks is None:
             e.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'], ranges[k], ba,
-                        SIGMA, R_MAX)
+                        sig, R_MAX)
             return
         e.predict(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'])
-        e.update_mbes(ranges[k], ba, SIGMA, R_MAX)
+        e.update_mbes(ranges[k], ba, sig, R_MAX)
         if landmarks is not None:
             e.update_landmarks(dets[k], 0.3, k=4, gate=11.345, accumulate=True)
         if resample:
@@ -349,6 +364,12 @@ def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, re
     tim = e.timing_get()
     e.timing_enable(False)
     path = mbes_path(e, P)
+    cloud = None
+    if resample:
+        mean, _, c9 = e.mean_cov()
+        truth = stream['truth'][total - 1]
+        cloud = {'sigma_x_m': round(float(np.sqrt(max(c9[0], 0.0))), 4), 'sigma_y_m': round(float(np.sqrt(max(c9[4], 0.0))), 4),
+                 'mean_error_m': round(float(np.hypot(mean[0] - truth[0], mean[1] - truth[1])), 4)}
     e.close()
     ms = 1e3 * dt / steps
     out = dict(mbes_path=path, workload='%d particles x %d beams, %s%s%s' % (
@@ -356,6 +377,10 @@ def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, re
         '' if landmarks is None else ', + %d detections x %d landmarks k-NN (k=4) per ping' % (landmarks[1], len(landmarks[0]))),
         steps=steps, ms_per_step=round(ms, 4), steps_per_s=round(1e3 / ms, 2),
         kernels={k: round(v[0] / steps, 5) for k, v in tim.items() if v[1]})
+    if cloud:
+        out['cloud'] = cloud
+    if sigma:
+        out['likelihood_sigma_m'] = round(sig, 3)
     return out
 
 
@@ -518,29 +543,46 @@ def worker(a, rank, world, local_rank):
 
     out = None
     if rank == 0:
-        ms_per_step = 1e3 * dt / a.steps
+        first_block_ms = 1e3 * dt / a.steps
+        ms_per_step = pctl(block_ms, 50)   # the median block (the first block still holds the clock ramp)
         total_particles = P * world
         path_main = mbes_path(e, P)
-        value = a.steps / dt * (total_particles / 1048576.0)
+        value = 1e3 / ms_per_step * (total_particles / 1048576.0)
         alg = alg_bytes(P, B, m['bytes'], world)
         kernels = kernel_table(tim, alg, a.steps)
         dom = max((k for k in kernels if k in alg), key=lambda k: tim[k][0])
-        dom_ms = tim[dom][0] / a.steps
+        # the dominant LAUNCH: HIP events around that one kernel (MCL_K_MBES_MAIN), not the update's whole region
+        if dom == 'update_mbes' and tim.get('mbes_main', (0, 0))[1]:
+            dom_ms = tim['mbes_main'][0] / tim['mbes_main'][1]
+            dom_time_source = 'HIP events around the one launch (%s), mean of %d launches' % (path_main['dominant_launch'], tim['mbes_main'][1])
+        else:
+            dom_ms = tim[dom][0] / a.steps
+            dom_time_source = 'HIP-event region of the phase'
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9
+        # the cloud the timed steps ran on: spread of the last step's posterior and its effective sample size
+        _, _, c9 = e.last_mean_cov()
+        q_fix, q_tot = e.fixed_weights()
+        qf = q_fix.astype(np.float64) / float(q_tot)
+        n_eff = float(1.0 / np.sum(qf * qf))
+        cloud = {'sigma_x_m': round(float(np.sqrt(max(c9[0], 0.0))), 4), 'sigma_y_m': round(float(np.sqrt(max(c9[4], 0.0))), 4),
+                 'n_eff': round(n_eff, 1), 'n_eff_frac': round(n_eff / P, 6),
+                 'note': 'posterior spread after the last timed step and the effective sample size of its weights (this '
+                         'shard): 512 beams at sigma = %.1f m per ping collapse the cloud to the resampling noise within '
+                         'the warm-up -- extra.filter_tempered runs the same step on a filter that keeps a healthy spread' % SIGMA}
         # PMC-measured HBM traffic of the dominant kernel: collected offline (counters cannot be read inside
         # this run) by tools/pmc_summarise.py into profiles/r02_traffic.json, attached ONLY when that file was
         # taken at the kernel sources this library was built from and at this workload
         traffic, traffic_source, pmc = None, None, {}
         src = source_hash()
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r02_traffic.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r03_traffic.json')) as f:
                 tj = json.load(f)
             if tj.get('source_hash') == src and P == 1048576 and B == 512 and world == 1:
                 pmc = tj.get(m['kind'], {})
                 traffic = pmc.get('traffic_bytes_per_launch')
-                traffic_source = 'offline: profiles/r02_traffic.json (rocprofv3 --pmc passes, kernel sources %s)' % src
+                traffic_source = 'offline: profiles/r03_traffic.json (rocprofv3 --pmc passes, kernel sources %s)' % src
             elif tj.get('source_hash') != src:
-                traffic_source = 'none: profiles/r02_traffic.json is for kernel sources %s, this library is %s' % (
+                traffic_source = 'none: profiles/r03_traffic.json is for kernel sources %s, this library is %s' % (
                     tj.get('source_hash'), src)
         except (IOError, ValueError):
             pass
@@ -548,21 +590,27 @@ def worker(a, rank, world, local_rank):
         out = {
             'metric': METRIC,
             'value': round(value, 3), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': a.scaling,
+            'ms_per_step': round(ms_per_step, 4), 'first_block_ms': round(first_block_ms, 4),
+            'higher_is_better': True, 'scaling': a.scaling,
             'vs_baseline': None, 'dtype': 'f64 state / f32 ray-cast', 'data': 'synthetic',
-            'steps_per_s': round(a.steps / dt, 3), 'particles_total': total_particles,
+            'steps_per_s': round(1e3 / ms_per_step, 3), 'particles_total': total_particles, 'cloud': cloud,
             'rccl_ranks': rccl_ranks, 'overlapped_state_gather': bool(has_overlap),
             'launcher': 'bench.py' if os.environ.get('MCL_BENCH_SPAWNED') == '1' else ('external' if world > 1 else 'none'),
             'timed': {'blocks': nblocks, 'steps_per_block': a.steps, 'steps_total': n_timed,
                       'ms_per_step_median': round(pctl(block_ms, 50), 4), 'ms_per_step_p95': round(pctl(block_ms, 95), 4),
                       'ms_per_step_min': round(min(block_ms), 4), 'ms_per_step_max': round(max(block_ms), 4),
-                      'note': 'value/ms_per_step are the first block (exactly --steps steps); the block is repeated '
-                              'until >= %d steps are timed, each between barrier+synchronize pairs' % MIN_TIMED_STEPS},
+                      'note': 'the timed block (exactly --steps steps between barrier+synchronize pairs, max over ranks) '
+                              'is repeated until >= %d steps are timed; value / ms_per_step are the MEDIAN block, '
+                              'first_block_ms the first one' % MIN_TIMED_STEPS},
             'config': {'workload': '%d particles/GPU x %d beams, %s, predict+MBES update+normalise+systematic '
                                    'resample+mean/cov per step' % (P, B, m['desc']),
                        'particles_per_gpu': P, 'beams': B, 'map': m['kind'], 'parallelism': 'particle-shard x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic,
+                         'launch_us': round(dom_ms * 1e3, 2), 'time_source': dom_time_source,
+                         'alg_bytes_per_launch': alg[dom],
+                         'alg_bytes_what': '56 B per particle + 8 B per beam + the map bytes this path must read: %s' % m['bytes_what'],
+                         'rocprof_launch_us': pmc.get('kernel_avg_us'),
                          'traffic_source': traffic_source, 'kernel_source_hash': src,
                          'rays_per_s': round(P * B / (dom_ms * 1e-3), 1),
                          'valu_insts_per_ray': (round(pmc['valu_insts_per_launch'] * 64.0 / (P * B), 1)
@@ -583,6 +631,15 @@ def worker(a, rank, world, local_rank):
             'kernels': kernels,
             'pose_rmse_m': round(pose_rmse, 4),
         }
+        if world > 1:
+            sent, lost = e.exchange_stats()
+            nst = float(total_steps)
+            out['exchange'] = {'mode': os.environ.get('MCL_EXCHANGE', 'p2p (O(n) per rank: hand-over records + point-to-point surplus copies)'),
+                               'rank0_states_sent_per_step': round(sent / nst, 1), 'rank0_lost_slots_per_step': round(lost / nst, 1),
+                               'rank0_bytes_sent_per_step': round(24.0 * sent / nst, 1),
+                               'note': 'x, y, yaw of every surplus copy that fills a lost slot of ANOTHER rank (z, roll, pitch are '
+                                       'the odometry\'s on every particle after predict); the all-gather exchange of rounds 1-2 '
+                                       'moved 28 B x N_global per rank per step'}
     e.close()
 
     # ---- N = 1: CPU baseline, trajectory RMSE against the oracle, extra workload legs
@@ -590,8 +647,10 @@ def worker(a, rank, world, local_rank):
         # all host cores (the oracle's particle loops are OpenMP-parallel) and, beside it, one thread
         ns = a.cpu_particles or (8192 if m['kind'] == 'grid' else 4096)
         cores = host_cores()
-        one = cpu_baseline(m, stream, ranges, ba, COV, 1048576, ns, 1, 8.0)
-        allc = cpu_baseline(m, stream, ranges, ba, COV, 1048576, ns * min(cores, 32), cores, 10.0)
+        one = cpu_baseline(m, stream, ranges, ba, COV, 1048576, ns, 1, 6.0)
+        # all cores: >= 262 144 particles (a quarter of the metric's cloud) so that the trajectory it leaves is a
+        # meaningful reference for "pose RMSE vs ref" -- about 25 s of CPU on 16 threads
+        allc = cpu_baseline(m, stream, ranges, ba, COV, 1048576, max(ns * min(cores, 32), 262144), cores, 22.0, max_steps=6)
         allc['value_1thread'] = one['value']
         allc['sample_1thread'] = one['sample']
         # "pose RMSE vs ref": the same filter (same Philox draws, same stream and map) on the GPU at the
@@ -622,9 +681,14 @@ def worker(a, rank, world, local_rank):
         mesh = m if a.map == 'mesh' else build_map('mesh')
         if a.map != 'grid':
             legs.append(('grid', dict(m=build_map('grid'), P=1048576, B=512, steps=30, warmup=5)))
+        # a filter that keeps a healthy spread: the 512 beams of a ping share ONE error budget (likelihood tempered by
+        # 1 / B: sigma_eff = sigma sqrt(B) = 4.5 m), so the posterior stays decimetres wide instead of collapsing to
+        # the resampling noise -- the same kernels, the same launches, lanes of a wave no longer walk the same triangles
+        legs.append(('filter_tempered', dict(m=mesh, P=1048576, B=512, steps=30, warmup=10, sigma=SIGMA * math.sqrt(512.0))))
         if a.map != 'mesh-general':
-            mg = dict(mesh, kind='mesh-general', desc=mesh['desc'] + ', treated as an arbitrary triangle mesh (MCL_MESH_GENERAL: no structured-mesh detection)')
-            legs.append(('mesh_general', dict(m=mg, P=1048576, B=512, steps=20, warmup=3)))
+            legs.append(('mesh_general', dict(m=build_map('mesh-general'), P=1048576, B=512, steps=10, warmup=2)))
+        if a.map != 'mesh-adjacency':
+            legs.append(('mesh_adjacency', dict(m=build_map('mesh-adjacency'), P=1048576, B=512, steps=20, warmup=3)))
         if a.map != 'mesh-tin':
             legs.append(('mesh_tin', dict(m=build_map('mesh-tin'), P=1048576, B=512, steps=20, warmup=3)))
         # global-localisation regime: sigma = 50 m cloud that nothing collapses (no resample).  Particles are

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MCL_ABI_VERSION 1
+#define MCL_ABI_VERSION 2   /* 2: mcl_timing gained MCL_K_MBES_MAIN */
 
 typedef struct mcl_handle mcl_handle;
 
@@ -100,7 +100,10 @@ enum mcl_kernel_id {
   MCL_K_MEAN_COV = 6,
   MCL_K_NOISE = 7,
   MCL_K_COMM = 8,
-  MCL_K_COUNT = 9
+  MCL_K_MBES_MAIN = 9, /* the ONE dominant launch of an MBES update (first sweep pass, or the fast traversal kernel):
+                          nested inside MCL_K_UPDATE_MBES, whose region also holds the memset, the pose kernel and the
+                          (usually empty) hand-over launches */
+  MCL_K_COUNT = 10
 };
 typedef struct mcl_timing {
   double ms[MCL_K_COUNT];       /* summed device milliseconds */

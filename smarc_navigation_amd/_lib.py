@@ -9,7 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get('MCL_LIB', os.path.join(_HERE, 'libmcl_hip.so'))  # MCL_LIB: kernel-variant A/B runs
 
-MCL_K_NAMES = ['predict', 'update_gps', 'update_mbes', 'normalise', 'scan', 'resample', 'mean_cov', 'noise', 'comm']
+MCL_K_NAMES = ['predict', 'update_gps', 'update_mbes', 'normalise', 'scan', 'resample', 'mean_cov', 'noise', 'comm',
+               'mbes_main']
 
 
 class MclError(RuntimeError):
@@ -42,7 +43,7 @@ class DrOdom(C.Structure):
 
 
 class Timing(C.Structure):
-    _fields_ = [('ms', C.c_double * 9), ('launches', C.c_int64 * 9)]
+    _fields_ = [('ms', C.c_double * 10), ('launches', C.c_int64 * 10)]
 
 
 # every symbol include/mcl.h, mcl_dr.h and mcl_map.h declare: name -> (restype, argtypes)
@@ -134,7 +135,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.mcl_abi_version() != 1:
+    if lib.mcl_abi_version() != 2:
         raise ImportError('libmcl_hip.so ABI version mismatch')
     _lib = lib
     return lib

@@ -45,6 +45,7 @@ thread_local std::string g_create_err;
 struct TimedRegion {
   hipEvent_t a, b;
   int k;
+  bool open;
 };
 
 }  // namespace
@@ -254,15 +255,22 @@ void t_begin(mcl_handle* h, int k) {
     (void)hipEventCreate(&ev.second);
   }
   (void)hipEventRecord(ev.first, h->stream);
-  h->regions.push_back(TimedRegion{ev.first, ev.second, k});
+  h->regions.push_back(TimedRegion{ev.first, ev.second, k, true});
 }
+// closes the innermost open region (regions nest: MCL_K_MBES_MAIN inside MCL_K_UPDATE_MBES)
 void t_end(mcl_handle* h) {
   if (!h->timing) return;
-  (void)hipEventRecord(h->regions.back().b, h->stream);
+  for (size_t r = h->regions.size(); r-- > 0;)
+    if (h->regions[r].open) {
+      h->regions[r].open = false;
+      (void)hipEventRecord(h->regions[r].b, h->stream);
+      return;
+    }
 }
 void t_collect(mcl_handle* h) {
   for (auto& r : h->regions) {
     float ms = 0.f;
+    if (r.open) (void)hipEventRecord(r.b, h->stream);  // (an error return left it open)
     (void)hipEventSynchronize(r.b);
     (void)hipEventElapsedTime(&ms, r.a, r.b);
     h->tacc.ms[r.k] += ms;
@@ -1540,7 +1548,9 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
 #define LAUNCH_SWEEP(SURFV, MAPV)                                                        \
   do {                                                                                   \
     if (with_ranges) {                                                                   \
+      t_begin(h, MCL_K_MBES_MAIN);                                                       \
       k_mbes_sweep<SURFV, false, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);    \
+      t_end(h);                                                                          \
       k_mbes_sweep<SURFV, false, true><<<s2grid, SWEEP_THREADS, lds, h->stream>>>(c);    \
       k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
       k_mbes_fast<SURFV, false><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);               \
@@ -1556,7 +1566,9 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
 #define LAUNCH_SWEEP_TIN(SURFV, MAPV)                                                    \
   do {                                                                                   \
     if (with_ranges) {                                                                   \
+      t_begin(h, MCL_K_MBES_MAIN);                                                       \
       k_mbes_sweep<5, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);               \
+      t_end(h);                                                                          \
       k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
       k_mbes_fast<SURFV, false><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);               \
       k_mbes_cast<MAPV, false, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);             \
@@ -1606,7 +1618,9 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
 #define LAUNCH_LEAN(SURFV, MAPV)                                                   \
   do {                                                                             \
     if (with_ranges) {                                                             \
+      t_begin(h, MCL_K_MBES_MAIN);                                                 \
       k_mbes_fast<SURFV, false><<<grid, MBES_THREADS, 0, h->stream>>>(a);          \
+      t_end(h);                                                                    \
       k_mbes_cast<MAPV, false, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);       \
     } else {                                                                       \
       k_mbes_fast<SURFV, true><<<grid, MBES_THREADS, 0, h->stream>>>(a);           \

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_summarise.py -- turn rocprofv3 --pmc CSV passes into profiles/r02_traffic.json.
+"""tools/pmc_summarise.py -- turn rocprofv3 --pmc CSV passes into profiles/r03_traffic.json.
 
     python tools/pmc_summarise.py <dir with pmc_<map>_{fetch,write,sq}/.../*_counter_collection.csv> [out.json]
 
@@ -39,11 +39,11 @@ def mean_counter(d, pass_name, kernel_prefix, counter):
 def main():
     import bench
     d = sys.argv[1]
-    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'profiles', 'r03_traffic.json')
     res = {'_how': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (three separate passes) on '
                    '`python3 bench.py --map <m> --steps 4 --warmup 1 --only-main`, dominant kernel k_mbes_sweep<2,false,false> (mesh) / k_mbes_sweep<0,false,false> (grid): the first sweep pass, '
                    'mean over dispatches; KB -> bytes x1024; FETCH_SIZE doubled (gfx950 reports half of a wide streaming read)',
-           '_round': 2, 'source_hash': bench.source_hash()}
+           '_round': 3, 'source_hash': bench.source_hash()}
     for kind, prefix in (('mesh', 'void k_mbes_sweep<2, false, false>'), ('grid', 'void k_mbes_sweep<0, false, false>')):
         e = {}
         f, nf = mean_counter(d, 'pmc_%s_fetch' % kind, prefix, 'FETCH_SIZE')
@@ -69,6 +69,13 @@ def main():
         if 'SQ_LDS_BANK_CONFLICT' in sq:
             e['lds_bank_conflict_cycles'] = sq['SQ_LDS_BANK_CONFLICT']
         e['sq_raw'] = sq
+        # in-kernel average of the same kernel from the --kernel-trace --stats pass of the same command
+        for p in glob.glob(os.path.join(d, 'stats_%s' % kind, '**', '*kernel_stats.csv'), recursive=True):
+            with open(p) as f:
+                for r in csv.DictReader(f):
+                    if r['Name'].startswith(prefix):
+                        e['kernel_avg_us'] = float(r['AverageNs']) / 1e3
+                        e['kernel_calls'] = int(r['Calls'])
         res[kind] = e
     with open(out, 'w') as f:
         json.dump(res, f, indent=1)
