@@ -170,7 +170,9 @@ struct mcl_handle {
   // surplus copies packed for the peers, copies received for this shard's lost slots
   bool exch_allgather = false;   // MCL_EXCHANGE=allgather: the all-gather exchange of rounds 1-2 instead
   u64* lsx = nullptr;            // device, world x 4 words
-  u64* lsx_host = nullptr;       // pinned, world x 4 words
+  u64* lsx_host = nullptr;       // pinned, world x 4 words + the sequence word k_publish_ls writes last
+  u64* lsx_host_dev = nullptr;   // its device-side address
+  u64 ls_seq = 0;
   double* xsend = nullptr;       // 6 x xsend_cap
   size_t xsend_cap = 0;
   double* xrecv = nullptr;       // 6 x n
@@ -619,14 +621,20 @@ int phase_expand(mcl_handle* h, bool fused_cdf, uint64_t u53) {
 }
 
 // ---- O(n)-per-rank exchange -------------------------------------------------------------------------------
+int alloc_lsx(mcl_handle* h) {
+  if (h->lsx) return MCL_OK;
+  HIPCHK(h, hipMalloc(&h->lsx, sizeof(u64) * 4 * (size_t)h->world));
+  HIPCHK(h, hipHostMalloc(&h->lsx_host, sizeof(u64) * (4 * (size_t)h->world + 1), hipHostMallocMapped | hipHostMallocCoherent));  // (fine-grained: the host polls it while kernels run)
+  memset(h->lsx_host, 0, sizeof(u64) * (4 * (size_t)h->world + 1));
+  if (hipHostGetDevicePointer((void**)&h->lsx_host_dev, h->lsx_host, 0) != hipSuccess) h->lsx_host_dev = nullptr;
+  return MCL_OK;
+}
+int launch_pack(mcl_handle* h);
 // CDF, lost ranks and dupes list of THIS shard only (k_cdf_expand<true> over the shard, global weight offsets from the
 // all-gathered totals); leaves the shard's hand-over record in lsx[rank]
 int phase_expand_local(mcl_handle* h, uint64_t u53) {
   RET_IF(set_device(h));
-  if (!h->lsx) {
-    HIPCHK(h, hipMalloc(&h->lsx, sizeof(u64) * 4 * (size_t)h->world));
-    HIPCHK(h, hipHostMalloc(&h->lsx_host, sizeof(u64) * 4 * (size_t)h->world, hipHostMallocDefault));
-  }
+  RET_IF(alloc_lsx(h));
   ExpandArgs a;
   memset(&a, 0, sizeof a);
   a.q = h->q;
@@ -667,9 +675,32 @@ int exchange_ls(mcl_handle** sh, int ns) {
     t_begin(h, MCL_K_COMM);
     if (h->comm && world > 1)
       NCCLCHK(h, ncclAllGather(h->lsx + 4 * (size_t)h->rank, h->lsx, 4, ncclUint64, h->comm, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->lsx_host, h->lsx, sizeof(u64) * 4 * (size_t)world, hipMemcpyDeviceToHost, h->stream));
-    t_end(h);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->lsx_host_dev) {
+      // the records travel to pinned memory by a kernel that writes a sequence word last; the pack kernel (sized on
+      // the device from the same records) is queued behind it BEFORE the host starts to wait, so the GPU keeps
+      // working while the host wakes up; the host spins on the word instead of synchronising the stream
+      const u64 seq = ++h->ls_seq;
+      k_publish_ls<<<1, 64, 0, h->stream>>>(h->lsx, 4 * world, h->lsx_host_dev, h->lsx_host_dev + 4 * (size_t)world, seq);
+      t_end(h);
+      HIPCHK(h, hipGetLastError());
+      RET_IF(launch_pack(h));
+      volatile u64* flag = h->lsx_host + 4 * (size_t)world;
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xfffu) == 0u) {
+          if (hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+            return fail(h, MCL_ERR_HIP, "resample exchange: the hand-over records never arrived");
+          if (std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count() > 60)
+            return fail(h, MCL_ERR_COMM, "resample exchange: timed out waiting for the hand-over records");
+        }
+        __builtin_ia32_pause();
+      }
+    } else {
+      HIPCHK(h, hipMemcpyAsync(h->lsx_host, h->lsx, sizeof(u64) * 4 * (size_t)world, hipMemcpyDeviceToHost, h->stream));
+      t_end(h);
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
   } else {
     for (int s = 0; s < ns; ++s) {
       mcl_handle* h = sh[s];
@@ -702,38 +733,51 @@ int exchange_ls(mcl_handle** sh, int ns) {
   return MCL_OK;
 }
 
-// surplus copies into the send buffer (own lost slots: straight into the receive buffer)
-int phase_pack(mcl_handle* h) {
+// surplus copies into the send buffer (own lost slots: straight into the receive buffer).  The kernel takes its sizes
+// from the records on the device, so it can be queued before the host has read them (exchange_ls)
+int launch_pack(mcl_handle* h) {
+  RET_IF(set_device(h));
+  if (!h->xrecv) HIPCHK(h, hipMalloc(&h->xrecv, sizeof(double) * 6 * (size_t)h->n));
+  if (!h->xsend) {
+    // a shard's surplus is statistically a few per cent of its slots; n / 4 entries to start with, grown on demand
+    const size_t cap = std::max<size_t>((size_t)h->n / 4, 4096);
+    HIPCHK(h, hipMalloc(&h->xsend, sizeof(double) * 6 * cap));
+    h->xsend_cap = cap;
+  }
+  h->gather_uni_mask = h->uni_valid ? 0x1cu : 0u;  // z, roll, pitch: the same on every particle of every shard
+  PackArgs a;
+  a.src = state_ptrs(h->state[h->cur], h->n);
+  a.dupes = h->dupes32;
+  a.lsx = h->lsx;
+  a.rank = h->rank;
+  a.world = h->world;
+  a.cap = (u32)std::min<size_t>(h->xsend_cap, 0xffffffffull);
+  a.uni_mask = h->gather_uni_mask;
+  a.send = state_ptrs(h->xsend, (long long)h->xsend_cap);
+  a.recv = state_ptrs(h->xrecv, h->n);
+  t_begin(h, MCL_K_RESAMPLE);
+  k_pack_dupes<<<(unsigned)std::min<long long>(grid_for(h->n), 512), MCL_BLOCK, 0, h->stream>>>(a);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+// after the host has read the records: the rare shard whose surplus exceeds the send buffer grows it and packs again;
+// LOCAL groups pack here in the first place
+int phase_pack(mcl_handle* h, bool already_packed) {
   RET_IF(set_device(h));
   const u32 S = h->ex_S[h->rank];
-  if (!h->xrecv) HIPCHK(h, hipMalloc(&h->xrecv, sizeof(double) * 6 * (size_t)h->n));
+  if (already_packed && (size_t)S <= h->xsend_cap) return MCL_OK;
   if ((size_t)S > h->xsend_cap) {
     if (h->xsend) {
       HIPCHK(h, hipStreamSynchronize(h->stream));
       (void)hipFree(h->xsend);
       h->xsend = nullptr;
     }
-    size_t cap = std::max<size_t>((size_t)S + (size_t)S / 4, 4096);
+    const size_t cap = std::max<size_t>((size_t)S + (size_t)S / 4, 4096);
     HIPCHK(h, hipMalloc(&h->xsend, sizeof(double) * 6 * cap));
     h->xsend_cap = cap;
   }
-  h->gather_uni_mask = h->uni_valid ? 0x1cu : 0u;  // z, roll, pitch: the same on every particle of every shard
-  if (S == 0) return MCL_OK;
-  PackArgs a;
-  a.src = state_ptrs(h->state[h->cur], h->n);
-  a.dupes = h->dupes32;
-  a.S = S;
-  a.Spre = h->ex_Spre[h->rank];
-  a.Lpre = h->ex_Lpre[h->rank];
-  a.L = h->ex_L[h->rank];
-  a.uni_mask = h->gather_uni_mask;
-  a.send = state_ptrs(h->xsend, (long long)h->xsend_cap);
-  a.recv = state_ptrs(h->xrecv, h->n);
-  t_begin(h, MCL_K_RESAMPLE);
-  k_pack_dupes<<<grid_for(S), MCL_BLOCK, 0, h->stream>>>(a);
-  t_end(h);
-  HIPCHK(h, hipGetLastError());
-  return MCL_OK;
+  return launch_pack(h);
 }
 
 // the range of global dupes positions that shard `from` holds and shard `to` needs: [lo, hi)
@@ -1066,7 +1110,7 @@ int run_resample(mcl_handle** sh, int ns, const double* uniforms, long long nu,
     // the surplus copies whose global positions fall into a peer's lost ranks cross a link
     for (int s = 0; s < ns; ++s) RET_IF(phase_expand_local(sh[s], u53));
     RET_IF(exchange_ls(sh, ns));
-    for (int s = 0; s < ns; ++s) RET_IF(phase_pack(sh[s]));
+    for (int s = 0; s < ns; ++s) RET_IF(phase_pack(sh[s], ns == 1 && sh[s]->lsx_host_dev != nullptr));
     RET_IF(exchange_dupes(sh, ns));
     for (int s = 0; s < ns; ++s)
       RET_IF(phase_gather(sh[s], (replay_normals && sh[s]->cfg.rng_mode == MCL_RNG_REPLAY) ? replay_normals[s] : nullptr,
@@ -2719,10 +2763,7 @@ int mcl_comm_selftest(mcl_handle* h, int32_t timeout_ms) {
     if (e == ncclSuccess && !h->exch_allgather && h->world > 1) {
       // the O(n) exchange's pattern: the hand-over records all-gathered, then grouped point-to-point transfers
       // (here: one word to the next rank, one from the previous)
-      if (!h->lsx) {
-        HIPCHK(h, hipMalloc(&h->lsx, sizeof(u64) * 4 * (size_t)h->world));
-        HIPCHK(h, hipHostMalloc(&h->lsx_host, sizeof(u64) * 4 * (size_t)h->world, hipHostMallocDefault));
-      }
+      RET_IF(alloc_lsx(h));
       e = ncclAllGather(h->lsx + 4 * (size_t)h->rank, h->lsx, 4, ncclUint64, h->comm, h->stream);
       if (e == ncclSuccess) e = ncclGroupStart();
       if (e == ncclSuccess) e = ncclSend(h->totals + h->rank, 1, ncclUint64, (h->rank + 1) % h->world, h->comm, h->stream);

@@ -316,26 +316,51 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
 struct PackArgs {
   StatePtrs src;       // this shard's pre-resample state
   const u32* dupes;    // local ancestor index of every surplus copy
-  u32 S, Spre, Lpre, L;
+  const u64* lsx;      // hand-over records of every shard (device): word 0 of record r = L_r | S_r << 32
+  int rank, world;
+  u32 cap;             // capacity of the send buffer (entries per component): copies beyond it are dropped, the host
+                       // sees S > cap in the same records, grows the buffer and packs again
   unsigned uni_mask;   // components that are not shipped (the same value on every particle of the cloud)
-  StatePtrs send;      // [c][S]
+  StatePtrs send;      // [c][cap]
   StatePtrs recv;      // [c][L]
 };
+// (sizes come from the records ON THE DEVICE: the kernel is queued before the host has seen them)
 __global__ void __launch_bounds__(MCL_BLOCK) k_pack_dupes(PackArgs a) {
-  for (u32 p = blockIdx.x * MCL_BLOCK + threadIdx.x; p < a.S; p += gridDim.x * MCL_BLOCK) {
+  u32 Spre = 0u, Lpre = 0u, S = 0u, L = 0u;
+  for (int r = 0; r <= a.rank; ++r) {
+    const u64 w = a.lsx[4 * (size_t)r];
+    const u32 l = (u32)(w & 0xffffffffull), sc = (u32)(w >> 32);
+    if (r < a.rank) {
+      Lpre += l;
+      Spre += sc;
+    } else {
+      L = l;
+      S = sc;
+    }
+  }
+  const u32 Sc = S < a.cap ? S : a.cap;
+  for (u32 p = blockIdx.x * MCL_BLOCK + threadIdx.x; p < Sc; p += gridDim.x * MCL_BLOCK) {
     const u32 anc = a.dupes[p];
-    const u32 g = a.Spre + p;
-    const bool self = g >= a.Lpre && g - a.Lpre < a.L;
+    const u32 g = Spre + p;
+    const bool self = g >= Lpre && g - Lpre < L;
 #pragma unroll
     for (int c = 0; c < 6; ++c)
       if (!((a.uni_mask >> c) & 1u)) {
         const double v = a.src.c[c][anc];
         if (self)
-          a.recv.c[c][g - a.Lpre] = v;
+          a.recv.c[c][g - Lpre] = v;
         else
           a.send.c[c][p] = v;
       }
   }
+}
+// the records to pinned host memory, then the sequence word the host spins on (system-scope release: the records are
+// visible before it) -- a stream synchronisation costs the host tens of microseconds of wake-up, this a few
+__global__ void __launch_bounds__(64) k_publish_ls(const u64* __restrict__ lsx, int n_words, u64* host_words, u64* host_seq, u64 seq) {
+  for (int k = threadIdx.x; k < n_words; k += 64) host_words[k] = lsx[k];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------ K3: gather + noise (+ fused moments)
