@@ -36,6 +36,13 @@ DEFAULT_PARAMS = {
     # new, behaviour-preserving defaults
     'resample_scheme': 'systematic', 'seed': 0, 'device': 0,
     'mbes_topic': '/mbes_scan', 'mbes_std': 0.2, 'mbes_sensor_offset': '[0.0, 0.0, 0.0, 0.0, 0.0, 0.0]',
+    # the bathymetric map the MBES update casts against: an .npz with `z` (nx, ny) + `origin` (2) + `res` (height
+    # grid, map frame) or with `verts` (nv, 3) + `tris` (nt, 3); an ASCII .ply triangle mesh.  '' = no map: pings ignored
+    'map_grid_file': '', 'map_mesh_file': '',
+    # MBES pings as sensor_msgs/PointCloud2 (what mbes_mapper's receptor makes of a LaserScan,
+    # mbes_receptor.cpp:126-165): '' = not subscribed.  `mbes_points_frame`: 'base' -- points in base_frame, as
+    # transformLaserScanToPointCloud(base_frame_, ...) leaves them -- or 'sensor'
+    'mbes_pointcloud_topic': '', 'mbes_points_frame': 'base', 'mbes_range_max': 100.0,
 }
 
 
@@ -56,6 +63,40 @@ def quaternion_from_euler(roll, pitch, yaw):
             cp * (cr * sy) - sp * (sr * cy), cp * (cr * cy) + sp * (sr * sy)]
 
 
+def load_map_file(path):
+    """('grid', z, origin, res) or ('mesh', verts, tris) from an .npz (keys above) or an ASCII .ply triangle mesh."""
+    if path.lower().endswith('.npz'):
+        with np.load(path, allow_pickle=False) as f:
+            if 'z' in f.files:
+                return ('grid', np.asarray(f['z'], np.float32), tuple(float(v) for v in f['origin']), float(f['res']))
+            return ('mesh', np.asarray(f['verts'], np.float32), np.asarray(f['tris'], np.uint32))
+    if path.lower().endswith('.ply'):
+        with open(path, 'r') as f:
+            if f.readline().strip() != 'ply':
+                raise ValueError('%s: not a PLY file' % path)
+            nv = nf = 0
+            for line in f:
+                t = line.split()
+                if t[:2] == ['format', 'ascii']:
+                    continue
+                if t and t[0] == 'format':
+                    raise ValueError('%s: only ASCII PLY is read' % path)
+                if t[:2] == ['element', 'vertex']:
+                    nv = int(t[2])
+                if t[:2] == ['element', 'face']:
+                    nf = int(t[2])
+                if t == ['end_header']:
+                    break
+            verts = np.array([[float(v) for v in f.readline().split()[:3]] for _ in range(nv)], np.float32)
+            tris = []
+            for _ in range(nf):
+                t = [int(v) for v in f.readline().split()]
+                for k in range(2, t[0]):   # fan-triangulate polygons
+                    tris.append((t[1], t[k], t[k + 1]))
+        return ('mesh', verts, np.array(tris, np.uint32))
+    raise ValueError('map file %s: expected .npz or .ply' % path)
+
+
 def matrix_from_tf(translation, rotation):
     """auv_particle.py:110-125: 4x4 from a tf translation (x,y,z) and quaternion (x,y,z,w)."""
     q = np.array(rotation[:4], dtype=np.float64)
@@ -68,6 +109,18 @@ def matrix_from_tf(translation, rotation):
                      [o[0, 1] + o[2, 3], 1.0 - o[0, 0] - o[2, 2], o[1, 2] - o[0, 3]],
                      [o[0, 2] - o[1, 3], o[1, 2] + o[0, 3], 1.0 - o[0, 0] - o[1, 1]]]
     m[:3, 3] = translation[:3]
+    return m
+
+
+def _rigid(tx, ty, tz, roll, pitch, yaw):
+    """T(t) R(static-xyz rpy): the pose of the sensor in base_link (`mbes_sensor_offset`)."""
+    cr, sr, cp, sp, cy, sy = (math.cos(roll), math.sin(roll), math.cos(pitch), math.sin(pitch), math.cos(yaw),
+                              math.sin(yaw))
+    m = np.identity(4)
+    m[:3, :3] = [[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                 [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                 [-sp, cp * sr, cp * cr]]
+    m[:3, 3] = (tx, ty, tz)
     return m
 
 
@@ -135,6 +188,11 @@ class auv_pf(object):
         self.diving = True  # auv_pf.py:103
         self.odom_latest = None
         self.has_map = False
+        self.mbes_range_max = float(p['mbes_range_max'])
+        self.mbes_points_frame = p['mbes_points_frame']
+        for key in ('map_grid_file', 'map_mesh_file'):   # the node's own map parameters
+            if p[key]:
+                self.load_map(p[key])
 
     # ---- REPLAY-mode RNG source (parity runs): rs must offer randn(n, 6) and random_sample(k)
     def set_replay_source(self, rs):
@@ -204,6 +262,35 @@ class auv_pf(object):
         with self.lock:
             self.particles.set_map_mesh(verts, tris)
             self.has_map = True
+
+    def load_map(self, path):
+        m = load_map_file(path)
+        if m[0] == 'grid':
+            self.set_map_grid(m[1], m[2], m[3])
+        else:
+            self.set_map_mesh(m[1], m[2])
+
+    def mbes_pc_cb(self, cloud):
+        """One ping as a sensor_msgs/PointCloud2 (or msgs.PointCloud2): every point is a beam's hit.  In the sensor
+        frame beam b looks along (0, sin a_b, -cos a_b) (include/mcl.h), so a point gives a_b = atan2(y, -z) and the
+        range |p|; points in base_frame (mbes_receptor.cpp:138: the receptor projects the scan into base_frame) are
+        taken back through the sensor offset first.  The beams are handed over in ascending angle."""
+        pts = _msgs.pointcloud2_xyz(cloud)
+        if self.mbes_points_frame != 'sensor':
+            o = self.mbes_sensor_offset
+            T = _rigid(o[0], o[1], o[2], o[3], o[4], o[5])
+            pts = (pts - T[:3, 3]).dot(T[:3, :3])   # R^T (p - t), row-wise
+        if pts.shape[0] == 0:
+            return
+        ang = np.arctan2(pts[:, 1], -pts[:, 2])
+        rng = np.sqrt(np.sum(pts * pts, axis=1))
+        order = np.argsort(ang, kind='stable')
+        with self.lock:
+            if not (self.old_time and self.has_map):
+                return
+            self.particles.update_mbes(rng[order].astype(np.float32), ang[order].astype(np.float32), self.mbes_std,
+                                       self.mbes_range_max, self.mbes_sensor_offset)
+            self.resample(self.particles)
 
     def mbes_cb(self, scan):
         with self.lock:

@@ -629,7 +629,7 @@ int alloc_lsx(mcl_handle* h) {
   if (hipHostGetDevicePointer((void**)&h->lsx_host_dev, h->lsx_host, 0) != hipSuccess) h->lsx_host_dev = nullptr;
   return MCL_OK;
 }
-int launch_pack(mcl_handle* h);
+int launch_pack(mcl_handle* h, u64 publish_seq = 0);
 // CDF, lost ranks and dupes list of THIS shard only (k_cdf_expand<true> over the shard, global weight offsets from the
 // all-gathered totals); leaves the shard's hand-over record in lsx[rank]
 int phase_expand_local(mcl_handle* h, uint64_t u53) {
@@ -680,10 +680,8 @@ int exchange_ls(mcl_handle** sh, int ns) {
       // the device from the same records) is queued behind it BEFORE the host starts to wait, so the GPU keeps
       // working while the host wakes up; the host spins on the word instead of synchronising the stream
       const u64 seq = ++h->ls_seq;
-      k_publish_ls<<<1, 64, 0, h->stream>>>(h->lsx, 4 * world, h->lsx_host_dev, h->lsx_host_dev + 4 * (size_t)world, seq);
       t_end(h);
-      HIPCHK(h, hipGetLastError());
-      RET_IF(launch_pack(h));
+      RET_IF(launch_pack(h, seq));   // (its first workgroup publishes the records before it packs)
       volatile u64* flag = h->lsx_host + 4 * (size_t)world;
       const auto t0 = std::chrono::steady_clock::now();
       unsigned spins = 0;
@@ -735,7 +733,7 @@ int exchange_ls(mcl_handle** sh, int ns) {
 
 // surplus copies into the send buffer (own lost slots: straight into the receive buffer).  The kernel takes its sizes
 // from the records on the device, so it can be queued before the host has read them (exchange_ls)
-int launch_pack(mcl_handle* h) {
+int launch_pack(mcl_handle* h, u64 publish_seq) {
   RET_IF(set_device(h));
   if (!h->xrecv) HIPCHK(h, hipMalloc(&h->xrecv, sizeof(double) * 6 * (size_t)h->n));
   if (!h->xsend) {
@@ -755,6 +753,9 @@ int launch_pack(mcl_handle* h) {
   a.uni_mask = h->gather_uni_mask;
   a.send = state_ptrs(h->xsend, (long long)h->xsend_cap);
   a.recv = state_ptrs(h->xrecv, h->n);
+  a.host_words = publish_seq ? h->lsx_host_dev : nullptr;
+  a.host_seq = publish_seq ? h->lsx_host_dev + 4 * (size_t)h->world : nullptr;
+  a.seq = publish_seq;
   t_begin(h, MCL_K_RESAMPLE);
   k_pack_dupes<<<(unsigned)std::min<long long>(grid_for(h->n), 512), MCL_BLOCK, 0, h->stream>>>(a);
   t_end(h);
@@ -1097,13 +1098,28 @@ int run_resample(mcl_handle** sh, int ns, const double* uniforms, long long nu,
     return phase_gather(h0, (replay_normals && h0->cfg.rng_mode == MCL_RNG_REPLAY) ? replay_normals[0] : nullptr,
                         with_moments);
   }
-  for (int s = 0; s < ns; ++s) {
-    sh[s]->group.assign(sh, sh + ns);
-    if (ns == 1) sh[s]->group.clear();
-    RET_IF(phase_local_max(sh[s]));
+  if (ns == 1) {
+    // one process per GPU: the 64 max-lw slots the update kernel filled are all-reduced as they are (ordered u64
+    // keys: the maximum of the keys is the key of the maximum) and the quantise kernel reads them -- no k_max_finish
+    h0->group.clear();
+    RET_IF(set_device(h0));
+    t_begin(h0, MCL_K_NORMALISE);
+    RET_IF(ensure_max_slots(h0));
+    t_end(h0);
+    if (h0->comm && h0->world > 1) {
+      t_begin(h0, MCL_K_COMM);
+      NCCLCHK(h0, ncclAllReduce(ctrl_slots(h0), ctrl_slots(h0), MCL_MAX_SLOTS, ncclUint64, ncclMax, h0->comm, h0->stream));
+      t_end(h0);
+    }
+    RET_IF(phase_quantise(h0, true));
+  } else {
+    for (int s = 0; s < ns; ++s) {
+      sh[s]->group.assign(sh, sh + ns);
+      RET_IF(phase_local_max(sh[s]));
+    }
+    RET_IF(exchange_max(sh, ns));
+    for (int s = 0; s < ns; ++s) RET_IF(phase_quantise(sh[s], false));
   }
-  RET_IF(exchange_max(sh, ns));
-  for (int s = 0; s < ns; ++s) RET_IF(phase_quantise(sh[s], false));
   RET_IF(exchange_totals(sh, ns));
   if (!h0->exch_allgather) {
     // O(n) per rank: every shard expands its OWN slice, the shards exchange two integers each, and only

@@ -323,9 +323,21 @@ struct PackArgs {
   unsigned uni_mask;   // components that are not shipped (the same value on every particle of the cloud)
   StatePtrs send;      // [c][cap]
   StatePtrs recv;      // [c][L]
+  // when set, workgroup 0 first copies the records to pinned host memory and then writes the sequence word the host
+  // spins on (system-scope release: the records are visible before it) -- a stream synchronisation costs the host tens
+  // of microseconds of wake-up, this a few
+  u64* host_words;
+  u64* host_seq;
+  u64 seq;
 };
 // (sizes come from the records ON THE DEVICE: the kernel is queued before the host has seen them)
 __global__ void __launch_bounds__(MCL_BLOCK) k_pack_dupes(PackArgs a) {
+  if (a.host_words && blockIdx.x == 0) {
+    for (int k = threadIdx.x; k < 4 * a.world; k += MCL_BLOCK) a.host_words[k] = a.lsx[k];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(a.host_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   u32 Spre = 0u, Lpre = 0u, S = 0u, L = 0u;
   for (int r = 0; r <= a.rank; ++r) {
     const u64 w = a.lsx[4 * (size_t)r];
@@ -354,15 +366,6 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_pack_dupes(PackArgs a) {
       }
   }
 }
-// the records to pinned host memory, then the sequence word the host spins on (system-scope release: the records are
-// visible before it) -- a stream synchronisation costs the host tens of microseconds of wake-up, this a few
-__global__ void __launch_bounds__(64) k_publish_ls(const u64* __restrict__ lsx, int n_words, u64* host_words, u64* host_seq, u64 seq) {
-  for (int k = threadIdx.x; k < n_words; k += 64) host_words[k] = lsx[k];
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // ------------------------------------------------------------------ K3: gather + noise (+ fused moments)
 #define MOM_COUNT 13   // sum d(x,y,z), sum roll, pitch, yaw, sum wrap(yaw), sum dxx dyy dzz dxy dxz dyz
 #define GATHER_MAX_GRID 256

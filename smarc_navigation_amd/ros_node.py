@@ -1,10 +1,12 @@
 #!/usr/bin/env python
 """rospy wrapper: node `auv_pf`, same private parameters, topics, frames and message types as
-auv_particle_filter/scripts/auv_pf.py; the numerics run in libmcl_hip.so.
+auv_particle_filter/scripts/auv_pf.py; the numerics run in libmcl_hip.so.  Beyond the reference:
+`~map_grid_file` / `~map_mesh_file` load the bathymetric map, `~mbes_topic` (sensor_msgs/LaserScan) and
+`~mbes_pointcloud_topic` (sensor_msgs/PointCloud2, the form mbes_mapper's receptor gives a ping) feed the MBES update.
 
-ROS is not installed in the build container, so this file is import-guarded and exercised only
-where rospy/tf/tf2_ros exist:  rosrun auv_particle_filter ros_node.py  (or from auv_pf.launch with
-type="ros_node.py")."""
+ROS is not installed in the build container: the module imports whatever `rospy` / `tf` / `tf2_ros` / `*_msgs` are on
+the path -- a ROS 1 installation, or the stand-ins of tests/ros_stubs that tests/test_ros_node_stub.py drives main()
+with, end to end.  rosrun auv_particle_filter_hip ros_node.py, or auv_pf.launch."""
 import sys
 
 import numpy as np
@@ -17,14 +19,14 @@ try:  # pragma: no cover - needs a ROS installation
     import tf2_ros
     from geometry_msgs.msg import Pose, PoseArray, Quaternion
     from nav_msgs.msg import Odometry
-    from sensor_msgs.msg import LaserScan
+    from sensor_msgs.msg import LaserScan, PointCloud2
     from std_msgs.msg import Bool
     HAVE_ROS = True
 except ImportError:
     HAVE_ROS = False
 
 
-class RosTransport(object):  # pragma: no cover - needs a ROS installation
+class RosTransport(object):
     """Publishers / tf of auv_pf.py:62-74 behind the transport interface of the mirror class."""
 
     def __init__(self, params, map_frame, max_poses):
@@ -75,7 +77,7 @@ class RosTransport(object):  # pragma: no cover - needs a ROS installation
         return rospy.Time.now()
 
 
-def main():  # pragma: no cover - needs a ROS installation
+def main():
     if not HAVE_ROS:
         sys.stderr.write('ros_node.py: rospy/tf not importable; this wrapper needs a ROS 1 environment\n')
         return 2
@@ -96,11 +98,19 @@ def main():  # pragma: no cover - needs a ROS installation
         rospy.logerr("PF: Could not lookup transform %s to %s" % (params['map_frame'], params['odom_frame']))
         return 1
     transport = RosTransport(params, params['map_frame'], int(rospy.get_param('~max_published_poses', 5000)))
-    pf = _node.auv_pf(params, m2o_mat=m2o, transport=transport)
+    try:
+        pf = _node.auv_pf(params, m2o_mat=m2o, transport=transport)   # (loads ~map_grid_file / ~map_mesh_file)
+    except (IOError, OSError, ValueError, KeyError) as ex:
+        rospy.logerr("PF: could not load the map: %s" % ex)
+        return 1
+    if not pf.has_map:
+        rospy.logwarn("PF: no ~map_grid_file / ~map_mesh_file: MBES pings will be ignored (GPS updates only)")
     pf.start_timing(rospy.Time.now().to_sec())
     rospy.Subscriber(params['aux_dive'], Bool, pf.dive_cb, queue_size=100)
     rospy.Subscriber(params['gps_odom_topic'], Odometry, pf.gps_odom_cb, queue_size=100)
     rospy.Subscriber(params['mbes_topic'], LaserScan, pf.mbes_cb, queue_size=10)
+    if params['mbes_pointcloud_topic']:
+        rospy.Subscriber(params['mbes_pointcloud_topic'], PointCloud2, pf.mbes_pc_cb, queue_size=10)
     rospy.Subscriber(params['odom_topic'], Odometry, pf.odom_callback, queue_size=100)
     rospy.Timer(rospy.Duration(0.1), pf.loc_loop)
     rospy.loginfo("Particle filter class successfully created")

@@ -1,0 +1,276 @@
+"""ros_node.main() end to end against stand-in ROS modules (tests/ros_stubs): parameters -> map file -> tf lookup ->
+publishers / subscribers / timer -> one odometry pair, a LaserScan ping, the same ping as a PointCloud2, a GPS fix,
+a timer tick -> what the node publishes.
+
+CPU (`-m "not gpu"`): the engine is replaced by a recording fake, so the test pins the PLUMBING -- which ABI call each
+ROS message turns into and with which arguments (beam angles and ranges recovered from the point cloud, dt from the
+stamps, the map handed to set_map_grid, the GPS fix transformed utm -> map once).
+GPU (`-m gpu`): the real engine; the node's publications equal those of the mirror class driven directly."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUBS = os.path.join(ROOT, 'tests', 'ros_stubs')
+_STUB_MODS = ('rospy', 'tf', 'tf2_ros', 'geometry_msgs', 'geometry_msgs.msg', 'nav_msgs', 'nav_msgs.msg', 'sensor_msgs',
+              'sensor_msgs.msg', 'std_msgs', 'std_msgs.msg')
+
+
+@pytest.fixture
+def ros(monkeypatch):
+    """ros_node imported with the stand-in ROS on the path; everything is unloaded again afterwards."""
+    monkeypatch.syspath_prepend(STUBS)
+    for m in _STUB_MODS + ('smarc_navigation_amd.ros_node',):
+        sys.modules.pop(m, None)
+    node = importlib.import_module('smarc_navigation_amd.ros_node')
+    assert node.HAVE_ROS
+    import rospy
+    import tf
+    import tf2_ros
+    rospy.reset()
+    tf2_ros.transforms.clear()
+    del tf.broadcasts[:]
+    tf.utm2map = np.identity(4)
+    yield node, rospy, tf, tf2_ros
+    for m in _STUB_MODS + ('smarc_navigation_amd.ros_node',):
+        sys.modules.pop(m, None)
+
+
+class FakeEngine(object):
+    """Records the ABI-level calls the node makes."""
+    calls = []
+
+    def __init__(self, n, **kw):
+        self.n = n
+        FakeEngine.calls.append(('create', n, kw))
+
+    def __getattr__(self, name):
+        def f(*a, **k):
+            FakeEngine.calls.append((name, a, k))
+            if name == 'mean_cov':
+                return np.arange(6.0), 0.25, np.arange(9.0)
+            if name == 'poses':
+                out = np.zeros((self.n, 7))
+                out[:, 6] = 1.0
+                return out
+            if name == 'resample_prepare':
+                return 1
+            return None
+        return f
+
+
+def _scene(tmp_path):
+    from smarc_navigation_amd import synth
+    origin = (-64.0, -64.0)
+    z = synth.bathymetry_grid(128, 128, 1.0, origin, seed=1)
+    path = str(tmp_path / 'map.npz')
+    np.savez(path, z=z, origin=np.array(origin), res=1.0)
+    return z, origin, path
+
+
+def _params(path, n):
+    return {'particle_count': n, 'map_grid_file': path, 'odom_topic': '/sam/dr/odom', 'gps_odom_topic': '/sam/dr/gps',
+            'odom_frame': 'sam/odom', 'base_frame': 'sam/base_link', 'mbes_topic': '/sam/mbes_scan',
+            'mbes_pointcloud_topic': '/sam/mbes_cloud', 'mbes_sensor_offset': '[0.3, 0.0, -0.1, 0.0, 0.05, 0.0]',
+            'odom_corrected_topic': '/sam/dr/odom_corrected', 'particle_poses_topic': '/sam/dr/particle_poses',
+            'init_covariance': '[0.5, 0.5, 0.0, 0.0, 0.0, 0.01]', 'motion_covariance': '[0.001, 0.001, 0.0, 0.0, 0.0, 0.00001]',
+            'resampling_noise_covariance': '[0.01, 0.01, 0.0, 0.0, 0.0, 0.0001]', 'measurement_std': 1.0, 'seed': 11}
+
+
+def _odom(stamp, vx, wz, z, q=(0.0, 0.0, 0.0, 1.0)):
+    import rospy
+    from nav_msgs.msg import Odometry
+    from geometry_msgs.msg import Quaternion
+    m = Odometry()
+    m.header.stamp = rospy.Time(stamp)
+    m.twist.twist.linear.x, m.twist.twist.angular.z = vx, wz
+    m.pose.pose.orientation = Quaternion(*q)
+    m.pose.pose.position.z = z
+    return m
+
+
+def _ping_msgs(ranges, angles, offset):
+    """The same ping as a LaserScan and as a PointCloud2 in base_frame (the receptor's projection of the scan)."""
+    from sensor_msgs.msg import LaserScan, PointCloud2, PointField
+    from smarc_navigation_amd import msgs, auv_pf
+    scan = LaserScan()
+    scan.angle_min, scan.angle_increment = float(angles[0]), float(angles[1] - angles[0])
+    scan.ranges, scan.range_max = [float(r) for r in ranges], 80.0
+    pts_sensor = np.stack([np.zeros_like(ranges), ranges * np.sin(angles), -ranges * np.cos(angles)], axis=1)
+    T = auv_pf._rigid(*offset)
+    pts_base = pts_sensor.dot(T[:3, :3].T) + T[:3, 3]
+    src = msgs.pointcloud2_from_xyz(pts_base[::-1], 'sam/base_link')   # (reversed: the node sorts the beams)
+    pc = PointCloud2()
+    pc.header.frame_id, pc.width, pc.point_step, pc.row_step, pc.data = 'sam/base_link', src.width, src.point_step, src.row_step, src.data
+    pc.fields = [PointField(f.name, f.offset, f.datatype, f.count) for f in src.fields]
+    return scan, pc
+
+
+def test_ros_node_main_plumbing_with_a_recording_engine(ros, tmp_path, monkeypatch):
+    node, rospy, tf, tf2_ros = ros
+    from smarc_navigation_amd import engine as eng
+    z, origin, path = _scene(tmp_path)
+    FakeEngine.calls = []
+    monkeypatch.setattr(eng, 'Engine', FakeEngine)
+    rospy.reset(_params(path, 64))
+    tf2_ros.transforms[('map', 'sam/odom')] = ((10.0, -5.0, 0.0), (0.0, 0.0, 0.0, 1.0))
+    tf.utm2map = np.array([[1.0, 0, 0, -1000.0], [0, 1.0, 0, -2000.0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    rospy.Time._now = 100.0
+    assert node.main() == 0
+    # ---- construction: particle count, covariances, map <- odom from tf, the map file
+    kind, n, kw = FakeEngine.calls[0]
+    assert (kind, n) == ('create', 64) and kw['seed'] == 11
+    np.testing.assert_allclose(np.asarray(kw['m2o'])[:3, 3], [10.0, -5.0, 0.0])
+    assert kw['init_cov'] == [0.5, 0.5, 0.0, 0.0, 0.0, 0.01] and kw['meas_std'] == 1.0
+    names = [c[0] for c in FakeEngine.calls]
+    k = names.index('set_map_grid')
+    gz, gorigin, gres = FakeEngine.calls[k][1]
+    assert np.array_equal(gz, z) and tuple(gorigin) == origin and gres == 1.0
+    # ---- the reference's topics and message types, plus the two MBES inputs
+    from nav_msgs.msg import Odometry
+    from geometry_msgs.msg import PoseArray
+    from sensor_msgs.msg import LaserScan, PointCloud2
+    from std_msgs.msg import Bool
+    assert {t: s.typ for t, s in rospy.subscribers.items()} == {
+        '/dive': Bool, '/sam/dr/gps': Odometry, '/sam/dr/odom': Odometry, '/sam/mbes_scan': LaserScan,
+        '/sam/mbes_cloud': PointCloud2}
+    assert {t: p.typ for t, p in rospy.publishers.items()} == {'/sam/dr/particle_poses': PoseArray,
+                                                              '/sam/dr/odom_corrected': Odometry}
+    assert len(rospy.timers) == 1 and abs(rospy.timers[0].period.to_sec() - 0.1) < 1e-12   # 10 Hz (auv_pf.py:114)
+    # ---- odometry: predict with dt from the stamps
+    FakeEngine.calls = []
+    rospy.subscribers['/sam/dr/odom'].cb(_odom(100.02, 1.0, 0.1, -2.0))
+    (name, a, k), = [c for c in FakeEngine.calls if c[0] == 'predict']
+    assert a[0] == [1.0, 0.0, 0.0] and a[1] == 0.1 and a[3] == -2.0 and abs(a[4] - 0.02) < 1e-9
+    # ---- a ping, twice: LaserScan and PointCloud2 give the engine the same beams
+    B = 64
+    angles = np.linspace(-1.0, 1.0, B)
+    ranges = 20.0 / np.cos(angles) + 0.01 * np.arange(B)
+    off = [0.3, 0.0, -0.1, 0.0, 0.05, 0.0]
+    scan, pc = _ping_msgs(ranges, angles, off)
+    FakeEngine.calls = []
+    rospy.subscribers['/sam/mbes_scan'].cb(scan)
+    rospy.subscribers['/sam/mbes_cloud'].cb(pc)
+    ups = [c for c in FakeEngine.calls if c[0] == 'update_mbes']
+    assert len(ups) == 2 and [c[0] for c in FakeEngine.calls].count('resample') == 2
+    (r1, a1, s1, rm1, o1), (r2, a2, s2, rm2, o2) = ups[0][1], ups[1][1]
+    np.testing.assert_allclose(a1, angles, atol=1e-6)
+    np.testing.assert_allclose(a2, angles, atol=2e-6)      # recovered from the points, sorted ascending
+    np.testing.assert_allclose(r2, r1, rtol=2e-6)
+    assert (s1, rm1, list(o1)) == (0.2, 80.0, off) and (s2, rm2, list(o2)) == (0.2, 100.0, off)
+    # ---- GPS: ignored while diving (auv_pf.py:103 starts True), then the fix goes utm -> map once
+    gps = Odometry()
+    gps.pose.pose.position.x, gps.pose.pose.position.y = 1003.0, 2001.0
+    FakeEngine.calls = []
+    rospy.subscribers['/sam/dr/gps'].cb(gps)
+    assert not FakeEngine.calls
+    rospy.subscribers['/dive'].cb(Bool(False))
+    rospy.subscribers['/sam/dr/gps'].cb(gps)
+    assert [c for c in FakeEngine.calls if c[0] == 'update_gps'][0][1] == (3.0, 1.0)
+    # ---- the 10 Hz tick: PoseArray, Odometry with the 3 x 3 covariance in the first nine slots, tf odom -> base
+    rospy.timers[0].cb(None)
+    od = rospy.publishers['/sam/dr/odom_corrected'].sent[-1]
+    assert (od.header.frame_id, od.child_frame_id) == ('sam/odom', 'sam/base_link')
+    assert (od.pose.pose.position.x, od.pose.pose.position.y) == (0.0, 1.0)
+    assert od.pose.covariance[:9] == list(np.arange(9.0)) and od.pose.covariance[9:] == [0.0] * 27
+    pa = rospy.publishers['/sam/dr/particle_poses'].sent[-1]
+    assert len(pa.poses) == 64 and pa.header.frame_id == 'sam/odom' and pa.poses[0].orientation.w == 1.0
+    trans, rot, child, parent = tf.broadcasts[-1]
+    assert trans == [0.0, 1.0, 0.0] and (child, parent) == ('sam/base_link', 'sam/odom')
+
+
+def test_ros_node_exits_quietly_without_the_map_transform_or_the_map_file(ros, tmp_path, monkeypatch):
+    """auv_pf.py:84-87: a failed tf lookup at start-up is logged and the node returns; a bad map file likewise."""
+    node, rospy, tf, tf2_ros = ros
+    from smarc_navigation_amd import engine as eng
+    monkeypatch.setattr(eng, 'Engine', FakeEngine)
+    z, origin, path = _scene(tmp_path)
+    rospy.reset(_params(path, 8))
+    assert node.main() == 1 and any(l[0] == 'err' and 'transform' in l[1] for l in rospy.log)
+    tf2_ros.transforms[('map', 'sam/odom')] = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0))
+    rospy.reset(dict(_params(str(tmp_path / 'missing.npz'), 8)))
+    assert node.main() == 1 and any(l[0] == 'err' and 'map' in l[1] for l in rospy.log)
+    # no map parameter at all: the node runs (GPS only) and says so
+    p = _params(path, 8)
+    p['map_grid_file'] = ''
+    rospy.reset(p)
+    assert node.main() == 0 and any(l[0] == 'warn' and 'MBES pings will be ignored' in l[1] for l in rospy.log)
+
+
+def test_ply_and_npz_mesh_files_load(tmp_path):
+    from smarc_navigation_amd import auv_pf, synth
+    z = synth.bathymetry_grid(6, 5, 2.0, (1.0, -3.0), seed=2)
+    verts, tris = synth.mesh_from_grid(z, 2.0, (1.0, -3.0))
+    np.savez(str(tmp_path / 'm.npz'), verts=verts, tris=tris)
+    kind, v, t = auv_pf.load_map_file(str(tmp_path / 'm.npz'))
+    assert kind == 'mesh' and np.array_equal(v, verts.astype(np.float32)) and np.array_equal(t, tris)
+    with open(str(tmp_path / 'm.ply'), 'w') as f:
+        f.write('ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n'
+                'element face %d\nproperty list uchar int vertex_indices\nend_header\n' % (len(verts), len(tris)))
+        for p in verts:
+            f.write('%r %r %r\n' % (float(p[0]), float(p[1]), float(p[2])))
+        for q in tris:
+            f.write('3 %d %d %d\n' % tuple(int(x) for x in q))
+    kind, v, t = auv_pf.load_map_file(str(tmp_path / 'm.ply'))
+    assert kind == 'mesh' and np.allclose(v, verts, atol=1e-6) and np.array_equal(t, tris)
+    with pytest.raises(ValueError):
+        auv_pf.load_map_file(str(tmp_path / 'm.txt'))
+
+
+@pytest.mark.gpu
+def test_ros_node_on_the_gpu_publishes_what_the_mirror_publishes(ros, tmp_path):
+    """The real engine behind the stand-in ROS: odometry, a LaserScan ping, the same ping as PointCloud2, a tick --
+    against the mirror class fed the same messages directly (same seed: same Philox draws)."""
+    node, rospy, tf, tf2_ros = ros
+    from smarc_navigation_amd import auv_pf, engine as eng, msgs
+    z, origin, path = _scene(tmp_path)
+    n = 4096
+    params = _params(path, n)
+    rospy.reset(params)
+    tf2_ros.transforms[('map', 'sam/odom')] = ((0.5, -0.5, 0.0), (0.0, 0.0, 0.0, 1.0))
+    rospy.Time._now = 100.0
+    assert node.main() == 0
+    m2o = auv_pf.matrix_from_tf((0.5, -0.5, 0.0), (0.0, 0.0, 0.0, 1.0))
+    mirror = auv_pf.auv_pf(params, m2o_mat=m2o)
+    mirror.start_timing(100.0)
+    # pings simulated at the truth pose
+    B = 96
+    angles = np.linspace(-1.0, 1.0, B).astype(np.float32)
+    one = eng.Engine(1, rng_mode=eng.RNG_REPLAY, m2o=m2o)
+    one.set_map_grid(z, origin, 1.0)
+    one.set_particles(np.array([[0.0], [0.0], [-2.0], [0.0], [0.0], [0.0]]))
+    off = [0.3, 0.0, -0.1, 0.0, 0.05, 0.0]
+    ranges = one.mbes_expected(0, 1, angles, 80.0, off)[0].astype(np.float64)
+    scan, pc = _ping_msgs(ranges, angles.astype(np.float64), off)
+    for k in range(3):
+        stamp = 100.02 * 1.0 + 0.02 * k
+        rospy.Time._now = stamp
+        om = _odom(stamp, 1.0, 0.05, -2.0)
+        rospy.subscribers['/sam/dr/odom'].cb(om)
+        mirror.odom_callback(om)
+        if k == 1:
+            rospy.subscribers['/sam/mbes_scan'].cb(scan)
+            mirror.mbes_cb(scan)
+        if k == 2:
+            rospy.subscribers['/sam/mbes_cloud'].cb(pc)
+            mirror.mbes_pc_cb(pc)
+    rospy.timers[0].cb(None)
+    mirror.loc_loop()
+    od = rospy.publishers['/sam/dr/odom_corrected'].sent[-1]
+    ref = mirror.transport.odom_corrected[-1]
+    got = [od.pose.pose.position.x, od.pose.pose.position.y, od.pose.pose.position.z, od.pose.pose.orientation.z]
+    exp = [ref.pose.pose.position.x, ref.pose.pose.position.y, ref.pose.pose.position.z, ref.pose.pose.orientation.z]
+    assert got == exp and list(od.pose.covariance) == list(ref.pose.covariance)
+    # the pings were used: the cloud has contracted around the truth
+    assert np.hypot(got[0], got[1]) < 0.5 and od.pose.covariance[0] < 0.1
+    pa = rospy.publishers['/sam/dr/particle_poses'].sent[-1]
+    assert len(pa.poses) == n
+    # point cloud and scan of the same ping give the same log-likelihoods
+    a = eng.Engine(256, m2o=m2o, seed=3, init_cov=[0.5, 0.5, 0, 0, 0, 0.01])
+    a.set_map_grid(z, origin, 1.0)
+    a.init_particles()
+    pts = msgs.pointcloud2_xyz(pc)
+    assert pts.shape == (B, 3)
