@@ -891,7 +891,7 @@ __device__ __forceinline__ float cast_clear(const float* __restrict__ tile, int 
 //         keeps the hot kernel free of the general code's registers (no scratch spills).
 // MODE 1: general traversal over the groups listed in a.worklist (usually none: map borders, wide clouds).
 template <int MAP, bool EXPECT_ONLY, int MODE>
-__global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 || MODE == 1 ? MBES_MIN_WAVES_MESH : MBES_MIN_WAVES_PER_SIMD))
+__global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 ? MBES_MIN_WAVES_MESH - 1 : (MODE == 1 ? MBES_MIN_WAVES_MESH : MBES_MIN_WAVES_PER_SIMD)))
     k_mbes_cast(MbesArgs a) {
   // general mesh tiles hold 8-byte cell words and run 3 workgroups per CU: give them 48 KiB
   constexpr int TILE_FLOATS = MAP == 1 ? (MBES_TILE_FLOATS * 3) / 2 : MBES_TILE_FLOATS;

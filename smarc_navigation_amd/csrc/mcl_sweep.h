@@ -723,7 +723,9 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
 }
 
 template <int SURF, bool EXPECT_ONLY, bool CHECKED = false>
-__global__ void __launch_bounds__(SWEEP_THREADS, (SURF == 0 || SURF == 5) ? SWEEP_MIN_WAVES_GRID : (CHECKED ? 6 : SWEEP_MIN_WAVES)) k_mbes_sweep(MbesArgs a) {
+// (register budgets: lattice first pass 8 waves / SIMD (64 VGPRs), grids, TINs and the lattice second pass 6, the bounds-
+//  checked second pass over a GRID 4 -- it carries the conic AND the border tests, and spilled 84 B per lane at 6)
+__global__ void __launch_bounds__(SWEEP_THREADS, (SURF == 0 && CHECKED) ? 4 : ((SURF == 0 || SURF == 5) ? SWEEP_MIN_WAVES_GRID : (CHECKED ? 6 : SWEEP_MIN_WAVES))) k_mbes_sweep(MbesArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sweep_lds[];
   __shared__ float xacc[SWEEP_PARTICLES];
   __shared__ int xok[SWEEP_PARTICLES];
