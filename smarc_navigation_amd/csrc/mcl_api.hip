@@ -124,13 +124,13 @@ struct mcl_handle {
   std::vector<float> ranges_host;   // last uploaded ranges (the sweep's beam table is built from them)
   bool sweep_angles_ok = false;     // ascending, finite, |a| <= 85 degrees
   int b_split = 0;
-  float sweep_tan0[4] = {0.f, 0.f, 0.f, 0.f};
   float4* sweep_beams = nullptr;
   float* sweep_tail = nullptr;
   int sweep_cap = 0;
   u32* defer_idx = nullptr;
   u32* defer_idx2 = nullptr;        // what the bounds-checked second pass hands on
   int env_sweep = -1;               // MCL_SWEEP=0/1 forces the decision (tests, A/B)
+  int env_nsub = 0;                 // MCL_SWEEP_NSUB=1/2/4 forces the lanes per particle side (A/B)
   bool sweep_now = false;           // decided by the first launch_mbes call of an update
   bool sweep_two_pass = false;      // lattice maps: a bounds-checked second pass precedes the traversal kernels
   int sweep_nvalid = 0;
@@ -1317,11 +1317,11 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
   // that take the hand-overs)
   if (B > h->sweep_cap) {
     if (h->sweep_beams) (void)hipFree(h->sweep_beams);
-    HIPCHK(h, hipMalloc(&h->sweep_beams, (sizeof(float4) + 2 * sizeof(float)) * (size_t)B));
+    HIPCHK(h, hipMalloc(&h->sweep_beams, (sizeof(float4) + 2 * sizeof(float)) * (size_t)B + 4 * sizeof(float)));
     h->sweep_cap = B;
   }
   h->sweep_tail = (float*)(h->sweep_beams + B);
-  std::vector<float> blk((size_t)B * 6);
+  std::vector<float> blk((size_t)B * 6 + 4);   // B records | B tail sums | B measured ranges | first / second tangent of either side
   float4* tb = (float4*)blk.data();
   float* tail = blk.data() + (size_t)B * 4;
   float* rng = tail + B;
@@ -1354,8 +1354,8 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
   h->sweep_nvalid = nvalid;
   for (int k = 0; k < 2; ++k) {
     const int bp = h->b_split + k, bm = h->b_split - 1 - k;
-    h->sweep_tan0[2 * k] = bp < B ? (float)std::tan((double)h->beam_cache[bp]) : INFINITY;
-    h->sweep_tan0[2 * k + 1] = bm >= 0 ? (float)(-std::tan((double)h->beam_cache[bm])) : INFINITY;
+    blk[(size_t)B * 6 + 2 * k] = bp < B ? (float)std::tan((double)h->beam_cache[bp]) : INFINITY;
+    blk[(size_t)B * 6 + 2 * k + 1] = bm >= 0 ? (float)(-std::tan((double)h->beam_cache[bm])) : INFINITY;
   }
   RET_IF(upload(h, h->sweep_beams, blk.data(), sizeof(float) * blk.size()));
   h->ranges_ptr = h->sweep_tail + B;
@@ -1432,7 +1432,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.sweep_tail = nullptr;
   a.b_split = 0;
   a.sweep_nvalid = 0;
-  for (int k = 0; k < 4; ++k) a.sweep_tan0[k] = INFINITY;
+  a.sweep_nsub = 1;
+  a.sweep_tan0 = nullptr;
   a.sweep_c2z_min = 2.f;
   a.sweep_slope = 0.f;
   a.defer_idx = nullptr;
@@ -1494,10 +1495,9 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   // ---- fan sweep (mcl_sweep.h): regularly triangulated meshes, ascending beam angles.  The fan plane may lean
   // from the vertical only as far as the steepest triangle allows (tan(tilt) * slope < 1, with a margin).
   if (!pose_done) {
-    // (one lane per particle side: below ~16 k particles (meshes; ~100 k on height grids, whose per-beam work is
-    //  heavier) the sweep cannot fill the chip and the wave-per-particle traversal is faster -- measured at 32 k ...
-    //  1 M; MCL_SWEEP=1 forces it)
-    const long long sweep_min_n = h->env_sweep == 1 ? 1 : (h->map_kind == 0 ? 98304 : 16384);
+    // (below ~16 k particles on meshes / ~32 k on height grids the sweep's lanes cannot fill the chip and the
+    //  wave-per-particle traversal is faster -- measured at 32 k ... 1 M; MCL_SWEEP=1 forces it)
+    const long long sweep_min_n = h->env_sweep == 1 ? 1 : (h->map_kind == 0 ? 32768 : 16384);
     // a height-field TIN with adjacency -- also a triangulated height grid whose cells are split along mixed diagonals
     // (tin_ok: mesh_build has PROVEN the mesh single-valued over (x, y) -- adjacency, fold and pairwise overlap tests)
     const bool tin = h->map_kind == 1 && h->mesh->tin_ok && !h->mesh_no_sweep && (!structured || a.diag_mode == 0);
@@ -1522,7 +1522,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.sweep_tail = h->sweep_tail;
     a.b_split = h->b_split;
     a.sweep_nvalid = h->sweep_nvalid;
-    for (int k = 0; k < 4; ++k) a.sweep_tan0[k] = h->sweep_tan0[k];
+    a.sweep_tan0 = h->sweep_tail + 2 * (size_t)B;
     // (grids: 0.45 -- below 0.5 the plane function cannot change sign around a cell's four corners, mcl_sweep.h)
     const double slope_max = h->map_kind == 0 ? h->gslope_max : h->mesh->slope_max;
     const double tan_lim = std::min(std::tan(35.0 * MCL_PI / 180.0), (h->map_kind == 0 ? 0.45 : 0.8) / std::max(slope_max, 1e-9));
@@ -1578,17 +1578,34 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       RET_IF(sort_visiting_order(h, a));
       a.perm = h->mbes_perm;
     }
+    // Lanes per particle side: a small cloud may split a side's beams over 2 or 4 lanes (each walks out from the nadir
+    // and resolves its own run of >= 16 beams); the GLOBAL particle count decides, so every shard sums in the same order.
+    // (measured, round 3, 256 beams, MBES update in ms -- traversal | sweep with 1 / 2 / 4 lanes per side:
+    //    grid  32 768: 0.096 | 0.103 0.080 0.078     grid  65 536: 0.100 | 0.109 0.098 0.132
+    //    mesh  32 768: 0.095 | 0.037 0.041 0.038     mesh  65 536: 0.099 | 0.038 0.045 0.048
+    //  every extra lane re-walks the inner part of the slice, so on meshes, whose per-beam work is light, one lane per
+    //  side is never beaten; on height grids the heavier per-beam work is worth spreading below ~100 k particles)
+    int nsub = 1;
+    if (with_ranges) {
+      if (h->map_kind == 0) nsub = h->ng >= 98304 ? 1 : (h->ng >= 49152 ? 2 : 4);
+      if (h->env_nsub) nsub = h->env_nsub;
+      while (nsub > 1 && B / (2 * nsub) < 16) nsub >>= 1;
+    }
+    a.sweep_nsub = nsub;
+    const int sthreads = nsub == 4 ? 512 : SWEEP_THREADS;
+    const int per_block = sthreads / 64 / (2 * nsub) * 64;
     // (expected ranges of a few particles: only their lanes are launched)
-    const long long n_lanes = 2 * ((!with_ranges && !a.perm) ? std::max<long long>(std::min<long long>(exp_count, h->n - exp_first), 1) : h->n);
-    const int sgrid = (int)((n_lanes + SWEEP_THREADS - 1) / SWEEP_THREADS);
-    const size_t lds = (size_t)(B + 2) * sizeof(float4) + (size_t)B * sizeof(float);
+    const long long n_part = (!with_ranges && !a.perm) ? std::max<long long>(std::min<long long>(exp_count, h->n - exp_first), 1) : h->n;
+    const int sgrid = (int)((n_part + per_block - 1) / per_block);
+    const size_t lds = (size_t)(B + 2) * sizeof(float4) + (size_t)(B + 4) * sizeof(float);
     // What the first pass declines goes through a second, bounds-checked pass (lattice maps: a slice that leaves the
     // map ends there), and what that one declines is cast the old way, in the order of its hand-over list: group
     // records and worklist (k_mbes_classify), the fast kernel, the general kernel.  All of them read the length of
     // their list on the device.
     const bool lattice = h->map_kind == 0 || (structured && a.diag_mode != 0);
     h->sweep_two_pass = lattice;
-    MbesArgs c = a;   // second pass
+    MbesArgs c = a;   // second pass (always one lane per side: it sees few particles)
+    c.sweep_nsub = 1;
     c.perm = h->defer_idx;
     c.n_dev = a.defer_count;
     c.defer_idx = h->defer_idx2;
@@ -1604,12 +1621,15 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     const int cgrid = (int)std::min<long long>(grid_for(h->n), few ? 32 : 1024);
     const int fgrid = (int)std::min<long long>(ngroups, few ? 64 : 2048);
     const int dgrid = (int)std::min<long long>(ngroups, few ? 64 : 512);
-    const int s2grid = (int)std::min<long long>(sgrid, few2 ? 32 : 4096);
+    const int s2grid = (int)std::min<long long>((h->n + SWEEP_THREADS / 2 - 1) / (SWEEP_THREADS / 2), few2 ? 32 : 4096);
 #define LAUNCH_SWEEP(SURFV, MAPV)                                                        \
   do {                                                                                   \
     if (with_ranges) {                                                                   \
       t_begin(h, MCL_K_MBES_MAIN);                                                       \
-      k_mbes_sweep<SURFV, false, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);    \
+      if (nsub > 1)                                                                      \
+        k_mbes_sweep<SURFV, false, false, true><<<sgrid, sthreads, lds, h->stream>>>(a); \
+      else                                                                               \
+        k_mbes_sweep<SURFV, false, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);  \
       t_end(h);                                                                          \
       k_mbes_sweep<SURFV, false, true><<<s2grid, SWEEP_THREADS, lds, h->stream>>>(c);    \
       k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
@@ -1627,7 +1647,10 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   do {                                                                                   \
     if (with_ranges) {                                                                   \
       t_begin(h, MCL_K_MBES_MAIN);                                                       \
-      k_mbes_sweep<5, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);               \
+      if (nsub > 1)                                                                      \
+        k_mbes_sweep<5, false, false, true><<<sgrid, sthreads, lds, h->stream>>>(a);     \
+      else                                                                               \
+        k_mbes_sweep<5, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);             \
       t_end(h);                                                                          \
       k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
       k_mbes_fast<SURFV, false><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);               \
@@ -1893,6 +1916,7 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
     h->env_debug_work = getenv("MCL_DEBUG_WORK") != nullptr;
     if (const char* sv = getenv("MCL_SORT_VISITS")) h->env_sort = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_SWEEP")) h->env_sweep = sv[0] == '1' ? 1 : 0;
+    if (const char* sv = getenv("MCL_SWEEP_NSUB")) h->env_nsub = (sv[0] == '2' || sv[0] == '4') ? sv[0] - '0' : 1;
     h->env_force_comm = on("MCL_FORCE_COMM");
     if (const char* ex = getenv("MCL_EXCHANGE")) h->exch_allgather = strcmp(ex, "allgather") == 0;
     h->env_no_overlap = on("MCL_NO_OVERLAP");

@@ -77,10 +77,14 @@ struct SweepNode {
 //   tilt, the map's steepest slope and the angle between fan and border decide (see the test in the walk); a level
 //   vehicle always qualifies, a tilted fan slanting along the border over steep terrain goes on to the traversal
 //   kernels, like everything else the second pass declines.
-template <int SURF, bool EXPECT_ONLY, bool CHECKED = false>
+// SUB (sub-fans, small clouds): the beams of a side are split over `nsub` lanes; every one of them walks out from the
+//   nadir like the whole side's lane would, but resolves only its own run of beams [sub * per, (sub + 1) * per) --
+//   the walk is a chain of dependent loads, so at 65 536 particles one lane per side leaves the chip three quarters
+//   empty and every lane waiting; four lanes per side fill it and each carries a quarter of the merge work.
+template <int SURF, bool EXPECT_ONLY, bool CHECKED = false, bool SUB = false>
 __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P, const float4* __restrict__ sbeam,
-                                           const float* __restrict__ stail, int side, float* __restrict__ exp_row,
-                                           float& acc_out) {
+                                           const float* __restrict__ stail, int side, int sub, int nsub,
+                                           float* __restrict__ exp_row, float& acc_out) {
   acc_out = 0.f;
   const int nx = a.nx, ny = a.ny, B = a.n_beams;
   // every test before the first map access feeds ONE verdict (`pre`), tested once
@@ -92,9 +96,13 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   const float ul = (float)(P.um - fum), vl = (float)(P.vm - fvm);
   const float res = a.res, inv_res = (float)a.inv_res, oz = P.oz;
   const float sg = side ? -1.f : 1.f;
-  // beams of this side, outward from the nadir
-  int ptr = side ? a.b_split - 1 : a.b_split;
-  const int pstep = side ? -1 : 1, pend = side ? -1 : B;
+  // beams of this side (of this lane's run of them), outward from the nadir
+  const int nb_side = side ? a.b_split : B - a.b_split;
+  const int per = SUB ? (nb_side + nsub - 1) / nsub : nb_side;
+  const int first = SUB ? min(sub * per, nb_side) : 0, last = SUB ? min(first + per, nb_side) : nb_side;
+  int ptr = side ? a.b_split - 1 - first : a.b_split + first;
+  const int pstep = side ? -1 : 1, pend = side ? a.b_split - 1 - last : a.b_split + last;
+  const int side_end = side ? -1 : B;
   const bool none = ptr == pend;
   // ---- how far out can the walk go?  The outermost beam of the side is below every node once it reaches z_min
   float s_stop = none ? 0.f : a.r_max;  // (a side without beams only takes part in the nadir cast)
@@ -214,8 +222,12 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   //  for the record that has just been requested)
   const float4* bp = sbeam + ptr;
   const float4* const bp_end = sbeam + pend;
-  float tcur = side ? a.sweep_tan0[1] : a.sweep_tan0[0];   // tan of the pending beam (side-signed)
-  float tnext = side ? a.sweep_tan0[3] : a.sweep_tan0[2];  // ... and of the one after it (SWEEP_TAN_AHEAD 2)
+  float tcur = stail[a.n_beams + side];   // tan of the pending beam (side-signed)
+  float tnext = stail[a.n_beams + 2 + side];  // ... and of the one after it (SWEEP_TAN_AHEAD 2)
+  if (SUB && first > 0) {   // (a later run of the side: its tangents are in the records two and one beams back)
+    tcur = bp[-2 * pstep].x;
+    tnext = bp[-pstep].x;
+  }
   float4 bm = bp[0];
   // SURF 0: does the current / previous vertex lie on a cell edge (and not on an auxiliary diagonal)?
   const auto on_cell_edge = [](int Pa, int Pb) { const int dP = Pa - Pb; return !(dP == 65537 || dP == -65537); };
@@ -343,9 +355,10 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
       };
       // (no end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0, so e_cur = -inf)
       if (SURF != 0) {
-        while (e_cur >= 0.f) resolve(false);   // until the pending beam passes beyond this vertex
+        while (e_cur >= 0.f && (!SUB || bp != bp_end)) resolve(false);   // until the pending beam passes beyond this vertex
       } else {
         for (;;) {
+          if (SUB && bp == bp_end) break;   // (the beams beyond belong to the next lane of this side)
           bool graze = false;
           if (!(e_cur >= 0.f)) {  // the beam passes beyond this vertex ...
             const float e_prev_g = fmaf(-tcur, tp, sp);
@@ -422,7 +435,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     if (EXPECT_ONLY) {
       for (; ptr != pend; ptr += pstep) exp_row[ptr] = a.r_max;
     } else {
-      acc += stail[ptr];
+      acc += stail[ptr] - ((SUB && pend != side_end) ? stail[pend] : 0.f);   // (tail sums run to the end of the side)
     }
   }
   acc_out = acc;
@@ -484,10 +497,10 @@ __device__ __forceinline__ float tin_nadir(const MbesArgs& a, int I0, int J0, fl
   return a.r_max;
 }
 
-template <bool EXPECT_ONLY>
+template <bool EXPECT_ONLY, bool SUB = false>
 __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose& P, const float4* __restrict__ sbeam,
-                                               const float* __restrict__ stail, int side, float* __restrict__ exp_row,
-                                               float& acc_out) {
+                                               const float* __restrict__ stail, int side, int sub, int nsub,
+                                               float* __restrict__ exp_row, float& acc_out) {
   acc_out = 0.f;
   const MeshArgs& ma = a.mesh;
   const int nx = a.nx, ny = a.ny, B = a.n_beams;  // (cells + 1 of the cell grid: the mesh's bounding box)
@@ -499,8 +512,12 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   const float ul = (float)(P.um - fum), vl = (float)(P.vm - fvm);
   const float res = a.res, inv_res = (float)a.inv_res, oz = P.oz;
   const float sg = side ? -1.f : 1.f;
-  int ptr = side ? a.b_split - 1 : a.b_split;
-  const int pstep = side ? -1 : 1, pend = side ? -1 : B;
+  const int nb_side = side ? a.b_split : B - a.b_split;
+  const int per = SUB ? (nb_side + nsub - 1) / nsub : nb_side;
+  const int first = SUB ? min(sub * per, nb_side) : 0, last = SUB ? min(first + per, nb_side) : nb_side;
+  int ptr = side ? a.b_split - 1 - first : a.b_split + first;
+  const int pstep = side ? -1 : 1, pend = side ? a.b_split - 1 - last : a.b_split + last;
+  const int side_end = side ? -1 : B;
   const bool none = ptr == pend;
   float s_stop = none ? 0.f : a.r_max;
   if (!none) {
@@ -582,8 +599,12 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   int step = 0;
   const float4* bp = sbeam + ptr;
   const float4* const bp_end = sbeam + pend;
-  float tcur = side ? a.sweep_tan0[1] : a.sweep_tan0[0];
-  float tnext = side ? a.sweep_tan0[3] : a.sweep_tan0[2];
+  float tcur = stail[a.n_beams + side];
+  float tnext = stail[a.n_beams + 2 + side];
+  if (SUB && first > 0) {
+    tcur = bp[-2 * pstep].x;
+    tnext = bp[-pstep].x;
+  }
   float4 bm = bp[0];
   for (;;) {
     // the neighbour's record is in flight while the beams are resolved
@@ -592,7 +613,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const uint4 tv3 = ma.tin_tri[2 * tq], tn3 = ma.tin_tri[2 * tq + 1];
     const float dts = t_cur - t_prev;
     float e_cur = fmaf(-tcur, t_cur, s_cur);
-    while (e_cur >= 0.f) {
+    while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
       const float e_prev = fmaf(-tcur, t_prev, s_prev);
       const float lam = __builtin_amdgcn_fmed3f(e_prev * fast_rcp(e_prev - e_cur), 0.f, 1.f);
       const float tau = fmaf(lam, dts, t_prev);
@@ -657,27 +678,29 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     if (EXPECT_ONLY) {
       for (; ptr != pend; ptr += pstep) exp_row[ptr] = a.r_max;
     } else {
-      acc += stail[ptr];
+      acc += stail[ptr] - ((SUB && pend != side_end) ? stail[pend] : 0.f);
     }
   }
   acc_out = acc;
   return ok;
 }
 
-// Work layout: a WAVE holds 64 particles' lanes of ONE side -- waves 2k and 2k+1 of a workgroup are the + and - sides
-// of the same 64 particles.  The lanes of a wave then walk alike whenever the cloud is coherent (a converged filter:
-// neighbouring slots are centimetres apart), so the merge loop's trip count -- the maximum over the wave of the beams
-// per segment -- is close to every lane's own count; with the two sides of a particle in neighbouring lanes (round 2)
-// every wave mixed two unrelated walks.  The two sides meet through LDS.
-#define SWEEP_PARTICLES (SWEEP_THREADS / 2)   // particles per workgroup
+// Work layout: a WAVE holds 64 particles' lanes of ONE side (and one run of its beams) -- with `nsub` runs per side,
+// waves 2 nsub g ... 2 nsub g + 2 nsub - 1 of a workgroup are the (side, run) combinations of the same 64 particles.
+// The lanes of a wave then walk alike whenever the cloud is coherent, and the beam table is read by broadcast (with the
+// two sides of a particle in neighbouring lanes, round 2, every ds_read hit two distant records: 2.2e7 bank-conflict
+// cycles per launch, now 3e5).  The lanes of a particle meet through LDS.
+#define SWEEP_MAX_WAVES 8   // SUB kernels: up to 4 runs per side x 2 sides
 
-// one particle side: cast; the + side's lane then combines both verdicts, writes lw or hands the particle over.
-// j0: position of the workgroup's first particle in the visiting order.  Returns lw (or -inf) in the + side's lanes.
-template <int SURF, bool EXPECT_ONLY, bool CHECKED>
+// one (particle, side, run): cast; the (+ side, run 0) lane then combines the verdicts and sums in a fixed order, writes
+// lw or hands the particle over.  j0: position of the workgroup's first particle in the visiting order.
+template <int SURF, bool EXPECT_ONLY, bool CHECKED, bool SUB>
 __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, long long n, const float4* sbeam,
                                              const float* stail, float* xacc, int* xok) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: scalar registers)
-  const int side = w & 1, pl = (w >> 1) * 64 + lane;   // particle within the workgroup
+  const int nsub = SUB ? a.sweep_nsub : 1, combos = 2 * nsub;
+  const int group = w / combos, combo = w - group * combos;
+  const int side = combo & 1, sub = combo >> 1, pl = group * 64 + lane;   // particle within the workgroup
   // (expected ranges in the natural order: the grid only covers the particles asked for)
   const long long j = j0 + pl + ((EXPECT_ONLY && !a.perm) ? a.exp_first : 0);
   const bool valid = j < n;
@@ -692,20 +715,24 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
   if (work) {
     const MbesPose P = a.pose[i];
     if (SURF == 5)
-      ok = sweep_side_tin<EXPECT_ONLY>(a, P, sbeam, stail, side, exp_row, acc);
+      ok = sweep_side_tin<EXPECT_ONLY, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
     else
-      ok = sweep_side<(SURF == 5 ? 2 : SURF), EXPECT_ONLY, CHECKED>(a, P, sbeam, stail, side, exp_row, acc);
+      ok = sweep_side<(SURF == 5 ? 2 : SURF), EXPECT_ONLY, CHECKED, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
   }
-  // both sides of a particle agree on its fate: the - side leaves its verdict and sum in LDS (every lane takes part)
-  if (side) {
-    xacc[pl] = acc;
-    xok[pl] = ok ? 1 : 0;
+  // the lanes of a particle agree on its fate: every lane but the first leaves its verdict and sum in LDS
+  if (combo) {
+    xacc[w * 64 + lane] = acc;
+    xok[w * 64 + lane] = ok ? 1 : 0;
   }
   __syncthreads();
   double v = -__builtin_inf();
-  if (!side) {
-    const bool ok2 = ok & (xok[pl] != 0);
-    const double acc2 = (double)acc + (double)xacc[pl];
+  if (!combo) {
+    bool ok2 = ok;
+    double acc2 = (double)acc;
+    for (int c = 1; c < combos; ++c) {   // fixed order: the sum does not depend on which wave finished first
+      ok2 = ok2 & (xok[(w + c) * 64 + lane] != 0);
+      acc2 += (double)xacc[(w + c) * 64 + lane];
+    }
     if (work && ok2 && !EXPECT_ONLY) {
       v = -0.5 * acc2 - (double)a.sweep_nvalid * a.lognorm;
       a.lw[i] = v;
@@ -722,42 +749,45 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
   return v == v ? v : -__builtin_inf();  // NaN never wins the maximum
 }
 
-template <int SURF, bool EXPECT_ONLY, bool CHECKED = false>
 // (register budgets: lattice first pass 8 waves / SIMD (64 VGPRs), grids, TINs and the lattice second pass 6, the bounds-
 //  checked second pass over a GRID 4 -- it carries the conic AND the border tests, and spilled 84 B per lane at 6)
-__global__ void __launch_bounds__(SWEEP_THREADS, (SURF == 0 && CHECKED) ? 4 : ((SURF == 0 || SURF == 5) ? SWEEP_MIN_WAVES_GRID : (CHECKED ? 6 : SWEEP_MIN_WAVES))) k_mbes_sweep(MbesArgs a) {
+template <int SURF, bool EXPECT_ONLY, bool CHECKED = false, bool SUB = false>
+__global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, (SURF == 0 && CHECKED) ? 4 : ((SURF == 0 || SURF == 5) ? SWEEP_MIN_WAVES_GRID : (CHECKED ? 6 : SWEEP_MIN_WAVES))) k_mbes_sweep(MbesArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sweep_lds[];
-  __shared__ float xacc[SWEEP_PARTICLES];
-  __shared__ int xok[SWEEP_PARTICLES];
+  __shared__ float xacc[64 * (SUB ? SWEEP_MAX_WAVES : SWEEP_THREADS / 64)];
+  __shared__ int xok[64 * (SUB ? SWEEP_MAX_WAVES : SWEEP_THREADS / 64)];
   float4* sbeam = (float4*)sweep_lds + 1;  // records -1 and n_beams exist (read, never used)
   float* stail = (float*)(sbeam + a.n_beams + 1);
   const long long n = mbes_count(a);  // (CHECKED pass: the length of the first pass's hand-over list, read here)
   if (CHECKED && a.host_count && blockIdx.x == 0 && threadIdx.x == 0) *a.host_count = (int)n;
   if (CHECKED && n == 0) return;
-  for (int b = threadIdx.x; b < a.n_beams; b += SWEEP_THREADS) {
+  for (int b = threadIdx.x; b < a.n_beams; b += blockDim.x) {
     sbeam[b] = a.sweep_beams[b];
     stail[b] = a.sweep_tail[b];
   }
+  if (threadIdx.x < 4) stail[a.n_beams + threadIdx.x] = a.sweep_tan0[threadIdx.x];   // (first / second tangent of either side)
   if (threadIdx.x == 0) sbeam[-1] = sbeam[a.n_beams] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);  // "never reached"
   __syncthreads();
+  // particles per workgroup: its waves divided by the (side, run) combinations of a particle
+  const int per_block = (int)(blockDim.x >> 6) / (2 * (SUB ? a.sweep_nsub : 1)) * 64;
   double vmax;
   if (!CHECKED) {
-    // the first pass is launched with one lane per particle side
-    vmax = sweep_lane<SURF, EXPECT_ONLY, false>(a, blockIdx.x * (long long)SWEEP_PARTICLES, n, sbeam, stail, xacc, xok);
+    // the first pass is launched with one lane per (particle, side, run)
+    vmax = sweep_lane<SURF, EXPECT_ONLY, false, SUB>(a, blockIdx.x * (long long)per_block, n, sbeam, stail, xacc, xok);
   } else {
     // the CHECKED pass strides over the first pass's list, a workgroup's worth of particles at a time
     vmax = -__builtin_inf();
-    for (long long j0 = blockIdx.x * (long long)SWEEP_PARTICLES; j0 < n; j0 += (long long)gridDim.x * SWEEP_PARTICLES) {
-      const double v = sweep_lane<SURF, EXPECT_ONLY, true>(a, j0, n, sbeam, stail, xacc, xok);
+    for (long long j0 = blockIdx.x * (long long)per_block; j0 < n; j0 += (long long)gridDim.x * per_block) {
+      const double v = sweep_lane<SURF, EXPECT_ONLY, true, SUB>(a, j0, n, sbeam, stail, xacc, xok);
       vmax = v > vmax ? v : vmax;
       __syncthreads();  // (xacc / xok are rewritten by the next round)
     }
   }
-  if (!EXPECT_ONLY && a.max_slots && !((threadIdx.x >> 6) & 1)) {
-    // the normalisation needs max lw: one atomic per (+ side) wave on an order-preserving key
+  if (!EXPECT_ONLY && a.max_slots) {
+    // the normalisation needs max lw: one atomic per wave that wrote log-likelihoods, on an order-preserving key
     const double m = wave_max(vmax);
     if ((threadIdx.x & 63) == 0 && m > -__builtin_inf())
-      atomicMax((unsigned long long*)&a.max_slots[(blockIdx.x * (SWEEP_THREADS / 64) + (threadIdx.x >> 6)) & (MCL_MAX_SLOTS - 1)],
+      atomicMax((unsigned long long*)&a.max_slots[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (MCL_MAX_SLOTS - 1)],
                 ordered_key(m));
   }
 }

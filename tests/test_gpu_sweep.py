@@ -555,6 +555,52 @@ def test_sharded_sweep_is_bitwise_the_unsharded_one(eng, monkeypatch):
         assert np.array_equal(one.get_particles(), np.concatenate([e.get_particles() for e in many], axis=1)), step
 
 
+@pytest.mark.parametrize('nsub', [2, 4])
+@pytest.mark.parametrize('kind', ['mesh', 'mesh2', 'grid', 'tin'])
+def test_sub_fans_split_a_sides_beams_over_several_lanes(kind, nsub, eng, orc, monkeypatch):
+    """Small clouds: the beams of a particle side are split over 2 or 4 lanes, each walking out from the nadir and
+    resolving its own run (mcl_sweep.h SUB).  Same log-likelihoods as one lane per side up to the order of the fp32
+    partial sums, same tolerance against the oracle; odd beam counts, an invalid beam in every run, a short r_max
+    (the outer runs end in the tail sums), a swath that is not centred (runs of unequal length on the two sides)."""
+    monkeypatch.setenv('MCL_SWEEP', '1')
+    z, origin = _terrain(seed=51)
+    n, B = 1500, 257
+    soa = _cloud(n, 9, (4.0, 4.0, 0.4, 0.04, 0.04, 3.0), (3.0, -4.0, -2.0))
+    ba = (synth.beam_angles(B, 1.1) + 0.15).astype(np.float32)     # off-centre swath
+    off = [0.2, -0.1, -0.1, 0.01, -0.02, 0.03]
+    if kind == 'grid':
+        omap = orc.Grid(z, origin, 1.0)
+    else:
+        if kind == 'tin':
+            verts, tris = synth.mesh_tin(z, 1.0, origin, seed=4)
+        else:
+            verts, tris = synth.mesh_from_grid(z, 1.0, origin, diagonal='00-11' if kind == 'mesh' else '10-01')
+        omap = orc.Mesh(verts, tris)
+    out = {}
+    for r_max in (80.0, 26.0):
+        _, ex = orc.mbes_update(soa[:, :1].copy(), np.identity(4), off, omap, ba, None, 0.2, r_max)
+        ranges = (ex[0] + 0.2 * np.random.RandomState(2).randn(B)).astype(np.float32)
+        ranges[::37] = 0.0
+        for k in (1, nsub):
+            monkeypatch.setenv('MCL_SWEEP_NSUB', str(k))
+            e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+            e.set_particles(soa)
+            if kind == 'grid':
+                e.set_map_grid(z, origin, 1.0)
+            else:
+                e.set_map_mesh(verts, tris)
+            e.update_mbes(ranges, ba, 0.2, r_max, off)
+            assert e.mbes_last_path()[0] == 1
+            out[k] = e.get_log_weights()
+            e.close()
+        lw_ref, _ = orc.mbes_update(soa, np.identity(4), off, omap, ba, ranges, 0.2, r_max)
+        d = np.abs(out[nsub] - lw_ref)
+        okm = (d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref))
+        assert (~okm).sum() <= n // 200, (kind, nsub, r_max, d.max())
+        rel = np.abs(out[nsub] - out[1]) / np.maximum(1.0, np.abs(out[1]))
+        assert rel.max() <= 1e-5, (kind, nsub, r_max, rel.max())   # the same residuals, summed in another order
+
+
 @pytest.mark.parametrize('seed', range(30))
 def test_sweep_fuzz_against_the_oracle(seed, eng, orc):
     """Random scenes: map kind (regular mesh of either diagonal, height grid, TIN), resolution, relief, vehicle
