@@ -1580,14 +1580,17 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     }
     // Lanes per particle side: a small cloud may split a side's beams over 2 or 4 lanes (each walks out from the nadir
     // and resolves its own run of >= 16 beams); the GLOBAL particle count decides, so every shard sums in the same order.
-    // (measured, round 3, 256 beams, MBES update in ms -- traversal | sweep with 1 / 2 / 4 lanes per side:
-    //    grid  32 768: 0.096 | 0.103 0.080 0.078     grid  65 536: 0.100 | 0.109 0.098 0.132
-    //    mesh  32 768: 0.095 | 0.037 0.041 0.038     mesh  65 536: 0.099 | 0.038 0.045 0.048
-    //  every extra lane re-walks the inner part of the slice, so on meshes, whose per-beam work is light, one lane per
-    //  side is never beaten; on height grids the heavier per-beam work is worth spreading below ~100 k particles)
+    // (measured, round 3, the dominant launch in ms -- traversal | sweep with 1 / 2 / 4 lanes per side:
+    //    grid  32 768 x 256: 0.093 | 0.103 0.068 0.055     mesh  32 768 x 256: 0.093 | 0.036 0.033 0.028
+    //    grid  65 536 x 256: 0.100 | 0.108 0.086 0.087     mesh  65 536 x 256: 0.098 | 0.038 0.039 0.037
+    //    grid 131 072 x 512: 0.273 | 0.216 0.208 0.205     mesh 131 072 x 512: 0.263 | 0.066 0.074 0.078
+    //  a later run pays one slanted traversal for its start; worth it while the chip is not full)
     int nsub = 1;
     if (with_ranges) {
-      if (h->map_kind == 0) nsub = h->ng >= 98304 ? 1 : (h->ng >= 49152 ? 2 : 4);
+      if (h->map_kind == 0)
+        nsub = h->ng < 49152 ? 4 : (h->ng < 196608 ? 2 : 1);
+      else if (h->mesh->heights && !h->force_general_mesh)
+        nsub = h->ng < 49152 ? 4 : 1;
       if (h->env_nsub) nsub = h->env_nsub;
       while (nsub > 1 && B / (2 * nsub) < 16) nsub >>= 1;
     }

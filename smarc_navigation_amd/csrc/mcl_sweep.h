@@ -77,10 +77,10 @@ struct SweepNode {
 //   tilt, the map's steepest slope and the angle between fan and border decide (see the test in the walk); a level
 //   vehicle always qualifies, a tilted fan slanting along the border over steep terrain goes on to the traversal
 //   kernels, like everything else the second pass declines.
-// SUB (sub-fans, small clouds): the beams of a side are split over `nsub` lanes; every one of them walks out from the
-//   nadir like the whole side's lane would, but resolves only its own run of beams [sub * per, (sub + 1) * per) --
-//   the walk is a chain of dependent loads, so at 65 536 particles one lane per side leaves the chip three quarters
-//   empty and every lane waiting; four lanes per side fill it and each carries a quarter of the merge work.
+// SUB (sub-fans, small clouds): the beams of a side are split over `nsub` lanes; each resolves only its own run of
+//   beams [sub * per, (sub + 1) * per) and starts its walk where the first of them meets the seabed (see the start of
+//   the walk below) -- the walk is a chain of dependent loads, so at 65 536 particles one lane per side leaves the
+//   chip three quarters empty and every lane waiting; four lanes per side fill it, each with a quarter of the walk.
 template <int SURF, bool EXPECT_ONLY, bool CHECKED = false, bool SUB = false>
 __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P, const float4* __restrict__ sbeam,
                                            const float* __restrict__ stail, int side, int sub, int nsub,
@@ -142,8 +142,28 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   // the height array as a raw buffer (stride 0, num_records in bytes): out-of-range reads return 0
   const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.grid, 0, nx * ny * 4, 0x00020000);
   const int ny4 = ny * 4, g0b = g0i * 4;
-  // ---- nadir hit: the ordinary clearance traversal on the global height array
-  const float r0 = cast_clear<SURF>(gp, ny, a, ul, vl, oz, -P.c2[0] * inv_res, -P.c2[1] * inv_res, -c2z, a.zmax_map, a.r_max);
+  // ---- start of the walk: the nadir hit, by the ordinary clearance traversal on the global height array.  A later
+  // run of a side's beams (SUB, first > 0) starts where ITS first beam meets the seabed instead -- the same traversal
+  // along that beam, a few dozen cells -- and walks on from there: under the tilt bound the slice is a graph over s, so
+  // everything the sweep's argument needs holds from any exact hit outward.  If that beam has no hit inside r_max the
+  // lane falls back to walking out from the nadir (it resolves nothing on the way: its first beam is still pending).
+  float dxs = -P.c2[0], dys = -P.c2[1], dzs = -c2z, r0 = 0.f;
+  bool own_start = false;
+  if (SUB && first > 0 && !none) {
+    const float2 sc = a.beam_sc[ptr];
+    dxs = sc.x * P.c1[0] - sc.y * P.c2[0];
+    dys = sc.x * P.c1[1] - sc.y * P.c2[1];
+    dzs = sc.x * P.c1[2] - sc.y * c2z;
+    own_start = true;
+  }
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    r0 = cast_clear<SURF>(gp, ny, a, ul, vl, oz, dxs * inv_res, dys * inv_res, dzs, a.zmax_map, a.r_max);
+    if (!SUB || !own_start || ((r0 < a.r_max) & (r0 > 0.f))) break;
+    dxs = -P.c2[0];
+    dys = -P.c2[1];
+    dzs = -c2z;
+    own_start = false;
+  }
   if (!(r0 < a.r_max)) SWEEP_FAIL(5);
   if (SURF == 0 && !(r0 > 0.f)) SWEEP_FAIL(9);  // the sensor is at or below the seabed (a grid is solid underneath)
   if (none) return true;
@@ -169,7 +189,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   int C, start_i, start_j;
   float s_prev, t_prev, s_cur, t_cur;
   {
-    const float uh = fmaf(r0, -P.c2[0] * inv_res, ul), vh = fmaf(r0, -P.c2[1] * inv_res, vl);
+    const float uh = fmaf(r0, dxs * inv_res, ul), vh = fmaf(r0, dys * inv_res, vl);
     const float cfi = floorf(uh), cfj = floorf(vh);
     const float fu = uh - cfi, fv = vh - cfj;
     const int c00 = (int)cfi * 65536 + (int)cfj;
