@@ -28,7 +28,7 @@ def rows(path_glob):
 
 def mean_counter(d, pass_name, kernel_prefix, counter):
     vals = {}
-    for r in rows(os.path.join(d, pass_name, '**', '*counter_collection.csv')):
+    for r in rows(os.path.join(d, pass_name, '**', '*counter_collection.csv*')):
         if r['Kernel_Name'].startswith(kernel_prefix) and r['Counter_Name'] == counter:
             vals.setdefault(r['Dispatch_Id'], 0.0)
             vals[r['Dispatch_Id']] += float(r['Counter_Value'])
@@ -44,7 +44,7 @@ def main():
                    '`python3 bench.py --map <m> --steps 4 --warmup 1 --only-main`, dominant kernel k_mbes_sweep<2,false,false> (mesh) / k_mbes_sweep<0,false,false> (grid): the first sweep pass, '
                    'mean over dispatches; KB -> bytes x1024; FETCH_SIZE doubled (gfx950 reports half of a wide streaming read)',
            '_round': 3, 'source_hash': bench.source_hash()}
-    for kind, prefix in (('mesh', 'void k_mbes_sweep<2, false, false>'), ('grid', 'void k_mbes_sweep<0, false, false>')):
+    for kind, prefix in (('mesh', 'void k_mbes_sweep<2, false, false, false>'), ('grid', 'void k_mbes_sweep<0, false, false, false>')):
         e = {}
         f, nf = mean_counter(d, 'pmc_%s_fetch' % kind, prefix, 'FETCH_SIZE')
         w, nw = mean_counter(d, 'pmc_%s_write' % kind, prefix, 'WRITE_SIZE')
