@@ -1,0 +1,317 @@
+// pf_core.hpp -- the `auv_pf` node's logic over the C ABI (include/mcl.h), ROS-free and header-only: what the roscpp
+// node (src/auv_pf_node.cpp) wraps with subscribers / publishers / tf, and what examples/pf_core_example.cpp drives
+// without ROS (tests/test_cpp_core.py compiles it on CPU and compares it with the Python mirror on the GPU).
+//
+// Mirrors auv_particle_filter/scripts/auv_pf.py method for method: parameters and their defaults (:27-56), the
+// covariance-string parser (:40-44), `diving` starts true (:103), odom_callback / predict (:201-216), gps_odom_cb /
+// update / resample (:125-192) with the gate specified away as in SURVEY A.10 ("every fix after the first predict
+// while not diving"), update_loc_pose (:218-260: covariance in the first nine of 36 slots, tf translation z = 0).
+// Beyond the reference: the bathymetric map and the MBES ping (LaserScan geometry of toy_mbes_manipulator.cpp:69-73;
+// a point cloud in base_frame as mbes_receptor.cpp:126-165 leaves it).  One owner at a time: the node serialises its
+// callbacks with a mutex (the reference's three rospy threads are unlocked).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <numeric>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "mcl.h"
+
+namespace auv_pf_hip {
+
+struct Params {
+  int particle_count = 10;                                                 // auv_pf.py:27
+  std::string map_frame = "map", base_frame = "base_link", utm_frame = "utm", odom_frame = "sam/odom";  // :28-31
+  double measurement_std = 0.01;                                           // :39
+  std::string motion_covariance = "[0.0000, 0.0000, 0.0, 0.0, 0.0, 0.000000000001]";   // launch defaults (no code default)
+  std::string init_covariance = "[0.1, 0.1, 0.0, 0.0, 0.0, 0.0]";
+  std::string resampling_noise_covariance = "[1., 1., 0.0, 0.0, 0.0, 0.0001]";
+  std::string particle_poses_topic = "/particle_poses", odom_corrected_topic = "/average_pose";   // :64,71
+  std::string aux_dive = "/dive", gps_odom_topic = "/gps", odom_topic = "odom";                    // :101,106,110
+  // beyond the reference
+  std::string resample_scheme = "systematic";
+  int seed = 0, device = 0;
+  std::string mbes_topic = "/mbes_scan", mbes_pointcloud_topic = "", mbes_points_frame = "base";
+  double mbes_std = 0.2, mbes_range_max = 100.0;
+  std::string mbes_sensor_offset = "[0.0, 0.0, 0.0, 0.0, 0.0, 0.0]";
+  std::string map_grid_file = "", map_mesh_file = "";
+};
+
+// the reference's ad-hoc parser (auv_pf.py:40-44): strip the brackets, split on ", "
+inline bool parse_cov_string(const std::string& in, double out[6]) {
+  std::string s;
+  for (char c : in)
+    if (c != '[' && c != ']') s.push_back(c);
+  size_t pos = 0;
+  for (int k = 0; k < 6; ++k) {
+    const size_t next = s.find(", ", pos);
+    const std::string tok = s.substr(pos, next == std::string::npos ? std::string::npos : next - pos);
+    char* end = nullptr;
+    out[k] = std::strtod(tok.c_str(), &end);
+    if (end == tok.c_str()) return false;
+    if (next == std::string::npos) return k == 5;
+    pos = next + 2;
+  }
+  return true;
+}
+
+// tf.transformations.quaternion_from_euler, axes 'sxyz' (auv_pf.py:233)
+inline void quaternion_from_euler(double roll, double pitch, double yaw, double q[4]) {
+  const double cr = std::cos(roll / 2), sr = std::sin(roll / 2), cp = std::cos(pitch / 2), sp = std::sin(pitch / 2);
+  const double cy = std::cos(yaw / 2), sy = std::sin(yaw / 2);
+  q[0] = cp * (sr * cy) - sp * (cr * sy);
+  q[1] = cp * (sr * sy) + sp * (cr * cy);
+  q[2] = cp * (cr * sy) - sp * (sr * cy);
+  q[3] = cp * (cr * cy) + sp * (sr * sy);
+}
+
+// Map files: an ASCII .ply triangle mesh, or a height grid as text header + raw floats (".mclgrid":
+// "mclgrid nx ny origin_x origin_y res\n" followed by nx*ny little-endian float32, z[ix*ny + iy]); both are also read
+// by the Python node (smarc_navigation_amd/auv_pf.py:load_map_file).
+struct MapFile {
+  bool is_grid = false;
+  int nx = 0, ny = 0;
+  double ox = 0, oy = 0, res = 1;
+  std::vector<float> z, verts;
+  std::vector<uint32_t> tris;
+};
+inline bool load_map_file(const std::string& path, MapFile& m, std::string& err) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) {
+    err = "cannot open " + path;
+    return false;
+  }
+  std::string magic;
+  f >> magic;
+  if (magic == "mclgrid") {
+    f >> m.nx >> m.ny >> m.ox >> m.oy >> m.res;
+    f.get();  // the newline that ends the header
+    if (!f || m.nx < 2 || m.ny < 2 || !(m.res > 0)) {
+      err = path + ": bad mclgrid header";
+      return false;
+    }
+    m.z.resize((size_t)m.nx * m.ny);
+    f.read((char*)m.z.data(), (std::streamsize)(sizeof(float) * m.z.size()));
+    if (f.gcount() != (std::streamsize)(sizeof(float) * m.z.size())) {
+      err = path + ": truncated height array";
+      return false;
+    }
+    m.is_grid = true;
+    return true;
+  }
+  if (magic == "ply") {
+    std::string line;
+    long nv = 0, nf = 0;
+    bool ascii = false;
+    std::getline(f, line);
+    while (std::getline(f, line)) {
+      std::istringstream t(line);
+      std::string a, b;
+      t >> a >> b;
+      if (a == "format") ascii = b == "ascii";
+      if (a == "element" && b == "vertex") t >> nv;
+      if (a == "element" && b == "face") t >> nf;
+      if (a == "end_header") break;
+    }
+    if (!ascii || nv < 3 || nf < 1) {
+      err = path + ": only ASCII PLY triangle meshes are read";
+      return false;
+    }
+    m.verts.resize((size_t)nv * 3);
+    for (long i = 0; i < nv; ++i) {
+      std::getline(f, line);
+      std::istringstream t(line);
+      t >> m.verts[3 * i] >> m.verts[3 * i + 1] >> m.verts[3 * i + 2];
+    }
+    for (long i = 0; i < nf; ++i) {
+      std::getline(f, line);
+      std::istringstream t(line);
+      int cnt = 0;
+      t >> cnt;
+      std::vector<uint32_t> idx(cnt > 0 ? cnt : 0);
+      for (auto& v : idx) t >> v;
+      for (int k = 1; k + 1 < cnt; ++k) {  // fan-triangulate polygons
+        m.tris.push_back(idx[0]);
+        m.tris.push_back(idx[k]);
+        m.tris.push_back(idx[k + 1]);
+      }
+    }
+    if (!f && !f.eof()) {
+      err = path + ": read error";
+      return false;
+    }
+    return true;
+  }
+  err = path + ": expected an ASCII .ply mesh or a .mclgrid height grid";
+  return false;
+}
+
+class Core {
+ public:
+  Core() = default;
+  Core(const Core&) = delete;
+  Core& operator=(const Core&) = delete;
+  ~Core() {
+    if (h_) mcl_destroy(h_);
+  }
+
+  // m2o: row-major 4x4 map <- odom (mcl_matrix_from_tf of the tf lookup, auv_pf.py:79-81)
+  bool init(const Params& p, const double m2o[16]) {
+    p_ = p;
+    mcl_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.n_particles = p.particle_count;
+    cfg.device = p.device;
+    cfg.seed = (uint64_t)p.seed;
+    cfg.rng_mode = MCL_RNG_NATIVE;
+    cfg.resample_scheme = p.resample_scheme == "residual"      ? MCL_RESAMPLE_RESIDUAL
+                          : p.resample_scheme == "stratified"  ? MCL_RESAMPLE_STRATIFIED
+                          : p.resample_scheme == "multinomial" ? MCL_RESAMPLE_MULTINOMIAL
+                                                               : MCL_RESAMPLE_SYSTEMATIC;
+    cfg.meas_std = p.measurement_std;
+    if (!parse_cov_string(p.init_covariance, cfg.init_cov) || !parse_cov_string(p.motion_covariance, cfg.process_cov) ||
+        !parse_cov_string(p.resampling_noise_covariance, cfg.resample_cov) ||
+        !parse_cov_string(p.mbes_sensor_offset, offset_)) {
+      err_ = "a covariance / offset string does not hold six numbers separated by \", \"";
+      return false;
+    }
+    std::memcpy(cfg.m2o, m2o, sizeof cfg.m2o);
+    int rc = mcl_create(&cfg, &h_);
+    if (rc != MCL_OK) {
+      err_ = std::string("mcl_create: ") + mcl_last_error(nullptr);
+      h_ = nullptr;
+      return false;
+    }
+    if (!check(mcl_init_particles(h_, nullptr))) return false;
+    for (const std::string* path : {&p.map_grid_file, &p.map_mesh_file})
+      if (!path->empty() && !load_map(*path)) return false;
+    return true;
+  }
+
+  bool load_map(const std::string& path) {
+    MapFile m;
+    if (!load_map_file(path, m, err_)) return false;
+    const bool ok = m.is_grid ? check(mcl_set_map_grid(h_, m.z.data(), m.nx, m.ny, m.ox, m.oy, m.res))
+                              : check(mcl_set_map_mesh(h_, m.verts.data(), (int64_t)(m.verts.size() / 3), m.tris.data(),
+                                                       (int64_t)(m.tris.size() / 3)));
+    has_map_ = has_map_ || ok;
+    return ok;
+  }
+
+  void start_timing(double stamp) { time_ = old_time_ = stamp; }   // auv_pf.py:96-98
+  void dive(bool diving) { diving_ = diving; }                      // :100-103 (starts true)
+  bool has_map() const { return has_map_; }
+  const std::string& error() const { return err_; }
+  const Params& params() const { return p_; }
+
+  // odom_callback + predict (auv_pf.py:201-216): twist.linear (body frame), twist.angular.z, orientation, position.z
+  bool odom(double stamp, const double v[3], double w_z, const double q[4], double z) {
+    time_ = stamp;
+    bool ok = true;
+    if (old_time_ != 0.0 && time_ > old_time_) {
+      mcl_odom od;
+      od.stamp = stamp;
+      for (int k = 0; k < 3; ++k) od.v[k] = v[k];
+      od.w_z = w_z;
+      for (int k = 0; k < 4; ++k) od.q[k] = q[k];
+      od.z = z;
+      ok = check(mcl_predict(h_, &od, time_ - old_time_, nullptr));
+    }
+    old_time_ = time_;
+    return ok;
+  }
+
+  // gps_odom_cb -> update -> resample (auv_pf.py:125-192); (x, y) already transformed utm -> map (once, not per particle)
+  bool gps(double x_map, double y_map) {
+    if (old_time_ == 0.0 || diving_) return true;
+    return check(mcl_update_gps(h_, x_map, y_map)) && check(mcl_resample(h_, nullptr, 0, nullptr));
+  }
+
+  // one ping as a LaserScan: angle_min + k * angle_increment, ranges[k]
+  bool ping_scan(const float* ranges, int n, double angle_min, double angle_increment, double range_max) {
+    if (old_time_ == 0.0 || !has_map_ || n < 1) return true;
+    angles_.resize(n);
+    for (int k = 0; k < n; ++k) angles_[k] = (float)(angle_min + angle_increment * k);
+    return check(mcl_update_mbes(h_, ranges, angles_.data(), n, p_.mbes_std, range_max, offset_)) &&
+           check(mcl_resample(h_, nullptr, 0, nullptr));
+  }
+
+  // one ping as points (x, y, z triples): every point is a beam's hit.  In the sensor frame beam b looks along
+  // (0, sin a, -cos a), so a_b = atan2(y, -z) and the range is |p|; points in base_frame are taken back through the
+  // sensor offset first; the beams are handed over in ascending angle.  NaN points are dropped.
+  bool ping_points(const float* xyz, int n_points, bool in_sensor_frame) {
+    if (old_time_ == 0.0 || !has_map_) return true;
+    double R[9];
+    rot(offset_[3], offset_[4], offset_[5], R);
+    std::vector<std::pair<float, float>> beams;  // (angle, range)
+    beams.reserve(n_points);
+    for (int i = 0; i < n_points; ++i) {
+      double p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+      if (!(p[0] == p[0] && p[1] == p[1] && p[2] == p[2])) continue;
+      if (!in_sensor_frame) {
+        const double d[3] = {p[0] - offset_[0], p[1] - offset_[1], p[2] - offset_[2]};
+        for (int c = 0; c < 3; ++c) p[c] = R[0 + c] * d[0] + R[3 + c] * d[1] + R[6 + c] * d[2];  // R^T d
+      }
+      beams.emplace_back((float)std::atan2(p[1], -p[2]), (float)std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
+    }
+    if (beams.empty()) return true;
+    std::stable_sort(beams.begin(), beams.end(), [](const std::pair<float, float>& a, const std::pair<float, float>& b) { return a.first < b.first; });
+    angles_.resize(beams.size());
+    ranges_.resize(beams.size());
+    for (size_t k = 0; k < beams.size(); ++k) {
+      angles_[k] = beams[k].first;
+      ranges_[k] = beams[k].second;
+    }
+    return check(mcl_update_mbes(h_, ranges_.data(), angles_.data(), (int)beams.size(), p_.mbes_std, p_.mbes_range_max, offset_)) &&
+           check(mcl_resample(h_, nullptr, 0, nullptr));
+  }
+
+  // update_loc_pose (auv_pf.py:218-260): mean pose, arithmetic mean of the wrapped yaws, 3 x 3 position covariance
+  // written row-major into the first nine of the 36 covariance slots, quaternion of (roll, pitch, yaw means)
+  bool loc_pose(double mean6[6], double* yaw, double cov36[36], double quat[4]) {
+    double cov9[9];
+    if (!check(mcl_mean_cov(h_, mean6, yaw, cov9))) return false;
+    std::fill(cov36, cov36 + 36, 0.0);
+    for (int k = 0; k < 9; ++k) cov36[k] = cov9[k];
+    quaternion_from_euler(mean6[3], mean6[4], *yaw, quat);
+    return true;
+  }
+
+  // PoseArray payload (auv_pf.py:264-277): n x (x, y, z, qx, qy, qz, qw)
+  bool poses(std::vector<double>& pose7) {
+    pose7.resize((size_t)p_.particle_count * 7);
+    return check(mcl_get_poses(h_, pose7.data()));
+  }
+
+  mcl_handle* handle() { return h_; }
+
+ private:
+  static void rot(double roll, double pitch, double yaw, double R[9]) {
+    const double cr = std::cos(roll), sr = std::sin(roll), cp = std::cos(pitch), sp = std::sin(pitch);
+    const double cy = std::cos(yaw), sy = std::sin(yaw);
+    const double M[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, sy * cp, sy * sp * sr + cy * cr,
+                         sy * sp * cr - cy * sr, -sp, cp * sr, cp * cr};
+    std::memcpy(R, M, sizeof M);
+  }
+  bool check(int rc) {
+    if (rc == MCL_OK) return true;
+    err_ = std::string(mcl_status_string(rc)) + ": " + mcl_last_error(h_);
+    return false;
+  }
+
+  Params p_;
+  mcl_handle* h_ = nullptr;
+  double offset_[6] = {0, 0, 0, 0, 0, 0};
+  double time_ = 0.0, old_time_ = 0.0;
+  bool diving_ = true, has_map_ = false;   // auv_pf.py:103
+  std::vector<float> angles_, ranges_;
+  std::string err_;
+};
+
+}  // namespace auv_pf_hip

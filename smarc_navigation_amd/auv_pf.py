@@ -37,7 +37,8 @@ DEFAULT_PARAMS = {
     'resample_scheme': 'systematic', 'seed': 0, 'device': 0,
     'mbes_topic': '/mbes_scan', 'mbes_std': 0.2, 'mbes_sensor_offset': '[0.0, 0.0, 0.0, 0.0, 0.0, 0.0]',
     # the bathymetric map the MBES update casts against: an .npz with `z` (nx, ny) + `origin` (2) + `res` (height
-    # grid, map frame) or with `verts` (nv, 3) + `tris` (nt, 3); an ASCII .ply triangle mesh.  '' = no map: pings ignored
+    # grid, map frame) or with `verts` (nv, 3) + `tris` (nt, 3); an ASCII .ply triangle mesh; a .mclgrid height grid
+    # (save_mclgrid: the format the roscpp node reads too).  '' = no map: pings ignored
     'map_grid_file': '', 'map_mesh_file': '',
     # MBES pings as sensor_msgs/PointCloud2 (what mbes_mapper's receptor makes of a LaserScan,
     # mbes_receptor.cpp:126-165): '' = not subscribed.  `mbes_points_frame`: 'base' -- points in base_frame, as
@@ -64,7 +65,8 @@ def quaternion_from_euler(roll, pitch, yaw):
 
 
 def load_map_file(path):
-    """('grid', z, origin, res) or ('mesh', verts, tris) from an .npz (keys above) or an ASCII .ply triangle mesh."""
+    """('grid', z, origin, res) or ('mesh', verts, tris) from an .npz (keys above), an ASCII .ply triangle mesh or a
+    .mclgrid height grid."""
     if path.lower().endswith('.npz'):
         with np.load(path, allow_pickle=False) as f:
             if 'z' in f.files:
@@ -94,7 +96,25 @@ def load_map_file(path):
                 for k in range(2, t[0]):   # fan-triangulate polygons
                     tris.append((t[1], t[k], t[k + 1]))
         return ('mesh', verts, np.array(tris, np.uint32))
-    raise ValueError('map file %s: expected .npz or .ply' % path)
+    if path.lower().endswith('.mclgrid'):   # text header + raw float32 (what the roscpp node reads: pf_core.hpp)
+        with open(path, 'rb') as f:
+            head = f.readline().split()
+            if len(head) != 6 or head[0] != b'mclgrid':
+                raise ValueError('%s: bad mclgrid header' % path)
+            nx, ny = int(head[1]), int(head[2])
+            z = np.frombuffer(f.read(4 * nx * ny), dtype='<f4')
+            if z.size != nx * ny:
+                raise ValueError('%s: truncated height array' % path)
+        return ('grid', z.reshape(nx, ny).astype(np.float32), (float(head[3]), float(head[4])), float(head[5]))
+    raise ValueError('map file %s: expected .npz, .ply or .mclgrid' % path)
+
+
+def save_mclgrid(path, z, origin, res):
+    """Height grid as `mclgrid nx ny origin_x origin_y res\\n` + nx * ny little-endian float32, z[ix * ny + iy]."""
+    z = np.ascontiguousarray(z, dtype='<f4')
+    with open(path, 'wb') as f:
+        f.write(('mclgrid %d %d %r %r %r\n' % (z.shape[0], z.shape[1], float(origin[0]), float(origin[1]), float(res))).encode())
+        f.write(z.tobytes())
 
 
 def matrix_from_tf(translation, rotation):
