@@ -122,6 +122,9 @@ __device__ __forceinline__ double max_from_slots(const u64* slots) {
 __device__ __forceinline__ double wrap_pi(double a) {
   const double b = 2.0 * MCL_PI;
   double s = a + MCL_PI;
+  // fmod(s, b) == s exactly for 0 <= s < b -- a yaw that has not just crossed +-pi: skip ocml's iterative fp64 fmod
+  // (the branch is taken by whole waves almost always; the result is bit for bit the same either way)
+  if (s >= 0.0 && s < b) return s - MCL_PI;
   double m = fmod(s, b);
   if (m != 0.0) {
     if (m < 0.0) m += b;
