@@ -124,9 +124,17 @@ struct mcl_handle {
   std::vector<float> ranges_host;   // last uploaded ranges (the sweep's beam table is built from them)
   bool sweep_angles_ok = false;     // ascending, finite, |a| <= 85 degrees
   int b_split = 0;
-  float4* sweep_beams = nullptr;
+  float4* sweep_beams = nullptr;   // the table of the CURRENT update: one of sweep_buf[2]
   float* sweep_tail = nullptr;
   int sweep_cap = 0;
+  // the table travels on its own stream into alternating device buffers, so the 12 KiB copy of ping k + 1 overlaps
+  // the kernels of ping k instead of standing between two steps (4 us of copy + its launch gaps)
+  float4* sweep_buf[2] = {nullptr, nullptr};
+  float* sweep_stage[2] = {nullptr, nullptr};   // pinned staging, one per buffer
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
+  bool stage_used[2] = {false, false};
+  int sweep_sel = 0;
+  hipStream_t copy_stream = nullptr;
   u32* defer_idx = nullptr;
   u32* defer_idx2 = nullptr;        // what the bounds-checked second pass hands on
   int env_sweep = -1;               // MCL_SWEEP=0/1 forces the decision (tests, A/B)
@@ -1315,13 +1323,32 @@ int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, i
 int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max) {
   // one device block, one copy per update: B records | B tail sums | B measured ranges (for the traversal kernels
   // that take the hand-overs)
+  const size_t blk_floats = (size_t)B * 6 + 4;   // B records | B tail sums | B measured ranges | first / second tangent of either side
   if (B > h->sweep_cap) {
-    if (h->sweep_beams) (void)hipFree(h->sweep_beams);
-    HIPCHK(h, hipMalloc(&h->sweep_beams, (sizeof(float4) + 2 * sizeof(float)) * (size_t)B + 4 * sizeof(float)));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->copy_stream) HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    for (int k = 0; k < 2; ++k) {
+      if (h->sweep_buf[k]) (void)hipFree(h->sweep_buf[k]);
+      if (h->sweep_stage[k]) (void)hipHostFree(h->sweep_stage[k]);
+      h->sweep_buf[k] = nullptr;
+      h->sweep_stage[k] = nullptr;
+      HIPCHK(h, hipMalloc(&h->sweep_buf[k], sizeof(float) * blk_floats));
+      HIPCHK(h, hipHostMalloc(&h->sweep_stage[k], sizeof(float) * blk_floats, hipHostMallocDefault));
+      if (!h->ev_stage[k]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_stage[k], hipEventDisableTiming));
+      h->stage_used[k] = false;
+    }
+    if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     h->sweep_cap = B;
   }
+  const int sel = (h->sweep_sel ^= 1);
+  h->sweep_beams = h->sweep_buf[sel];
   h->sweep_tail = (float*)(h->sweep_beams + B);
-  std::vector<float> blk((size_t)B * 6 + 4);   // B records | B tail sums | B measured ranges | first / second tangent of either side
+  if (h->stage_used[sel]) HIPCHK(h, hipEventSynchronize(h->ev_stage[sel]));   // (two updates old: long complete)
+  struct Blk {   // (the table is built straight into the pinned staging buffer)
+    float* p;
+    float* data() { return p; }
+    float& operator[](size_t k) { return p[k]; }
+  } blk{h->sweep_stage[sel]};
   float4* tb = (float4*)blk.data();
   float* tail = blk.data() + (size_t)B * 4;
   float* rng = tail + B;
@@ -1357,7 +1384,13 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
     blk[(size_t)B * 6 + 2 * k] = bp < B ? (float)std::tan((double)h->beam_cache[bp]) : INFINITY;
     blk[(size_t)B * 6 + 2 * k + 1] = bm >= 0 ? (float)(-std::tan((double)h->beam_cache[bm])) : INFINITY;
   }
-  RET_IF(upload(h, h->sweep_beams, blk.data(), sizeof(float) * blk.size()));
+  // the device buffer was last read by the update two before this one: the copy waits for that update's event,
+  // the compute stream for the copy
+  if (h->ev_upd[0] && h->upd_seq >= 2) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_upd[(h->upd_seq - 2) & 3], 0));
+  HIPCHK(h, hipMemcpyAsync(h->sweep_beams, blk.data(), sizeof(float) * blk_floats, hipMemcpyHostToDevice, h->copy_stream));
+  HIPCHK(h, hipEventRecord(h->ev_stage[sel], h->copy_stream));
+  h->stage_used[sel] = true;
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_stage[sel], 0));
   h->ranges_ptr = h->sweep_tail + B;
   h->ranges_pending = false;
   return MCL_OK;
@@ -1559,7 +1592,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   if (!pose_done) {
     // (the fused predict has already reset the control block and written poses, group records and worklist)
     if (a.max_slots)
-      HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_DEFER2 + sizeof(int), h->stream));  // slots + work and hand-over counters
+      HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_BYTES, h->stream));  // slots + work and hand-over counters (one aligned fill)
     else
       HIPCHK(h, hipMemsetAsync(a.work_count, 0, 3 * sizeof(int), h->stream));
     if (lean && !sweep)
@@ -1774,6 +1807,8 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
   a.roll = roll;
   a.pitch = pitch;
   a.nz = noise_args(h, h->cfg.process_cov, 1u, h->step_predict);
+  a.zero_ptr = nullptr;
+  a.zero_words = 0;
   const double* rp = nullptr;
   if (h->cfg.rng_mode == MCL_RNG_REPLAY) {
     if (replay_normals) {
@@ -1789,9 +1824,15 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
     // noise-free: feed zeros through the native branch with sq = 0
   }
   if (pose_for && !rp && h->cfg.rng_mode == MCL_RNG_NATIVE) {
-    // reset the slots + work counter first: the kernel appends the deferred groups to the worklist
-    HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_DEFER2 + sizeof(int), h->stream));
     const bool lean = !pose_for->sweep_beams;  // the fan sweep needs no group records
+    if (lean) {
+      // reset the slots + work counter first: the kernel appends the deferred groups to the worklist
+      // (the whole block: ONE aligned fill; the kernel tickets in it are zero between launches anyway)
+      HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_BYTES, h->stream));
+    } else {
+      a.zero_ptr = (unsigned long long*)h->ctrl;   // the kernel's first workgroup zeroes it: no memset launch
+      a.zero_words = CTRL_BYTES / 8;
+    }
     if (lean)
       k_predict_pose<true><<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, *pose_for);
     else
@@ -1995,7 +2036,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_beams, h->defer_idx, h->defer_idx2, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_buf[0], h->sweep_buf[1], h->defer_idx, h->defer_idx2, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev, h->lsx, h->xsend, h->xrecv};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -2005,6 +2046,14 @@ int mcl_destroy(mcl_handle* h) {
   if (h->host_pin) (void)hipHostFree(h->host_pin);
   if (h->lsx_host) (void)hipHostFree(h->lsx_host);
   if (h->work_host) (void)hipHostFree(h->work_host);
+  if (h->copy_stream) {
+    (void)hipStreamSynchronize(h->copy_stream);
+    (void)hipStreamDestroy(h->copy_stream);
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (h->sweep_stage[k]) (void)hipHostFree(h->sweep_stage[k]);
+    if (h->ev_stage[k]) (void)hipEventDestroy(h->ev_stage[k]);
+  }
   for (auto& e : h->ev_upd)
     if (e) (void)hipEventDestroy(e);
   for (auto& sl : h->pin_ring) {

@@ -69,6 +69,10 @@ struct PredictArgs {
   double wzdt;        // w_z * dt
   double z, roll, pitch;
   NoiseArgs nz;
+  // fused step, sweep path: the predict kernel's first workgroup also zeroes the control block (max-lw slots, hand-over
+  // counters) for the update that follows -- a hipMemsetAsync of 524 B is TWO fill kernels and a launch gap, 15 us
+  unsigned long long* zero_ptr;
+  int zero_words;
 };
 __global__ void __launch_bounds__(MCL_BLOCK) k_predict(StatePtrs s, long long n, PredictArgs a,
                                                        const double* __restrict__ replay) {

@@ -298,6 +298,8 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_predict_pose(StatePtrs s, long lo
   sincos(a.roll, &sr, &cr);
   sincos(a.pitch, &sp, &cp);
   const long long n_pad = (n + 63) & ~63ll;
+  if (!CLASSIFY && a.zero_ptr && blockIdx.x == 0)   // (this kernel does not touch the block; the update after it does)
+    for (int k = threadIdx.x; k < a.zero_words; k += blockDim.x) a.zero_ptr[k] = 0ull;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_pad;
        i += (long long)gridDim.x * blockDim.x) {
     const bool valid = i < n;
