@@ -1384,9 +1384,10 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
     blk[(size_t)B * 6 + 2 * k] = bp < B ? (float)std::tan((double)h->beam_cache[bp]) : INFINITY;
     blk[(size_t)B * 6 + 2 * k + 1] = bm >= 0 ? (float)(-std::tan((double)h->beam_cache[bm])) : INFINITY;
   }
-  // the device buffer was last read by the update two before this one: the copy waits for that update's event,
-  // the compute stream for the copy
-  if (h->ev_upd[0] && h->upd_seq >= 2) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_upd[(h->upd_seq - 2) & 3], 0));
+  // the device buffer was last read by the update two before this one; the copy waits for the event of the update
+  // just before (later on the same stream, so certainly enough -- whatever an error path did to the alternation): it
+  // then runs under that step's normalise / scan / gather kernels.  The compute stream waits for the copy.
+  if (h->ev_upd[0] && h->upd_seq >= 1) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_upd[(h->upd_seq - 1) & 3], 0));
   HIPCHK(h, hipMemcpyAsync(h->sweep_beams, blk.data(), sizeof(float) * blk_floats, hipMemcpyHostToDevice, h->copy_stream));
   HIPCHK(h, hipEventRecord(h->ev_stage[sel], h->copy_stream));
   h->stage_used[sel] = true;

@@ -323,6 +323,48 @@ def test_sharded_equals_unsharded_bitwise(shards, exchange, eng, monkeypatch):
     np.testing.assert_allclose(m1[2], m2[2], rtol=1e-11, atol=1e-13)
 
 
+@pytest.mark.parametrize('where', ['one_shard', 'last_particle', 'every_other_shard'])
+def test_sharded_exchange_when_the_weight_sits_in_few_places(where, eng, monkeypatch):
+    """The O(n) exchange's extremes: all the weight in one shard (it ships copies to every other shard, far more than
+    the send buffer's initial capacity: the grow-and-pack-again path), in ONE particle (every slot but one is lost,
+    one ancestor owns every surplus copy), or in alternate shards (shards with no lost slot at all next to shards
+    with no survivor).  Bit for bit the unsharded filter, twice in a row (the buffers are reused)."""
+    monkeypatch.delenv('MCL_EXCHANGE', raising=False)
+    shards, n = 4, 4 * 8192
+    nl = n // shards
+    cov = dict(resample_cov=[0.01, 0.01, 0.0025, 1e-4, 1e-4, 1e-4], seed=31)
+    rs = np.random.RandomState(5)
+    soa = rs.randn(6, n)
+    one = eng.Engine(n, **cov)
+    many = [eng.Engine(nl, rank=r, world=shards, n_global=n, global_offset=r * nl, **cov) for r in range(shards)]
+    for rep in range(2):
+        lw = np.full(n, -800.0)
+        if where == 'one_shard':
+            lw[2 * nl:2 * nl + 100] = -0.5 * rs.randn(100) ** 2
+        elif where == 'last_particle':
+            lw[n - 1] = 0.0
+        else:
+            lw[0:nl] = -0.5 * rs.randn(nl) ** 2
+            lw[2 * nl:3 * nl] = -0.5 * rs.randn(nl) ** 2
+        one.set_particles(soa)
+        one.set_log_weights(lw, eng.WEIGHT_LOG_SHIFT)
+        one.resample()
+        for r, e in enumerate(many):
+            sl = slice(r * nl, (r + 1) * nl)
+            e.set_particles(np.ascontiguousarray(soa[:, sl]))
+            e.set_log_weights(lw[sl], eng.WEIGHT_LOG_SHIFT)
+        eng.group_resample(many)
+        assert np.array_equal(one.last_indices(), np.concatenate([e.last_indices() for e in many])), (where, rep)
+        got = np.concatenate([e.get_particles() for e in many], axis=1)
+        assert np.array_equal(one.get_particles(), got), (where, rep)
+        soa = got + 0.0
+    sent = [e.exchange_stats()[0] for e in many]
+    if where == 'one_shard':
+        assert sent[2] > 2 * 3 * nl * 0.9 and sent[0] == sent[1] == sent[3] == 0   # shard 2 fed all the others, twice
+    if where == 'last_particle':
+        assert sent[3] == 2 * 3 * nl and sum(sent[:3]) == 0
+
+
 def test_rccl_paths_with_one_rank_match_plain_filter(eng, monkeypatch):
     """MCL_FORCE_COMM=1 builds a 1-rank RCCL communicator: all-reduce / all-gather calls, the second
     communicator and the overlapped state all-gather of mcl_step_mbes run for real, and must not
