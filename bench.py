@@ -491,8 +491,8 @@ def worker(a, rank, world, local_rank):
         sys.exit(2)
     m = build_map(a.map)
     nblocks = max(1, int(math.ceil(MIN_TIMED_STEPS / float(a.steps))))
-    nblocks = min(nblocks, max(1, (4000 - a.warmup) // a.steps))  # mcl_mean_history keeps 4096 results
-    total_steps = a.warmup + a.steps * nblocks
+    nblocks = min(nblocks, max(1, (4000 - a.warmup) // a.steps - 1))  # mcl_mean_history keeps 4096 results
+    total_steps = a.warmup + a.steps * (nblocks + 1)   # (+ one block at the end that carries the per-phase events)
     stream = synth.odom_stream(total_steps)
     ba = synth.beam_angles(B)
 
@@ -528,13 +528,10 @@ def worker(a, rank, world, local_rank):
     run(0, a.warmup)
     barrier()
     # ---- the contract's timed region: EXACTLY --steps steps between two barrier + synchronize pairs
-    e.timing_enable(True)
     t0 = time.perf_counter()
     run(a.warmup, a.warmup + a.steps)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
-    tim = e.timing_get()
-    e.timing_enable(False)
     # ---- the same block repeated until >= MIN_TIMED_STEPS steps are timed: median and p95 per block
     block_ms = [1e3 * dt / a.steps]
     for b in range(1, nblocks):
@@ -543,8 +540,18 @@ def worker(a, rank, world, local_rank):
         run(k0, k0 + a.steps)
         barrier()
         block_ms.append(1e3 * max_over_ranks(time.perf_counter() - t0) / a.steps)
+    # ---- per-phase HIP events on ONE more block, after the timed ones (the events cost the stream a few microseconds per
+    # region, so they stay out of every timed block; at the end of the run the filter is in its steady state, like
+    # the median block and like the rocprofv3 average the roofline is checked against -- the first steps after the
+    # warm-up still work on a wider cloud and a sweep launch takes 15 % longer there)
+    e.timing_enable(True)
+    k0 = a.warmup + nblocks * a.steps
+    run(k0, k0 + a.steps)
+    barrier()
+    tim = e.timing_get()
+    e.timing_enable(False)
     # pose RMSE of the filter's mean (x, y) against the synthetic ground truth over every timed step
-    n_timed = a.steps * nblocks
+    n_timed = a.steps * (nblocks + 1)
     hist = e.mean_history(n_timed)
     truth = stream['truth'][a.warmup:total_steps]
     pose_rmse = float(np.sqrt(np.mean((hist[:, 0] - truth[:, 0]) ** 2 + (hist[:, 1] - truth[:, 1]) ** 2)))
@@ -553,6 +560,7 @@ def worker(a, rank, world, local_rank):
     if rank == 0:
         first_block_ms = 1e3 * dt / a.steps
         ms_per_step = pctl(block_ms, 50)   # the median block (the first block still holds the clock ramp)
+        n_timed = a.steps * nblocks
         total_particles = P * world
         path_main = mbes_path(e, P)
         value = 1e3 / ms_per_step * (total_particles / 1048576.0)
@@ -562,7 +570,10 @@ def worker(a, rank, world, local_rank):
         # the dominant LAUNCH: HIP events around that one kernel (MCL_K_MBES_MAIN), not the update's whole region
         if dom == 'update_mbes' and tim.get('mbes_main', (0, 0))[1]:
             dom_ms = tim['mbes_main'][0] / tim['mbes_main'][1]
-            dom_time_source = 'HIP events around the one launch (%s), mean of %d launches' % (path_main['dominant_launch'], tim['mbes_main'][1])
+            dom_time_source = ('HIP events (no system fence) around the one launch (%s), mean of the %d launches of the block after '
+                               'the timed ones: the filter in its steady state.  rocprof_launch_us is the mean over ALL '
+                               'dispatches of a profiled run, whose first steps after the init work on a wider cloud '
+                               '(kernel stats: min / avg / max)' % (path_main['dominant_launch'], tim['mbes_main'][1]))
         else:
             dom_ms = tim[dom][0] / a.steps
             dom_time_source = 'HIP-event region of the phase'
@@ -609,7 +620,8 @@ def worker(a, rank, world, local_rank):
                       'ms_per_step_min': round(min(block_ms), 4), 'ms_per_step_max': round(max(block_ms), 4),
                       'note': 'the timed block (exactly --steps steps between barrier+synchronize pairs, max over ranks) '
                               'is repeated until >= %d steps are timed; value / ms_per_step are the MEDIAN block, '
-                              'first_block_ms the first one' % MIN_TIMED_STEPS},
+                              'first_block_ms the first one; the per-phase HIP events (kernels, roofline.launch_us) are '
+                              'recorded on one further block after them' % MIN_TIMED_STEPS},
             'config': {'workload': '%d particles/GPU x %d beams, %s, predict+MBES update+normalise+systematic '
                                    'resample+mean/cov per step' % (P, B, m['desc']),
                        'particles_per_gpu': P, 'beams': B, 'map': m['kind'], 'parallelism': 'particle-shard x%d' % world},

@@ -261,8 +261,11 @@ void t_begin(mcl_handle* h, int k) {
     ev = h->ev_pool.back();
     h->ev_pool.pop_back();
   } else {
-    (void)hipEventCreate(&ev.first);
-    (void)hipEventCreate(&ev.second);
+    // timing-only events: no system-scope fence when they are recorded (a default event releases / acquires at system
+    // scope -- a cache write-back and invalidate around every timed region, which made the regions ~20 % longer than
+    // the kernels inside them are under rocprofv3)
+    if (hipEventCreateWithFlags(&ev.first, hipEventDisableSystemFence) != hipSuccess) (void)hipEventCreate(&ev.first);
+    if (hipEventCreateWithFlags(&ev.second, hipEventDisableSystemFence) != hipSuccess) (void)hipEventCreate(&ev.second);
   }
   (void)hipEventRecord(ev.first, h->stream);
   h->regions.push_back(TimedRegion{ev.first, ev.second, k, true});
@@ -1318,12 +1321,33 @@ int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, i
   return MCL_OK;
 }
 
+// Lanes per particle side of the fan sweep: a small cloud splits a side's beams over 2 or 4 lanes (mcl_sweep.h SUB:
+// each resolves its own run of >= 16 beams, starting at the hit of the run's first beam); the GLOBAL particle count
+// decides, so every shard sums in the same order.
+// (measured, round 3, the dominant launch in ms -- traversal | sweep with 1 / 2 / 4 lanes per side:
+//    grid  32 768 x 256: 0.093 | 0.103 0.068 0.055     mesh  32 768 x 256: 0.093 | 0.036 0.033 0.028
+//    grid  65 536 x 256: 0.100 | 0.108 0.086 0.087     mesh  65 536 x 256: 0.098 | 0.038 0.039 0.037
+//    grid 131 072 x 512: 0.273 | 0.216 0.208 0.205     mesh 131 072 x 512: 0.263 | 0.066 0.074 0.078
+//  a later run pays one slanted traversal for its start; worth it while the chip is not full)
+int sweep_lanes_per_side(const mcl_handle* h, bool with_ranges, int B) {
+  int nsub = 1;
+  if (with_ranges) {
+    if (h->map_kind == 0)
+      nsub = h->ng < 49152 ? 4 : (h->ng < 196608 ? 2 : 1);
+    else if (h->mesh && h->mesh->heights && !h->force_general_mesh)
+      nsub = h->ng < 49152 ? 4 : 1;
+    if (h->env_nsub) nsub = h->env_nsub;
+    while (nsub > 1 && B / (2 * nsub) < 16) nsub >>= 1;
+  }
+  return nsub;
+}
+
 // beam table of the fan sweep: side-signed tangent, secant, measured range, weight; and per beam the sum of the
 // squared normalised residuals against r_max over the beams from it to the end of its side (mcl_sweep.h)
-int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max) {
+int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max, int nsub) {
   // one device block, one copy per update: B records | B tail sums | B measured ranges (for the traversal kernels
   // that take the hand-overs)
-  const size_t blk_floats = (size_t)B * 6 + 4;   // B records | B tail sums | B measured ranges | first / second tangent of either side
+  const size_t blk_floats = (size_t)B * 7 + 4;   // B records | B tail sums | B measured ranges | first / second tangent of either side | B tail sums per run
   if (B > h->sweep_cap) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->copy_stream) HIPCHK(h, hipStreamSynchronize(h->copy_stream));
@@ -1378,6 +1402,21 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
   for (int b = B - 1; b >= h->b_split; --b) tail[b] = (run += miss(b));
   run = 0.f;
   for (int b = 0; b < h->b_split; ++b) tail[b] = (run += miss(b));
+  // the same sums per RUN of a side's beams (sub-fans: a lane accounts for its own run only; taking them as
+  // differences of the side's sums lost digits when r_max is short and the sums are large)
+  float* tail_run = blk.data() + (size_t)B * 6 + 4;
+  for (int side = 0; side < 2; ++side) {
+    const int nb = side ? h->b_split : B - h->b_split;
+    const int per = nsub > 1 ? std::max((nb + nsub - 1) / nsub, 2) : std::max(nb, 1);
+    for (int first = 0; first < nb; first += per) {
+      const int last = std::min(first + per, nb);
+      float acc = 0.f;
+      for (int k = last - 1; k >= first; --k) {   // k-th beam of the side, counted outward from the nadir
+        const int b = side ? h->b_split - 1 - k : h->b_split + k;
+        tail_run[b] = (acc += miss(b));
+      }
+    }
+  }
   h->sweep_nvalid = nvalid;
   for (int k = 0; k < 2; ++k) {
     const int bp = h->b_split + k, bm = h->b_split - 1 - k;
@@ -1468,6 +1507,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.sweep_nvalid = 0;
   a.sweep_nsub = 1;
   a.sweep_tan0 = nullptr;
+  a.sweep_tail_run = nullptr;
   a.sweep_c2z_min = 2.f;
   a.sweep_slope = 0.f;
   a.defer_idx = nullptr;
@@ -1540,7 +1580,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
                  h->n < (1ll << 31) && (long long)a.nx * a.ny < (1ll << 30) && a.ny < (1 << 21);
     h->sweep_now = sweep;
     if (sweep) {
-      RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max));
+      RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max, sweep_lanes_per_side(h, with_ranges, B)));
     } else if (with_ranges && h->ranges_pending) {
       RET_IF(upload(h, h->ranges_dev, h->ranges_host.data(), sizeof(float) * (size_t)B));
       h->ranges_ptr = h->ranges_dev;
@@ -1557,6 +1597,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.b_split = h->b_split;
     a.sweep_nvalid = h->sweep_nvalid;
     a.sweep_tan0 = h->sweep_tail + 2 * (size_t)B;
+    a.sweep_tail_run = h->sweep_tail + 2 * (size_t)B + 4;
     // (grids: 0.45 -- below 0.5 the plane function cannot change sign around a cell's four corners, mcl_sweep.h)
     const double slope_max = h->map_kind == 0 ? h->gslope_max : h->mesh->slope_max;
     const double tan_lim = std::min(std::tan(35.0 * MCL_PI / 180.0), (h->map_kind == 0 ? 0.45 : 0.8) / std::max(slope_max, 1e-9));
@@ -1612,22 +1653,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       RET_IF(sort_visiting_order(h, a));
       a.perm = h->mbes_perm;
     }
-    // Lanes per particle side: a small cloud may split a side's beams over 2 or 4 lanes (each walks out from the nadir
-    // and resolves its own run of >= 16 beams); the GLOBAL particle count decides, so every shard sums in the same order.
-    // (measured, round 3, the dominant launch in ms -- traversal | sweep with 1 / 2 / 4 lanes per side:
-    //    grid  32 768 x 256: 0.093 | 0.103 0.068 0.055     mesh  32 768 x 256: 0.093 | 0.036 0.033 0.028
-    //    grid  65 536 x 256: 0.100 | 0.108 0.086 0.087     mesh  65 536 x 256: 0.098 | 0.038 0.039 0.037
-    //    grid 131 072 x 512: 0.273 | 0.216 0.208 0.205     mesh 131 072 x 512: 0.263 | 0.066 0.074 0.078
-    //  a later run pays one slanted traversal for its start; worth it while the chip is not full)
-    int nsub = 1;
-    if (with_ranges) {
-      if (h->map_kind == 0)
-        nsub = h->ng < 49152 ? 4 : (h->ng < 196608 ? 2 : 1);
-      else if (h->mesh->heights && !h->force_general_mesh)
-        nsub = h->ng < 49152 ? 4 : 1;
-      if (h->env_nsub) nsub = h->env_nsub;
-      while (nsub > 1 && B / (2 * nsub) < 16) nsub >>= 1;
-    }
+    const int nsub = sweep_lanes_per_side(h, with_ranges, B);
     a.sweep_nsub = nsub;
     const int sthreads = nsub == 4 ? 512 : SWEEP_THREADS;
     const int per_block = sthreads / 64 / (2 * nsub) * 64;

@@ -98,11 +98,10 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   const float sg = side ? -1.f : 1.f;
   // beams of this side (of this lane's run of them), outward from the nadir
   const int nb_side = side ? a.b_split : B - a.b_split;
-  const int per = SUB ? (nb_side + nsub - 1) / nsub : nb_side;
+  const int per = SUB ? max((nb_side + nsub - 1) / nsub, 2) : nb_side;   // (>= 2: a later run finds its first two tangents in the records of the two beams before it)
   const int first = SUB ? min(sub * per, nb_side) : 0, last = SUB ? min(first + per, nb_side) : nb_side;
   int ptr = side ? a.b_split - 1 - first : a.b_split + first;
   const int pstep = side ? -1 : 1, pend = side ? a.b_split - 1 - last : a.b_split + last;
-  const int side_end = side ? -1 : B;
   const bool none = ptr == pend;
   // ---- how far out can the walk go?  The outermost beam of the side is below every node once it reaches z_min
   float s_stop = none ? 0.f : a.r_max;  // (a side without beams only takes part in the nadir cast)
@@ -455,7 +454,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     if (EXPECT_ONLY) {
       for (; ptr != pend; ptr += pstep) exp_row[ptr] = a.r_max;
     } else {
-      acc += stail[ptr] - ((SUB && pend != side_end) ? stail[pend] : 0.f);   // (tail sums run to the end of the side)
+      acc += stail[ptr];   // (SUB: the staged tail sums end with this lane's run)
     }
   }
   acc_out = acc;
@@ -533,11 +532,10 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   const float res = a.res, inv_res = (float)a.inv_res, oz = P.oz;
   const float sg = side ? -1.f : 1.f;
   const int nb_side = side ? a.b_split : B - a.b_split;
-  const int per = SUB ? (nb_side + nsub - 1) / nsub : nb_side;
+  const int per = SUB ? max((nb_side + nsub - 1) / nsub, 2) : nb_side;   // (>= 2: a later run finds its first two tangents in the records of the two beams before it)
   const int first = SUB ? min(sub * per, nb_side) : 0, last = SUB ? min(first + per, nb_side) : nb_side;
   int ptr = side ? a.b_split - 1 - first : a.b_split + first;
   const int pstep = side ? -1 : 1, pend = side ? a.b_split - 1 - last : a.b_split + last;
-  const int side_end = side ? -1 : B;
   const bool none = ptr == pend;
   float s_stop = none ? 0.f : a.r_max;
   if (!none) {
@@ -698,7 +696,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     if (EXPECT_ONLY) {
       for (; ptr != pend; ptr += pstep) exp_row[ptr] = a.r_max;
     } else {
-      acc += stail[ptr] - ((SUB && pend != side_end) ? stail[pend] : 0.f);
+      acc += stail[ptr];
     }
   }
   acc_out = acc;
@@ -783,7 +781,7 @@ __global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, (S
   if (CHECKED && n == 0) return;
   for (int b = threadIdx.x; b < a.n_beams; b += blockDim.x) {
     sbeam[b] = a.sweep_beams[b];
-    stail[b] = a.sweep_tail[b];
+    stail[b] = SUB ? a.sweep_tail_run[b] : a.sweep_tail[b];   // (SUB: tail sums that end with the lane's own run)
   }
   if (threadIdx.x < 4) stail[a.n_beams + threadIdx.x] = a.sweep_tan0[threadIdx.x];   // (first / second tangent of either side)
   if (threadIdx.x == 0) sbeam[-1] = sbeam[a.n_beams] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);  // "never reached"

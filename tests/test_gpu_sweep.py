@@ -567,6 +567,8 @@ def test_sub_fans_split_a_sides_beams_over_several_lanes(kind, nsub, eng, orc, m
     n, B = 1500, 257
     soa = _cloud(n, 9, (4.0, 4.0, 0.4, 0.04, 0.04, 3.0), (3.0, -4.0, -2.0))
     ba = (synth.beam_angles(B, 1.1) + 0.15).astype(np.float32)     # off-centre swath
+    if kind == 'mesh2':
+        ba = (synth.beam_angles(B, 0.6) + 0.59).astype(np.float32)  # ... so far that ONE side holds only a few beams
     off = [0.2, -0.1, -0.1, 0.01, -0.02, 0.03]
     if kind == 'grid':
         omap = orc.Grid(z, origin, 1.0)
@@ -597,8 +599,10 @@ def test_sub_fans_split_a_sides_beams_over_several_lanes(kind, nsub, eng, orc, m
         d = np.abs(out[nsub] - lw_ref)
         okm = (d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref))
         assert (~okm).sum() <= n // 200, (kind, nsub, r_max, d.max())
-        rel = np.abs(out[nsub] - out[1]) / np.maximum(1.0, np.abs(out[1]))
-        assert rel.max() <= 1e-5, (kind, nsub, r_max, rel.max())   # the same residuals, summed in another order
+        # the same residuals, summed in another order (fp32 partial sums of up to ~10^6, then lw = a difference of two
+        # large terms): a few 1e-5 absolute on small |lw|, 1e-5 relative on large
+        dk = np.abs(out[nsub] - out[1])
+        assert np.all(dk <= 2e-4 + 1e-5 * np.abs(out[1])), (kind, nsub, r_max, dk.max())
 
 
 @pytest.mark.parametrize('seed', range(30))

@@ -6,6 +6,11 @@
 set -e
 cd "$(dirname "$0")/.."
 S=gpurun_out/prof_r03
+# gpurun MERGES into gpurun_out/: keep only the newest run's file(s) in every pass directory before summarising
+for d in $S/stats_* $S/pmc_*; do
+  newest=$(ls -t $d/runc/ | head -1 | sed 's/_.*//')
+  for f in $d/runc/*; do case $(basename $f) in ${newest}_*) ;; *) rm -f $f ;; esac; done
+done
 python3 tools/pmc_summarise.py $S $S/traffic.json > /dev/null
 for m in mesh grid; do
   cp $(ls -t $S/stats_$m/*/*_kernel_stats.csv | head -1) profiles/r03_${m}_1M_x512_kernel_stats.csv
