@@ -587,7 +587,8 @@ def worker(a, rank, world, local_rank):
                  'n_eff': round(n_eff, 1), 'n_eff_frac': round(n_eff / P, 6),
                  'note': 'posterior spread after the last timed step and the effective sample size of its weights (this '
                          'shard): 512 beams at sigma = %.1f m per ping collapse the cloud to the resampling noise within '
-                         'the warm-up -- extra.filter_tempered runs the same step on a filter that keeps a healthy spread' % SIGMA}
+                         'the warm-up -- extra.filter_tempered runs the same step on a filter that keeps a healthy spread (its dominant '
+                         'launch takes ~20 %% longer: compare extra.filter_tempered.kernels.mbes_main with roofline.launch_us)' % SIGMA}
         # PMC-measured HBM traffic of the dominant kernel: collected offline (counters cannot be read inside
         # this run) by tools/pmc_summarise.py into profiles/r02_traffic.json, attached ONLY when that file was
         # taken at the kernel sources this library was built from and at this workload
