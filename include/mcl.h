@@ -279,6 +279,13 @@ int mcl_group_step_mbes(mcl_handle** shards, int32_t n_shards, const mcl_odom* o
  * mcl_get_last_offspring_cdf all-gather it on demand -- under RCCL that is a COLLECTIVE call (every rank makes it).
  * mcl_exchange_stats: particle states this shard sent to peers and lost slots it filled, summed since the last reset. */
 int mcl_exchange_stats(mcl_handle* h, int64_t* states_sent, int64_t* lost_slots, int32_t reset);
+/* The transfer plan of that exchange as pure host arithmetic (no device, no handle): given every shard's lost-slot
+ * and surplus-copy counts, what `rank` sends to / receives from each peer r -- send_off / send_cnt: a range of rank's
+ * packed surplus list; recv_off / recv_cnt: a range of rank's lost ranks; entry [rank] is the part that stays at home.
+ * MCL_ERR_INVALID unless the counts add up (sum lost == sum surplus).  The library sizes its ncclSend / ncclRecv calls
+ * with exactly this function; tests/test_exchange_plan.py checks its properties for random worlds on CPU. */
+int mcl_exchange_plan(int32_t world, const uint32_t* lost, const uint32_t* surplus, int32_t rank, uint32_t* send_off,
+                      uint32_t* send_cnt, uint32_t* recv_off, uint32_t* recv_cnt);
 
 /* ---- instrumentation */
 int mcl_timing_enable(mcl_handle* h, int32_t on);

@@ -95,6 +95,7 @@ SYMBOLS = {
     'mcl_group_mean_cov': (C.c_int, [C.POINTER(_vp), _i32, _vp, _vp, _vp]),
     'mcl_group_step_mbes': (C.c_int, [C.POINTER(_vp), _i32, C.POINTER(Odom), _d, _vp, _vp, _i32, _d, _d, _vp]),
     'mcl_exchange_stats': (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i32]),
+    'mcl_exchange_plan': (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     'mcl_timing_enable': (C.c_int, [_vp, _i32]),
     'mcl_timing_get': (C.c_int, [_vp, C.POINTER(Timing)]),
     'mcl_mbes_last_path': (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

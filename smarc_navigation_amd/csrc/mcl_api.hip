@@ -792,11 +792,16 @@ int phase_pack(mcl_handle* h, bool already_packed) {
   return launch_pack(h);
 }
 
-// the range of global dupes positions that shard `from` holds and shard `to` needs: [lo, hi)
-void ex_range(const mcl_handle* h, int from, int to, u32& lo, u32& hi) {
-  lo = std::max(h->ex_Spre[from], h->ex_Lpre[to]);
-  hi = std::min(h->ex_Spre[from + 1], h->ex_Lpre[to + 1]);
+// the range of global dupes positions that shard `from` holds and shard `to` needs: [lo, hi).  Lpre / Spre: exclusive
+// prefix sums of the shards' lost-slot and surplus-copy counts (world + 1 entries).  Pure host arithmetic: also what
+// mcl_exchange_plan exposes, so the plan is property-tested without a GPU (tests/test_exchange_plan.py).
+void plan_range(const u32* Lpre, const u32* Spre, int from, int to, u32& lo, u32& hi) {
+  lo = std::max(Spre[from], Lpre[to]);
+  hi = std::min(Spre[from + 1], Lpre[to + 1]);
   if (hi < lo) hi = lo;
+}
+void ex_range(const mcl_handle* h, int from, int to, u32& lo, u32& hi) {
+  plan_range(h->ex_Lpre.data(), h->ex_Spre.data(), from, to, lo, hi);
 }
 
 int exchange_dupes(mcl_handle** sh, int ns) {
@@ -2723,6 +2728,32 @@ int mcl_group_step_mbes(mcl_handle** shards, int32_t ns, const mcl_odom* odom, d
   }
   RET_IF(run_resample(shards, ns, nullptr, 0, nullptr, true));
   return collect_fused_moments(shards, ns);
+}
+
+int mcl_exchange_plan(int32_t world, const uint32_t* lost, const uint32_t* surplus, int32_t rank, uint32_t* send_off,
+                      uint32_t* send_cnt, uint32_t* recv_off, uint32_t* recv_cnt) {
+  if (world < 1 || !lost || !surplus || rank < 0 || rank >= world || !send_off || !send_cnt || !recv_off || !recv_cnt)
+    return MCL_ERR_INVALID;
+  std::vector<u32> Lpre((size_t)world + 1, 0u), Spre((size_t)world + 1, 0u);
+  unsigned long long tl = 0, ts = 0;
+  for (int r = 0; r < world; ++r) {
+    tl += lost[r];
+    ts += surplus[r];
+    if (tl > 0xffffffffull || ts > 0xffffffffull) return MCL_ERR_INVALID;
+    Lpre[r + 1] = (u32)tl;
+    Spre[r + 1] = (u32)ts;
+  }
+  if (tl != ts) return MCL_ERR_INVALID;   // every lost slot takes exactly one surplus copy
+  for (int r = 0; r < world; ++r) {
+    u32 lo, hi;
+    plan_range(Lpre.data(), Spre.data(), rank, r, lo, hi);   // what `rank` holds and r needs
+    send_off[r] = lo - Spre[rank];
+    send_cnt[r] = hi - lo;
+    plan_range(Lpre.data(), Spre.data(), r, rank, lo, hi);   // what r holds and `rank` needs
+    recv_off[r] = lo - Lpre[rank];
+    recv_cnt[r] = hi - lo;
+  }
+  return MCL_OK;
 }
 
 int mcl_exchange_stats(mcl_handle* h, int64_t* states_sent, int64_t* lost_slots, int32_t reset) {

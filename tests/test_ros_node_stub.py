@@ -274,3 +274,42 @@ def test_ros_node_on_the_gpu_publishes_what_the_mirror_publishes(ros, tmp_path):
     a.init_particles()
     pts = msgs.pointcloud2_xyz(pc)
     assert pts.shape == (B, 3)
+
+
+def test_pointcloud2_parser_reads_the_declared_byte_layout():
+    """FLOAT32 / FLOAT64 fields at arbitrary offsets, big-endian data, organised clouds with padded rows, extra
+    fields (intensity) in between, NaN points dropped; a cloud without x / y / z is an error."""
+    from smarc_navigation_amd import msgs
+    rs = np.random.RandomState(4)
+    xyz = rs.randn(12, 3) * 10.0
+    xyz[5, 2] = np.nan
+    good = np.delete(xyz, 5, axis=0)
+    # (a) float32, intensity between y and z, 20-byte points, big-endian
+    m = msgs.PointCloud2()
+    m.fields = [msgs.PointField('x', 0, 7), msgs.PointField('y', 4, 7), msgs.PointField('intensity', 8, 7), msgs.PointField('z', 12, 7)]
+    m.point_step, m.width, m.height, m.is_bigendian = 20, 12, 1, True
+    buf = np.zeros((12, 20), np.uint8)
+    for k, off in ((0, 0), (1, 4), (2, 12)):
+        buf[:, off:off + 4] = xyz[:, k].astype('>f4').view(np.uint8).reshape(-1, 4)
+    m.data, m.row_step = buf.tobytes(), 240
+    np.testing.assert_allclose(msgs.pointcloud2_xyz(m), good.astype(np.float32), rtol=1e-7)
+    # (b) float64, organised 3 x 4 with 8 bytes of padding per row
+    m = msgs.PointCloud2()
+    m.fields = [msgs.PointField('z', 16, 8), msgs.PointField('x', 0, 8), msgs.PointField('y', 8, 8)]
+    m.point_step, m.width, m.height = 24, 4, 3
+    m.row_step = 4 * 24 + 8
+    rows = []
+    for r in range(3):
+        row = np.zeros(m.row_step, np.uint8)
+        pts = xyz[4 * r:4 * r + 4]
+        packed = np.zeros((4, 24), np.uint8)
+        for k, off in ((0, 0), (1, 8), (2, 16)):
+            packed[:, off:off + 8] = pts[:, k].astype('<f8').view(np.uint8).reshape(-1, 8)
+        row[:96] = packed.reshape(-1)
+        rows.append(row)
+    m.data = np.concatenate(rows).tobytes()
+    np.testing.assert_array_equal(msgs.pointcloud2_xyz(m), good)
+    # (c) no z field
+    m.fields = [msgs.PointField('x', 0, 8), msgs.PointField('y', 8, 8)]
+    with pytest.raises(ValueError):
+        msgs.pointcloud2_xyz(m)
