@@ -174,6 +174,9 @@ struct mcl_handle {
   bool uni_valid = false;       // true from a predict until the state is written by anything else
   double uni_val[3] = {0, 0, 0};
   unsigned gather_uni_mask = 0; // components the last state exchange skipped (phase_gather substitutes uni_val)
+  bool fault_step = false;      // MCL_FAULT_INJECT=step_after_predict (tests): the fused step fails after its predict
+  bool uni_deferred = false;    // fused step in flight: the predict kernel did NOT store z, roll, pitch (the gather of
+                                // the same call substitutes them; materialise_uniform() on any other way out)
   // O(n)-per-rank resample exchange: hand-over records {L | S << 32, x0, y0, z0} of every shard,
   // surplus copies packed for the peers, copies received for this shard's lost slots
   bool exch_allgather = false;   // MCL_EXCHANGE=allgather: the all-gather exchange of rounds 1-2 instead
@@ -556,7 +559,7 @@ int exchange_cdf_state(mcl_handle** sh, int ns) {
   for (int s = 0; s < ns; ++s) HIPCHK(sh[s], hipStreamSynchronize(sh[s]->stream));
   for (int d = 0; d < ns; ++d) {
     mcl_handle* D = sh[d];
-    D->gather_uni_mask = 0u;  // (LOCAL groups copy everything)
+    D->gather_uni_mask = D->uni_valid ? 0x1cu : 0u;  // z, roll, pitch: the same on every particle of every shard
     RET_IF(set_device(D));
     for (int s = 0; s < ns; ++s) {
       mcl_handle* S = sh[s];
@@ -564,8 +567,9 @@ int exchange_cdf_state(mcl_handle** sh, int ns) {
         HIPCHK(D, hipMemcpyAsync(D->ncum + S->goff, S->ncum + S->goff, sizeof(u32) * (size_t)S->n,
                                  hipMemcpyDefault, D->stream));
       for (int c = 0; c < 6; ++c)
-        HIPCHK(D, hipMemcpyAsync(D->state_glob + (size_t)c * D->ng + S->goff, S->state[S->cur] + (size_t)c * S->n,
-                                 sizeof(double) * (size_t)S->n, hipMemcpyDefault, D->stream));
+        if (!((D->gather_uni_mask >> c) & 1u))
+          HIPCHK(D, hipMemcpyAsync(D->state_glob + (size_t)c * D->ng + S->goff, S->state[S->cur] + (size_t)c * S->n,
+                                   sizeof(double) * (size_t)S->n, hipMemcpyDefault, D->stream));
     }
     HIPCHK(D, hipStreamSynchronize(D->stream));
   }
@@ -897,7 +901,9 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   a.add_noise = 1;
   a.part = h->part;
   a.sums_out = h->scal + 32;
-  a.uni_mask = multi ? h->gather_uni_mask : 0u;
+  // (single shard: the gather reads straight from the pre-resample state; after a predict z, roll, pitch are the same
+  //  three numbers on every particle, so they are substituted instead of read -- bit-identical, 24 B x N less traffic)
+  a.uni_mask = multi ? h->gather_uni_mask : (h->uni_valid ? 0x1cu : 0u);
   for (int c = 0; c < 6; ++c) a.uni[c] = (c >= 2 && c <= 4) ? h->uni_val[c - 2] : 0.0;
   if (with_moments && !multi && h->host_pin_dev) {
     // single shard: the last block writes the sums straight into the pinned ring entry (no copy command);
@@ -923,6 +929,7 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   HIPCHK(h, hipGetLastError());
   h->cur ^= 1;
   h->uni_valid = false;  // (the new state carries resampling noise)
+  h->uni_deferred = false;
   h->gather_uni_mask = 0u;
   h->step_resample++;
   h->have_cdf = true;
@@ -1817,10 +1824,21 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   return MCL_OK;
 }
 
+// a fused step that leaves before its gather: store the z, roll, pitch its predict kernel did not
+int materialise_uniform(mcl_handle* h) {
+  if (!h->uni_deferred) return MCL_OK;
+  h->uni_deferred = false;
+  RET_IF(set_device(h));
+  k_fill_uniform<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, h->uni_val[0],
+                                                             h->uni_val[1], h->uni_val[2]);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+
 // pose_for: when given (fused step, NATIVE rng) the kernel also writes the MBES pose records of the new
 // state; *pose_written tells the caller whether it did (a dt <= 0 step leaves the state untouched)
 int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* replay_normals,
-               const MbesArgs* pose_for = nullptr, bool* pose_written = nullptr) {
+               const MbesArgs* pose_for = nullptr, bool* pose_written = nullptr, bool defer_uniform = false) {
   if (pose_written) *pose_written = false;
   if (!(dt > 0.0)) return MCL_OK;  // auv_pf.py:205 gate
   double rpy[3];
@@ -1841,6 +1859,7 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
   a.nz = noise_args(h, h->cfg.process_cov, 1u, h->step_predict);
   a.zero_ptr = nullptr;
   a.zero_words = 0;
+  a.skip_uniform = 0;
   const double* rp = nullptr;
   if (h->cfg.rng_mode == MCL_RNG_REPLAY) {
     if (replay_normals) {
@@ -1857,6 +1876,8 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
   }
   if (pose_for && !rp && h->cfg.rng_mode == MCL_RNG_NATIVE) {
     const bool lean = !pose_for->sweep_beams;  // the fan sweep needs no group records
+    a.skip_uniform = defer_uniform ? 1 : 0;
+    h->uni_deferred = defer_uniform;
     if (lean) {
       // reset the slots + work counter first: the kernel appends the deferred groups to the worklist
       // (the whole block: ONE aligned fill; the kernel tickets in it are zero between launches anyway)
@@ -1995,6 +2016,7 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
     if (const char* sv = getenv("MCL_SWEEP_NSUB")) h->env_nsub = (sv[0] == '2' || sv[0] == '4') ? sv[0] - '0' : 1;
     h->env_force_comm = on("MCL_FORCE_COMM");
     if (const char* ex = getenv("MCL_EXCHANGE")) h->exch_allgather = strcmp(ex, "allgather") == 0;
+    if (const char* fi = getenv("MCL_FAULT_INJECT")) h->fault_step = strcmp(fi, "step_after_predict") == 0;
     h->env_no_overlap = on("MCL_NO_OVERLAP");
   }
   if (h->ng > 0xffffffffll || h->goff + h->n > h->ng || h->rank >= h->world) {
@@ -2679,12 +2701,15 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
   MbesArgs pa;
   RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, false, &pa));
   bool pose_done = false;
-  RET_IF(do_predict(h, odom, dt, nullptr, &pa, &pose_done));
-  RET_IF(start_state_gather(h));
-  int rc_u = launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, pose_done);
+  const bool sys = h->cfg.resample_scheme == MCL_RESAMPLE_SYSTEMATIC || h->cfg.resample_scheme == MCL_RESAMPLE_NAIVE;
+  // (systematic scheme: the gather of this call substitutes z, roll, pitch -- the predict kernel does not store them)
+  RET_IF(do_predict(h, odom, dt, nullptr, &pa, &pose_done, sys));
+  int rc_u = h->fault_step ? fail(h, MCL_ERR_STATE, "step_mbes: injected fault after predict") : start_state_gather(h);
+  if (rc_u == MCL_OK) rc_u = launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, pose_done);
   if (rc_u != MCL_OK) {
     const std::string keep = h->err;
     (void)cancel_state_gather(h);
+    (void)materialise_uniform(h);
     h->err = keep;
     return rc_u;
   }
@@ -2692,8 +2717,13 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
   h->have_lw = true;
   h->residual_k = -1;
   // resample; the gather pass also accumulates the sums of update_loc_pose of the new state
-  const bool sys = h->cfg.resample_scheme == MCL_RESAMPLE_SYSTEMATIC || h->cfg.resample_scheme == MCL_RESAMPLE_NAIVE;
-  RET_IF(run_resample(&h, 1, nullptr, 0, nullptr, sys));
+  rc_u = run_resample(&h, 1, nullptr, 0, nullptr, sys);
+  if (rc_u != MCL_OK) {
+    const std::string keep = h->err;
+    (void)materialise_uniform(h);
+    h->err = keep;
+    return rc_u;
+  }
   if (sys)
     RET_IF(collect_fused_moments(&h, 1));
   else
@@ -2720,13 +2750,26 @@ int mcl_group_step_mbes(mcl_handle** shards, int32_t ns, const mcl_odom* odom, d
     MbesArgs pa;
     RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, false, &pa));
     bool pose_done = false;
-    RET_IF(do_predict(h, odom, dt, nullptr, &pa, &pose_done));
-    RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, pose_done));
+    int rc = do_predict(h, odom, dt, nullptr, &pa, &pose_done, true);
+    if (rc == MCL_OK && h->fault_step) rc = fail(h, MCL_ERR_STATE, "group_step_mbes: injected fault after predict");
+    if (rc == MCL_OK) rc = launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, pose_done);
+    if (rc != MCL_OK) {
+      const std::string keep = h->err;
+      for (int t = 0; t <= s; ++t) (void)materialise_uniform(shards[t]);
+      h->err = keep;
+      return rc;
+    }
     h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
     h->have_lw = true;
     h->residual_k = -1;
   }
-  RET_IF(run_resample(shards, ns, nullptr, 0, nullptr, true));
+  const int rc = run_resample(shards, ns, nullptr, 0, nullptr, true);
+  if (rc != MCL_OK) {
+    const std::string keep = shards[0]->err;
+    for (int t = 0; t < ns; ++t) (void)materialise_uniform(shards[t]);
+    shards[0]->err = keep;
+    return rc;
+  }
   return collect_fused_moments(shards, ns);
 }
 

@@ -73,7 +73,20 @@ struct PredictArgs {
   // counters) for the update that follows -- a hipMemsetAsync of 524 B is TWO fill kernels and a launch gap, 15 us
   unsigned long long* zero_ptr;
   int zero_words;
+  // fused step: z, roll and pitch are the odometry's on EVERY particle after motion_pred (auv_particle.py:55-57,70) and
+  // the resample gather of the same call substitutes them -- they are not stored here and not read there (48 B x N of
+  // HBM traffic per step); the host fills them in if the step fails between the two kernels
+  int skip_uniform;
 };
+// z, roll, pitch of every particle := the three constants (the deferred stores of a fused step that did not reach
+// its gather)
+__global__ void __launch_bounds__(MCL_BLOCK) k_fill_uniform(StatePtrs s, long long n, double z, double roll, double pitch) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    s.c[2][i] = z;
+    s.c[3][i] = roll;
+    s.c[4][i] = pitch;
+  }
+}
 __global__ void __launch_bounds__(MCL_BLOCK) k_predict(StatePtrs s, long long n, PredictArgs a,
                                                        const double* __restrict__ replay) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;

@@ -319,9 +319,11 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_predict_pose(StatePtrs s, long lo
       const double y = s.c[1][i] + ((sy * a.m0 + cy * a.m1) + a.nz.sq[1] * n1);
       s.c[0][i] = x;
       s.c[1][i] = y;
-      s.c[2][i] = a.z;
-      s.c[3][i] = a.roll;
-      s.c[4][i] = a.pitch;
+      if (!a.skip_uniform) {
+        s.c[2][i] = a.z;
+        s.c[3][i] = a.roll;
+        s.c[4][i] = a.pitch;
+      }
       s.c[5][i] = yaw_t;
       P = make_pose(T, x, y, a.z, sr, cr, sp, cp, sy, cy);
       m.pose[i] = P;

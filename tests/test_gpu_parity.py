@@ -539,6 +539,44 @@ def test_fused_step_equals_separate_calls_bitwise(eng):
         np.testing.assert_allclose(ma[2], c9, rtol=1e-8, atol=1e-15)
 
 
+def test_fused_step_that_fails_after_predict_leaves_a_complete_state(eng, monkeypatch):
+    """The fused step's predict kernel does not store z, roll, pitch (the gather of the same call substitutes them);
+    a step that leaves between the two must store them itself: the state then equals a plain mcl_predict's."""
+    from smarc_navigation_amd import synth
+    n, B = 20000, 64
+    origin = (-64.0, -64.0)
+    z = synth.bathymetry_grid(128, 128, 1.0, origin, seed=3)
+    ba = synth.beam_angles(B)
+    cov = dict(init_cov=[1, 1, 0, 0, 0, 0.01], process_cov=[1e-3, 1e-3, 0, 0, 0, 1e-5],
+               resample_cov=[0.01, 0.01, 0, 0, 0, 1e-4], seed=31)
+    stream = synth.odom_stream(2)
+    ranges = np.full(B, 30.0, np.float32)
+    b = eng.Engine(n, **cov)
+    monkeypatch.setenv('MCL_FAULT_INJECT', 'step_after_predict')
+    a = eng.Engine(n, **cov)
+    shards = [eng.Engine(n // 2, rank=r, world=2, n_global=n, global_offset=r * (n // 2), **cov) for r in range(2)]
+    monkeypatch.delenv('MCL_FAULT_INJECT')
+    for e in [a, b] + shards:
+        e.set_map_grid(z, origin, 1.0)
+        e.init_particles()
+    args = (stream['v'][0], stream['wz'][0], stream['q'][0], stream['z'][0], stream['dt'])
+    with pytest.raises(eng.MclError, match='injected fault'):
+        a.step_mbes(*args, ranges, ba, 0.3, 80.0)
+    with pytest.raises(eng.MclError, match='injected fault'):
+        eng.group_step_mbes(shards, *args, ranges, ba, 0.3, 80.0)
+    b.predict(*args)
+    want = b.get_particles()
+    assert np.array_equal(a.get_particles(), want)
+    assert np.array_equal(np.concatenate([e.get_particles() for e in shards], axis=1)[:, :n // 2], want[:, :n // 2])
+    assert np.all(want[2] == stream['z'][0])
+    # and the handle goes on working: the update + resample of that state
+    a.update_mbes(ranges, ba, 0.3, 80.0)
+    a.resample()
+    b.update_mbes(ranges, ba, 0.3, 80.0)
+    b.resample()
+    assert np.array_equal(a.get_particles(), b.get_particles())
+
+
 @pytest.mark.parametrize('n,heavy,where', [(65536, 150, 'first_tile'), (65536, 1, 'one'), (300000, 40, 'spread'),
                                            (2048 * 3 + 5, 2, 'tile_edges')])
 def test_expansion_of_heavy_ancestors_matches_list_semantics(eng, n, heavy, where):
