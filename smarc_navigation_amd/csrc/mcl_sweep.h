@@ -43,6 +43,9 @@
 #ifndef SWEEP_SCHED_BARRIER
 #define SWEEP_SCHED_BARRIER 1
 #endif
+#ifndef SWEEP_GRID_CELLWALK
+#define SWEEP_GRID_CELLWALK 1   // height grids: sweep_side_grid (cell by cell) instead of the triangulated walk
+#endif
 
 // v_max_f32 as the hardware does it (IEEE maxNum: a NaN operand loses).  fmaxf() adds a canonicalising v_max(x, x) in
 // front of every operand that comes out of memory -- one more instruction in a 12-instruction loop.
@@ -461,6 +464,330 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   return ok;
 }
 
+// ------------------------------------------------------------------ height GRIDS (SURF 0): the cell walk
+// The same sweep, cell by cell instead of triangle by triangle.  Along cell edges a bilinear patch is linear, so the
+// points where the fan plane crosses CELL edges are exact; inside a cell the plane function is bilinear and -- unless
+// its four corner signs alternate, which the tilt bound for grids excludes (tan(tilt) * slope < 0.45) -- its zero set
+// joins the two edges whose end points differ in sign.  State: the edge (A, B) the slice leaves the current cell
+// through (A: plane function <= 0, B: > 0; e = B - A and n = the step across that edge into the next cell, both as
+// packed lattice vectors: the handedness of (e, n) never changes along a walk).  One step: the two far corners C = A + n
+// and D = B + n of the next cell decide its exit edge -- (A, C) if C is positive, (D, B) if both are not, (C, D)
+// otherwise --, and between the entry and the exit crossing the slice is an arc of a conic inside ONE cell: a beam whose
+// angle the two crossings bracket meets the surface in that cell, at the root of the bilinear-patch quadratic of the
+// oracle (orc_ray_grid) at which the clearance turns negative (the first hit is always an entry); a beam that passes
+// just beyond the far crossing may still graze the arc -- bounded by the patch's twist -- and is then tested against the
+// same quadratic, the root accepted if its point lies in the cell.
+// (until round 3 the grid was walked along the 00-11 triangulation of the node values like a lattice mesh, passing
+//  over the crossings of the auxiliary diagonals: two steps per cell, of which the lanes of a wave took the beam-
+//  resolving one at different times -- lane utilisation 0.51, 2.8 x the instructions of the mesh walk.)
+template <bool EXPECT_ONLY, bool CHECKED = false, bool SUB = false>
+__device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPose& P, const float4* __restrict__ sbeam,
+                                                const float* __restrict__ stail, int side, int sub, int nsub,
+                                                float* __restrict__ exp_row, float& acc_out) {
+  acc_out = 0.f;
+  const int nx = a.nx, ny = a.ny, B = a.n_beams;
+  bool pre = P.um >= 1.0 && P.um < (double)(nx - 2) && P.vm >= 1.0 && P.vm < (double)(ny - 2);  // (NaN: false)
+  const float c2z = P.c2[2];
+  pre = pre & (c2z >= a.sweep_c2z_min);
+  const double fum = pre ? floor(P.um) : 1.0, fvm = pre ? floor(P.vm) : 1.0;
+  const int I0 = (int)fum, J0 = (int)fvm;
+  const float ul = (float)(P.um - fum), vl = (float)(P.vm - fvm);
+  const float res = a.res, inv_res = (float)a.inv_res, oz = P.oz;
+  const float sg = side ? -1.f : 1.f;
+  const int nb_side = side ? a.b_split : B - a.b_split;
+  const int per = SUB ? max((nb_side + nsub - 1) / nsub, 2) : nb_side;
+  const int first = SUB ? min(sub * per, nb_side) : 0, last = SUB ? min(first + per, nb_side) : nb_side;
+  int ptr = side ? a.b_split - 1 - first : a.b_split + first;
+  const int pstep = side ? -1 : 1, pend = side ? a.b_split - 1 - last : a.b_split + last;
+  const bool none = ptr == pend;
+  float s_stop = none ? 0.f : a.r_max;
+  if (!none) {
+    const float2 sc = a.beam_sc[side ? 0 : B - 1];
+    const float dz_e = sc.x * P.c1[2] - sc.y * c2z;
+    if (dz_e < -1e-4f) s_stop = fminf(s_stop, (a.zmin_map - oz) * fast_rcp(dz_e) * fabsf(sc.x));
+  }
+  s_stop += 2.f * res;
+  // (s, t) -> cells: u = ul + ax s + bx t, v = vl + ay s + by t
+  const float ax = sg * P.c1[0] * inv_res, ay = sg * P.c1[1] * inv_res, bx = -P.c2[0] * inv_res, by = -P.c2[1] * inv_res;
+  {  // footprint (see sweep_side)
+    const float rc = fast_rcp(c2z);
+    const float sl = fabsf(P.c1[2]) * (s_stop + 2.f * res);
+    const float t_hi = ((oz - a.zmin_map) + sl) * rc + res, t_lo = fminf(((oz - a.zmax_map) - sl) * rc - res, 0.f);
+    const float s_lo = -2.f * res, s_hi = s_stop + 2.f * res;
+    const float fi0 = (float)I0, fj0 = (float)J0;
+    if (!CHECKED) {
+      const float ux0 = fminf(s_lo * ax, s_hi * ax) + fminf(t_lo * bx, t_hi * bx);
+      const float ux1 = fmaxf(s_lo * ax, s_hi * ax) + fmaxf(t_lo * bx, t_hi * bx);
+      const float vy0 = fminf(s_lo * ay, s_hi * ay) + fminf(t_lo * by, t_hi * by);
+      const float vy1 = fmaxf(s_lo * ay, s_hi * ay) + fmaxf(t_lo * by, t_hi * by);
+      pre = pre & (fi0 + ux0 >= 3.f) & (fi0 + ux1 <= (float)(nx - 5)) & (fj0 + vy0 >= 3.f) & (fj0 + vy1 <= (float)(ny - 5));
+    } else {
+      const float n0 = fminf(t_lo * bx, t_hi * bx), n1 = fmaxf(t_lo * bx, t_hi * bx);
+      const float m0 = fminf(t_lo * by, t_hi * by), m1 = fmaxf(t_lo * by, t_hi * by);
+      pre = pre & (fi0 + n0 >= 3.f) & (fi0 + n1 <= (float)(nx - 5)) & (fj0 + m0 >= 3.f) & (fj0 + m1 <= (float)(ny - 5));
+    }
+    pre = pre & (s_hi * fmaxf(fabsf(ax), fabsf(ay)) + fmaxf(-t_lo, t_hi) * fmaxf(fabsf(bx), fabsf(by)) < 30000.f);
+  }
+  if (!pre) SWEEP_FAIL(1);
+  const float* __restrict__ gp = a.grid + ((size_t)I0 * ny + J0);
+  const int g0i = I0 * ny + J0;
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.grid, 0, nx * ny * 4, 0x00020000);
+  const int ny4 = ny * 4, g0b = g0i * 4;
+  // ---- start of the walk (see sweep_side): the nadir hit, or the hit of the first beam of a later run
+  float dxs = -P.c2[0], dys = -P.c2[1], dzs = -c2z, r0 = 0.f;
+  bool own_start = false;
+  if (SUB && first > 0 && !none) {
+    const float2 sc = a.beam_sc[ptr];
+    dxs = sc.x * P.c1[0] - sc.y * P.c2[0];
+    dys = sc.x * P.c1[1] - sc.y * P.c2[1];
+    dzs = sc.x * P.c1[2] - sc.y * c2z;
+    own_start = true;
+  }
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    r0 = cast_clear<0>(gp, ny, a, ul, vl, oz, dxs * inv_res, dys * inv_res, dzs, a.zmax_map, a.r_max);
+    if (!SUB || !own_start || ((r0 < a.r_max) & (r0 > 0.f))) break;
+    dxs = -P.c2[0];
+    dys = -P.c2[1];
+    dzs = -c2z;
+    own_start = false;
+  }
+  if (!(r0 < a.r_max)) SWEEP_FAIL(5);
+  if (!(r0 > 0.f)) SWEEP_FAIL(9);  // the sensor is at or below the seabed (a grid is solid underneath)
+  if (none) return true;
+  // ---- plane and in-plane coordinates as affine functions of (i, j, h): lattice coordinates relative to (I0, J0)
+  const float nx_ = P.c1[1] * P.c2[2] - P.c1[2] * P.c2[1], ny_ = P.c1[2] * P.c2[0] - P.c1[0] * P.c2[2],
+              nz_ = P.c1[0] * P.c2[1] - P.c1[1] * P.c2[0];
+  const float pu = nx_ * res, pv = ny_ * res, pz = nz_, p0 = -(pu * ul + pv * vl + pz * oz);
+  const float su = sg * P.c1[0] * res, sv = sg * P.c1[1] * res, sz = sg * P.c1[2], s0 = -(su * ul + sv * vl + sz * oz);
+  const float tu = -P.c2[0] * res, tv = -P.c2[1] * res, tz = -c2z, t0 = -(tu * ul + tv * vl + tz * oz);
+  // ---- the cell under the start hit: its two crossings, the outer one is where this side leaves it
+  int PA, e, n;                       // packed lattice: node A, the edge vector A -> B, the step into the next cell
+  float dA, sA, tA, dB, sB, tB;       // plane function and in-plane coordinates of the edge's nodes
+  float sp, tp, sc, tc;               // the arc of the current cell: entry and exit crossing
+  float hp00, hp01, hp10, hp11;       // corner heights of the current cell
+  {
+    const float uh = fmaf(r0, dxs * inv_res, ul), vh = fmaf(r0, dys * inv_res, vl);
+    const float cfi = floorf(uh), cfj = floorf(vh);
+    const int ci = (int)cfi, cj = (int)cfj;
+    const int c00 = ci * 65536 + cj;
+    const float* cp = gp + (ci * ny + cj);
+    hp00 = cp[0];
+    hp01 = cp[1];
+    hp10 = cp[ny];
+    hp11 = cp[ny + 1];
+    struct Nd { float d, s, t; };
+    const auto nd = [&](float fi, float fj, float h) {
+      Nd N;
+      N.d = fmaf(pu, fi, fmaf(pv, fj, fmaf(pz, h, p0)));
+      N.s = fmaf(su, fi, fmaf(sv, fj, fmaf(sz, h, s0)));
+      N.t = fmaf(tu, fi, fmaf(tv, fj, fmaf(tz, h, t0)));
+      return N;
+    };
+    const Nd N00 = nd(cfi, cfj, hp00), N10 = nd(cfi + 1.f, cfj, hp10), N01 = nd(cfi, cfj + 1.f, hp01),
+             N11 = nd(cfi + 1.f, cfj + 1.f, hp11);
+    // edges in the order 00-10 (outward -j), 10-11 (+i), 01-11 (+j), 00-01 (-i)
+    const float NEG = -__builtin_inff();
+    float se[4], te[4];
+    int cnt = 0;
+    const auto cross = [&](const Nd& X, const Nd& Y, int k) {
+      const bool c = (X.d > 0.f) != (Y.d > 0.f);
+      const float lam = X.d * fast_rcp(X.d - Y.d);
+      se[k] = c ? fmaf(lam, Y.s - X.s, X.s) : NEG;
+      te[k] = fmaf(lam, Y.t - X.t, X.t);
+      cnt += c ? 1 : 0;
+    };
+    cross(N00, N10, 0);
+    cross(N10, N11, 1);
+    cross(N01, N11, 2);
+    cross(N00, N01, 3);
+    if (cnt != 2) SWEEP_FAIL(6);  // the plane misses the cell (rounding at its border), touches a corner, or the signs alternate
+    int kf = 0;
+    sc = se[0];
+    tc = te[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (se[k] > sc) {
+        kf = k;
+        sc = se[k];
+        tc = te[k];
+      }
+    sp = NEG;
+    tp = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k != kf && se[k] > sp) {
+        sp = se[k];
+        tp = te[k];
+      }
+    if (!(sp < sc)) SWEEP_FAIL(7);  // (NaN, or the two crossings coincide at a node)
+    if (!(tc > 0.f)) SWEEP_FAIL(8);
+    const Nd X = (kf == 0 || kf == 3) ? N00 : (kf == 1 ? N10 : N01);
+    const Nd Y = kf == 0 ? N10 : (kf == 3 ? N01 : N11);
+    const int PX = (kf == 0 || kf == 3) ? c00 : (kf == 1 ? c00 + 65536 : c00 + 1);
+    const int PY = kf == 0 ? c00 + 65536 : (kf == 3 ? c00 + 1 : c00 + 65537);
+    const bool xpos = X.d > 0.f;
+    PA = xpos ? PY : PX;
+    e = xpos ? PX - PY : PY - PX;
+    n = kf == 0 ? -1 : (kf == 1 ? 65536 : (kf == 2 ? 1 : -65536));
+    dA = xpos ? Y.d : X.d;
+    sA = xpos ? Y.s : X.s;
+    tA = xpos ? Y.t : X.t;
+    dB = xpos ? X.d : Y.d;
+    sB = xpos ? X.s : Y.s;
+    tB = xpos ? X.t : Y.t;
+  }
+  // ---- walk outward, merging the beam table against the arcs
+  float acc = 0.f;
+  bool ok = true;
+  const int max_steps = (int)(3.f * (s_stop + 4.f * res) * inv_res) + 16;
+  int step = 0;
+  const float4* bp = sbeam + ptr;
+  const float4* const bp_end = sbeam + pend;
+  float tcur = stail[a.n_beams + side];       // tan of the pending beam (side-signed)
+  float tnext = stail[a.n_beams + 2 + side];  // ... and of the one after it
+  if (SUB && first > 0) {
+    tcur = bp[-2 * pstep].x;
+    tnext = bp[-pstep].x;
+  }
+  float4 bm = bp[0];
+  const float rc2z = fast_rcp(c2z);
+  const float axay2 = 2.f * (ax * ay), axby2 = 2.f * fmaf(ax, by, ay * bx), bxby2 = 2.f * (bx * by);
+  for (;;) {
+    // the far corners of the cell across (A, B): their heights are in flight while this cell's beams are resolved
+    // (the footprint test keeps a sane walk inside the map; a NaN-driven one is stopped by the buffer's own range check)
+    const int PC = PA + n, PD = PC + e;
+    const int cj = __builtin_amdgcn_sbfe(PC, 0, 16), ci = (PC - cj) >> 16;
+    const int dj = __builtin_amdgcn_sbfe(PD, 0, 16), di = (PD - dj) >> 16;
+    const float hC = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(ci, ny4) + ((cj << 2) + g0b), 0, 0));
+    const float hD = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(di, ny4) + ((dj << 2) + g0b), 0, 0));
+    const bool off_x = CHECKED && (unsigned)(I0 + ci) >= (unsigned)nx, off_y = CHECKED && (unsigned)(J0 + cj) >= (unsigned)ny;
+    // ---- the conic of the current cell (the one on the -n side of the edge): in the fan plane the clearance
+    // z - h(u, v) over it is G = g0 + g1 s + g2 t + g3 s^2 + g4 s t + g5 t^2 (u, v, z affine in (s, t), h bilinear), and
+    // along beam s = t tan a the quadratic g0 + (g1 T + g2) t + (g3 T^2 + g4 T + g5) t^2 -- orc_ray_grid's, with tau = t
+    const int emin = min(e, 0);
+    const int Pm = PA + emin - max(n, 0);
+    const int j0 = __builtin_amdgcn_sbfe(Pm, 0, 16), i0 = (Pm - j0) >> 16;
+    const float pB = hp10 - hp00, pC = hp01 - hp00, pD = (hp00 - hp10) - (hp01 - hp11);
+    const float uc = ul - (float)i0, vc = vl - (float)j0;
+    const float g0 = oz - fmaf(pD * uc, vc, fmaf(pC, vc, fmaf(pB, uc, hp00)));
+    const float g1 = sz - fmaf(pD, fmaf(uc, ay, vc * ax), fmaf(pC, ay, pB * ax));
+    const float g2 = tz - fmaf(pD, fmaf(uc, by, vc * bx), fmaf(pC, by, pB * bx));
+    const float g3n = pD * axay2, g4n = pD * axby2, g5n = pD * bxby2;   // -2 g3, -2 g4, -2 g5
+    const float G0 = 2.f * g0;
+    // how far (in e = s - t tan a, per unit tan a) the arc can bulge beyond its chord: along the chord the clearance is
+    // -twist * du * dv * l (1 - l) <= |twist du dv| / 4, and moving along -c2 changes the clearance at a rate of at
+    // least c2z (1 - slope tan(tilt)) >= 0.55 c2z
+    const float ds = sc - sp, dts = tc - tp;
+    const float kb = 0.46f * fabsf(pD * fmaf(ax, ds, bx * dts) * fmaf(ay, ds, by * dts)) * rc2z + 1e-6f;
+    // the corner heights of the NEXT cell
+    {
+      const int Pn = PA + emin + min(n, 0);
+      const int j1 = __builtin_amdgcn_sbfe(Pn, 0, 16), i1 = (Pn - j1) >> 16;
+      const int ob = __mul24(i1, ny4) + ((j1 << 2) + g0b);
+      hp00 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, ob, 0, 0));
+      hp01 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, ob + 4, 0, 0));
+      hp10 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, ob, ny4, 0));
+      hp11 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, ob + 4, ny4, 0));
+    }
+    // ---- the beams of this arc.  (No end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0,
+    // so e_cur = -inf.  The loop is rotated: e_cur of the NEXT beam is formed at the end of the body.)
+    float e_cur = fmaf(-tcur, tc, sc);
+    for (;;) {
+      if (SUB && bp == bp_end) break;   // (the beams beyond belong to the next lane of this side)
+      bool graze = false;
+      if (!(e_cur >= 0.f)) {  // the beam passes beyond the exit crossing ...
+        const float e_prev = fmaf(-tcur, tp, sp);
+        if (!(fmaxf(e_cur, e_prev) + tcur * kb >= 0.f)) break;  // ... by more than the arc can bulge (sentinel: NaN)
+        graze = true;
+      }
+      // the root at which the clearance turns negative, in the form that does not cancel:
+      // with w = q1 + sgn(q1) sqrt(q1^2 - 4 q2 g0):  q1 >= 0: w / (-2 q2),  q1 < 0: -2 g0 / w
+      const float q1 = fmaf(g1, tcur, g2), q2n = fmaf(fmaf(g3n, tcur, g4n), tcur, g5n);
+      const float disc = fmaf(q2n, G0, q1 * q1);
+      const float sq = fast_sqrt(fmaxf(disc, 0.f));
+      const bool qpos = q1 >= 0.f;
+      const float w = q1 + (qpos ? sq : -sq);
+      const float tau = (qpos ? w : -G0) * fast_rcp(qpos ? q2n : w);
+#if SWEEP_SCHED_BARRIER
+      __builtin_amdgcn_sched_barrier(0);   // (the record's fields are first needed below: the wait for it belongs here)
+#endif
+      if (graze) {
+        // a beam beyond the exit crossing: it meets the arc only if that root's point lies in this cell
+        const float du = fmaf(ax, tcur, bx), dv = fmaf(ay, tcur, by);  // cells per unit t along the beam
+        const float EPS = 2e-4f;
+        const bool in = (disc >= 0.f) & (tau > 0.f) & (fabsf(fmaf(du, tau, uc) - 0.5f) <= 0.5f + EPS) &
+                        (fabsf(fmaf(dv, tau, vc) - 0.5f) <= 0.5f + EPS);
+        if (!in) break;
+      }
+      // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants (mcl_api.hip:
+      // upload_sweep_beams): (range_b - r) w = max(z w - t (w / cos a), (z - r_max) w)
+      if (EXPECT_ONLY) {
+        exp_row[bp - sbeam] = fminf(tau * bm.y, a.r_max);
+      } else {
+        const float dd = hw_max(fmaf(-tau, bm.y, bm.z), bm.w);
+        acc = fmaf(dd, dd, acc);
+      }
+      tcur = tnext;
+      tnext = bm.x;
+      bp += pstep;
+      bm = bp[0];
+      e_cur = fmaf(-tcur, tc, sc);
+    }
+    if (bp == bp_end) break;
+    if (sc > s_stop) break;  // every beam left misses inside r_max (tail below)
+    if (CHECKED && (off_x | off_y)) {
+      // the slice ends at the map border: final if it cannot come back (see sweep_side)
+      const float sb = fast_sqrt(fmaxf(1.f - c2z * c2z, 0.f));
+      const float lhs = sb * (a.sweep_slope + sb), rhs = 0.9f * (c2z - a.sweep_slope * sb);
+      ok = (off_x != off_y) & (lhs < rhs * fabsf(off_x ? P.c1[0] : P.c1[1]));
+      break;  // (ok: the beams left get r_max through the tail below)
+    }
+    if (++step > max_steps) {
+      ok = false;
+      break;
+    }
+    // ---- across the edge: the exit edge of the next cell
+    const float fci = (float)ci, fcj = (float)cj, fdi = (float)di, fdj = (float)dj;
+    const float dC = fmaf(pu, fci, fmaf(pv, fcj, fmaf(pz, hC, p0)));
+    const float sC = fmaf(su, fci, fmaf(sv, fcj, fmaf(sz, hC, s0)));
+    const float tC = fmaf(tu, fci, fmaf(tv, fcj, fmaf(tz, hC, t0)));
+    const float dD = fmaf(pu, fdi, fmaf(pv, fdj, fmaf(pz, hD, p0)));
+    const float sD = fmaf(su, fdi, fmaf(sv, fdj, fmaf(sz, hD, s0)));
+    const float tD = fmaf(tu, fdi, fmaf(tv, fdj, fmaf(tz, hD, t0)));
+    const bool viaA = dC > 0.f;               // exit (A, C): A stays, C takes B's place
+    const bool viaB = !viaA & !(dD > 0.f);    // exit (D, B): D takes A's place, B stays; else (C, D)
+    PA = viaA ? PA : (viaB ? PD : PC);
+    dA = viaA ? dA : (viaB ? dD : dC);
+    sA = viaA ? sA : (viaB ? sD : sC);
+    tA = viaA ? tA : (viaB ? tD : tC);
+    dB = viaA ? dC : (viaB ? dB : dD);
+    sB = viaA ? sC : (viaB ? sB : sD);
+    tB = viaA ? tC : (viaB ? tB : tD);
+    const int e_old = e;
+    e = viaA ? n : (viaB ? -n : e);
+    n = viaA ? -e_old : (viaB ? e_old : n);
+    const float lam = dA * fast_rcp(dA - dB);
+    sp = sc;
+    tp = tc;
+    sc = fmaf(lam, sB - sA, sA);
+    tc = fmaf(lam, tB - tA, tA);
+    if (!(tc > 0.f)) {  // the seabed rises above the sensor's own horizon: not for the sweep (see the sentinel records)
+      ok = false;
+      break;
+    }
+  }
+  if (ok && bp != bp_end) {
+    ptr = (int)(bp - sbeam);
+    if (EXPECT_ONLY) {
+      for (; ptr != pend; ptr += pstep) exp_row[ptr] = a.r_max;
+    } else {
+      acc += stail[ptr];   // (SUB: the staged tail sums end with this lane's run)
+    }
+  }
+  acc_out = acc;
+  return ok;
+}
+
 // ------------------------------------------------------------------ arbitrary height-field TINs (SURF 5)
 // The same sweep without the lattice: the triangle across an edge comes from the adjacency table built by
 // mesh_build (mcl_mesh.h: two uint4 per triangle -- vertex ids, neighbour ids), nodes are vertex records (x, y, z).
@@ -734,6 +1061,8 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
     const MbesPose P = a.pose[i];
     if (SURF == 5)
       ok = sweep_side_tin<EXPECT_ONLY, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
+    else if (SURF == 0 && SWEEP_GRID_CELLWALK)
+      ok = sweep_side_grid<EXPECT_ONLY, CHECKED, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
     else
       ok = sweep_side<(SURF == 5 ? 2 : SURF), EXPECT_ONLY, CHECKED, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
   }
