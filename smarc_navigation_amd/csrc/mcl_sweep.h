@@ -30,7 +30,10 @@
 #define SWEEP_THREADS 256
 #endif
 #ifndef SWEEP_MIN_WAVES_GRID
-#define SWEEP_MIN_WAVES_GRID 6   // height grids carry the conic of the current cell as well (<= 80 VGPRs); so does the bounds-checked second pass
+#define SWEEP_MIN_WAVES_GRID 6   // height grids carry the conic of the current cell as well (<= 80 VGPRs; measured: 4, 5 and 6 waves run alike -- the kernel is bound by VALU issue, not by latency)
+#endif
+#ifndef SWEEP_MIN_WAVES_TIN
+#define SWEEP_MIN_WAVES_TIN 6
 #endif
 #ifndef SWEEP_MIN_WAVES
 #define SWEEP_MIN_WAVES 8   // waves per SIMD the register budget is held to (<= 64 VGPRs)
@@ -42,9 +45,6 @@
 #endif
 #ifndef SWEEP_SCHED_BARRIER
 #define SWEEP_SCHED_BARRIER 1
-#endif
-#ifndef SWEEP_GRID_CELLWALK
-#define SWEEP_GRID_CELLWALK 1   // height grids: sweep_side_grid (cell by cell) instead of the triangulated walk
 #endif
 
 // v_max_f32 as the hardware does it (IEEE maxNum: a NaN operand loses).  fmaxf() adds a canonicalising v_max(x, x) in
@@ -61,16 +61,7 @@ struct SweepNode {
   float s, t;   // in-plane coordinates, s mirrored so that it grows outward on this lane's side
 };
 
-// SURF 2: every cell split along 00-11; SURF 3: along 10-01.
-// SURF 0: a height GRID (bilinear patches).  The walk is the same -- along cell edges a bilinear patch is linear, so
-//   the points where the fan plane crosses CELL edges are exact, and walking the 00-11 triangulation of the node
-//   values of the plane function visits them in order (the plane function is bilinear in a cell; its zero set joins
-//   the same pairs of edge crossings as that of the triangulated values unless the four corner signs alternate,
-//   which the tilt bound for grids excludes: tan(tilt) * slope < 0.45).  Crossings of the auxiliary diagonals are
-//   passed over.  Between two consecutive cell-edge crossings the slice is an arc of a conic inside ONE cell: a beam
-//   whose angle they bracket meets the surface in that cell, at a root of the bilinear-patch quadratic of the oracle
-//   (orc_ray_grid); a beam that passes just beyond the far crossing may still graze the arc -- bounded by the patch's
-//   twist -- and is then tested against the same quadratic.
+// SURF 2: every cell split along 00-11; SURF 3: along 10-01.  (Height grids, SURF 0: sweep_side_grid below.)
 // Returns false when the particle has to go to the general kernel.  acc: sum over this side's beams of
 // ((range - expected) * weight)^2; EXPECT_ONLY: expected ranges to exp_row[b] instead.
 // CHECKED (second pass, over what the first one declined): the footprint need not lie inside the map -- every node is
@@ -139,8 +130,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   }
   if (!pre) SWEEP_FAIL(1);
   const float* __restrict__ gp = a.grid + ((size_t)I0 * ny + J0);  // node (I0, J0); every access below is inside the footprint
-  const float* __restrict__ grid = a.grid;
-  const int g0i = I0 * ny + J0, g_hi = nx * ny - 1;  // (maps below 2^30 nodes: checked on the host)
+  const int g0i = I0 * ny + J0;  // (maps below 2^30 nodes: checked on the host)
   // the height array as a raw buffer (stride 0, num_records in bytes): out-of-range reads return 0
   const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.grid, 0, nx * ny * 4, 0x00020000);
   const int ny4 = ny * 4, g0b = g0i * 4;
@@ -167,7 +157,6 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     own_start = false;
   }
   if (!(r0 < a.r_max)) SWEEP_FAIL(5);
-  if (SURF == 0 && !(r0 > 0.f)) SWEEP_FAIL(9);  // the sensor is at or below the seabed (a grid is solid underneath)
   if (none) return true;
   // ---- plane and in-plane coordinates as affine functions of (i, j, h): lattice coordinates relative to (I0, J0)
   const float nx_ = P.c1[1] * P.c2[2] - P.c1[2] * P.c2[1], ny_ = P.c1[2] * P.c2[0] - P.c1[0] * P.c2[2],
@@ -188,17 +177,15 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   };
   // ---- the triangle under the nadir hit
   SweepNode A, Bn;
-  int C, start_i, start_j;
+  int C;
   float s_prev, t_prev, s_cur, t_cur;
   {
     const float uh = fmaf(r0, dxs * inv_res, ul), vh = fmaf(r0, dys * inv_res, vl);
     const float cfi = floorf(uh), cfj = floorf(vh);
     const float fu = uh - cfi, fv = vh - cfj;
     const int c00 = (int)cfi * 65536 + (int)cfj;
-    start_i = (int)cfi;
-    start_j = (int)cfj;
     int k0, k1, k2;
-    if (SURF == 2 || SURF == 0) {
+    if (SURF == 2) {
       const bool lower = fv <= fu;  // (00, 10, 11) : (00, 11, 01)
       k0 = c00;
       k1 = lower ? c00 + 65536 : c00 + 65537;
@@ -251,20 +238,6 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     tnext = bp[-pstep].x;
   }
   float4 bm = bp[0];
-  // SURF 0: does the current / previous vertex lie on a cell edge (and not on an auxiliary diagonal)?
-  const auto on_cell_edge = [](int Pa, int Pb) { const int dP = Pa - Pb; return !(dP == 65537 || dP == -65537); };
-  bool cur_edge = SURF != 0 || on_cell_edge(A.P, Bn.P), prev_edge = false;
-  float hp00 = 0.f, hp01 = 0.f, hp10 = 0.f, hp11 = 0.f;  // SURF 0: corner heights of the cell the walk is in
-  if (SURF == 0) {
-    const unsigned gs = (unsigned)min(max(g0i + start_i * ny + start_j, 0), g_hi - ny - 1);
-    hp00 = grid[gs];
-    hp01 = grid[gs + 1];
-    hp10 = grid[gs + ny];
-    hp11 = grid[gs + ny + 1];
-  }
-  const float rc2z = fast_rcp(c2z);
-  // (s, t) -> cells: u = ul + ax s + bx t, v = vl + ay s + by t
-  const float ax = sg * P.c1[0] * inv_res, ay = sg * P.c1[1] * inv_res, bx = -P.c2[0] * inv_res, by = -P.c2[1] * inv_res;
   // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the next triangle.
   // Returns true when the walk is over (all beams resolved, stop distance, map border, failure).
   const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc) -> bool {
@@ -278,84 +251,19 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     // CHECKED: is that node on the map at all?  (if not, the slice leaves the map through the edge it stands on)
     const bool off_x = CHECKED && (unsigned)(I0 + ni) >= (unsigned)nx, off_y = CHECKED && (unsigned)(J0 + nj) >= (unsigned)ny;
     const float dts = tc - tp;
-    if (cur_edge) {
-      // SURF 0: the patch of the cell the arc (prev -> cur) lies in = the cell of the triangle (A, Bn, C)
-      // In the fan plane the clearance z - h(u, v) over this cell is a conic in (s, t),
-      //   G = g0 + g1 s + g2 t + g3 s^2 + g4 s t + g5 t^2   (u, v, z are affine in (s, t), h is bilinear),
-      // and along beam s = t tan a it is the quadratic  g0 + (g1 T + g2) t + (g3 T^2 + g4 T + g5) t^2  -- the same
-      // polynomial as the oracle's ray / patch quadratic (orc_ray_grid), with tau = t.
-      float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, kb = 0.f, uc = 0.f, vc = 0.f;
-      if (SURF == 0) {
-        const int ja = __builtin_amdgcn_sbfe(A.P, 0, 16), ia = (A.P - ja) >> 16;
-        const int jb = __builtin_amdgcn_sbfe(Bn.P, 0, 16), ib = (Bn.P - jb) >> 16;
-        const int jc = __builtin_amdgcn_sbfe(C, 0, 16), ic = (C - jc) >> 16;
-        const int i0 = min(ia, min(ib, ic)), j0 = min(ja, min(jb, jc));
-        // (hp: the corner heights of this cell, loaded one cell edge ago)
-        const float pB = hp10 - hp00, pC = hp01 - hp00, pD = (hp00 - hp10) - (hp01 - hp11);
-        uc = ul - (float)i0;
-        vc = vl - (float)j0;
-        // u = uc + ax s + bx t, v = vc + ay s + by t (cells), z = oz + sz s + tz t
-        g0 = oz - fmaf(pD * uc, vc, fmaf(pC, vc, fmaf(pB, uc, hp00)));
-        g1 = sz - fmaf(pD, fmaf(uc, ay, vc * ax), fmaf(pC, ay, pB * ax));
-        g2 = tz - fmaf(pD, fmaf(uc, by, vc * bx), fmaf(pC, by, pB * bx));
-        g3 = -pD * (ax * ay);
-        g4 = -pD * fmaf(ax, by, ay * bx);
-        g5 = -pD * (bx * by);
-        // how far (in e = s - t tan a, per unit tan a) the arc can bulge beyond its chord: along the chord the
-        // clearance is -twist * du * dv * l (1 - l) <= |twist du dv| / 4, and moving along -c2 changes the clearance
-        // at a rate of at least c2z (1 - slope tan(tilt)) >= 0.55 c2z
-        const float ds = sc - sp;
-        const float cu = prev_edge ? fmaf(ax, ds, bx * dts) : 1.f, cv = prev_edge ? fmaf(ay, ds, by * dts) : 1.f;
-        kb = 0.46f * fabsf(pD * cu * cv) * rc2z + 1e-6f;
-        // the corner heights of the NEXT cell (the one across this edge: the cell of (A, Bn, N)) are in flight
-        // while this arc's beams are resolved
-        const int i1 = min(ia, min(ib, ni)), j1 = min(ja, min(jb, nj));
-        const unsigned gn = (unsigned)min(max(g0i + i1 * ny + j1, 0), g_hi - ny - 1);
-        hp00 = grid[gn];
-        hp01 = grid[gn + 1];
-        hp10 = grid[gn + ny];
-        hp11 = grid[gn + ny + 1];
-      }
+    {
       // (no end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0, so e_cur = -inf.  The
       //  loop is rotated: e_cur of the NEXT beam is formed at the end of the body, one compare decides)
       float e_cur = fmaf(-tcur, tc, sc);
       // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes sign:
-      // <= 0 at prev, >= 0 at cur), SURF 0: refined on the patch; then on to the next beam of the table
-      const auto resolve = [&](bool graze) -> bool {
+      // <= 0 at prev, >= 0 at cur); then on to the next beam of the table
+      while (e_cur >= 0.f && (!SUB || bp != bp_end)) {   // until the pending beam passes beyond this vertex
         const float e_prev = fmaf(-tcur, tp, sp);
         const float lam = __builtin_amdgcn_fmed3f(e_prev * fast_rcp(e_prev - e_cur), 0.f, 1.f);
-        float tau = fmaf(lam, dts, tp);
+        const float tau = fmaf(lam, dts, tp);
 #if SWEEP_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);   // (the record's fields are first needed below: the wait for it belongs here)
 #endif
-        if (SURF == 0) {
-          const float q1 = fmaf(g1, tcur, g2), q2 = fmaf(fmaf(g3, tcur, g4), tcur, g5);
-          // the root next to the chord's estimate: one Newton step (the estimate is off by at most the arc's bulge, a
-          // few millimetres on smooth terrain), accepted when the residual confirms it to 3e-5 m.  On strongly twisted
-          // patches, or where the beam meets the seabed at a shallow angle (two close roots: Newton stalls), the closed
-          // form takes over (wave-uniform branch)
-          const float f0 = fmaf(fmaf(q2, tau, q1), tau, g0), fp = fmaf(2.f * q2, tau, q1);
-          float tn = fmaf(-f0, fast_rcp(fp), tau);
-          const float fr = fmaf(fmaf(q2, tn, q1), tn, g0);
-          const bool exact = graze | !(fabsf(fr) <= 3e-5f * fabsf(fp));
-          if (__builtin_amdgcn_ballot_w64(exact) != 0ull) {
-            if (exact) {
-              const float disc = fmaf(q1, q1, -4.f * q2 * g0);
-              const float sq = fast_sqrt(fmaxf(disc, 0.f));
-              const float qq = -0.5f * (q1 + (q1 >= 0.f ? sq : -sq));
-              const float r1 = g0 * fast_rcp(qq), r2 = qq * fast_rcp(q2);  // r2 = inf / NaN on a planar patch
-              const float lo = fminf(r1, r2), hi = fmaxf(r1, r2);
-              const float du = fmaf(ax, tcur, bx), dv = fmaf(ay, tcur, by);  // cells per unit t along the beam
-              // a root counts if its point lies in this cell (the arc is the only piece of the slice there)
-              const float EPS = 2e-4f;
-              const bool vlo = (disc >= 0.f) & (lo > 0.f) & (fabsf(fmaf(du, lo, uc) - 0.5f) <= 0.5f + EPS) & (fabsf(fmaf(dv, lo, vc) - 0.5f) <= 0.5f + EPS);
-              const bool vhi = (disc >= 0.f) & (hi > 0.f) & (fabsf(fmaf(du, hi, uc) - 0.5f) <= 0.5f + EPS) & (fabsf(fmaf(dv, hi, vc) - 0.5f) <= 0.5f + EPS);
-              if (graze & !(vlo | vhi)) return false;  // a beam beyond the far vertex that passes over the arc: not in this cell
-              tn = vlo ? lo : (vhi ? hi : tau);  // (neither, bracketed: rounding at the cell border -- the chord)
-            }
-          }
-          tau = tn;
-        }
         // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants (mcl_api.hip:
         // upload_sweep_beams): (range_b - r) w = max(z w - t (w / cos a), (z - r_max) w)
         if (EXPECT_ONLY) {
@@ -373,22 +281,6 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
         bp += pstep;
         bm = bp[0];   // (needed a handful of instructions into the next iteration -- not by its loop test)
         e_cur = fmaf(-tcur, tc, sc);
-        return true;
-      };
-      // (no end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0, so e_cur = -inf)
-      if (SURF != 0) {
-        while (e_cur >= 0.f && (!SUB || bp != bp_end)) resolve(false);   // until the pending beam passes beyond this vertex
-      } else {
-        for (;;) {
-          if (SUB && bp == bp_end) break;   // (the beams beyond belong to the next lane of this side)
-          bool graze = false;
-          if (!(e_cur >= 0.f)) {  // the beam passes beyond this vertex ...
-            const float e_prev_g = fmaf(-tcur, tp, sp);
-            if (!(fmaxf(e_cur, e_prev_g) + tcur * kb >= 0.f)) break;  // ... by more than the arc can bulge (sentinel: NaN)
-            graze = true;
-          }
-          if (!resolve(graze)) break;
-        }
       }
     }
     if (bp == bp_end) return true;
@@ -422,35 +314,19 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     Bn.t = pos ? tN : Bn.t;
     const float lam = A.d * fast_rcp(A.d - Bn.d);
     const float s_new = fmaf(lam, Bn.s - A.s, A.s), t_new = fmaf(lam, Bn.t - A.t, A.t);
-    if (SURF != 0) {
-      // lattice meshes: every crossing is a vertex of the slice.  The new vertex takes the place of the one before
-      // last and the CALLER swaps the roles (the walk loop is unrolled by two): no register shuffling per step
-      sp = s_new;
-      tp = t_new;
-    } else {
-      if (cur_edge) {  // (a diagonal crossing is not a vertex of the slice)
-        sp = sc;
-        tp = tc;
-        prev_edge = true;
-      }
-      sc = s_new;
-      tc = t_new;
-      cur_edge = on_cell_edge(A.P, Bn.P);
-    }
+    // every crossing is a vertex of the slice.  The new vertex takes the place of the one before last and the CALLER
+    // swaps the roles (the walk loop is unrolled by two): no register shuffling per step
+    sp = s_new;
+    tp = t_new;
     if (!(t_new > 0.f)) {  // the seabed rises above the sensor's own horizon: not for the sweep (see the sentinel records)
       ok = false;
       return true;
     }
     return false;
   };
-  if (SURF != 0) {
-    for (;;) {
-      if (walk_step(s_prev, t_prev, s_cur, t_cur)) break;
-      if (walk_step(s_cur, t_cur, s_prev, t_prev)) break;
-    }
-  } else {
-    while (!walk_step(s_prev, t_prev, s_cur, t_cur)) {
-    }
+  for (;;) {
+    if (walk_step(s_prev, t_prev, s_cur, t_cur)) break;
+    if (walk_step(s_cur, t_cur, s_prev, t_prev)) break;
   }
   if (ok && bp != bp_end) {
     ptr = (int)(bp - sbeam);
@@ -673,7 +549,6 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
     const float g1 = sz - fmaf(pD, fmaf(uc, ay, vc * ax), fmaf(pC, ay, pB * ax));
     const float g2 = tz - fmaf(pD, fmaf(uc, by, vc * bx), fmaf(pC, by, pB * bx));
     const float g3n = pD * axay2, g4n = pD * axby2, g5n = pD * bxby2;   // -2 g3, -2 g4, -2 g5
-    const float G0 = 2.f * g0;
     // how far (in e = s - t tan a, per unit tan a) the arc can bulge beyond its chord: along the chord the clearance is
     // -twist * du * dv * l (1 - l) <= |twist du dv| / 4, and moving along -c2 changes the clearance at a rate of at
     // least c2z (1 - slope tan(tilt)) >= 0.55 c2z
@@ -692,35 +567,24 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
     // ---- the beams of this arc.  (No end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0,
     // so e_cur = -inf.  The loop is rotated: e_cur of the NEXT beam is formed at the end of the body.)
     float e_cur = fmaf(-tcur, tc, sc);
-    for (;;) {
-      if (SUB && bp == bp_end) break;   // (the beams beyond belong to the next lane of this side)
-      bool graze = false;
-      if (!(e_cur >= 0.f)) {  // the beam passes beyond the exit crossing ...
-        const float e_prev = fmaf(-tcur, tp, sp);
-        if (!(fmaxf(e_cur, e_prev) + tcur * kb >= 0.f)) break;  // ... by more than the arc can bulge (sentinel: NaN)
-        graze = true;
-      }
-      // the root at which the clearance turns negative, in the form that does not cancel:
-      // with w = q1 + sgn(q1) sqrt(q1^2 - 4 q2 g0):  q1 >= 0: w / (-2 q2),  q1 < 0: -2 g0 / w
+    // The root at which the clearance turns negative, in the form that does not cancel: with
+    // w = q1 + sgn(q1) sqrt(q1^2 - 4 q2 g0):  q1 < 0 (the clearance falls along the beam from the start: all but
+    // strongly twisted, distant patches): -2 g0 / w;  q1 >= 0: w / (-2 q2)
+    const float nG0 = -2.f * g0;
+    const auto root = [&](float& disc) {
       const float q1 = fmaf(g1, tcur, g2), q2n = fmaf(fmaf(g3n, tcur, g4n), tcur, g5n);
-      const float disc = fmaf(q2n, G0, q1 * q1);
-      const float sq = fast_sqrt(fmaxf(disc, 0.f));
-      const bool qpos = q1 >= 0.f;
-      const float w = q1 + (qpos ? sq : -sq);
-      const float tau = (qpos ? w : -G0) * fast_rcp(qpos ? q2n : w);
-#if SWEEP_SCHED_BARRIER
-      __builtin_amdgcn_sched_barrier(0);   // (the record's fields are first needed below: the wait for it belongs here)
-#endif
-      if (graze) {
-        // a beam beyond the exit crossing: it meets the arc only if that root's point lies in this cell
-        const float du = fmaf(ax, tcur, bx), dv = fmaf(ay, tcur, by);  // cells per unit t along the beam
-        const float EPS = 2e-4f;
-        const bool in = (disc >= 0.f) & (tau > 0.f) & (fabsf(fmaf(du, tau, uc) - 0.5f) <= 0.5f + EPS) &
-                        (fabsf(fmaf(dv, tau, vc) - 0.5f) <= 0.5f + EPS);
-        if (!in) break;
+      disc = fmaf(q2n, -nG0, q1 * q1);
+      const float sq = fast_sqrt(fabsf(disc));   // (negative by rounding only: a tangent beam)
+      float tau = nG0 * fast_rcp(q1 - sq);
+      if (__builtin_amdgcn_ballot_w64(q1 >= 0.f) != 0ull) {   // (wave-uniform, rare: a real branch)
+        asm volatile("; q1 >= 0");
+        if (q1 >= 0.f) tau = (q1 + sq) * fast_rcp(q2n);
       }
-      // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants (mcl_api.hip:
-      // upload_sweep_beams): (range_b - r) w = max(z w - t (w / cos a), (z - r_max) w)
+      return tau;
+    };
+    // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants (mcl_api.hip:
+    // upload_sweep_beams): (range_b - r) w = max(z w - t (w / cos a), (z - r_max) w); then on to the next beam
+    const auto take = [&](float tau) {
       if (EXPECT_ONLY) {
         exp_row[bp - sbeam] = fminf(tau * bm.y, a.r_max);
       } else {
@@ -732,6 +596,29 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
       bp += pstep;
       bm = bp[0];
       e_cur = fmaf(-tcur, tc, sc);
+    };
+    for (;;) {
+      while (e_cur >= 0.f && (!SUB || bp != bp_end)) {   // the beams the two crossings bracket
+        float disc;
+        const float tau = root(disc);
+#if SWEEP_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);   // (the record's fields are first needed below: the wait for it belongs here)
+#endif
+        take(tau);
+      }
+      if (SUB && bp == bp_end) break;   // (the beams beyond belong to the next lane of this side)
+      // the pending beam passes beyond the exit crossing: by more than the arc can bulge?  (sentinel: NaN)
+      const float e_prev = fmaf(-tcur, tp, sp);
+      if (!(hw_max(e_cur, e_prev) + tcur * kb >= 0.f)) break;
+      // it may graze the arc: only if the root's point lies in this cell
+      float disc;
+      const float tau = root(disc);
+      const float du = fmaf(ax, tcur, bx), dv = fmaf(ay, tcur, by);  // cells per unit t along the beam
+      const float EPS = 2e-4f;
+      const bool in = (disc >= 0.f) & (tau > 0.f) & (fabsf(fmaf(du, tau, uc) - 0.5f) <= 0.5f + EPS) &
+                      (fabsf(fmaf(dv, tau, vc) - 0.5f) <= 0.5f + EPS);
+      if (!in) break;
+      take(tau);
     }
     if (bp == bp_end) break;
     if (sc > s_stop) break;  // every beam left misses inside r_max (tail below)
@@ -1061,10 +948,10 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
     const MbesPose P = a.pose[i];
     if (SURF == 5)
       ok = sweep_side_tin<EXPECT_ONLY, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
-    else if (SURF == 0 && SWEEP_GRID_CELLWALK)
+    else if (SURF == 0)
       ok = sweep_side_grid<EXPECT_ONLY, CHECKED, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
     else
-      ok = sweep_side<(SURF == 5 ? 2 : SURF), EXPECT_ONLY, CHECKED, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
+      ok = sweep_side<(SURF == 3 ? 3 : 2), EXPECT_ONLY, CHECKED, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
   }
   // the lanes of a particle agree on its fate: every lane but the first leaves its verdict and sum in LDS
   if (combo) {
@@ -1099,7 +986,7 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
 // (register budgets: lattice first pass 8 waves / SIMD (64 VGPRs), grids, TINs and the lattice second pass 6, the bounds-
 //  checked second pass over a GRID 4 -- it carries the conic AND the border tests, and spilled 84 B per lane at 6)
 template <int SURF, bool EXPECT_ONLY, bool CHECKED = false, bool SUB = false>
-__global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, (SURF == 0 && CHECKED) ? 4 : ((SURF == 0 || SURF == 5) ? SWEEP_MIN_WAVES_GRID : (CHECKED ? 6 : SWEEP_MIN_WAVES))) k_mbes_sweep(MbesArgs a) {
+__global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, (SURF == 0 && CHECKED) ? 4 : (SURF == 0 ? SWEEP_MIN_WAVES_GRID : (SURF == 5 ? SWEEP_MIN_WAVES_TIN : (CHECKED ? 6 : SWEEP_MIN_WAVES)))) k_mbes_sweep(MbesArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sweep_lds[];
   __shared__ float xacc[64 * (SUB ? SWEEP_MAX_WAVES : SWEEP_THREADS / 64)];
   __shared__ int xok[64 * (SUB ? SWEEP_MAX_WAVES : SWEEP_THREADS / 64)];
