@@ -1336,16 +1336,20 @@ int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, i
 // Lanes per particle side of the fan sweep: a small cloud splits a side's beams over 2 or 4 lanes (mcl_sweep.h SUB:
 // each resolves its own run of >= 16 beams, starting at the hit of the run's first beam); the GLOBAL particle count
 // decides, so every shard sums in the same order.
-// (measured, round 3, the dominant launch in ms -- traversal | sweep with 1 / 2 / 4 lanes per side:
-//    grid  32 768 x 256: 0.093 | 0.103 0.068 0.055     mesh  32 768 x 256: 0.093 | 0.036 0.033 0.028
-//    grid  65 536 x 256: 0.100 | 0.108 0.086 0.087     mesh  65 536 x 256: 0.098 | 0.038 0.039 0.037
-//    grid 131 072 x 512: 0.273 | 0.216 0.208 0.205     mesh 131 072 x 512: 0.263 | 0.066 0.074 0.078
-//  a later run pays one slanted traversal for its start; worth it while the chip is not full)
+// (measured, round 3 with the grid's cell walk, the whole fused step in ms -- traversal | sweep with 1 / 2 / 4 lanes per
+//  side, 256 beams:
+//    grid   4 096: 0.086 | 0.095 0.090 0.083     mesh   4 096: 0.079 | 0.097 0.092 0.075
+//    grid   8 192: 0.089 | 0.093 0.085 0.081     mesh   8 192: 0.089 | 0.094 0.090 0.082
+//    grid  32 768: 0.158 | 0.094 0.089 0.087     mesh  32 768: 0.157 | 0.095 0.093 0.088
+//    grid  65 536: 0.154 | 0.100 0.098 0.101     mesh  65 536: 0.153 | 0.099 0.100 0.098
+//    grid 131 072: 0.218 | 0.120 0.125 0.133     mesh 131 072: 0.218 | 0.116 0.122 0.128
+//  below 4 096 the traversal wins (128 particles: 0.059 against 0.067); a later run pays one slanted traversal for its
+//  start; worth it while the chip is not full)
 int sweep_lanes_per_side(const mcl_handle* h, bool with_ranges, int B) {
   int nsub = 1;
   if (with_ranges) {
     if (h->map_kind == 0)
-      nsub = h->ng < 49152 ? 4 : (h->ng < 196608 ? 2 : 1);
+      nsub = h->ng < 49152 ? 4 : (h->ng < 98304 ? 2 : 1);
     else if (h->mesh && h->mesh->heights && !h->force_general_mesh)
       nsub = h->ng < 49152 ? 4 : 1;
     if (h->env_nsub) nsub = h->env_nsub;
@@ -1581,9 +1585,10 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   // ---- fan sweep (mcl_sweep.h): regularly triangulated meshes, ascending beam angles.  The fan plane may lean
   // from the vertical only as far as the steepest triangle allows (tan(tilt) * slope < 1, with a margin).
   if (!pose_done) {
-    // (below ~16 k particles on meshes / ~32 k on height grids the sweep's lanes cannot fill the chip and the
-    //  wave-per-particle traversal is faster -- measured at 32 k ... 1 M; MCL_SWEEP=1 forces it)
-    const long long sweep_min_n = h->env_sweep == 1 ? 1 : (h->map_kind == 0 ? 32768 : 16384);
+    // (below ~8 k particles even four lanes per side cannot fill the chip and the wave-per-particle traversal is
+    //  faster -- measured at 128 ... 262 144 particles x 256 / 512 beams; MCL_SWEEP=1 forces it)
+    const bool lattice = h->map_kind == 0 || (structured && (a.diag_mode == 1 || a.diag_mode == 2));
+    const long long sweep_min_n = h->env_sweep == 1 ? 1 : (lattice ? 8192 : 16384);   // (adjacency sweep: one lane per side only)
     // a height-field TIN with adjacency -- also a triangulated height grid whose cells are split along mixed diagonals
     // (tin_ok: mesh_build has PROVEN the mesh single-valued over (x, y) -- adjacency, fold and pairwise overlap tests)
     const bool tin = h->map_kind == 1 && h->mesh->tin_ok && !h->mesh_no_sweep && (!structured || a.diag_mode == 0);
