@@ -367,6 +367,40 @@ def test_grid_sweep_on_twisted_patches_and_grazing_beams(eng, orc, monkeypatch):
     assert jumps.sum() > 50   # the scene really has shadow boundaries
 
 
+@pytest.mark.parametrize('rough', [False, True])
+def test_grid_cell_walk_agrees_with_the_traversal_on_millions_of_rays(rough, eng, orc, monkeypatch):
+    """The grid sweep (cell walk, closed-form entering root) against the traversal kernels -- an independent method,
+    itself checked against the oracle -- ray by ray over a wide cloud: 65 536 particles x 256 beams, gentle and rough
+    terrain, all headings, rolls and pitches to 0.1 rad.  Rare paths (patches on which the clearance first rises along
+    the beam, beams grazing an arc, fans ending at the map border) occur by the thousand at this size."""
+    kw = dict(fbm_amp=3.0, swell=4.0) if rough else {}
+    z, origin = _terrain(nx=400, ny=380, seed=23, origin=(-200.0, -190.0), **kw)
+    n, B = 65536, 256
+    soa = _cloud(n, 7, (60.0, 60.0, 1.5, 0.05, 0.05, 3.0), (0.0, 0.0, -6.0 if rough else -3.0))
+    ba = synth.beam_angles(B, 1.3 if rough else 1.05)
+    res = {}
+    for sweep in (True, False):
+        monkeypatch.setenv('MCL_SWEEP', '1' if sweep else '0')
+        e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+        e.set_particles(soa)
+        e.set_map_grid(z, origin, 1.0)
+        res[sweep] = (e.mbes_expected(0, n, ba, 90.0), e.mbes_last_path())
+        e.close()
+    assert res[True][1][0] == 1 and res[False][1][0] == 0
+    err = np.abs(res[True][0] - res[False][0])
+    bad = int((err > 1e-3).sum())
+    print('grid cell walk vs traversal (%s): %d of %d rays differ by more than 1e-3 m (p99.99 %.2e m), %d of %d particles '
+          'handed over' % ('rough' if rough else 'gentle', bad, err.size, np.quantile(err, 0.9999), res[True][1][1], n))
+    assert res[True][1][1] < n // 2
+    assert bad <= err.size // 20000
+    # a sample of the particles against the fp64 oracle as well
+    pick = np.random.RandomState(1).choice(n, 256, replace=False)
+    g = orc.Grid(z, origin, 1.0)
+    _, ref = orc.mbes_update(np.ascontiguousarray(soa[:, pick]), np.identity(4), [0] * 6, g, ba, None, 0.2, 90.0)
+    err_o = np.abs(res[True][0][pick] - ref)
+    assert (err_o > 1e-3).sum() <= max(4, err_o.size // 20000)
+
+
 def test_grid_ridge_occlusion_and_short_r_max(eng, orc):
     nx, ny = 160, 160
     origin = (-80.0, -80.0)
