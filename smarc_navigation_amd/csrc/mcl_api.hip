@@ -2404,10 +2404,12 @@ int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, do
   a.accumulate = accumulate ? 1 : 0;
   a.lw = h->lw;
   t_begin(h, MCL_K_UPDATE_MBES);
-  const long long per_block = 256 / LM_SUB;
-  long long blocks = (h->n + per_block - 1) / per_block;
+  long long blocks = (h->n + 255) / 256;   // (a wave per 64 particles, four waves per workgroup)
   if (blocks > 16384) blocks = 16384;
-  k_landmark_update<<<(unsigned)blocks, 256, 0, h->stream>>>(a);
+  if (a.maha)
+    k_landmark_update<true><<<(unsigned)blocks, 256, 0, h->stream>>>(a);
+  else
+    k_landmark_update<false><<<(unsigned)blocks, 256, 0, h->stream>>>(a);
   t_end(h);
   HIPCHK(h, hipGetLastError());
   if (!accumulate) h->weight_mode = MCL_WEIGHT_LOG_SHIFT;

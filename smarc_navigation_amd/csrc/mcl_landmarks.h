@@ -71,10 +71,11 @@ __device__ __forceinline__ void landmark_qm(const LandmarkArgs& a, const double 
     Qm[k] = T[r * 3] * Rs[c * 3] + T[r * 3 + 1] * Rs[c * 3 + 1] + T[r * 3 + 2] * Rs[c * 3 + 2];
   }
 }
+template <bool MAHA>
 __device__ __forceinline__ double landmark_pair_cost(const LandmarkArgs& a, const double Qm[6], double px, double py,
                                                      double pz, u32 e, double* logdet) {
   const double dx = px - a.lm[3 * (size_t)e], dy = py - a.lm[3 * (size_t)e + 1], dz = pz - a.lm[3 * (size_t)e + 2];
-  if (!a.maha) {
+  if (!MAHA) {
     *logdet = 0.0;  // constant: folded into lognorm
     return (dx * dx + dy * dy + dz * dz) * a.inv_s2;
   }
@@ -91,100 +92,10 @@ __device__ __forceinline__ double landmark_pair_cost(const LandmarkArgs& a, cons
   return quad / det;
 }
 
-__global__ void __launch_bounds__(256) k_landmark_update(LandmarkArgs a) {
-  const int sub = threadIdx.x & (LM_SUB - 1);
-  const long long per_block = blockDim.x / LM_SUB;
-  for (long long i = blockIdx.x * per_block + threadIdx.x / LM_SUB; i < a.n; i += (long long)gridDim.x * per_block) {
-    // sensor pose in the map frame (fp64): M = m2o * T(x,y,z) R(rpy) * T_off R_off
-    const double x = a.st[0][i], y = a.st[1][i], z = a.st[2][i];
-    double sr, cr, sp, cp, sy, cy;
-    sincos(a.st[3][i], &sr, &cr);
-    sincos(a.st[4][i], &sp, &cp);
-    sincos(a.st[5][i], &sy, &cy);
-    const double Rp[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
-                          sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
-                          -sp,     cp * sr,                cp * cr};
-    double Rmp[9], Rs[9], o[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        Rmp[r * 3 + c] = a.m2o[r * 4 + 0] * Rp[c] + a.m2o[r * 4 + 1] * Rp[3 + c] + a.m2o[r * 4 + 2] * Rp[6 + c];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        Rs[r * 3 + c] = Rmp[r * 3 + 0] * a.off_R[c] + Rmp[r * 3 + 1] * a.off_R[3 + c] + Rmp[r * 3 + 2] * a.off_R[6 + c];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-      o[r] = (a.m2o[r * 4 + 0] * x + a.m2o[r * 4 + 1] * y + a.m2o[r * 4 + 2] * z + a.m2o[r * 4 + 3]) +
-             (Rmp[r * 3 + 0] * a.off_t[0] + Rmp[r * 3 + 1] * a.off_t[1] + Rmp[r * 3 + 2] * a.off_t[2]);
-    double Qm[6] = {0, 0, 0, 0, 0, 0};
-    if (a.maha) landmark_qm(a, Rs, Qm);
-    double acc = 0.0;
-    int nvalid = 0;
-    for (int d = sub; d < a.n_det; d += LM_SUB) {
-      const double zx = a.det[3 * d], zy = a.det[3 * d + 1], zz = a.det[3 * d + 2];
-      if (!(zx == zx && zy == zy && zz == zz)) continue;  // NaN = invalid detection
-      const double px = o[0] + Rs[0] * zx + Rs[1] * zy + Rs[2] * zz;
-      const double py = o[1] + Rs[3] * zx + Rs[4] * zy + Rs[5] * zz;
-      const double pz = o[2] + Rs[6] * zx + Rs[7] * zy + Rs[8] * zz;
-      double best[LM_MAX_K], bld[LM_MAX_K];
-#pragma unroll
-      for (int q = 0; q < LM_MAX_K; ++q) {
-        best[q] = __builtin_inf();
-        bld[q] = 0.0;
-      }
-      const int cx = (int)floor((px - a.x0) * a.inv_cs), cyi = (int)floor((py - a.y0) * a.inv_cs);
-      for (int ix = max(cx - 1, 0); ix <= min(cx + 1, a.gx - 1); ++ix)
-        for (int iy = max(cyi - 1, 0); iy <= min(cyi + 1, a.gy - 1); ++iy) {
-          const size_t c = (size_t)ix * a.gy + iy;
-          for (u32 e = a.cell_start[c]; e < a.cell_start[c + 1]; ++e) {
-            double ld;
-            double m = landmark_pair_cost(a, Qm, px, py, pz, e, &ld);
-            if (m <= a.gate) {
-              // insert into the sorted k-best list
-#pragma unroll
-              for (int q = 0; q < LM_MAX_K; ++q) {
-                if (m < best[q]) {
-                  const double t = best[q], tl = bld[q];
-                  best[q] = m;
-                  bld[q] = ld;
-                  m = t;
-                  ld = tl;
-                }
-              }
-            }
-          }
-        }
-      double lwd;
-      if (best[0] == __builtin_inf()) {
-        lwd = -0.5 * a.gate;
-      } else {
-        // log sum_k exp(-d_k^2 / 2) / sqrt(det S_k / det Q) over the k nearest inside the gate, anchored at the nearest
-        const double e0 = -0.5 * (best[0] + bld[0]);
-        double s = 0.0;
-#pragma unroll
-        for (int q = 0; q < LM_MAX_K; ++q)
-          if (q < a.k && best[q] != __builtin_inf()) s += exp(-0.5 * (best[q] + bld[q]) - e0);
-        lwd = e0 + log(s);
-      }
-      acc += lwd;
-      ++nvalid;
-    }
-    // reduce over the LM_SUB lanes of this particle
-#pragma unroll
-    for (int o2 = LM_SUB / 2; o2 > 0; o2 >>= 1) {
-      acc += __shfl_xor(acc, o2, 64);
-      nvalid += __shfl_xor(nvalid, o2, 64);
-    }
-    if (sub == 0) {
-      const double v = acc - (double)nvalid * a.lognorm;
-      a.lw[i] = a.accumulate ? a.lw[i] + v : v;
-    }
-  }
+__device__ __forceinline__ double landmark_pair_cost(const LandmarkArgs& a, const double Qm[6], double px, double py,
+                                                     double pz, u32 e, double* logdet) {
+  return a.maha ? landmark_pair_cost<true>(a, Qm, px, py, pz, e, logdet) : landmark_pair_cost<false>(a, Qm, px, py, pz, e, logdet);
 }
-
 
 // sensor pose of particle i in the map frame (fp64): M = m2o * T(x,y,z) R(rpy) * T_off R_off
 __device__ __forceinline__ void landmark_sensor_pose(const LandmarkArgs& a, long long i, double Rs[9], double o[3]) {
@@ -212,6 +123,135 @@ __device__ __forceinline__ void landmark_sensor_pose(const LandmarkArgs& a, long
     o[r] = (a.m2o[r * 4 + 0] * x + a.m2o[r * 4 + 1] * y + a.m2o[r * 4 + 2] * z + a.m2o[r * 4 + 3]) +
            (Rmp[r * 3 + 0] * a.off_t[0] + Rmp[r * 3 + 1] * a.off_t[1] + Rmp[r * 3 + 2] * a.off_t[2]);
 }
+
+// Work layout (round 3): a wave takes 64 particles.  First every lane builds the sensor pose of ONE of them (three fp64
+// sincos, two 3x3 products, R Q R^T in Mahalanobis mode) and leaves it in LDS; then, sixteen times, the wave's 4 x 16
+// lanes answer the (<= 16 per pass) detections of four particles from those records.  (Rounds 1-2 let each of a
+// particle's 16 lanes rebuild the pose: half the kernel's instructions.)  The three cells of a grid row are
+// neighbours in the cell-ordered landmark array: one range per row, three per query, visited in the old order.
+#define LM_POSE_WORDS 18   // o[3], Rs[9], Qm[6]
+template <bool MAHA>
+__global__ void __launch_bounds__(256) k_landmark_update(LandmarkArgs a) {
+  __shared__ double pose_s[4][LM_POSE_WORDS][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sub = lane & (LM_SUB - 1), grp = lane >> 4;
+  double (*ps)[64] = pose_s[w];
+  for (long long base = (blockIdx.x * 4ll + w) * 64; base < a.n; base += (long long)gridDim.x * 256) {
+    {
+      const long long i = base + lane;
+      if (i < a.n) {
+        double Rs[9], o[3];
+        landmark_sensor_pose(a, i, Rs, o);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ps[k][lane] = o[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ps[3 + k][lane] = Rs[k];
+        if (MAHA) {
+          double Qm[6];
+          landmark_qm(a, Rs, Qm);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ps[12 + k][lane] = Qm[k];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (one wave: LDS runs in order; this is for the compiler)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int r = 0; r < 64 / 4; ++r) {
+      if (base + r * 4 >= a.n) break;   // (wave-uniform)
+      const int p = r * 4 + grp;
+      const long long i = base + p;
+      double acc = 0.0;
+      int nvalid = 0;
+      if (i < a.n) {
+        double o[3], Rs[9], Qm[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] = ps[k][p];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rs[k] = ps[3 + k][p];
+        if (MAHA) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) Qm[k] = ps[12 + k][p];
+        }
+        for (int d = sub; d < a.n_det; d += LM_SUB) {
+          const double zx = a.det[3 * d], zy = a.det[3 * d + 1], zz = a.det[3 * d + 2];
+          if (!(zx == zx && zy == zy && zz == zz)) continue;  // NaN = invalid detection
+          const double px = o[0] + Rs[0] * zx + Rs[1] * zy + Rs[2] * zz;
+          const double py = o[1] + Rs[3] * zx + Rs[4] * zy + Rs[5] * zz;
+          const double pz = o[2] + Rs[6] * zx + Rs[7] * zy + Rs[8] * zz;
+          double best[LM_MAX_K], bld[LM_MAX_K];
+#pragma unroll
+          for (int q = 0; q < LM_MAX_K; ++q) {
+            best[q] = __builtin_inf();
+            bld[q] = 0.0;
+          }
+          const int cx = (int)floor((px - a.x0) * a.inv_cs), cyi = (int)floor((py - a.y0) * a.inv_cs);
+          const int iy0 = max(cyi - 1, 0), iy1 = min(cyi + 1, a.gy - 1);
+          // the three row ranges first (six independent loads), then the landmarks
+          u32 rb[3], re[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int ix = cx - 1 + k;
+            const bool in = ix >= 0 && ix < a.gx && iy0 <= iy1;
+            const size_t c = (size_t)(in ? ix : 0) * a.gy;
+            rb[k] = in ? a.cell_start[c + iy0] : 0u;
+            re[k] = in ? a.cell_start[c + iy1 + 1] : 0u;
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+              for (u32 e = rb[k]; e < re[k]; ++e) {
+                double ld;
+                double m = landmark_pair_cost<MAHA>(a, Qm, px, py, pz, e, &ld);
+                if (m <= a.gate) {
+                  // insert into the sorted k-best list
+#pragma unroll
+                  for (int q = 0; q < LM_MAX_K; ++q) {
+                    if (m < best[q]) {
+                      const double t = best[q], tl = bld[q];
+                      best[q] = m;
+                      bld[q] = ld;
+                      m = t;
+                      ld = tl;
+                    }
+                  }
+                }
+              }
+            }
+          double lwd;
+          if (best[0] == __builtin_inf()) {
+            lwd = -0.5 * a.gate;
+          } else {
+            // log sum_k exp(-d_k^2 / 2) / sqrt(det S_k / det Q) over the k nearest inside the gate, anchored at the nearest
+            const double e0 = -0.5 * (best[0] + bld[0]);
+            lwd = e0;   // (one neighbour in the gate: exp(0) = 1, log(1) = 0 -- the same number without the calls)
+            if (a.k > 1 && best[1] != __builtin_inf()) {
+              double s = 0.0;
+#pragma unroll
+              for (int q = 0; q < LM_MAX_K; ++q)
+                if (q < a.k && best[q] != __builtin_inf()) s += exp(-0.5 * (best[q] + bld[q]) - e0);
+              lwd = e0 + log(s);
+            }
+          }
+          acc += lwd;
+          ++nvalid;
+        }
+      }
+      // reduce over the LM_SUB lanes of this particle
+#pragma unroll
+      for (int o2 = LM_SUB / 2; o2 > 0; o2 >>= 1) {
+        acc += __shfl_xor(acc, o2, 64);
+        nvalid += __shfl_xor(nvalid, o2, 64);
+      }
+      if (sub == 0 && i < a.n) {
+        const double v = acc - (double)nvalid * a.lognorm;
+        a.lw[i] = a.accumulate ? a.lw[i] + v : v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // (the next pass rewrites the pose records)
+  }
+}
+
 
 // ------------------------------------------------------------------ global (Hungarian) assignment
 // SURVEY 8(f) rank 4.  Per particle the correspondence table of the reference's batch association
@@ -303,10 +343,12 @@ __global__ void __launch_bounds__(LA_PER_BLOCK * LM_SUB) k_landmark_assign(Landm
         double Qm[6] = {0, 0, 0, 0, 0, 0};
         if (a.maha) landmark_qm(a, Rs, Qm);
         const int cx = (int)floor((px - a.x0) * a.inv_cs), cyi = (int)floor((py - a.y0) * a.inv_cs);
-        for (int ix = max(cx - 1, 0); ix <= min(cx + 1, a.gx - 1); ++ix)
-          for (int iy = max(cyi - 1, 0); iy <= min(cyi + 1, a.gy - 1); ++iy) {
-            const size_t c = (size_t)ix * a.gy + iy;
-            for (u32 e = a.cell_start[c]; e < a.cell_start[c + 1]; ++e) {
+        // (the three cells of a grid row are neighbours in the cell-ordered landmark array: one range per row)
+        const int iy0 = max(cyi - 1, 0), iy1 = min(cyi + 1, a.gy - 1);
+        for (int ix = max(cx - 1, 0); ix <= min(cx + 1, a.gx - 1) && iy0 <= iy1; ++ix)
+          {
+            const size_t c = (size_t)ix * a.gy;
+            for (u32 e = a.cell_start[c + iy0], e1 = a.cell_start[c + iy1 + 1]; e < e1; ++e) {
               double ld_unused;
               double m = landmark_pair_cost(a, Qm, px, py, pz, e, &ld_unused);
               if (m < a.gate) {  // strict, ekf_slam_core.cpp:173
