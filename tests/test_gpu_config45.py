@@ -188,3 +188,52 @@ def test_metric_config_fused_step_trajectory_vs_oracle():
         steps, dxy.max(), np.sqrt(np.mean(dxy ** 2)), dyaw.max()))
     assert dxy.max() <= TRAJ_TOL_XY_M and dyaw.max() <= TRAJ_TOL_YAW_RAD
     np.testing.assert_allclose(got[:, 2:5], ref[:, 2:5], rtol=0, atol=1e-9)   # z, roll, pitch: the odometry's
+
+
+def test_grid_fused_step_trajectory_vs_oracle():
+    """BASELINE config 2's map kind at size: 262 144 particles x 256 beams on the 708 x 708 height GRID (bilinear
+    patches: the cell-walk sweep), mcl_step_mbes x 4 against the oracle filter with the same Philox draws.  Same bound
+    as the mesh."""
+    from smarc_navigation_amd import engine as eng
+    from oracle import oracle as orc
+    from tests.helpers import host_threads
+    orc.set_threads(host_threads())
+    n, steps, Bg = 1 << 18, 4, 256
+    origin = (-64.0, -354.0)
+    z = synth.bathymetry_grid(708, 708, 1.0, origin, seed=3)
+    omap = orc.Grid(z, origin, 1.0)
+    stream = synth.odom_stream(steps)
+    ba = synth.beam_angles(Bg)
+    one = eng.Engine(1, rng_mode=eng.RNG_REPLAY)
+    one.set_map_grid(z, origin, 1.0)
+    rs = np.random.RandomState(4)
+    ranges = np.zeros((steps, Bg), np.float32)
+    for k in range(steps):
+        one.set_particles(stream['truth'][k][:, None].copy())
+        ranges[k] = one.mbes_expected(0, 1, ba, R_MAX)[0] + SIGMA * rs.randn(Bg)
+    one.close()
+    e = eng.Engine(n, seed=5, **COV)
+    e.set_map_grid(z, origin, 1.0)
+    e.init_particles()
+    for k in range(steps):
+        e.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'], ranges[k], ba, SIGMA, R_MAX)
+    e.sync()
+    assert e.mbes_last_path()[:2] == (1, 0)
+    got = e.mean_history(steps)
+    soa = np.zeros((6, n))
+    orc.add_noise(soa, COV['init_cov'], orc.native_normals(n, 0, 5, 0, 0))
+    ref = np.zeros((steps, 6))
+    for k in range(steps):
+        orc.predict(soa, stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'],
+                    COV['process_cov'], orc.native_normals(n, 0, 5, 1, k))
+        lw, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, ranges[k], SIGMA, R_MAX, want_expected=False)
+        idx, _, _ = orc.systematic_fixed(lw, 1, orc.native_u53(5, k))
+        lost, dupes = orc.lost_dupes(idx)
+        orc.reassign(soa, lost, dupes)
+        orc.add_noise(soa, COV['resample_cov'], orc.native_normals(n, 0, 5, 2, k))
+        ref[k] = orc.mean_cov(soa)[0]
+    dxy = np.hypot(got[:, 0] - ref[:, 0], got[:, 1] - ref[:, 1])
+    dyaw = np.abs(got[:, 5] - ref[:, 5])
+    print('262 144 x 256 fused step on the height grid vs oracle, %d steps: mean-pose deviation max %.3e m, yaw max %.3e rad' % (
+        steps, dxy.max(), dyaw.max()))
+    assert dxy.max() <= TRAJ_TOL_XY_M and dyaw.max() <= TRAJ_TOL_YAW_RAD
