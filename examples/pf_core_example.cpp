@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
   }
   core.start_timing(100.0);
   const double v[3] = {1.0, 0.0, 0.0};
-  const double amin = -1.0, ainc = 2.0 / (B - 1);
+  const double amin = -1.0, ainc = (double)(float)(2.0 / (B - 1));   // (float32, as a sensor_msgs/LaserScan carries it)
   // the ping as points in base_frame: sensor-frame hit (0, r sin a, -r cos a) through the sensor offset
   double off[6];
   auv_pf_hip::parse_cov_string(p.mbes_sensor_offset, off);

@@ -3,7 +3,8 @@
 // through the C ABI (include/mcl.h).  All logic lives in pf_core.hpp (ROS-free, compiled and tested without ROS);
 // this file is only the transport: parameters, the map <- odom lookup, subscribers, publishers, tf, the 10 Hz timer.
 //
-// NOT COMPILED IN THE BUILD CONTAINER (no ROS there): CMakeLists.txt builds it only when catkin finds roscpp & co.
+// CMakeLists.txt builds it when catkin finds roscpp & co.  In the build container (no ROS) it is compiled unchanged
+// against the stand-in headers of tests/ros_stubs_cpp and run in one process (tests/test_roscpp_node_stub.py).
 #include <mutex>
 
 #include <geometry_msgs/PointStamped.h>

@@ -1,0 +1,8 @@
+#pragma once
+#include <geometry_msgs/Pose.h>
+namespace geometry_msgs {
+struct PoseArray {
+  std_msgs::Header header;
+  std::vector<Pose> poses;
+};
+}  // namespace geometry_msgs

@@ -1,6 +1,6 @@
 """The roscpp node's ROS-free core (ros/auv_particle_filter_hip/include/auv_particle_filter_hip/pf_core.hpp) -- C++ host
 code over the C ABI.  CPU: it compiles and links against libmcl_hip.so with plain g++ (the roscpp glue around it,
-src/auv_pf_node.cpp, needs a ROS installation and is not built here).  GPU: examples/pf_core_example.cpp fed a map
+src/auv_pf_node.cpp, is compiled against stand-in ROS headers in tests/test_roscpp_node_stub.py).  GPU: examples/pf_core_example.cpp fed a map
 file, odometry, a LaserScan ping, the same ping as points in base_frame and a GPS fix publishes what the Python
 mirror publishes for the same inputs (same seed: same Philox draws)."""
 import os
@@ -71,8 +71,9 @@ def test_cpp_core_publishes_what_the_python_mirror_publishes(tmp_path):
               'mbes_sensor_offset': '[0.3, 0.0, -0.1, 0.0, 0.05, 0.0]', 'map_grid_file': mpath}
     pf = auv_pf.auv_pf(params, m2o_mat=m2o)
     pf.start_timing(100.0)
-    scan = msgs.LaserScan(ranges, -1.0, 2.0 / (B - 1), 80.0)
-    a = -1.0 + (2.0 / (B - 1)) * np.arange(B)
+    ainc = float(np.float32(2.0 / (B - 1)))   # (float32, as a sensor_msgs/LaserScan carries it)
+    scan = msgs.LaserScan(ranges, -1.0, ainc, 80.0)
+    a = -1.0 + ainc * np.arange(B)
     pts_sensor = np.stack([np.zeros(B), ranges * np.sin(a), -ranges * np.cos(a)], axis=1)
     T = auv_pf._rigid(*off)
     pc = msgs.pointcloud2_from_xyz((pts_sensor.dot(T[:3, :3].T) + T[:3, 3])[::-1], 'base')
