@@ -1,0 +1,632 @@
+// mcl_host_update.h -- host side, part 4: beam tables, the MBES update (fan sweep / traversal stages) and the predict
+// launch of the fused step.
+#pragma once
+#include "mcl_host_moments.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ MBES
+int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, int B) {
+  if (B > h->beams_cap) {
+    if (h->beam_sc) (void)hipFree(h->beam_sc);
+    if (h->ranges_dev) (void)hipFree(h->ranges_dev);
+    HIPCHK(h, hipMalloc(&h->beam_sc, sizeof(float2) * (size_t)B));
+    HIPCHK(h, hipMalloc(&h->ranges_dev, sizeof(float) * (size_t)B));
+    h->beams_cap = B;
+    h->beam_cache.clear();
+  }
+  if ((int)h->beam_cache.size() != B || memcmp(h->beam_cache.data(), beam_angles, sizeof(float) * B) != 0) {
+    std::vector<float2> sc(B);
+    for (int b = 0; b < B; ++b) {
+      sc[b].x = (float)std::sin((double)beam_angles[b]);
+      sc[b].y = (float)std::cos((double)beam_angles[b]);
+    }
+    RET_IF(upload(h, h->beam_sc, sc.data(), sizeof(float2) * (size_t)B));
+    h->beam_cache.assign(beam_angles, beam_angles + B);
+    int lo = 0, hi = 0;
+    bool finite = true;
+    for (int b = 0; b < B; ++b) {
+      if (!(beam_angles[b] == beam_angles[b])) finite = false;
+      if (beam_angles[b] < beam_angles[lo]) lo = b;
+      if (beam_angles[b] > beam_angles[hi]) hi = b;
+    }
+    const bool ok = finite && (double)beam_angles[hi] - (double)beam_angles[lo] < 3.0;  // span < pi
+    h->beam_lo = ok ? lo : -1;
+    h->beam_hi = ok ? hi : -1;
+    bool asc = finite;
+    for (int b = 1; b < B && asc; ++b) asc = beam_angles[b] >= beam_angles[b - 1];
+    h->beams_sorted = asc;
+    // the fan sweep walks outward from the nadir on either side: ascending angles, all within 85 degrees of it
+    h->sweep_angles_ok = asc && B <= 2048 && beam_angles[0] >= -1.4835f && beam_angles[B - 1] <= 1.4835f;
+    h->b_split = 0;
+    while (h->b_split < B && beam_angles[h->b_split] < 0.f) ++h->b_split;
+  }
+  // (the ranges travel with the first launch_mbes of the update: in one copy with the sweep's beam table, or alone)
+  if (ranges) {
+    h->ranges_host.assign(ranges, ranges + B);
+    h->ranges_pending = true;
+  } else {
+    h->ranges_host.clear();
+    h->ranges_pending = false;
+  }
+  return MCL_OK;
+}
+
+// Lanes per particle side of the fan sweep: a small cloud splits a side's beams over 2 or 4 lanes (mcl_sweep.h SUB:
+// each resolves its own run of >= 16 beams, starting at the hit of the run's first beam); the GLOBAL particle count
+// decides, so every shard sums in the same order.
+// (measured, round 3 with the grid's cell walk, the whole fused step in ms -- traversal | sweep with 1 / 2 / 4 lanes per
+//  side, 256 beams:
+//    grid   4 096: 0.086 | 0.095 0.090 0.083     mesh   4 096: 0.079 | 0.097 0.092 0.075
+//    grid   8 192: 0.089 | 0.093 0.085 0.081     mesh   8 192: 0.089 | 0.094 0.090 0.082
+//    grid  32 768: 0.158 | 0.094 0.089 0.087     mesh  32 768: 0.157 | 0.095 0.093 0.088
+//    grid  65 536: 0.154 | 0.100 0.098 0.101     mesh  65 536: 0.153 | 0.099 0.100 0.098
+//    grid 131 072: 0.218 | 0.120 0.125 0.133     mesh 131 072: 0.218 | 0.116 0.122 0.128
+//  below 4 096 the traversal wins (128 particles: 0.059 against 0.067); a later run pays one slanted traversal for its
+//  start; worth it while the chip is not full)
+int sweep_lanes_per_side(const mcl_handle* h, bool with_ranges, int B) {
+  int nsub = 1;
+  if (with_ranges) {
+    if (h->map_kind == 0)
+      nsub = h->ng < 49152 ? 4 : (h->ng < 98304 ? 2 : 1);
+    else if (h->mesh && h->mesh->heights && !h->force_general_mesh)
+      nsub = h->ng < 49152 ? 4 : 1;
+    if (h->env_nsub) nsub = h->env_nsub;
+    while (nsub > 1 && B / (2 * nsub) < 16) nsub >>= 1;
+  }
+  return nsub;
+}
+
+// beam table of the fan sweep: side-signed tangent, secant, measured range, weight; and per beam the sum of the
+// squared normalised residuals against r_max over the beams from it to the end of its side (mcl_sweep.h)
+int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max, int nsub) {
+  // one device block, one copy per update: B records | B tail sums | B measured ranges (for the traversal kernels
+  // that take the hand-overs)
+  const size_t blk_floats = (size_t)B * 7 + 4;   // B records | B tail sums | B measured ranges | first / second tangent of either side | B tail sums per run
+  if (B > h->sweep_cap) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->copy_stream) HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    for (int k = 0; k < 2; ++k) {
+      if (h->sweep_buf[k]) (void)hipFree(h->sweep_buf[k]);
+      if (h->sweep_stage[k]) (void)hipHostFree(h->sweep_stage[k]);
+      h->sweep_buf[k] = nullptr;
+      h->sweep_stage[k] = nullptr;
+      HIPCHK(h, hipMalloc(&h->sweep_buf[k], sizeof(float) * blk_floats));
+      HIPCHK(h, hipHostMalloc(&h->sweep_stage[k], sizeof(float) * blk_floats, hipHostMallocDefault));
+      if (!h->ev_stage[k]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_stage[k], hipEventDisableTiming));
+      h->stage_used[k] = false;
+    }
+    if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    h->sweep_cap = B;
+  }
+  const int sel = (h->sweep_sel ^= 1);
+  h->sweep_beams = h->sweep_buf[sel];
+  h->sweep_tail = (float*)(h->sweep_beams + B);
+  if (h->stage_used[sel]) HIPCHK(h, hipEventSynchronize(h->ev_stage[sel]));   // (two updates old: long complete)
+  struct Blk {   // (the table is built straight into the pinned staging buffer)
+    float* p;
+    float* data() { return p; }
+    float& operator[](size_t k) { return p[k]; }
+  } blk{h->sweep_stage[sel]};
+  float4* tb = (float4*)blk.data();
+  float* tail = blk.data() + (size_t)B * 4;
+  float* rng = tail + B;
+  for (int b = 0; b < B; ++b) tail[b] = 0.f;
+  const float rmaxf = (float)r_max;
+  int nvalid = 0;
+  for (int b = 0; b < B; ++b) {
+    const double ang = (double)h->beam_cache[b];
+    const float rm = (with_ranges && (int)h->ranges_host.size() == B) ? h->ranges_host[b] : 0.f;
+    const bool valid = rm > 0.f;  // NaN fails the test (as in the cast kernels)
+    nvalid += valid ? 1 : 0;
+    // the residual's constants: (range_b - r) w with r = min(t / cos a, r_max) is max(z w - t (w / cos a), (z - r_max) w);
+    // an invalid beam has all three zero.  Expected-range calls (no measured ranges) keep 1 / cos a in .y
+    const double sec = 1.0 / std::cos(ang);
+    // .x: the side-signed tangent of the beam SWEEP_TAN_AHEAD places further out on this beam's side (mcl_sweep.h)
+    {
+      const int nb = b < h->b_split ? b - SWEEP_TAN_AHEAD : b + SWEEP_TAN_AHEAD;
+      tb[b].x = (nb < 0 || nb >= B) ? INFINITY : (float)(std::tan((double)h->beam_cache[nb]) * (b < h->b_split ? -1.0 : 1.0));
+    }
+    tb[b].y = with_ranges ? (valid ? (float)(sec / sigma) : 0.f) : (float)sec;
+    tb[b].z = valid ? (float)((double)rm / sigma) : 0.f;
+    tb[b].w = valid ? (float)(((double)rm - (double)rmaxf) / sigma) : 0.f;
+    rng[b] = rm;
+  }
+  auto miss = [&](int b) { return tb[b].w * tb[b].w; };
+  float run = 0.f;
+  for (int b = B - 1; b >= h->b_split; --b) tail[b] = (run += miss(b));
+  run = 0.f;
+  for (int b = 0; b < h->b_split; ++b) tail[b] = (run += miss(b));
+  // the same sums per RUN of a side's beams (sub-fans: a lane accounts for its own run only; taking them as
+  // differences of the side's sums lost digits when r_max is short and the sums are large)
+  float* tail_run = blk.data() + (size_t)B * 6 + 4;
+  for (int side = 0; side < 2; ++side) {
+    const int nb = side ? h->b_split : B - h->b_split;
+    const int per = nsub > 1 ? std::max((nb + nsub - 1) / nsub, 2) : std::max(nb, 1);
+    for (int first = 0; first < nb; first += per) {
+      const int last = std::min(first + per, nb);
+      float acc = 0.f;
+      for (int k = last - 1; k >= first; --k) {   // k-th beam of the side, counted outward from the nadir
+        const int b = side ? h->b_split - 1 - k : h->b_split + k;
+        tail_run[b] = (acc += miss(b));
+      }
+    }
+  }
+  h->sweep_nvalid = nvalid;
+  for (int k = 0; k < 2; ++k) {
+    const int bp = h->b_split + k, bm = h->b_split - 1 - k;
+    blk[(size_t)B * 6 + 2 * k] = bp < B ? (float)std::tan((double)h->beam_cache[bp]) : INFINITY;
+    blk[(size_t)B * 6 + 2 * k + 1] = bm >= 0 ? (float)(-std::tan((double)h->beam_cache[bm])) : INFINITY;
+  }
+  // the device buffer was last read by the update two before this one; the copy waits for the event of the update
+  // just before (later on the same stream, so certainly enough -- whatever an error path did to the alternation): it
+  // then runs under that step's normalise / scan / gather kernels.  The compute stream waits for the copy.
+  if (h->ev_upd[0] && h->upd_seq >= 1) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_upd[(h->upd_seq - 1) & 3], 0));
+  HIPCHK(h, hipMemcpyAsync(h->sweep_beams, blk.data(), sizeof(float) * blk_floats, hipMemcpyHostToDevice, h->copy_stream));
+  HIPCHK(h, hipEventRecord(h->ev_stage[sel], h->copy_stream));
+  h->stage_used[sel] = true;
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_stage[sel], 0));
+  h->ranges_ptr = h->sweep_tail + B;
+  h->ranges_pending = false;
+  return MCL_OK;
+}
+
+void rot_rpy(double roll, double pitch, double yaw, double R[9]) {
+  double cr = std::cos(roll), sr = std::sin(roll), cp = std::cos(pitch), sp = std::sin(pitch);
+  double cy = std::cos(yaw), sy = std::sin(yaw);
+  R[0] = cy * cp;
+  R[1] = cy * sp * sr - sy * cr;
+  R[2] = cy * sp * cr + sy * sr;
+  R[3] = sy * cp;
+  R[4] = sy * sp * sr + cy * cr;
+  R[5] = sy * sp * cr - cy * sr;
+  R[6] = -sp;
+  R[7] = cp * sr;
+  R[8] = cp * cr;
+}
+
+// Morton visiting order of the particles' pose records (k_mbes_keys): h->mbes_perm
+int sort_visiting_order(mcl_handle* h, const MbesArgs& a) {
+  const size_t n = (size_t)h->n;
+  if (!h->sort_keys) {
+    HIPCHK(h, hipMalloc(&h->sort_keys, sizeof(u32) * n));
+    HIPCHK(h, hipMalloc(&h->sort_keys_out, sizeof(u32) * n));
+    HIPCHK(h, hipMalloc(&h->sort_idx, sizeof(u32) * n));
+    HIPCHK(h, hipMalloc(&h->mbes_perm, sizeof(u32) * n));
+    HIPCHK(h, rocprim::radix_sort_pairs(nullptr, h->sort_tmp_bytes, h->sort_keys, h->sort_keys_out, h->sort_idx,
+                                        h->mbes_perm, n, 0, 24, h->stream));
+    HIPCHK(h, hipMalloc(&h->sort_tmp, h->sort_tmp_bytes));
+  }
+  k_mbes_keys<<<grid_for(h->n), 256, 0, h->stream>>>(a, h->sort_keys, h->sort_idx);
+  // stable LSD radix sort of (key, slot) pairs: the visiting order is deterministic
+  HIPCHK(h, rocprim::radix_sort_pairs(h->sort_tmp, h->sort_tmp_bytes, h->sort_keys, h->sort_keys_out, h->sort_idx,
+                                      h->mbes_perm, n, 0, 24, h->stream));
+  return MCL_OK;
+}
+
+int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max, const double sensor_offset[6],
+                double* lw_out, float* exp_out, long long exp_first, long long exp_count, bool pose_done = false,
+                MbesArgs* args_only = nullptr) {
+  if (h->map_kind < 0) return fail(h, MCL_ERR_STATE, "update_mbes: no map (call mcl_set_map_grid/mesh first)");
+  static const double zero6[6] = {0, 0, 0, 0, 0, 0};
+  const double* so = sensor_offset ? sensor_offset : zero6;
+  MbesArgs a;
+  for (int c = 0; c < 6; ++c) a.st[c] = h->state[h->cur] + (size_t)c * h->n;
+  a.n = h->n;
+  for (int k = 0; k < 12; ++k) a.m2o[k] = h->cfg.m2o[k];
+  for (int k = 0; k < 3; ++k) a.off_t[k] = so[k];
+  rot_rpy(so[3], so[4], so[5], a.off_R);
+  a.beam_sc = h->beam_sc;
+  a.ranges = nullptr;  // (set below, once the ranges are on the device)
+  a.n_beams = B;
+  a.sorted = h->beams_sorted ? 1 : 0;
+  a.b_lo = h->beam_lo;
+  a.b_hi = h->beam_hi;
+  a.inv_sigma = (float)(1.0 / sigma);
+  a.r_max = (float)r_max;
+  a.lognorm = std::log(sigma * std::sqrt(2.0 * MCL_PI));
+  a.lw = lw_out;
+  a.exp_out = exp_out;
+  a.exp_first = exp_first;
+  a.exp_count = exp_count;
+  if (!h->pose_dev) HIPCHK(h, hipMalloc(&h->pose_dev, sizeof(MbesPose) * (size_t)h->n));
+  a.pose = h->pose_dev;
+  memset(&a.mesh, 0, sizeof a.mesh);
+  a.stats = nullptr;
+  a.cells = 0;
+  a.perm = nullptr;
+  a.diag_mode = 0;
+  a.sweep_beams = nullptr;
+  a.sweep_tail = nullptr;
+  a.b_split = 0;
+  a.sweep_nvalid = 0;
+  a.sweep_nsub = 1;
+  a.sweep_tan0 = nullptr;
+  a.sweep_tail_run = nullptr;
+  a.sweep_c2z_min = 2.f;
+  a.sweep_slope = 0.f;
+  a.defer_idx = nullptr;
+  a.defer_count = (int*)(h->ctrl + CTRL_DEFER);
+  a.n_dev = nullptr;
+  a.host_count = nullptr;
+#ifdef MBES_STATS
+  {
+    static unsigned long long* g_stats = nullptr;
+    if (!g_stats) {
+      hipMalloc(&g_stats, 32);
+      hipMemset(g_stats, 0, 32);
+    }
+    unsigned long long hs[4];
+    hipMemcpy(hs, g_stats, 32, hipMemcpyDeviceToHost);
+    if (hs[2]) fprintf(stderr, "[mbes stats] rays %llu steps/ray %.2f tests/ray %.2f retries/ray %.4f\n", hs[2], (double)hs[0] / hs[2], (double)hs[1] / hs[2], (double)hs[3] / hs[2]);
+    hipMemset(g_stats, 0, 32);
+    a.stats = g_stats;
+  }
+#endif
+  if (h->map_kind == 0) {
+    a.grid = h->grid;
+    a.nx = h->gnx;
+    a.ny = h->gny;
+    a.ox = h->gox;
+    a.oy = h->goy;
+    a.inv_res = 1.0 / h->gres;
+    a.res = (float)h->gres;
+    a.zmin_map = h->gzmin;
+    a.zmax_map = h->gzmax;
+  } else {
+    const MeshDev* m = h->mesh;
+    a.mesh = mesh_args(m);
+    a.grid = m->heights;  // non-null: structured mesh (triangulated regular height grid)
+    a.nx = m->gx + 1;
+    a.ny = m->gy + 1;
+    a.ox = m->x0;
+    a.oy = m->y0;
+    a.inv_res = 1.0 / m->cs;
+    a.res = (float)m->cs;
+    a.zmin_map = m->zmin;
+    a.zmax_map = m->zmax;
+    a.diag_mode = m->diag_mode;
+    a.cells = (m->heights && !h->force_general_mesh) ? 0 : 1;
+  }
+  const long long ngroups = (h->n + MBES_WAVES - 1) / MBES_WAVES;
+  const int grid = (int)(ngroups < 4096 ? ngroups : 4096);
+  if (!h->mbes_worklist) HIPCHK(h, hipMalloc(&h->mbes_worklist, sizeof(int) * (size_t)(ngroups + 1)));
+  if (!h->mbes_groups) HIPCHK(h, hipMalloc(&h->mbes_groups, sizeof(MbesGroup) * (size_t)ngroups));
+  a.worklist = h->mbes_worklist;
+  a.groups = h->mbes_groups;
+  a.work_count = (int*)(h->ctrl + CTRL_WORK);
+  // the cast kernels leave max lw in the control block's slots: the normalisation needs no reduction pass
+  a.max_slots = (with_ranges && lw_out == h->lw) ? ctrl_slots(h) : nullptr;
+  // height grids and structured meshes: the pose kernel classifies the groups, k_mbes_fast casts the
+  // eligible ones, k_mbes_cast<.,.,1> the worklist; triangle-record meshes keep the two-mode kernel
+  const bool lean = true;  // every map kind: the pose kernel classifies the groups
+  const bool structured = h->map_kind == 1 && h->mesh->heights && !h->force_general_mesh;
+  // ---- fan sweep (mcl_sweep.h): regularly triangulated meshes, ascending beam angles.  The fan plane may lean
+  // from the vertical only as far as the steepest triangle allows (tan(tilt) * slope < 1, with a margin).
+  if (!pose_done) {
+    // (below ~8 k particles even four lanes per side cannot fill the chip and the wave-per-particle traversal is
+    //  faster -- measured at 128 ... 262 144 particles x 256 / 512 beams; MCL_SWEEP=1 forces it)
+    const bool lattice = h->map_kind == 0 || (structured && (a.diag_mode == 1 || a.diag_mode == 2));
+    const long long sweep_min_n = h->env_sweep == 1 ? 1 : (lattice ? 8192 : 16384);   // (adjacency sweep: one lane per side only)
+    // a height-field TIN with adjacency -- also a triangulated height grid whose cells are split along mixed diagonals
+    // (tin_ok: mesh_build has PROVEN the mesh single-valued over (x, y) -- adjacency, fold and pairwise overlap tests)
+    const bool tin = h->map_kind == 1 && h->mesh->tin_ok && !h->mesh_no_sweep && (!structured || a.diag_mode == 0);
+    bool sweep = ((structured && (a.diag_mode == 1 || a.diag_mode == 2)) || h->map_kind == 0 || tin) && h->sweep_angles_ok && h->env_sweep != 0 &&
+                 h->ng >= sweep_min_n &&  // (the GLOBAL count: every shard of a cloud takes the same path, results do not depend on the GPU count)
+                 h->n < (1ll << 31) && (long long)a.nx * a.ny < (1ll << 30) && a.ny < (1 << 21);
+    h->sweep_now = sweep;
+    if (sweep) {
+      RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max, sweep_lanes_per_side(h, with_ranges, B)));
+    } else if (with_ranges && h->ranges_pending) {
+      RET_IF(upload(h, h->ranges_dev, h->ranges_host.data(), sizeof(float) * (size_t)B));
+      h->ranges_ptr = h->ranges_dev;
+      h->ranges_pending = false;
+    }
+  }
+  a.ranges = with_ranges ? h->ranges_ptr : nullptr;
+  const bool sweep = h->sweep_now;
+  if (sweep) {
+    if (!h->defer_idx) HIPCHK(h, hipMalloc(&h->defer_idx, sizeof(u32) * (size_t)h->n));
+    if (!h->defer_idx2) HIPCHK(h, hipMalloc(&h->defer_idx2, sizeof(u32) * (size_t)h->n));
+    a.sweep_beams = h->sweep_beams;
+    a.sweep_tail = h->sweep_tail;
+    a.b_split = h->b_split;
+    a.sweep_nvalid = h->sweep_nvalid;
+    a.sweep_tan0 = h->sweep_tail + 2 * (size_t)B;
+    a.sweep_tail_run = h->sweep_tail + 2 * (size_t)B + 4;
+    // (grids: 0.45 -- below 0.5 the plane function cannot change sign around a cell's four corners, mcl_sweep.h)
+    const double slope_max = h->map_kind == 0 ? h->gslope_max : h->mesh->slope_max;
+    const double tan_lim = std::min(std::tan(35.0 * MCL_PI / 180.0), (h->map_kind == 0 ? 0.45 : 0.8) / std::max(slope_max, 1e-9));
+    a.sweep_c2z_min = (float)(1.0 / std::sqrt(1.0 + tan_lim * tan_lim));
+    a.sweep_slope = (float)slope_max;
+    a.defer_idx = h->defer_idx;
+  }
+  if (args_only) {
+    *args_only = a;
+    return MCL_OK;
+  }
+  // ---- counters of the update two before this one (deterministic lag, see mcl_handle::work_host)
+  if (!h->work_host) {
+    HIPCHK(h, hipHostMalloc(&h->work_host, 64, hipHostMallocDefault));
+    memset(h->work_host, 0, 64);
+    for (int k = 0; k < 4; ++k) HIPCHK(h, hipEventCreateWithFlags(&h->ev_upd[k], hipEventDisableTiming));
+  }
+  static const int wh_zero[4] = {0, 0, 0, 0};
+  const int* wh_prev = wh_zero;
+  if (h->upd_seq >= 2) {
+    HIPCHK(h, hipEventSynchronize(h->ev_upd[(h->upd_seq - 2) & 3]));
+    wh_prev = h->work_host + 4 * ((h->upd_seq - 2) & 3);
+  }
+  int* wh_cur = h->work_host + 4 * (h->upd_seq & 3);  // (its last user, four updates ago, finished before the event above)
+  wh_cur[0] = wh_cur[1] = wh_cur[2] = wh_cur[3] = 0;
+  struct SeqGuard {  // whatever path returns: this update's kernels are behind its event
+    mcl_handle* h;
+    ~SeqGuard() {
+      (void)hipEventRecord(h->ev_upd[h->upd_seq & 3], h->stream);
+      h->upd_seq++;
+    }
+  } seq_guard{h};
+  t_begin(h, MCL_K_UPDATE_MBES);
+  if (!pose_done) {
+    // (the fused predict has already reset the control block and written poses, group records and worklist)
+    if (a.max_slots)
+      HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_BYTES, h->stream));  // slots + work and hand-over counters (one aligned fill)
+    else
+      HIPCHK(h, hipMemsetAsync(a.work_count, 0, 3 * sizeof(int), h->stream));
+    if (lean && !sweep)
+      k_mbes_pose<true><<<grid_for(h->n), 256, 0, h->stream>>>(a);
+    else
+      k_mbes_pose<false><<<grid_for(h->n), 256, 0, h->stream>>>(a);
+  }
+  if (a.max_slots) h->max_valid = true;
+  a.perm = nullptr;
+  if (sweep) {
+    // The hand-over count of the sweep two updates ago (see work_host).  When it was large (a cloud on the map
+    // border, a fan too tilted for the terrain) the particles are visited in Morton order: the hand-over list
+    // inherits it wave by wave, so the groups of eight the cast kernels form from it share tiles.
+    const bool sort_now = h->env_sort >= 0 ? h->env_sort == 1 : (long long)wh_prev[1] * 16 > h->n;
+    if (sort_now && h->n > MBES_WAVES) {
+      RET_IF(sort_visiting_order(h, a));
+      a.perm = h->mbes_perm;
+    }
+    const int nsub = sweep_lanes_per_side(h, with_ranges, B);
+    a.sweep_nsub = nsub;
+    const int sthreads = nsub == 4 ? 512 : SWEEP_THREADS;
+    const int per_block = sthreads / 64 / (2 * nsub) * 64;
+    // (expected ranges of a few particles: only their lanes are launched)
+    const long long n_part = (!with_ranges && !a.perm) ? std::max<long long>(std::min<long long>(exp_count, h->n - exp_first), 1) : h->n;
+    const int sgrid = (int)((n_part + per_block - 1) / per_block);
+    const size_t lds = (size_t)(B + 2) * sizeof(float4) + (size_t)(B + 4) * sizeof(float);
+    // What the first pass declines goes through a second, bounds-checked pass (lattice maps: a slice that leaves the
+    // map ends there), and what that one declines is cast the old way, in the order of its hand-over list: group
+    // records and worklist (k_mbes_classify), the fast kernel, the general kernel.  All of them read the length of
+    // their list on the device.
+    const bool lattice = h->map_kind == 0 || (structured && a.diag_mode != 0);
+    h->sweep_two_pass = lattice;
+    MbesArgs c = a;   // second pass (always one lane per side: it sees few particles)
+    c.sweep_nsub = 1;
+    c.perm = h->defer_idx;
+    c.n_dev = a.defer_count;
+    c.defer_idx = h->defer_idx2;
+    c.defer_count = (int*)(h->ctrl + CTRL_DEFER2);
+    c.host_count = wh_cur + 2;
+    MbesArgs d = a;   // traversal kernels
+    d.perm = lattice ? h->defer_idx2 : h->defer_idx;
+    d.n_dev = lattice ? c.defer_count : a.defer_count;
+    d.host_count = wh_cur + 1;  // (pinned: the classify kernel stores the count there, no copy on the stream)
+    // (their loops are grid-stride: the grids only set the parallelism.  After an update that handed nothing over
+    //  they are launched small -- three empty 2048-workgroup launches cost 15 us, 2.5 % of the update)
+    const bool few = wh_prev[1] == 0, few2 = wh_prev[2] == 0;
+    const int cgrid = (int)std::min<long long>(grid_for(h->n), few ? 32 : 1024);
+    const int fgrid = (int)std::min<long long>(ngroups, few ? 64 : 2048);
+    const int dgrid = (int)std::min<long long>(ngroups, few ? 64 : 512);
+    const int s2grid = (int)std::min<long long>((h->n + SWEEP_THREADS / 2 - 1) / (SWEEP_THREADS / 2), few2 ? 32 : 4096);
+#define LAUNCH_SWEEP(SURFV, MAPV)                                                        \
+  do {                                                                                   \
+    if (with_ranges) {                                                                   \
+      t_begin(h, MCL_K_MBES_MAIN);                                                       \
+      if (nsub > 1)                                                                      \
+        k_mbes_sweep<SURFV, false, false, true><<<sgrid, sthreads, lds, h->stream>>>(a); \
+      else                                                                               \
+        k_mbes_sweep<SURFV, false, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);  \
+      t_end(h);                                                                          \
+      k_mbes_sweep<SURFV, false, true><<<s2grid, SWEEP_THREADS, lds, h->stream>>>(c);    \
+      k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
+      k_mbes_fast<SURFV, false><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);               \
+      k_mbes_cast<MAPV, false, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);             \
+    } else {                                                                             \
+      k_mbes_sweep<SURFV, true, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);     \
+      k_mbes_sweep<SURFV, true, true><<<s2grid, SWEEP_THREADS, lds, h->stream>>>(c);     \
+      k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
+      k_mbes_fast<SURFV, true><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);                \
+      k_mbes_cast<MAPV, true, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);              \
+    }                                                                                    \
+  } while (0)
+#define LAUNCH_SWEEP_TIN(SURFV, MAPV)                                                    \
+  do {                                                                                   \
+    if (with_ranges) {                                                                   \
+      t_begin(h, MCL_K_MBES_MAIN);                                                       \
+      if (nsub > 1)                                                                      \
+        k_mbes_sweep<5, false, false, true><<<sgrid, sthreads, lds, h->stream>>>(a);     \
+      else                                                                               \
+        k_mbes_sweep<5, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);             \
+      t_end(h);                                                                          \
+      k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
+      k_mbes_fast<SURFV, false><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);               \
+      k_mbes_cast<MAPV, false, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);             \
+    } else {                                                                             \
+      k_mbes_sweep<5, true><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);                \
+      k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
+      k_mbes_fast<SURFV, true><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);                \
+      k_mbes_cast<MAPV, true, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);              \
+    }                                                                                    \
+  } while (0)
+    if (h->map_kind == 0)
+      LAUNCH_SWEEP(0, 0);
+    else if (!structured)
+      LAUNCH_SWEEP_TIN(4, 1);   // hand-overs: triangle records
+    else if (a.diag_mode == 0)
+      LAUNCH_SWEEP_TIN(1, 2);   // hand-overs: node heights with the per-cell diagonal bit
+    else if (a.diag_mode == 1)
+      LAUNCH_SWEEP(2, 2);
+    else
+      LAUNCH_SWEEP(3, 2);
+#undef LAUNCH_SWEEP
+#undef LAUNCH_SWEEP_TIN
+    if (h->env_debug_work) {
+      int cnt = 0;
+      (void)hipMemcpyAsync(&cnt, a.defer_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+      (void)hipStreamSynchronize(h->stream);
+      fprintf(stderr, "[mbes] sweep handed over %d of %lld particles\n", cnt, (long long)h->n);
+    }
+    t_end(h);
+    HIPCHK(h, hipGetLastError());
+    return MCL_OK;
+  }
+  if (lean) {
+    // Dispersed cloud?  The natural-order classification has just counted the groups without a common tile.
+    // That count travels to the host asynchronously and is read one call late (no synchronisation): when the
+    // previous update deferred more than 1/16 of its groups, this one visits the particles in Morton order.
+    const bool sort_now = h->env_sort >= 0 ? h->env_sort == 1 : (long long)wh_prev[0] * 16 > ngroups;
+    HIPCHK(h, hipMemcpyAsync(wh_cur, a.work_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (sort_now && h->n > MBES_WAVES) {
+      RET_IF(sort_visiting_order(h, a));
+      a.perm = h->mbes_perm;
+      HIPCHK(h, hipMemsetAsync(a.work_count, 0, sizeof(int), h->stream));
+      k_mbes_classify<<<grid_for(h->n), 256, 0, h->stream>>>(a);
+    }
+  }
+  const int ggrid = (int)(ngroups < 512 ? ngroups : 512);
+#define LAUNCH_LEAN(SURFV, MAPV)                                                   \
+  do {                                                                             \
+    if (with_ranges) {                                                             \
+      t_begin(h, MCL_K_MBES_MAIN);                                                 \
+      k_mbes_fast<SURFV, false><<<grid, MBES_THREADS, 0, h->stream>>>(a);          \
+      t_end(h);                                                                    \
+      k_mbes_cast<MAPV, false, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);       \
+    } else {                                                                       \
+      k_mbes_fast<SURFV, true><<<grid, MBES_THREADS, 0, h->stream>>>(a);           \
+      k_mbes_cast<MAPV, true, 1><<<ggrid, MBES_THREADS, 0, h->stream>>>(a);        \
+    }                                                                              \
+  } while (0)
+  if (h->map_kind == 0) {
+    LAUNCH_LEAN(0, 0);
+  } else if (structured) {
+    if (a.diag_mode == 1)
+      LAUNCH_LEAN(2, 2);
+    else if (a.diag_mode == 2)
+      LAUNCH_LEAN(3, 2);
+    else
+      LAUNCH_LEAN(1, 2);
+  } else {
+    LAUNCH_LEAN(4, 1);  // triangle records: cell-word tiles
+  }
+#undef LAUNCH_LEAN
+  if (h->env_debug_work) {  // diagnostics: how many groups the fast kernel deferred
+    int cnt = 0;
+    (void)hipMemcpyAsync(&cnt, a.work_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    fprintf(stderr, "[mbes] deferred %d of %lld groups\n", cnt, ngroups);
+    if (lean && cnt > 0) {
+      std::vector<MbesGroup> g((size_t)ngroups);
+      (void)hipMemcpy(g.data(), h->mbes_groups, sizeof(MbesGroup) * (size_t)ngroups, hipMemcpyDeviceToHost);
+      long long why[32] = {0}, area = 0, na = 0;
+      for (const MbesGroup& G : g)
+        if (!G.fast) {
+          why[G.why & 31]++;
+          area += (long long)G.tw * G.th;
+          ++na;
+        }
+      fprintf(stderr, "[mbes] why:");
+      for (int k = 0; k < 32; ++k)
+        if (why[k]) fprintf(stderr, " %d:%lld", k, why[k]);
+      fprintf(stderr, "  mean window of deferred groups %lld nodes\n", na ? area / na : 0);
+    }
+  }
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+
+// a fused step that leaves before its gather: store the z, roll, pitch its predict kernel did not
+int materialise_uniform(mcl_handle* h) {
+  if (!h->uni_deferred) return MCL_OK;
+  h->uni_deferred = false;
+  RET_IF(set_device(h));
+  k_fill_uniform<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, h->uni_val[0],
+                                                             h->uni_val[1], h->uni_val[2]);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+
+// pose_for: when given (fused step, NATIVE rng) the kernel also writes the MBES pose records of the new
+// state; *pose_written tells the caller whether it did (a dt <= 0 step leaves the state untouched)
+int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* replay_normals,
+               const MbesArgs* pose_for = nullptr, bool* pose_written = nullptr, bool defer_uniform = false) {
+  if (pose_written) *pose_written = false;
+  if (!(dt > 0.0)) return MCL_OK;  // auv_pf.py:205 gate
+  double rpy[3];
+  euler_from_quat(od->q, rpy);
+  const double roll = rpy[0], pitch = rpy[1];
+  const double cp = std::cos(pitch), sp = std::sin(pitch), cr = std::cos(roll), sr = std::sin(roll);
+  // M1 = Ry' Rx with the reference's Ry' (auv_particle.py:90-92); rows 0,1 only
+  const double M1r0[3] = {cp, sp * sr, sp * cr};
+  const double M1r1[3] = {0.0, cr, -sr};
+  const double vdt[3] = {od->v[0] * dt, od->v[1] * dt, od->v[2] * dt};
+  PredictArgs a;
+  a.m0 = M1r0[0] * vdt[0] + M1r0[1] * vdt[1] + M1r0[2] * vdt[2];
+  a.m1 = M1r1[0] * vdt[0] + M1r1[1] * vdt[1] + M1r1[2] * vdt[2];
+  a.wzdt = od->w_z * dt;
+  a.z = od->z;
+  a.roll = roll;
+  a.pitch = pitch;
+  a.nz = noise_args(h, h->cfg.process_cov, 1u, h->step_predict);
+  a.zero_ptr = nullptr;
+  a.zero_words = 0;
+  a.skip_uniform = 0;
+  const double* rp = nullptr;
+  if (h->cfg.rng_mode == MCL_RNG_REPLAY) {
+    if (replay_normals) {
+      RET_IF(upload_replay(h, replay_normals));
+      rp = h->replay_dev;
+    } else {
+      for (int c = 0; c < 6; ++c) a.nz.sq[c] = 0.0;  // REPLAY without draws: noise-free
+      rp = nullptr;
+    }
+  }
+  t_begin(h, MCL_K_PREDICT);
+  if (h->cfg.rng_mode == MCL_RNG_REPLAY && !rp) {
+    // noise-free: feed zeros through the native branch with sq = 0
+  }
+  if (pose_for && !rp && h->cfg.rng_mode == MCL_RNG_NATIVE) {
+    const bool lean = !pose_for->sweep_beams;  // the fan sweep needs no group records
+    a.skip_uniform = defer_uniform ? 1 : 0;
+    h->uni_deferred = defer_uniform;
+    if (lean) {
+      // reset the slots + work counter first: the kernel appends the deferred groups to the worklist
+      // (the whole block: ONE aligned fill; the kernel tickets in it are zero between launches anyway)
+      HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_BYTES, h->stream));
+    } else {
+      a.zero_ptr = (unsigned long long*)h->ctrl;   // the kernel's first workgroup zeroes it: no memset launch
+      a.zero_words = CTRL_BYTES / 8;
+    }
+    if (lean)
+      k_predict_pose<true><<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, *pose_for);
+    else
+      k_predict_pose<false><<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, *pose_for);
+    if (pose_written) *pose_written = true;
+  } else {
+    k_predict<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, rp);
+  }
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  h->step_predict++;
+  // every particle now holds the odometry's depth, roll and pitch (both kernels store these three constants)
+  h->uni_valid = true;
+  h->uni_val[0] = a.z;
+  h->uni_val[1] = a.roll;
+  h->uni_val[2] = a.pitch;
+  return MCL_OK;
+}
+
+}  // namespace

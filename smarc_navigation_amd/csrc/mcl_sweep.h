@@ -264,7 +264,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
 #if SWEEP_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);   // (the record's fields are first needed below: the wait for it belongs here)
 #endif
-        // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants (mcl_api.hip:
+        // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants (mcl_host_update.h:
         // upload_sweep_beams): (range_b - r) w = max(z w - t (w / cos a), (z - r_max) w)
         if (EXPECT_ONLY) {
           exp_row[bp - sbeam] = fminf(tau * bm.y, a.r_max);
@@ -582,7 +582,7 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
       }
       return tau;
     };
-    // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants (mcl_api.hip:
+    // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants (mcl_host_update.h:
     // upload_sweep_beams): (range_b - r) w = max(z w - t (w / cos a), (z - r_max) w); then on to the next beam
     const auto take = [&](float tau) {
       if (EXPECT_ONLY) {
@@ -679,8 +679,8 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
 // The same sweep without the lattice: the triangle across an edge comes from the adjacency table built by
 // mesh_build (mcl_mesh.h: two uint4 per triangle -- vertex ids, neighbour ids), nodes are vertex records (x, y, z).
 // Per step: the neighbour's record (32 B), the one vertex of it that is not on the shared edge (16 B, dependent),
-// plane function and in-plane coordinates from map-frame coordinates (the subtraction of the sensor position is done
-// in fp64: vertices are fp32 inputs, the sensor is not).  The walk ends at a mesh border: the map's outer border (the
+// plane function and in-plane coordinates from map-frame coordinates (the sensor position, fp64, is subtracted as an
+// fp32 part and its sub-ulp rest: vertices are fp32 inputs, the sensor is not).  The walk ends at a mesh border: the map's outer border (the
 // beams left return r_max, under the rule of the second pass above) or a hole / ragged outline (hand-over).
 // The start triangle: the (cell, triangle) records of mcl_mesh.h carry their source triangle's index in a spare word.
 __device__ __forceinline__ float tin_nadir(const MbesArgs& a, int I0, int J0, float ul, float vl, float oz, float dx, float dy,
@@ -767,6 +767,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   if (none) return true;
   // plane and in-plane coordinates from (x - Ox, y - Oy, z - Oz) in metres
   const double Ox = ma.x0 + P.um * (double)ma.cs, Oy = ma.y0 + P.vm * (double)ma.cs;
+  const float Oxf = (float)Ox, Oyf = (float)Oy, dOx = (float)(Ox - (double)Oxf), dOy = (float)(Oy - (double)Oyf);
   const float nx_ = P.c1[1] * P.c2[2] - P.c1[2] * P.c2[1], ny_ = P.c1[2] * P.c2[0] - P.c1[0] * P.c2[2],
               nz_ = P.c1[0] * P.c2[1] - P.c1[1] * P.c2[0];
   const float su = sg * P.c1[0], sv = sg * P.c1[1], sz = sg * P.c1[2];
@@ -786,7 +787,9 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   };
   auto node = [&](u32 vid) {
     const float4 v = ma.tin_vert[vid];
-    const float rx = (float)((double)v.x - Ox), ry = (float)((double)v.y - Oy), rz = v.z - oz;
+    // v - O with O = Of + dO split once per lane: the difference of two fp32 numbers a swath apart is exact (or off by
+    // one ulp of a <= 100 m difference), the sub-ulp rest of the sensor position follows -- no fp64 per node
+    const float rx = (v.x - Oxf) - dOx, ry = (v.y - Oyf) - dOy, rz = v.z - oz;
     TinNode N;
     N.id = vid;
     N.d = fmaf(nx_, rx, fmaf(ny_, ry, nz_ * rz));

@@ -77,7 +77,7 @@ def _worker(rank, world, port, n, seed, ret):
 
 
 def _worker_p2p(rank, world, port, n, seed, spread, ret):
-    """The O(n)-per-rank exchange: mcl_api.hip phase_expand_local / exchange_ls / phase_pack / exchange_dupes."""
+    """The O(n)-per-rank exchange: mcl_host_resample.h phase_expand_local / exchange_ls / phase_pack / exchange_dupes."""
     import torch
     import torch.distributed as dist
     from oracle import oracle as orc
