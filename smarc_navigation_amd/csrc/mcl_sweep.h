@@ -55,6 +55,83 @@ __device__ __forceinline__ float hw_max(float x, float y) {
   return r;
 }
 
+// The merge loop of the lattice sweep in assembly (gfx950): the beams of ONE segment (sp, tp) -> (sc, tc), unrolled by
+// two so that the two-deep tangent queue (t0: the pending beam's tangent, t1: the next one's) is consumed and refilled
+// in place -- the compiler's version of the same loop rotates three registers per beam (14 VALU against 12 here; its
+// own unrolling fetches the two records into different registers and copies them back).  The arithmetic is the
+// C++ loop's, instruction for instruction (sweep_side keeps that loop for the sub-fan and expected-range kernels):
+//   e_prev = sp - T tp;  lam = clamp(e_prev / (e_prev - e_cur));  tau = tp + lam dts;
+//   dd = max(z w - tau (w / cos a), (z - r_max) w);  acc += dd^2;  next record;  e_cur = sc - T' tc
+// A lane leaves the loop (its exec bit is cleared) when its pending beam passes beyond the vertex (e_cur < 0 or NaN:
+// the sentinel records end every table); lanes that leave after an odd number of beams swap t0 / t1 at the end.  On
+// exit no fetch is in flight and (bx, by, bz, bw) hold the pending beam's record, bp its LDS byte address.
+// (hazards: the v_rcp result is first read three instructions later; SALU reads of VCC after v_cmp and VALU after a
+//  write of EXEC are interlocked.)
+__device__ __forceinline__ void sweep_merge_asm(float& t0, float& t1, float& acc, unsigned& bp, float e_cur, float& bx,
+                                                float& by, float& bz, float& bw, float sp, float tp, float sc, float tc,
+                                                float dts, int pstep16) {
+  float ep, d;
+  unsigned long long sav, odd, tmp;
+  asm volatile(
+      "s_mov_b64 %[sav], exec\n\t"
+      "s_mov_b64 %[odd], 0\n\t"
+      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"
+      "s_and_b64 exec, exec, vcc\n\t"
+      "s_cbranch_execz 9f\n"
+      "1:\n\t"
+      "v_fma_f32 %[ep], -%[t0], %[tp], %[sp]\n\t"
+      "v_sub_f32 %[d], %[ep], %[ec]\n\t"
+      "v_rcp_f32 %[d], %[d]\n\t"
+      "v_add_u32 %[bp], %[ps], %[bp]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_mov_b32 %[t0], %[bx]\n\t"
+      "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"
+      "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"
+      "v_fma_f32 %[ep], -%[ep], %[by], %[bz]\n\t"
+      "v_max_f32 %[ep], %[ep], %[bw]\n\t"
+      "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"
+      "ds_read_b32 %[bx], %[bp]\n\t"
+      "ds_read_b32 %[by], %[bp] offset:4\n\t"
+      "ds_read_b32 %[bz], %[bp] offset:8\n\t"
+      "ds_read_b32 %[bw], %[bp] offset:12\n\t"
+      "v_fma_f32 %[ec], -%[t1], %[tc], %[sc]\n\t"
+      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"
+      "s_andn2_b64 %[tmp], exec, vcc\n\t"
+      "s_or_b64 %[odd], %[odd], %[tmp]\n\t"
+      "s_and_b64 exec, exec, vcc\n\t"
+      "s_cbranch_execz 9f\n\t"
+      "v_fma_f32 %[ep], -%[t1], %[tp], %[sp]\n\t"
+      "v_sub_f32 %[d], %[ep], %[ec]\n\t"
+      "v_rcp_f32 %[d], %[d]\n\t"
+      "v_add_u32 %[bp], %[ps], %[bp]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_mov_b32 %[t1], %[bx]\n\t"
+      "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"
+      "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"
+      "v_fma_f32 %[ep], -%[ep], %[by], %[bz]\n\t"
+      "v_max_f32 %[ep], %[ep], %[bw]\n\t"
+      "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"
+      "ds_read_b32 %[bx], %[bp]\n\t"
+      "ds_read_b32 %[by], %[bp] offset:4\n\t"
+      "ds_read_b32 %[bz], %[bp] offset:8\n\t"
+      "ds_read_b32 %[bw], %[bp] offset:12\n\t"
+      "v_fma_f32 %[ec], -%[t0], %[tc], %[sc]\n\t"
+      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"
+      "s_and_b64 exec, exec, vcc\n\t"
+      "s_cbranch_execnz 1b\n"
+      "9:\n\t"
+      "s_mov_b64 exec, %[odd]\n\t"
+      "v_mov_b32 %[ep], %[t0]\n\t"
+      "v_mov_b32 %[t0], %[t1]\n\t"
+      "v_mov_b32 %[t1], %[ep]\n\t"
+      "s_mov_b64 exec, %[sav]\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : [t0] "+v"(t0), [t1] "+v"(t1), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur), [bx] "+v"(bx), [by] "+v"(by),
+        [bz] "+v"(bz), [bw] "+v"(bw), [ep] "=&v"(ep), [d] "=&v"(d), [sav] "=&s"(sav), [odd] "=&s"(odd), [tmp] "=&s"(tmp)
+      : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts), [ps] "s"(pstep16)
+      : "vcc");
+}
+
 struct SweepNode {
   int P;        // lattice coordinates relative to the sensor's cell, packed i * 65536 + j (j signed)
   float d;      // signed distance to the fan plane (scaled)
@@ -229,15 +306,25 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   // after it is already on its way from LDS: the table is walked by pointer, one add per beam
   // (record b carries the tangent of the NEXT beam of its side in .x: the decision to leave the merge loop never waits
   //  for the record that has just been requested)
-  const float4* bp = sbeam + ptr;
-  const float4* const bp_end = sbeam + pend;
+  // (by its LDS byte address: the merge loop of the main kernels is assembly, sweep_merge_asm above)
+  const unsigned sb_off = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)sbeam;
+  unsigned bp = sb_off + (unsigned)(ptr * 16);
+  const unsigned bp_end = sb_off + (unsigned)(pend * 16);
+  const int pstep16 = pstep * 16;
   float tcur = stail[a.n_beams + side];   // tan of the pending beam (side-signed)
   float tnext = stail[a.n_beams + 2 + side];  // ... and of the one after it (SWEEP_TAN_AHEAD 2)
   if (SUB && first > 0) {   // (a later run of the side: its tangents are in the records two and one beams back)
-    tcur = bp[-2 * pstep].x;
-    tnext = bp[-pstep].x;
+    tcur = sbeam[ptr - 2 * pstep].x;
+    tnext = sbeam[ptr - pstep].x;
   }
-  float4 bm = bp[0];
+  float bx, by, bz, bw;   // the pending beam's record {tan of the beam 2 ahead, w / cos a, z w, (z - r_max) w}
+  {
+    const float4 r = sbeam[ptr];
+    bx = r.x;
+    by = r.y;
+    bz = r.z;
+    bw = r.w;
+  }
   // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the next triangle.
   // Returns true when the walk is over (all beams resolved, stop distance, map border, failure).
   const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc) -> bool {
@@ -255,32 +342,33 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
       // (no end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0, so e_cur = -inf.  The
       //  loop is rotated: e_cur of the NEXT beam is formed at the end of the body, one compare decides)
       float e_cur = fmaf(-tcur, tc, sc);
-      // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes sign:
-      // <= 0 at prev, >= 0 at cur); then on to the next beam of the table
-      while (e_cur >= 0.f && (!SUB || bp != bp_end)) {   // until the pending beam passes beyond this vertex
-        const float e_prev = fmaf(-tcur, tp, sp);
-        const float lam = __builtin_amdgcn_fmed3f(e_prev * fast_rcp(e_prev - e_cur), 0.f, 1.f);
-        const float tau = fmaf(lam, dts, tp);
-#if SWEEP_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0);   // (the record's fields are first needed below: the wait for it belongs here)
-#endif
-        // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants (mcl_host_update.h:
-        // upload_sweep_beams): (range_b - r) w = max(z w - t (w / cos a), (z - r_max) w)
-        if (EXPECT_ONLY) {
-          exp_row[bp - sbeam] = fminf(tau * bm.y, a.r_max);
-        } else {
-          const float dd = hw_max(fmaf(-tau, bm.y, bm.z), bm.w);
-          acc = fmaf(dd, dd, acc);
+      if (!EXPECT_ONLY && !SUB) {
+        sweep_merge_asm(tcur, tnext, acc, bp, e_cur, bx, by, bz, bw, sp, tp, sc, tc, dts, pstep16);
+      } else {
+        // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes
+        // sign: <= 0 at prev, >= 0 at cur); then on to the next beam of the table
+        while (e_cur >= 0.f && (!SUB || bp != bp_end)) {   // until the pending beam passes beyond this vertex
+          const float e_prev = fmaf(-tcur, tp, sp);
+          const float lam = __builtin_amdgcn_fmed3f(e_prev * fast_rcp(e_prev - e_cur), 0.f, 1.f);
+          const float tau = fmaf(lam, dts, tp);
+          // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants
+          // (mcl_host_update.h: upload_sweep_beams): (range_b - r) w = max(z w - t (w / cos a), (z - r_max) w)
+          if (EXPECT_ONLY) {
+            exp_row[(int)(bp - sb_off) >> 4] = fminf(tau * by, a.r_max);
+          } else {
+            const float dd = hw_max(fmaf(-tau, by, bz), bw);
+            acc = fmaf(dd, dd, acc);
+          }
+          tcur = tnext;
+          tnext = bx;
+          bp += pstep16;
+          const float4 r = sbeam[(int)(bp - sb_off) >> 4];
+          bx = r.x;
+          by = r.y;
+          bz = r.z;
+          bw = r.w;
+          e_cur = fmaf(-tcur, tc, sc);
         }
-#if SWEEP_TAN_AHEAD == 2
-        tcur = tnext;
-        tnext = bm.x;
-#else
-        tcur = bm.x;
-#endif
-        bp += pstep;
-        bm = bp[0];   // (needed a handful of instructions into the next iteration -- not by its loop test)
-        e_cur = fmaf(-tcur, tc, sc);
       }
     }
     if (bp == bp_end) return true;
@@ -329,7 +417,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     if (walk_step(s_cur, t_cur, s_prev, t_prev)) break;
   }
   if (ok && bp != bp_end) {
-    ptr = (int)(bp - sbeam);
+    ptr = (int)(bp - sb_off) >> 4;
     if (EXPECT_ONLY) {
       for (; ptr != pend; ptr += pstep) exp_row[ptr] = a.r_max;
     } else {
