@@ -920,15 +920,25 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   bool ok = true;
   const int max_steps = (int)(6.f * (s_stop + 4.f * res) * inv_res) + 64;  // (triangles may be much smaller than a cell)
   int step = 0;
-  const float4* bp = sbeam + ptr;
-  const float4* const bp_end = sbeam + pend;
+  // (the table is walked by LDS byte address: the merge loop of the main kernel is sweep_merge_asm, as in sweep_side)
+  const unsigned sb_off = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)sbeam;
+  unsigned bp = sb_off + (unsigned)(ptr * 16);
+  const unsigned bp_end = sb_off + (unsigned)(pend * 16);
+  const int pstep16 = pstep * 16;
   float tcur = stail[a.n_beams + side];
   float tnext = stail[a.n_beams + 2 + side];
   if (SUB && first > 0) {
-    tcur = bp[-2 * pstep].x;
-    tnext = bp[-pstep].x;
+    tcur = sbeam[ptr - 2 * pstep].x;
+    tnext = sbeam[ptr - pstep].x;
   }
-  float4 bm = bp[0];
+  float bx, by, bz, bw;   // the pending beam's record
+  {
+    const float4 r = sbeam[ptr];
+    bx = r.x;
+    by = r.y;
+    bz = r.z;
+    bw = r.w;
+  }
   for (;;) {
     // the neighbour's record is in flight while the beams are resolved
     const bool border = nb >= 0xfffffff0u;
@@ -936,28 +946,29 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const uint4 tv3 = ma.tin_tri[2 * tq], tn3 = ma.tin_tri[2 * tq + 1];
     const float dts = t_cur - t_prev;
     float e_cur = fmaf(-tcur, t_cur, s_cur);
-    while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
-      const float e_prev = fmaf(-tcur, t_prev, s_prev);
-      const float lam = __builtin_amdgcn_fmed3f(e_prev * fast_rcp(e_prev - e_cur), 0.f, 1.f);
-      const float tau = fmaf(lam, dts, t_prev);
-#if SWEEP_SCHED_BARRIER
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      if (EXPECT_ONLY) {
-        exp_row[bp - sbeam] = fminf(tau * bm.y, a.r_max);
-      } else {
-        const float dd = hw_max(fmaf(-tau, bm.y, bm.z), bm.w);
-        acc = fmaf(dd, dd, acc);
+    if (!EXPECT_ONLY && !SUB) {
+      sweep_merge_asm(tcur, tnext, acc, bp, e_cur, bx, by, bz, bw, s_prev, t_prev, s_cur, t_cur, dts, pstep16);
+    } else {
+      while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
+        const float e_prev = fmaf(-tcur, t_prev, s_prev);
+        const float lam = __builtin_amdgcn_fmed3f(e_prev * fast_rcp(e_prev - e_cur), 0.f, 1.f);
+        const float tau = fmaf(lam, dts, t_prev);
+        if (EXPECT_ONLY) {
+          exp_row[(int)(bp - sb_off) >> 4] = fminf(tau * by, a.r_max);
+        } else {
+          const float dd = hw_max(fmaf(-tau, by, bz), bw);
+          acc = fmaf(dd, dd, acc);
+        }
+        tcur = tnext;
+        tnext = bx;
+        bp += pstep16;
+        const float4 r = sbeam[(int)(bp - sb_off) >> 4];
+        bx = r.x;
+        by = r.y;
+        bz = r.z;
+        bw = r.w;
+        e_cur = fmaf(-tcur, t_cur, s_cur);
       }
-#if SWEEP_TAN_AHEAD == 2
-      tcur = tnext;
-      tnext = bm.x;
-#else
-      tcur = bm.x;
-#endif
-      bp += pstep;
-      bm = bp[0];
-      e_cur = fmaf(-tcur, t_cur, s_cur);
     }
     if (bp == bp_end) break;
     if (s_cur > s_stop) break;
@@ -997,7 +1008,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     }
   }
   if (ok && bp != bp_end) {
-    ptr = (int)(bp - sbeam);
+    ptr = (int)(bp - sb_off) >> 4;
     if (EXPECT_ONLY) {
       for (; ptr != pend; ptr += pstep) exp_row[ptr] = a.r_max;
     } else {
