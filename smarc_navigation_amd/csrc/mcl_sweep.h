@@ -64,12 +64,16 @@ __device__ __forceinline__ float hw_max(float x, float y) {
 //   dd = max(z w - tau (w / cos a), (z - r_max) w);  acc += dd^2;  next record;  e_cur = sc - T' tc
 // A lane leaves the loop (its exec bit is cleared) when its pending beam passes beyond the vertex (e_cur < 0 or NaN:
 // the sentinel records end every table); lanes that leave after an odd number of beams swap t0 / t1 at the end.  On
-// exit no fetch is in flight and (bx, by, bz, bw) hold the pending beam's record, bp its LDS byte address.
+// exit no fetch is in flight, `rec` holds the pending beam's record and bp its LDS byte address.  The record is pinned
+// to v[60:63] for the duration of the statement (a physical-register constraint): one ds_read_b128 fills it, and its
+// fields are named v60 .. v63 in the text -- inline assembly has no way to name the parts of a register tuple operand,
+// and four ds_read_b32 into free-standing registers cost an 8-way bank conflict each as soon as the lanes of a wave
+// stand at different beams (a cloud that is not collapsed: + 20 % on the sigma = 50 m cloud).
 // (hazards: the v_rcp result is first read three instructions later; SALU reads of VCC after v_cmp and VALU after a
 //  write of EXEC are interlocked.)
-__device__ __forceinline__ void sweep_merge_asm(float& t0, float& t1, float& acc, unsigned& bp, float e_cur, float& bx,
-                                                float& by, float& bz, float& bw, float sp, float tp, float sc, float tc,
-                                                float dts, int pstep16) {
+typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {tan of the beam 2 ahead, w / cos a, z w, (z - r_max) w}
+__device__ __forceinline__ void sweep_merge_asm(float& t0, float& t1, float& acc, unsigned& bp, float e_cur, sweep_rec& rec,
+                                                float sp, float tp, float sc, float tc, float dts, int pstep16) {
   float ep, d;
   unsigned long long sav, odd, tmp;
   asm volatile(
@@ -84,16 +88,13 @@ __device__ __forceinline__ void sweep_merge_asm(float& t0, float& t1, float& acc
       "v_rcp_f32 %[d], %[d]\n\t"
       "v_add_u32 %[bp], %[ps], %[bp]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
-      "v_mov_b32 %[t0], %[bx]\n\t"
+      "v_mov_b32 %[t0], v60\n\t"
       "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"
       "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"
-      "v_fma_f32 %[ep], -%[ep], %[by], %[bz]\n\t"
-      "v_max_f32 %[ep], %[ep], %[bw]\n\t"
+      "v_fma_f32 %[ep], -%[ep], v61, v62\n\t"
+      "v_max_f32 %[ep], %[ep], v63\n\t"
       "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"
-      "ds_read_b32 %[bx], %[bp]\n\t"
-      "ds_read_b32 %[by], %[bp] offset:4\n\t"
-      "ds_read_b32 %[bz], %[bp] offset:8\n\t"
-      "ds_read_b32 %[bw], %[bp] offset:12\n\t"
+      "ds_read_b128 v[60:63], %[bp]\n\t"
       "v_fma_f32 %[ec], -%[t1], %[tc], %[sc]\n\t"
       "v_cmp_le_f32 vcc, 0, %[ec]\n\t"
       "s_andn2_b64 %[tmp], exec, vcc\n\t"
@@ -105,16 +106,13 @@ __device__ __forceinline__ void sweep_merge_asm(float& t0, float& t1, float& acc
       "v_rcp_f32 %[d], %[d]\n\t"
       "v_add_u32 %[bp], %[ps], %[bp]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
-      "v_mov_b32 %[t1], %[bx]\n\t"
+      "v_mov_b32 %[t1], v60\n\t"
       "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"
       "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"
-      "v_fma_f32 %[ep], -%[ep], %[by], %[bz]\n\t"
-      "v_max_f32 %[ep], %[ep], %[bw]\n\t"
+      "v_fma_f32 %[ep], -%[ep], v61, v62\n\t"
+      "v_max_f32 %[ep], %[ep], v63\n\t"
       "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"
-      "ds_read_b32 %[bx], %[bp]\n\t"
-      "ds_read_b32 %[by], %[bp] offset:4\n\t"
-      "ds_read_b32 %[bz], %[bp] offset:8\n\t"
-      "ds_read_b32 %[bw], %[bp] offset:12\n\t"
+      "ds_read_b128 v[60:63], %[bp]\n\t"
       "v_fma_f32 %[ec], -%[t0], %[tc], %[sc]\n\t"
       "v_cmp_le_f32 vcc, 0, %[ec]\n\t"
       "s_and_b64 exec, exec, vcc\n\t"
@@ -126,10 +124,20 @@ __device__ __forceinline__ void sweep_merge_asm(float& t0, float& t1, float& acc
       "v_mov_b32 %[t1], %[ep]\n\t"
       "s_mov_b64 exec, %[sav]\n\t"
       "s_waitcnt lgkmcnt(0)"
-      : [t0] "+v"(t0), [t1] "+v"(t1), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur), [bx] "+v"(bx), [by] "+v"(by),
-        [bz] "+v"(bz), [bw] "+v"(bw), [ep] "=&v"(ep), [d] "=&v"(d), [sav] "=&s"(sav), [odd] "=&s"(odd), [tmp] "=&s"(tmp)
+      : [t0] "+v"(t0), [t1] "+v"(t1), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur), "+{v[60:63]}"(rec),
+        [ep] "=&v"(ep), [d] "=&v"(d), [sav] "=&s"(sav), [odd] "=&s"(odd), [tmp] "=&s"(tmp)
       : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts), [ps] "s"(pstep16)
       : "vcc");
+}
+
+// a * b clamped to [0, 1] by the multiplier's output modifier (NaN -> 0): the same instruction in the C++ merge loops and
+// in sweep_merge_asm, so that every kernel resolves a degenerate beam (0 / 0) alike.  (s_nop: an operand may come
+// straight from v_rcp_f32, and gfx950 wants one instruction between a transcendental and the first use of its result --
+// the compiler's hazard pass cannot see into an asm statement.)
+__device__ __forceinline__ float mul_clamp01(float x, float y) {
+  float r;
+  asm("s_nop 0\n\tv_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(y));
+  return r;
 }
 
 struct SweepNode {
@@ -317,13 +325,13 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     tcur = sbeam[ptr - 2 * pstep].x;
     tnext = sbeam[ptr - pstep].x;
   }
-  float bx, by, bz, bw;   // the pending beam's record {tan of the beam 2 ahead, w / cos a, z w, (z - r_max) w}
+  sweep_rec bm;   // the pending beam's record
   {
     const float4 r = sbeam[ptr];
-    bx = r.x;
-    by = r.y;
-    bz = r.z;
-    bw = r.w;
+    bm.x = r.x;
+    bm.y = r.y;
+    bm.z = r.z;
+    bm.w = r.w;
   }
   // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the next triangle.
   // Returns true when the walk is over (all beams resolved, stop distance, map border, failure).
@@ -343,30 +351,30 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
       //  loop is rotated: e_cur of the NEXT beam is formed at the end of the body, one compare decides)
       float e_cur = fmaf(-tcur, tc, sc);
       if (!EXPECT_ONLY && !SUB) {
-        sweep_merge_asm(tcur, tnext, acc, bp, e_cur, bx, by, bz, bw, sp, tp, sc, tc, dts, pstep16);
+        sweep_merge_asm(tcur, tnext, acc, bp, e_cur, bm, sp, tp, sc, tc, dts, pstep16);
       } else {
         // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes
         // sign: <= 0 at prev, >= 0 at cur); then on to the next beam of the table
         while (e_cur >= 0.f && (!SUB || bp != bp_end)) {   // until the pending beam passes beyond this vertex
           const float e_prev = fmaf(-tcur, tp, sp);
-          const float lam = __builtin_amdgcn_fmed3f(e_prev * fast_rcp(e_prev - e_cur), 0.f, 1.f);
+          const float lam = mul_clamp01(e_prev, fast_rcp(e_prev - e_cur));
           const float tau = fmaf(lam, dts, tp);
           // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants
           // (mcl_host_update.h: upload_sweep_beams): (range_b - r) w = max(z w - t (w / cos a), (z - r_max) w)
           if (EXPECT_ONLY) {
-            exp_row[(int)(bp - sb_off) >> 4] = fminf(tau * by, a.r_max);
+            exp_row[(int)(bp - sb_off) >> 4] = fminf(tau * bm.y, a.r_max);
           } else {
-            const float dd = hw_max(fmaf(-tau, by, bz), bw);
+            const float dd = hw_max(fmaf(-tau, bm.y, bm.z), bm.w);
             acc = fmaf(dd, dd, acc);
           }
           tcur = tnext;
-          tnext = bx;
+          tnext = bm.x;
           bp += pstep16;
           const float4 r = sbeam[(int)(bp - sb_off) >> 4];
-          bx = r.x;
-          by = r.y;
-          bz = r.z;
-          bw = r.w;
+          bm.x = r.x;
+          bm.y = r.y;
+          bm.z = r.z;
+          bm.w = r.w;
           e_cur = fmaf(-tcur, tc, sc);
         }
       }
@@ -931,13 +939,13 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     tcur = sbeam[ptr - 2 * pstep].x;
     tnext = sbeam[ptr - pstep].x;
   }
-  float bx, by, bz, bw;   // the pending beam's record
+  sweep_rec bm;   // the pending beam's record
   {
     const float4 r = sbeam[ptr];
-    bx = r.x;
-    by = r.y;
-    bz = r.z;
-    bw = r.w;
+    bm.x = r.x;
+    bm.y = r.y;
+    bm.z = r.z;
+    bm.w = r.w;
   }
   for (;;) {
     // the neighbour's record is in flight while the beams are resolved
@@ -947,26 +955,26 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const float dts = t_cur - t_prev;
     float e_cur = fmaf(-tcur, t_cur, s_cur);
     if (!EXPECT_ONLY && !SUB) {
-      sweep_merge_asm(tcur, tnext, acc, bp, e_cur, bx, by, bz, bw, s_prev, t_prev, s_cur, t_cur, dts, pstep16);
+      sweep_merge_asm(tcur, tnext, acc, bp, e_cur, bm, s_prev, t_prev, s_cur, t_cur, dts, pstep16);
     } else {
       while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
         const float e_prev = fmaf(-tcur, t_prev, s_prev);
-        const float lam = __builtin_amdgcn_fmed3f(e_prev * fast_rcp(e_prev - e_cur), 0.f, 1.f);
+        const float lam = mul_clamp01(e_prev, fast_rcp(e_prev - e_cur));
         const float tau = fmaf(lam, dts, t_prev);
         if (EXPECT_ONLY) {
-          exp_row[(int)(bp - sb_off) >> 4] = fminf(tau * by, a.r_max);
+          exp_row[(int)(bp - sb_off) >> 4] = fminf(tau * bm.y, a.r_max);
         } else {
-          const float dd = hw_max(fmaf(-tau, by, bz), bw);
+          const float dd = hw_max(fmaf(-tau, bm.y, bm.z), bm.w);
           acc = fmaf(dd, dd, acc);
         }
         tcur = tnext;
-        tnext = bx;
+        tnext = bm.x;
         bp += pstep16;
         const float4 r = sbeam[(int)(bp - sb_off) >> 4];
-        bx = r.x;
-        by = r.y;
-        bz = r.z;
-        bw = r.w;
+        bm.x = r.x;
+        bm.y = r.y;
+        bm.z = r.z;
+        bm.w = r.w;
         e_cur = fmaf(-tcur, t_cur, s_cur);
       }
     }
