@@ -46,6 +46,9 @@
 #ifndef SWEEP_SCHED_BARRIER
 #define SWEEP_SCHED_BARRIER 1
 #endif
+#ifndef SWEEP_MERGE_CXX
+#define SWEEP_MERGE_CXX 0   // 1: every kernel takes the compiler's merge loop (tests/test_gpu_merge_asm.py builds that variant and compares bit for bit)
+#endif
 
 // v_max_f32 as the hardware does it (IEEE maxNum: a NaN operand loses).  fmaxf() adds a canonicalising v_max(x, x) in
 // front of every operand that comes out of memory -- one more instruction in a 12-instruction loop.
@@ -350,7 +353,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
       // (no end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0, so e_cur = -inf.  The
       //  loop is rotated: e_cur of the NEXT beam is formed at the end of the body, one compare decides)
       float e_cur = fmaf(-tcur, tc, sc);
-      if (!EXPECT_ONLY && !SUB) {
+      if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
         sweep_merge_asm(tcur, tnext, acc, bp, e_cur, bm, sp, tp, sc, tc, dts, pstep16);
       } else {
         // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes
@@ -954,7 +957,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const uint4 tv3 = ma.tin_tri[2 * tq], tn3 = ma.tin_tri[2 * tq + 1];
     const float dts = t_cur - t_prev;
     float e_cur = fmaf(-tcur, t_cur, s_cur);
-    if (!EXPECT_ONLY && !SUB) {
+    if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
       sweep_merge_asm(tcur, tnext, acc, bp, e_cur, bm, s_prev, t_prev, s_cur, t_cur, dts, pstep16);
     } else {
       while (e_cur >= 0.f && (!SUB || bp != bp_end)) {

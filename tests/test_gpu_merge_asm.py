@@ -1,0 +1,83 @@
+"""The assembly merge loop of the fan sweep (mcl_sweep.h: sweep_merge_asm -- first pass, bounds-checked pass, TIN) against
+the compiler's build of the same loop: a second library compiled here with -DSWEEP_MERGE_CXX=1 (every kernel takes the
+C++ loop), the same clouds through both, log-weights BIT FOR BIT.  Collapsed and wide clouds (lanes of a wave at the same
+/ at different beams), a cloud hanging over the map border (the second pass and the hand-over to the traversal
+kernels), odd beam counts, invalid beams, the lattice mesh and the irregular TIN."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'smarc_navigation_amd', 'csrc')
+
+_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from smarc_navigation_amd import engine as eng, synth
+out = {}
+origin = (-64.0, -354.0)
+z = synth.bathymetry_grid(708, 708, 1.0, origin, seed=3)
+for kind in ('mesh', 'tin'):
+    if kind == 'mesh':
+        verts, tris = synth.mesh_from_grid(z, 1.0, origin)
+    else:
+        verts, tris = synth.mesh_tin(z, 1.0, origin, seed=7)
+    for n, spread, B, x0 in ((131072, 0.05, 512, 100.0), (65536, 30.0, 301, 100.0), (60000, 300.0, 128, 100.0), (20000, 1.0, 511, -40.0)):
+        rs = np.random.RandomState(3)
+        soa = rs.randn(6, n) * np.array([spread, spread, 0.3, 0.03, 0.03, 1.0])[:, None]
+        soa[0] += x0
+        soa[2] -= 5.0
+        e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+        e.set_map_mesh(verts, tris)
+        e.set_particles(soa)
+        ba = synth.beam_angles(B)
+        ranges = (25.0 / np.cos(ba) + 0.1 * rs.randn(B)).astype(np.float32)
+        ranges[::9] = 0.0
+        e.update_mbes(ranges, ba, 0.2, 100.0)
+        path = e.mbes_last_path()
+        assert path[0] == 1, path
+        out['%%s_%%d_%%g_%%d' %% (kind, n, spread, B)] = e.get_log_weights()
+        out['path_%%s_%%d' %% (kind, n)] = np.array(path)
+        e.close()
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_assembly_merge_loop_equals_the_compilers_bit_for_bit(tmp_path):
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc on this box')
+    variant = str(tmp_path / 'libmcl_cxx_merge.so')
+    subprocess.check_call([hipcc, '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950', '-Wno-unused-function',
+                           '-Wno-bitwise-instead-of-logical', '-fno-slp-vectorize', '-DSWEEP_MERGE_CXX=1', '-o', variant,
+                           os.path.join(CSRC, 'mcl_api.hip'), '-L/opt/rocm/lib', '-lrccl', '-Wl,-rpath,/opt/rocm/lib'])
+    child = str(tmp_path / 'child.py')
+    with open(child, 'w') as f:
+        f.write(_CHILD % {'root': ROOT})
+    res = {}
+    for name, lib in (('asm', None), ('cxx', variant)):
+        env = dict(os.environ)
+        env.pop('MCL_LIB', None)
+        if lib:
+            env['MCL_LIB'] = lib
+        out = str(tmp_path / (name + '.npz'))
+        subprocess.check_call([sys.executable, child, out], env=env)
+        res[name] = np.load(out)
+    keys = [k for k in res['asm'].files if not k.startswith('path_')]
+    assert len(keys) == 8
+    handed = 0
+    for k in res['asm'].files:
+        a, c = res['asm'][k], res['cxx'][k]
+        if k.startswith('path_'):
+            assert np.array_equal(a, c), k
+            handed += int(a[1])
+            continue
+        assert np.isfinite(a).all(), k
+        assert np.array_equal(a, c), '%s: %d of %d log-weights differ (max %.3e)' % (k, (a != c).sum(), a.size, np.abs(a - c).max())
+    assert handed > 1000   # the border clouds really went through the second pass and the traversal kernels
