@@ -43,8 +43,9 @@
 #ifndef SWEEP_TAN_AHEAD
 #define SWEEP_TAN_AHEAD 2   // record b carries the tangent of the beam this many places further out on its side
 #endif
+static_assert(SWEEP_TAN_AHEAD == 2, "the merge loops keep a two-deep tangent queue (tcur, tnext)");
 #ifndef SWEEP_SCHED_BARRIER
-#define SWEEP_SCHED_BARRIER 1
+#define SWEEP_SCHED_BARRIER 1   // (the grid's inner loop: pins the wait for a beam record to its first use)
 #endif
 #ifndef SWEEP_MERGE_CXX
 #define SWEEP_MERGE_CXX 0   // 1: every kernel takes the compiler's merge loop (tests/test_gpu_merge_asm.py builds that variant and compares bit for bit)
