@@ -191,7 +191,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_buf[0], h->sweep_buf[1], h->defer_idx, h->defer_idx2, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_buf[0], h->sweep_buf[1], h->defer_idx, h->reasons_dev, h->grid_pad, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev, h->lsx, h->xsend, h->xrecv};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -279,11 +279,15 @@ int mcl_set_map_grid(mcl_handle* h, const float* z, int32_t nx, int32_t ny, doub
   if (!h || !z || nx < 2 || ny < 2 || !(res > 0.0)) return fail(h, MCL_ERR_INVALID, "set_map_grid: bad argument");
   RET_IF(set_device(h));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (nx > (1 << 21) || ny > (1 << 21)) return fail(h, MCL_ERR_UNSUPPORTED, "set_map_grid: more than 2^21 nodes a side");
   if (h->grid) (void)hipFree(h->grid);
+  if (h->grid_pad) (void)hipFree(h->grid_pad);
   h->grid = nullptr;
+  h->grid_pad = nullptr;
   const size_t cnt = (size_t)nx * (size_t)ny;
   HIPCHK(h, hipMalloc(&h->grid, sizeof(float) * cnt));
   HIPCHK(h, hipMemcpy(h->grid, z, sizeof(float) * cnt, hipMemcpyHostToDevice));
+  HIPCHK(h, upload_padded_heights(z, nx, ny, &h->grid_pad));
   float mn = z[0], mx = z[0];
   for (size_t k = 1; k < cnt; ++k) {
     if (z[k] < mn) mn = z[k];
@@ -1101,10 +1105,10 @@ int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64
   if (!h) return MCL_ERR_INVALID;
   RET_IF(set_device(h));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  int cnt[3] = {0, 0, 0};  // deferred groups, declined by the first sweep pass, declined by the second
+  int cnt[2] = {0, 0};  // groups the fast kernel left to the general one; particles the sweep handed over
   HIPCHK(h, hipMemcpy(cnt, h->ctrl + CTRL_WORK, sizeof cnt, hipMemcpyDeviceToHost));
   if (path) *path = h->sweep_now ? 1 : 0;
-  if (handed_over) *handed_over = h->sweep_now ? (h->sweep_two_pass ? cnt[2] : cnt[1]) : 0;
+  if (handed_over) *handed_over = h->sweep_now ? cnt[1] : 0;
   if (deferred_groups) *deferred_groups = cnt[0];
   return MCL_OK;
 }

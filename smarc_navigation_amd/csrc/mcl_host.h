@@ -33,8 +33,7 @@
 // control block layout (bytes)
 #define CTRL_SLOTS 0                       // MCL_MAX_SLOTS u64
 #define CTRL_WORK (8 * MCL_MAX_SLOTS)      // int: groups deferred by the fast MBES kernel
-#define CTRL_DEFER (CTRL_WORK + 4)         // int: particles the first sweep pass declined
-#define CTRL_DEFER2 (CTRL_WORK + 8)        // int: particles the bounds-checked second pass handed to the traversal kernels
+#define CTRL_DEFER (CTRL_WORK + 4)         // int: particles the fan sweep handed to the general kernel
 #define CTRL_T_QUANT (CTRL_WORK + 12)      // u32 tickets, self-resetting
 #define CTRL_T_EXPAND (CTRL_WORK + 16)
 #define CTRL_T_GATHER (CTRL_WORK + 20)
@@ -100,7 +99,7 @@ struct mcl_handle {
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   // pinned ring of 4 slots x 4 ints, one slot per MBES update: [0] groups the natural-order classification deferred,
-  // [1] particles the sweep handed to the traversal kernels, [2] particles its first pass declined.  An update reads
+  // [1] particles the sweep handed to the general kernel.  An update reads
   // the slot of the update TWO before it, after waiting for that update's event (long since complete when the host
   // runs ahead): the visiting-order and grid-size decisions are a function of the filter's history, never of timing.
   int* work_host = nullptr;
@@ -137,14 +136,14 @@ struct mcl_handle {
   bool stage_used[2] = {false, false};
   int sweep_sel = 0;
   hipStream_t copy_stream = nullptr;
-  u32* defer_idx = nullptr;
-  u32* defer_idx2 = nullptr;        // what the bounds-checked second pass hands on
+  u32* defer_idx = nullptr;         // particles the sweep hands to k_mbes_cast<., ., 2>
+  unsigned* reasons_dev = nullptr;  // -DSWEEP_REASONS builds: why the sweep declined (16 counters)
   int env_sweep = -1;               // MCL_SWEEP=0/1 forces the decision (tests, A/B)
   int env_nsub = 0;                 // MCL_SWEEP_NSUB=1/2/4 forces the lanes per particle side (A/B)
   bool sweep_now = false;           // decided by the first launch_mbes call of an update
-  bool sweep_two_pass = false;      // lattice maps: a bounds-checked second pass precedes the traversal kernels
   int sweep_nvalid = 0;
   float* grid = nullptr;
+  float* grid_pad = nullptr;   // the same heights inside a one-node ring of NaNs (fan sweep: MbesArgs::grid_pad)
   int gnx = 0, gny = 0;
   double gox = 0, goy = 0, gres = 1;
   float gzmin = 0, gzmax = 0;

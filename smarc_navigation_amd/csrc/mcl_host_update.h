@@ -249,6 +249,16 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.defer_count = (int*)(h->ctrl + CTRL_DEFER);
   a.n_dev = nullptr;
   a.host_count = nullptr;
+  a.reasons = nullptr;
+  a.grid_pad = nullptr;
+  a.nyp = 0;
+#ifdef SWEEP_REASONS
+  if (!h->reasons_dev) {
+    HIPCHK(h, hipMalloc(&h->reasons_dev, 64));
+    HIPCHK(h, hipMemset(h->reasons_dev, 0, 64));
+  }
+  a.reasons = h->reasons_dev;
+#endif
 #ifdef MBES_STATS
   {
     static unsigned long long* g_stats = nullptr;
@@ -265,6 +275,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
 #endif
   if (h->map_kind == 0) {
     a.grid = h->grid;
+    a.grid_pad = h->grid_pad;
+    a.nyp = h->gny + 2;
     a.nx = h->gnx;
     a.ny = h->gny;
     a.ox = h->gox;
@@ -277,6 +289,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     const MeshDev* m = h->mesh;
     a.mesh = mesh_args(m);
     a.grid = m->heights;  // non-null: structured mesh (triangulated regular height grid)
+    a.grid_pad = m->heights_pad;
+    a.nyp = m->gy + 3;
     a.nx = m->gx + 1;
     a.ny = m->gy + 1;
     a.ox = m->x0;
@@ -327,7 +341,6 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   const bool sweep = h->sweep_now;
   if (sweep) {
     if (!h->defer_idx) HIPCHK(h, hipMalloc(&h->defer_idx, sizeof(u32) * (size_t)h->n));
-    if (!h->defer_idx2) HIPCHK(h, hipMalloc(&h->defer_idx2, sizeof(u32) * (size_t)h->n));
     a.sweep_beams = h->sweep_beams;
     a.sweep_tail = h->sweep_tail;
     a.b_split = h->b_split;
@@ -372,7 +385,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     if (a.max_slots)
       HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_BYTES, h->stream));  // slots + work and hand-over counters (one aligned fill)
     else
-      HIPCHK(h, hipMemsetAsync(a.work_count, 0, 3 * sizeof(int), h->stream));
+      HIPCHK(h, hipMemsetAsync(a.work_count, 0, 2 * sizeof(int), h->stream));
     if (lean && !sweep)
       k_mbes_pose<true><<<grid_for(h->n), 256, 0, h->stream>>>(a);
     else
@@ -381,98 +394,51 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   if (a.max_slots) h->max_valid = true;
   a.perm = nullptr;
   if (sweep) {
-    // The hand-over count of the sweep two updates ago (see work_host).  When it was large (a cloud on the map
-    // border, a fan too tilted for the terrain) the particles are visited in Morton order: the hand-over list
-    // inherits it wave by wave, so the groups of eight the cast kernels form from it share tiles.
-    const bool sort_now = h->env_sort >= 0 ? h->env_sort == 1 : (long long)wh_prev[1] * 16 > h->n;
-    if (sort_now && h->n > MBES_WAVES) {
-      RET_IF(sort_visiting_order(h, a));
-      a.perm = h->mbes_perm;
-    }
     const int nsub = sweep_lanes_per_side(h, with_ranges, B);
     a.sweep_nsub = nsub;
     const int sthreads = nsub == 4 ? 512 : SWEEP_THREADS;
     const int per_block = sthreads / 64 / (2 * nsub) * 64;
     // (expected ranges of a few particles: only their lanes are launched)
-    const long long n_part = (!with_ranges && !a.perm) ? std::max<long long>(std::min<long long>(exp_count, h->n - exp_first), 1) : h->n;
+    const long long n_part = !with_ranges ? std::max<long long>(std::min<long long>(exp_count, h->n - exp_first), 1) : h->n;
     const int sgrid = (int)((n_part + per_block - 1) / per_block);
     const size_t lds = (size_t)(B + 2) * sizeof(float4) + (size_t)(B + 4) * sizeof(float);
-    // What the first pass declines goes through a second, bounds-checked pass (lattice maps: a slice that leaves the
-    // map ends there), and what that one declines is cast the old way, in the order of its hand-over list: group
-    // records and worklist (k_mbes_classify), the fast kernel, the general kernel.  All of them read the length of
-    // their list on the device.
-    const bool lattice = h->map_kind == 0 || (structured && a.diag_mode != 0);
-    h->sweep_two_pass = lattice;
-    MbesArgs c = a;   // second pass (always one lane per side: it sees few particles)
-    c.sweep_nsub = 1;
-    c.perm = h->defer_idx;
-    c.n_dev = a.defer_count;
-    c.defer_idx = h->defer_idx2;
-    c.defer_count = (int*)(h->ctrl + CTRL_DEFER2);
-    c.host_count = wh_cur + 2;
-    MbesArgs d = a;   // traversal kernels
-    d.perm = lattice ? h->defer_idx2 : h->defer_idx;
-    d.n_dev = lattice ? c.defer_count : a.defer_count;
-    d.host_count = wh_cur + 1;  // (pinned: the classify kernel stores the count there, no copy on the stream)
-    // (their loops are grid-stride: the grids only set the parallelism.  After an update that handed nothing over
-    //  they are launched small -- three empty 2048-workgroup launches cost 15 us, 2.5 % of the update)
-    const bool few = wh_prev[1] == 0, few2 = wh_prev[2] == 0;
-    const int cgrid = (int)std::min<long long>(grid_for(h->n), few ? 32 : 1024);
-    const int fgrid = (int)std::min<long long>(ngroups, few ? 64 : 2048);
-    const int dgrid = (int)std::min<long long>(ngroups, few ? 64 : 512);
-    const int s2grid = (int)std::min<long long>((h->n + SWEEP_THREADS / 2 - 1) / (SWEEP_THREADS / 2), few2 ? 32 : 4096);
-#define LAUNCH_SWEEP(SURFV, MAPV)                                                        \
-  do {                                                                                   \
-    if (with_ranges) {                                                                   \
-      t_begin(h, MCL_K_MBES_MAIN);                                                       \
-      if (nsub > 1)                                                                      \
-        k_mbes_sweep<SURFV, false, false, true><<<sgrid, sthreads, lds, h->stream>>>(a); \
-      else                                                                               \
-        k_mbes_sweep<SURFV, false, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);  \
-      t_end(h);                                                                          \
-      k_mbes_sweep<SURFV, false, true><<<s2grid, SWEEP_THREADS, lds, h->stream>>>(c);    \
-      k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
-      k_mbes_fast<SURFV, false><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);               \
-      k_mbes_cast<MAPV, false, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);             \
-    } else {                                                                             \
-      k_mbes_sweep<SURFV, true, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);     \
-      k_mbes_sweep<SURFV, true, true><<<s2grid, SWEEP_THREADS, lds, h->stream>>>(c);     \
-      k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
-      k_mbes_fast<SURFV, true><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);                \
-      k_mbes_cast<MAPV, true, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);              \
-    }                                                                                    \
-  } while (0)
-#define LAUNCH_SWEEP_TIN(SURFV, MAPV)                                                    \
-  do {                                                                                   \
-    if (with_ranges) {                                                                   \
-      t_begin(h, MCL_K_MBES_MAIN);                                                       \
-      if (nsub > 1)                                                                      \
-        k_mbes_sweep<5, false, false, true><<<sgrid, sthreads, lds, h->stream>>>(a);     \
-      else                                                                               \
-        k_mbes_sweep<5, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);             \
-      t_end(h);                                                                          \
-      k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
-      k_mbes_fast<SURFV, false><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);               \
-      k_mbes_cast<MAPV, false, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);             \
-    } else {                                                                             \
-      k_mbes_sweep<5, true><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);                \
-      k_mbes_classify<<<cgrid, 256, 0, h->stream>>>(d);                                  \
-      k_mbes_fast<SURFV, true><<<fgrid, MBES_THREADS, 0, h->stream>>>(d);                \
-      k_mbes_cast<MAPV, true, 1><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);              \
-    }                                                                                    \
+    // What the sweep declines (mcl_sweep.h: tilt, position, no nadir hit, a border the slice may re-cross) is cast by
+    // the general kernel, one wavefront per particle, in the order of the hand-over list -- whose length it reads on
+    // the device.  TWO launches per update (rounds 2-3: five -- a bounds-checked second sweep pass, classify, fast, cast).
+    MbesArgs d = a;
+    d.perm = h->defer_idx;
+    d.n_dev = a.defer_count;
+    d.host_count = wh_cur + 1;  // (pinned: the kernel stores the count there, no copy on the stream)
+    // (its loop is grid-stride: the grid only sets the parallelism.  After an update that handed nothing over it is
+    //  launched small)
+    const bool few = wh_prev[1] == 0;
+    const int dgrid = (int)std::min<long long>(ngroups, few ? 64 : 4096);
+#define LAUNCH_SWEEP(SURFV, MAPV)                                                      \
+  do {                                                                                 \
+    if (with_ranges) {                                                                 \
+      t_begin(h, MCL_K_MBES_MAIN);                                                     \
+      if (nsub > 1)                                                                    \
+        k_mbes_sweep<SURFV, false, true><<<sgrid, sthreads, lds, h->stream>>>(a);      \
+      else                                                                             \
+        k_mbes_sweep<SURFV, false><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);       \
+      t_end(h);                                                                        \
+      k_mbes_cast<MAPV, false, 2><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);           \
+    } else {                                                                           \
+      k_mbes_sweep<SURFV, true><<<sgrid, SWEEP_THREADS, lds, h->stream>>>(a);          \
+      k_mbes_cast<MAPV, true, 2><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);            \
+    }                                                                                  \
   } while (0)
     if (h->map_kind == 0)
       LAUNCH_SWEEP(0, 0);
     else if (!structured)
-      LAUNCH_SWEEP_TIN(4, 1);   // hand-overs: triangle records
+      LAUNCH_SWEEP(5, 1);   // TIN by adjacency; hand-overs: triangle records
     else if (a.diag_mode == 0)
-      LAUNCH_SWEEP_TIN(1, 2);   // hand-overs: node heights with the per-cell diagonal bit
+      LAUNCH_SWEEP(5, 2);   // mixed diagonals: the adjacency walk; hand-overs: node heights with the per-cell diagonal bit
     else if (a.diag_mode == 1)
       LAUNCH_SWEEP(2, 2);
     else
       LAUNCH_SWEEP(3, 2);
 #undef LAUNCH_SWEEP
-#undef LAUNCH_SWEEP_TIN
     if (h->env_debug_work) {
       int cnt = 0;
       (void)hipMemcpyAsync(&cnt, a.defer_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);

@@ -10,8 +10,18 @@
 //   k_mbes_fast : one WAVEFRONT per particle, lanes = consecutive beams (a fan is coherent: neighbouring lanes walk
 //                 neighbouring cells), MBES_WAVES particles per workgroup share one LDS tile (heights; cell words for
 //                 triangle records); the ray follows the surface's clearance cell by cell (cast_clear).
-//   k_mbes_cast : the general kernel -- groups whose window is clipped by the map border or larger than LDS, sensors
-//                 off the map, global-memory march (cast_ray), triangle records (records_hit).
+//   k_mbes_cast : the general kernel, one wavefront per particle on the map in global memory (L2) -- MODE 1: the groups
+//                 k_mbes_fast left on the worklist (window clipped by the map border or larger than LDS), MODE 2: the
+//                 particles the fan sweep handed over (a.perm[0 .. *a.n_dev)).
+//
+// DETERMINISM RULE (round 4): the log-likelihood of a particle is a pure function of its pose record, the beam table
+// and the map -- never of the particles it happens to be grouped with, of the grid size, of a tile origin or of the
+// order of a hand-over list.  Hence: (i) ray coordinates are relative to the PARTICLE's own cell (own_fan: integer cell
+// + fraction in [0, 1)), tiles and arrays are addressed through a base pointer shifted to that cell; (ii) the water
+// column is skipped down to the MAP's highest point, not a tile's; (iii) which algorithm casts a particle is decided
+// by the particle alone (own_fan::simple: its own fan footprint lies inside the map -> the clearance walk, from LDS or
+// from global memory alike; else the clipped general march).  A sharded filter therefore equals the unsharded one bit
+// for bit on every path, and a hand-over list may be built with atomics.
 // Bound: VALU issue + LDS reads; compulsory HBM traffic is only 48 B + 8 B per particle plus the map tile reads
 // (L2-resident).
 #pragma once
@@ -55,8 +65,7 @@ struct MbesPose {   // 48 B
 struct MbesGroup {   // 32 B
   int tx0, ty0, tw, th;  // window origin and size: nodes (grid / structured mesh)
   int fast;              // 1: k_mbes_fast casts this group; 0: it is on the worklist of the general kernel
-  int why;               // diagnostics (MCL_DEBUG_WORK): 1 no two-beam footprint, 2 clipped by the map border,
-                         // 4 window larger than the LDS tile, 8 a sensor outside the window, 16 no valid fan
+  int why;               // diagnostics (MCL_DEBUG_WORK): 1 a fan that is not simple (own_fan), 4 window larger than the LDS tile
   int pad[2];
 };
 
@@ -85,6 +94,8 @@ struct MbesArgs {
   int sorted;             // 1: beam angles ascend with the beam index
   int b_lo, b_hi;         // indices of the extreme beam angles (span < pi), or -1: scan every beam for the footprint
   const float* grid;      // z[ix*ny + iy]
+  const float* grid_pad;  // fan sweep (lattice maps): the same heights inside a one-node ring of NaNs, (nx + 2) x nyp, node (i, j) at [(i + 1) * nyp + j + 1]; the ring's payload says which border: 1 = an x side, 2 = a y side, 3 = a corner
+  int nyp;                // its pitch: ny + 2
   int nx, ny;             // grid: nodes; mesh: cells + 1
   double ox, oy, inv_res;
   float res;
@@ -116,7 +127,8 @@ struct MbesArgs {
   u32* defer_idx;             // particles the sweep hands over: the visiting order (perm) of the cast kernels that follow it
   int* defer_count;           // device counter, zeroed with the control block
   const int* n_dev;           // when set, the classify / cast kernels visit *n_dev entries of perm instead of a.n
-  int* host_count;            // pinned host word (or nullptr): k_mbes_classify leaves the hand-over count there
+  int* host_count;            // pinned host word (or nullptr): k_mbes_cast<.,.,2> leaves the hand-over count there
+  unsigned* reasons;          // SWEEP_REASONS builds: 16 counters, why the sweep declined a particle side (or nullptr)
 };
 __device__ __forceinline__ long long mbes_count(const MbesArgs& a) { return a.n_dev ? (long long)*a.n_dev : a.n; }
 
@@ -189,75 +201,95 @@ __device__ __forceinline__ PoseXform pose_xform(const MbesArgs& a) {
   T.inv_res = a.inv_res;
   return T;
 }
-// Group classification for the fast cast kernel (height grids and structured meshes).  Called by every
-// lane of a wave with the pose record of "its" particle (lanes 8k..8k+7 = one group).  The footprint of a
-// fan is bounded by its two extreme-angle beams followed down to z_min(map) (planar fan: the end points of
-// all beams at that depth are collinear and ordered by angle); a group is FAST when all its fans have such
-// a footprint, the bounding window is not clipped by the map border, fits the LDS tile and contains every
-// sensor with a cell of margin.  Everything else goes on the worklist of the general kernel.
+// ---- what a particle's own fan needs (the determinism rule above): its cell, the fraction inside it, and the node
+// (cell) window its fan covers.  The footprint of a fan is bounded by its two extreme-angle beams followed down to
+// z_min(map) (planar fan: the end points of all beams at that depth are collinear and ordered by angle).  `simple`:
+// both of them point downward and reach z_min inside r_max, and the window -- one node of margin -- is not clipped by
+// the map border: the clearance walk (cast_clear / cast_fast) then needs no bounds test, and the sensor lies inside
+// the window with a cell of margin by construction.
+struct OwnFan {
+  int I0, J0;              // the sensor's cell (floor of its position in cell units)
+  float ul, vl;            // position inside that cell, [0, 1)
+  int wx0, wy0, wx1, wy1;  // window: nodes (grid / structured mesh) or cells (a.cells), inclusive
+  bool sane;               // finite position within +-1e9 cells
+  bool simple;
+};
+__device__ __forceinline__ OwnFan own_fan(const MbesArgs& a, const MbesPose& P) {
+  OwnFan F;
+  F.sane = fabs(P.um) < 1e9 && fabs(P.vm) < 1e9;  // (NaN: false)
+  const double fu = F.sane ? floor(P.um) : 0.0, fv = F.sane ? floor(P.vm) : 0.0;
+  F.I0 = (int)fu;
+  F.J0 = (int)fv;
+  F.ul = F.sane ? (float)(P.um - fu) : 0.f;
+  F.vl = F.sane ? (float)(P.vm - fv) : 0.f;
+  const float inv_res = (float)a.inv_res;
+  float umin = F.ul, umax = F.ul, vmin = F.vl, vmax = F.vl;
+  bool simple = F.sane && a.b_lo >= 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float2 sc = a.beam_sc[k == 0 ? max(a.b_lo, 0) : max(a.b_hi, 0)];
+    const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
+    const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
+    const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
+    const float t_end = fmaxf((a.zmin_map - P.oz) * __builtin_amdgcn_rcpf(dz), 0.f);
+    simple = simple & (dz < -1e-4f) & (t_end <= a.r_max);
+    const float ue = F.ul + t_end * dx * inv_res, ve = F.vl + t_end * dy * inv_res;
+    umin = fminf(umin, ue);
+    umax = fmaxf(umax, ue);
+    vmin = fminf(vmin, ve);
+    vmax = fmaxf(vmax, ve);
+  }
+  // (a fan that is not simple has no finite footprint: its window is never used)
+  simple = simple & (fmaxf(fmaxf(-umin, umax), fmaxf(-vmin, vmax)) < 1e6f);
+  const int cz = a.cells ? 1 : 0;
+  F.wx0 = F.I0 + (simple ? (int)floorf(umin) : 0) - 1;
+  F.wy0 = F.J0 + (simple ? (int)floorf(vmin) : 0) - 1;
+  F.wx1 = F.I0 + (simple ? (int)floorf(umax) : 0) + 2 - cz;
+  F.wy1 = F.J0 + (simple ? (int)floorf(vmax) : 0) + 2 - cz;
+  const int lim_x = a.nx - 1 - cz, lim_y = a.ny - 1 - cz;
+  F.simple = simple && F.wx0 >= 0 && F.wy0 >= 0 && F.wx1 <= lim_x && F.wy1 <= lim_y;
+  return F;
+}
+
+// Group classification for the fast cast kernel (height grids, structured meshes, cell words of triangle records).
+// Called by every lane of a wave with the pose record of "its" particle (lanes 8k..8k+7 = one group).  A group is FAST
+// when every fan in it is simple (own_fan) and their common window fits the LDS tile; everything else goes on the
+// worklist of the general kernel -- which casts a simple particle with the same arithmetic from global memory, so the
+// grouping decides where the heights are read from and nothing else.
 __device__ __forceinline__ void classify_group(const MbesArgs& a, const MbesPose& P, bool valid, long long i) {
   const int lane = threadIdx.x & 63;
-  const float inv_res = (float)a.inv_res;
-  float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = umin, vmax = umax;
-  bool simple = true;
-  if (valid) {
-    umin = umax = (float)P.um;
-    vmin = vmax = (float)P.vm;
-    simple = a.b_lo >= 0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const float2 sc = a.beam_sc[k == 0 ? max(a.b_lo, 0) : max(a.b_hi, 0)];
-      const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
-      const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
-      const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
-      const float t_end = fmaxf((a.zmin_map - P.oz) * fast_rcp(dz), 0.f);
-      simple = simple & (dz < -1e-4f) & (t_end <= a.r_max);
-      const float ue = (float)P.um + t_end * dx * inv_res, ve = (float)P.vm + t_end * dy * inv_res;
-      umin = fminf(umin, ue);
-      umax = fmaxf(umax, ue);
-      vmin = fminf(vmin, ve);
-      vmax = fmaxf(vmax, ve);
-    }
-  }
+  const OwnFan F = own_fan(a, P);
+  const int BIG = 0x3fffffff;
+  int x0 = (valid && F.simple) ? F.wx0 : BIG, y0 = (valid && F.simple) ? F.wy0 : BIG;
+  int x1 = (valid && F.simple) ? F.wx1 : -BIG, y1 = (valid && F.simple) ? F.wy1 : -BIG;
 #pragma unroll
   for (int o = 1; o < MBES_WAVES; o <<= 1) {
-    umin = fminf(umin, __shfl_xor(umin, o, 64));
-    umax = fmaxf(umax, __shfl_xor(umax, o, 64));
-    vmin = fminf(vmin, __shfl_xor(vmin, o, 64));
-    vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    x0 = min(x0, __shfl_xor(x0, o, 64));
+    y0 = min(y0, __shfl_xor(y0, o, 64));
+    x1 = max(x1, __shfl_xor(x1, o, 64));
+    y1 = max(y1, __shfl_xor(y1, o, 64));
   }
-  // node windows (grid, structured mesh): nx x ny nodes, + 2 so that the far corner of the last cell is inside;
-  // cell windows (triangle records): (nx - 1) x (ny - 1) cells, 8-byte words, 6144 of them in the 48 KiB tile
   const int cz = a.cells ? 1 : 0;
-  const int lim_x = a.nx - 1 - cz, lim_y = a.ny - 1 - cz;
-  const int wx0 = (int)floorf(umin) - 1, wy0 = (int)floorf(vmin) - 1;
-  const int wx1 = (int)floorf(umax) + 2 - cz, wy1 = (int)floorf(vmax) + 2 - cz;
-  const bool clipped = wx0 < 0 || wy0 < 0 || wx1 > lim_x || wy1 > lim_y;
-  const int tx0 = max(wx0, 0), ty0 = max(wy0, 0);
-  const int tw = min(wx1, lim_x) - tx0 + 1, th = min(wy1, lim_y) - ty0 + 1;
-  const bool fits = tw >= 2 - cz && th >= 2 - cz && (long long)tw * th <= (cz ? (MBES_TILE_FLOATS * 3) / 4 : MBES_TILE_FLOATS);
-  const float ul = (float)(P.um - (double)tx0), vl = (float)(P.vm - (double)ty0);
-  const int ncx = tw - 1 + cz, ncy = th - 1 + cz;  // cells in the window
-  const bool inside = !valid || (ul >= 1.f && vl >= 1.f && ul < (float)(ncx - 1) && vl < (float)(ncy - 1));
-  const unsigned long long okm = __ballot(inside && simple);
-  const unsigned grp_bits = (unsigned)(okm >> (lane & ~(MBES_WAVES - 1))) & ((1u << MBES_WAVES) - 1u);
-  const bool fast = (umin <= umax) && !clipped && fits && grp_bits == ((1u << MBES_WAVES) - 1u);
-  const bool leader = (lane & (MBES_WAVES - 1)) == 0 && valid;
-  const unsigned long long sm = __ballot(simple), im = __ballot(inside);  // (diagnostics)
+  const int tw = x1 - x0 + 1, th = y1 - y0 + 1;
+  const bool fits = x0 <= x1 && tw >= 2 - cz && th >= 2 - cz && (long long)tw * th <= (cz ? (MBES_TILE_FLOATS * 3) / 4 : MBES_TILE_FLOATS);
+  const unsigned long long okm = __ballot(!valid || F.simple);
   const unsigned gm = (1u << MBES_WAVES) - 1u;
+  const unsigned grp_bits = (unsigned)(okm >> (lane & ~(MBES_WAVES - 1))) & gm;
+  const bool fast = fits && grp_bits == gm;
+  const bool leader = (lane & (MBES_WAVES - 1)) == 0 && valid;
   if (leader) {
     MbesGroup G;
-    G.tx0 = tx0;
-    G.ty0 = ty0;
+    G.tx0 = x0;
+    G.ty0 = y0;
     G.tw = tw;
     G.th = th;
     G.fast = fast ? 1 : 0;
-    G.why = ((((unsigned)(sm >> (lane & ~(MBES_WAVES - 1))) & gm) != gm) ? 1 : 0) | (clipped ? 2 : 0) | (fits ? 0 : 4) |
-            ((((unsigned)(im >> (lane & ~(MBES_WAVES - 1))) & gm) != gm) ? 8 : 0) | ((umin <= umax) ? 0 : 16);
+    G.why = (grp_bits != gm ? 1 : 0) | (fits ? 0 : 4);   // diagnostics: 1 a fan that is not simple, 4 window larger than the LDS tile
     G.pad[0] = G.pad[1] = 0;
     a.groups[i / MBES_WAVES] = G;
   }
-  // one atomic per wave: the leaders of its deferred groups take consecutive worklist slots
+  // one atomic per wave: the leaders of its deferred groups take consecutive worklist slots (the ORDER of the
+  // worklist only schedules the general kernel: results do not depend on it)
   const unsigned long long dm = __ballot(leader && !fast);
   if (dm) {
     int base = 0;
@@ -471,38 +503,42 @@ __device__ __forceinline__ void cell_zrange(u32 hz, float& zlo, float& zhi) {
 }
 
 // ------------------------------------------------------------------ the ray traversal
-// MAP 0: `tile` holds node heights, pitch th (nodes); window of cw x ch cells.
-// MAP 1: `tile` holds (zmin,zmax) per cell as float2, pitch th (cells).
-// LDS=true: tile is the LDS copy with origin (tx0,ty0); LDS=false: tile is the global array, (0,0).
-template <int MAP, bool LDS>
-__device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th, const MbesArgs& a, int tx0, int ty0,
+// The clipped general march over the WHOLE map in global memory (L2): sensors off the map or at its border, fans that
+// reach beyond it, windows larger than LDS.
+// MAP 0: `map` holds node heights, pitch `pitch` (nodes); MAP 1: (zmin, zmax | record range) words per cell, pitch in
+// cells.  The map covers cw x ch cells.  Coordinates are relative to the particle's own cell (bi, bj) -- u0, v0 in
+// [0, 1), cell indices ix, iy relative to it: the arithmetic does not depend on where the map's origin is.
+template <int MAP>
+__device__ __forceinline__ float cast_ray(const void* __restrict__ map, int pitch, const MbesArgs& a, int bi, int bj,
                                           int cw, int ch, float u0, float v0, float oz, float du, float dv, float dx,
                                           float dy, float dz, float t_lo, float r_max, bool& entry_below, RayStats& rs) {
   entry_below = false;
   STAT_INC(rs.rays);
   float t0 = t_lo, t1 = r_max;
   const float inv_du = du != 0.f ? fast_rcp(du) : 0.f, inv_dv = dv != 0.f ? fast_rcp(dv) : 0.f;
-  // clip to the window [0,cw] x [0,ch]
+  // clip to the map: [-bi, cw - bi] x [-bj, ch - bj] in these coordinates (small integers: exact in fp32)
+  const int ix_lo = -bi, ix_hi = cw - 1 - bi, iy_lo = -bj, iy_hi = ch - 1 - bj;
+  const float ux0 = (float)ix_lo, ux1 = (float)(cw - bi), vy0 = (float)iy_lo, vy1 = (float)(ch - bj);
   if (du == 0.f) {
-    if (u0 < 0.f || u0 > (float)cw) return r_max;
+    if (u0 < ux0 || u0 > ux1) return r_max;
   } else {
-    const float ta = (0.f - u0) * inv_du, tb = ((float)cw - u0) * inv_du;
+    const float ta = (ux0 - u0) * inv_du, tb = (ux1 - u0) * inv_du;
     t0 = fmaxf(t0, fminf(ta, tb));
     t1 = fminf(t1, fmaxf(ta, tb));
   }
   if (dv == 0.f) {
-    if (v0 < 0.f || v0 > (float)ch) return r_max;
+    if (v0 < vy0 || v0 > vy1) return r_max;
   } else {
-    const float ta = (0.f - v0) * inv_dv, tb = ((float)ch - v0) * inv_dv;
+    const float ta = (vy0 - v0) * inv_dv, tb = (vy1 - v0) * inv_dv;
     t0 = fmaxf(t0, fminf(ta, tb));
     t1 = fminf(t1, fmaxf(ta, tb));
   }
   if (!(t0 <= t1)) return r_max;
   const float pu = u0 + t0 * du, pv = v0 + t0 * dv;
-  int ix = min(max((int)floorf(pu), 0), cw - 1);
-  int iy = min(max((int)floorf(pv), 0), ch - 1);
-  if (du < 0.f && ix > 0 && (float)ix >= pu) --ix;
-  if (dv < 0.f && iy > 0 && (float)iy >= pv) --iy;
+  int ix = min(max((int)floorf(pu), ix_lo), ix_hi);
+  int iy = min(max((int)floorf(pv), iy_lo), iy_hi);
+  if (du < 0.f && ix > ix_lo && (float)ix >= pu) --ix;
+  if (dv < 0.f && iy > iy_lo && (float)iy >= pv) --iy;
   const float INF = __builtin_inff();
   const int sx = du > 0.f ? 1 : -1, sy = dv > 0.f ? 1 : -1;
   const float dtx = fabsf(inv_du), dty = fabsf(inv_dv);
@@ -511,12 +547,12 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
   float t_in = t0;
   float z_in = oz + t0 * dz;
   // the entry point only needs the below-the-seabed check when the march does not start above the
-  // tile's highest node (slab start => ray_z(t0) > every height in the window)
+  // map's highest node (slab start => ray_z(t0) > every height)
   bool first = (MAP == 0) && !(t_lo > 0.f && t0 <= t_lo);
   float result = r_max;
   int guard = cw + ch + 4;
   for (;;) {
-    // ---- phase 1: walk cells until one might contain the surface (LDS reject test only)
+    // ---- phase 1: walk cells until one might contain the surface (reject test only)
     bool cand = false;
     float t_out = t1, z_out = z_in;
     float h00 = 0.f, h10 = 0.f, h01 = 0.f, h11 = 0.f;
@@ -527,15 +563,14 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
       z_out = oz + t_out * dz;
       const float zlo = fminf(z_in, z_out);
       if (MAP == 0) {
-        const float* p = LDS ? (const float*)tile + ix * th + iy
-                             : (const float*)tile + (size_t)ix * th + iy;
+        const float* p = (const float*)map + (size_t)(ix + bi) * pitch + (iy + bj);
         h00 = p[0];
         h01 = p[1];
-        h10 = p[th];
-        h11 = p[th + 1];
+        h10 = p[pitch];
+        h11 = p[pitch + 1];
         cand = first || zlo <= fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
       } else {
-        const uint2 ci = LDS ? ((const uint2*)tile)[ix * th + iy] : ((const uint2*)tile)[(size_t)ix * th + iy];
+        const uint2 ci = ((const uint2*)map)[(size_t)(ix + bi) * pitch + (iy + bj)];
         float czlo, czhi;
         cell_zrange(ci.x, czlo, czhi);
         cand = zlo <= czhi + 1e-4f && fmaxf(z_in, z_out) >= czlo - 1e-4f;
@@ -545,7 +580,7 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
       const bool stepx = tnx <= tny;
       ix += stepx ? sx : 0;
       iy += stepx ? 0 : sy;
-      if ((unsigned)ix >= (unsigned)cw || (unsigned)iy >= (unsigned)ch) {  // fp32 slop at the window edge
+      if ((unsigned)(ix + bi) >= (unsigned)cw || (unsigned)(iy + bj) >= (unsigned)ch) {  // fp32 slop at the map edge
         guard = 0;
         break;
       }
@@ -566,7 +601,7 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
       }
       first = false;
     } else {
-      const float t = cell_triangles_hit(a.mesh, tx0 + ix, ty0 + iy, (u0 - (float)ix) * a.mesh.cs,
+      const float t = cell_triangles_hit(a.mesh, ix + bi, iy + bj, (u0 - (float)ix) * a.mesh.cs,
                                          (v0 - (float)iy) * a.mesh.cs, oz, dx, dy, dz, t_out + 1e-4f);
       if (t < INF) {
         result = fminf(t, r_max);
@@ -577,7 +612,7 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
     const bool stepx = tnx <= tny;
     ix += stepx ? sx : 0;
     iy += stepx ? 0 : sy;
-    if ((unsigned)ix >= (unsigned)cw || (unsigned)iy >= (unsigned)ch) break;
+    if ((unsigned)(ix + bi) >= (unsigned)cw || (unsigned)(iy + bj) >= (unsigned)ch) break;
     tnx += stepx ? dtx : 0.f;
     tny += stepx ? 0.f : dty;
     t_in = t_out;
@@ -587,13 +622,14 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ tile, int th,
 }
 
 // ------------------------------------------------------------------ fast traversal (LDS tile)
-// Preconditions (checked per wave by the caller): the tile was not clipped by the map border, and
-// the sensor origin lies inside it with a cell of margin.  The footprint construction then
-// guarantees the ray stays inside the tile until it is below every node (t1), so no window
+// Preconditions (own_fan::simple): the fan's window was not clipped by the map border.  The footprint
+// construction then guarantees the ray stays inside it until it is below every node (t1), so no window
 // clipping and no per-step bounds tests are needed.  ~35 VALU of set-up, ~16 per cell, ~45 per
 // exact patch test (both roots of the patch quadratic at once: crossing and grazing cases).
+// `tile` points at the word of the particle's OWN cell (tx0, ty0) -- in an LDS tile or in the global array alike --,
+// pitch th; u0, v0 in [0, 1) and the cell indices are relative to that cell (the determinism rule).
 template <int MAP>
-__device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int th, int tw, const MbesArgs& a, int tx0,
+__device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int th, const MbesArgs& a, int tx0,
                                            int ty0, float u0, float v0, float oz, float du, float dv, float dz,
                                            float zmax, float r_max, RayStats& rs) {
   STAT_INC(rs.rays);
@@ -702,7 +738,7 @@ __device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int t
       const u32 rs0 = ci.y & 0x7ffffffu;
       u32 cnt = ci.y >> 27;
       if (cnt == 31u) {
-        if ((unsigned)ix >= (unsigned)tw || (unsigned)iy >= (unsigned)th) return r_max;
+        if ((unsigned)(tx0 + ix) >= (unsigned)a.mesh.gx || (unsigned)(ty0 + iy) >= (unsigned)a.mesh.gy) return r_max;
         const size_t c = (size_t)(tx0 + ix) * a.mesh.gy + (ty0 + iy);
         cnt = a.mesh.cell_start[c + 1] - a.mesh.cell_start[c];
       }
@@ -723,8 +759,9 @@ __device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int t
   return r_max;
 }
 
-// ------------------------------------------------------------------ clearance traversal (LDS tile)
-// Same preconditions as cast_fast.  ONE loop, no separate exact test: the ray is followed cell by cell in
+// ------------------------------------------------------------------ clearance traversal (LDS tile or global array)
+// Same preconditions and conventions as cast_fast: `tile` points at the node (I0, J0) of the particle's own cell, u0, v0
+// are the fractions inside it, zmax is the MAP's highest point.  ONE loop, no separate exact test: the ray is followed cell by cell in
 // its own "forward" frame (a', b' grow along the ray in both axes, F00 is the corner it enters by, F11 the
 // one it leaves by), carrying the clearance g = z_ray - h at the cell border it has just crossed.  Heights
 // along cell EDGES are linear for bilinear patches and for either triangulation, so g at the exit point is
@@ -891,39 +928,31 @@ __device__ __forceinline__ float cast_clear(const float* __restrict__ tile, int 
   return root <= r_max ? fmaxf(root, 0.f) : r_max;
 }
 
-// ------------------------------------------------------------------ the cast kernel
-// MODE 0: fast traversal only -- a workgroup whose tile is clipped by the map border, does not fit LDS
-//         or whose sensors are not inside it appends its group id to a.worklist and returns; this
-//         keeps the hot kernel free of the general code's registers (no scratch spills).
-// MODE 1: general traversal over the groups listed in a.worklist (usually none: map borders, wide clouds).
+// ------------------------------------------------------------------ the general cast kernel
+// One wavefront per particle, lanes = consecutive beams, the map in global memory (L2); no LDS, no barriers.
+// MODE 1: the groups k_mbes_fast left on a.worklist (window larger than LDS, a fan that is not simple).
+// MODE 2: the particles a.perm[0 .. *a.n_dev) -- the fan sweep's hand-over list, in any order.
+// Per particle (own_fan): a simple fan is cast by the clearance walk -- the arithmetic of k_mbes_fast, from the global
+// array instead of an LDS tile, bit for bit the same result --, everything else by the clipped general march.
 template <int MAP, bool EXPECT_ONLY, int MODE>
-__global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 ? MBES_MIN_WAVES_MESH - 1 : (MODE == 1 ? MBES_MIN_WAVES_MESH : MBES_MIN_WAVES_PER_SIMD)))
-    k_mbes_cast(MbesArgs a) {
-  // general mesh tiles hold 8-byte cell words and run 3 workgroups per CU: give them 48 KiB
-  constexpr int TILE_FLOATS = MAP == 1 ? (MBES_TILE_FLOATS * 3) / 2 : MBES_TILE_FLOATS;
-  __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS];
-  __shared__ float red[5][MBES_WAVES];  // umin, umax, vmin, vmax, zmax per wave
-
+__global__ void __launch_bounds__(MBES_THREADS, MAP == 1 ? MBES_MIN_WAVES_MESH - 1 : MBES_MIN_WAVES_MESH) k_mbes_cast(MbesArgs a) {
+  static_assert(MODE == 1 || MODE == 2, "MODE 1: worklist of groups, MODE 2: list of particles");
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long long ngroups = (mbes_count(a) + MBES_WAVES - 1) / MBES_WAVES;
-  const float inv_res = (float)a.inv_res;
-  // window limits: grid nodes nx x ny; mesh cells (nx-1) x (ny-1)
-  const int lim_x = MAP != 1 ? a.nx - 1 : a.nx - 2, lim_y = MAP != 1 ? a.ny - 1 : a.ny - 2;
-  const int tile_cap = MAP != 1 ? TILE_FLOATS : TILE_FLOATS / 2;
-
   const long long n_eff = mbes_count(a);
+  if (MODE == 2 && a.host_count && blockIdx.x == 0 && threadIdx.x == 0) *a.host_count = (int)n_eff;  // (read by the host two updates later)
+  const float inv_res = (float)a.inv_res;
   const u32* perm = a.perm;
-  const long long nwork = MODE == 1 ? (long long)*a.work_count : ngroups;
+  const long long nwork = MODE == 1 ? (long long)*a.work_count : (n_eff + MBES_WAVES - 1) / MBES_WAVES;
   double wmax = -__builtin_inf();  // lane 0: largest log-likelihood this wave has written
   for (long long it = blockIdx.x; it < nwork; it += gridDim.x) {
     const long long grp = MODE == 1 ? (long long)a.worklist[it] : it;
     const long long j = grp * MBES_WAVES + w;  // position in the visiting order
-    const bool valid = j < n_eff;
-    const long long i = (valid && perm) ? (long long)perm[j] : j;  // the particle
+    if (j >= n_eff) continue;
+    const long long i = perm ? (long long)perm[j] : j;  // the particle
     MbesPose P;
-    if (valid) {
-      // the record is wave-uniform: pin it in SGPRs (frees ~11 VGPRs per lane)
+    {
+      // the record is wave-uniform: pin it in SGPRs
       const MbesPose Pv = a.pose[i];
       P.um = uniform_f64(Pv.um);
       P.vm = uniform_f64(Pv.vm);
@@ -934,221 +963,40 @@ __global__ void __launch_bounds__(MBES_THREADS, (MAP == 1 ? MBES_MIN_WAVES_MESH 
         P.c2[r] = uniform_f32(Pv.c2[r]);
       }
     }
-    // ---- footprint of this wave's fan (global cell units)
-    float umin = __builtin_inff(), umax = -__builtin_inff(), vmin = umin, vmax = umax;
-    if (valid) {
-      umin = umax = (float)P.um;
-      vmin = vmax = (float)P.vm;
-      // The fan is planar, so the points where its beams reach depth z_min(map) are collinear and
-      // ordered by beam angle: the two extreme-angle beams bound the footprint, provided both point
-      // downward and reach z_min before r_max (then every beam between them does too).
-      // A height grid is a solid below its surface: a ray that comes in from OUTSIDE the map below the
-      // seabed hits at its entry point (oracle: orc_ray_grid), possibly deeper than z_min.  For a sensor
-      // off the map the footprint therefore runs to r_max along every beam (an arc, not a segment: no
-      // two-beam shortcut).  Meshes have no side walls, their footprint stops at z_min.
-      const bool off_map = MAP == 0 && !(P.um >= 0.0 && P.um <= (double)(a.nx - 1) && P.vm >= 0.0 && P.vm <= (double)(a.ny - 1));
-      bool simple = a.b_lo >= 0 && !off_map;
-      float ue[2], ve[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const float2 sc = a.beam_sc[k == 0 ? max(a.b_lo, 0) : max(a.b_hi, 0)];
-        const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
-        const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
-        const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
-        const float t_end = fmaxf((a.zmin_map - P.oz) * fast_rcp(dz), 0.f);
-        simple = simple && dz < -1e-4f && t_end <= a.r_max;
-        ue[k] = (float)P.um + t_end * dx * inv_res;
-        ve[k] = (float)P.vm + t_end * dy * inv_res;
-      }
-      if (simple) {
-        umin = fminf(umin, fminf(ue[0], ue[1]));
-        umax = fmaxf(umax, fmaxf(ue[0], ue[1]));
-        vmin = fminf(vmin, fminf(ve[0], ve[1]));
-        vmax = fmaxf(vmax, fmaxf(ve[0], ve[1]));
-      } else {
-        for (int b = lane; b < a.n_beams; b += 64) {
-          const float2 sc = a.beam_sc[b];
-          const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
-          const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
-          const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
-          float t_end = a.r_max;
-          if (dz < -1e-6f && !off_map) t_end = fminf(t_end, fmaxf((a.zmin_map - P.oz) * fast_rcp(dz), 0.f));
-          const float ub = (float)P.um + t_end * dx * inv_res, vb = (float)P.vm + t_end * dy * inv_res;
-          umin = fminf(umin, ub);
-          umax = fmaxf(umax, ub);
-          vmin = fminf(vmin, vb);
-          vmax = fmaxf(vmax, vb);
-        }
-      }
-    }
-    umin = wave_min(umin);
-    umax = wave_max(umax);
-    vmin = wave_min(vmin);
-    vmax = wave_max(vmax);
-    __syncthreads();  // previous group's tile and red[] fully consumed
-    if (lane == 0) {
-      red[0][w] = umin;
-      red[1][w] = umax;
-      red[2][w] = vmin;
-      red[3][w] = vmax;
-    }
-    __syncthreads();
-    // every wave derives the same tile window (no second barrier)
-    float a0 = red[0][lane & (MBES_WAVES - 1)], a1 = red[1][lane & (MBES_WAVES - 1)];
-    float b0 = red[2][lane & (MBES_WAVES - 1)], b1 = red[3][lane & (MBES_WAVES - 1)];
-#pragma unroll
-    for (int o = MBES_WAVES / 2; o > 0; o >>= 1) {
-      a0 = fminf(a0, __shfl_xor(a0, o, 64));
-      a1 = fmaxf(a1, __shfl_xor(a1, o, 64));
-      b0 = fminf(b0, __shfl_xor(b0, o, 64));
-      b1 = fmaxf(b1, __shfl_xor(b1, o, 64));
-    }
-    int tx0, ty0, tw, th, use, clipped;
-    {
-      // grid: node range; mesh: cell range; clipped to the map, one cell of margin for fp32 slop
-      const int wx0 = (int)floorf(a0) - 1, wy0 = (int)floorf(b0) - 1;
-      const int wx1 = (int)floorf(a1) + (MAP != 1 ? 2 : 1), wy1 = (int)floorf(b1) + (MAP != 1 ? 2 : 1);
-      clipped = (wx0 < 0 || wy0 < 0 || wx1 > lim_x || wy1 > lim_y) ? 1 : 0;
-      tx0 = max(wx0, 0);
-      ty0 = max(wy0, 0);
-      const int tx1 = min(wx1, lim_x);
-      const int ty1 = min(wy1, lim_y);
-      tw = tx1 - tx0 + 1;
-      th = ty1 - ty0 + 1;
-      const int need = MAP != 1 ? 2 : 1;
-      use = (tw >= need && th >= need && (long long)tw * th <= tile_cap) ? 1 : 0;
-      if (!(a0 <= a1) || tw < need || th < need) use = -1;  // no valid fan / fans entirely off the map
-      tx0 = __builtin_amdgcn_readfirstlane(tx0);
-      ty0 = __builtin_amdgcn_readfirstlane(ty0);
-      tw = __builtin_amdgcn_readfirstlane(tw);
-      th = __builtin_amdgcn_readfirstlane(th);
-      use = __builtin_amdgcn_readfirstlane(use);
-      clipped = __builtin_amdgcn_readfirstlane(clipped);
-    }
-    if (MODE == 0) {
-      // block-uniform vote: every valid sensor must sit inside the (unclipped) tile with a cell of margin
-      const float ul = (float)(P.um - (double)tx0), vl = (float)(P.vm - (double)ty0);
-      const int ncx = MAP == 1 ? tw : tw - 1, ncy = MAP == 1 ? th : th - 1;  // cells in the tile
-      const bool inside = !valid || (ul >= 1.f && vl >= 1.f && ul < (float)(ncx - 1) && vl < (float)(ncy - 1));
-      if (lane == 0) red[4][w] = inside ? 1.f : 0.f;
-      __syncthreads();
-      float ok = red[4][lane & (MBES_WAVES - 1)];
-#pragma unroll
-      for (int o = MBES_WAVES / 2; o > 0; o >>= 1) ok = fminf(ok, __shfl_xor(ok, o, 64));
-      const bool all_fast = use == 1 && !clipped && ok > 0.5f;
-      if (!all_fast) {
-        if (use >= 0 && threadIdx.x == 0) a.worklist[atomicAdd(a.work_count, 1)] = (int)grp;
-        if (use < 0 && valid) {  // fans entirely off the map: every beam returns r_max
-          if (EXPECT_ONLY) {
-            if (i >= a.exp_first && i < a.exp_first + a.exp_count)
-              for (int b = lane; b < a.n_beams; b += 64) a.exp_out[(size_t)(i - a.exp_first) * a.n_beams + b] = a.r_max;
-          } else {
-            float acc0 = 0.f;
-            int nv0 = 0;
-            for (int b = lane; b < a.n_beams; b += 64) {
-              const float rm = a.ranges[b];
-              if (rm > 0.f) {
-                const float d = (rm - a.r_max) * a.inv_sigma;
-                acc0 += d * d;
-                ++nv0;
-              }
-            }
-            const double accd0 = wave_sum((double)acc0);
-            const int nvs = wave_sum(nv0);
-            if (lane == 0) {
-              const double v = -0.5 * accd0 - (double)nvs * a.lognorm;
-              a.lw[i] = v;
-              wmax = v > wmax ? v : wmax;
-            }
-          }
-        }
-        continue;  // uniform for the whole workgroup
-      }
-      __syncthreads();  // red[4] is reused for the tile max below
-    }
-    float zmax = a.zmax_map;
-    if (use == 1) {
-      // ---- stage the tile (coalesced along iy) and its max height
-      float m = -__builtin_inff();
-      // rows go to waves, columns to lanes (coalesced along iy, no integer division)
-      if (MAP != 1) {
-        for (int ix = w; ix < tw; ix += MBES_WAVES) {
-          const float* src = a.grid + (size_t)(tx0 + ix) * a.ny + ty0;
-          for (int iy = lane; iy < th; iy += 64) {
-            const float h = src[iy];
-            tile[ix * th + iy] = h;
-            m = fmaxf(m, h);
-          }
-        }
-      } else {
-        uint2* t2 = (uint2*)tile;
-        for (int ix = w; ix < tw; ix += MBES_WAVES) {
-          const uint2* src = a.mesh.cell_info + (size_t)(tx0 + ix) * a.mesh.gy + ty0;
-          for (int iy = lane; iy < th; iy += 64) {
-            const uint2 ci = src[iy];
-            t2[ix * th + iy] = ci;
-            float czlo, czhi;
-            cell_zrange(ci.x, czlo, czhi);
-            m = fmaxf(m, czhi);
-          }
-        }
-      }
-      m = wave_max(m);
-      if (lane == 0) red[4][w] = m;
-      __syncthreads();
-      float mm = red[4][lane & (MBES_WAVES - 1)];
-#pragma unroll
-      for (int o = MBES_WAVES / 2; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
-      zmax = mm;
-    }
-    if (!valid) continue;
-    // ---- cast this particle's beams
+    const OwnFan F = own_fan(a, P);
     float acc = 0.f;
     int nvalid = 0;
-    const float u0 = use == 1 ? (float)(P.um - (double)tx0) : (float)P.um;
-    const float v0 = use == 1 ? (float)(P.vm - (double)ty0) : (float)P.vm;
-    // lanes = consecutive beams (coherent: neighbouring lanes walk neighbouring cells)
     RayStats rs = {0, 0, 0, 0};
-    // MODE 0 reaches this point only with every wave eligible for the fast traversal
     for (int b = lane; b < a.n_beams; b += 64) {
       const float2 sc = a.beam_sc[b];
       const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
       const float dy = sc.x * P.c1[1] - sc.y * P.c2[1];
       const float dz = sc.x * P.c1[2] - sc.y * P.c2[2];
-      float t_lo = 0.f;  // skip the water column above the tile's highest point
-      if (dz < 0.f && P.oz > zmax) t_lo = fmaxf((zmax - P.oz) * fast_rcp(dz) - 1e-3f, 0.f);
       float e;
-      bool below;
-      if (MODE == 0) {
-#ifdef MBES_OLD_FAST
-        e = cast_fast<MAP>(tile, th, tw, a, tx0, ty0, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max, rs);
-#else
-        if (MAP == 0)
-          e = cast_clear<0>(tile, th, a, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max);
-        else if (MAP == 2)
-          e = a.diag_mode == 1 ? cast_clear<2>(tile, th, a, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max)
-            : a.diag_mode == 2 ? cast_clear<3>(tile, th, a, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max)
-                               : cast_clear<1>(tile, th, a, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max);
-        else
-          e = cast_fast<MAP>(tile, th, tw, a, tx0, ty0, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max, rs);
-#endif
-      } else if (MAP == 2) {
-        // structured mesh off the fast path (map border, wide cloud, sweep hand-overs): general mesh march on global memory
-        e = use < 0 ? a.r_max
-                    : cast_ray<1, false>(a.mesh.cell_info, a.mesh.gy, a, 0, 0, a.mesh.gx, a.mesh.gy, (float)P.um,
-                                         (float)P.vm, P.oz, dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
-      } else if (use == 1) {
-        e = cast_ray<(MAP == 2 ? 1 : MAP), true>(tile, th, a, tx0, ty0, MAP == 0 ? tw - 1 : tw, MAP == 0 ? th - 1 : th, u0, v0, P.oz,
-                                dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
-      } else if (use == 0) {
-        if (MAP == 0)
-          e = cast_ray<0, false>(a.grid, a.ny, a, 0, 0, a.nx - 1, a.ny - 1, u0, v0, P.oz, dx * inv_res, dy * inv_res,
-                                   dx, dy, dz, t_lo, a.r_max, below, rs);
-        else
-          e = cast_ray<1, false>(a.mesh.cell_info, a.mesh.gy, a, 0, 0, a.mesh.gx, a.mesh.gy, u0, v0, P.oz,
-                                   dx * inv_res, dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
+      if (!F.sane) {
+        e = a.r_max;  // (NaN / absurd position: every beam misses)
+      } else if (F.simple) {
+        if (MAP == 0) {
+          e = cast_clear<0>(a.grid + ((size_t)F.I0 * a.ny + F.J0), a.ny, a, F.ul, F.vl, P.oz, dx * inv_res, dy * inv_res, dz, a.zmax_map, a.r_max);
+        } else if (MAP == 2) {
+          const float* gp = a.grid + ((size_t)F.I0 * a.ny + F.J0);
+          e = a.diag_mode == 1 ? cast_clear<2>(gp, a.ny, a, F.ul, F.vl, P.oz, dx * inv_res, dy * inv_res, dz, a.zmax_map, a.r_max)
+            : a.diag_mode == 2 ? cast_clear<3>(gp, a.ny, a, F.ul, F.vl, P.oz, dx * inv_res, dy * inv_res, dz, a.zmax_map, a.r_max)
+                               : cast_clear<1>(gp, a.ny, a, F.ul, F.vl, P.oz, dx * inv_res, dy * inv_res, dz, a.zmax_map, a.r_max);
+        } else {
+          e = cast_fast<1>((const float*)(a.mesh.cell_info + ((size_t)F.I0 * a.mesh.gy + F.J0)), a.mesh.gy, a, F.I0, F.J0, F.ul, F.vl,
+                           P.oz, dx * inv_res, dy * inv_res, dz, a.zmax_map, a.r_max, rs);
+        }
       } else {
-        e = a.r_max;
+        float t_lo = 0.f;  // skip the water column above the map's highest point
+        if (dz < 0.f && P.oz > a.zmax_map) t_lo = fmaxf((a.zmax_map - P.oz) * fast_rcp(dz) - 1e-3f, 0.f);
+        bool below;
+        if (MAP == 0)
+          e = cast_ray<0>(a.grid, a.ny, a, F.I0, F.J0, a.nx - 1, a.ny - 1, F.ul, F.vl, P.oz, dx * inv_res, dy * inv_res, dx, dy, dz,
+                          t_lo, a.r_max, below, rs);
+        else  // triangle records (a structured mesh keeps them for exactly this)
+          e = cast_ray<1>(a.mesh.cell_info, a.mesh.gy, a, F.I0, F.J0, a.mesh.gx, a.mesh.gy, F.ul, F.vl, P.oz, dx * inv_res,
+                          dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
       }
       if (EXPECT_ONLY) {
         if (i >= a.exp_first && i < a.exp_first + a.exp_count)
@@ -1203,18 +1051,16 @@ __global__ void __launch_bounds__(MBES_THREADS, SURF == 4 ? MBES_MIN_WAVES_MESH 
   constexpr int TILE_WORDS = CELLS ? (MBES_TILE_FLOATS * 3) / 2 : MBES_TILE_FLOATS;  // 48 KiB of cell words / 32 KiB of heights
   constexpr int TILE_CAP = CELLS ? TILE_WORDS / 2 : TILE_WORDS;
   __shared__ __attribute__((aligned(16))) float tile[TILE_WORDS];
-  __shared__ float red[MBES_WAVES];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long n_eff = mbes_count(a);
   const long long ngroups = (n_eff + MBES_WAVES - 1) / MBES_WAVES;
   const float inv_res = (float)a.inv_res;
   double wmax = -__builtin_inf();  // lane 0: largest log-likelihood this wave has written
-  // the staged tile: origin, size (cw == 0: none yet) and maximum height.  Consecutive groups of a converged
-  // cloud have (nearly) the same window, so the tile is staged with a margin and re-used for as long as the
-  // next group's window lies inside it -- no staging, no barrier, the waves of the workgroup drift freely.
+  // the staged tile: origin and size (cw == 0: none yet).  Consecutive groups of a converged cloud have (nearly) the
+  // same window, so the tile is re-used for as long as the next group's window lies inside it -- no staging, no
+  // barrier, the waves of the workgroup drift freely.  (Which tile a particle is cast from does not change its result.)
   int cx0 = 0, cy0 = 0, cw = 0, ch = 0;
-  float zmax = 0.f;
   for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const MbesGroup G = a.groups[grp];  // uniform address: scalar loads
     if (!G.fast) continue;              // on the general kernel's worklist
@@ -1239,43 +1085,28 @@ __global__ void __launch_bounds__(MBES_THREADS, SURF == 4 ? MBES_MIN_WAVES_MESH 
       cw = ew;
       ch = eh;
       __syncthreads();  // every wave is done with the previous tile
-      // rows to waves, columns to lanes (coalesced along iy); the tile's maximum height on the way
-      float m = -__builtin_inff();
+      // rows to waves, columns to lanes (coalesced along iy)
       if (!CELLS) {
         for (int ix = w; ix < cw; ix += MBES_WAVES) {
           const float* src = a.grid + (size_t)(cx0 + ix) * a.ny + cy0;
-          for (int iy = lane; iy < ch; iy += 64) {
-            const float h = src[iy];
-            tile[ix * ch + iy] = h;
-            m = fmaxf(m, h);
-          }
+          for (int iy = lane; iy < ch; iy += 64) tile[ix * ch + iy] = src[iy];
         }
       } else {
         uint2* t2 = (uint2*)tile;
         for (int ix = w; ix < cw; ix += MBES_WAVES) {
           const uint2* src = a.mesh.cell_info + (size_t)(cx0 + ix) * a.mesh.gy + cy0;
-          for (int iy = lane; iy < ch; iy += 64) {
-            const uint2 ci = src[iy];
-            t2[ix * ch + iy] = ci;
-            float czlo, czhi;
-            cell_zrange(ci.x, czlo, czhi);
-            m = fmaxf(m, czhi);
-          }
+          for (int iy = lane; iy < ch; iy += 64) t2[ix * ch + iy] = src[iy];
         }
       }
-      m = wave_max(m);
-      if (lane == 0) red[w] = m;
       __syncthreads();
-      float mm = red[lane & (MBES_WAVES - 1)];
-#pragma unroll
-      for (int o = MBES_WAVES / 2; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
-      zmax = uniform_f32(mm);
     }
-    const int tx0 = cx0, ty0 = cy0, th = ch;
+    const int th = ch;
     if (!valid) continue;
-    // the pose record is wave-uniform (scalar loads)
+    // the pose record is wave-uniform (scalar loads); coordinates relative to the particle's own cell, the tile
+    // addressed from that cell's word (the determinism rule at the top of this file)
     const MbesPose P = a.pose[i];
-    const float u0 = (float)(P.um - (double)tx0), v0 = (float)(P.vm - (double)ty0);
+    const OwnFan F = own_fan(a, P);
+    const int toff = (F.I0 - cx0) * th + (F.J0 - cy0);
     float acc = 0.f;
     int nvalid = 0;
     for (int b = lane; b < a.n_beams; b += 64) {
@@ -1286,9 +1117,10 @@ __global__ void __launch_bounds__(MBES_THREADS, SURF == 4 ? MBES_MIN_WAVES_MESH 
       float e;
       if (CELLS) {
         RayStats rs = {0, 0, 0, 0};
-        e = cast_fast<1>(tile, th, cw, a, tx0, ty0, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max, rs);
+        e = cast_fast<1>((const float*)((const uint2*)tile + toff), th, a, F.I0, F.J0, F.ul, F.vl, P.oz, dx * inv_res, dy * inv_res, dz,
+                         a.zmax_map, a.r_max, rs);
       } else {
-        e = cast_clear<(CELLS ? 0 : SURF)>(tile, th, a, u0, v0, P.oz, dx * inv_res, dy * inv_res, dz, zmax, a.r_max);
+        e = cast_clear<(CELLS ? 0 : SURF)>(tile + toff, th, a, F.ul, F.vl, P.oz, dx * inv_res, dy * inv_res, dz, a.zmax_map, a.r_max);
       }
       if (EXPECT_ONLY) {
         if (i >= a.exp_first && i < a.exp_first + a.exp_count)

@@ -30,6 +30,7 @@ struct MeshDev {
   size_t n_records = 0;
   // structured mesh (a triangulated regular height grid): node heights, diagonal bit in the LSB
   float* heights = nullptr;  // (gx+1)*(gy+1), or nullptr if the mesh is not structured
+  float* heights_pad = nullptr;  // the same inside a one-node ring of NaNs, (gx+3)*(gy+3) (fan sweep: MbesArgs::grid_pad)
   size_t n_vertical = 0;  // triangles whose xy projection is degenerate (cannot be a height field)
   int diag_mode = 0;      // structured: 1 = every cell split along 00-11, 2 = along 10-01, 0 = mixed (LSB per cell)
   double slope_max = 0;   // steepest triangle, |grad h| (the fan sweep's tilt bound, mcl_sweep.h)
@@ -43,6 +44,29 @@ struct MeshDev {
   bool tin_ok = false;
 };
 
+// The height array of a lattice map inside a one-node ring of quiet NaNs whose payload names the border: 1 = beyond an
+// x side (i = -1 or nx), 2 = beyond a y side, 3 = a corner.  The fan sweep (mcl_sweep.h) walks node by node: stepping
+// off the map it loads a NaN, which ends the walk through the test that ends it anyway -- no bounds test per step.
+inline hipError_t upload_padded_heights(const float* z, int nx, int ny, float** out) {
+  const size_t nyp = (size_t)ny + 2, cnt = ((size_t)nx + 2) * nyp;
+  std::vector<float> pad(cnt);
+  auto nanp = [](uint32_t payload) {
+    const uint32_t b = 0x7fc00000u | payload;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+  };
+  for (size_t i = 0; i < (size_t)nx + 2; ++i)
+    for (size_t j = 0; j < nyp; ++j) {
+      const bool ox = i == 0 || i == (size_t)nx + 1, oy = j == 0 || j == nyp - 1;
+      pad[i * nyp + j] = (ox || oy) ? nanp((ox ? 1u : 0u) | (oy ? 2u : 0u)) : z[(i - 1) * (size_t)ny + (j - 1)];
+    }
+  *out = nullptr;
+  hipError_t e = hipMalloc(out, sizeof(float) * cnt);
+  if (e != hipSuccess) return e;
+  return hipMemcpy(*out, pad.data(), sizeof(float) * cnt, hipMemcpyHostToDevice);
+}
+
 inline void mesh_free(MeshDev* m) {
   if (!m) return;
   if (m->tri) (void)hipFree(m->tri);
@@ -50,6 +74,7 @@ inline void mesh_free(MeshDev* m) {
   if (m->cell_info) (void)hipFree(m->cell_info);
   if (m->tri_mt) (void)hipFree(m->tri_mt);
   if (m->heights) (void)hipFree(m->heights);
+  if (m->heights_pad) (void)hipFree(m->heights_pad);
   if (m->tin_tri) (void)hipFree(m->tin_tri);
   if (m->tin_vert) (void)hipFree(m->tin_vert);
   delete m;
@@ -514,7 +539,8 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
         m->slope_max = std::sqrt(g2) / cs;
       }
       if (hipMalloc(&m->heights, sizeof(float) * hts.size()) != hipSuccess ||
-          hipMemcpy(m->heights, hts.data(), sizeof(float) * hts.size(), hipMemcpyHostToDevice) != hipSuccess) {
+          hipMemcpy(m->heights, hts.data(), sizeof(float) * hts.size(), hipMemcpyHostToDevice) != hipSuccess ||
+          upload_padded_heights(hts.data(), (int)nnx, (int)nny, &m->heights_pad) != hipSuccess) {
         *err = "set_map_mesh: device allocation failed";
         mesh_free(m);
         return MCL_ERR_ALLOC;

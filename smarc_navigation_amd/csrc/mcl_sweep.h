@@ -20,9 +20,17 @@
 // 2-D segment intersection (~19 VALU) instead of a cell-by-cell march (~200 VALU in k_mbes_fast).  No LDS
 // tile, no groups: heights come through L1/L2 (the walks of a converged cloud share their lines).
 //
-// Anything the sweep cannot prove simple -- fan too tilted for the slope bound, footprint not inside the map,
-// no nadir hit inside r_max, a degenerate start triangle -- is handed over, per PARTICLE: the hand-over list is the
-// visiting order of an ordinary k_mbes_classify / k_mbes_fast / k_mbes_cast pass that reads its length on the device.
+// The map border (lattice maps, round 4: ONE pass): the sweep reads a copy of the height array inside a one-node ring
+// of NaNs (MbesArgs::grid_pad).  A walk that steps off the map loads a NaN, its next vertex becomes NaN and the test
+// that ends a walk anyway (`t > 0`) fails -- no bounds test per step.  Only then, outside the loop, the lane asks
+// whether the slice may END there (the beams left return r_max: a mesh has no side walls, a ray from inside a grid
+// never re-enters it); the NaN's payload says which border it was.  Rounds 2-3 ran a second, bounds-checked launch
+// over the particles whose footprint was not inside the map.
+//
+// Anything the sweep cannot prove simple -- fan too tilted for the slope bound, the nadir ray's footprint not inside
+// the map, no nadir hit inside r_max, a degenerate start triangle, a slice that may come back over the border -- is
+// handed over, per PARTICLE, to k_mbes_cast<., ., 2> (one wavefront per particle, reads the list's length on the
+// device).  The ORDER of that list is arbitrary (atomics): every particle's result is a function of the particle alone.
 #pragma once
 #include "mcl_mbes.h"
 
@@ -39,7 +47,15 @@
 #define SWEEP_MIN_WAVES 8   // waves per SIMD the register budget is held to (<= 64 VGPRs)
 #endif
 
-#define SWEEP_FAIL(code) return false  // (code: which test declined -- for a debugger)
+// why a lane declined its particle: 1 position / tilt / footprint, 5 no nadir hit inside r_max, 6-8 degenerate start,
+// 9 sensor under a grid's surface, 10 border the slice may re-cross, 11 step limit, 12 seabed above the horizon,
+// 13 TIN: hole or ragged outline.  -DSWEEP_REASONS counts them in MbesArgs::reasons[code] (tools/sweep_reasons.py).
+#ifdef SWEEP_REASONS
+#define SWEEP_NOTE(code) do { if (a.reasons) atomicAdd(&a.reasons[(code) & 15], 1u); } while (0)
+#else
+#define SWEEP_NOTE(code) ((void)0)
+#endif
+#define SWEEP_FAIL(code) do { SWEEP_NOTE(code); return false; } while (0)
 #ifndef SWEEP_TAN_AHEAD
 #define SWEEP_TAN_AHEAD 2   // record b carries the tangent of the beam this many places further out on its side
 #endif
@@ -153,18 +169,27 @@ struct SweepNode {
 // SURF 2: every cell split along 00-11; SURF 3: along 10-01.  (Height grids, SURF 0: sweep_side_grid below.)
 // Returns false when the particle has to go to the general kernel.  acc: sum over this side's beams of
 // ((range - expected) * weight)^2; EXPECT_ONLY: expected ranges to exp_row[b] instead.
-// CHECKED (second pass, over what the first one declined): the footprint need not lie inside the map -- every node is
-//   tested against the map's bounds, and a slice that leaves the map ENDS there: the beams left return r_max (a mesh
-//   has no side walls; a ray from inside a grid never re-enters it).  That conclusion needs the slice to cross the
-//   border line once: the border's trace in the fan plane must be steeper than the slice can be, which the fan's
-//   tilt, the map's steepest slope and the angle between fan and border decide (see the test in the walk); a level
-//   vehicle always qualifies, a tilted fan slanting along the border over steep terrain goes on to the traversal
-//   kernels, like everything else the second pass declines.
+// The map border: only the nadir ray (cast without bounds tests) has to stay inside the map; a slice that leaves the
+//   map ENDS there (the NaN ring, top of this file): the beams left return r_max.  That conclusion needs the slice to
+//   cross the border line once: the border's trace in the fan plane must be steeper than the slice can be, which the
+//   fan's tilt, the map's steepest slope and the angle between fan and border decide (sweep_border_final); a level
+//   vehicle always qualifies, a tilted fan slanting along the border over steep terrain goes to the traversal kernel.
 // SUB (sub-fans, small clouds): the beams of a side are split over `nsub` lanes; each resolves only its own run of
 //   beams [sub * per, (sub + 1) * per) and starts its walk where the first of them meets the seabed (see the start of
 //   the walk below) -- the walk is a chain of dependent loads, so at 65 536 particles one lane per side leaves the
 //   chip three quarters empty and every lane waiting; four lanes per side fill it, each with a quarter of the walk.
-template <int SURF, bool EXPECT_ONLY, bool CHECKED = false, bool SUB = false>
+// May a slice that has just stepped off the map end there?  h: the NaN it loaded (payload 1: an x side, 2: a y side,
+// 3: a corner).  In plane coordinates the border x = x_b is the line s = s_L + k t with |k| <= sin(tilt) / |c1x|, the
+// slice is t = f(s) with |f'| <= (slope + sin(tilt)) / (cos(tilt) - slope sin(tilt)); they meet once if |k f'| < 1
+// (0.9 here).  c1x, c1y: the map components of the fan's across-track unit vector (sign irrelevant).
+__device__ __forceinline__ bool sweep_border_final(const MbesArgs& a, float h, float c2z, float c1x, float c1y) {
+  const unsigned side = __float_as_uint(h) & 3u;
+  const float sb = fast_sqrt(fmaxf(1.f - c2z * c2z, 0.f));
+  const float lhs = sb * (a.sweep_slope + sb), rhs = 0.9f * (c2z - a.sweep_slope * sb);
+  return (side == 1u || side == 2u) & (lhs < rhs * fabsf(side == 1u ? c1x : c1y));
+}
+
+template <int SURF, bool EXPECT_ONLY, bool SUB = false>
 __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P, const float4* __restrict__ sbeam,
                                            const float* __restrict__ stail, int side, int sub, int nsub,
                                            float* __restrict__ exp_row, float& acc_out) {
@@ -200,29 +225,23 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     const float rc = fast_rcp(c2z);
     const float sl = fabsf(P.c1[2]) * (s_stop + 2.f * res);
     const float t_hi = ((oz - a.zmin_map) + sl) * rc + res, t_lo = fminf(((oz - a.zmax_map) - sl) * rc - res, 0.f);
-    const float s_lo = -2.f * res, s_hi = s_stop + 2.f * res;
+    const float s_hi = s_stop + 2.f * res;
     const float ax = sg * P.c1[0] * inv_res, ay = sg * P.c1[1] * inv_res, bx = -P.c2[0] * inv_res, by = -P.c2[1] * inv_res;
-    const float ux0 = fminf(s_lo * ax, s_hi * ax) + fminf(t_lo * bx, t_hi * bx);
-    const float ux1 = fmaxf(s_lo * ax, s_hi * ax) + fmaxf(t_lo * bx, t_hi * bx);
-    const float vy0 = fminf(s_lo * ay, s_hi * ay) + fminf(t_lo * by, t_hi * by);
-    const float vy1 = fmaxf(s_lo * ay, s_hi * ay) + fmaxf(t_lo * by, t_hi * by);
     const float fi0 = (float)I0, fj0 = (float)J0;
-    if (!CHECKED) {
-      pre = pre & (fi0 + ux0 >= 3.f) & (fi0 + ux1 <= (float)(nx - 5)) & (fj0 + vy0 >= 3.f) & (fj0 + vy1 <= (float)(ny - 5));
-    } else {
-      // only the nadir ray (cast below without bounds tests) has to stay inside: t in [t_lo, t_hi] along -c2
-      const float n0 = fminf(t_lo * bx, t_hi * bx), n1 = fmaxf(t_lo * bx, t_hi * bx);
-      const float m0 = fminf(t_lo * by, t_hi * by), m1 = fmaxf(t_lo * by, t_hi * by);
-      pre = pre & (fi0 + n0 >= 3.f) & (fi0 + n1 <= (float)(nx - 5)) & (fj0 + m0 >= 3.f) & (fj0 + m1 <= (float)(ny - 5));
-    }
+    // only the nadir ray (cast below without bounds tests) has to stay inside: t in [t_lo, t_hi] along -c2
+    const float n0 = fminf(t_lo * bx, t_hi * bx), n1 = fmaxf(t_lo * bx, t_hi * bx);
+    const float m0 = fminf(t_lo * by, t_hi * by), m1 = fmaxf(t_lo * by, t_hi * by);
+    pre = pre & (fi0 + n0 >= 3.f) & (fi0 + n1 <= (float)(nx - 5)) & (fj0 + m0 >= 3.f) & (fj0 + m1 <= (float)(ny - 5));
     pre = pre & (s_hi * fmaxf(fabsf(ax), fabsf(ay)) + fmaxf(-t_lo, t_hi) * fmaxf(fabsf(bx), fabsf(by)) < 30000.f);  // packed coordinates
   }
   if (!pre) SWEEP_FAIL(1);
-  const float* __restrict__ gp = a.grid + ((size_t)I0 * ny + J0);  // node (I0, J0); every access below is inside the footprint
-  const int g0i = I0 * ny + J0;  // (maps below 2^30 nodes: checked on the host)
-  // the height array as a raw buffer (stride 0, num_records in bytes): out-of-range reads return 0
-  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.grid, 0, nx * ny * 4, 0x00020000);
-  const int ny4 = ny * 4, g0b = g0i * 4;
+  // the height array inside its ring of NaNs: pitch nyp = ny + 2, node (i, j) at [(i + 1) * nyp + j + 1]
+  const int nyp = a.nyp;
+  const int g0i = (I0 + 1) * nyp + (J0 + 1);  // (maps below 2^30 nodes: checked on the host)
+  const float* __restrict__ gp = a.grid_pad + (size_t)g0i;  // node (I0, J0)
+  // ... as a raw buffer (stride 0, num_records in bytes): out-of-range reads return 0
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.grid_pad, 0, (nx + 2) * nyp * 4, 0x00020000);
+  const int ny4 = nyp * 4, g0b = g0i * 4;
   // ---- start of the walk: the nadir hit, by the ordinary clearance traversal on the global height array.  A later
   // run of a side's beams (SUB, first > 0) starts where ITS first beam meets the seabed instead -- the same traversal
   // along that beam, a few dozen cells -- and walks on from there: under the tilt bound the slice is a graph over s, so
@@ -235,10 +254,20 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     dxs = sc.x * P.c1[0] - sc.y * P.c2[0];
     dys = sc.x * P.c1[1] - sc.y * P.c2[1];
     dzs = sc.x * P.c1[2] - sc.y * c2z;
-    own_start = true;
+    // like the nadir ray, the start ray is cast without bounds tests: down to z_min (or r_max) it has to stay inside
+    // the map with three nodes of margin -- else this lane walks out from the nadir like the first run
+    const float te = dzs < -1e-4f ? fminf(a.r_max, (a.zmin_map - oz) * fast_rcp(dzs) + res) : a.r_max;
+    const float ex = te * dxs * inv_res, ey = te * dys * inv_res;
+    own_start = ((float)I0 + fminf(ex, 0.f) >= 3.f) & ((float)I0 + fmaxf(ex, 0.f) <= (float)(nx - 5)) &
+                ((float)J0 + fminf(ey, 0.f) >= 3.f) & ((float)J0 + fmaxf(ey, 0.f) <= (float)(ny - 5));
+    if (!own_start) {
+      dxs = -P.c2[0];
+      dys = -P.c2[1];
+      dzs = -c2z;
+    }
   }
   for (int attempt = 0; attempt < 2; ++attempt) {
-    r0 = cast_clear<SURF>(gp, ny, a, ul, vl, oz, dxs * inv_res, dys * inv_res, dzs, a.zmax_map, a.r_max);
+    r0 = cast_clear<SURF>(gp, nyp, a, ul, vl, oz, dxs * inv_res, dys * inv_res, dzs, a.zmax_map, a.r_max);
     if (!SUB || !own_start || ((r0 < a.r_max) & (r0 > 0.f))) break;
     dxs = -P.c2[0];
     dys = -P.c2[1];
@@ -257,7 +286,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     SweepNode N;
     N.P = Pk;
     const int j = __builtin_amdgcn_sbfe(Pk, 0, 16), i = (Pk - j) >> 16;
-    const float h = gp[i * ny + j];
+    const float h = gp[i * nyp + j];
     const float fi = (float)i, fj = (float)j;
     N.d = fmaf(pu, fi, fmaf(pv, fj, fmaf(pz, h, p0)));
     N.s = fmaf(su, fi, fmaf(sv, fj, fmaf(sz, h, s0)));
@@ -347,8 +376,6 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     //  a raw buffer load beyond num_records returns 0 -- no clamp, no 64-bit address arithmetic.  |ni| < 30000 and
     //  4 ny < 2^23 -- checked on the host --: the full-rate 24-bit multiply)
     const float hN = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(ni, ny4) + ((nj << 2) + g0b), 0, 0));
-    // CHECKED: is that node on the map at all?  (if not, the slice leaves the map through the edge it stands on)
-    const bool off_x = CHECKED && (unsigned)(I0 + ni) >= (unsigned)nx, off_y = CHECKED && (unsigned)(J0 + nj) >= (unsigned)ny;
     const float dts = tc - tp;
     {
       // (no end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0, so e_cur = -inf.  The
@@ -385,16 +412,8 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     }
     if (bp == bp_end) return true;
     if (sc > s_stop) return true;  // every beam left misses inside r_max (tail below)
-    if (CHECKED && (off_x | off_y)) {
-      // The slice ends at the map border: final if it cannot come back.  In plane coordinates the border x = x_b is
-      // the line s = s_L + k t with |k| <= sin(tilt) / |c1x|, the slice is t = f(s) with
-      // |f'| <= (slope + sin(tilt)) / (cos(tilt) - slope sin(tilt)); they meet once if |k f'| < 1 (0.9 here).
-      const float sb = fast_sqrt(fmaxf(1.f - c2z * c2z, 0.f));
-      const float lhs = sb * (a.sweep_slope + sb), rhs = 0.9f * (c2z - a.sweep_slope * sb);
-      ok = (off_x != off_y) & (lhs < rhs * fabsf(off_x ? P.c1[0] : P.c1[1]));
-      return true;  // (ok: the beams left get r_max through the tail below)
-    }
     if (++step > max_steps) {
+      SWEEP_NOTE(11);
       ok = false;
       return true;
     }
@@ -418,8 +437,12 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     // swaps the roles (the walk loop is unrolled by two): no register shuffling per step
     sp = s_new;
     tp = t_new;
-    if (!(t_new > 0.f)) {  // the seabed rises above the sensor's own horizon: not for the sweep (see the sentinel records)
-      ok = false;
+    if (!(t_new > 0.f)) {
+      // a NaN height: the walk has stepped off the map, the slice ends at the border -- final if it cannot come back
+      // (the beams left get r_max through the tail below).  Else the seabed rises above the sensor's own horizon (or a
+      // degenerate crossing): not for the sweep (see the sentinel records).
+      ok = (hN != hN) && sweep_border_final(a, hN, c2z, su * inv_res, sv * inv_res);   // (su = +-c1x res: the walk keeps no other copy)
+      if (!ok) SWEEP_NOTE(hN != hN ? 10 : 12);
       return true;
     }
     return false;
@@ -456,7 +479,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
 // (until round 3 the grid was walked along the 00-11 triangulation of the node values like a lattice mesh, passing
 //  over the crossings of the auxiliary diagonals: two steps per cell, of which the lanes of a wave took the beam-
 //  resolving one at different times -- lane utilisation 0.51, 2.8 x the instructions of the mesh walk.)
-template <bool EXPECT_ONLY, bool CHECKED = false, bool SUB = false>
+template <bool EXPECT_ONLY, bool SUB = false>
 __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPose& P, const float4* __restrict__ sbeam,
                                                 const float* __restrict__ stail, int side, int sub, int nsub,
                                                 float* __restrict__ exp_row, float& acc_out) {
@@ -489,26 +512,21 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
     const float rc = fast_rcp(c2z);
     const float sl = fabsf(P.c1[2]) * (s_stop + 2.f * res);
     const float t_hi = ((oz - a.zmin_map) + sl) * rc + res, t_lo = fminf(((oz - a.zmax_map) - sl) * rc - res, 0.f);
-    const float s_lo = -2.f * res, s_hi = s_stop + 2.f * res;
+    const float s_hi = s_stop + 2.f * res;
     const float fi0 = (float)I0, fj0 = (float)J0;
-    if (!CHECKED) {
-      const float ux0 = fminf(s_lo * ax, s_hi * ax) + fminf(t_lo * bx, t_hi * bx);
-      const float ux1 = fmaxf(s_lo * ax, s_hi * ax) + fmaxf(t_lo * bx, t_hi * bx);
-      const float vy0 = fminf(s_lo * ay, s_hi * ay) + fminf(t_lo * by, t_hi * by);
-      const float vy1 = fmaxf(s_lo * ay, s_hi * ay) + fmaxf(t_lo * by, t_hi * by);
-      pre = pre & (fi0 + ux0 >= 3.f) & (fi0 + ux1 <= (float)(nx - 5)) & (fj0 + vy0 >= 3.f) & (fj0 + vy1 <= (float)(ny - 5));
-    } else {
-      const float n0 = fminf(t_lo * bx, t_hi * bx), n1 = fmaxf(t_lo * bx, t_hi * bx);
-      const float m0 = fminf(t_lo * by, t_hi * by), m1 = fmaxf(t_lo * by, t_hi * by);
-      pre = pre & (fi0 + n0 >= 3.f) & (fi0 + n1 <= (float)(nx - 5)) & (fj0 + m0 >= 3.f) & (fj0 + m1 <= (float)(ny - 5));
-    }
+    // only the start ray (cast below without bounds tests) has to stay inside the map (see sweep_side)
+    const float n0 = fminf(t_lo * bx, t_hi * bx), n1 = fmaxf(t_lo * bx, t_hi * bx);
+    const float m0 = fminf(t_lo * by, t_hi * by), m1 = fmaxf(t_lo * by, t_hi * by);
+    pre = pre & (fi0 + n0 >= 3.f) & (fi0 + n1 <= (float)(nx - 5)) & (fj0 + m0 >= 3.f) & (fj0 + m1 <= (float)(ny - 5));
     pre = pre & (s_hi * fmaxf(fabsf(ax), fabsf(ay)) + fmaxf(-t_lo, t_hi) * fmaxf(fabsf(bx), fabsf(by)) < 30000.f);
   }
   if (!pre) SWEEP_FAIL(1);
-  const float* __restrict__ gp = a.grid + ((size_t)I0 * ny + J0);
-  const int g0i = I0 * ny + J0;
-  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.grid, 0, nx * ny * 4, 0x00020000);
-  const int ny4 = ny * 4, g0b = g0i * 4;
+  // the height array inside its ring of NaNs (see sweep_side)
+  const int nyp = a.nyp;
+  const int g0i = (I0 + 1) * nyp + (J0 + 1);
+  const float* __restrict__ gp = a.grid_pad + (size_t)g0i;
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.grid_pad, 0, (nx + 2) * nyp * 4, 0x00020000);
+  const int ny4 = nyp * 4, g0b = g0i * 4;
   // ---- start of the walk (see sweep_side): the nadir hit, or the hit of the first beam of a later run
   float dxs = -P.c2[0], dys = -P.c2[1], dzs = -c2z, r0 = 0.f;
   bool own_start = false;
@@ -517,10 +535,20 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
     dxs = sc.x * P.c1[0] - sc.y * P.c2[0];
     dys = sc.x * P.c1[1] - sc.y * P.c2[1];
     dzs = sc.x * P.c1[2] - sc.y * c2z;
-    own_start = true;
+    // like the nadir ray, the start ray is cast without bounds tests: down to z_min (or r_max) it has to stay inside
+    // the map with three nodes of margin -- else this lane walks out from the nadir like the first run
+    const float te = dzs < -1e-4f ? fminf(a.r_max, (a.zmin_map - oz) * fast_rcp(dzs) + res) : a.r_max;
+    const float ex = te * dxs * inv_res, ey = te * dys * inv_res;
+    own_start = ((float)I0 + fminf(ex, 0.f) >= 3.f) & ((float)I0 + fmaxf(ex, 0.f) <= (float)(nx - 5)) &
+                ((float)J0 + fminf(ey, 0.f) >= 3.f) & ((float)J0 + fmaxf(ey, 0.f) <= (float)(ny - 5));
+    if (!own_start) {
+      dxs = -P.c2[0];
+      dys = -P.c2[1];
+      dzs = -c2z;
+    }
   }
   for (int attempt = 0; attempt < 2; ++attempt) {
-    r0 = cast_clear<0>(gp, ny, a, ul, vl, oz, dxs * inv_res, dys * inv_res, dzs, a.zmax_map, a.r_max);
+    r0 = cast_clear<0>(gp, nyp, a, ul, vl, oz, dxs * inv_res, dys * inv_res, dzs, a.zmax_map, a.r_max);
     if (!SUB || !own_start || ((r0 < a.r_max) & (r0 > 0.f))) break;
     dxs = -P.c2[0];
     dys = -P.c2[1];
@@ -546,11 +574,11 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
     const float cfi = floorf(uh), cfj = floorf(vh);
     const int ci = (int)cfi, cj = (int)cfj;
     const int c00 = ci * 65536 + cj;
-    const float* cp = gp + (ci * ny + cj);
+    const float* cp = gp + (ci * nyp + cj);
     hp00 = cp[0];
     hp01 = cp[1];
-    hp10 = cp[ny];
-    hp11 = cp[ny + 1];
+    hp10 = cp[nyp];
+    hp11 = cp[nyp + 1];
     struct Nd { float d, s, t; };
     const auto nd = [&](float fi, float fj, float h) {
       Nd N;
@@ -636,7 +664,6 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
     const int dj = __builtin_amdgcn_sbfe(PD, 0, 16), di = (PD - dj) >> 16;
     const float hC = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(ci, ny4) + ((cj << 2) + g0b), 0, 0));
     const float hD = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(di, ny4) + ((dj << 2) + g0b), 0, 0));
-    const bool off_x = CHECKED && (unsigned)(I0 + ci) >= (unsigned)nx, off_y = CHECKED && (unsigned)(J0 + cj) >= (unsigned)ny;
     // ---- the conic of the current cell (the one on the -n side of the edge): in the fan plane the clearance
     // z - h(u, v) over it is G = g0 + g1 s + g2 t + g3 s^2 + g4 s t + g5 t^2 (u, v, z affine in (s, t), h bilinear), and
     // along beam s = t tan a the quadratic g0 + (g1 T + g2) t + (g3 T^2 + g4 T + g5) t^2 -- orc_ray_grid's, with tau = t
@@ -722,14 +749,8 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
     }
     if (bp == bp_end) break;
     if (sc > s_stop) break;  // every beam left misses inside r_max (tail below)
-    if (CHECKED && (off_x | off_y)) {
-      // the slice ends at the map border: final if it cannot come back (see sweep_side)
-      const float sb = fast_sqrt(fmaxf(1.f - c2z * c2z, 0.f));
-      const float lhs = sb * (a.sweep_slope + sb), rhs = 0.9f * (c2z - a.sweep_slope * sb);
-      ok = (off_x != off_y) & (lhs < rhs * fabsf(off_x ? P.c1[0] : P.c1[1]));
-      break;  // (ok: the beams left get r_max through the tail below)
-    }
     if (++step > max_steps) {
+      SWEEP_NOTE(11);
       ok = false;
       break;
     }
@@ -758,8 +779,12 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
     tp = tc;
     sc = fmaf(lam, sB - sA, sA);
     tc = fmaf(lam, tB - tA, tA);
-    if (!(tc > 0.f)) {  // the seabed rises above the sensor's own horizon: not for the sweep (see the sentinel records)
-      ok = false;
+    if (!(tc > 0.f)) {
+      // a NaN corner: the next cell is off the map, the slice ends at the border -- final if it cannot come back (see
+      // sweep_side; C and D lie beyond the same border line).  Else the seabed rises above the sensor's own horizon.
+      const float hB = hC != hC ? hC : hD;
+      ok = (hB != hB) && sweep_border_final(a, hB, c2z, su * inv_res, sv * inv_res);
+      if (!ok) SWEEP_NOTE(hB != hB ? 10 : 12);
       break;
     }
   }
@@ -1039,22 +1064,21 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
 #define SWEEP_MAX_WAVES 8   // SUB kernels: up to 4 runs per side x 2 sides
 
 // one (particle, side, run): cast; the (+ side, run 0) lane then combines the verdicts and sums in a fixed order, writes
-// lw or hands the particle over.  j0: position of the workgroup's first particle in the visiting order.
-template <int SURF, bool EXPECT_ONLY, bool CHECKED, bool SUB>
+// lw or hands the particle over.  j0: the workgroup's first particle.
+template <int SURF, bool EXPECT_ONLY, bool SUB>
 __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, long long n, const float4* sbeam,
                                              const float* stail, float* xacc, int* xok) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: scalar registers)
   const int nsub = SUB ? a.sweep_nsub : 1, combos = 2 * nsub;
   const int group = w / combos, combo = w - group * combos;
   const int side = combo & 1, sub = combo >> 1, pl = group * 64 + lane;   // particle within the workgroup
-  // (expected ranges in the natural order: the grid only covers the particles asked for)
-  const long long j = j0 + pl + ((EXPECT_ONLY && !a.perm) ? a.exp_first : 0);
-  const bool valid = j < n;
-  const long long i = (valid && a.perm) ? (long long)a.perm[j] : j;
+  // (expected ranges: the grid only covers the particles asked for)
+  const long long i = j0 + pl + (EXPECT_ONLY ? a.exp_first : 0);
+  const bool valid = i < n;
   bool ok = true, work = valid;
   float* exp_row = nullptr;
   if (EXPECT_ONLY) {
-    work = valid && i >= a.exp_first && i < a.exp_first + a.exp_count;
+    work = valid && i < a.exp_first + a.exp_count;
     if (work) exp_row = a.exp_out + (size_t)(i - a.exp_first) * a.n_beams;
   }
   float acc = 0.f;
@@ -1063,9 +1087,9 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
     if (SURF == 5)
       ok = sweep_side_tin<EXPECT_ONLY, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
     else if (SURF == 0)
-      ok = sweep_side_grid<EXPECT_ONLY, CHECKED, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
+      ok = sweep_side_grid<EXPECT_ONLY, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
     else
-      ok = sweep_side<(SURF == 3 ? 3 : 2), EXPECT_ONLY, CHECKED, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
+      ok = sweep_side<(SURF == 3 ? 3 : 2), EXPECT_ONLY, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
   }
   // the lanes of a particle agree on its fate: every lane but the first leaves its verdict and sum in LDS
   if (combo) {
@@ -1085,7 +1109,8 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
       v = -0.5 * acc2 - (double)a.sweep_nvalid * a.lognorm;
       a.lw[i] = v;
     }
-    // hand-overs: one atomic per wave
+    // hand-overs: one atomic per wave.  (The list's order is the waves' finishing order: k_mbes_cast<., ., 2> casts
+    // every entry with arithmetic that depends on the particle alone -- mcl_mbes.h, the determinism rule.)
     const unsigned long long dm = __ballot(work && !ok2);
     if (dm) {
       int base = 0;
@@ -1097,18 +1122,15 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
   return v == v ? v : -__builtin_inf();  // NaN never wins the maximum
 }
 
-// (register budgets: lattice first pass 8 waves / SIMD (64 VGPRs), grids, TINs and the lattice second pass 6, the bounds-
-//  checked second pass over a GRID 4 -- it carries the conic AND the border tests, and spilled 84 B per lane at 6)
-template <int SURF, bool EXPECT_ONLY, bool CHECKED = false, bool SUB = false>
-__global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, (SURF == 0 && CHECKED) ? 4 : (SURF == 0 ? SWEEP_MIN_WAVES_GRID : (SURF == 5 ? SWEEP_MIN_WAVES_TIN : (CHECKED ? 6 : SWEEP_MIN_WAVES)))) k_mbes_sweep(MbesArgs a) {
+// (register budgets: the lattice walk 8 waves / SIMD (64 VGPRs), grids and TINs 6; the sub-fan kernel over a grid 5 -- it
+//  carries the conic AND the start ray's footprint test, and spilled 8 B per lane at 6: small clouds, latency-bound anyway)
+template <int SURF, bool EXPECT_ONLY, bool SUB = false>
+__global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, SURF == 0 ? (SUB ? SWEEP_MIN_WAVES_GRID - 1 : SWEEP_MIN_WAVES_GRID) : (SURF == 5 ? SWEEP_MIN_WAVES_TIN : SWEEP_MIN_WAVES)) k_mbes_sweep(MbesArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sweep_lds[];
   __shared__ float xacc[64 * (SUB ? SWEEP_MAX_WAVES : SWEEP_THREADS / 64)];
   __shared__ int xok[64 * (SUB ? SWEEP_MAX_WAVES : SWEEP_THREADS / 64)];
   float4* sbeam = (float4*)sweep_lds + 1;  // records -1 and n_beams exist (read, never used)
   float* stail = (float*)(sbeam + a.n_beams + 1);
-  const long long n = mbes_count(a);  // (CHECKED pass: the length of the first pass's hand-over list, read here)
-  if (CHECKED && a.host_count && blockIdx.x == 0 && threadIdx.x == 0) *a.host_count = (int)n;
-  if (CHECKED && n == 0) return;
   for (int b = threadIdx.x; b < a.n_beams; b += blockDim.x) {
     sbeam[b] = a.sweep_beams[b];
     stail[b] = SUB ? a.sweep_tail_run[b] : a.sweep_tail[b];   // (SUB: tail sums that end with the lane's own run)
@@ -1116,21 +1138,10 @@ __global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, (S
   if (threadIdx.x < 4) stail[a.n_beams + threadIdx.x] = a.sweep_tan0[threadIdx.x];   // (first / second tangent of either side)
   if (threadIdx.x == 0) sbeam[-1] = sbeam[a.n_beams] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);  // "never reached"
   __syncthreads();
-  // particles per workgroup: its waves divided by the (side, run) combinations of a particle
+  // particles per workgroup: its waves divided by the (side, run) combinations of a particle; one lane per
+  // (particle, side, run)
   const int per_block = (int)(blockDim.x >> 6) / (2 * (SUB ? a.sweep_nsub : 1)) * 64;
-  double vmax;
-  if (!CHECKED) {
-    // the first pass is launched with one lane per (particle, side, run)
-    vmax = sweep_lane<SURF, EXPECT_ONLY, false, SUB>(a, blockIdx.x * (long long)per_block, n, sbeam, stail, xacc, xok);
-  } else {
-    // the CHECKED pass strides over the first pass's list, a workgroup's worth of particles at a time
-    vmax = -__builtin_inf();
-    for (long long j0 = blockIdx.x * (long long)per_block; j0 < n; j0 += (long long)gridDim.x * per_block) {
-      const double v = sweep_lane<SURF, EXPECT_ONLY, true, SUB>(a, j0, n, sbeam, stail, xacc, xok);
-      vmax = v > vmax ? v : vmax;
-      __syncthreads();  // (xacc / xok are rewritten by the next round)
-    }
-  }
+  const double vmax = sweep_lane<SURF, EXPECT_ONLY, SUB>(a, blockIdx.x * (long long)per_block, a.n, sbeam, stail, xacc, xok);
   if (!EXPECT_ONLY && a.max_slots) {
     // the normalisation needs max lw: one atomic per wave that wrote log-likelihoods, on an order-preserving key
     const double m = wave_max(vmax);

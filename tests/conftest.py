@@ -35,3 +35,21 @@ def _has_gpu():
 @pytest.fixture(scope="session")
 def gpu_available():
     return _has_gpu()
+
+
+# Order of the GPU suite: the tests pinned to the reference's own golden vectors first, then the dominant
+# kernel's, then everything else in file order; build-vs-build A/B tests last.  Under `pytest -x` a failure then cuts off
+# as little reference-pinned evidence as possible.
+_FIRST = ('test_gpu_parity.py', 'test_gpu_mbes_golden.py', 'test_gpu_sweep.py', 'test_gpu_determinism.py')
+_LAST = ('test_gpu_zz_merge_asm.py',)
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        if name in _FIRST:
+            return _FIRST.index(name)
+        if name in _LAST:
+            return len(_FIRST) + 1 + _LAST.index(name)
+        return len(_FIRST)
+    items.sort(key=rank)   # (stable: file order within a rank)

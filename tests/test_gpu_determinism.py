@@ -1,0 +1,170 @@
+"""The determinism rule of the MBES update (smarc_navigation_amd/csrc/mcl_mbes.h, top): the log-likelihood of a particle
+is a function of its pose, the ping and the map ALONE -- not of the particles it is grouped with, of the order of a
+hand-over list (built with atomics: wave finishing order), of a tile origin, a grid size or the number of GPUs.  The
+reference filter is deterministic for given draws (auv_pf.py:169-198); so is this one, on every path:
+
+  * the same update twice -> the same bits (border-straddling sigma = 300 m cloud: thousands of hand-overs);
+  * any permutation of the particles -> the same permutation of the log-weights, bit for bit (fan sweep with hand-overs,
+    ray traversal with and without the Morton visiting order, triangle soups);
+  * shards of a cloud == the unsharded cloud, bit for bit, with particles_handed_to_traversal > 0 (fused group step:
+    log-weights, indices, states).
+
+VERDICT r3 "weak 2": the hand-over list order used to decide which 8 particles shared a tile origin."""
+import numpy as np
+import pytest
+
+from smarc_navigation_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ORIGIN = (-64.0, -354.0)
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from smarc_navigation_amd import engine
+    return engine
+
+
+@pytest.fixture(scope='module')
+def terrain():
+    return synth.bathymetry_grid(708, 708, 1.0, ORIGIN, seed=3)
+
+
+def _maps(z, kind):
+    if kind == 'grid':
+        return ('grid', z)
+    if kind == 'mesh':
+        return ('mesh',) + tuple(synth.mesh_from_grid(z, 1.0, ORIGIN))
+    if kind == 'tin':
+        return ('mesh',) + tuple(synth.mesh_tin(z, 1.0, ORIGIN, seed=7))
+    raise ValueError(kind)
+
+
+def _set_map(e, m, **kw):
+    if m[0] == 'grid':
+        e.set_map_grid(m[1], ORIGIN, 1.0)
+    else:
+        e.set_map_mesh(m[1], m[2], **kw)
+
+
+def _cloud(n, spread, x0, seed=3, tilt=0.03):
+    rs = np.random.RandomState(seed)
+    soa = rs.randn(6, n) * np.array([spread, spread, 0.3, tilt, tilt, 1.0])[:, None]
+    soa[0] += x0
+    soa[2] -= 5.0
+    return soa
+
+
+def _ping(B, seed=5):
+    ba = synth.beam_angles(B)
+    rs = np.random.RandomState(seed)
+    ranges = (25.0 / np.cos(ba) + 0.1 * rs.randn(B)).astype(np.float32)
+    ranges[::9] = 0.0
+    return ba, ranges
+
+
+def _update(eng, m, soa, ba, ranges, **kw):
+    e = eng.Engine(soa.shape[1], rng_mode=eng.RNG_REPLAY)
+    _set_map(e, m, **kw)
+    e.set_particles(soa)
+    e.update_mbes(ranges, ba, 0.2, 100.0)
+    lw = e.get_log_weights()
+    path = e.mbes_last_path()
+    e.close()
+    return lw, path
+
+
+@pytest.mark.parametrize('kind', ['mesh', 'grid', 'tin'])
+def test_same_update_twice_is_bitwise_equal_on_a_border_straddling_cloud(kind, eng, terrain, monkeypatch):
+    """sigma = 300 m around a point 36 m inside the map's x border: a third of the cloud is off the map, thousands of
+    slices end at the border, thousands of particles go through the hand-over list."""
+    monkeypatch.delenv('MCL_SWEEP', raising=False)
+    m = _maps(terrain, kind)
+    soa = _cloud(60000, 300.0, -100.0)
+    ba, ranges = _ping(128)
+    runs = [_update(eng, m, soa, ba, ranges) for _ in range(3)]
+    assert runs[0][1][0] == 1, runs[0][1]              # the fan sweep ...
+    assert runs[0][1][1] > 1000, runs[0][1]            # ... with hand-overs
+    print('%s: %d of %d particles handed to the general kernel' % (kind, runs[0][1][1], soa.shape[1]))
+    for lw, path in runs[1:]:
+        assert path == runs[0][1]
+        assert np.array_equal(lw, runs[0][0])
+    assert np.isfinite(runs[0][0]).all()
+
+
+@pytest.mark.parametrize('kind,sweep,sort', [('mesh', '1', None), ('grid', '1', None), ('tin', '1', None),
+                                             ('mesh', '0', '0'), ('mesh', '0', '1'), ('grid', '0', '1'), ('soup', '0', '0'),
+                                             ('soup', '0', '1')])
+def test_permuting_the_particles_permutes_the_log_weights(kind, sweep, sort, eng, terrain, monkeypatch):
+    """Grouping independence: shuffle the slots of a wide, border-straddling cloud -- every group of 8, every tile, every
+    hand-over list changes -- and the log-weight of each particle keeps its bits."""
+    monkeypatch.setenv('MCL_SWEEP', sweep)
+    if sort is not None:
+        monkeypatch.setenv('MCL_SORT_VISITS', sort)
+    kw = {}
+    if kind == 'soup':
+        m, kw = _maps(terrain, 'mesh'), dict(general=True)
+    else:
+        m = _maps(terrain, kind)
+    n = 20000
+    soa = _cloud(n, 60.0, -30.0, seed=11, tilt=0.08)
+    soa[:, :64] = _cloud(64, 0.05, 100.0, seed=2)      # a tight clump well inside the map among them
+    ba, ranges = _ping(200)
+    lw0, path0 = _update(eng, m, soa, ba, ranges, **kw)
+    assert path0[0] == int(sweep)
+    if sweep == '1':
+        assert path0[1] > 100, path0
+    else:
+        assert path0[2] > 10, path0                    # groups the fast kernel left to the general one
+    rs = np.random.RandomState(1)
+    for trial in range(2):
+        perm = rs.permutation(n)
+        lw1, path1 = _update(eng, m, np.ascontiguousarray(soa[:, perm]), ba, ranges, **kw)
+        assert path1[:2] == path0[:2]
+        bad = np.flatnonzero(lw1 != lw0[perm])
+        assert bad.size == 0, '%d of %d log-weights changed with the slot order (first: particle %d, %r vs %r)' % (
+            bad.size, n, perm[bad[0]], lw1[bad[0]], lw0[perm[bad[0]]])
+
+
+@pytest.mark.parametrize('kind', ['mesh', 'grid'])
+def test_sharded_equals_unsharded_bitwise_with_hand_overs(kind, eng, terrain, monkeypatch):
+    """4 LOCAL shards x 16 384 against the unsharded 65 536-particle filter, fused steps on a cloud born across the map
+    border: log-weights, indices and states bit for bit while the sweep hands particles over in every step."""
+    monkeypatch.delenv('MCL_SWEEP', raising=False)
+    m = _maps(terrain, kind)
+    shards, ns = 4, 16384
+    n = shards * ns
+    cov = dict(init_cov=[900.0, 900.0, 0.0, 0.0, 0.0, 0.5], process_cov=[1e-2, 1e-2, 0.0, 0.0, 0.0, 1e-4],
+               resample_cov=[1.0, 1.0, 0.0, 0.0, 0.0, 1e-3])
+    # the odom frame's origin sits 20 m inside the map's x border: the initial cloud (sigma 30 m) hangs over it
+    m2o = synth.rigid_matrix(ORIGIN[0] + 20.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    one = eng.Engine(n, seed=9, m2o=m2o, **cov)
+    many = [eng.Engine(ns, rank=r, world=shards, n_global=n, global_offset=r * ns, seed=9, m2o=m2o, **cov) for r in range(shards)]
+    for e in [one] + many:
+        _set_map(e, m)
+        e.init_particles()
+    steps = 3
+    stream = synth.odom_stream(steps)
+    B = 256
+    ba = synth.beam_angles(B)
+    handed = []
+    for k in range(steps):
+        # (a flat seabed's ranges with a huge sigma: the likelihood is flat over the map and dead off it, so the survivors
+        #  keep lining the border -- the ones within a few nodes of it are handed over in every step)
+        ranges = (21.0 / np.cos(ba)).astype(np.float32)
+        args = (stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'], ranges, ba, 50.0, 100.0)
+        one.step_mbes(*args)
+        eng.group_step_mbes(many, *args)
+        p1 = one.mbes_last_path()
+        pm = [e.mbes_last_path() for e in many]
+        assert p1[0] == 1 and all(p[0] == 1 for p in pm)
+        assert p1[1] == sum(p[1] for p in pm)
+        handed.append(p1[1])
+        assert np.array_equal(one.get_log_weights(), np.concatenate([e.get_log_weights() for e in many])), k
+        assert np.array_equal(one.last_indices(), np.concatenate([e.last_indices() for e in many])), k
+        assert np.array_equal(one.get_particles(), np.concatenate([e.get_particles() for e in many], axis=1)), k
+    print('%s: particles handed to traversal per step: %r' % (kind, handed))
+    assert handed[0] > 1000 and min(handed) > 100, handed
+    for e in [one] + many:
+        e.close()

@@ -42,7 +42,7 @@ def test_no_hot_path_kernel_spills_to_scratch(table):
 def test_headline_sweep_keeps_eight_waves_per_simd_and_uses_no_matrix_cores(table):
     rows, asm = table
     for surf in (2, 3):   # the two diagonals of a triangulated DEM: the same workload
-        r = rows['void k_mbes_sweep<%d, false, false, false>' % surf]
+        r = rows['void k_mbes_sweep<%d, false, false>' % surf]
         assert r['vgpr'] <= 64 and r['occ'] == 8 and r['scratch'] == 0, r
     assert 'v_mfma' not in asm   # nothing on this path is a dense contraction (north_star)
     assert 'v_pk_fma_f32' not in asm and 'v_pk_add_f32' not in asm   # -fno-slp-vectorize: packed f32 holds the SIMD twice
