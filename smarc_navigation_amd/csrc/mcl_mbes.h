@@ -413,50 +413,7 @@ __global__ void __launch_bounds__(256) k_mbes_classify(MbesArgs a) {
   }
 }
 
-// ------------------------------------------------------------------ per-cell exact tests
-// Bilinear patch: first root of f(t) = ray_z(t) - h(u(t), v(t)) in [t_in, t_out] (fp32 restatement
-// of oracle/mcl_oracle.c:orc_ray_grid).  uc, vc = ray origin relative to the cell corner (cells).
-__device__ __forceinline__ bool patch_hit(float h00, float h10, float h01, float h11, float uc, float vc, float oz,
-                                          float du, float dv, float dz, float t_in, float t_out, bool check_entry,
-                                          float& t_hit) {
-  const float B = h10 - h00, C = h01 - h00, D = (h00 - h10) - (h01 - h11);
-  const float c0 = oz - (h00 + B * uc + C * vc + D * uc * vc);
-  const float c1 = dz - (B * du + C * dv + D * (uc * dv + vc * du));
-  const float c2 = -D * du * dv;
-  if (check_entry) {
-    const float f0 = c0 + t_in * (c1 + t_in * c2);
-    if (f0 <= 0.f) {  // origin / map entry at or below the seabed
-      t_hit = t_in;
-      return true;
-    }
-  }
-  const float f_out = c0 + t_out * (c1 + t_out * c2);
-  bool hit = f_out <= 0.f;
-  float hi_t = t_out;
-  if (!hit && c2 != 0.f) {  // grazing: both ends above, dips below in between
-    const float tv = -0.5f * c1 * fast_rcp(c2);
-    if (tv > t_in && tv < t_out && c0 + tv * (c1 + tv * c2) < 0.f) {
-      hit = true;
-      hi_t = tv;
-    }
-  }
-  if (!hit) return false;
-  float root;
-  if (fabsf(c2) < 1e-12f) {
-    root = -c0 * fast_rcp(c1);
-  } else {
-    const float disc = fmaxf(c1 * c1 - 4.f * c2 * c0, 0.f);
-    const float sq = fast_sqrt(disc);
-    const float qv = -0.5f * (c1 + (c1 >= 0.f ? sq : -sq));
-    const float r1 = qv != 0.f ? c0 * fast_rcp(qv) : 0.f;
-    const float r2 = qv * fast_rcp(c2);
-    const float ra = fminf(r1, r2), rb = fmaxf(r1, r2);
-    root = (ra >= t_in - 1e-3f && ra <= hi_t + 1e-3f) ? ra : rb;
-  }
-  t_hit = fminf(fmaxf(root, t_in), hi_t);
-  return true;
-}
-
+// ------------------------------------------------------------------ per-cell exact tests (triangle records)
 // nearest hit of the ray with the records [s, e) of one cell; ray origin relative to that cell's
 // corner (metres).  Accepts t in [0, t_hi].  Plane-form records: t from the plane equation, then
 // the barycentrics of the hit point in the xy projection (~26 VALU per triangle); near-vertical
@@ -502,17 +459,16 @@ __device__ __forceinline__ void cell_zrange(u32 hz, float& zlo, float& zhi) {
   zhi = __half2float(__ushort_as_half((unsigned short)(hz >> 16)));
 }
 
-// ------------------------------------------------------------------ the ray traversal
-// The clipped general march over the WHOLE map in global memory (L2): sensors off the map or at its border, fans that
-// reach beyond it, windows larger than LDS.
-// MAP 0: `map` holds node heights, pitch `pitch` (nodes); MAP 1: (zmin, zmax | record range) words per cell, pitch in
-// cells.  The map covers cw x ch cells.  Coordinates are relative to the particle's own cell (bi, bj) -- u0, v0 in
-// [0, 1), cell indices ix, iy relative to it: the arithmetic does not depend on where the map's origin is.
-template <int MAP>
-__device__ __forceinline__ float cast_ray(const void* __restrict__ map, int pitch, const MbesArgs& a, int bi, int bj,
+// ------------------------------------------------------------------ the ray traversal (triangle records)
+// The clipped general march over the WHOLE cell grid of a triangle-record mesh in global memory (L2): sensors off the
+// map or at its border, fans that reach beyond it, windows larger than LDS.  (Lattice maps -- height grids, structured
+// meshes -- take cast_clear<SURF, true> on the NaN-ringed height array instead.)
+// `map`: (zmin, zmax | record range) words per cell, pitch in cells, cw x ch cells.  Coordinates are relative to the
+// particle's own cell (bi, bj) -- u0, v0 in [0, 1), cell indices ix, iy relative to it: the arithmetic does not depend
+// on where the map's origin is.
+__device__ __forceinline__ float cast_ray(const uint2* __restrict__ map, int pitch, const MbesArgs& a, int bi, int bj,
                                           int cw, int ch, float u0, float v0, float oz, float du, float dv, float dx,
-                                          float dy, float dz, float t_lo, float r_max, bool& entry_below, RayStats& rs) {
-  entry_below = false;
+                                          float dy, float dz, float t_lo, float r_max, RayStats& rs) {
   STAT_INC(rs.rays);
   float t0 = t_lo, t1 = r_max;
   const float inv_du = du != 0.f ? fast_rcp(du) : 0.f, inv_dv = dv != 0.f ? fast_rcp(dv) : 0.f;
@@ -544,37 +500,22 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ map, int pitc
   const float dtx = fabsf(inv_du), dty = fabsf(inv_dv);
   float tnx = du != 0.f ? ((float)(ix + (du > 0.f ? 1 : 0)) - u0) * inv_du : INF;
   float tny = dv != 0.f ? ((float)(iy + (dv > 0.f ? 1 : 0)) - v0) * inv_dv : INF;
-  float t_in = t0;
   float z_in = oz + t0 * dz;
-  // the entry point only needs the below-the-seabed check when the march does not start above the
-  // map's highest node (slab start => ray_z(t0) > every height)
-  bool first = (MAP == 0) && !(t_lo > 0.f && t0 <= t_lo);
   float result = r_max;
   int guard = cw + ch + 4;
   for (;;) {
-    // ---- phase 1: walk cells until one might contain the surface (reject test only)
+    // ---- phase 1: walk cells until one might contain the surface (z-range reject test only)
     bool cand = false;
     float t_out = t1, z_out = z_in;
-    float h00 = 0.f, h10 = 0.f, h01 = 0.f, h11 = 0.f;
     while (guard > 0) {
       --guard;
       STAT_INC(rs.steps);
       t_out = fminf(fminf(tnx, tny), t1);
       z_out = oz + t_out * dz;
-      const float zlo = fminf(z_in, z_out);
-      if (MAP == 0) {
-        const float* p = (const float*)map + (size_t)(ix + bi) * pitch + (iy + bj);
-        h00 = p[0];
-        h01 = p[1];
-        h10 = p[pitch];
-        h11 = p[pitch + 1];
-        cand = first || zlo <= fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
-      } else {
-        const uint2 ci = ((const uint2*)map)[(size_t)(ix + bi) * pitch + (iy + bj)];
-        float czlo, czhi;
-        cell_zrange(ci.x, czlo, czhi);
-        cand = zlo <= czhi + 1e-4f && fmaxf(z_in, z_out) >= czlo - 1e-4f;
-      }
+      const uint2 ci = map[(size_t)(ix + bi) * pitch + (iy + bj)];
+      float czlo, czhi;
+      cell_zrange(ci.x, czlo, czhi);
+      cand = fminf(z_in, z_out) <= czhi + 1e-4f && fmaxf(z_in, z_out) >= czlo - 1e-4f;
       if (cand) break;
       if (t_out >= t1) break;
       const bool stepx = tnx <= tny;
@@ -586,27 +527,16 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ map, int pitc
       }
       tnx += stepx ? dtx : 0.f;
       tny += stepx ? 0.f : dty;
-      t_in = t_out;
       z_in = z_out;
     }
     if (!cand) break;
     // ---- phase 2: exact test in the candidate cell (lanes reconverge here)
     STAT_INC(rs.tests);
-    if (MAP == 0) {
-      float t_hit;
-      if (patch_hit(h00, h10, h01, h11, u0 - (float)ix, v0 - (float)iy, oz, du, dv, dz, t_in, t_out, first, t_hit)) {
-        entry_below = first && t_hit <= t_in;
-        result = fminf(t_hit, r_max);
-        break;
-      }
-      first = false;
-    } else {
-      const float t = cell_triangles_hit(a.mesh, ix + bi, iy + bj, (u0 - (float)ix) * a.mesh.cs,
-                                         (v0 - (float)iy) * a.mesh.cs, oz, dx, dy, dz, t_out + 1e-4f);
-      if (t < INF) {
-        result = fminf(t, r_max);
-        break;
-      }
+    const float t = cell_triangles_hit(a.mesh, ix + bi, iy + bj, (u0 - (float)ix) * a.mesh.cs,
+                                       (v0 - (float)iy) * a.mesh.cs, oz, dx, dy, dz, t_out + 1e-4f);
+    if (t < INF) {
+      result = fminf(t, r_max);
+      break;
     }
     if (t_out >= t1 || guard <= 0) break;
     const bool stepx = tnx <= tny;
@@ -615,7 +545,6 @@ __device__ __forceinline__ float cast_ray(const void* __restrict__ map, int pitc
     if ((unsigned)(ix + bi) >= (unsigned)cw || (unsigned)(iy + bj) >= (unsigned)ch) break;
     tnx += stepx ? dtx : 0.f;
     tny += stepx ? 0.f : dty;
-    t_in = t_out;
     z_in = z_out;
   }
   return result;
@@ -775,15 +704,29 @@ __device__ __forceinline__ float cast_fast(const float* __restrict__ tile, int t
 //     K = -(twist) cu cv dt^2: a sign change at the exit, or both ends above and a real root inside (grazing).
 // ~41 VALU + 4 LDS reads per cell for the triangulated surfaces, against 25 per cell + 76 per exact
 // two-plane test before; the wave executes max-over-lanes CELLS only, there is no second divergent phase.
-template <int SURF>
+// RING (the general kernel, lattice maps): `tile` is the height array inside its one-node ring of NaNs
+//   (MbesArgs::grid_pad) and nothing is assumed about the fan: the ray may start outside the map -- it is over the
+//   map's rectangle for t in [t_min, t_exit], computed by the caller; the start cell is clamped to the map's cells [fu_lo, fu_hi] x [fv_lo, fv_hi] (relative to
+//   the particle's cell) -- and may leave it: the first cell beyond the border has a NaN exit corner, the clearance
+//   there is NaN and the march ends with r_max (a mesh has no side walls; a ray from inside a grid never re-enters
+//   it).  A grid is solid below its surface: a ray that enters the map from the side under the seabed hits at its
+//   entry.  For a fan that IS simple (t_min = 0, every cell inside the map) the arithmetic is that of the plain
+//   version, bit for bit.
+template <int SURF, bool RING = false>
 __device__ __forceinline__ float cast_clear(const float* __restrict__ tile, int th, const MbesArgs& a, float u0, float v0,
-                                            float oz, float du, float dv, float dz, float zmax, float r_max) {
+                                            float oz, float du, float dv, float dz, float zmax, float r_max,
+                                            float t_min = 0.f, float t_exit = 0.f, float fu_lo = 0.f, float fu_hi = 0.f,
+                                            float fv_lo = 0.f, float fv_hi = 0.f) {
   const float INF = __builtin_inff();
   const float rdz = fast_rcp(dz);
   float t_lo = 0.f, t1 = r_max;
   if (dz < 0.f) {
-    if (oz > zmax) t_lo = fmaxf((zmax - oz) * rdz - 1e-3f, 0.f);  // skip the water column above the tile
+    if (oz > zmax) t_lo = fmaxf((zmax - oz) * rdz - 1e-3f, 0.f);  // skip the water column above the map
     t1 = fminf(r_max, (a.zmin_map - oz) * rdz + 1e-2f);           // below every node beyond this
+  }
+  if (RING) {
+    t_lo = fmaxf(t_lo, t_min);
+    if (!(t_lo <= t_exit)) return r_max;   // the ray is over the map's edge before it comes down to the highest node
   }
   const bool px = du > 0.f, py = dv > 0.f;
   const float cu = fabsf(du), cv = fabsf(dv);                        // cells per metre along each axis
@@ -791,7 +734,11 @@ __device__ __forceinline__ float cast_clear(const float* __restrict__ tile, int 
   // a NaN (0 * inf marched the other axis forever) and a vertical ray simply "leaves" its cell at
   // t ~ 1e30, where the linear interpolation of the clearance still returns g_in / |dz|
   const float iu = fminf(fabsf(fast_rcp(du)), 1e30f), iv = fminf(fabsf(fast_rcp(dv)), 1e30f);
-  const float fu = floorf(fmaf(t_lo, du, u0)), fv = floorf(fmaf(t_lo, dv, v0));
+  float fu = floorf(fmaf(t_lo, du, u0)), fv = floorf(fmaf(t_lo, dv, v0));
+  if (RING) {  // (rounding at the map's edge must not put the start cell into the ring)
+    fu = fminf(fmaxf(fu, fu_lo), fu_hi);
+    fv = fminf(fmaxf(fv, fv_lo), fv_hi);
+  }
   // forward-frame coordinates of the ray at parameter t inside the current cell: a' = A0 + t cu, b' = B0 + t cv
   float A0 = px ? u0 - fu : (fu + 1.f) - u0;
   float B0 = py ? v0 - fv : (fv + 1.f) - v0;
@@ -821,6 +768,7 @@ __device__ __forceinline__ float cast_clear(const float* __restrict__ tile, int 
       const float f = fmaf(t_s, via_x ? cv : cu, via_x ? B0 : A0);
       t_in = t_s;
       g_in = fmaf(t_s, dz, oz) - fmaf(f, Fn - F00, F00);
+      if (RING && SURF == 0 && t_min > 0.f && g_in <= 0.f) return fminf(t_in, r_max);  // into the map from the side, under the seabed
     } else {
       const float F00 = TILE_AT(a00), F01 = TILE_AT(a00 + oyb), F10 = TILE_AT(a00 + oxb), F11 = TILE_AT(a00 + oxyb);
       const float as = fmaf(t_lo, cu, A0), bs = fmaf(t_lo, cv, B0);
@@ -893,7 +841,7 @@ __device__ __forceinline__ float cast_clear(const float* __restrict__ tile, int 
       const bool x1 = in & (c_d != c_i);  // sign change on the first piece
       hit = x1 | ((c_o != c_i) != x1);    // or on the last one: c_o != (in ? c_d : c_i), as lane-mask XORs
     }
-    if (hit | !(t_out < t1)) break;
+    if (RING ? (hit | !(t_out < t1) | (g_out != g_out)) : (hit | !(t_out < t1))) break;
     a00 = aE;
     A0 -= stepx ? 1.f : 0.f;
     B0 -= stepx ? 0.f : 1.f;
@@ -903,6 +851,7 @@ __device__ __forceinline__ float cast_clear(const float* __restrict__ tile, int 
     g_in = g_out;
   }
 #undef TILE_AT
+  if (RING && g_out != g_out) return r_max;   // left the map
   if (!hit) return r_max;
   float root;
   if (SURF == 0) {
@@ -967,6 +916,9 @@ __global__ void __launch_bounds__(MBES_THREADS, MAP == 1 ? MBES_MIN_WAVES_MESH -
     float acc = 0.f;
     int nvalid = 0;
     RayStats rs = {0, 0, 0, 0};
+    // lattice maps: the map's cells and nodes relative to the particle's own cell (small integers: exact in fp32)
+    const float cu_lo = (float)(-F.I0), cu_hi = (float)(a.nx - 2 - F.I0), cv_lo = (float)(-F.J0), cv_hi = (float)(a.ny - 2 - F.J0);
+    const float* gpp = a.grid_pad + ((long long)(F.I0 + 1) * a.nyp + (F.J0 + 1));   // node (I0, J0) inside the ring (only ever dereferenced at map cells)
     for (int b = lane; b < a.n_beams; b += 64) {
       const float2 sc = a.beam_sc[b];
       const float dx = sc.x * P.c1[0] - sc.y * P.c2[0];
@@ -975,28 +927,42 @@ __global__ void __launch_bounds__(MBES_THREADS, MAP == 1 ? MBES_MIN_WAVES_MESH -
       float e;
       if (!F.sane) {
         e = a.r_max;  // (NaN / absurd position: every beam misses)
-      } else if (F.simple) {
-        if (MAP == 0) {
-          e = cast_clear<0>(a.grid + ((size_t)F.I0 * a.ny + F.J0), a.ny, a, F.ul, F.vl, P.oz, dx * inv_res, dy * inv_res, dz, a.zmax_map, a.r_max);
-        } else if (MAP == 2) {
-          const float* gp = a.grid + ((size_t)F.I0 * a.ny + F.J0);
-          e = a.diag_mode == 1 ? cast_clear<2>(gp, a.ny, a, F.ul, F.vl, P.oz, dx * inv_res, dy * inv_res, dz, a.zmax_map, a.r_max)
-            : a.diag_mode == 2 ? cast_clear<3>(gp, a.ny, a, F.ul, F.vl, P.oz, dx * inv_res, dy * inv_res, dz, a.zmax_map, a.r_max)
-                               : cast_clear<1>(gp, a.ny, a, F.ul, F.vl, P.oz, dx * inv_res, dy * inv_res, dz, a.zmax_map, a.r_max);
+      } else if (MAP != 1) {
+        // where the ray enters the map's rectangle (t_min = 0 for a sensor over the map), if at all
+        const float du = dx * inv_res, dv = dy * inv_res;
+        float t0 = 0.f, t1 = a.r_max;
+        bool miss = false;
+        if (du == 0.f) {
+          miss = F.ul < cu_lo || F.ul > cu_hi + 1.f;
         } else {
-          e = cast_fast<1>((const float*)(a.mesh.cell_info + ((size_t)F.I0 * a.mesh.gy + F.J0)), a.mesh.gy, a, F.I0, F.J0, F.ul, F.vl,
-                           P.oz, dx * inv_res, dy * inv_res, dz, a.zmax_map, a.r_max, rs);
+          const float r = fast_rcp(du), ta = (cu_lo - F.ul) * r, tb = (cu_hi + 1.f - F.ul) * r;
+          t0 = fmaxf(t0, fminf(ta, tb));
+          t1 = fminf(t1, fmaxf(ta, tb));
         }
+        if (dv == 0.f) {
+          miss = miss || F.vl < cv_lo || F.vl > cv_hi + 1.f;
+        } else {
+          const float r = fast_rcp(dv), ta = (cv_lo - F.vl) * r, tb = (cv_hi + 1.f - F.vl) * r;
+          t0 = fmaxf(t0, fminf(ta, tb));
+          t1 = fminf(t1, fmaxf(ta, tb));
+        }
+        if (miss || !(t0 <= t1)) {
+          e = a.r_max;
+        } else if (MAP == 0) {
+          e = cast_clear<0, true>(gpp, a.nyp, a, F.ul, F.vl, P.oz, du, dv, dz, a.zmax_map, a.r_max, t0, t1, cu_lo, cu_hi, cv_lo, cv_hi);
+        } else {
+          e = a.diag_mode == 1 ? cast_clear<2, true>(gpp, a.nyp, a, F.ul, F.vl, P.oz, du, dv, dz, a.zmax_map, a.r_max, t0, t1, cu_lo, cu_hi, cv_lo, cv_hi)
+            : a.diag_mode == 2 ? cast_clear<3, true>(gpp, a.nyp, a, F.ul, F.vl, P.oz, du, dv, dz, a.zmax_map, a.r_max, t0, t1, cu_lo, cu_hi, cv_lo, cv_hi)
+                               : cast_clear<1, true>(gpp, a.nyp, a, F.ul, F.vl, P.oz, du, dv, dz, a.zmax_map, a.r_max, t0, t1, cu_lo, cu_hi, cv_lo, cv_hi);
+        }
+      } else if (F.simple) {
+        e = cast_fast<1>((const float*)(a.mesh.cell_info + ((size_t)F.I0 * a.mesh.gy + F.J0)), a.mesh.gy, a, F.I0, F.J0, F.ul, F.vl,
+                         P.oz, dx * inv_res, dy * inv_res, dz, a.zmax_map, a.r_max, rs);
       } else {
         float t_lo = 0.f;  // skip the water column above the map's highest point
         if (dz < 0.f && P.oz > a.zmax_map) t_lo = fmaxf((a.zmax_map - P.oz) * fast_rcp(dz) - 1e-3f, 0.f);
-        bool below;
-        if (MAP == 0)
-          e = cast_ray<0>(a.grid, a.ny, a, F.I0, F.J0, a.nx - 1, a.ny - 1, F.ul, F.vl, P.oz, dx * inv_res, dy * inv_res, dx, dy, dz,
-                          t_lo, a.r_max, below, rs);
-        else  // triangle records (a structured mesh keeps them for exactly this)
-          e = cast_ray<1>(a.mesh.cell_info, a.mesh.gy, a, F.I0, F.J0, a.mesh.gx, a.mesh.gy, F.ul, F.vl, P.oz, dx * inv_res,
-                          dy * inv_res, dx, dy, dz, t_lo, a.r_max, below, rs);
+        e = cast_ray(a.mesh.cell_info, a.mesh.gy, a, F.I0, F.J0, a.mesh.gx, a.mesh.gy, F.ul, F.vl, P.oz, dx * inv_res,
+                     dy * inv_res, dx, dy, dz, t_lo, a.r_max, rs);
       }
       if (EXPECT_ONLY) {
         if (i >= a.exp_first && i < a.exp_first + a.exp_count)

@@ -368,6 +368,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   }
   // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the next triangle.
   // Returns true when the walk is over (all beams resolved, stop distance, map border, failure).
+  float hN = 0.f;   // the height loaded last (read after the loop: why did the walk end?)
   const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc) -> bool {
     // the third node of the triangle across (A, Bn): its height load is in flight while the beams are resolved
     const int Nk = (int)((unsigned)A.P + (unsigned)Bn.P - (unsigned)C);
@@ -375,7 +376,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     // (the footprint test keeps a sane walk inside the map; a NaN-driven one is stopped by the buffer's own range check:
     //  a raw buffer load beyond num_records returns 0 -- no clamp, no 64-bit address arithmetic.  |ni| < 30000 and
     //  4 ny < 2^23 -- checked on the host --: the full-rate 24-bit multiply)
-    const float hN = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(ni, ny4) + ((nj << 2) + g0b), 0, 0));
+    hN = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(ni, ny4) + ((nj << 2) + g0b), 0, 0));
     const float dts = tc - tp;
     {
       // (no end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0, so e_cur = -inf.  The
@@ -438,11 +439,9 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     sp = s_new;
     tp = t_new;
     if (!(t_new > 0.f)) {
-      // a NaN height: the walk has stepped off the map, the slice ends at the border -- final if it cannot come back
-      // (the beams left get r_max through the tail below).  Else the seabed rises above the sensor's own horizon (or a
-      // degenerate crossing): not for the sweep (see the sentinel records).
-      ok = (hN != hN) && sweep_border_final(a, hN, c2z, su * inv_res, sv * inv_res);   // (su = +-c1x res: the walk keeps no other copy)
-      if (!ok) SWEEP_NOTE(hN != hN ? 10 : 12);
+      // the seabed rises above the sensor's own horizon (see the sentinel records) -- or the height was a NaN: the walk
+      // has stepped off the map (decided after the loop: nothing here but the exit)
+      ok = false;
       return true;
     }
     return false;
@@ -450,6 +449,12 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   for (;;) {
     if (walk_step(s_prev, t_prev, s_cur, t_cur)) break;
     if (walk_step(s_cur, t_cur, s_prev, t_prev)) break;
+  }
+  if (!ok && step <= max_steps) {
+    // a NaN height: the slice ends at the map border -- final if it cannot come back (the beams left get r_max through
+    // the tail below).  (hN: the last height this lane loaded; su = +-c1x res: the walk keeps no other copy)
+    ok = (hN != hN) && sweep_border_final(a, hN, c2z, su * inv_res, sv * inv_res);
+    if (!ok) SWEEP_NOTE(hN != hN ? 10 : 12);
   }
   if (ok && bp != bp_end) {
     ptr = (int)(bp - sb_off) >> 4;
@@ -656,14 +661,15 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
   float4 bm = bp[0];
   const float rc2z = fast_rcp(c2z);
   const float axay2 = 2.f * (ax * ay), axby2 = 2.f * fmaf(ax, by, ay * bx), bxby2 = 2.f * (bx * by);
+  float hC = 0.f, hD = 0.f;   // the far corners loaded last (read after the loop: why did the walk end?)
   for (;;) {
     // the far corners of the cell across (A, B): their heights are in flight while this cell's beams are resolved
     // (the footprint test keeps a sane walk inside the map; a NaN-driven one is stopped by the buffer's own range check)
     const int PC = PA + n, PD = PC + e;
     const int cj = __builtin_amdgcn_sbfe(PC, 0, 16), ci = (PC - cj) >> 16;
     const int dj = __builtin_amdgcn_sbfe(PD, 0, 16), di = (PD - dj) >> 16;
-    const float hC = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(ci, ny4) + ((cj << 2) + g0b), 0, 0));
-    const float hD = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(di, ny4) + ((dj << 2) + g0b), 0, 0));
+    hC = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(ci, ny4) + ((cj << 2) + g0b), 0, 0));
+    hD = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(di, ny4) + ((dj << 2) + g0b), 0, 0));
     // ---- the conic of the current cell (the one on the -n side of the edge): in the fan plane the clearance
     // z - h(u, v) over it is G = g0 + g1 s + g2 t + g3 s^2 + g4 s t + g5 t^2 (u, v, z affine in (s, t), h bilinear), and
     // along beam s = t tan a the quadratic g0 + (g1 T + g2) t + (g3 T^2 + g4 T + g5) t^2 -- orc_ray_grid's, with tau = t
@@ -779,14 +785,17 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
     tp = tc;
     sc = fmaf(lam, sB - sA, sA);
     tc = fmaf(lam, tB - tA, tA);
-    if (!(tc > 0.f)) {
-      // a NaN corner: the next cell is off the map, the slice ends at the border -- final if it cannot come back (see
-      // sweep_side; C and D lie beyond the same border line).  Else the seabed rises above the sensor's own horizon.
-      const float hB = hC != hC ? hC : hD;
-      ok = (hB != hB) && sweep_border_final(a, hB, c2z, su * inv_res, sv * inv_res);
-      if (!ok) SWEEP_NOTE(hB != hB ? 10 : 12);
+    if (!(tc > 0.f)) {  // the seabed rises above the sensor's own horizon -- or a NaN corner (decided below)
+      ok = false;
       break;
     }
+  }
+  if (!ok && step <= max_steps) {
+    // a NaN corner: the next cell is off the map, the slice ends at the border -- final if it cannot come back (see
+    // sweep_side; C and D lie beyond the same border line)
+    const float hB = hC != hC ? hC : hD;
+    ok = (hB != hB) && sweep_border_final(a, hB, c2z, su * inv_res, sv * inv_res);
+    if (!ok) SWEEP_NOTE(hB != hB ? 10 : 12);
   }
   if (ok && bp != bp_end) {
     ptr = (int)(bp - sbeam);
