@@ -55,7 +55,7 @@ def parse(argv=None):
     ap.add_argument('--total-particles', type=int, default=4194304, help='total particles (strong scaling)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--beams', type=int, default=512)
-    ap.add_argument('--map', default='mesh', choices=['grid', 'mesh', 'mesh-general', 'mesh-adjacency', 'mesh-tin'])
+    ap.add_argument('--map', default='mesh', choices=['grid', 'mesh', 'mesh-general', 'mesh-adjacency', 'mesh-tin', 'mesh-soup'])
     ap.add_argument('--mesh-general', action='store_true', help='same as --map mesh-general')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the extra workload legs (N = 1 runs them by default)')
@@ -148,14 +148,17 @@ def build_map(kind):
                     desc='512x512 fp32 height grid, 1 m cells')
     origin = (-64.0, -354.0)
     z = synth.bathymetry_grid(708, 708, 1.0, origin, seed=3)
-    if kind == 'mesh-tin':
+    if kind in ('mesh-tin', 'mesh-soup'):
         verts, tris = synth.mesh_tin(z, 1.0, origin, seed=7)
         desc = '%d-triangle irregular TIN (708x708 nodes jittered in xy, random diagonals)' % tris.shape[0]
+        if kind == 'mesh-soup':
+            desc += ', cast as an arbitrary triangle soup (MCL_MESH_GENERAL: no height-field assumption)'
+
     else:
         verts, tris = synth.mesh_from_grid(z, 1.0, origin)
         desc = '%d-triangle mesh (708x708 height field triangulated)' % tris.shape[0]
         if kind == 'mesh-general':
-            desc += ', cast as an arbitrary triangle soup (MCL_MESH_GENERAL: triangle-record traversal only)'
+            desc += ', cast as an arbitrary triangle soup (MCL_MESH_GENERAL: no height-field assumption)'
         if kind == 'mesh-adjacency':
             desc += ', swept by triangle adjacency (MCL_MESH_UNSTRUCTURED: no structured-mesh detection)'
     # the bytes the chosen path is REQUIRED to read per ping (M), not the size of the input arrays:
@@ -167,7 +170,7 @@ def build_map(kind):
     elif kind in ('mesh-tin', 'mesh-adjacency'):
         mb, what = 32 * nt + 16 * nv, '32 B adjacency record per triangle + 16 B per vertex'
     else:
-        mb, what = 48 * nt + 8 * (nt // 2), '>= 48 B plane record per triangle + 8 B per cell'
+        mb, what = 16 * nt + 16 * nv + 8 * (nt // 2), '>= 16 B vertex-id record per triangle + 16 B per vertex + 8 B per cell (fan slice)'
     return dict(kind=kind, z=z, origin=origin, res=1.0, verts=verts, tris=tris, bytes=mb, bytes_what=what, desc=desc)
 
 
@@ -175,7 +178,7 @@ def attach_map(e, m):
     if m['kind'] == 'grid':
         e.set_map_grid(m['z'], m['origin'], m['res'])
     else:
-        e.set_map_mesh(m['verts'], m['tris'], general=(m['kind'] == 'mesh-general'),
+        e.set_map_mesh(m['verts'], m['tris'], general=(m['kind'] in ('mesh-general', 'mesh-soup')),
                        unstructured=(m['kind'] == 'mesh-adjacency'))
 
 
@@ -280,9 +283,10 @@ def mbes_path(e, P):
     """Which kernels cast the last MBES update (mcl_mbes_last_path): the fan sweep (regularly triangulated
     meshes) or the ray traversal, and how much of the cloud the first stage passed on to the general kernels."""
     path, handed, deferred = e.mbes_last_path()
-    return {'algorithm': 'fan sweep (mcl_sweep.h: k_mbes_sweep)' if path == 1 else 'ray traversal (mcl_mbes.h: k_mbes_fast)',
-            'dominant_launch': 'k_mbes_sweep<SURF,false>' if path == 1 else 'k_mbes_fast<SURF,false>',
-            'particles_handed_to_traversal': handed if path == 1 else None,
+    return {'algorithm': {1: 'fan sweep (mcl_sweep.h: k_mbes_sweep)', 2: 'fan slice (mcl_slice.h: k_mbes_slice)'}.get(
+                path, 'ray traversal (mcl_mbes.h: k_mbes_fast)'),
+            'dominant_launch': {1: 'k_mbes_sweep<SURF,false>', 2: 'k_mbes_slice<false>'}.get(path, 'k_mbes_fast<SURF,false>'),
+            'particles_handed_to_traversal': handed if path in (1, 2) else None,
             'groups_deferred_to_general_kernel': deferred, 'of_particles': P}
 
 
@@ -713,6 +717,8 @@ def worker(a, rank, world, local_rank):
         legs.append(('filter_tempered', dict(m=mesh, P=1048576, B=512, steps=30, warmup=10, sigma=SIGMA * math.sqrt(512.0))))
         if a.map != 'mesh-general':
             legs.append(('mesh_general', dict(m=build_map('mesh-general'), P=1048576, B=512, steps=10, warmup=2)))
+        if a.map != 'mesh-soup':
+            legs.append(('mesh_soup_irregular', dict(m=build_map('mesh-soup'), P=1048576, B=512, steps=10, warmup=2)))
         if a.map != 'mesh-adjacency':
             legs.append(('mesh_adjacency', dict(m=build_map('mesh-adjacency'), P=1048576, B=512, steps=20, warmup=3)))
         if a.map != 'mesh-tin':

@@ -290,9 +290,10 @@ int mcl_exchange_plan(int32_t world, const uint32_t* lost, const uint32_t* surpl
 /* ---- instrumentation */
 int mcl_timing_enable(mcl_handle* h, int32_t on);
 int mcl_timing_get(mcl_handle* h, mcl_timing* out); /* syncs, returns and resets the accumulators */
-/* Which kernels cast the last MBES update (syncs): path = 1 fan sweep (mcl_sweep.h: regularly triangulated meshes,
- * ascending beam angles), 0 ray traversal; handed_over = particles the sweep (both passes) passed on to the traversal kernels
- * (path 1), deferred_groups = groups of eight the fast traversal passed on to the general one.  Any pointer may be NULL. */
+/* Which kernels cast the last MBES update (syncs): path = 1 fan sweep (mcl_sweep.h: height grids, regularly triangulated
+ * meshes, height-field TINs; ascending beam angles), 2 fan slice (mcl_slice.h: every other triangle mesh, ascending beam
+ * angles), 0 ray traversal; handed_over = particles the sweep / slice passed on to the general kernel (paths 1, 2),
+ * deferred_groups = groups of eight the fast traversal passed on to the general one.  Any pointer may be NULL. */
 int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64_t* deferred_groups);
 
 #ifdef __cplusplus

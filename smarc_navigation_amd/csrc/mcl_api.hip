@@ -114,6 +114,7 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
     h->env_debug_work = getenv("MCL_DEBUG_WORK") != nullptr;
     if (const char* sv = getenv("MCL_SORT_VISITS")) h->env_sort = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_SWEEP")) h->env_sweep = sv[0] == '1' ? 1 : 0;
+    if (const char* sv = getenv("MCL_SLICE")) h->env_slice = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_SWEEP_NSUB")) h->env_nsub = (sv[0] == '2' || sv[0] == '4') ? sv[0] - '0' : 1;
     h->env_force_comm = on("MCL_FORCE_COMM");
     if (const char* ex = getenv("MCL_EXCHANGE")) h->exch_allgather = strcmp(ex, "allgather") == 0;
@@ -1107,8 +1108,8 @@ int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64
   HIPCHK(h, hipStreamSynchronize(h->stream));
   int cnt[2] = {0, 0};  // groups the fast kernel left to the general one; particles the sweep handed over
   HIPCHK(h, hipMemcpy(cnt, h->ctrl + CTRL_WORK, sizeof cnt, hipMemcpyDeviceToHost));
-  if (path) *path = h->sweep_now ? 1 : 0;
-  if (handed_over) *handed_over = h->sweep_now ? cnt[1] : 0;
+  if (path) *path = h->sweep_now ? 1 : (h->slice_now ? 2 : 0);
+  if (handed_over) *handed_over = (h->sweep_now || h->slice_now) ? cnt[1] : 0;
   if (deferred_groups) *deferred_groups = cnt[0];
   return MCL_OK;
 }

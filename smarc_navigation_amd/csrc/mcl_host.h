@@ -23,6 +23,7 @@
 #include "mcl_kernels.h"
 #include "mcl_mbes.h"
 #include "mcl_sweep.h"
+#include "mcl_slice.h"
 #include "mcl_mesh.h"
 #include "mcl_resample.h"
 #include "mcl_resample_alt.h"
@@ -141,6 +142,8 @@ struct mcl_handle {
   int env_sweep = -1;               // MCL_SWEEP=0/1 forces the decision (tests, A/B)
   int env_nsub = 0;                 // MCL_SWEEP_NSUB=1/2/4 forces the lanes per particle side (A/B)
   bool sweep_now = false;           // decided by the first launch_mbes call of an update
+  bool slice_now = false;           // ... the fan slice (mcl_slice.h) casts it
+  int env_slice = -1;               // MCL_SLICE=0 keeps the ray traversal on triangle soups (tests, A/B)
   int sweep_nvalid = 0;
   float* grid = nullptr;
   float* grid_pad = nullptr;   // the same heights inside a one-node ring of NaNs (fan sweep: MbesArgs::grid_pad)

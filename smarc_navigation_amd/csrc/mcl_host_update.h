@@ -250,6 +250,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.n_dev = nullptr;
   a.host_count = nullptr;
   a.reasons = nullptr;
+  a.slice = 0;
   a.grid_pad = nullptr;
   a.nyp = 0;
 #ifdef SWEEP_REASONS
@@ -329,6 +330,10 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
                  h->ng >= sweep_min_n &&  // (the GLOBAL count: every shard of a cloud takes the same path, results do not depend on the GPU count)
                  h->n < (1ll << 31) && (long long)a.nx * a.ny < (1ll << 30) && a.ny < (1 << 21);
     h->sweep_now = sweep;
+    // ---- fan slice (mcl_slice.h): every other triangle mesh -- soups, meshes mesh_build could not prove a height
+    // field, MCL_MESH_GENERAL -- with an ascending beam table; MCL_SLICE=0 keeps the ray traversal (tests, A/B)
+    h->slice_now = !sweep && h->map_kind == 1 && !structured && h->mesh->cell_tri && h->sweep_angles_ok && h->env_slice != 0 &&
+                   h->n < (1ll << 31);
     if (sweep) {
       RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max, sweep_lanes_per_side(h, with_ranges, B)));
     } else if (with_ranges && h->ranges_pending) {
@@ -353,6 +358,12 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     a.sweep_c2z_min = (float)(1.0 / std::sqrt(1.0 + tan_lim * tan_lim));
     a.sweep_slope = (float)slope_max;
     a.defer_idx = h->defer_idx;
+  }
+  const bool slice = h->slice_now;
+  if (slice) {
+    if (!h->defer_idx) HIPCHK(h, hipMalloc(&h->defer_idx, sizeof(u32) * (size_t)h->n));
+    a.defer_idx = h->defer_idx;
+    a.slice = 1;
   }
   if (args_only) {
     *args_only = a;
@@ -386,7 +397,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_BYTES, h->stream));  // slots + work and hand-over counters (one aligned fill)
     else
       HIPCHK(h, hipMemsetAsync(a.work_count, 0, 2 * sizeof(int), h->stream));
-    if (lean && !sweep)
+    if (lean && !sweep && !slice)
       k_mbes_pose<true><<<grid_for(h->n), 256, 0, h->stream>>>(a);
     else
       k_mbes_pose<false><<<grid_for(h->n), 256, 0, h->stream>>>(a);
@@ -444,6 +455,30 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       (void)hipMemcpyAsync(&cnt, a.defer_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
       (void)hipStreamSynchronize(h->stream);
       fprintf(stderr, "[mbes] sweep handed over %d of %lld particles\n", cnt, (long long)h->n);
+    }
+    t_end(h);
+    HIPCHK(h, hipGetLastError());
+    return MCL_OK;
+  }
+  if (slice) {
+    // one wavefront per particle; what it declines (fans far from vertical) goes to the general kernel over the
+    // triangle records, through the same hand-over list as the sweep's
+    MbesArgs d = a;
+    d.perm = h->defer_idx;
+    d.n_dev = a.defer_count;
+    d.host_count = wh_cur + 1;
+    const long long n_part = !with_ranges ? std::max<long long>(std::min<long long>(exp_count, h->n - exp_first), 1) : h->n;
+    const int sgrid = (int)std::min<long long>((n_part + SLICE_WAVES - 1) / SLICE_WAVES, 1 << 20);
+    const size_t lds = ((size_t)B * (2 + SLICE_WAVES) + (size_t)SLICE_WAVES * (SLICE_LIST + 1)) * sizeof(float);
+    const int dgrid = (int)std::min<long long>(ngroups, wh_prev[1] == 0 ? 64 : 4096);
+    if (with_ranges) {
+      t_begin(h, MCL_K_MBES_MAIN);
+      k_mbes_slice<false><<<sgrid, SLICE_THREADS, lds, h->stream>>>(a);
+      t_end(h);
+      k_mbes_cast<1, false, 2><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);
+    } else {
+      k_mbes_slice<true><<<sgrid, SLICE_THREADS, lds, h->stream>>>(a);
+      k_mbes_cast<1, true, 2><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);
     }
     t_end(h);
     HIPCHK(h, hipGetLastError());
@@ -565,7 +600,7 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
     // noise-free: feed zeros through the native branch with sq = 0
   }
   if (pose_for && !rp && h->cfg.rng_mode == MCL_RNG_NATIVE) {
-    const bool lean = !pose_for->sweep_beams;  // the fan sweep needs no group records
+    const bool lean = !pose_for->sweep_beams && !pose_for->slice;  // the fan sweep and the fan slice need no group records
     a.skip_uniform = defer_uniform ? 1 : 0;
     h->uni_deferred = defer_uniform;
     if (lean) {

@@ -78,6 +78,7 @@ struct MeshArgs {
   float cs;
   const uint4* tin_tri;    // fan sweep over a TIN: {v0, v1, v2, -} {neighbours across v0v1, v1v2, v2v0, -} per triangle
   const float4* tin_vert;  // (x, y, z, -) per vertex, map frame
+  const float4* cell_tri;  // fan slice (mcl_slice.h): the three vertices (x, y, z, -), map frame, of every (cell, triangle) record, indexed like `tri`
   double x0, y0;           // map-frame position of cell (0, 0)'s corner
 };
 
@@ -128,6 +129,7 @@ struct MbesArgs {
   int* defer_count;           // device counter, zeroed with the control block
   const int* n_dev;           // when set, the classify / cast kernels visit *n_dev entries of perm instead of a.n
   int* host_count;            // pinned host word (or nullptr): k_mbes_cast<.,.,2> leaves the hand-over count there
+  int slice;                  // 1: this update is cast by the fan slice (mcl_slice.h)
   unsigned* reasons;          // SWEEP_REASONS builds: 16 counters, why the sweep declined a particle side (or nullptr)
 };
 __device__ __forceinline__ long long mbes_count(const MbesArgs& a) { return a.n_dev ? (long long)*a.n_dev : a.n; }

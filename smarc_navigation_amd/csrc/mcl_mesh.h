@@ -42,6 +42,11 @@ struct MeshDev {
   uint4* tin_tri = nullptr;
   float4* tin_vert = nullptr;
   bool tin_ok = false;
+  // fan slice over an arbitrary triangle soup (mcl_slice.h): per (cell, triangle) record the three vertices of its source
+  // triangle in MAP-FRAME coordinates, 3 float4 {x, y, z, -}, same indexing as `tri`.  (Absolute, not cell-relative: a
+  // vertex has the same bits in every record it appears in, so the slices of two triangles that share an edge meet in
+  // one point.  No index indirection: the walk over a cell's records is one dependent load, not two.)
+  float4* cell_tri = nullptr;
 };
 
 // The height array of a lattice map inside a one-node ring of quiet NaNs whose payload names the border: 1 = beyond an
@@ -77,6 +82,7 @@ inline void mesh_free(MeshDev* m) {
   if (m->heights_pad) (void)hipFree(m->heights_pad);
   if (m->tin_tri) (void)hipFree(m->tin_tri);
   if (m->tin_vert) (void)hipFree(m->tin_vert);
+  if (m->cell_tri) (void)hipFree(m->cell_tri);
   delete m;
 }
 
@@ -320,6 +326,23 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
     mesh_free(m);
     return MCL_ERR_HIP;
   }
+  // ---- fan slice (mcl_slice.h): the three vertices of every record's source triangle, map frame
+  {
+    std::vector<float4> ct(3 * std::max<size_t>(m->n_records, 1));
+    for (size_t r = 0; r < m->n_records; ++r) {
+      const u32 k = rec_tri[r];
+      for (int c = 0; c < 3; ++c) {
+        const float* v = verts + 3 * (size_t)tris[3 * (size_t)k + c];
+        ct[3 * r + c] = make_float4(v[0], v[1], v[2], 0.f);
+      }
+    }
+    if (hipMalloc(&m->cell_tri, sizeof(float4) * ct.size()) != hipSuccess ||
+        hipMemcpy(m->cell_tri, ct.data(), sizeof(float4) * ct.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      *err = "set_map_mesh: device allocation failed";
+      mesh_free(m);
+      return MCL_ERR_ALLOC;
+    }
+  }
   // ---- triangle adjacency (fan sweep over a TIN): edge -> the (at most two) triangles on it
   if (!any_vertical && nt < (1ll << 31) && nv < (1ll << 31)) {
     bool ok = true;
@@ -562,6 +585,7 @@ inline MeshArgs mesh_args(const MeshDev* m) {
   ma.cs = (float)m->cs;
   ma.tin_tri = m->tin_tri;
   ma.tin_vert = m->tin_vert;
+  ma.cell_tri = m->cell_tri;
   ma.x0 = m->x0;
   ma.y0 = m->y0;
   return ma;

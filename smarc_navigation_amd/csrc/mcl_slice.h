@@ -1,0 +1,332 @@
+// mcl_slice.h -- MBES update over an ARBITRARY triangle mesh without a march per ray: the fan slice.
+//
+// The beams of one ping lie in one plane through the sensor (mcl_sweep.h).  On a height field the fan sweep walks the
+// slice of the seabed by that plane from the nadir outward; a triangle soup -- vertical faces, overhangs, wrecks
+// floating over the seabed, non-manifold edges: everything mesh_build cannot prove a single-valued height field -- has
+// no such order.  But the slice is still only a few hundred SEGMENTS (plane x triangle), and a beam's expected range is
+// the nearest crossing of its half line with any of them:
+//
+//   one WAVEFRONT per particle;
+//   1. lanes = columns of the mesh's cell grid along the fan plane's trace: every lane enumerates the two to four cells
+//      of its column the plane can cut inside the map's depth range (their cell words loaded as one batch), tests each
+//      cell's box (its own z-range) against the plane, and appends the triangle records of the cells that are cut to
+//      the wave's list in LDS;
+//   2. lanes = triangles of that list (balanced to one iteration; columns that miss the map or hold one cell no longer
+//      idle): first the cheap question -- does the plane separate its vertices? --, the list compacted in place to the
+//      ones it does, then the expensive part with every lane busy.  Per triangle: the three
+//      vertices (map-frame coordinates in the record: a vertex has the same bits in every record it appears in), their
+//      distance to the plane and in-plane coordinates (s along c1, t along -c2: beam b is the half
+//      line s = t tan a_b, t > 0); a triangle the plane separates gives one segment -- its end points interpolated
+//      from the vertex BELOW the plane to the one ABOVE it, so that two triangles sharing an edge compute the same
+//      point bit for bit: the slice is watertight;
+//   3. per segment: the run of beams whose tangent lies between those of its end points (lower bound by bisection in
+//      the ascending tangent table in LDS), and for each of them the crossing -> range = t / cos a -> an LDS
+//      atomicMin on the beam's slot (positive floats order like their bit patterns);
+//   4. the wave's lanes then take the beams back (b = lane, lane + 64, ...): residual, sum, log-likelihood -- the same
+//      epilogue as the traversal kernels.
+//
+// Work per particle: ~150-600 triangle tests + ~1 000 beam x segment pairs, against 512 rays x ~35 cells x (z-range
+// test + triangle records) for the traversal (k_mbes_fast<4>): measured at 1 048 576 x 512 on one MI355X 4.8 -> 4.0 ms
+// per update on the regular 1 M-triangle mesh cast as a soup, 21.3 -> 6.7 ms on the irregular TIN cast as a soup
+// (bench.py extra.mesh_general / mesh_soup_irregular).  The kernel is VALU-issue-bound: 2 600 / 4 000 wave
+// instructions per particle at lane utilisation 0.49 / 0.58 (rocprofv3 SQ counters, tools/pmc_kernel.sh); what is
+// left is the divergence of the beam loop (a segment under the sensor covers a dozen beams, one at the swath's edge
+// one or two) and the bisection (nine LDS reads per segment).
+//
+// Exact by construction (two-sided triangles, no side walls: the oracle's definition), deterministic (a minimum does
+// not depend on the order of its operands), a function of the particle alone (the determinism rule of mcl_mbes.h).
+// Declined -- and handed to k_mbes_cast<1, ., 2> through the sweep's hand-over list --: fans whose plane is closer to
+// horizontal than 60 degrees or whose across-track axis points more than 60 degrees out of the horizontal (the column
+// enumeration assumes a near-vertical plane with a near-horizontal trace), NaN poses.  Beam tables: ascending, within
+// 85 degrees of the nadir (the host checks: sweep_angles_ok), like the sweep.
+#pragma once
+#include "mcl_mbes.h"
+
+#ifndef SLICE_WAVES
+#define SLICE_WAVES 4   // particles per workgroup
+#endif
+#define SLICE_THREADS (SLICE_WAVES * 64)
+#ifndef SLICE_LIST
+#define SLICE_LIST 511    // triangle records a wave's list holds per chunk of columns (2 KiB with its counter); more: the general kernel
+#endif
+#define SLICE_ROWS 4      // cell words of one column loaded per batch
+#ifndef SLICE_COLS
+#define SLICE_COLS 32     // columns per chunk (<= 64: one per lane).  (measured, 1 M x 512, regular mesh as a soup / irregular TIN, ms:
+                          //  4 waves, list 1023, 64 columns 4.81 / 7.10; 8 waves, 767, 64: 4.44 / 6.54; 8, 511, 32: 4.11 / 6.90;
+                          //  4, 511, 32: 3.95 / 6.69 -- 20 KiB of LDS per workgroup, 8 waves per SIMD)
+#endif
+
+// v_min_u32 on an LDS word: ranges are positive floats, their order is the order of their bit patterns
+__device__ __forceinline__ void lds_min_range(unsigned* slot, float range) {
+  __hip_atomic_fetch_min(slot, __float_as_uint(range), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <bool EXPECT_ONLY>
+__global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char slice_lds[];
+  const int B = a.n_beams;
+  float* tanb = (float*)slice_lds;                   // B: ascending tangents
+  float* secb = tanb + B;                            // B: 1 / cos a
+  unsigned* rng_all = (unsigned*)(secb + B);         // SLICE_WAVES x B: nearest crossing per beam (float bits)
+  unsigned* tl_all = rng_all + (size_t)SLICE_WAVES * B;   // SLICE_WAVES x (SLICE_LIST + 1): the wave's triangle list, its length
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float2 sc = a.beam_sc[b];
+    const float sec = __builtin_amdgcn_rcpf(sc.y);
+    tanb[b] = sc.x * sec;
+    secb[b] = sec;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned* rng = rng_all + (size_t)w * B;
+  unsigned* tlist = tl_all + (size_t)w * (SLICE_LIST + 1);
+  unsigned* tcount = tlist + SLICE_LIST;
+  const MeshArgs& ma = a.mesh;
+  const float cs = ma.cs, ics = 1.f / cs;
+  const unsigned rmax_bits = __float_as_uint(a.r_max);
+  const float tan_lo = tanb[0], tan_hi = tanb[B - 1];
+  const float2 sc_lo = a.beam_sc[0], sc_hi = a.beam_sc[B - 1];
+  double wmax = -__builtin_inf();
+  for (long long i = (long long)blockIdx.x * SLICE_WAVES + w; i < a.n; i += (long long)gridDim.x * SLICE_WAVES) {
+    if (EXPECT_ONLY && (i < a.exp_first || i >= a.exp_first + a.exp_count)) continue;
+    MbesPose P;
+    {
+      const MbesPose Pv = a.pose[i];   // wave-uniform: scalar registers
+      P.um = uniform_f64(Pv.um);
+      P.vm = uniform_f64(Pv.vm);
+      P.oz = uniform_f32(Pv.oz);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        P.c1[r] = uniform_f32(Pv.c1[r]);
+        P.c2[r] = uniform_f32(Pv.c2[r]);
+      }
+    }
+    const float c2z = P.c2[2];
+    const float h1 = P.c1[0] * P.c1[0] + P.c1[1] * P.c1[1];   // squared horizontal part of the across-track axis
+    const bool sane = fabs(P.um) < 1e9 && fabs(P.vm) < 1e9;
+    if (!(sane && c2z >= 0.5f && h1 >= 0.25f)) {   // (NaN: declined) -> the general kernel
+      if (lane == 0) a.defer_idx[atomicAdd(a.defer_count, 1)] = (u32)i;
+      continue;
+    }
+    for (int b = lane; b < B; b += 64) rng[b] = rmax_bits;
+    // the sensor in the map frame, split into an fp32 part and its sub-ulp rest (vertices are fp32, the sensor is not)
+    const double Ox = ma.x0 + P.um * (double)cs, Oy = ma.y0 + P.vm * (double)cs;
+    const float Oxf = (float)Ox, Oyf = (float)Oy, dOx = (float)(Ox - (double)Oxf), dOy = (float)(Oy - (double)Oyf);
+    const float oz = P.oz;
+    const float nx = P.c1[1] * P.c2[2] - P.c1[2] * P.c2[1], ny = P.c1[2] * P.c2[0] - P.c1[0] * P.c2[2],
+                nz = P.c1[0] * P.c2[1] - P.c1[1] * P.c2[0];
+    // ---- how far out the fan can meet the map: the outermost beam of either side down to z_min, or r_max
+    float s_pos = 0.f, s_neg = 0.f;
+    {
+      const float2 hi = sc_hi, lo = sc_lo;
+      const float rate_hi = hi.y * c2z - hi.x * P.c1[2], rate_lo = lo.y * c2z - lo.x * P.c1[2];   // descent per metre of range
+      const float rho_hi = rate_hi > 1e-4f ? fminf(a.r_max, fmaxf(oz - a.zmin_map, 0.f) * __builtin_amdgcn_rcpf(rate_hi)) : a.r_max;
+      const float rho_lo = rate_lo > 1e-4f ? fminf(a.r_max, fmaxf(oz - a.zmin_map, 0.f) * __builtin_amdgcn_rcpf(rate_lo)) : a.r_max;
+      s_pos = fmaxf(hi.x, 0.f) * rho_hi + cs;
+      s_neg = fmaxf(-lo.x, 0.f) * rho_lo + cs;
+    }
+    // depth range along -c2 inside which a point of the plane can lie on the map (z in [z_min, z_max])
+    const float s_abs = fmaxf(s_pos, s_neg);
+    const float rc = __builtin_amdgcn_rcpf(c2z);
+    const float t_b = fminf(((oz - a.zmin_map) + fabsf(P.c1[2]) * s_abs) * rc, a.r_max) + cs;
+    const float t_a = fmaxf(((oz - a.zmax_map) - fabsf(P.c1[2]) * s_abs) * rc - cs, 0.f);
+    // ---- columns of cells along the trace.  Major axis M: the larger horizontal component of c1; a point of the
+    // plane is O + s c1 - t c2, its major coordinate m = s c1m - t c2m, its minor one q = s c1q - t c2q
+    const bool major_x = fabsf(P.c1[0]) >= fabsf(P.c1[1]);
+    const float c1m = major_x ? P.c1[0] : P.c1[1], c1q = major_x ? P.c1[1] : P.c1[0];
+    const float c2m = major_x ? P.c2[0] : P.c2[1], c2q = major_x ? P.c2[1] : P.c2[0];
+    const double pm_d = major_x ? P.um : P.vm, pq_d = major_x ? P.vm : P.um;   // sensor position, cell units
+    const int gm = major_x ? ma.gx : ma.gy, gq = major_x ? ma.gy : ma.gx;
+    const int Im = (int)floor(pm_d), Iq = (int)floor(pq_d);
+    const float fm = (float)(pm_d - (double)Im), fq = (float)(pq_d - (double)Iq);   // fraction inside the sensor's cell
+    // range of the major coordinate (metres from the sensor) over s in [-s_neg, s_pos], t in [t_a, t_b]
+    const float m0 = fminf(-s_neg * c1m, s_pos * c1m) + fminf(-t_a * c2m, -t_b * c2m);
+    const float m1 = fmaxf(-s_neg * c1m, s_pos * c1m) + fmaxf(-t_a * c2m, -t_b * c2m);
+    int k_lo = Im + (int)floorf(fm + m0 * ics), k_hi = Im + (int)floorf(fm + m1 * ics);
+    k_lo = max(k_lo, 0);
+    k_hi = min(k_hi, gm - 1);
+    const float rmq = c1q * __builtin_amdgcn_rcpf(c1m);   // |.| <= 1
+    const float kq = c2m * rmq - c2q;                      // minor coordinate: q = m rmq + t kq
+    // The columns are taken in chunks of at most 64 (one per lane), sized evenly; per chunk three phases share the
+    // wave's list in LDS.
+    const int ncols = k_hi - k_lo + 1;
+    const int nchunks = (ncols + SLICE_COLS - 1) / SLICE_COLS;
+    int per_chunk = nchunks > 0 ? (ncols + nchunks - 1) / nchunks : 1;
+    bool overflow = false;
+    for (int cbase = k_lo; cbase <= k_hi;) {
+      // ---- phase A: lanes = columns.  The triangle records of the cells the plane cuts go onto the list, one word per
+      // record (the order of the list is the order of the LDS atomics -- a minimum does not care).  The cell words of a
+      // column's rows are loaded as one batch: ONE memory latency per chunk.
+      if (lane == 0) *tcount = 0u;
+      const int col = cbase + lane;
+      const bool col_ok = lane < per_chunk && col <= k_hi;
+      // this column's slab of the major coordinate (metres from the sensor), and the minor range of the plane over it
+      const float ma0 = ((float)(col - Im) - fm) * cs, ma1 = ma0 + cs;
+      const float q0 = fminf(ma0 * rmq, ma1 * rmq) + fminf(t_a * kq, t_b * kq);
+      const float q1 = fmaxf(ma0 * rmq, ma1 * rmq) + fmaxf(t_a * kq, t_b * kq);
+      int r_lo = Iq + (int)floorf(fq + q0 * ics), r_hi = Iq + (int)floorf(fq + q1 * ics);
+      r_lo = max(r_lo, 0);
+      r_hi = col_ok ? min(r_hi, gq - 1) : r_lo - 1;
+      for (int rb = r_lo; __builtin_amdgcn_ballot_w64(rb <= r_hi) != 0ull; rb += SLICE_ROWS) {
+        uint2 info[SLICE_ROWS];
+#pragma unroll
+        for (int r = 0; r < SLICE_ROWS; ++r) {
+          const int row = rb + r;
+          const size_t c = major_x ? (size_t)col * ma.gy + row : (size_t)row * ma.gy + col;
+          info[r] = row <= r_hi ? ma.cell_info[c] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < SLICE_ROWS; ++r) {
+          const int row = rb + r;
+          u32 cnt = info[r].y >> 27;
+          if (cnt == 0u) continue;
+          const int ci = major_x ? col : row, cj = major_x ? row : col;
+          const u32 rs = info[r].y & 0x7ffffffu;
+          // the cell's box against the plane (its own z-range, conservative half floats)
+          float zlo, zhi;
+          cell_zrange(info[r].x, zlo, zhi);
+          const float I0x = (float)(ci - (major_x ? Im : Iq)) - (major_x ? fm : fq), I0y = (float)(cj - (major_x ? Iq : Im)) - (major_x ? fq : fm);
+          const float cxm = (I0x + 0.5f) * cs, cym = (I0y + 0.5f) * cs, czm = 0.5f * (zlo + zhi) - oz;
+          const float dist = nx * cxm + ny * cym + nz * czm;
+          const float ext = 0.5f * cs * (fabsf(nx) + fabsf(ny)) + (0.5f * (zhi - zlo) + 1e-3f) * fabsf(nz) + 1e-4f;
+          if (!(fabsf(dist) <= ext)) continue;
+          if (cnt == 31u) cnt = ma.cell_start[(size_t)ci * ma.gy + cj + 1] - rs;   // "31 or more": the exact count
+          const u32 pos = __hip_atomic_fetch_add(tcount, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (u32 k = 0; k < cnt && pos + k < SLICE_LIST; ++k) tlist[pos + k] = rs + k;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      const u32 ntri = (u32)__builtin_amdgcn_readfirstlane((int)*(volatile unsigned*)tcount);
+      if (ntri > SLICE_LIST) {   // more records than the list holds (wave-uniform): the same columns again in halves
+        if (per_chunk > 1) {
+          per_chunk = (per_chunk + 1) >> 1;
+          continue;
+        }
+        overflow = true;   // (one column alone: a pile-up of records) -> the general kernel casts this particle
+        break;
+      }
+      // ---- phase B1: lanes = triangles of the list.  Which of them does the plane separate?  The list is compacted
+      // in place (ballot + prefix count: every lane has read its entry before any lane writes), so that the expensive
+      // phase runs with all lanes busy
+      u32 nseg = 0;
+      for (u32 base = 0; base < ntri; base += 64) {
+        const u32 it = base + lane;
+        const u32 k = it < ntri ? tlist[it] : 0u;
+        bool cut = false;
+        if (it < ntri) {
+          const float4 v0 = ma.cell_tri[3 * (size_t)k], v1 = ma.cell_tri[3 * (size_t)k + 1], v2 = ma.cell_tri[3 * (size_t)k + 2];
+          const float d0 = fmaf(nx, (v0.x - Oxf) - dOx, fmaf(ny, (v0.y - Oyf) - dOy, nz * (v0.z - oz)));
+          const float d1 = fmaf(nx, (v1.x - Oxf) - dOx, fmaf(ny, (v1.y - Oyf) - dOy, nz * (v1.z - oz)));
+          const float d2 = fmaf(nx, (v2.x - Oxf) - dOx, fmaf(ny, (v2.y - Oyf) - dOy, nz * (v2.z - oz)));
+          const bool p0 = d0 > 0.f, p1 = d1 > 0.f, p2 = d2 > 0.f;
+          cut = !(p0 == p1 && p1 == p2);   // (NaN vertices: all false, not cut)
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cut);
+        if (cut) tlist[nseg + (u32)__popcll(m & ((1ull << lane) - 1ull))] = k;
+        nseg += (u32)__popcll(m);
+      }
+      // ---- phase B2: lanes = triangles the plane separates
+      for (u32 it = lane; it < nseg; it += 64) {
+      const size_t k = tlist[it];
+      const float4 c0 = ma.cell_tri[3 * k], c1v = ma.cell_tri[3 * k + 1], c2v = ma.cell_tri[3 * k + 2];
+      // vertices relative to the sensor (v - O with O = Of + dO: exact up to one ulp of a <= 100 m difference)
+      const float x0 = (c0.x - Oxf) - dOx, y0 = (c0.y - Oyf) - dOy, z0 = c0.z - oz;
+      const float x1 = (c1v.x - Oxf) - dOx, y1 = (c1v.y - Oyf) - dOy, z1 = c1v.z - oz;
+      const float x2 = (c2v.x - Oxf) - dOx, y2 = (c2v.y - Oyf) - dOy, z2 = c2v.z - oz;
+      const float d0 = fmaf(nx, x0, fmaf(ny, y0, nz * z0)), d1 = fmaf(nx, x1, fmaf(ny, y1, nz * z1)),
+                  d2 = fmaf(nx, x2, fmaf(ny, y2, nz * z2));
+      const bool p0 = d0 > 0.f, p1 = d1 > 0.f, p2 = d2 > 0.f;
+      // the vertex alone on its side, and the two others: crossings on the edges (L, M) and (L, N)
+      const int L = (p0 != p1 && p0 != p2) ? 0 : ((p1 != p0 && p1 != p2) ? 1 : 2);
+      const float xl = L == 0 ? x0 : (L == 1 ? x1 : x2), yl = L == 0 ? y0 : (L == 1 ? y1 : y2), zl = L == 0 ? z0 : (L == 1 ? z1 : z2);
+      const float xm = L == 0 ? x1 : x0, ym = L == 0 ? y1 : y0, zm = L == 0 ? z1 : z0;
+      const float xn = L == 2 ? x1 : x2, yn = L == 2 ? y1 : y2, zn = L == 2 ? z1 : z2;
+      const float dl = L == 0 ? d0 : (L == 1 ? d1 : d2), dm = L == 0 ? d1 : d0, dn = L == 2 ? d1 : d2;
+      // in-plane coordinates of the three
+      const float sl = fmaf(P.c1[0], xl, fmaf(P.c1[1], yl, P.c1[2] * zl)), tl = -fmaf(P.c2[0], xl, fmaf(P.c2[1], yl, c2z * zl));
+      const float sm = fmaf(P.c1[0], xm, fmaf(P.c1[1], ym, P.c1[2] * zm)), tm = -fmaf(P.c2[0], xm, fmaf(P.c2[1], ym, c2z * zm));
+      const float sn = fmaf(P.c1[0], xn, fmaf(P.c1[1], yn, P.c1[2] * zn)), tn = -fmaf(P.c2[0], xn, fmaf(P.c2[1], yn, c2z * zn));
+      // crossing of an edge, always from its vertex below the plane (d <= 0) to the one above: the same operands in
+      // the same order from either triangle on the edge
+      const bool lpos = dl > 0.f;
+      float sA, tA, sB, tB;
+      {
+        const float db = lpos ? dm : dl, da = lpos ? dl : dm;            // below, above
+        const float sbv = lpos ? sm : sl, sav = lpos ? sl : sm, tbv = lpos ? tm : tl, tav = lpos ? tl : tm;
+        const float lam = db * __builtin_amdgcn_rcpf(db - da);
+        sA = fmaf(lam, sav - sbv, sbv);
+        tA = fmaf(lam, tav - tbv, tbv);
+      }
+      {
+        const float db = lpos ? dn : dl, da = lpos ? dl : dn;
+        const float sbv = lpos ? sn : sl, sav = lpos ? sl : sn, tbv = lpos ? tn : tl, tav = lpos ? tl : tn;
+        const float lam = db * __builtin_amdgcn_rcpf(db - da);
+        sB = fmaf(lam, sav - sbv, sbv);
+        tB = fmaf(lam, tav - tbv, tbv);
+      }
+      if (!(tA > 0.f) && !(tB > 0.f)) continue;   // behind the sensor's own horizon (or NaN)
+      // tangents of the end points as seen from the sensor (an end point behind the horizon: beyond every beam)
+      const float INF = __builtin_inff();
+      const float TA = tA > 0.f ? sA * __builtin_amdgcn_rcpf(tA) : (sA > 0.f ? INF : -INF);
+      const float TB = tB > 0.f ? sB * __builtin_amdgcn_rcpf(tB) : (sB > 0.f ? INF : -INF);
+      const float T_lo = fminf(TA, TB), T_hi = fmaxf(TA, TB);
+      if (T_hi < tan_lo || T_lo > tan_hi) continue;
+      // first beam with tan >= T_lo (minus a hair: rounding of the quotient), by bisection
+      const float T_first = T_lo - 1e-6f * fmaxf(1.f, fabsf(T_lo)), T_last = T_hi + 1e-6f * fmaxf(1.f, fabsf(T_hi));
+      int lo = 0, hi = B;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (tanb[mid] < T_first) lo = mid + 1; else hi = mid;
+      }
+      const float dts = tB - tA;
+      for (int b = lo; b < B; ++b) {
+        const float T = tanb[b];
+        if (T > T_last) break;
+        // crossing of the half line s = t T with the segment A -> B: e = s - T t changes sign
+        const float eA = fmaf(-T, tA, sA), eB = fmaf(-T, tB, sB);
+        if ((eA > 0.f) == (eB > 0.f) && eA != 0.f && eB != 0.f) continue;
+        const float den = eA - eB;
+        float lam = den != 0.f ? eA * __builtin_amdgcn_rcpf(den) : 0.f;
+        lam = fminf(fmaxf(lam, 0.f), 1.f);
+        const float tau = fmaf(lam, dts, tA);
+        if (!(tau > 0.f)) continue;
+        const float range = tau * secb[b];
+        if (range < a.r_max) lds_min_range(&rng[b], range);
+      }
+      }
+      cbase += per_chunk;
+    }
+    if (overflow) {   // (wave-uniform)
+      if (lane == 0) a.defer_idx[atomicAdd(a.defer_count, 1)] = (u32)i;
+      continue;
+    }
+    // (the LDS operations of one wave complete in order: no barrier between its lanes' minima and the reads below)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    float acc = 0.f;
+    int nvalid = 0;
+    for (int b = lane; b < B; b += 64) {
+      const float e = __uint_as_float(rng[b]);
+      if (EXPECT_ONLY) {
+        a.exp_out[(size_t)(i - a.exp_first) * B + b] = e;
+      } else {
+        const float rm = a.ranges[b];
+        if (rm > 0.f) {  // NaN fails the test
+          const float d = (rm - e) * a.inv_sigma;
+          acc += d * d;
+          ++nvalid;
+        }
+      }
+    }
+    if (!EXPECT_ONLY) {
+      const double accd = wave_sum((double)acc);
+      const int nv = wave_sum(nvalid);
+      if (lane == 0) {
+        const double v = -0.5 * accd - (double)nv * a.lognorm;
+        a.lw[i] = v;
+        wmax = v > wmax ? v : wmax;  // NaN never wins
+      }
+    }
+  }
+  if (!EXPECT_ONLY && lane == 0 && a.max_slots && wmax > -__builtin_inf())
+    atomicMax((unsigned long long*)&a.max_slots[(blockIdx.x * SLICE_WAVES + w) & (MCL_MAX_SLOTS - 1)], ordered_key(wmax));
+}

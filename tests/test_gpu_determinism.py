@@ -95,7 +95,7 @@ def test_same_update_twice_is_bitwise_equal_on_a_border_straddling_cloud(kind, e
 
 @pytest.mark.parametrize('kind,sweep,sort', [('mesh', '1', None), ('grid', '1', None), ('tin', '1', None),
                                              ('mesh', '0', '0'), ('mesh', '0', '1'), ('grid', '0', '1'), ('soup', '0', '0'),
-                                             ('soup', '0', '1')])
+                                             ('soup', '0', '1'), ('soup-slice', '0', None)])
 def test_permuting_the_particles_permutes_the_log_weights(kind, sweep, sort, eng, terrain, monkeypatch):
     """Grouping independence: shuffle the slots of a wide, border-straddling cloud -- every group of 8, every tile, every
     hand-over list changes -- and the log-weight of each particle keeps its bits."""
@@ -103,17 +103,23 @@ def test_permuting_the_particles_permutes_the_log_weights(kind, sweep, sort, eng
     if sort is not None:
         monkeypatch.setenv('MCL_SORT_VISITS', sort)
     kw = {}
+    expect = int(sweep)
+    tilt = 0.08
     if kind == 'soup':
         m, kw = _maps(terrain, 'mesh'), dict(general=True)
+        monkeypatch.setenv('MCL_SLICE', '0')           # the ray traversal over triangle records
+    elif kind == 'soup-slice':
+        m, kw = _maps(terrain, 'tin'), dict(general=True)
+        expect, tilt = 2, 0.5                          # the fan slice; rolls of 30 degrees and more are handed over
     else:
         m = _maps(terrain, kind)
     n = 20000
-    soa = _cloud(n, 60.0, -30.0, seed=11, tilt=0.08)
+    soa = _cloud(n, 60.0, -30.0, seed=11, tilt=tilt)
     soa[:, :64] = _cloud(64, 0.05, 100.0, seed=2)      # a tight clump well inside the map among them
     ba, ranges = _ping(200)
     lw0, path0 = _update(eng, m, soa, ba, ranges, **kw)
-    assert path0[0] == int(sweep)
-    if sweep == '1':
+    assert path0[0] == expect
+    if expect:
         assert path0[1] > 100, path0
     else:
         assert path0[2] > 10, path0                    # groups the fast kernel left to the general one

@@ -31,6 +31,9 @@ def _engine_with_map(eng, g, general=False):
 @pytest.mark.parametrize('name,general,sweep', [('mbes_grid_interior', False, False), ('mbes_grid_rough', False, False),
                                                 ('mbes_grid_border', False, False), ('mbes_mesh_regular', False, False),
                                                 ('mbes_mesh_regular', True, False), ('mbes_mesh_tin', False, False),
+                                                # triangle soups: the fan slice (mcl_slice.h) / the ray traversal over records
+                                                ('mbes_mesh_regular', 'slice', False), ('mbes_mesh_tin', 'slice', False),
+                                                ('mbes_tin_sweep', 'slice', False), ('mbes_mesh_sweep', 'slice', False),
                                                 # the fan sweep (mcl_sweep.h), forced for these small pose sets
                                                 ('mbes_mesh_regular', False, True), ('mbes_grid_interior', False, True),
                                                 ('mbes_grid_rough', False, True), ('mbes_grid_border', False, True),
@@ -42,7 +45,8 @@ def _engine_with_map(eng, g, general=False):
 def test_gpu_expected_ranges_and_loglik_match_independent_golden(name, general, sweep, eng, monkeypatch):
     g = helpers.load(name)
     monkeypatch.setenv('MCL_SWEEP', '1' if sweep else '0')
-    e, n = _engine_with_map(eng, g, general)
+    monkeypatch.setenv('MCL_SLICE', '1' if general == 'slice' else '0')
+    e, n = _engine_with_map(eng, g, bool(general))
     r_max, sigma = float(g['r_max']), float(g['sigma'])
     got = e.mbes_expected(0, n, g['beam_angles'], r_max, g['sensor_offset'])
     ok = g['ok']
@@ -51,7 +55,9 @@ def test_gpu_expected_ranges_and_loglik_match_independent_golden(name, general, 
         name, ' (general path)' if general else '', err[ok].max(), int(ok.sum()), int((g['expected'] >= r_max)[ok].sum())))
     assert err[ok].max() <= 1e-3
     path, handed, _ = e.mbes_last_path()
-    assert path == (1 if sweep else 0)
+    assert path == (1 if sweep else (2 if general == 'slice' else 0))
+    if general == 'slice':
+        print('   fan slice: %d of %d poses handed to the general kernel' % (handed, n))
     if sweep:
         print('   fan sweep: %d of %d poses handed to the traversal kernels' % (handed, n))
         # (small maps / rough terrain: the sweep declines, the result is checked either way; the *_sweep maps are

@@ -481,13 +481,13 @@ def test_tin_with_holes_hands_over_and_folded_mesh_is_not_swept(eng, orc, monkey
         monkeypatch.setenv('MCL_SWEEP', '0')
         e0 = _engine(eng, soa, verts, holes)
         got0 = e0.mbes_expected(0, n, ba, 80.0)
-        assert e0.mbes_last_path()[0] == 0
+        assert e0.mbes_last_path()[0] != 1   # (the fan slice or the ray traversal: either is independent of the sweep)
         monkeypatch.delenv('MCL_SWEEP')
         assert np.abs(got - got0)[bad].max() <= 1e-3, (err[bad], np.abs(got - got0)[bad])
     dup = np.ascontiguousarray(np.concatenate([tris, tris[:1]], axis=0))
     e2 = _engine(eng, soa, verts, dup)
     e2.mbes_expected(0, n, ba, 80.0)
-    assert e2.mbes_last_path()[0] == 0
+    assert e2.mbes_last_path()[0] != 1
 
 
 def test_two_sheets_overlapping_in_xy_are_not_swept(eng, orc, monkeypatch):
@@ -495,7 +495,7 @@ def test_two_sheets_overlapping_in_xy_are_not_swept(eng, orc, monkeypatch):
     adjacency build passes (each sheet is edge-manifold and fold-free) but the mesh is not single-valued over (x, y):
     a walk by adjacency from the nadir triangle would never meet the other sheet.  mesh_build proves global
     single-valuedness (pairwise xy-overlap test per cell) before it allows the sweep, so this map is cast by the
-    traversal kernels -- at a cloud size where a TIN would otherwise be swept -- and matches the oracle's nearest hit."""
+    fan slice (mcl_slice.h: any triangle soup) -- at a cloud size where a TIN would otherwise be swept -- and matches the oracle's nearest hit."""
     monkeypatch.delenv('MCL_SWEEP', raising=False)
     z, origin = _terrain(seed=33)
     verts, tris = synth.mesh_tin(z, 1.0, origin, seed=6)
@@ -509,7 +509,7 @@ def test_two_sheets_overlapping_in_xy_are_not_swept(eng, orc, monkeypatch):
     ba = synth.beam_angles(B)
     e = _engine(eng, soa, v2, t2)
     got = e.mbes_expected(0, 512, ba, 80.0)
-    assert e.mbes_last_path()[0] == 0, 'a two-sheet mesh must not go through the adjacency sweep'
+    assert e.mbes_last_path()[0] != 1, 'a two-sheet mesh must not go through the adjacency sweep'
     sub = np.ascontiguousarray(soa[:, :512])
     _, ref = orc.mbes_update(sub, np.identity(4), [0] * 6, orc.Mesh(v2, t2), ba, None, 0.2, 80.0)
     err = np.abs(got - ref)

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 V=$1; M=$2
 if [ $V != main ]; then export MCL_LIB=$R/variants/$V.so; else unset MCL_LIB; fi
-O=/tmp/pmc_$V_$M; rm -rf $O; mkdir -p $O
+O=/tmp/pmc_${V}_${M}; rm -rf $O; mkdir -p $O
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY --output-format csv -d $O/a -- python3 $R/bench.py --map $M --steps 4 --warmup 1 --only-main > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD --output-format csv -d $O/b -- python3 $R/bench.py --map $M --steps 4 --warmup 1 --only-main > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s -- python3 $R/bench.py --map $M --steps 20 --warmup 3 --only-main > /dev/null 2>&1
