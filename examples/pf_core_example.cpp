@@ -2,7 +2,7 @@
 // without ROS: a map file, odometry, a LaserScan ping, the same ping as points in base_frame, a GPS fix, a tick.
 //   g++ -std=c++14 -Iinclude -Iros/auv_particle_filter_hip/include examples/pf_core_example.cpp \
 //       -Lsmarc_navigation_amd -lmcl_hip -Wl,-rpath,$PWD/smarc_navigation_amd -o /tmp/pf_core_example
-//   /tmp/pf_core_example map.mclgrid ranges.txt   -> one line of numbers (tests/test_cpp_core.py compares it with
+//   /tmp/pf_core_example map.mclgrid ranges.txt [landmarks.yaml]   -> one line of numbers (tests/test_cpp_core.py compares it with
 //   the Python mirror fed the same inputs)
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +23,10 @@ int main(int argc, char** argv) {
   p.measurement_std = 1.0;
   p.mbes_sensor_offset = "[0.3, 0.0, -0.1, 0.0, 0.05, 0.0]";
   p.map_grid_file = argv[1];
+  if (argc > 3) {   // BASELINE config 5: a landmark map; two detections arrive with the first ping
+    p.landmark_map_file = argv[3];
+    p.landmark_k = 2;
+  }
   std::vector<float> ranges;
   {
     std::ifstream f(argv[2]);
@@ -56,7 +60,11 @@ int main(int argc, char** argv) {
   }
   for (int k = 0; k < 3; ++k) {
     if (!core.odom(100.02 + 0.02 * k, v, 0.05, q0, -2.0)) return 1;
-    if (k == 1 && !core.ping_scan(ranges.data(), B, amin, ainc, 80.0)) return 1;
+    if (k == 1 && argc > 3) {
+      const double det[6] = {3.0, 4.0, -18.0, -2.0, -6.0, -17.5};   // base_frame, stamped like the ping
+      if (!core.detections(100.02 + 0.02 * k, det, 2)) return 1;
+    }
+    if (k == 1 && !core.ping_scan(ranges.data(), B, amin, ainc, 80.0, 100.02 + 0.02 * k)) return 1;
     if (k == 2 && !core.ping_points(pts.data(), B, false)) return 1;
   }
   core.dive(false);

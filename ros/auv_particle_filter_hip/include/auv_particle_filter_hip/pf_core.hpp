@@ -7,7 +7,8 @@
 // update / resample (:125-192) with the gate specified away as in SURVEY A.10 ("every fix after the first predict
 // while not diving"), update_loc_pose (:218-260: covariance in the first nine of 36 slots, tf translation z = 0).
 // Beyond the reference: the bathymetric map and the MBES ping (LaserScan geometry of toy_mbes_manipulator.cpp:69-73;
-// a point cloud in base_frame as mbes_receptor.cpp:126-165 leaves it).  One owner at a time: the node serialises its
+// a point cloud in base_frame as mbes_receptor.cpp:126-165 leaves it); the landmark map and the receptors' detections
+// (BASELINE config 5: map_provider_node.py:35-56, toy_mbes_receptor.cpp:68-110).  One owner at a time: the node serialises its
 // callbacks with a mutex (the reference's three rospy threads are unlocked).
 #pragma once
 #include <algorithm>
@@ -41,6 +42,12 @@ struct Params {
   double mbes_std = 0.2, mbes_range_max = 100.0;
   std::string mbes_sensor_offset = "[0.0, 0.0, 0.0, 0.0, 0.0, 0.0]";
   std::string map_grid_file = "", map_mesh_file = "";
+  // BASELINE config 5: landmark map (the .yaml of the reference's map provider, map_provider_node.py:35-56, or x y z
+  // rows; map frame; models with z < rocks_depth kept) and the detections of the MBES receptors
+  // (geometry_msgs/PoseArray in base_frame, toy_mbes_receptor.cpp:68-110; ekf_slam.cpp:41 names the topic parameter)
+  std::string landmark_map_file = "", lm_detect_topic = "/landmarks_detected";
+  double rocks_depth = 1e300, landmark_std = 0.3, landmark_gate = 11.345, landmark_sync_tol = 0.5;
+  int landmark_k = 1;
 };
 
 // the reference's ad-hoc parser (auv_pf.py:40-44): strip the brackets, split on ", "
@@ -152,6 +159,77 @@ inline bool load_map_file(const std::string& path, MapFile& m, std::string& err)
   return false;
 }
 
+// Landmark map: n x (x, y, z) in the map frame.  A .yaml / .yml file is read the way the reference's map provider reads
+// its Gazebo model list (map_provider_node.py:43-52) without a YAML library: every `position:` block contributes its
+// x / y / z scalars, in whichever order they appear; anything else is whitespace-separated x y z rows.  Landmarks with
+// z >= rocks_depth are dropped (the provider's filter).
+inline bool load_landmark_file(const std::string& path, double rocks_depth, std::vector<double>& xyz, std::string& err) {
+  std::ifstream f(path);
+  if (!f) {
+    err = "cannot open " + path;
+    return false;
+  }
+  xyz.clear();
+  const bool yaml = path.size() > 4 && (path.rfind(".yaml") == path.size() - 5 || path.rfind(".yml") == path.size() - 4);
+  std::string line;
+  if (yaml) {
+    double p[3] = {0, 0, 0};
+    int have = 0;
+    bool in_pos = false;
+    auto flush = [&]() {
+      if (have == 7 && p[2] < rocks_depth) xyz.insert(xyz.end(), p, p + 3);
+      have = 0;
+    };
+    while (std::getline(f, line)) {
+      const size_t c = line.find(':');
+      if (c == std::string::npos) continue;
+      std::string key = line.substr(0, c), val = line.substr(c + 1);
+      key.erase(0, key.find_first_not_of(" \t-{"));
+      key.erase(key.find_last_not_of(" \t") + 1);
+      if (key == "position") {
+        flush();
+        in_pos = true;
+        // flow style on one line: position: {x: 1, y: 2, z: 3}
+        for (const char* k : {"x", "y", "z"}) {
+          const size_t q = val.find(std::string(k) + ":");
+          if (q != std::string::npos) {
+            p[k[0] - 'x'] = std::strtod(val.c_str() + q + 2, nullptr);
+            have |= 1 << (k[0] - 'x');
+          }
+        }
+        if (have == 7) {
+          flush();
+          in_pos = false;
+        }
+        continue;
+      }
+      if (in_pos && key.size() == 1 && key[0] >= 'x' && key[0] <= 'z') {
+        p[key[0] - 'x'] = std::strtod(val.c_str(), nullptr);
+        have |= 1 << (key[0] - 'x');
+        if (have == 7) {
+          flush();
+          in_pos = false;
+        }
+      } else if (in_pos) {
+        in_pos = false;
+        have = 0;
+      }
+    }
+    flush();
+  } else {
+    while (std::getline(f, line)) {
+      std::istringstream t(line);
+      double p[3];
+      if ((t >> p[0] >> p[1] >> p[2]) && p[2] < rocks_depth) xyz.insert(xyz.end(), p, p + 3);
+    }
+  }
+  if (xyz.empty()) {
+    err = path + ": no landmarks (all filtered by rocks_depth?)";
+    return false;
+  }
+  return true;
+}
+
 class Core {
  public:
   Core() = default;
@@ -191,7 +269,34 @@ class Core {
     if (!check(mcl_init_particles(h_, nullptr))) return false;
     for (const std::string* path : {&p.map_grid_file, &p.map_mesh_file})
       if (!path->empty() && !load_map(*path)) return false;
+    if (!p.landmark_map_file.empty()) {
+      std::vector<double> xyz;
+      if (!load_landmark_file(p.landmark_map_file, p.rocks_depth, xyz, err_)) return false;
+      if (!set_landmarks(xyz.data(), (int64_t)(xyz.size() / 3))) return false;
+    }
     return true;
+  }
+
+  bool set_landmarks(const double* xyz, int64_t n) {
+    const bool ok = check(mcl_set_landmarks(h_, xyz, n));
+    has_landmarks_ = has_landmarks_ || ok;
+    return ok;
+  }
+  bool has_landmarks() const { return has_landmarks_; }
+
+  // Landmark detections of one ping (base_frame positions, toy_mbes_receptor.cpp:75-105).  With a bathymetric map they
+  // wait for their ping -- the next ping_scan / ping_points within landmark_sync_tol seconds adds their log-likelihood
+  // to the ping's (mcl_update_landmarks, accumulate = 1) before the resampling; without one they are a measurement
+  // update of their own followed by the resampling, like a GPS fix.
+  bool detections(double stamp, const double* xyz, int n_det) {
+    if (old_time_ == 0.0 || !has_landmarks_ || n_det < 1) return true;
+    if (has_map_) {
+      pending_stamp_ = stamp;
+      pending_det_.assign(xyz, xyz + (size_t)n_det * 3);
+      return true;
+    }
+    return check(mcl_update_landmarks(h_, xyz, n_det, p_.landmark_std, p_.landmark_k, p_.landmark_gate, nullptr, 0)) &&
+           check(mcl_resample(h_, nullptr, 0, nullptr));
   }
 
   bool load_map(const std::string& path) {
@@ -234,18 +339,18 @@ class Core {
   }
 
   // one ping as a LaserScan: angle_min + k * angle_increment, ranges[k]
-  bool ping_scan(const float* ranges, int n, double angle_min, double angle_increment, double range_max) {
+  bool ping_scan(const float* ranges, int n, double angle_min, double angle_increment, double range_max, double stamp = 0.0) {
     if (old_time_ == 0.0 || !has_map_ || n < 1) return true;
     angles_.resize(n);
     for (int k = 0; k < n; ++k) angles_[k] = (float)(angle_min + angle_increment * k);
     return check(mcl_update_mbes(h_, ranges, angles_.data(), n, p_.mbes_std, range_max, offset_)) &&
-           check(mcl_resample(h_, nullptr, 0, nullptr));
+           accumulate_pending(stamp) && check(mcl_resample(h_, nullptr, 0, nullptr));
   }
 
   // one ping as points (x, y, z triples): every point is a beam's hit.  In the sensor frame beam b looks along
   // (0, sin a, -cos a), so a_b = atan2(y, -z) and the range is |p|; points in base_frame are taken back through the
   // sensor offset first; the beams are handed over in ascending angle.  NaN points are dropped.
-  bool ping_points(const float* xyz, int n_points, bool in_sensor_frame) {
+  bool ping_points(const float* xyz, int n_points, bool in_sensor_frame, double stamp = 0.0) {
     if (old_time_ == 0.0 || !has_map_) return true;
     double R[9];
     rot(offset_[3], offset_[4], offset_[5], R);
@@ -269,7 +374,7 @@ class Core {
       ranges_[k] = beams[k].second;
     }
     return check(mcl_update_mbes(h_, ranges_.data(), angles_.data(), (int)beams.size(), p_.mbes_std, p_.mbes_range_max, offset_)) &&
-           check(mcl_resample(h_, nullptr, 0, nullptr));
+           accumulate_pending(stamp) && check(mcl_resample(h_, nullptr, 0, nullptr));
   }
 
   // update_loc_pose (auv_pf.py:218-260): mean pose, arithmetic mean of the wrapped yaws, 3 x 3 position covariance
@@ -292,6 +397,16 @@ class Core {
   mcl_handle* handle() { return h_; }
 
  private:
+  // right after an MBES update: the detections of this ping, if any, onto its likelihood (detections of another ping
+  // are dropped, never applied to the wrong one)
+  bool accumulate_pending(double ping_stamp) {
+    if (pending_det_.empty()) return true;
+    std::vector<double> det;
+    det.swap(pending_det_);
+    if (std::fabs(ping_stamp - pending_stamp_) > p_.landmark_sync_tol) return true;
+    return check(mcl_update_landmarks(h_, det.data(), (int)(det.size() / 3), p_.landmark_std, p_.landmark_k, p_.landmark_gate,
+                                      nullptr, 1));
+  }
   static void rot(double roll, double pitch, double yaw, double R[9]) {
     const double cr = std::cos(roll), sr = std::sin(roll), cp = std::cos(pitch), sp = std::sin(pitch);
     const double cy = std::cos(yaw), sy = std::sin(yaw);
@@ -310,6 +425,9 @@ class Core {
   double offset_[6] = {0, 0, 0, 0, 0, 0};
   double time_ = 0.0, old_time_ = 0.0;
   bool diving_ = true, has_map_ = false;   // auv_pf.py:103
+  bool has_landmarks_ = false;
+  double pending_stamp_ = 0.0;
+  std::vector<double> pending_det_;
   std::vector<float> angles_, ranges_;
   std::string err_;
 };

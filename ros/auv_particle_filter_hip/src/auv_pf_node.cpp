@@ -57,7 +57,15 @@ class AuvPfNode {
     pnh_.param("mbes_sensor_offset", p.mbes_sensor_offset, p.mbes_sensor_offset);
     pnh_.param("map_grid_file", p.map_grid_file, p.map_grid_file);
     pnh_.param("map_mesh_file", p.map_mesh_file, p.map_mesh_file);
+    pnh_.param("landmark_map_file", p.landmark_map_file, p.landmark_map_file);
+    pnh_.param("rocks_depth", p.rocks_depth, p.rocks_depth);
+    pnh_.param("lm_detect_topic", p.lm_detect_topic, p.lm_detect_topic);
+    pnh_.param("landmark_std", p.landmark_std, p.landmark_std);
+    pnh_.param("landmark_k", p.landmark_k, p.landmark_k);
+    pnh_.param("landmark_gate", p.landmark_gate, p.landmark_gate);
+    pnh_.param("landmark_sync_tol", p.landmark_sync_tol, p.landmark_sync_tol);
     pnh_.param("max_published_poses", max_poses_, 5000);
+    if (max_poses_ < 1) max_poses_ = 1;   // (the stride of the thinned PoseArray divides by it)
 
     // map <- odom once at start, 60 s timeout; exit quietly on failure (auv_pf.py:76-87)
     double m2o[16];
@@ -87,6 +95,7 @@ class AuvPfNode {
     gps_sub_ = nh.subscribe(p.gps_odom_topic, 100, &AuvPfNode::gpsCb, this);
     scan_sub_ = nh.subscribe(p.mbes_topic, 10, &AuvPfNode::scanCb, this);
     if (!p.mbes_pointcloud_topic.empty()) cloud_sub_ = nh.subscribe(p.mbes_pointcloud_topic, 10, &AuvPfNode::cloudCb, this);
+    if (core_.has_landmarks()) lm_sub_ = nh.subscribe(p.lm_detect_topic, 10, &AuvPfNode::lmCb, this);   // config 5
     odom_sub_ = nh.subscribe(p.odom_topic, 100, &AuvPfNode::odomCb, this);
     timer_ = nh.createTimer(ros::Duration(0.1), &AuvPfNode::locLoop, this);   // auv_pf.py:114
     ROS_INFO("Particle filter class successfully created");
@@ -125,20 +134,53 @@ class AuvPfNode {
   }
   void scanCb(const sensor_msgs::LaserScan::ConstPtr& s) {
     std::lock_guard<std::mutex> lk(mu_);
-    if (!core_.ping_scan(s->ranges.data(), (int)s->ranges.size(), s->angle_min, s->angle_increment, s->range_max))
+    if (!core_.ping_scan(s->ranges.data(), (int)s->ranges.size(), s->angle_min, s->angle_increment, s->range_max,
+                         s->header.stamp.toSec()))
       ROS_WARN_THROTTLE(1.0, "PF MBES update: %s", core_.error().c_str());
   }
-  void cloudCb(const sensor_msgs::PointCloud2::ConstPtr& c) {
-    std::vector<float> xyz;
-    xyz.reserve((size_t)c->width * c->height * 3);
-    sensor_msgs::PointCloud2ConstIterator<float> ix(*c, "x"), iy(*c, "y"), iz(*c, "z");
-    for (; ix != ix.end(); ++ix, ++iy, ++iz) {
-      xyz.push_back(*ix);
-      xyz.push_back(*iy);
-      xyz.push_back(*iz);
+  // detections of the MBES receptors: PoseArray in base_frame, positions only (toy_mbes_receptor.cpp:75-105)
+  void lmCb(const geometry_msgs::PoseArray::ConstPtr& m) {
+    std::vector<double> xyz;
+    xyz.reserve(m->poses.size() * 3);
+    for (const auto& ps : m->poses) {
+      xyz.push_back(ps.position.x);
+      xyz.push_back(ps.position.y);
+      xyz.push_back(ps.position.z);
     }
     std::lock_guard<std::mutex> lk(mu_);
-    if (!core_.ping_points(xyz.data(), (int)(xyz.size() / 3), core_.params().mbes_points_frame == "sensor"))
+    if (!core_.detections(m->header.stamp.toSec(), xyz.data(), (int)(xyz.size() / 3)))
+      ROS_WARN_THROTTLE(1.0, "PF landmark update: %s", core_.error().c_str());
+  }
+  void cloudCb(const sensor_msgs::PointCloud2::ConstPtr& c) {
+    // x / y / z as FLOAT32 (7) or FLOAT64 (8), whichever the cloud declares; anything else: the cloud is dropped
+    int dtype = 0;
+    for (const auto& fld : c->fields)
+      if (fld.name == "x") dtype = fld.datatype;
+    for (const auto& fld : c->fields)
+      if ((fld.name == "y" || fld.name == "z") && fld.datatype != dtype) dtype = 0;
+    std::vector<float> xyz;
+    xyz.reserve((size_t)c->width * c->height * 3);
+    if (dtype == 7) {
+      sensor_msgs::PointCloud2ConstIterator<float> ix(*c, "x"), iy(*c, "y"), iz(*c, "z");
+      for (; ix != ix.end(); ++ix, ++iy, ++iz) {
+        xyz.push_back(*ix);
+        xyz.push_back(*iy);
+        xyz.push_back(*iz);
+      }
+    } else if (dtype == 8) {
+      sensor_msgs::PointCloud2ConstIterator<double> ix(*c, "x"), iy(*c, "y"), iz(*c, "z");
+      for (; ix != ix.end(); ++ix, ++iy, ++iz) {
+        xyz.push_back((float)*ix);
+        xyz.push_back((float)*iy);
+        xyz.push_back((float)*iz);
+      }
+    } else {
+      ROS_WARN_THROTTLE(1.0, "PF: point cloud without FLOAT32 / FLOAT64 x, y, z fields: dropped");
+      return;
+    }
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!core_.ping_points(xyz.data(), (int)(xyz.size() / 3), core_.params().mbes_points_frame == "sensor",
+                           c->header.stamp.toSec()))
       ROS_WARN_THROTTLE(1.0, "PF MBES update: %s", core_.error().c_str());
   }
   void locLoop(const ros::TimerEvent&) {
@@ -197,7 +239,7 @@ class AuvPfNode {
   auv_pf_hip::Core core_;
   std::mutex mu_;
   ros::Publisher pf_pub_, loc_pub_;
-  ros::Subscriber dive_sub_, gps_sub_, scan_sub_, cloud_sub_, odom_sub_;
+  ros::Subscriber dive_sub_, gps_sub_, scan_sub_, cloud_sub_, lm_sub_, odom_sub_;
   ros::Timer timer_;
   std::vector<double> pose7_;
   int max_poses_ = 5000;

@@ -44,6 +44,17 @@ DEFAULT_PARAMS = {
     # mbes_receptor.cpp:126-165): '' = not subscribed.  `mbes_points_frame`: 'base' -- points in base_frame, as
     # transformLaserScanToPointCloud(base_frame_, ...) leaves them -- or 'sensor'
     'mbes_pointcloud_topic': '', 'mbes_points_frame': 'base', 'mbes_range_max': 100.0,
+    # BASELINE config 5: landmark detections with per-particle k-NN data association.  `landmark_map_file`: the
+    # feature map -- the .yaml the reference's map provider serves (auv_ekf_localization/scripts/map_provider_node.py:
+    # 35-56: a list of models with position {x, y, z}, those below `rocks_depth` kept), an .npz with `landmarks`
+    # (n, 3), or a text file of x y z rows; map frame.  '' = no landmark map: detections ignored.
+    # `lm_detect_topic`: geometry_msgs/PoseArray of detections in base_frame, positions only, as the MBES receptors
+    # publish them (mbes_toy_processor/src/toy_mbes_receptor.cpp:68-110; consumer auv_ekf_slam/src/ekf_slam.cpp:41).
+    # A detection message is held for the ping it came from (the receptor stamps it with the ping's stamp and
+    # publishes it after processing the ping): the next MBES update within `landmark_sync_tol` seconds adds its
+    # log-likelihood to the ping's before the resampling; without a bathymetric map it is an update of its own.
+    'landmark_map_file': '', 'rocks_depth': float('inf'), 'lm_detect_topic': '/landmarks_detected',
+    'landmark_std': 0.3, 'landmark_k': 1, 'landmark_gate': 11.345, 'landmark_sync_tol': 0.5,
 }
 
 
@@ -107,6 +118,28 @@ def load_map_file(path):
                 raise ValueError('%s: truncated height array' % path)
         return ('grid', z.reshape(nx, ny).astype(np.float32), (float(head[3]), float(head[4])), float(head[5]))
     raise ValueError('map file %s: expected .npz, .ply or .mclgrid' % path)
+
+
+def load_landmark_file(path, rocks_depth=float('inf')):
+    """(n, 3) float64 landmark positions in the map frame.  .yaml / .yml: the Gazebo model list of the reference's map
+    provider (map_provider_node.py:43-52: the first top-level entry is a list of models with position {x, y, z};
+    models with z < rocks_depth are kept -- the provider's own filter; its default keeps the ones below -90 m, the
+    default here keeps all); .npz: key `landmarks`; anything else: whitespace-separated x y z rows."""
+    low = path.lower()
+    if low.endswith('.npz'):
+        with np.load(path, allow_pickle=False) as f:
+            pts = np.asarray(f['landmarks'], np.float64).reshape(-1, 3)
+    elif low.endswith('.yaml') or low.endswith('.yml'):
+        import yaml
+        with open(path, 'r') as f:
+            data = yaml.safe_load(f)
+        models = list(data.values())[0] if isinstance(data, dict) else data
+        pts = np.array([[float(m['position']['x']), float(m['position']['y']), float(m['position']['z'])]
+                        for m in models], np.float64).reshape(-1, 3)
+    else:
+        pts = np.loadtxt(path, dtype=np.float64, ndmin=2)[:, :3]
+    keep = pts[:, 2] < float(rocks_depth)
+    return np.ascontiguousarray(pts[keep])
 
 
 def save_mclgrid(path, z, origin, res):
@@ -213,6 +246,13 @@ class auv_pf(object):
         for key in ('map_grid_file', 'map_mesh_file'):   # the node's own map parameters
             if p[key]:
                 self.load_map(p[key])
+        # landmark detections (config 5)
+        self.has_landmarks = False
+        self.landmark_std, self.landmark_k = float(p['landmark_std']), int(p['landmark_k'])
+        self.landmark_gate, self.landmark_sync_tol = float(p['landmark_gate']), float(p['landmark_sync_tol'])
+        self._pending_det = None   # (stamp, (n_det, 3) detections in base_frame) waiting for their ping
+        if p['landmark_map_file']:
+            self.set_landmarks(load_landmark_file(p['landmark_map_file'], float(p['rocks_depth'])))
 
     # ---- REPLAY-mode RNG source (parity runs): rs must offer randn(n, 6) and random_sample(k)
     def set_replay_source(self, rs):
@@ -290,6 +330,49 @@ class auv_pf(object):
         else:
             self.set_map_mesh(m[1], m[2])
 
+    # ---- landmark detections (BASELINE config 5)
+    def set_landmarks(self, xyz):
+        xyz = np.ascontiguousarray(np.asarray(xyz, np.float64).reshape(-1, 3))
+        if xyz.shape[0] == 0:
+            raise ValueError('landmark map: no landmarks (all filtered by rocks_depth?)')
+        with self.lock:
+            self.particles.set_landmarks(xyz)
+            self.has_landmarks = True
+
+    def lm_detect_cb(self, lm_msg):
+        """geometry_msgs/PoseArray of detections in base_frame (toy_mbes_receptor.cpp:75-105: positions only, stamped
+        with the ping's stamp).  With a bathymetric map the detections wait for their ping (mbes_cb adds their
+        log-likelihood to the ping's: mcl_update_landmarks(accumulate = 1)); without one they are a measurement update
+        of their own, followed by the resampling like a GPS fix."""
+        det = np.array([[p.position.x, p.position.y, p.position.z] for p in lm_msg.poses], np.float64).reshape(-1, 3)
+        if det.shape[0] == 0:
+            return
+        with self.lock:
+            if not (self.old_time and self.has_landmarks):
+                return
+            if self.has_map:
+                self._pending_det = (self._stamp_of(lm_msg), det)
+                return
+            self.particles.update_landmarks(det, self.landmark_std, k=self.landmark_k, gate=self.landmark_gate,
+                                            accumulate=False)
+            self.resample(self.particles)
+
+    def _stamp_of(self, msg):
+        """header.stamp in seconds; a message without one (hand-made test messages) counts as `now`."""
+        stamp = getattr(getattr(msg, 'header', None), 'stamp', None)
+        return float(stamp.to_sec()) if stamp is not None else float(self.time)
+
+    def _accumulate_pending_detections(self, ping_stamp):
+        """Called under the lock right after an MBES update: the detections of this ping, if any, onto its likelihood."""
+        if self._pending_det is None:
+            return
+        stamp, det = self._pending_det
+        self._pending_det = None
+        if abs(float(ping_stamp) - stamp) > self.landmark_sync_tol:
+            return   # (detections of another ping: dropped, never applied to the wrong one)
+        self.particles.update_landmarks(det, self.landmark_std, k=self.landmark_k, gate=self.landmark_gate,
+                                        accumulate=True)
+
     def mbes_pc_cb(self, cloud):
         """One ping as a sensor_msgs/PointCloud2 (or msgs.PointCloud2): every point is a beam's hit.  In the sensor
         frame beam b looks along (0, sin a_b, -cos a_b) (include/mcl.h), so a point gives a_b = atan2(y, -z) and the
@@ -310,6 +393,7 @@ class auv_pf(object):
                 return
             self.particles.update_mbes(rng[order].astype(np.float32), ang[order].astype(np.float32), self.mbes_std,
                                        self.mbes_range_max, self.mbes_sensor_offset)
+            self._accumulate_pending_detections(self._stamp_of(cloud))
             self.resample(self.particles)
 
     def mbes_cb(self, scan):
@@ -320,6 +404,7 @@ class auv_pf(object):
             angles = scan.angle_min + scan.angle_increment * np.arange(n)
             self.particles.update_mbes(np.asarray(scan.ranges, dtype=np.float32), angles.astype(np.float32),
                                        self.mbes_std, float(scan.range_max), self.mbes_sensor_offset)
+            self._accumulate_pending_detections(self._stamp_of(scan))
             self.resample(self.particles)
 
     # ---- publishing, auv_pf.py:218-285

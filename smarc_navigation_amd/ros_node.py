@@ -2,7 +2,9 @@
 """rospy wrapper: node `auv_pf`, same private parameters, topics, frames and message types as
 auv_particle_filter/scripts/auv_pf.py; the numerics run in libmcl_hip.so.  Beyond the reference:
 `~map_grid_file` / `~map_mesh_file` load the bathymetric map, `~mbes_topic` (sensor_msgs/LaserScan) and
-`~mbes_pointcloud_topic` (sensor_msgs/PointCloud2, the form mbes_mapper's receptor gives a ping) feed the MBES update.
+`~mbes_pointcloud_topic` (sensor_msgs/PointCloud2, the form mbes_mapper's receptor gives a ping) feed the MBES update;
+`~landmark_map_file` + `~lm_detect_topic` (geometry_msgs/PoseArray, toy_mbes_receptor.cpp:68-110) the landmark k-NN
+update of BASELINE config 5.
 
 ROS is not installed in the build container: the module imports whatever `rospy` / `tf` / `tf2_ros` / `*_msgs` are on
 the path -- a ROS 1 installation, or the stand-ins of tests/ros_stubs that tests/test_ros_node_stub.py drives main()
@@ -100,7 +102,7 @@ def main():
     transport = RosTransport(params, params['map_frame'], int(rospy.get_param('~max_published_poses', 5000)))
     try:
         pf = _node.auv_pf(params, m2o_mat=m2o, transport=transport)   # (loads ~map_grid_file / ~map_mesh_file)
-    except (IOError, OSError, ValueError, KeyError) as ex:
+    except (IOError, OSError, ValueError, KeyError, TypeError) as ex:
         rospy.logerr("PF: could not load the map: %s" % ex)
         return 1
     if not pf.has_map:
@@ -111,6 +113,8 @@ def main():
     rospy.Subscriber(params['mbes_topic'], LaserScan, pf.mbes_cb, queue_size=10)
     if params['mbes_pointcloud_topic']:
         rospy.Subscriber(params['mbes_pointcloud_topic'], PointCloud2, pf.mbes_pc_cb, queue_size=10)
+    if pf.has_landmarks:   # config 5: detections of the MBES receptors (toy_mbes_receptor.cpp:39 publishes them)
+        rospy.Subscriber(params['lm_detect_topic'], PoseArray, pf.lm_detect_cb, queue_size=10)
     rospy.Subscriber(params['odom_topic'], Odometry, pf.odom_callback, queue_size=100)
     rospy.Timer(rospy.Duration(0.1), pf.loc_loop)
     rospy.loginfo("Particle filter class successfully created")

@@ -18,6 +18,7 @@
 
 namespace {
 std::vector<float> g_ranges;
+bool g_landmarks = false;
 const double OFF[6] = {0.3, 0.0, -0.1, 0.0, 0.05, 0.0};
 }  // namespace
 
@@ -50,6 +51,12 @@ void init(int& argc, char** argv, const std::string& name) {
               {"odom_corrected_topic", "/sam/dr/odom_corrected"},
               {"particle_poses_topic", "/sam/dr/particle_poses"}};
   if (argc > 3 && std::strcmp(argv[3], "no-tf") == 0) return;   // (the start-up failure path, auv_pf.py:84-87)
+  if (argc > 3) {   // BASELINE config 5: a landmark map, detections on the receptors' topic
+    m.params["landmark_map_file"] = argv[3];
+    m.params["lm_detect_topic"] = "/sam/mbes_detections";
+    m.params["landmark_k"] = "2";
+    g_landmarks = true;
+  }
   geometry_msgs::Transform t;
   t.translation.x = 0.5;
   t.translation.y = -0.5;
@@ -103,6 +110,23 @@ void waitForShutdown() {
     od.pose.pose.orientation.w = 1.0;
     od.pose.pose.position.z = -2.0;
     stub::deliver("/sam/dr/odom", od);
+    if (k == 1 && g_landmarks) {
+      // the receptor's detections of this ping: PoseArray in base_frame, stamped like the ping
+      // (toy_mbes_receptor.cpp:75-105); delivered BEFORE the ping, held by the node until it arrives
+      geometry_msgs::PoseArray det;
+      det.header.frame_id = "sam/base_link";
+      det.header.stamp = Time(m.now);
+      const double d[2][3] = {{3.0, 4.0, -18.0}, {-2.0, -6.0, -17.5}};
+      for (const auto& row : d) {
+        geometry_msgs::Pose ps;
+        ps.position.x = row[0];
+        ps.position.y = row[1];
+        ps.position.z = row[2];
+        det.poses.push_back(ps);
+      }
+      stub::deliver("/sam/mbes_detections", det);
+      scan.header.stamp = Time(m.now);
+    }
     if (k == 1) stub::deliver("/sam/mbes_scan", scan);
     if (k == 2) stub::deliver("/sam/mbes_cloud", pc);
   }

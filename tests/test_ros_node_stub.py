@@ -313,3 +313,153 @@ def test_pointcloud2_parser_reads_the_declared_byte_layout():
     m.fields = [msgs.PointField('x', 0, 8), msgs.PointField('y', 8, 8)]
     with pytest.raises(ValueError):
         msgs.pointcloud2_xyz(m)
+
+
+# ------------------------------------------------------------------ BASELINE config 5 through the node
+def _landmark_yaml(path, rows):
+    """The Gazebo model list the reference's map provider parses (map_provider_node.py:43-52)."""
+    with open(path, 'w') as f:
+        f.write('models:\n')
+        for k, (x, y, z) in enumerate(rows):
+            f.write('- name: rock_%d\n  position:\n    x: %r\n    y: %r\n    z: %r\n' % (k, x, y, z))
+
+
+def _detections(rows, stamp):
+    import rospy
+    from geometry_msgs.msg import Pose, PoseArray
+    m = PoseArray()
+    m.header.frame_id = 'sam/base_link'   # toy_mbes_receptor.cpp:77
+    m.header.stamp = rospy.Time(stamp)
+    for x, y, z in rows:
+        p = Pose()
+        p.position.x, p.position.y, p.position.z = x, y, z
+        m.poses.append(p)
+    return m
+
+
+def test_ros_node_landmark_plumbing_with_a_recording_engine(ros, tmp_path, monkeypatch):
+    """~landmark_map_file + ~lm_detect_topic: the map goes to set_landmarks (the provider's rocks_depth filter applied);
+    a detection message is held for its ping and becomes update_landmarks(accumulate=True) between that ping's
+    update_mbes and its resample; detections of another ping are dropped; without a bathymetric map a detection
+    message is an update of its own (accumulate=False) followed by the resampling."""
+    node, rospy, tf, tf2_ros = ros
+    from smarc_navigation_amd import engine as eng
+    import rospy as rp
+    z, origin, path = _scene(tmp_path)
+    lpath = str(tmp_path / 'rocks.yaml')
+    rocks = [(3.0, 4.0, -95.0), (-2.0, -6.0, -97.5), (20.0, 20.0, -19.0)]
+    _landmark_yaml(lpath, rocks)
+    monkeypatch.setattr(eng, 'Engine', FakeEngine)
+    tf2_ros.transforms[('map', 'sam/odom')] = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0))
+    p = _params(path, 32)
+    p.update({'landmark_map_file': lpath, 'rocks_depth': -90.0, 'lm_detect_topic': '/sam/mbes_detections', 'landmark_k': 4,
+              'landmark_std': 0.5})
+    FakeEngine.calls = []
+    rospy.reset(p)
+    rospy.Time._now = 100.0
+    assert node.main() == 0
+    (name, a, k), = [c for c in FakeEngine.calls if c[0] == 'set_landmarks']
+    np.testing.assert_array_equal(a[0], np.array(rocks[:2]))            # z < rocks_depth only (map_provider_node.py:47)
+    from geometry_msgs.msg import PoseArray
+    assert rospy.subscribers['/sam/mbes_detections'].typ is PoseArray
+    rospy.subscribers['/sam/dr/odom'].cb(_odom(100.02, 1.0, 0.0, -2.0))
+    B = 32
+    angles = np.linspace(-1.0, 1.0, B)
+    scan, _ = _ping_msgs(20.0 / np.cos(angles), angles, [0.0] * 6)
+    det = [(1.0, 2.0, -15.0), (0.5, -3.0, -14.0)]
+    # ---- detections, then their ping: MBES update, the detections on top of it, ONE resampling
+    FakeEngine.calls = []
+    rospy.subscribers['/sam/mbes_detections'].cb(_detections(det, 100.02))
+    assert not FakeEngine.calls                                          # held for the ping
+    scan.header.stamp = rp.Time(100.02)
+    rospy.subscribers['/sam/mbes_scan'].cb(scan)
+    names = [c[0] for c in FakeEngine.calls]
+    assert names == ['update_mbes', 'update_landmarks', 'resample'], names
+    (d, sigma), kw = FakeEngine.calls[1][1], FakeEngine.calls[1][2]
+    np.testing.assert_array_equal(d, np.array(det))
+    assert sigma == 0.5 and kw == {'k': 4, 'gate': 11.345, 'accumulate': True}
+    # ---- a ping without detections: nothing extra
+    FakeEngine.calls = []
+    rospy.subscribers['/sam/mbes_scan'].cb(scan)
+    assert [c[0] for c in FakeEngine.calls] == ['update_mbes', 'resample']
+    # ---- stale detections (another ping's) are dropped, never applied to the wrong ping
+    FakeEngine.calls = []
+    rospy.subscribers['/sam/mbes_detections'].cb(_detections(det, 90.0))
+    rospy.subscribers['/sam/mbes_scan'].cb(scan)
+    assert [c[0] for c in FakeEngine.calls] == ['update_mbes', 'resample']
+    # ---- no bathymetric map: the detection message is a measurement update of its own
+    p['map_grid_file'] = ''
+    FakeEngine.calls = []
+    rospy.reset(p)
+    rospy.Time._now = 100.0
+    assert node.main() == 0
+    rospy.subscribers['/sam/dr/odom'].cb(_odom(100.02, 1.0, 0.0, -2.0))
+    FakeEngine.calls = []
+    rospy.subscribers['/sam/mbes_detections'].cb(_detections(det, 100.02))
+    assert [c[0] for c in FakeEngine.calls] == ['update_landmarks', 'resample']
+    assert FakeEngine.calls[0][2]['accumulate'] is False
+    # ---- an empty landmark map is an error at start-up, not a silent no-op
+    p['rocks_depth'] = -1000.0
+    rospy.reset(p)
+    assert node.main() == 1 and any(l[0] == 'err' for l in rospy.log)
+
+
+@pytest.mark.gpu
+def test_ros_node_with_landmarks_publishes_the_engines_pose(ros, tmp_path):
+    """Config 5 end to end through ros_node.main() on the GPU: the published pose equals that of an engine driven
+    directly with the same calls (predict, update_mbes, update_landmarks(accumulate), resample, mean)."""
+    node, rospy, tf, tf2_ros = ros
+    import rospy as rp
+    from smarc_navigation_amd import engine as eng, synth
+    z, origin, path = _scene(tmp_path)
+    lm = synth.landmark_map(64, (-60.0, -60.0, 60.0, 60.0), seed=6)
+    lpath = str(tmp_path / 'landmarks.npz')
+    np.savez(lpath, landmarks=lm)
+    tf2_ros.transforms[('map', 'sam/odom')] = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0))
+    n = 8192
+    p = _params(path, n)
+    p.update({'landmark_map_file': lpath, 'lm_detect_topic': '/sam/mbes_detections', 'landmark_k': 2, 'mbes_pointcloud_topic': '',
+              'mbes_sensor_offset': '[0.0, 0.0, 0.0, 0.0, 0.0, 0.0]'})
+    rospy.reset(p)
+    rospy.Time._now = 100.0
+    assert node.main() == 0
+    B = 64
+    angles = np.linspace(-1.0, 1.0, B).astype(np.float32)
+    one = eng.Engine(1, rng_mode=eng.RNG_REPLAY)
+    one.set_map_grid(z, origin, 1.0)
+    one.set_particles(np.array([[0.02], [0.0], [-2.0], [0.0], [0.0], [0.0]]))
+    ranges = one.mbes_expected(0, 1, angles, 80.0)[0]
+    one.close()
+    # the three landmarks nearest to the vehicle, seen from it (base_frame = map frame here: identity pose but z)
+    d2 = np.sum((lm[:, :2]) ** 2, axis=1)
+    det = lm[np.argsort(d2)[:3]] - np.array([0.02, 0.0, -2.0])
+    scan, _ = _ping_msgs(ranges.astype(np.float64), angles.astype(np.float64), [0.0] * 6)
+    scan.header.stamp = rp.Time(100.02)
+    rospy.subscribers['/sam/dr/odom'].cb(_odom(100.02, 1.0, 0.0, -2.0))
+    rospy.subscribers['/sam/mbes_detections'].cb(_detections([tuple(r) for r in det], 100.02))
+    rospy.subscribers['/sam/mbes_scan'].cb(scan)
+    rospy.timers[0].cb(None)
+    od = rospy.publishers['/sam/dr/odom_corrected'].sent[-1]
+    # the same calls on an engine of our own
+    e = eng.Engine(n, init_cov=[0.5, 0.5, 0.0, 0.0, 0.0, 0.01], process_cov=[0.001, 0.001, 0.0, 0.0, 0.0, 0.00001],
+                   resample_cov=[0.01, 0.01, 0.0, 0.0, 0.0, 0.0001], meas_std=1.0, seed=11)
+    e.set_map_grid(z, origin, 1.0)
+    e.set_landmarks(lm)
+    e.init_particles()
+    e.predict([1.0, 0.0, 0.0], 0.0, [0.0, 0.0, 0.0, 1.0], -2.0, 100.02 - 100.0)
+    a64 = scan.angle_min + scan.angle_increment * np.arange(B)
+    e.update_mbes(np.asarray(scan.ranges, np.float32), a64.astype(np.float32), 0.2, 80.0, [0.0] * 6)
+    e.update_landmarks(det, 0.3, k=2, gate=11.345, accumulate=True)
+    e.resample()
+    mean, yaw, cov = e.mean_cov()
+    assert (od.pose.pose.position.x, od.pose.pose.position.y) == (mean[0], mean[1])
+    assert od.pose.covariance[:9] == [float(v) for v in cov]
+    # ... and the detections mattered: without them the estimate is another
+    e2 = eng.Engine(n, init_cov=[0.5, 0.5, 0.0, 0.0, 0.0, 0.01], process_cov=[0.001, 0.001, 0.0, 0.0, 0.0, 0.00001],
+                    resample_cov=[0.01, 0.01, 0.0, 0.0, 0.0, 0.0001], meas_std=1.0, seed=11)
+    e2.set_map_grid(z, origin, 1.0)
+    e2.init_particles()
+    e2.predict([1.0, 0.0, 0.0], 0.0, [0.0, 0.0, 0.0, 1.0], -2.0, 100.02 - 100.0)
+    e2.update_mbes(np.asarray(scan.ranges, np.float32), a64.astype(np.float32), 0.2, 80.0, [0.0] * 6)
+    e2.resample()
+    assert tuple(e2.mean_cov()[0][:2]) != (mean[0], mean[1])
