@@ -15,6 +15,14 @@ A raw-sensor file (ev_t, ev_kind, ev_data as synth.raw_sensor_events makes them;
 pressure_tf) is first run through the dead-reckoning integrator (--raw).
 
     python -m smarc_navigation_amd.replay stream.npz --particles 65536 [--map-grid map.npz] [--out traj.csv]
+
+rosbag input (BASELINE config 1 is "rosbag replay"): `--bag` reads a ROS 1 bag (format 2.0, rosbag_io.py: no ROS
+installation needed) and runs its messages IN RECORDED ORDER through the node's callbacks -- what `rosbag play` into
+the live node does (the reference reads its bags with rosbag.Bag(...).read_messages(),
+auv_ekf_localization/rosbags/rosbag_handler.py:8-19):
+
+    python -m smarc_navigation_amd.replay run.bag --bag --odom-topic /sam/dr/odom --gps-topic /sam/dr/gps \
+        --mbes-topic /sam/mbes_scan --particles 128
 """
 import argparse
 import json
@@ -199,6 +207,90 @@ def replay(stream, params=None, m2o=None, utm2map=None, grid=None, mesh=None, pu
     return out
 
 
+def stream_to_bag(path, stream, odom_topic='/sam/dr/odom', gps_topic='/sam/dr/gps', mbes_topic='/sam/mbes_scan',
+                  dive_topic='/dive', compression='none'):
+    """A stream file's content as a rosbag 2.0 file (rosbag_io.write_bag): one nav_msgs/Odometry per sample, the GPS
+    fixes (nav_msgs/Odometry in utm, preceded once by std_msgs/Bool false on the dive topic -- the node ignores fixes
+    while `diving`, auv_pf.py:103,126) and the pings (sensor_msgs/LaserScan) right after the sample they belong to."""
+    from . import msgs, rosbag_io
+    out = []
+    n = len(stream['stamp'])
+    gps_at = {int(k): j for j, k in enumerate(stream['gps_idx'])} if 'gps_idx' in stream else {}
+    mbes_at = {int(k): j for j, k in enumerate(stream['mbes_idx'])} if 'mbes_idx' in stream else {}
+    surfaced = False
+    for k in range(n):
+        t = float(stream['stamp'][k])
+        od = msgs.odometry_from_stream(stream, k)
+        od.header.frame_id, od.child_frame_id = 'sam/odom', 'sam/base_link'
+        out.append((odom_topic, 'nav_msgs/Odometry', od, t))
+        if k in gps_at:
+            if not surfaced:
+                out.append((dive_topic, 'std_msgs/Bool', msgs.Bool(False), t))
+                surfaced = True
+            g = msgs.Odometry()
+            g.header.stamp, g.header.frame_id = msgs.Time(t), 'utm'
+            g.pose.pose.position.x = float(stream['gps_xy_utm'][gps_at[k]][0])
+            g.pose.pose.position.y = float(stream['gps_xy_utm'][gps_at[k]][1])
+            out.append((gps_topic, 'nav_msgs/Odometry', g, t))
+        if k in mbes_at:
+            ang = np.asarray(stream['mbes_angles'], dtype=np.float64)
+            scan = msgs.LaserScan(np.asarray(stream['mbes_ranges'][mbes_at[k]], np.float32), float(ang[0]),
+                                  float(ang[1] - ang[0]) if ang.size > 1 else 0.0,
+                                  float(stream['mbes_range_max']) if 'mbes_range_max' in stream else 100.0)
+            scan.header.stamp, scan.header.frame_id = msgs.Time(t), 'sam/mbes_link'
+            out.append((mbes_topic, 'sensor_msgs/LaserScan', scan, t))
+    rosbag_io.write_bag(path, out, compression=compression)
+    return len(out)
+
+
+def replay_bag(path, params=None, m2o=None, utm2map=None, grid=None, mesh=None, odom_topic='/sam/dr/odom',
+               gps_topic='/sam/dr/gps', mbes_topic='/sam/mbes_scan', mbes_cloud_topic=None, dive_topic='/dive',
+               lm_detect_topic=None, publish_period=0.1, t0=None):
+    """BASELINE config 1, literally: a recorded ROS 1 bag's messages in recorded order through the node's callbacks
+    (odom_callback, gps_odom_cb, dive_cb, mbes_cb, mbes_pc_cb, lm_detect_cb), loc_loop every `publish_period` seconds
+    of bag time (auv_pf.py:114: a 10 Hz timer).  Returns dict(pf_xyz[k,3], pf_stamp[k], counts{topic: messages},
+    summary); no ROS installation is needed (rosbag_io.Bag)."""
+    from . import auv_pf as node
+    from . import rosbag_io
+    tr = node.RecordingTransport(utm2map)
+    pf = node.auv_pf(params or {}, m2o_mat=m2o, transport=tr)
+    if grid is not None:
+        pf.set_map_grid(grid['z'], grid['origin'], float(grid['res']))
+    if mesh is not None:
+        pf.set_map_mesh(mesh['verts'], mesh['tris'])
+    route = {odom_topic: pf.odom_callback, gps_topic: pf.gps_odom_cb, dive_topic: pf.dive_cb, mbes_topic: pf.mbes_cb}
+    if mbes_cloud_topic:
+        route[mbes_cloud_topic] = pf.mbes_pc_cb
+    if lm_detect_topic:
+        route[lm_detect_topic] = pf.lm_detect_cb
+    counts, pf_xyz, pf_stamp = {}, [], []
+    started, next_pub, last_t = False, None, None
+    for topic, msg, t in rosbag_io.Bag(path).read_messages(topics=list(route)):
+        if not started:
+            # "Start timing now" (auv_pf.py:96-98): the node is up before the first message
+            pf.start_timing(float(t0) if t0 is not None else t - 0.02)
+            next_pub, started = t + publish_period, True
+        while t >= next_pub:   # the 10 Hz timer, in bag time
+            pf.loc_loop(None)
+            p = tr.odom_corrected[-1].pose.pose.position
+            pf_xyz.append([p.x, p.y, p.z])
+            pf_stamp.append(next_pub)
+            next_pub += publish_period
+        route[topic](msg)
+        counts[topic] = counts.get(topic, 0) + 1
+        last_t = t
+    if started:
+        pf.loc_loop(None)
+        p = tr.odom_corrected[-1].pose.pose.position
+        pf_xyz.append([p.x, p.y, p.z])
+        pf_stamp.append(last_t)
+    pf_xyz = np.array(pf_xyz).reshape(-1, 3)
+    summary = {'messages': counts}
+    if len(pf_xyz):
+        summary['pf_distance'], summary['pf_final'] = track_metrics(pf_xyz.T)
+    return dict(pf_xyz=pf_xyz, pf_stamp=np.array(pf_stamp), counts=counts, summary=summary, node=pf)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
     ap.add_argument('stream')
@@ -207,7 +299,20 @@ def main(argv=None):
     ap.add_argument('--out', help='CSV of the published mean pose')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--raw', action='store_true', help='the file holds raw sensor events: integrate them first')
+    ap.add_argument('--bag', action='store_true', help='the file is a ROS 1 bag (format 2.0): replay its messages in recorded order')
+    ap.add_argument('--odom-topic', default='/sam/dr/odom')
+    ap.add_argument('--gps-topic', default='/sam/dr/gps')
+    ap.add_argument('--mbes-topic', default='/sam/mbes_scan')
+    ap.add_argument('--dive-topic', default='/dive')
     a = ap.parse_args(argv)
+    if a.bag:
+        grid = dict(np.load(a.map_grid)) if a.map_grid else None
+        res = replay_bag(a.stream, dict(particle_count=a.particles, seed=a.seed), grid=grid, odom_topic=a.odom_topic,
+                         gps_topic=a.gps_topic, mbes_topic=a.mbes_topic, dive_topic=a.dive_topic)
+        if a.out:
+            np.savetxt(a.out, np.column_stack([res['pf_stamp'], res['pf_xyz']]), delimiter=',', header='stamp,x,y,z')
+        print(json.dumps(res['summary']))
+        return
     stream = dict(np.load(a.stream, allow_pickle=False))
     m2o = None
     if a.raw:
