@@ -558,6 +558,14 @@ def worker(a, rank, world, local_rank):
     run(k0, k0 + a.steps)
     barrier()
     tim = e.timing_get()
+    # every rank's share of the resample exchange (states sent to peers, lost slots), so that the first multi-GPU run
+    # explains itself: which rank fed which, and how far the traffic is from the (world - 1) / world worst case
+    ex_all = None
+    if world > 1 and dist is not None:
+        s_, l_ = e.exchange_stats()
+        tl = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([float(s_), float(l_)], dtype=torch.float64))
+        ex_all = [(float(x[0]), float(x[1])) for x in tl]
     e.timing_enable(False)
     # pose RMSE of the filter's mean (x, y) against the synthetic ground truth over every timed step
     n_timed = a.steps * (nblocks + 1)
@@ -667,6 +675,10 @@ def worker(a, rank, world, local_rank):
             out['exchange'] = {'mode': os.environ.get('MCL_EXCHANGE', 'p2p (O(n) per rank: hand-over records + point-to-point surplus copies)'),
                                'rank0_states_sent_per_step': round(sent / nst, 1), 'rank0_lost_slots_per_step': round(lost / nst, 1),
                                'rank0_bytes_sent_per_step': round(24.0 * sent / nst, 1),
+                               'bytes_sent_per_step_by_rank': [round(24.0 * x[0] / nst, 1) for x in ex_all] if ex_all else None,
+                               'lost_slots_per_step_by_rank': [round(x[1] / nst, 1) for x in ex_all] if ex_all else None,
+                               'fraction_of_cloud_moved_per_step': round(sum(x[0] for x in ex_all) / nst / (P * world), 6) if ex_all else None,
+                               'worst_case_fraction': round((world - 1.0) / world, 4),
                                'note': 'x, y, yaw of every surplus copy that fills a lost slot of ANOTHER rank (z, roll, pitch are '
                                        'the odometry\'s on every particle after predict); the all-gather exchange of rounds 1-2 '
                                        'moved 28 B x N_global per rank per step'}

@@ -174,3 +174,29 @@ def test_sharded_resample_world2_gloo(n):
         ret = mgr.dict()
         mp.spawn(_worker, args=(world, port, n, 17, ret), nprocs=world, join=True)
         assert dict(ret) == {0: True, 1: True}
+
+
+def test_sharded_resample_world8_all_weight_in_one_shard_gloo():
+    """world 8, the weight in ONE shard.  Every other shard loses (nearly) all its slots and is
+    refilled from shard 0: the exchanged state is bounded by the lost slots -- here (world - 1) / world of the cloud,
+    the bound DESIGN.md 6 states for the exchange (a rank receives at most its own n / world particles, a rank sends at
+    most the surplus copies it holds) -- and the result is still the unsharded filter's, bit for bit."""
+    import torch.multiprocessing as mp
+    world, n = 8, 8 * 1500
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_p2p, args=(world, port, n, 31, 1e3, ret), nprocs=world, join=True)
+        out = dict(ret)
+    assert all(out[r][0] for r in range(world)), out
+    nl = n // world
+    sent = [out[r][1] for r in range(world)]
+    lost = [out[r][2] for r in range(world)]
+    # one ancestor carries (nearly) all the weight: every shard -- its own included -- loses almost all its slots ...
+    assert all(l > 0.95 * nl for l in lost), lost
+    # ... and is refilled from that ancestor's shard, the only sender worth the name
+    heavy = int(np.argmax(sent))
+    assert sent[heavy] > 0.9 * (world - 1) * nl and sum(sent) - sent[heavy] < 0.05 * n, sent
+    # what crosses the wire is bounded by the lost slots of the OTHER shards: at most (world - 1) / world of the cloud
+    # (DESIGN.md 6: a rank receives at most its own n / world particles) -- and this case comes close to it
+    assert sum(sent) <= sum(lost) - (lost[heavy] - 0) + lost[heavy] and sum(sent) <= (world - 1) * nl
