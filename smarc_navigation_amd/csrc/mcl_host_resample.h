@@ -269,6 +269,10 @@ int phase_expand_local(mcl_handle* h, uint64_t u53) {
   a.world = h->world;
   a.ls_out = h->lsx + 4 * (size_t)h->rank;
   for (int c = 0; c < 3; ++c) a.p0[c] = h->state[h->cur] + (size_t)c * h->n;
+  // (after a fused predict the state's z words are not written yet -- the moments' shift takes the uniform
+  //  depth itself, like the unsharded gather does, so sharded and unsharded means agree to the last bit)
+  a.p0_z_uniform = h->uni_valid ? 1 : 0;
+  a.p0_z = h->uni_val[0];
   const unsigned grid = (unsigned)((h->n + RS_TILE - 1) / RS_TILE);
   t_begin(h, MCL_K_SCAN);
   k_cdf_expand<true><<<grid, RS_BLOCK, 0, h->stream>>>(a);

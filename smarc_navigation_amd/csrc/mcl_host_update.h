@@ -455,6 +455,16 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       (void)hipMemcpyAsync(&cnt, a.defer_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
       (void)hipStreamSynchronize(h->stream);
       fprintf(stderr, "[mbes] sweep handed over %d of %lld particles\n", cnt, (long long)h->n);
+#ifdef SWEEP_REASONS
+      // why (mcl_sweep.h: SWEEP_FAIL / SWEEP_NOTE codes, per particle SIDE): -DSWEEP_REASONS builds only
+      unsigned why[16];
+      (void)hipMemcpy(why, h->reasons_dev, sizeof why, hipMemcpyDeviceToHost);
+      (void)hipMemset(h->reasons_dev, 0, sizeof why);
+      fprintf(stderr, "[mbes] declined sides by reason:");
+      for (int k = 0; k < 16; ++k)
+        if (why[k]) fprintf(stderr, " %d:%u", k, why[k]);
+      fprintf(stderr, "\n");
+#endif
     }
     t_end(h);
     HIPCHK(h, hipGetLastError());

@@ -150,6 +150,8 @@ struct ExpandArgs {
   int rank, world;
   u64* ls_out;           // 4 words: L | S << 32, then x, y, z of local particle 0 as doubles
   const double* p0[3];
+  int p0_z_uniform;      // the fused step has not stored z yet (k_predict_pose, skip_uniform): it is the odometry's ...
+  double p0_z;           // ... depth on every particle -- the shift's z component is this value, not a stale state word
 };
 template <bool FROM_Q>
 __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
@@ -268,7 +270,8 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
     const u32 S = (snc[(a.n - 1) - tile * RS_TILE] - nc_start) - (u32)a.n + L;
     a.ls_out[0] = (u64)L | ((u64)S << 32);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) a.ls_out[1 + c] = (u64)__double_as_longlong(a.p0[c][0]);
+    for (int c = 0; c < 3; ++c)
+      a.ls_out[1 + c] = (u64)__double_as_longlong((c == 2 && a.p0_z_uniform) ? a.p0_z : a.p0[c][0]);
   }
   // ---- ranks of the lost slots; dupes entries of the ancestors with surplus copies
   {

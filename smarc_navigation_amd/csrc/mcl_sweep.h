@@ -84,15 +84,21 @@ __device__ __forceinline__ float hw_max(float x, float y) {
 //   dd = max(z w - tau (w / cos a), (z - r_max) w);  acc += dd^2;  next record;  e_cur = sc - T' tc
 // A lane leaves the loop (its exec bit is cleared) when its pending beam passes beyond the vertex (e_cur < 0 or NaN:
 // the sentinel records end every table); lanes that leave after an odd number of beams swap t0 / t1 at the end.  On
-// exit no fetch is in flight, `rec` holds the pending beam's record and bp its LDS byte address.  The record is pinned
-// to v[60:63] for the duration of the statement (a physical-register constraint): one ds_read_b128 fills it, and its
+// exit no fetch is in flight and bp is the pending beam's LDS byte address.  The record lives in v[60:63] for the
+// duration of the statement: one ds_read_b128 fills it, and its
 // fields are named v60 .. v63 in the text -- inline assembly has no way to name the parts of a register tuple operand,
 // and four ds_read_b32 into free-standing registers cost an 8-way bank conflict each as soon as the lanes of a wave
 // stand at different beams (a cloud that is not collapsed: + 20 % on the sigma = 50 m cloud).
 // (hazards: the v_rcp result is first read three instructions later; SALU reads of VCC after v_cmp and VALU after a
 //  write of EXEC are interlocked.)
 typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {tan of the beam 2 ahead, w / cos a, z w, (z - r_max) w}
-__device__ __forceinline__ void sweep_merge_asm(float& t0, float& t1, float& acc, unsigned& bp, float e_cur, sweep_rec& rec,
+// (round 4: the pending beam's record is no longer carried in registers from one segment to the next -- as an in / out
+//  operand pinned to v[60:63] it cost two 64-bit moves into the tuple before and two out of it after EVERY statement,
+//  four VALU instructions per walk step, because the register allocator would not leave a value in a physical register
+//  between two asm statements.  The statement now fetches the record itself, right after the test that at least one lane
+//  has a beam on this segment: one more ds_read_b128 per walk step, whose latency the first four instructions of the
+//  loop cover, and four VGPRs fewer live across the walk.  v[60:63] are plain clobbers.)
+__device__ __forceinline__ void sweep_merge_asm(float& t0, float& t1, float& acc, unsigned& bp, float e_cur,
                                                 float sp, float tp, float sc, float tc, float dts, int pstep16) {
   float ep, d;
   unsigned long long sav, odd, tmp;
@@ -101,7 +107,8 @@ __device__ __forceinline__ void sweep_merge_asm(float& t0, float& t1, float& acc
       "s_mov_b64 %[odd], 0\n\t"
       "v_cmp_le_f32 vcc, 0, %[ec]\n\t"
       "s_and_b64 exec, exec, vcc\n\t"
-      "s_cbranch_execz 9f\n"
+      "s_cbranch_execz 9f\n\t"
+      "ds_read_b128 v[60:63], %[bp]\n"
       "1:\n\t"
       "v_fma_f32 %[ep], -%[t0], %[tp], %[sp]\n\t"
       "v_sub_f32 %[d], %[ep], %[ec]\n\t"
@@ -144,10 +151,10 @@ __device__ __forceinline__ void sweep_merge_asm(float& t0, float& t1, float& acc
       "v_mov_b32 %[t1], %[ep]\n\t"
       "s_mov_b64 exec, %[sav]\n\t"
       "s_waitcnt lgkmcnt(0)"
-      : [t0] "+v"(t0), [t1] "+v"(t1), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur), "+{v[60:63]}"(rec),
+      : [t0] "+v"(t0), [t1] "+v"(t1), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur),
         [ep] "=&v"(ep), [d] "=&v"(d), [sav] "=&s"(sav), [odd] "=&s"(odd), [tmp] "=&s"(tmp)
       : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts), [ps] "s"(pstep16)
-      : "vcc");
+      : "vcc", "v60", "v61", "v62", "v63");
 }
 
 // a * b clamped to [0, 1] by the multiplier's output modifier (NaN -> 0): the same instruction in the C++ merge loops and
@@ -383,7 +390,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
       //  loop is rotated: e_cur of the NEXT beam is formed at the end of the body, one compare decides)
       float e_cur = fmaf(-tcur, tc, sc);
       if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-        sweep_merge_asm(tcur, tnext, acc, bp, e_cur, bm, sp, tp, sc, tc, dts, pstep16);
+        sweep_merge_asm(tcur, tnext, acc, bp, e_cur, sp, tp, sc, tc, dts, pstep16);
       } else {
         // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes
         // sign: <= 0 at prev, >= 0 at cur); then on to the next beam of the table
@@ -993,7 +1000,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const float dts = t_cur - t_prev;
     float e_cur = fmaf(-tcur, t_cur, s_cur);
     if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-      sweep_merge_asm(tcur, tnext, acc, bp, e_cur, bm, s_prev, t_prev, s_cur, t_cur, dts, pstep16);
+      sweep_merge_asm(tcur, tnext, acc, bp, e_cur, s_prev, t_prev, s_cur, t_cur, dts, pstep16);
     } else {
       while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
         const float e_prev = fmaf(-tcur, t_prev, s_prev);
