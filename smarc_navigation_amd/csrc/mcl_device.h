@@ -172,8 +172,10 @@ struct u32x4 {
 __device__ __forceinline__ u32x4 philox4x32(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    u32 hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    u32 hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // (one 32 x 32 -> 64 multiply per product: v_mad_u64_u32 instead of a v_mul_hi_u32 / v_mul_lo_u32 pair -- both
+    //  quarter rate, so half the multiplier time of the ten rounds)
+    const u64 p0 = (u64)0xD2511F53u * (u64)c0, p1 = (u64)0xCD9E8D57u * (u64)c2;
+    const u32 hi0 = (u32)(p0 >> 32), lo0 = (u32)p0, hi1 = (u32)(p1 >> 32), lo1 = (u32)p1;
     u32 n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
     c0 = n0;
     c1 = n1;

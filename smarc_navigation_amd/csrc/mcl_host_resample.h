@@ -522,8 +522,13 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   // one particle per thread up to 256 blocks (= 256 tickets), grid-stride beyond
   long long gg = (h->n + RS_BLOCK - 1) / RS_BLOCK;
   gg = gg < 1 ? 1 : (gg > GATHER_MAX_GRID ? GATHER_MAX_GRID : gg);
-  if (with_moments)
+  const bool uni = a.uni_mask == 0x1cu;   // z, roll, pitch substituted: the lean kernel
+  if (with_moments && uni)
+    k_resample_gather<true, true><<<(unsigned)gg, RS_BLOCK, 0, h->stream>>>(a, rp);
+  else if (with_moments)
     k_resample_gather<true><<<(unsigned)gg, RS_BLOCK, 0, h->stream>>>(a, rp);
+  else if (uni)
+    k_resample_gather<false, true><<<(unsigned)gg, RS_BLOCK, 0, h->stream>>>(a, rp);
   else
     k_resample_gather<false><<<(unsigned)gg, RS_BLOCK, 0, h->stream>>>(a, rp);
   t_end(h);

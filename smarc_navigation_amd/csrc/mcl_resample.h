@@ -394,7 +394,10 @@ struct GatherArgs {
   StatePtrs recv;
   const double* shift_dev;
 };
-template <bool MOMENTS>
+// UNI: z, roll, pitch are the odometry's on every particle (a.uni_mask == 0x1c: the resample right after a predict --
+// every fused step): three state components are kernel arguments, not loads, and the three that are left fit the
+// register budget while in flight across the arithmetic (the generic kernel, with six, loads them after it)
+template <bool MOMENTS, bool UNI = false>
 __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, const double* __restrict__ replay) {
   __shared__ double red[MOM_COUNT][RS_BLOCK / 64];
   __shared__ u32 last_sh;
@@ -407,13 +410,34 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
     for (int c = 0; c < 3; ++c)  // a member of the cloud, the same on every shard
       shift[c] = a.recv_mode ? a.shift_dev[c] : (((a.uni_mask >> c) & 1u) ? a.uni[c] : a.src.c[c][0]);
   }
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < a.n;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long g = a.goff + i;
-    const u32 r = a.zr[i];
+  // The gather of a resampled cloud is a chain of three dependent, scattered loads per particle (zr -> dupes -> state)
+  // in front of ~500 instructions of Philox / Box-Muller arithmetic that need none of them, and with four waves per
+  // SIMD (123 VGPRs) nothing else hides the chain (round 3: 70 % of the wave cycles waiting, rocprofv3 SQ_WAIT_ANY).
+  // The loop is therefore software-pipelined by hand: the state loads of THIS particle and the index load of the NEXT
+  // one are issued before the arithmetic, the next particle's ancestor index after it.  (A batch of two particles per
+  // iteration spilled 68 B per lane: 13 fp64 accumulators leave no room for a second state.)
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  u32 r = i < a.n ? a.zr[i] : ZR_SURVIVOR;
+  long long src = 0;
+  bool from_recv = false;
+  if (i < a.n) {
     const bool surv = r == ZR_SURVIVOR;
-    const long long src = a.recv_mode ? (surv ? i : (long long)r) : (surv ? g : (long long)a.dupes[r]);
-    const bool from_recv = a.recv_mode && !surv;
+    src = a.recv_mode ? (surv ? i : (long long)r) : (surv ? a.goff + i : (long long)a.dupes[r]);
+    from_recv = a.recv_mode && !surv;
+  }
+  for (; i < a.n; i += stride) {
+    const long long g = a.goff + i;
+    double v[6];
+    if (UNI) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {   // this particle's state: in flight during the arithmetic below
+        const double* from = from_recv ? a.recv.c[c] : a.src.c[c];
+        v[c] = (c >= 2 && c <= 4) ? a.uni[c] : from[src];
+      }
+    }
+    const long long in = i + stride;
+    const u32 rn = in < a.n ? a.zr[in] : ZR_SURVIVOR;   // the next particle's slot record: likewise
     double z[6] = {0, 0, 0, 0, 0, 0};
     if (a.add_noise) {
       if (replay) {
@@ -423,11 +447,19 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
         native_normals6(g, a.nz, z);
       }
     }
-    double v[6];
+    // ... and its ancestor (rn has arrived by now): in flight during the stores and the moments
+    const bool survn = rn == ZR_SURVIVOR;
+    const long long srcn = a.recv_mode ? (survn ? in : (long long)rn) : (survn ? a.goff + in : (long long)a.dupes[rn]);
+    if (!UNI) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double* from = from_recv ? a.recv.c[c] : a.src.c[c];
+        v[c] = ((a.uni_mask >> c) & 1u) ? a.uni[c] : from[src];
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      const double* from = from_recv ? a.recv.c[c] : a.src.c[c];
-      v[c] = (((a.uni_mask >> c) & 1u) ? a.uni[c] : from[src]) + a.nz.sq[c] * z[c];
+      v[c] = v[c] + a.nz.sq[c] * z[c];
       a.dst.c[c][i] = v[c];
     }
     if (MOMENTS) {
@@ -446,6 +478,8 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
       acc[11] += dx * dz;
       acc[12] += dy * dz;
     }
+    src = srcn;
+    from_recv = a.recv_mode && !survn;
   }
   if (!MOMENTS) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
