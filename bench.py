@@ -607,19 +607,19 @@ def worker(a, rank, world, local_rank):
                          'the warm-up -- extra.filter_tempered runs the same step on a filter that keeps a healthy spread (its dominant '
                          'launch takes ~20 %% longer: compare extra.filter_tempered.kernels.mbes_main with roofline.launch_us)' % SIGMA}
         # PMC-measured HBM traffic of the dominant kernel: collected offline (counters cannot be read inside
-        # this run) by tools/pmc_summarise.py into profiles/r02_traffic.json, attached ONLY when that file was
+        # this run) by tools/pmc_summarise.py into profiles/r04_traffic.json, attached ONLY when that file was
         # taken at the kernel sources this library was built from and at this workload
         traffic, traffic_source, pmc = None, None, {}
         src = source_hash()
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r03_traffic.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r04_traffic.json')) as f:
                 tj = json.load(f)
             if tj.get('source_hash') == src and P == 1048576 and B == 512 and world == 1:
                 pmc = tj.get(m['kind'], {})
                 traffic = pmc.get('traffic_bytes_per_launch')
-                traffic_source = 'offline: profiles/r03_traffic.json (rocprofv3 --pmc passes, kernel sources %s)' % src
+                traffic_source = 'offline: profiles/r04_traffic.json (rocprofv3 --pmc passes, kernel sources %s)' % src
             elif tj.get('source_hash') != src:
-                traffic_source = 'none: profiles/r03_traffic.json is for kernel sources %s, this library is %s' % (
+                traffic_source = 'none: profiles/r04_traffic.json is for kernel sources %s, this library is %s' % (
                     tj.get('source_hash'), src)
         except (IOError, ValueError):
             pass
@@ -628,6 +628,10 @@ def worker(a, rank, world, local_rank):
             'metric': METRIC,
             'value': round(value, 3), 'unit': 'steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(ms_per_step, 4), 'first_block_ms': round(first_block_ms, 4),
+            'value_definition': 'steps/s of the MEDIAN of the timed blocks (each exactly --steps steps between barrier + '
+                                'synchronize pairs, max over ranks; >= %d steps in all); first_block_value is the contract\'s '
+                                'single block right after the warm-up (rounds 1-2 reported that one)' % MIN_TIMED_STEPS,
+            'first_block_value': round(1e3 / first_block_ms * (total_particles / 1048576.0), 3),
             'higher_is_better': True, 'scaling': a.scaling,
             'vs_baseline': None, 'dtype': 'f64 state / f32 ray-cast', 'data': 'synthetic',
             'steps_per_s': round(1e3 / ms_per_step, 3), 'particles_total': total_particles, 'cloud': cloud,

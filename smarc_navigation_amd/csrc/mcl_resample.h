@@ -59,15 +59,23 @@ struct QuantArgs {
 };
 __global__ void __launch_bounds__(MCL_BLOCK) k_quantise_tiles(QuantArgs a) {
   __shared__ u64 sh[16];
-  const double m = a.slots ? max_from_slots(a.slots) : a.m_lw[0];
   const long long tile = blockIdx.x;  // the grid is exactly the number of tiles
   const long long base = tile * MCL_SCAN_TILE;
+  // (the log-weights first: their loads are in flight while the maximum is read from the 64 slots -- two memory
+  //  latencies in a 9 us kernel were one after the other)
+  double lwv[MCL_SCAN_ITEMS];
+#pragma unroll
+  for (int k = 0; k < MCL_SCAN_ITEMS; ++k) {
+    const long long i = base + (long long)k * MCL_BLOCK + threadIdx.x;
+    lwv[k] = i < a.n ? a.lw[i] : 0.0;
+  }
+  const double m = a.slots ? max_from_slots(a.slots) : a.m_lw[0];
   u64 acc = 0;
 #pragma unroll
   for (int k = 0; k < MCL_SCAN_ITEMS; ++k) {
     const long long i = base + (long long)k * MCL_BLOCK + threadIdx.x;
     if (i < a.n) {
-      const u64 qi = quantise_weight(a.lw[i], m, a.mode, a.scale);
+      const u64 qi = quantise_weight(lwv[k], m, a.mode, a.scale);
       a.q[i] = qi;
       acc += qi;
     }
@@ -176,6 +184,10 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
   u32 nc_start = 0u;   // ... and just before the scanned range (non-zero only for a later shard of a sharded cloud)
   if (FROM_Q) {
     const long long fine0 = tile * RS_FINE;
+    // (this tile's weights first: in flight while every block adds the tile sums up)
+    u64 v[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) v[k] = (base + k < a.n) ? a.q[base + k] : 0ull;
     u64 off = 0ull, T = 0ull;
     if (a.totals) {
       // one shard of several: the weight before the shard and the global total from the all-gathered shard totals
@@ -214,9 +226,6 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
       __syncthreads();  // sh64 is reused by the scan below
       if (blockIdx.x == 0 && tid == 0) a.total_out[0] = T;
     }
-    u64 v[RS_ITEMS];
-#pragma unroll
-    for (int k = 0; k < RS_ITEMS; ++k) v[k] = (base + k < a.n) ? a.q[base + k] : 0ull;
     tile_scan_blocked(v, sh64);
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; ++k) {

@@ -1,11 +1,12 @@
 #!/bin/bash
-# tools/collect_profiles.sh -- copy what tools/profile_gpu.sh left under gpurun_out/prof_r03/ into profiles/r03_*
+# tools/collect_profiles.sh -- copy what tools/profile_gpu.sh left under gpurun_out/prof_$ROUND/ into profiles/$ROUND_* (ROUND: r04)
 # (run in the build container after the gpurun call; profiles/ is what the judge reads, gpurun_out/ is scratch).
 # The raw counter rows are trimmed to the first 12 dispatches of the dominant kernel (the means over all ~200 are in
-# r03_traffic.json): once per round, a few dozen KB.
+# <round>_traffic.json): once per round, a few dozen KB.
 set -e
 cd "$(dirname "$0")/.."
-S=gpurun_out/prof_r03
+ROUND=${ROUND:-r04}
+S=gpurun_out/prof_$ROUND
 # gpurun MERGES into gpurun_out/: keep only the newest run's file(s) in every pass directory before summarising
 for d in $S/stats_* $S/pmc_*; do
   newest=$(ls -t $d/runc/ | head -1 | sed 's/_.*//')
@@ -13,13 +14,13 @@ for d in $S/stats_* $S/pmc_*; do
 done
 python3 tools/pmc_summarise.py $S $S/traffic.json > /dev/null
 for m in mesh grid; do
-  cp $(ls -t $S/stats_$m/*/*_kernel_stats.csv | head -1) profiles/r03_${m}_1M_x512_kernel_stats.csv
+  cp $(ls -t $S/stats_$m/*/*_kernel_stats.csv | head -1) profiles/${ROUND}_${m}_1M_x512_kernel_stats.csv
   for c in fetch write sq; do
     f=$(ls -t $S/pmc_${m}_$c/*/*_counter_collection.csv.mbes | head -1)
-    python3 - "$f" profiles/r03_${m}_pmc_$c.csv <<'PY'
+    python3 - "$f" profiles/${ROUND}_${m}_pmc_$c.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-keep = [r for r in rows if ', false, false, false>' in r['Kernel_Name']]
+keep = [r for r in rows if r['Kernel_Name'].startswith('void k_mbes_sweep') and r['Kernel_Name'].endswith(', false, false>')]
 ids = sorted({int(r['Dispatch_Id']) for r in keep})[:12]
 with open(sys.argv[2], 'w', newline='') as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
@@ -29,7 +30,7 @@ with open(sys.argv[2], 'w', newline='') as f:
             w.writerow(r)
 PY
   done
-  grep '^{"metric"' $S/bench_$m.log | tail -1 > profiles/r03_${m}_bench_only_main.json
+  grep '^{"metric"' $S/bench_$m.log | tail -1 > profiles/${ROUND}_${m}_bench_only_main.json
 done
-cp $S/traffic.json profiles/r03_traffic.json
-ls -la profiles/r03_*
+cp $S/traffic.json profiles/${ROUND}_traffic.json
+ls -la profiles/${ROUND}_*

@@ -1,10 +1,10 @@
 #!/bin/bash
 # tools/profile_gpu.sh -- run on the GPU box (gpurun): kernel-trace stats and the three PMC passes for the
-# mesh and grid workloads; results under gpurun_out/prof_r03/.  Counters are collected in their own runs
+# mesh and grid workloads; results under gpurun_out/prof_${ROUND:-r04}/.  Counters are collected in their own runs
 # (never together with a trace), the program itself follows `--` (no wrapper that would re-exec).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r03
+O=$R/gpurun_out/prof_${ROUND:-r04}
 rm -rf $O && mkdir -p $O
 for m in mesh grid; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -- python3 $R/bench.py --map $m --steps 50 --warmup 5 --only-main > $O/bench_$m.log 2>&1
@@ -15,7 +15,7 @@ done
 cd $R && python3 tools/pmc_summarise.py $O $O/traffic.json > $O/summarise.log 2>&1
 # keep only what is small enough to travel back: the stats CSVs, the dominant kernel's counter rows, the summary
 find $O -name "*kernel_stats.csv" | head
-for f in $(find $O -name "*counter_collection.csv"); do grep -E "Correlation_Id|k_mbes_fast|k_mbes_sweep" $f > $f.mbes; rm $f; done
+for f in $(find $O -name "*counter_collection.csv"); do grep -E "Correlation_Id|k_mbes_fast|k_mbes_sweep|k_mbes_slice" $f > $f.mbes; rm $f; done
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O
 head -c 1500 $O/traffic.json
