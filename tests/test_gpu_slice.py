@@ -170,3 +170,50 @@ def test_fused_steps_on_a_soup_take_the_slice_and_track_the_truth(eng, orc, monk
     err = np.hypot(mean[0] - stream['truth'][steps - 1][0], mean[1] - stream['truth'][steps - 1][1])
     print('soup filter: mean error %.3f m after %d steps, sigma %.3f x %.3f' % (err, steps, np.sqrt(cov[0]), np.sqrt(cov[4])))
     assert err < 0.5
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_slice_fuzz_against_the_oracle(seed, eng, orc, monkeypatch):
+    """Random soups (triangle sizes from 0.5 to 12 m, depths from -35 to -8 m, a floor under them), random attitudes up to
+    35 degrees of roll / pitch, sensors inside, over the edge of and well off the soup's extent, odd beam counts and
+    swaths: every ray within 1e-3 m of the brute-force oracle except a handful that graze an edge (counted, bounded)."""
+    rs = np.random.RandomState(100 + seed)
+    nt = int(rs.choice([40, 200, 800]))
+    size = float(rs.choice([0.5, 3.0, 12.0]))
+    ext = float(rs.choice([15.0, 40.0]))
+    c = rs.uniform(-ext, ext, size=(nt, 2))
+    zc = rs.uniform(-35.0, -8.0, size=nt)
+    verts = np.zeros((nt * 3 + 4, 3), np.float32)
+    for k in range(nt):
+        for v in range(3):
+            verts[3 * k + v, :2] = c[k] + rs.uniform(-size, size, size=2)
+            verts[3 * k + v, 2] = zc[k] + rs.uniform(-0.3 * size, 0.3 * size)
+    tris = np.arange(nt * 3, dtype=np.uint32).reshape(nt, 3)
+    e2 = ext + 15.0
+    verts[-4:] = [[-e2, -e2, -40.0], [e2, -e2, -40.5], [e2, e2, -40.0], [-e2, e2, -39.5]]
+    b = nt * 3
+    tris = np.vstack([tris, np.array([[b, b + 1, b + 2], [b, b + 2, b + 3]], np.uint32)])
+    n = 48
+    soa = rs.randn(6, n) * np.array([0.6 * ext, 0.6 * ext, 1.0, 0.25, 0.25, 3.0])[:, None]
+    soa[2] -= 3.0
+    soa[:2, ::6] *= 2.5                                   # every sixth sensor far out, some beyond the floor's edge
+    soa[3:5] = np.clip(soa[3:5], -0.6, 0.6)
+    B = int(rs.choice([1, 7, 64, 255]))
+    half = float(rs.choice([0.6, 1.05, 1.4]))
+    ba = synth.beam_angles(B, half)
+    r_max = float(rs.choice([45.0, 90.0]))
+    mesh = orc.Mesh(verts, tris)
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, mesh, ba, None, 0.2, r_max)
+    monkeypatch.setenv('MCL_SLICE', '1')
+    e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_map_mesh(verts, tris)
+    got = e.mbes_expected(0, n, ba, r_max)
+    path = e.mbes_last_path()
+    e.close()
+    assert path[0] == 2, path
+    err = np.abs(got - ref)
+    bad = int((err > 1e-3).sum())
+    print('fuzz %d: %d triangles of ~%.1f m, %d beams, handed over %d of %d; max err %.2e, %d of %d rays beyond 1e-3' % (
+        seed, nt, size, B, path[1], n, err.max(), bad, err.size))
+    assert bad <= max(3, err.size // 2000), np.sort(err.ravel())[-6:]
