@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
   for (int k = 0; k < 3; ++k) {
     if (!core.odom(100.02 + 0.02 * k, v, 0.05, q0, -2.0)) return 1;
     if (k == 1 && argc > 3) {
-      const double det[6] = {3.0, 4.0, -18.0, -2.0, -6.0, -17.5};   // base_frame, stamped like the ping
+      const double det[6] = {3.0, 4.0, -16.0, -2.0, -6.0, -15.5};   // base_frame, stamped like the ping
       if (!core.detections(100.02 + 0.02 * k, det, 2)) return 1;
     }
     if (k == 1 && !core.ping_scan(ranges.data(), B, amin, ainc, 80.0, 100.02 + 0.02 * k)) return 1;

@@ -19,8 +19,8 @@
 //      line s = t tan a_b, t > 0); a triangle the plane separates gives one segment -- its end points interpolated
 //      from the vertex BELOW the plane to the one ABOVE it, so that two triangles sharing an edge compute the same
 //      point bit for bit: the slice is watertight;
-//   3. per segment: the run of beams whose tangent lies between those of its end points (lower bound by bisection in
-//      the ascending tangent table in LDS), and for each of them the crossing -> range = t / cos a -> an LDS
+//   3. per segment: the run of beams whose tangent lies between those of its end points (lower bound from a bucket
+//      table over the ascending tangent table in LDS), and for each of them the crossing -> range = t / cos a -> an LDS
 //      atomicMin on the beam's slot (positive floats order like their bit patterns);
 //   4. the wave's lanes then take the beams back (b = lane, lane + 64, ...): residual, sum, log-likelihood -- the same
 //      epilogue as the traversal kernels.
@@ -50,6 +50,7 @@
 #define SLICE_LIST 511    // triangle records a wave's list holds per chunk of columns (2 KiB with its counter); more: the general kernel
 #endif
 #define SLICE_ROWS 4      // cell words of one column loaded per batch
+#define SLICE_LUT 512     // tangent buckets of the beam look-up table (1 KiB per workgroup)
 #ifndef SLICE_COLS
 #define SLICE_COLS 32     // columns per chunk (<= 64: one per lane).  (measured, 1 M x 512, regular mesh as a soup / irregular TIN, ms:
                           //  4 waves, list 1023, 64 columns 4.81 / 7.10; 8 waves, 767, 64: 4.44 / 6.54; 8, 511, 32: 4.11 / 6.90;
@@ -69,11 +70,26 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
   float* secb = tanb + B;                            // B: 1 / cos a
   unsigned* rng_all = (unsigned*)(secb + B);         // SLICE_WAVES x B: nearest crossing per beam (float bits)
   unsigned* tl_all = rng_all + (size_t)SLICE_WAVES * B;   // SLICE_WAVES x (SLICE_LIST + 1): the wave's triangle list, its length
+  unsigned short* lut = (unsigned short*)(tl_all + (size_t)SLICE_WAVES * (SLICE_LIST + 1));   // SLICE_LUT: first beam at or beyond a tangent bucket's lower end
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     const float2 sc = a.beam_sc[b];
     const float sec = __builtin_amdgcn_rcpf(sc.y);
     tanb[b] = sc.x * sec;
     secb[b] = sec;
+  }
+  __syncthreads();
+  // "first beam with tan >= T" without a bisection per segment: SLICE_LUT uniform buckets over the table's tangent
+  // range, each holding the first beam at or beyond its lower end (built here by bisection, once per workgroup); a
+  // query reads its bucket and scans forward -- one or two beams for a table that is uniform in angle
+  const float lut_lo = tanb[0], lut_w = fmaxf((tanb[B - 1] - tanb[0]) * (1.f / SLICE_LUT), 1e-12f), lut_iw = 1.f / lut_w;
+  for (int k = threadIdx.x; k < SLICE_LUT; k += blockDim.x) {
+    const float T = lut_lo + (float)k * lut_w;
+    int lo = 0, hi = B;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (tanb[mid] < T) lo = mid + 1; else hi = mid;
+    }
+    lut[k] = (unsigned short)lo;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -271,13 +287,11 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
       const float TB = tB > 0.f ? sB * __builtin_amdgcn_rcpf(tB) : (sB > 0.f ? INF : -INF);
       const float T_lo = fminf(TA, TB), T_hi = fmaxf(TA, TB);
       if (T_hi < tan_lo || T_lo > tan_hi) continue;
-      // first beam with tan >= T_lo (minus a hair: rounding of the quotient), by bisection
+      // first beam with tan >= T_lo (minus a hair: rounding of the quotient).  The bucket's lower end is <= T_first, so
+      // its first beam is at or before the one wanted: scan forward (rounding of the bucket index: one bucket back)
       const float T_first = T_lo - 1e-6f * fmaxf(1.f, fabsf(T_lo)), T_last = T_hi + 1e-6f * fmaxf(1.f, fabsf(T_hi));
-      int lo = 0, hi = B;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (tanb[mid] < T_first) lo = mid + 1; else hi = mid;
-      }
+      int lo = (int)lut[min(max((int)((T_first - lut_lo) * lut_iw) - 1, 0), SLICE_LUT - 1)];
+      while (lo < B && tanb[lo] < T_first) ++lo;
       const float dts = tB - tA;
       for (int b = lo; b < B; ++b) {
         const float T = tanb[b];

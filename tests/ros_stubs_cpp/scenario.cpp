@@ -116,7 +116,7 @@ void waitForShutdown() {
       geometry_msgs::PoseArray det;
       det.header.frame_id = "sam/base_link";
       det.header.stamp = Time(m.now);
-      const double d[2][3] = {{3.0, 4.0, -18.0}, {-2.0, -6.0, -17.5}};
+      const double d[2][3] = {{3.0, 4.0, -16.0}, {-2.0, -6.0, -15.5}};   // (the vehicle is 2 m down: landmarks at -18 / -17.5)
       for (const auto& row : d) {
         geometry_msgs::Pose ps;
         ps.position.x = row[0];
