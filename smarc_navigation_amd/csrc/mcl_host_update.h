@@ -328,7 +328,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     const bool tin = h->map_kind == 1 && h->mesh->tin_ok && !h->mesh_no_sweep && (!structured || a.diag_mode == 0);
     bool sweep = ((structured && (a.diag_mode == 1 || a.diag_mode == 2)) || h->map_kind == 0 || tin) && h->sweep_angles_ok && h->env_sweep != 0 &&
                  h->ng >= sweep_min_n &&  // (the GLOBAL count: every shard of a cloud takes the same path, results do not depend on the GPU count)
-                 h->n < (1ll << 31) && (long long)a.nx * a.ny < (1ll << 30) && a.ny < (1 << 21);
+                 h->n < (1ll << 31) && (long long)(a.nx + 2) * (a.ny + 2) < (1ll << 30) && a.ny < (1 << 21);   // (the ringed height array as ONE raw buffer: < 2^32 bytes)
     h->sweep_now = sweep;
     // ---- fan slice (mcl_slice.h): every other triangle mesh -- soups, meshes mesh_build could not prove a height
     // field, MCL_MESH_GENERAL -- with an ascending beam table; MCL_SLICE=0 keeps the ray traversal (tests, A/B)
