@@ -1,6 +1,6 @@
 """Register / scratch budget of the hot-path kernels (tools/isa.sh: hipcc -S for gfx950 + kernel-resource-usage
 remarks; no GPU needed).  A kernel of the filter step that spills to scratch pays HBM traffic the roofline accounting
-does not know about: none of them may.  The table is also kept under profiles/ (r03_isa_resources.tsv)."""
+does not know about: none of them may.  The table is also kept under profiles/ (r04_isa_resources.tsv)."""
 import os
 import shutil
 import subprocess
