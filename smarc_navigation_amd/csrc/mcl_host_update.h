@@ -478,7 +478,9 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     d.n_dev = a.defer_count;
     d.host_count = wh_cur + 1;
     const long long n_part = !with_ranges ? std::max<long long>(std::min<long long>(exp_count, h->n - exp_first), 1) : h->n;
-    const int sgrid = (int)std::min<long long>((n_part + SLICE_WAVES - 1) / SLICE_WAVES, 1 << 20);
+    // a capped grid: the beam tables and the tangent buckets a workgroup builds in LDS are shared by 8 particles per wave
+    // at 1 M instead of ONE (mcl_slice.h: SLICE_GRID, measured)
+    const int sgrid = (int)std::min<long long>((n_part + SLICE_WAVES - 1) / SLICE_WAVES, SLICE_GRID);
     const size_t lds = ((size_t)B * (2 + SLICE_WAVES) + (size_t)SLICE_WAVES * (SLICE_LIST + 1)) * sizeof(float) + SLICE_LUT * sizeof(unsigned short);
     const int dgrid = (int)std::min<long long>(ngroups, wh_prev[1] == 0 ? 64 : 4096);
     if (with_ranges) {

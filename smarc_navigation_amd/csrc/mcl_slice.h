@@ -31,7 +31,8 @@
 // (bench.py extra.mesh_general / mesh_soup_irregular).  The kernel is VALU-issue-bound: 2 600 / 4 000 wave
 // instructions per particle at lane utilisation 0.49 / 0.58 (rocprofv3 SQ counters, tools/pmc_kernel.sh); what is
 // left is the divergence of the beam loop (a segment under the sensor covers a dozen beams, one at the swath's edge
-// one or two) and the bisection (nine LDS reads per segment).
+// one or two) and phase 1 itself -- a chain of dependent global loads with next to no arithmetic, 40 - 60 % of the
+// kernel's time (ablation: the launch without phases 2 - 4 takes 2.5 of the 4.1 / 6.7 ms).
 //
 // Exact by construction (two-sided triangles, no side walls: the oracle's definition), deterministic (a minimum does
 // not depend on the order of its operands), a function of the particle alone (the determinism rule of mcl_mbes.h).
@@ -50,6 +51,13 @@
 #define SLICE_LIST 511    // triangle records a wave's list holds per chunk of columns (2 KiB with its counter); more: the general kernel
 #endif
 #define SLICE_ROWS 4      // cell words of one column loaded per batch
+#ifndef SLICE_GRID
+#define SLICE_GRID 32768   // workgroups of a launch: a wave takes every (4 x SLICE_GRID)-th particle.  (measured at 1 M x 512, regular mesh
+                           //  as a soup / irregular TIN, ms: one particle per wave 4.12 / 6.71; 2 048 workgroups 4.57 / 7.90; 8 192: 3.80 / 6.44;
+                           //  32 768: 3.68 / 6.21; 65 536: 3.72 / 6.26 -- the tables a workgroup builds are shared by 8 particles per wave.
+                           //  Requesting the NEXT chunk's cell words before this chunk's triangles are worked on was built and
+                           //  measured too: 95 VGPRs, 5 waves per SIMD instead of 7 -- 4.26 / 7.12, reverted.)
+#endif
 #define SLICE_LUT 512     // tangent buckets of the beam look-up table (1 KiB per workgroup)
 #ifndef SLICE_COLS
 #define SLICE_COLS 32     // columns per chunk (<= 64: one per lane).  (measured, 1 M x 512, regular mesh as a soup / irregular TIN, ms:
