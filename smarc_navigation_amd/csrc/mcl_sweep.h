@@ -75,86 +75,88 @@ __device__ __forceinline__ float hw_max(float x, float y) {
   return r;
 }
 
-// The merge loop of the lattice sweep in assembly (gfx950): the beams of ONE segment (sp, tp) -> (sc, tc), unrolled by
-// two so that the two-deep tangent queue (t0: the pending beam's tangent, t1: the next one's) is consumed and refilled
-// in place -- the compiler's version of the same loop rotates three registers per beam (14 VALU against 12 here; its
-// own unrolling fetches the two records into different registers and copies them back).  The arithmetic is the
-// C++ loop's, instruction for instruction (sweep_side keeps that loop for the sub-fan and expected-range kernels):
+// The merge loop of the lattice sweep in assembly (gfx950): the beams of ONE segment (sp, tp) -> (sc, tc).  The arithmetic
+// is the C++ loop's, instruction for instruction (sweep_side keeps that loop for the sub-fan and expected-range kernels,
+// and tests/test_gpu_zz_merge_asm.py compares a build that takes it everywhere, bit for bit):
 //   e_prev = sp - T tp;  lam = clamp(e_prev / (e_prev - e_cur));  tau = tp + lam dts;
 //   dd = max(z w - tau (w / cos a), (z - r_max) w);  acc += dd^2;  next record;  e_cur = sc - T' tc
-// A lane leaves the loop (its exec bit is cleared) when its pending beam passes beyond the vertex (e_cur < 0 or NaN:
-// the sentinel records end every table); lanes that leave after an odd number of beams swap t0 / t1 at the end.  On
-// exit no fetch is in flight and bp is the pending beam's LDS byte address.  The record lives in v[60:63] for the
-// duration of the statement: one ds_read_b128 fills it, and its
-// fields are named v60 .. v63 in the text -- inline assembly has no way to name the parts of a register tuple operand,
-// and four ds_read_b32 into free-standing registers cost an 8-way bank conflict each as soon as the lanes of a wave
-// stand at different beams (a cloud that is not collapsed: + 20 % on the sigma = 50 m cloud).
+// 11 VALU per beam + one ds_read_b128 (the compiler's version of the loop: 14 -- it rotates a tangent queue through three
+// registers per beam, and its own unrolling fetches two records into different registers and copies them back).
+// * The launches that take this loop get a table whose record b carries the tangent of the NEXT beam of its side
+//   (mcl_host_update.h: upload_sweep_beams, `ahead` = 1; every other kernel: 2, a two-deep queue).  The loop is unrolled
+//   by two and alternates between TWO record tuples, A = v[60:63] and B = v[56:59]: the tangent of the beam pending in one
+//   half is the .x of the record the other half has just used, read where it lies -- no copy into a queue register (round
+//   3 and the first step of round 4: 12 VALU per beam, one of them that copy).  A tuple is reloaded right after the one
+//   instruction that still needs its .x.  On entry the pending tangent is put into B.x by one move; on exit the lanes
+//   that left after the first half of an iteration find theirs in A.x, the others in B.x.
+// * The statement fetches the pending beam's record itself, right after the test that at least one lane has a beam on
+//   this segment (as an in / out operand pinned to a tuple it cost four moves around EVERY statement: the register
+//   allocator will not leave a value in a physical register between two asm statements).  The tuples are plain clobbers;
+//   their fields are named v56 .. v63 in the text -- inline assembly has no way to name the parts of a tuple operand, and
+//   four ds_read_b32 into free-standing registers cost an 8-way bank conflict each as soon as the lanes of a wave stand
+//   at different beams (+ 20 % on the sigma = 50 m cloud).
+// * A lane leaves the loop (its exec bit is cleared) when its pending beam passes beyond the vertex (e_cur < 0 or NaN:
+//   the sentinel records end every table).  On exit no fetch is in flight and bp is the pending beam's LDS byte address.
 // (hazards: the v_rcp result is first read three instructions later; SALU reads of VCC after v_cmp and VALU after a
 //  write of EXEC are interlocked.)
-typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {tan of the beam 2 ahead, w / cos a, z w, (z - r_max) w}
-// (round 4: the pending beam's record is no longer carried in registers from one segment to the next -- as an in / out
-//  operand pinned to v[60:63] it cost two 64-bit moves into the tuple before and two out of it after EVERY statement,
-//  four VALU instructions per walk step, because the register allocator would not leave a value in a physical register
-//  between two asm statements.  The statement now fetches the record itself, right after the test that at least one lane
-//  has a beam on this segment: one more ds_read_b128 per walk step, whose latency the first four instructions of the
-//  loop cover, and four VGPRs fewer live across the walk.  v[60:63] are plain clobbers.)
-__device__ __forceinline__ void sweep_merge_asm(float& t0, float& t1, float& acc, unsigned& bp, float e_cur,
+typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed tan of a beam further out, w / cos a, z w, (z - r_max) w}
+__device__ __forceinline__ void sweep_merge_asm(float& t0, float& acc, unsigned& bp, float e_cur,
                                                 float sp, float tp, float sc, float tc, float dts, int pstep16) {
   float ep, d;
-  unsigned long long sav, odd, tmp;
+  unsigned long long sav, odd, ent;
   asm volatile(
       "s_mov_b64 %[sav], exec\n\t"
       "s_mov_b64 %[odd], 0\n\t"
       "v_cmp_le_f32 vcc, 0, %[ec]\n\t"
       "s_and_b64 exec, exec, vcc\n\t"
+      "s_mov_b64 %[ent], exec\n\t"
       "s_cbranch_execz 9f\n\t"
-      "ds_read_b128 v[60:63], %[bp]\n"
+      "ds_read_b128 v[60:63], %[bp]\n\t"
+      "v_mov_b32 v56, %[t0]\n"
       "1:\n\t"
-      "v_fma_f32 %[ep], -%[t0], %[tp], %[sp]\n\t"
+      "v_fma_f32 %[ep], -v56, %[tp], %[sp]\n\t"
       "v_sub_f32 %[d], %[ep], %[ec]\n\t"
       "v_rcp_f32 %[d], %[d]\n\t"
       "v_add_u32 %[bp], %[ps], %[bp]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
-      "v_mov_b32 %[t0], v60\n\t"
+      "ds_read_b128 v[56:59], %[bp]\n\t"
       "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"
       "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"
       "v_fma_f32 %[ep], -%[ep], v61, v62\n\t"
       "v_max_f32 %[ep], %[ep], v63\n\t"
       "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"
-      "ds_read_b128 v[60:63], %[bp]\n\t"
-      "v_fma_f32 %[ec], -%[t1], %[tc], %[sc]\n\t"
+      "v_fma_f32 %[ec], -v60, %[tc], %[sc]\n\t"
       "v_cmp_le_f32 vcc, 0, %[ec]\n\t"
-      "s_andn2_b64 %[tmp], exec, vcc\n\t"
-      "s_or_b64 %[odd], %[odd], %[tmp]\n\t"
-      "s_and_b64 exec, exec, vcc\n\t"
+      "s_andn2_b64 vcc, exec, vcc\n\t"
+      "s_or_b64 %[odd], %[odd], vcc\n\t"
+      "s_andn2_b64 exec, exec, vcc\n\t"
       "s_cbranch_execz 9f\n\t"
-      "v_fma_f32 %[ep], -%[t1], %[tp], %[sp]\n\t"
+      "v_fma_f32 %[ep], -v60, %[tp], %[sp]\n\t"
       "v_sub_f32 %[d], %[ep], %[ec]\n\t"
       "v_rcp_f32 %[d], %[d]\n\t"
       "v_add_u32 %[bp], %[ps], %[bp]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
-      "v_mov_b32 %[t1], v60\n\t"
+      "ds_read_b128 v[60:63], %[bp]\n\t"
       "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"
       "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"
-      "v_fma_f32 %[ep], -%[ep], v61, v62\n\t"
-      "v_max_f32 %[ep], %[ep], v63\n\t"
+      "v_fma_f32 %[ep], -%[ep], v57, v58\n\t"
+      "v_max_f32 %[ep], %[ep], v59\n\t"
       "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"
-      "ds_read_b128 v[60:63], %[bp]\n\t"
-      "v_fma_f32 %[ec], -%[t0], %[tc], %[sc]\n\t"
+      "v_fma_f32 %[ec], -v56, %[tc], %[sc]\n\t"
       "v_cmp_le_f32 vcc, 0, %[ec]\n\t"
       "s_and_b64 exec, exec, vcc\n\t"
       "s_cbranch_execnz 1b\n"
       "9:\n\t"
       "s_mov_b64 exec, %[odd]\n\t"
-      "v_mov_b32 %[ep], %[t0]\n\t"
-      "v_mov_b32 %[t0], %[t1]\n\t"
-      "v_mov_b32 %[t1], %[ep]\n\t"
+      "v_mov_b32 %[t0], v60\n\t"
+      "s_andn2_b64 exec, %[ent], %[odd]\n\t"
+      "v_mov_b32 %[t0], v56\n\t"
       "s_mov_b64 exec, %[sav]\n\t"
       "s_waitcnt lgkmcnt(0)"
-      : [t0] "+v"(t0), [t1] "+v"(t1), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur),
-        [ep] "=&v"(ep), [d] "=&v"(d), [sav] "=&s"(sav), [odd] "=&s"(odd), [tmp] "=&s"(tmp)
+      : [t0] "+v"(t0), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur),
+        [ep] "=&v"(ep), [d] "=&v"(d), [sav] "=&s"(sav), [odd] "=&s"(odd), [ent] "=&s"(ent)
       : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts), [ps] "s"(pstep16)
-      : "vcc", "v60", "v61", "v62", "v63");
+      : "vcc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
 // a * b clamped to [0, 1] by the multiplier's output modifier (NaN -> 0): the same instruction in the C++ merge loops and
@@ -390,7 +392,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
       //  loop is rotated: e_cur of the NEXT beam is formed at the end of the body, one compare decides)
       float e_cur = fmaf(-tcur, tc, sc);
       if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-        sweep_merge_asm(tcur, tnext, acc, bp, e_cur, sp, tp, sc, tc, dts, pstep16);
+        sweep_merge_asm(tcur, acc, bp, e_cur, sp, tp, sc, tc, dts, pstep16);
       } else {
         // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes
         // sign: <= 0 at prev, >= 0 at cur); then on to the next beam of the table
@@ -1000,7 +1002,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const float dts = t_cur - t_prev;
     float e_cur = fmaf(-tcur, t_cur, s_cur);
     if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-      sweep_merge_asm(tcur, tnext, acc, bp, e_cur, s_prev, t_prev, s_cur, t_cur, dts, pstep16);
+      sweep_merge_asm(tcur, acc, bp, e_cur, s_prev, t_prev, s_cur, t_cur, dts, pstep16);
     } else {
       while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
         const float e_prev = fmaf(-tcur, t_prev, s_prev);
