@@ -100,63 +100,77 @@ __device__ __forceinline__ float hw_max(float x, float y) {
 // (hazards: the v_rcp result is first read three instructions later; SALU reads of VCC after v_cmp and VALU after a
 //  write of EXEC are interlocked.)
 typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed tan of a beam further out, w / cos a, z w, (z - r_max) w}
+// * The table is walked by the ds_read's immediate offset: one pointer add per TWO beams.  SIDE 0 (+ side, ascending
+//   records): the pending record is at bp, the next two at bp + 16 and bp + 32.  SIDE 1 (- side, descending): the
+//   caller keeps bp 32 bytes BELOW the pending record (an immediate offset cannot be negative), so the pending record is
+//   at bp + 32 and the next two at bp + 16 and bp + 0.  A lane that leaves after the first half has moved by one record.
+#define SWEEP_MERGE_ASM_TEXT(OFF0, OFF1, OFF2, STEP2, STEP1)                              \
+      "s_mov_b64 %[sav], exec\n\t"                                                       \
+      "s_mov_b64 %[odd], 0\n\t"                                                          \
+      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"                                                   \
+      "s_and_b64 exec, exec, vcc\n\t"                                                    \
+      "s_mov_b64 %[ent], exec\n\t"                                                       \
+      "s_cbranch_execz 9f\n\t"                                                           \
+      "ds_read_b128 v[60:63], %[bp]" OFF0 "\n\t"                                         \
+      "v_mov_b32 v56, %[t0]\n"                                                            \
+      "1:\n\t"                                                                           \
+      "v_fma_f32 %[ep], -v56, %[tp], %[sp]\n\t"                                          \
+      "v_sub_f32 %[d], %[ep], %[ec]\n\t"                                                 \
+      "v_rcp_f32 %[d], %[d]\n\t"                                                         \
+      "s_waitcnt lgkmcnt(0)\n\t"                                                         \
+      "ds_read_b128 v[56:59], %[bp]" OFF1 "\n\t"                                         \
+      "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"                                       \
+      "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"                                        \
+      "v_fma_f32 %[ep], -%[ep], v61, v62\n\t"                                            \
+      "v_max_f32 %[ep], %[ep], v63\n\t"                                                  \
+      "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"                                              \
+      "v_fma_f32 %[ec], -v60, %[tc], %[sc]\n\t"                                          \
+      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"                                                   \
+      "s_andn2_b64 vcc, exec, vcc\n\t"                                                   \
+      "s_or_b64 %[odd], %[odd], vcc\n\t"                                                 \
+      "s_andn2_b64 exec, exec, vcc\n\t"                                                  \
+      "s_cbranch_execz 9f\n\t"                                                           \
+      "v_fma_f32 %[ep], -v60, %[tp], %[sp]\n\t"                                          \
+      "v_sub_f32 %[d], %[ep], %[ec]\n\t"                                                 \
+      "v_rcp_f32 %[d], %[d]\n\t"                                                         \
+      "s_waitcnt lgkmcnt(0)\n\t"                                                         \
+      "ds_read_b128 v[60:63], %[bp]" OFF2 "\n\t"                                         \
+      STEP2 "\n\t"                                                                       \
+      "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"                                       \
+      "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"                                        \
+      "v_fma_f32 %[ep], -%[ep], v57, v58\n\t"                                            \
+      "v_max_f32 %[ep], %[ep], v59\n\t"                                                  \
+      "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"                                              \
+      "v_fma_f32 %[ec], -v56, %[tc], %[sc]\n\t"                                          \
+      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"                                                   \
+      "s_and_b64 exec, exec, vcc\n\t"                                                    \
+      "s_cbranch_execnz 1b\n"                                                             \
+      "9:\n\t"                                                                           \
+      "s_mov_b64 exec, %[odd]\n\t"                                                       \
+      "v_mov_b32 %[t0], v60\n\t"                                                         \
+      STEP1 "\n\t"                                                                       \
+      "s_andn2_b64 exec, %[ent], %[odd]\n\t"                                             \
+      "v_mov_b32 %[t0], v56\n\t"                                                         \
+      "s_mov_b64 exec, %[sav]\n\t"                                                       \
+      "s_waitcnt lgkmcnt(0)"
+template <int SIDE>
 __device__ __forceinline__ void sweep_merge_asm(float& t0, float& acc, unsigned& bp, float e_cur,
-                                                float sp, float tp, float sc, float tc, float dts, int pstep16) {
+                                                float sp, float tp, float sc, float tc, float dts) {
   float ep, d;
   unsigned long long sav, odd, ent;
-  asm volatile(
-      "s_mov_b64 %[sav], exec\n\t"
-      "s_mov_b64 %[odd], 0\n\t"
-      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"
-      "s_and_b64 exec, exec, vcc\n\t"
-      "s_mov_b64 %[ent], exec\n\t"
-      "s_cbranch_execz 9f\n\t"
-      "ds_read_b128 v[60:63], %[bp]\n\t"
-      "v_mov_b32 v56, %[t0]\n"
-      "1:\n\t"
-      "v_fma_f32 %[ep], -v56, %[tp], %[sp]\n\t"
-      "v_sub_f32 %[d], %[ep], %[ec]\n\t"
-      "v_rcp_f32 %[d], %[d]\n\t"
-      "v_add_u32 %[bp], %[ps], %[bp]\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "ds_read_b128 v[56:59], %[bp]\n\t"
-      "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"
-      "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"
-      "v_fma_f32 %[ep], -%[ep], v61, v62\n\t"
-      "v_max_f32 %[ep], %[ep], v63\n\t"
-      "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"
-      "v_fma_f32 %[ec], -v60, %[tc], %[sc]\n\t"
-      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"
-      "s_andn2_b64 vcc, exec, vcc\n\t"
-      "s_or_b64 %[odd], %[odd], vcc\n\t"
-      "s_andn2_b64 exec, exec, vcc\n\t"
-      "s_cbranch_execz 9f\n\t"
-      "v_fma_f32 %[ep], -v60, %[tp], %[sp]\n\t"
-      "v_sub_f32 %[d], %[ep], %[ec]\n\t"
-      "v_rcp_f32 %[d], %[d]\n\t"
-      "v_add_u32 %[bp], %[ps], %[bp]\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "ds_read_b128 v[60:63], %[bp]\n\t"
-      "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"
-      "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"
-      "v_fma_f32 %[ep], -%[ep], v57, v58\n\t"
-      "v_max_f32 %[ep], %[ep], v59\n\t"
-      "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"
-      "v_fma_f32 %[ec], -v56, %[tc], %[sc]\n\t"
-      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"
-      "s_and_b64 exec, exec, vcc\n\t"
-      "s_cbranch_execnz 1b\n"
-      "9:\n\t"
-      "s_mov_b64 exec, %[odd]\n\t"
-      "v_mov_b32 %[t0], v60\n\t"
-      "s_andn2_b64 exec, %[ent], %[odd]\n\t"
-      "v_mov_b32 %[t0], v56\n\t"
-      "s_mov_b64 exec, %[sav]\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : [t0] "+v"(t0), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur),
-        [ep] "=&v"(ep), [d] "=&v"(d), [sav] "=&s"(sav), [odd] "=&s"(odd), [ent] "=&s"(ent)
-      : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts), [ps] "s"(pstep16)
-      : "vcc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+  if (SIDE == 0) {
+    asm volatile(SWEEP_MERGE_ASM_TEXT("", " offset:16", " offset:32", "v_add_u32 %[bp], 32, %[bp]", "v_add_u32 %[bp], 16, %[bp]")
+                 : [t0] "+v"(t0), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur),
+                   [ep] "=&v"(ep), [d] "=&v"(d), [sav] "=&s"(sav), [odd] "=&s"(odd), [ent] "=&s"(ent)
+                 : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts)
+                 : "vcc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+  } else {
+    asm volatile(SWEEP_MERGE_ASM_TEXT(" offset:32", " offset:16", "", "v_subrev_u32 %[bp], 32, %[bp]", "v_subrev_u32 %[bp], 16, %[bp]")
+                 : [t0] "+v"(t0), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur),
+                   [ep] "=&v"(ep), [d] "=&v"(d), [sav] "=&s"(sav), [odd] "=&s"(odd), [ent] "=&s"(ent)
+                 : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts)
+                 : "vcc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+  }
 }
 
 // a * b clamped to [0, 1] by the multiplier's output modifier (NaN -> 0): the same instruction in the C++ merge loops and
@@ -357,7 +371,10 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   // (record b carries the tangent of the NEXT beam of its side in .x: the decision to leave the merge loop never waits
   //  for the record that has just been requested)
   // (by its LDS byte address: the merge loop of the main kernels is assembly, sweep_merge_asm above)
-  const unsigned sb_off = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)sbeam;
+  // (the assembly loop walks the - side's records downward through immediate offsets, which cannot be negative: on that
+  //  side every table address is kept 32 bytes low -- sweep_merge_asm<1> -- and (bp - sb_off) >> 4 is still the beam)
+  const unsigned sb_off = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)sbeam -
+                          ((!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX && side) ? 32u : 0u);
   unsigned bp = sb_off + (unsigned)(ptr * 16);
   const unsigned bp_end = sb_off + (unsigned)(pend * 16);
   const int pstep16 = pstep * 16;
@@ -392,7 +409,10 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
       //  loop is rotated: e_cur of the NEXT beam is formed at the end of the body, one compare decides)
       float e_cur = fmaf(-tcur, tc, sc);
       if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-        sweep_merge_asm(tcur, acc, bp, e_cur, sp, tp, sc, tc, dts, pstep16);
+        if (side)   // (wave-uniform)
+          sweep_merge_asm<1>(tcur, acc, bp, e_cur, sp, tp, sc, tc, dts);
+        else
+          sweep_merge_asm<0>(tcur, acc, bp, e_cur, sp, tp, sc, tc, dts);
       } else {
         // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes
         // sign: <= 0 at prev, >= 0 at cur); then on to the next beam of the table
@@ -976,7 +996,10 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   const int max_steps = (int)(6.f * (s_stop + 4.f * res) * inv_res) + 64;  // (triangles may be much smaller than a cell)
   int step = 0;
   // (the table is walked by LDS byte address: the merge loop of the main kernel is sweep_merge_asm, as in sweep_side)
-  const unsigned sb_off = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)sbeam;
+  // (the assembly loop walks the - side's records downward through immediate offsets, which cannot be negative: on that
+  //  side every table address is kept 32 bytes low -- sweep_merge_asm<1> -- and (bp - sb_off) >> 4 is still the beam)
+  const unsigned sb_off = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)sbeam -
+                          ((!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX && side) ? 32u : 0u);
   unsigned bp = sb_off + (unsigned)(ptr * 16);
   const unsigned bp_end = sb_off + (unsigned)(pend * 16);
   const int pstep16 = pstep * 16;
@@ -1002,7 +1025,10 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const float dts = t_cur - t_prev;
     float e_cur = fmaf(-tcur, t_cur, s_cur);
     if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-      sweep_merge_asm(tcur, acc, bp, e_cur, s_prev, t_prev, s_cur, t_cur, dts, pstep16);
+      if (side)   // (wave-uniform)
+        sweep_merge_asm<1>(tcur, acc, bp, e_cur, s_prev, t_prev, s_cur, t_cur, dts);
+      else
+        sweep_merge_asm<0>(tcur, acc, bp, e_cur, s_prev, t_prev, s_cur, t_cur, dts);
     } else {
       while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
         const float e_prev = fmaf(-tcur, t_prev, s_prev);
