@@ -20,7 +20,7 @@ for m in mesh grid; do
     python3 - "$f" profiles/${ROUND}_${m}_pmc_$c.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-keep = [r for r in rows if r['Kernel_Name'].startswith('void k_mbes_sweep') and r['Kernel_Name'].endswith(', false, false>')]
+keep = [r for r in rows if r['Kernel_Name'].startswith('void k_mbes_sweep') and ', false, false>' in r['Kernel_Name']]
 ids = sorted({int(r['Dispatch_Id']) for r in keep})[:12]
 with open(sys.argv[2], 'w', newline='') as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
