@@ -1134,3 +1134,12 @@ int mcl_timing_get(mcl_handle* h, mcl_timing* out) {
 }
 
 }  // extern "C"
+
+#ifdef SWEEP_TIMELINE
+// debug builds only (tools/sweep_timeline.py): the per-wave clock records of the last sweep launch
+extern "C" int mcl_debug_sweep_timeline(unsigned long long* out, int n_waves) {
+  if (n_waves > SWEEP_TL_WAVES) n_waves = SWEEP_TL_WAVES;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_tl), (size_t)n_waves * 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+

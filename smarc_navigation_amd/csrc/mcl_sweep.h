@@ -34,6 +34,9 @@
 #pragma once
 #include "mcl_mbes.h"
 
+#ifndef SWEEP_PRIO
+#define SWEEP_PRIO 0
+#endif
 #ifndef SWEEP_THREADS
 #define SWEEP_THREADS 256
 #endif
@@ -56,6 +59,12 @@
 #define SWEEP_NOTE(code) ((void)0)
 #endif
 #define SWEEP_FAIL(code) do { SWEEP_NOTE(code); return false; } while (0)
+// -DSWEEP_TIMELINE (tools/sweep_timeline.py): every wave of the last sweep launch leaves {start, reached the barrier, end}
+// on the 100 MHz device clock and its hardware slot -- how full the machine is over the launch, where the tail begins
+#ifdef SWEEP_TIMELINE
+#define SWEEP_TL_WAVES 65536
+__device__ unsigned long long g_sweep_tl[6 * SWEEP_TL_WAVES];
+#endif
 #ifndef SWEEP_TAN_AHEAD
 #define SWEEP_TAN_AHEAD 2   // record b carries the tangent of the beam this many places further out on its side
 #endif
@@ -104,16 +113,73 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
 //   records): the pending record is at bp, the next two at bp + 16 and bp + 32.  SIDE 1 (- side, descending): the
 //   caller keeps bp 32 bytes BELOW the pending record (an immediate offset cannot be negative), so the pending record is
 //   at bp + 32 and the next two at bp + 16 and bp + 0.  A lane that leaves after the first half has moved by one record.
-#define SWEEP_MERGE_ASM_TEXT(OFF0, OFF1, OFF2, STEP2, STEP1)                              \
+#ifndef SWEEP_MERGE_ILP
+#define SWEEP_MERGE_ILP 1
+#endif
+#if SWEEP_MERGE_ILP
+// (two independent chains per half: the pending beam's crossing and residual, and the NEXT beam's test against the
+//  vertex -- e_cur alternates between two registers -- so that a wave has something to issue while a result is in flight)
+#define SWEEP_MERGE_ASM_TEXT(OFF0, OFF1, OFF2, STEP2, STEP1, L1, L9)                              \
       "s_mov_b64 %[sav], exec\n\t"                                                       \
       "s_mov_b64 %[odd], 0\n\t"                                                          \
       "v_cmp_le_f32 vcc, 0, %[ec]\n\t"                                                   \
       "s_and_b64 exec, exec, vcc\n\t"                                                    \
       "s_mov_b64 %[ent], exec\n\t"                                                       \
-      "s_cbranch_execz 9f\n\t"                                                           \
+      "s_cbranch_execz " L9 "f\n\t"                                                           \
       "ds_read_b128 v[60:63], %[bp]" OFF0 "\n\t"                                         \
       "v_mov_b32 v56, %[t0]\n"                                                            \
-      "1:\n\t"                                                                           \
+      L1 ":\n\t"                                                                           \
+      "v_fma_f32 %[ep], -v56, %[tp], %[sp]\n\t"                                          \
+      "v_sub_f32 %[d], %[ep], %[ec]\n\t"                                                 \
+      "s_waitcnt lgkmcnt(0)\n\t"                                                         \
+      "v_fma_f32 %[e2], -v60, %[tc], %[sc]\n\t"                                          \
+      "ds_read_b128 v[56:59], %[bp]" OFF1 "\n\t"                                         \
+      "v_rcp_f32 %[d], %[d]\n\t"                                                         \
+      "v_cmp_le_f32 vcc, 0, %[e2]\n\t"                                                   \
+      "s_andn2_b64 vcc, exec, vcc\n\t"                                                   \
+      "s_or_b64 %[odd], %[odd], vcc\n\t"                                                 \
+      "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"                                       \
+      "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"                                        \
+      "v_fma_f32 %[ep], -%[ep], v61, v62\n\t"                                            \
+      "v_max_f32 %[ep], %[ep], v63\n\t"                                                  \
+      "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"                                              \
+      "s_andn2_b64 exec, exec, vcc\n\t"                                                  \
+      "s_cbranch_execz " L9 "f\n\t"                                                           \
+      "v_fma_f32 %[ep], -v60, %[tp], %[sp]\n\t"                                          \
+      "v_sub_f32 %[d], %[ep], %[e2]\n\t"                                                 \
+      "s_waitcnt lgkmcnt(0)\n\t"                                                         \
+      "v_fma_f32 %[ec], -v56, %[tc], %[sc]\n\t"                                          \
+      "ds_read_b128 v[60:63], %[bp]" OFF2 "\n\t"                                         \
+      STEP2 "\n\t"                                                                       \
+      "v_rcp_f32 %[d], %[d]\n\t"                                                         \
+      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"                                                   \
+      "s_nop 0\n\t"                                                                      \
+      "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"                                       \
+      "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"                                        \
+      "v_fma_f32 %[ep], -%[ep], v57, v58\n\t"                                            \
+      "v_max_f32 %[ep], %[ep], v59\n\t"                                                  \
+      "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"                                              \
+      "s_and_b64 exec, exec, vcc\n\t"                                                    \
+      "s_cbranch_execnz " L1 "b\n"                                                             \
+      L9 ":\n\t"                                                                           \
+      "s_mov_b64 exec, %[odd]\n\t"                                                       \
+      "v_mov_b32 %[t0], v60\n\t"                                                         \
+      STEP1 "\n\t"                                                                       \
+      "s_andn2_b64 exec, %[ent], %[odd]\n\t"                                             \
+      "v_mov_b32 %[t0], v56\n\t"                                                         \
+      "s_mov_b64 exec, %[sav]\n\t"                                                       \
+      "s_waitcnt lgkmcnt(0)"
+#else
+#define SWEEP_MERGE_ASM_TEXT(OFF0, OFF1, OFF2, STEP2, STEP1, L1, L9)                              \
+      "s_mov_b64 %[sav], exec\n\t"                                                       \
+      "s_mov_b64 %[odd], 0\n\t"                                                          \
+      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"                                                   \
+      "s_and_b64 exec, exec, vcc\n\t"                                                    \
+      "s_mov_b64 %[ent], exec\n\t"                                                       \
+      "s_cbranch_execz " L9 "f\n\t"                                                           \
+      "ds_read_b128 v[60:63], %[bp]" OFF0 "\n\t"                                         \
+      "v_mov_b32 v56, %[t0]\n"                                                            \
+      L1 ":\n\t"                                                                           \
       "v_fma_f32 %[ep], -v56, %[tp], %[sp]\n\t"                                          \
       "v_sub_f32 %[d], %[ep], %[ec]\n\t"                                                 \
       "v_rcp_f32 %[d], %[d]\n\t"                                                         \
@@ -129,7 +195,7 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
       "s_andn2_b64 vcc, exec, vcc\n\t"                                                   \
       "s_or_b64 %[odd], %[odd], vcc\n\t"                                                 \
       "s_andn2_b64 exec, exec, vcc\n\t"                                                  \
-      "s_cbranch_execz 9f\n\t"                                                           \
+      "s_cbranch_execz " L9 "f\n\t"                                                           \
       "v_fma_f32 %[ep], -v60, %[tp], %[sp]\n\t"                                          \
       "v_sub_f32 %[d], %[ep], %[ec]\n\t"                                                 \
       "v_rcp_f32 %[d], %[d]\n\t"                                                         \
@@ -144,8 +210,8 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
       "v_fma_f32 %[ec], -v56, %[tc], %[sc]\n\t"                                          \
       "v_cmp_le_f32 vcc, 0, %[ec]\n\t"                                                   \
       "s_and_b64 exec, exec, vcc\n\t"                                                    \
-      "s_cbranch_execnz 1b\n"                                                             \
-      "9:\n\t"                                                                           \
+      "s_cbranch_execnz " L1 "b\n"                                                             \
+      L9 ":\n\t"                                                                           \
       "s_mov_b64 exec, %[odd]\n\t"                                                       \
       "v_mov_b32 %[t0], v60\n\t"                                                         \
       STEP1 "\n\t"                                                                       \
@@ -153,24 +219,24 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
       "v_mov_b32 %[t0], v56\n\t"                                                         \
       "s_mov_b64 exec, %[sav]\n\t"                                                       \
       "s_waitcnt lgkmcnt(0)"
-template <int SIDE>
-__device__ __forceinline__ void sweep_merge_asm(float& t0, float& acc, unsigned& bp, float e_cur,
+#endif
+// (ONE statement for both sides, a scalar branch between two copies of the loop: two statements under `if (side)` made
+//  the compiler copy every in / out operand before and after them -- seven moves per walk step)
+__device__ __forceinline__ void sweep_merge_asm(int side, float& t0, float& acc, unsigned& bp, float e_cur,
                                                 float sp, float tp, float sc, float tc, float dts) {
-  float ep, d;
+  float ep, d, e2;
   unsigned long long sav, odd, ent;
-  if (SIDE == 0) {
-    asm volatile(SWEEP_MERGE_ASM_TEXT("", " offset:16", " offset:32", "v_add_u32 %[bp], 32, %[bp]", "v_add_u32 %[bp], 16, %[bp]")
-                 : [t0] "+v"(t0), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur),
-                   [ep] "=&v"(ep), [d] "=&v"(d), [sav] "=&s"(sav), [odd] "=&s"(odd), [ent] "=&s"(ent)
-                 : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts)
-                 : "vcc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
-  } else {
-    asm volatile(SWEEP_MERGE_ASM_TEXT(" offset:32", " offset:16", "", "v_subrev_u32 %[bp], 32, %[bp]", "v_subrev_u32 %[bp], 16, %[bp]")
-                 : [t0] "+v"(t0), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur),
-                   [ep] "=&v"(ep), [d] "=&v"(d), [sav] "=&s"(sav), [odd] "=&s"(odd), [ent] "=&s"(ent)
-                 : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts)
-                 : "vcc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
-  }
+  asm volatile("s_cmp_lg_u32 %[side], 0\n\t"
+               "s_cbranch_scc1 5f\n\t"
+               SWEEP_MERGE_ASM_TEXT("", " offset:16", " offset:32", "v_add_u32 %[bp], 32, %[bp]", "v_add_u32 %[bp], 16, %[bp]", "1", "9") "\n\t"
+               "s_branch 6f\n"
+               "5:\n\t"
+               SWEEP_MERGE_ASM_TEXT(" offset:32", " offset:16", "", "v_subrev_u32 %[bp], 32, %[bp]", "v_subrev_u32 %[bp], 16, %[bp]", "2", "8") "\n"
+               "6:"
+               : [t0] "+v"(t0), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur),
+                 [ep] "=&v"(ep), [d] "=&v"(d), [e2] "=&v"(e2), [sav] "=&s"(sav), [odd] "=&s"(odd), [ent] "=&s"(ent)
+               : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts), [side] "s"(side)
+               : "vcc", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
 // a * b clamped to [0, 1] by the multiplier's output modifier (NaN -> 0): the same instruction in the C++ merge loops and
@@ -338,7 +404,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
       k2 = c00 + 1;
     }
     const SweepNode N0 = node(k0), N1 = node(k1), N2 = node(k2);
-    const bool p0b = N0.d > 0.f, p1b = N1.d > 0.f, p2b = N2.d > 0.f;
+    const bool p0b = __float_as_int(N0.d) >= 0, p1b = __float_as_int(N1.d) >= 0, p2b = __float_as_int(N2.d) >= 0;   // (sides of the plane by the sign bit, like the walk)
     if (p0b == p1b && p1b == p2b) SWEEP_FAIL(6);  // the plane misses the triangle (rounding at its border)
     // the node alone on its side of the plane, and the two edges the plane crosses
     const int L = (p0b != p1b && p0b != p2b) ? 0 : ((p1b != p0b && p1b != p2b) ? 1 : 2);
@@ -351,9 +417,9 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     if (!(sm != sn)) SWEEP_FAIL(7);  // the plane only touches the triangle at a node (or NaN)
     const bool far_m = sm > sn;     // this side walks out through the edge whose crossing lies further out
     const SweepNode NF = far_m ? NM : NN;
-    const bool pl = NL.d > 0.f;
-    A = pl ? NF : NL;   // A: d <= 0, Bn: d > 0
-    Bn = pl ? NL : NF;
+    const bool pl = __float_as_int(NL.d) >= 0;
+    A = pl ? NF : NL;   // (along the walk A is the node found last and Bn the other end of the edge the slice leaves
+    Bn = pl ? NL : NF;  //  through: plane functions of opposite sign bits)
     C = far_m ? NN.P : NM.P;
     s_cur = far_m ? sm : sn;
     t_cur = far_m ? tm : tn;
@@ -365,14 +431,13 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   float acc = 0.f;
   bool ok = true;
   const int max_steps = (int)(3.f * (s_stop + 4.f * res) * inv_res) + 16;
-  int step = 0;
   // the next beam to resolve stays in registers across segments (a vertex it passes beyond costs no LDS read), the one
   // after it is already on its way from LDS: the table is walked by pointer, one add per beam
   // (record b carries the tangent of the NEXT beam of its side in .x: the decision to leave the merge loop never waits
   //  for the record that has just been requested)
   // (by its LDS byte address: the merge loop of the main kernels is assembly, sweep_merge_asm above)
   // (the assembly loop walks the - side's records downward through immediate offsets, which cannot be negative: on that
-  //  side every table address is kept 32 bytes low -- sweep_merge_asm<1> -- and (bp - sb_off) >> 4 is still the beam)
+  //  side every table address is kept 32 bytes low -- sweep_merge_asm -- and (bp - sb_off) >> 4 is still the beam)
   const unsigned sb_off = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)sbeam -
                           ((!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX && side) ? 32u : 0u);
   unsigned bp = sb_off + (unsigned)(ptr * 16);
@@ -394,25 +459,21 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   }
   // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the next triangle.
   // Returns true when the walk is over (all beams resolved, stop distance, map border, failure).
-  float hN = 0.f;   // the height loaded last (read after the loop: why did the walk end?)
-  const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc) -> bool {
+  const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc, const int step) -> bool {
     // the third node of the triangle across (A, Bn): its height load is in flight while the beams are resolved
     const int Nk = (int)((unsigned)A.P + (unsigned)Bn.P - (unsigned)C);
     const int nj = __builtin_amdgcn_sbfe(Nk, 0, 16), ni = (Nk - nj) >> 16;
     // (the footprint test keeps a sane walk inside the map; a NaN-driven one is stopped by the buffer's own range check:
     //  a raw buffer load beyond num_records returns 0 -- no clamp, no 64-bit address arithmetic.  |ni| < 30000 and
     //  4 ny < 2^23 -- checked on the host --: the full-rate 24-bit multiply)
-    hN = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(ni, ny4) + ((nj << 2) + g0b), 0, 0));
+    const float hN = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(ni, ny4) + ((nj << 2) + g0b), 0, 0));
     const float dts = tc - tp;
     {
       // (no end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0, so e_cur = -inf.  The
       //  loop is rotated: e_cur of the NEXT beam is formed at the end of the body, one compare decides)
       float e_cur = fmaf(-tcur, tc, sc);
       if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-        if (side)   // (wave-uniform)
-          sweep_merge_asm<1>(tcur, acc, bp, e_cur, sp, tp, sc, tc, dts);
-        else
-          sweep_merge_asm<0>(tcur, acc, bp, e_cur, sp, tp, sc, tc, dts);
+        sweep_merge_asm(side, tcur, acc, bp, e_cur, sp, tp, sc, tc, dts);   // (side: wave-uniform)
       } else {
         // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes
         // sign: <= 0 at prev, >= 0 at cur); then on to the next beam of the table
@@ -442,25 +503,28 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     }
     if (bp == bp_end) return true;
     if (sc > s_stop) return true;  // every beam left misses inside r_max (tail below)
-    if (++step > max_steps) {
+    if (step > max_steps) {   // (step: the wave's own count -- every lane still walking has taken as many)
       SWEEP_NOTE(11);
-      ok = false;
+      ok = false;   // (the node found last has a height: the test after the loop hands the particle over)
       return true;
     }
     const float fi = (float)ni, fj = (float)nj;
     const float dN = fmaf(pu, fi, fmaf(pv, fj, fmaf(pz, hN, p0)));
-    const float sN = fmaf(su, fi, fmaf(sv, fj, fmaf(sz, hN, s0)));
-    const float tN = fmaf(tu, fi, fmaf(tv, fj, fmaf(tz, hN, t0)));
-    const bool pos = dN > 0.f;
-    C = pos ? Bn.P : A.P;
-    A.P = pos ? A.P : Nk;
-    A.d = pos ? A.d : dN;
-    A.s = pos ? A.s : sN;
-    A.t = pos ? A.t : tN;
-    Bn.P = pos ? Nk : Bn.P;
-    Bn.d = pos ? dN : Bn.d;
-    Bn.s = pos ? sN : Bn.s;
-    Bn.t = pos ? tN : Bn.t;
+    // the new node replaces the one on ITS side of the plane; the next edge joins it to the one that stays.  The new
+    // node always becomes A, the one that stays moves to Bn only when it was A: five selects and two moves per step
+    // (nine selects with fixed roles "A below, Bn above"); the new node's s and t are formed in A's registers, after
+    // the selects have read them
+    // (sides by the SIGN BIT of the plane function: one xor and one compare, no state)
+    const bool keep_a = (__float_as_int(dN) ^ __float_as_int(A.d)) < 0;
+    C = keep_a ? Bn.P : A.P;
+    Bn.P = keep_a ? A.P : Bn.P;
+    Bn.d = keep_a ? A.d : Bn.d;
+    Bn.s = keep_a ? A.s : Bn.s;
+    Bn.t = keep_a ? A.t : Bn.t;
+    A.P = Nk;
+    A.d = dN;
+    A.s = fmaf(su, fi, fmaf(sv, fj, fmaf(sz, hN, s0)));
+    A.t = fmaf(tu, fi, fmaf(tv, fj, fmaf(tz, hN, t0)));
     const float lam = A.d * fast_rcp(A.d - Bn.d);
     const float s_new = fmaf(lam, Bn.s - A.s, A.s), t_new = fmaf(lam, Bn.t - A.t, A.t);
     // every crossing is a vertex of the slice.  The new vertex takes the place of the one before last and the CALLER
@@ -475,13 +539,16 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     }
     return false;
   };
-  for (;;) {
-    if (walk_step(s_prev, t_prev, s_cur, t_cur)) break;
-    if (walk_step(s_cur, t_cur, s_prev, t_prev)) break;
+  for (int step = 1;; step += 2) {
+    if (walk_step(s_prev, t_prev, s_cur, t_cur, step)) break;
+    if (walk_step(s_cur, t_cur, s_prev, t_prev, step + 1)) break;
   }
-  if (!ok && step <= max_steps) {
+  if (!ok) {
     // a NaN height: the slice ends at the map border -- final if it cannot come back (the beams left get r_max through
-    // the tail below).  (hN: the last height this lane loaded; su = +-c1x res: the walk keeps no other copy)
+    // the tail below).  (hN: the height of the node this lane found last, A -- loaded again here rather than kept alive
+    // across the loop; su = +-c1x res: the walk keeps no other copy)
+    const int lj = __builtin_amdgcn_sbfe(A.P, 0, 16), li = (A.P - lj) >> 16;
+    const float hN = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(li, ny4) + ((lj << 2) + g0b), 0, 0));
     ok = (hN != hN) && sweep_border_final(a, hN, c2z, su * inv_res, sv * inv_res);
     if (!ok) SWEEP_NOTE(hN != hN ? 10 : 12);
   }
@@ -997,7 +1064,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   int step = 0;
   // (the table is walked by LDS byte address: the merge loop of the main kernel is sweep_merge_asm, as in sweep_side)
   // (the assembly loop walks the - side's records downward through immediate offsets, which cannot be negative: on that
-  //  side every table address is kept 32 bytes low -- sweep_merge_asm<1> -- and (bp - sb_off) >> 4 is still the beam)
+  //  side every table address is kept 32 bytes low -- sweep_merge_asm -- and (bp - sb_off) >> 4 is still the beam)
   const unsigned sb_off = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)sbeam -
                           ((!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX && side) ? 32u : 0u);
   unsigned bp = sb_off + (unsigned)(ptr * 16);
@@ -1025,10 +1092,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const float dts = t_cur - t_prev;
     float e_cur = fmaf(-tcur, t_cur, s_cur);
     if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-      if (side)   // (wave-uniform)
-        sweep_merge_asm<1>(tcur, acc, bp, e_cur, s_prev, t_prev, s_cur, t_cur, dts);
-      else
-        sweep_merge_asm<0>(tcur, acc, bp, e_cur, s_prev, t_prev, s_cur, t_cur, dts);
+      sweep_merge_asm(side, tcur, acc, bp, e_cur, s_prev, t_prev, s_cur, t_cur, dts);   // (side: wave-uniform)
     } else {
       while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
         const float e_prev = fmaf(-tcur, t_prev, s_prev);
@@ -1140,6 +1204,10 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
     xacc[w * 64 + lane] = acc;
     xok[w * 64 + lane] = ok ? 1 : 0;
   }
+#ifdef SWEEP_TIMELINE
+  if (lane == 0 && blockIdx.x * (blockDim.x >> 6) + w < SWEEP_TL_WAVES)
+    g_sweep_tl[6 * (blockIdx.x * (blockDim.x >> 6) + w) + 1] = wall_clock64();
+#endif
   __syncthreads();
   double v = -__builtin_inf();
   if (!combo) {
@@ -1170,9 +1238,24 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
 //  carries the conic AND the start ray's footprint test, and spilled 8 B per lane at 6: small clouds, latency-bound anyway)
 template <int SURF, bool EXPECT_ONLY, bool SUB = false>
 __global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, SURF == 0 ? (SUB ? SWEEP_MIN_WAVES_GRID - 1 : SWEEP_MIN_WAVES_GRID) : (SURF == 5 ? SWEEP_MIN_WAVES_TIN : SWEEP_MIN_WAVES)) k_mbes_sweep(MbesArgs a) {
+#ifdef SWEEP_TIMELINE
+  const unsigned long long tl0 = wall_clock64(), tc0 = __builtin_readcyclecounter();
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char sweep_lds[];
   __shared__ float xacc[64 * (SUB ? SWEEP_MAX_WAVES : SWEEP_THREADS / 64)];
   __shared__ int xok[64 * (SUB ? SWEEP_MAX_WAVES : SWEEP_THREADS / 64)];
+#if SWEEP_PRIO == 1
+  if (blockIdx.x * 4 >= gridDim.x * 3) __builtin_amdgcn_s_setprio(1);
+#elif SWEEP_PRIO == 2
+  if (blockIdx.x * 4 >= gridDim.x * 3) __builtin_amdgcn_s_setprio(2);
+  else if (blockIdx.x * 4 >= gridDim.x * 2) __builtin_amdgcn_s_setprio(1);
+#elif SWEEP_PRIO == 3
+  if (blockIdx.x * 4 >= gridDim.x * 3) __builtin_amdgcn_s_setprio(3);
+  else if (blockIdx.x * 4 >= gridDim.x * 2) __builtin_amdgcn_s_setprio(2);
+  else if (blockIdx.x * 4 >= gridDim.x * 1) __builtin_amdgcn_s_setprio(1);
+#elif SWEEP_PRIO == 4
+  if (blockIdx.x * 8 >= gridDim.x * 7) __builtin_amdgcn_s_setprio(1);
+#endif
   float4* sbeam = (float4*)sweep_lds + 1;  // records -1 and n_beams exist (read, never used)
   float* stail = (float*)(sbeam + a.n_beams + 1);
   for (int b = threadIdx.x; b < a.n_beams; b += blockDim.x) {
@@ -1193,4 +1276,17 @@ __global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, SU
       atomicMax((unsigned long long*)&a.max_slots[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (MCL_MAX_SLOTS - 1)],
                 ordered_key(m));
   }
+#ifdef SWEEP_TIMELINE
+  {
+    const unsigned wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0 && wv < SWEEP_TL_WAVES) {
+      g_sweep_tl[6 * wv] = tl0;
+      g_sweep_tl[6 * wv + 2] = wall_clock64();
+      g_sweep_tl[6 * wv + 4] = tc0;                           // shader clock (s_memtime): the clock the launch ran at
+      g_sweep_tl[6 * wv + 5] = __builtin_readcyclecounter();
+      g_sweep_tl[6 * wv + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)             // HW_ID
+                               | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // XCC_ID
+    }
+  }
+#endif
 }
