@@ -418,7 +418,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     // (expected ranges of a few particles: only their lanes are launched)
     const long long n_part = !with_ranges ? std::max<long long>(std::min<long long>(exp_count, h->n - exp_first), 1) : h->n;
     const int sgrid = (int)((n_part + per_block - 1) / per_block);
-    const size_t lds = (size_t)(B + 2) * sizeof(float4) + (size_t)(B + 4) * sizeof(float);
+    const size_t lds = (size_t)(B + 7) * sizeof(float4) + (size_t)(B + 4) * sizeof(float);   // (k_mbes_sweep: 4 spare records, two sentinels, one record in front of either side)
     // What the sweep declines (mcl_sweep.h: tilt, position, no nadir hit, a border the slice may re-cross) is cast by
     // the general kernel, one wavefront per particle, in the order of the hand-over list -- whose length it reads on
     // the device.  TWO launches per update (rounds 2-3: five -- a bounds-checked second sweep pass, classify, fast, cast).

@@ -89,47 +89,41 @@ __device__ __forceinline__ float hw_max(float x, float y) {
 // and tests/test_gpu_zz_merge_asm.py compares a build that takes it everywhere, bit for bit):
 //   e_prev = sp - T tp;  lam = clamp(e_prev / (e_prev - e_cur));  tau = tp + lam dts;
 //   dd = max(z w - tau (w / cos a), (z - r_max) w);  acc += dd^2;  next record;  e_cur = sc - T' tc
-// 11 VALU per beam + one ds_read_b128 (the compiler's version of the loop: 14 -- it rotates a tangent queue through three
-// registers per beam, and its own unrolling fetches two records into different registers and copies them back).
+// 10.5 VALU per beam + one ds_read_b128 (the compiler's version of the loop: 14 -- it rotates a tangent queue through
+// three registers per beam, and its own unrolling fetches two records into different registers and copies them back).
 // * The launches that take this loop get a table whose record b carries the tangent of the NEXT beam of its side
 //   (mcl_host_update.h: upload_sweep_beams, `ahead` = 1; every other kernel: 2, a two-deep queue).  The loop is unrolled
 //   by two and alternates between TWO record tuples, A = v[60:63] and B = v[56:59]: the tangent of the beam pending in one
-//   half is the .x of the record the other half has just used, read where it lies -- no copy into a queue register (round
-//   3 and the first step of round 4: 12 VALU per beam, one of them that copy).  A tuple is reloaded right after the one
-//   instruction that still needs its .x.  On entry the pending tangent is put into B.x by one move; on exit the lanes
-//   that left after the first half of an iteration find theirs in A.x, the others in B.x.
-// * The statement fetches the pending beam's record itself, right after the test that at least one lane has a beam on
-//   this segment (as an in / out operand pinned to a tuple it cost four moves around EVERY statement: the register
-//   allocator will not leave a value in a physical register between two asm statements).  The tuples are plain clobbers;
+//   half is the .x of the record the other half has just used, read where it lies -- no copy into a queue register.  A
+//   tuple is reloaded right after the one instruction that still needs its .x.
+// * Two independent chains per half: the pending beam's crossing and residual, and the NEXT beam's test against the
+//   vertex (e_cur alternates between two registers): a wave has something to issue while a result is in flight.
+// * The statement keeps NO state but acc and bp: it fetches the pending beam's record and its tangent itself -- the
+//   tangent is the .x of the record one place back towards the nadir, bp + SWEEP_PREV_OFF on either side, read straight
+//   into B.x (k_mbes_sweep stages the table with a record in front of either side's first beam for this) -- and forms
+//   the test that at least one lane has a beam on this segment.  (As an in / out operand the tangent cost a move on
+//   entry and two under two exec masks on exit; the record as an operand pinned to a tuple four moves around EVERY
+//   statement: the register allocator will not leave a value in a physical register between two asm statements.)  The tuples are plain clobbers;
 //   their fields are named v56 .. v63 in the text -- inline assembly has no way to name the parts of a tuple operand, and
 //   four ds_read_b32 into free-standing registers cost an 8-way bank conflict each as soon as the lanes of a wave stand
 //   at different beams (+ 20 % on the sigma = 50 m cloud).
 // * A lane leaves the loop (its exec bit is cleared) when its pending beam passes beyond the vertex (e_cur < 0 or NaN:
-//   the sentinel records end every table).  On exit no fetch is in flight and bp is the pending beam's LDS byte address.
+//   the sentinel records end every table).  On exit no fetch is in flight and bp belongs to the pending beam.
+// * The table is walked by the ds_read's immediate offset: one pointer add per TWO beams.  An immediate cannot be
+//   negative and the two sides walk in opposite directions, so bp is kept BELOW the pending record: by 64 bytes on
+//   side 0 (ascending: pending at bp + 64, the next two at + 80, + 96, the one before at + 48), by 32 on side 1
+//   (descending: pending at + 32, the next two at + 16, + 0, the one before at + 48).
+// * ONE statement for both sides, a scalar branch between two copies: two statements under `if (side)` made the
+//   compiler copy every in / out operand before and after them -- seven moves per walk step.
 // (hazards: the v_rcp result is first read three instructions later; SALU reads of VCC after v_cmp and VALU after a
 //  write of EXEC are interlocked.)
 typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed tan of a beam further out, w / cos a, z w, (z - r_max) w}
-// * The table is walked by the ds_read's immediate offset: one pointer add per TWO beams.  SIDE 0 (+ side, ascending
-//   records): the pending record is at bp, the next two at bp + 16 and bp + 32.  SIDE 1 (- side, descending): the
-//   caller keeps bp 32 bytes BELOW the pending record (an immediate offset cannot be negative), so the pending record is
-//   at bp + 32 and the next two at bp + 16 and bp + 0.  A lane that leaves after the first half has moved by one record.
-#ifndef SWEEP_MERGE_ILP
-#define SWEEP_MERGE_ILP 1
-#endif
-#if SWEEP_MERGE_ILP
-// (two independent chains per half: the pending beam's crossing and residual, and the NEXT beam's test against the
-//  vertex -- e_cur alternates between two registers -- so that a wave has something to issue while a result is in flight)
-#define SWEEP_MERGE_ASM_TEXT(OFF0, OFF1, OFF2, STEP2, STEP1, L1, L9)                              \
-      "s_mov_b64 %[sav], exec\n\t"                                                       \
-      "s_mov_b64 %[odd], 0\n\t"                                                          \
-      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"                                                   \
-      "s_and_b64 exec, exec, vcc\n\t"                                                    \
-      "s_mov_b64 %[ent], exec\n\t"                                                       \
-      "s_cbranch_execz " L9 "f\n\t"                                                           \
-      "ds_read_b128 v[60:63], %[bp]" OFF0 "\n\t"                                         \
-      "v_mov_b32 v56, %[t0]\n"                                                            \
-      L1 ":\n\t"                                                                           \
-      "v_fma_f32 %[ep], -v56, %[tp], %[sp]\n\t"                                          \
+#define SWEEP_BIAS0 64u      // bp = address of the pending record - bias (side 0 / side 1)
+#define SWEEP_BIAS1 32u
+#define SWEEP_PREV_OFF 48u   // ... and the record one place back towards the nadir is at bp + 48 on either side
+// first half: the pending beam's tangent in TAN, its record in A = v[60:63] (.x: the next beam's tangent); fetches B
+#define SWEEP_MERGE_HALF1(TAN, OFF1)                                                     \
+      "v_fma_f32 %[ep], -" TAN ", %[tp], %[sp]\n\t"                                      \
       "v_sub_f32 %[d], %[ep], %[ec]\n\t"                                                 \
       "s_waitcnt lgkmcnt(0)\n\t"                                                         \
       "v_fma_f32 %[e2], -v60, %[tc], %[sc]\n\t"                                          \
@@ -143,8 +137,9 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
       "v_fma_f32 %[ep], -%[ep], v61, v62\n\t"                                            \
       "v_max_f32 %[ep], %[ep], v63\n\t"                                                  \
       "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"                                              \
-      "s_andn2_b64 exec, exec, vcc\n\t"                                                  \
-      "s_cbranch_execz " L9 "f\n\t"                                                           \
+      "s_andn2_b64 exec, exec, vcc\n\t"
+// second half: the pending beam's tangent in A.x = v60, its record in B = v[56:59]; fetches A, moves bp by two records
+#define SWEEP_MERGE_HALF2(OFF2, STEP2)                                                   \
       "v_fma_f32 %[ep], -v60, %[tp], %[sp]\n\t"                                          \
       "v_sub_f32 %[d], %[ep], %[e2]\n\t"                                                 \
       "s_waitcnt lgkmcnt(0)\n\t"                                                         \
@@ -159,82 +154,40 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
       "v_fma_f32 %[ep], -%[ep], v57, v58\n\t"                                            \
       "v_max_f32 %[ep], %[ep], v59\n\t"                                                  \
       "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"                                              \
-      "s_and_b64 exec, exec, vcc\n\t"                                                    \
-      "s_cbranch_execnz " L1 "b\n"                                                             \
-      L9 ":\n\t"                                                                           \
-      "s_mov_b64 exec, %[odd]\n\t"                                                       \
-      "v_mov_b32 %[t0], v60\n\t"                                                         \
-      STEP1 "\n\t"                                                                       \
-      "s_andn2_b64 exec, %[ent], %[odd]\n\t"                                             \
-      "v_mov_b32 %[t0], v56\n\t"                                                         \
-      "s_mov_b64 exec, %[sav]\n\t"                                                       \
-      "s_waitcnt lgkmcnt(0)"
-#else
-#define SWEEP_MERGE_ASM_TEXT(OFF0, OFF1, OFF2, STEP2, STEP1, L1, L9)                              \
+      "s_and_b64 exec, exec, vcc\n\t"
+#define SWEEP_MERGE_ASM_TEXT(OFFP, OFF0, OFF1, OFF2, STEP2, STEP1, L1, L9)                \
       "s_mov_b64 %[sav], exec\n\t"                                                       \
       "s_mov_b64 %[odd], 0\n\t"                                                          \
-      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"                                                   \
-      "s_and_b64 exec, exec, vcc\n\t"                                                    \
-      "s_mov_b64 %[ent], exec\n\t"                                                       \
-      "s_cbranch_execz " L9 "f\n\t"                                                           \
+      "ds_read_b32 v56, %[bp]" OFFP "\n\t"                                               \
       "ds_read_b128 v[60:63], %[bp]" OFF0 "\n\t"                                         \
-      "v_mov_b32 v56, %[t0]\n"                                                            \
-      L1 ":\n\t"                                                                           \
-      "v_fma_f32 %[ep], -v56, %[tp], %[sp]\n\t"                                          \
-      "v_sub_f32 %[d], %[ep], %[ec]\n\t"                                                 \
-      "v_rcp_f32 %[d], %[d]\n\t"                                                         \
       "s_waitcnt lgkmcnt(0)\n\t"                                                         \
-      "ds_read_b128 v[56:59], %[bp]" OFF1 "\n\t"                                         \
-      "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"                                       \
-      "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"                                        \
-      "v_fma_f32 %[ep], -%[ep], v61, v62\n\t"                                            \
-      "v_max_f32 %[ep], %[ep], v63\n\t"                                                  \
-      "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"                                              \
-      "v_fma_f32 %[ec], -v60, %[tc], %[sc]\n\t"                                          \
-      "v_cmp_le_f32 vcc, 0, %[ec]\n\t"                                                   \
-      "s_andn2_b64 vcc, exec, vcc\n\t"                                                   \
-      "s_or_b64 %[odd], %[odd], vcc\n\t"                                                 \
-      "s_andn2_b64 exec, exec, vcc\n\t"                                                  \
-      "s_cbranch_execz " L9 "f\n\t"                                                           \
-      "v_fma_f32 %[ep], -v60, %[tp], %[sp]\n\t"                                          \
-      "v_sub_f32 %[d], %[ep], %[ec]\n\t"                                                 \
-      "v_rcp_f32 %[d], %[d]\n\t"                                                         \
-      "s_waitcnt lgkmcnt(0)\n\t"                                                         \
-      "ds_read_b128 v[60:63], %[bp]" OFF2 "\n\t"                                         \
-      STEP2 "\n\t"                                                                       \
-      "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"                                       \
-      "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"                                        \
-      "v_fma_f32 %[ep], -%[ep], v57, v58\n\t"                                            \
-      "v_max_f32 %[ep], %[ep], v59\n\t"                                                  \
-      "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"                                              \
       "v_fma_f32 %[ec], -v56, %[tc], %[sc]\n\t"                                          \
       "v_cmp_le_f32 vcc, 0, %[ec]\n\t"                                                   \
       "s_and_b64 exec, exec, vcc\n\t"                                                    \
-      "s_cbranch_execnz " L1 "b\n"                                                             \
-      L9 ":\n\t"                                                                           \
+      "s_cbranch_execz " L9 "f\n"                                                         \
+      L1 ":\n\t"                                                                         \
+      SWEEP_MERGE_HALF1("v56", OFF1)                                                     \
+      "s_cbranch_execz " L9 "f\n\t"                                                      \
+      SWEEP_MERGE_HALF2(OFF2, STEP2)                                                     \
+      "s_cbranch_execnz " L1 "b\n"                                                        \
+      L9 ":\n\t"                                                                         \
       "s_mov_b64 exec, %[odd]\n\t"                                                       \
-      "v_mov_b32 %[t0], v60\n\t"                                                         \
       STEP1 "\n\t"                                                                       \
-      "s_andn2_b64 exec, %[ent], %[odd]\n\t"                                             \
-      "v_mov_b32 %[t0], v56\n\t"                                                         \
       "s_mov_b64 exec, %[sav]\n\t"                                                       \
       "s_waitcnt lgkmcnt(0)"
-#endif
-// (ONE statement for both sides, a scalar branch between two copies of the loop: two statements under `if (side)` made
-//  the compiler copy every in / out operand before and after them -- seven moves per walk step)
-__device__ __forceinline__ void sweep_merge_asm(int side, float& t0, float& acc, unsigned& bp, float e_cur,
-                                                float sp, float tp, float sc, float tc, float dts) {
-  float ep, d, e2;
-  unsigned long long sav, odd, ent;
+__device__ __forceinline__ void sweep_merge_asm(int side, float& acc, unsigned& bp, float sp, float tp, float sc, float tc,
+                                                float dts) {
+  float ep, d, ec, e2;
+  unsigned long long sav, odd;
   asm volatile("s_cmp_lg_u32 %[side], 0\n\t"
                "s_cbranch_scc1 5f\n\t"
-               SWEEP_MERGE_ASM_TEXT("", " offset:16", " offset:32", "v_add_u32 %[bp], 32, %[bp]", "v_add_u32 %[bp], 16, %[bp]", "1", "9") "\n\t"
+               SWEEP_MERGE_ASM_TEXT(" offset:48", " offset:64", " offset:80", " offset:96", "v_add_u32 %[bp], 32, %[bp]", "v_add_u32 %[bp], 16, %[bp]", "1", "9") "\n\t"
                "s_branch 6f\n"
                "5:\n\t"
-               SWEEP_MERGE_ASM_TEXT(" offset:32", " offset:16", "", "v_subrev_u32 %[bp], 32, %[bp]", "v_subrev_u32 %[bp], 16, %[bp]", "2", "8") "\n"
+               SWEEP_MERGE_ASM_TEXT(" offset:48", " offset:32", " offset:16", "", "v_subrev_u32 %[bp], 32, %[bp]", "v_subrev_u32 %[bp], 16, %[bp]", "2", "8") "\n"
                "6:"
-               : [t0] "+v"(t0), [acc] "+v"(acc), [bp] "+v"(bp), [ec] "+v"(e_cur),
-                 [ep] "=&v"(ep), [d] "=&v"(d), [e2] "=&v"(e2), [sav] "=&s"(sav), [odd] "=&s"(odd), [ent] "=&s"(ent)
+               : [acc] "+v"(acc), [bp] "+v"(bp),
+                 [ep] "=&v"(ep), [d] "=&v"(d), [ec] "=&v"(ec), [e2] "=&v"(e2), [sav] "=&s"(sav), [odd] "=&s"(odd)
                : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts), [side] "s"(side)
                : "vcc", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
@@ -436,10 +389,10 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   // (record b carries the tangent of the NEXT beam of its side in .x: the decision to leave the merge loop never waits
   //  for the record that has just been requested)
   // (by its LDS byte address: the merge loop of the main kernels is assembly, sweep_merge_asm above)
-  // (the assembly loop walks the - side's records downward through immediate offsets, which cannot be negative: on that
-  //  side every table address is kept 32 bytes low -- sweep_merge_asm -- and (bp - sb_off) >> 4 is still the beam)
+  // (the assembly loop walks the table through immediate offsets, which cannot be negative: every table address is
+  //  kept low by the side's bias -- sweep_merge_asm -- and (bp - sb_off) >> 4 is still the beam)
   const unsigned sb_off = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)sbeam -
-                          ((!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX && side) ? 32u : 0u);
+                          ((!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) ? (side ? SWEEP_BIAS1 : SWEEP_BIAS0) : 0u);
   unsigned bp = sb_off + (unsigned)(ptr * 16);
   const unsigned bp_end = sb_off + (unsigned)(pend * 16);
   const int pstep16 = pstep * 16;
@@ -459,7 +412,9 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   }
   // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the next triangle.
   // Returns true when the walk is over (all beams resolved, stop distance, map border, failure).
-  const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc, const int step) -> bool {
+  // (EXITS: the three tests that end a walk normally are made every SECOND step -- a step too many finds its beams
+  //  beyond the stop distance, at r_max, or none; the test for a NaN / a horizon stays in every step)
+  const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc, const int step, auto EXITS) -> bool {
     // the third node of the triangle across (A, Bn): its height load is in flight while the beams are resolved
     const int Nk = (int)((unsigned)A.P + (unsigned)Bn.P - (unsigned)C);
     const int nj = __builtin_amdgcn_sbfe(Nk, 0, 16), ni = (Nk - nj) >> 16;
@@ -473,7 +428,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
       //  loop is rotated: e_cur of the NEXT beam is formed at the end of the body, one compare decides)
       float e_cur = fmaf(-tcur, tc, sc);
       if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-        sweep_merge_asm(side, tcur, acc, bp, e_cur, sp, tp, sc, tc, dts);   // (side: wave-uniform)
+        sweep_merge_asm(side, acc, bp, sp, tp, sc, tc, dts);   // (side: wave-uniform)
       } else {
         // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes
         // sign: <= 0 at prev, >= 0 at cur); then on to the next beam of the table
@@ -501,12 +456,14 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
         }
       }
     }
-    if (bp == bp_end) return true;
-    if (sc > s_stop) return true;  // every beam left misses inside r_max (tail below)
-    if (step > max_steps) {   // (step: the wave's own count -- every lane still walking has taken as many)
-      SWEEP_NOTE(11);
-      ok = false;   // (the node found last has a height: the test after the loop hands the particle over)
-      return true;
+    if (decltype(EXITS)::value) {
+      if (bp == bp_end) return true;
+      if (sc > s_stop) return true;  // every beam left misses inside r_max (tail below)
+      if (step > max_steps) {   // (step: the wave's own count -- every lane still walking has taken as many)
+        SWEEP_NOTE(11);
+        ok = false;   // (the node found last has a height: the test after the loop hands the particle over)
+        return true;
+      }
     }
     const float fi = (float)ni, fj = (float)nj;
     const float dN = fmaf(pu, fi, fmaf(pv, fj, fmaf(pz, hN, p0)));
@@ -540,8 +497,8 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     return false;
   };
   for (int step = 1;; step += 2) {
-    if (walk_step(s_prev, t_prev, s_cur, t_cur, step)) break;
-    if (walk_step(s_cur, t_cur, s_prev, t_prev, step + 1)) break;
+    if (walk_step(s_prev, t_prev, s_cur, t_cur, step, std::true_type())) break;
+    if (walk_step(s_cur, t_cur, s_prev, t_prev, step + 1, std::false_type())) break;
   }
   if (!ok) {
     // a NaN height: the slice ends at the map border -- final if it cannot come back (the beams left get r_max through
@@ -1063,10 +1020,10 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   const int max_steps = (int)(6.f * (s_stop + 4.f * res) * inv_res) + 64;  // (triangles may be much smaller than a cell)
   int step = 0;
   // (the table is walked by LDS byte address: the merge loop of the main kernel is sweep_merge_asm, as in sweep_side)
-  // (the assembly loop walks the - side's records downward through immediate offsets, which cannot be negative: on that
-  //  side every table address is kept 32 bytes low -- sweep_merge_asm -- and (bp - sb_off) >> 4 is still the beam)
+  // (the assembly loop walks the table through immediate offsets, which cannot be negative: every table address is
+  //  kept low by the side's bias -- sweep_merge_asm -- and (bp - sb_off) >> 4 is still the beam)
   const unsigned sb_off = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)sbeam -
-                          ((!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX && side) ? 32u : 0u);
+                          ((!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) ? (side ? SWEEP_BIAS1 : SWEEP_BIAS0) : 0u);
   unsigned bp = sb_off + (unsigned)(ptr * 16);
   const unsigned bp_end = sb_off + (unsigned)(pend * 16);
   const int pstep16 = pstep * 16;
@@ -1092,7 +1049,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const float dts = t_cur - t_prev;
     float e_cur = fmaf(-tcur, t_cur, s_cur);
     if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-      sweep_merge_asm(side, tcur, acc, bp, e_cur, s_prev, t_prev, s_cur, t_cur, dts);   // (side: wave-uniform)
+      sweep_merge_asm(side, acc, bp, s_prev, t_prev, s_cur, t_cur, dts);   // (side: wave-uniform)
     } else {
       while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
         const float e_prev = fmaf(-tcur, t_prev, s_prev);
@@ -1190,14 +1147,15 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
     if (work) exp_row = a.exp_out + (size_t)(i - a.exp_first) * a.n_beams;
   }
   float acc = 0.f;
+  const float4* sside = sbeam + (side ? 0 : 2);   // (this side's records by beam index: k_mbes_sweep's table layout)
   if (work) {
     const MbesPose P = a.pose[i];
     if (SURF == 5)
-      ok = sweep_side_tin<EXPECT_ONLY, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
+      ok = sweep_side_tin<EXPECT_ONLY, SUB>(a, P, sside, stail, side, sub, nsub, exp_row, acc);
     else if (SURF == 0)
-      ok = sweep_side_grid<EXPECT_ONLY, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
+      ok = sweep_side_grid<EXPECT_ONLY, SUB>(a, P, sside, stail, side, sub, nsub, exp_row, acc);
     else
-      ok = sweep_side<(SURF == 3 ? 3 : 2), EXPECT_ONLY, SUB>(a, P, sbeam, stail, side, sub, nsub, exp_row, acc);
+      ok = sweep_side<(SURF == 3 ? 3 : 2), EXPECT_ONLY, SUB>(a, P, sside, stail, side, sub, nsub, exp_row, acc);
   }
   // the lanes of a particle agree on its fate: every lane but the first leaves its verdict and sum in LDS
   if (combo) {
@@ -1256,14 +1214,20 @@ __global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, SU
 #elif SWEEP_PRIO == 4
   if (blockIdx.x * 8 >= gridDim.x * 7) __builtin_amdgcn_s_setprio(1);
 #endif
-  float4* sbeam = (float4*)sweep_lds + 1;  // records -1 and n_beams exist (read, never used)
-  float* stail = (float*)(sbeam + a.n_beams + 1);
+  // the table in LDS: four spare records | -1 (sentinel) | side 1's beams 0 .. b_split - 1 | a record in front of either
+  // side's first beam (its .x: that beam's tangent, read by sweep_merge_asm) | side 0's beams | sentinel | tail sums.
+  // Side 1 indexes it by beam from sbeam, side 0 from sbeam + 2 (sweep_lane); the merge statement reads up to three
+  // records beyond either end (never used)
+  float4* sbeam = (float4*)sweep_lds + 4;
+  float* stail = (float*)(sbeam + a.n_beams + 3);
   for (int b = threadIdx.x; b < a.n_beams; b += blockDim.x) {
-    sbeam[b] = a.sweep_beams[b];
+    sbeam[b + (b >= a.b_split ? 2 : 0)] = a.sweep_beams[b];
     stail[b] = SUB ? a.sweep_tail_run[b] : a.sweep_tail[b];   // (SUB: tail sums that end with the lane's own run)
   }
   if (threadIdx.x < 4) stail[a.n_beams + threadIdx.x] = a.sweep_tan0[threadIdx.x];   // (first / second tangent of either side)
-  if (threadIdx.x == 0) sbeam[-1] = sbeam[a.n_beams] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);  // "never reached"
+  if (threadIdx.x == 0) sbeam[-1] = sbeam[a.n_beams + 2] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);  // "never reached"
+  if (threadIdx.x == 1) sbeam[a.b_split] = make_float4(a.sweep_tan0[1], 0.f, 0.f, 0.f);
+  if (threadIdx.x == 2) sbeam[a.b_split + 1] = make_float4(a.sweep_tan0[0], 0.f, 0.f, 0.f);
   __syncthreads();
   // particles per workgroup: its waves divided by the (side, run) combinations of a particle; one lane per
   // (particle, side, run)
