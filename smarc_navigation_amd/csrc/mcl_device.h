@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define MCL_WAVE 64
 #define MCL_PI 3.14159265358979323846
@@ -10,11 +11,65 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 // ---------------------------------------------------------------- wave / block reductions
+// Through the data-parallel-primitive lane moves (row_shr 1 / 2 / 4 / 8 inside rows of 16 lanes, then row_bcast 15 and
+// 31 across rows) a wave's inclusive scan takes six moves and six additions and no LDS round trip; a __shfl of a 64-bit
+// value is two ds_bpermute and ~100 cycles of latency per step, and the short kernels of the resampling chain (tile
+// scans, 13 moment sums) spent microseconds there.  Lanes without a source add 0.
+template <int CTRL, int ROW_MASK, class T>
+__device__ __forceinline__ T dpp_move(T v) {
+  static_assert(sizeof(T) == 8 || sizeof(T) == 4, "32- or 64-bit values");
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int w[2]; } a, r;
+    a.t = v;
+    r.w[0] = __builtin_amdgcn_update_dpp(0, a.w[0], CTRL, ROW_MASK, 0xf, false);
+    r.w[1] = __builtin_amdgcn_update_dpp(0, a.w[1], CTRL, ROW_MASK, 0xf, false);
+    return r.t;
+  } else {
+    union { T t; int w; } a, r;
+    a.t = v;
+    r.w = __builtin_amdgcn_update_dpp(0, a.w, CTRL, ROW_MASK, 0xf, false);
+    return r.t;
+  }
+}
+template <class T>
+__device__ __forceinline__ T readlane63(T v) {
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int w[2]; } a, r;
+    a.t = v;
+    r.w[0] = __builtin_amdgcn_readlane(a.w[0], 63);
+    r.w[1] = __builtin_amdgcn_readlane(a.w[1], 63);
+    return r.t;
+  } else {
+    union { T t; int w; } a, r;
+    a.t = v;
+    r.w = __builtin_amdgcn_readlane(a.w, 63);
+    return r.t;
+  }
+}
+// inclusive scan across the 64 lanes of a wave (additions in a fixed order)
+template <class T>
+__device__ __forceinline__ T wave_scan_incl_dpp(T v) {
+  v += dpp_move<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_move<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_move<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_move<0x118, 0xf>(v);   // row_shr:8   -> prefix sums inside every row of 16
+  v += dpp_move<0x142, 0xa>(v);   // row_bcast:15: the sums of rows 0 and 2 into rows 1 and 3
+  v += dpp_move<0x143, 0xc>(v);   // row_bcast:31: the sum of rows 0 - 1 into rows 2 and 3
+  return v;
+}
+// the wave's sum in EVERY lane; the additions in the scan's order (not wave_sum's tree: use one or the other where
+// the last bit of a floating-point sum is compared)
+template <class T>
+__device__ __forceinline__ T wave_sum_dpp(T v) { return readlane63(wave_scan_incl_dpp(v)); }
 template <class T>
 __device__ __forceinline__ T wave_sum(T v) {
+  if constexpr (std::is_integral<T>::value) {
+    return wave_sum_dpp(v);   // (integers: any order gives the same sum)
+  } else {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, MCL_WAVE);
-  return v;  // valid in lane 0
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, MCL_WAVE);
+    return v;  // valid in lane 0
+  }
 }
 template <class T>
 __device__ __forceinline__ T wave_max(T v) {
@@ -37,13 +92,17 @@ __device__ __forceinline__ T wave_min(T v) {
 // inclusive scan across the 64 lanes of a wave
 template <class T>
 __device__ __forceinline__ T wave_scan_incl(T v) {
-  const int lane = threadIdx.x & 63;
+  if constexpr (std::is_integral<T>::value) {
+    return wave_scan_incl_dpp(v);
+  } else {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    T w = __shfl_up(v, o, MCL_WAVE);
-    if (lane >= o) v += w;
+    for (int o = 1; o < 64; o <<= 1) {
+      T w = __shfl_up(v, o, MCL_WAVE);
+      if (lane >= o) v += w;
+    }
+    return v;
   }
-  return v;
 }
 
 // Block sum for blockDim.x <= 1024; result valid in thread 0.  `sh` must hold 16 T.

@@ -87,11 +87,7 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_quantise_tiles(QuantArgs a) {
 // ------------------------------------------------------------------ decoupled look-back (u32 sums)
 #define DESC_AGG 1ull
 #define DESC_PREFIX 2ull
-__device__ __forceinline__ u32 wave_sum_all(u32 v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, MCL_WAVE);
-  return v;
-}
+__device__ __forceinline__ u32 wave_sum_all(u32 v) { return wave_sum_dpp(v); }
 // Called by ONE full wave.  Publishes this tile's aggregate, returns the sum of all earlier tiles.
 __device__ __forceinline__ u32 scan_lookback(u64* desc, long long tile, u32 agg, u32 epoch) {
   const int lane = threadIdx.x & 63;
@@ -494,7 +490,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int c = 0; c < MOM_COUNT; ++c) {
-    const double s = wave_sum(acc[c]);
+    const double s = wave_sum_dpp(acc[c]);   // (13 shuffle trees through LDS were half of this kernel's 9 us tail)
     if (lane == 0) red[c][w] = s;
   }
   __syncthreads();
@@ -513,12 +509,12 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
   if (!last_sh) return;
   // ---- the last block adds the partials in a fixed order (the result does not depend on which block is last):
   // wave c takes component c, lane l the blocks l, l + 64, ...; then the fixed shuffle tree
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
+  // (no acquire fence -- an L1 invalidate, ~1.7 us --: the partials were stored write-through and drained before
+  //  their block's ticket, and are read here by agent-scope loads, issued after the ticket's value has come back)
   if (w < MOM_COUNT) {
     double s = 0.0;
     for (unsigned b = lane; b < gridDim.x; b += 64) s += load_agent(&a.part[(size_t)w * gridDim.x + b]);
-    s = wave_sum(s);
+    s = wave_sum_dpp(s);
     if (lane == 0) a.sums_out[w] = s;
   }
   if (threadIdx.x < 3) a.sums_out[MOM_COUNT + threadIdx.x] = shift[threadIdx.x];
