@@ -243,6 +243,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.b_split = 0;
   a.sweep_nvalid = 0;
   a.sweep_nsub = 1;
+  a.sweep_noclamp = 0;
   a.sweep_tan0 = nullptr;
   a.sweep_tail_run = nullptr;
   a.sweep_c2z_min = 2.f;
@@ -413,6 +414,31 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   if (sweep) {
     const int nsub = sweep_lanes_per_side(h, with_ranges, B);
     a.sweep_nsub = nsub;
+    // May the merge loop skip the clamp of the expected range to r_max?  Straight after a predict every particle holds
+    // the odometry's depth, roll and pitch; if the map frame is not tilted against the odometry frame the sensor's depth
+    // and the vertical component of every beam are then the same for the whole cloud (yaw turns about the vertical),
+    // and a beam cannot travel further than down to the map's lowest point: if that is inside r_max for every valid beam
+    // of the ping, max(residual, (z - r_max) w) is the residual.
+    a.sweep_noclamp = 0;
+    {
+      static const bool allow = !(getenv("MCL_SWEEP_NOCLAMP") && atoi(getenv("MCL_SWEEP_NOCLAMP")) == 0);
+      if (allow && with_ranges && h->uni_valid && a.m2o[8] == 0.0 && a.m2o[9] == 0.0 && (int)h->ranges_host.size() == B) {
+        const double roll = h->uni_val[1], pitch = h->uni_val[2], k = a.m2o[10];
+        const double zr[3] = {-std::sin(pitch), std::cos(pitch) * std::sin(roll), std::cos(pitch) * std::cos(roll)};
+        const double c1z = k * (zr[0] * a.off_R[1] + zr[1] * a.off_R[4] + zr[2] * a.off_R[7]);
+        const double c2z = k * (zr[0] * a.off_R[2] + zr[1] * a.off_R[5] + zr[2] * a.off_R[8]);
+        const double oz = a.m2o[11] + k * (h->uni_val[0] + zr[0] * a.off_t[0] + zr[1] * a.off_t[1] + zr[2] * a.off_t[2]);
+        bool inside = true;
+        for (int b = 0; b < B && inside; ++b) {
+          if (!(h->ranges_host[b] > 0.f)) continue;
+          const double ang = (double)h->beam_cache[b];
+          const double dz = std::sin(ang) * c1z - std::cos(ang) * c2z;   // vertical component of the beam's direction
+          const double far = dz < -1e-3 ? ((double)a.zmin_map - oz) / dz : -1.0;
+          inside = far >= 0.0 && far <= r_max * (1.0 - 1e-3);
+        }
+        a.sweep_noclamp = inside ? 1 : 0;
+      }
+    }
     const int sthreads = nsub == 4 ? 512 : SWEEP_THREADS;
     const int per_block = sthreads / 64 / (2 * nsub) * 64;
     // (expected ranges of a few particles: only their lanes are launched)
@@ -460,7 +486,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       int cnt = 0;
       (void)hipMemcpyAsync(&cnt, a.defer_count, sizeof(int), hipMemcpyDeviceToHost, h->stream);
       (void)hipStreamSynchronize(h->stream);
-      fprintf(stderr, "[mbes] sweep handed over %d of %lld particles\n", cnt, (long long)h->n);
+      fprintf(stderr, "[mbes] sweep handed over %d of %lld particles (clamp to r_max %s)\n", cnt, (long long)h->n,
+              a.sweep_noclamp ? "proved idle: skipped" : "kept");
 #ifdef SWEEP_REASONS
       // why (mcl_sweep.h: SWEEP_FAIL / SWEEP_NOTE codes, per particle SIDE): -DSWEEP_REASONS builds only
       unsigned why[16];

@@ -123,6 +123,7 @@ struct MbesArgs {
   int b_split;                // first beam with a >= 0: beams [b_split, B) sweep outward on the + side, [0, b_split) on the - side
   int sweep_nvalid;           // beams with a valid measured range
   int sweep_nsub;             // lanes per particle side (1, 2 or 4: small clouds split a side's beams over several lanes)
+  int sweep_noclamp;          // 1: no beam of this ping can meet the seabed beyond r_max (proved on the host): the merge loop skips the clamp
   float sweep_c2z_min;        // cos of the largest fan-plane tilt the sweep accepts (terrain slope bound, mcl_host_update.h)
   float sweep_slope;          // the map's steepest slope |grad h| (second pass: may a slice end at the map border?)
   u32* defer_idx;             // particles the sweep hands over: the visiting order (perm) of the cast kernels that follow it

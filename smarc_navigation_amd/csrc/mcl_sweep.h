@@ -122,7 +122,7 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
 #define SWEEP_BIAS1 32u
 #define SWEEP_PREV_OFF 48u   // ... and the record one place back towards the nadir is at bp + 48 on either side
 // first half: the pending beam's tangent in TAN, its record in A = v[60:63] (.x: the next beam's tangent); fetches B
-#define SWEEP_MERGE_HALF1(TAN, OFF1)                                                     \
+#define SWEEP_MERGE_HALF1(TAN, OFF1, CLAMP)                                                     \
       "v_fma_f32 %[ep], -" TAN ", %[tp], %[sp]\n\t"                                      \
       "v_sub_f32 %[d], %[ep], %[ec]\n\t"                                                 \
       "s_waitcnt lgkmcnt(0)\n\t"                                                         \
@@ -135,11 +135,11 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
       "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"                                       \
       "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"                                        \
       "v_fma_f32 %[ep], -%[ep], v61, v62\n\t"                                            \
-      "v_max_f32 %[ep], %[ep], v63\n\t"                                                  \
+      CLAMP("v_max_f32 %[ep], %[ep], v63\n\t")                                           \
       "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"                                              \
       "s_andn2_b64 exec, exec, vcc\n\t"
 // second half: the pending beam's tangent in A.x = v60, its record in B = v[56:59]; fetches A, moves bp by two records
-#define SWEEP_MERGE_HALF2(OFF2, STEP2)                                                   \
+#define SWEEP_MERGE_HALF2(OFF2, STEP2, CLAMP)                                                   \
       "v_fma_f32 %[ep], -v60, %[tp], %[sp]\n\t"                                          \
       "v_sub_f32 %[d], %[ep], %[e2]\n\t"                                                 \
       "s_waitcnt lgkmcnt(0)\n\t"                                                         \
@@ -152,10 +152,12 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
       "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"                                       \
       "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"                                        \
       "v_fma_f32 %[ep], -%[ep], v57, v58\n\t"                                            \
-      "v_max_f32 %[ep], %[ep], v59\n\t"                                                  \
+      CLAMP("v_max_f32 %[ep], %[ep], v59\n\t")                                           \
       "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"                                              \
       "s_and_b64 exec, exec, vcc\n\t"
-#define SWEEP_MERGE_ASM_TEXT(OFFP, OFF0, OFF1, OFF2, STEP2, STEP1, L1, L9)                \
+#define SWEEP_CLAMP_ON(x) x
+#define SWEEP_CLAMP_OFF(x)
+#define SWEEP_MERGE_ASM_TEXT(OFFP, OFF0, OFF1, OFF2, STEP2, STEP1, L1, L9, CLAMP)                \
       "s_mov_b64 %[sav], exec\n\t"                                                       \
       "s_mov_b64 %[odd], 0\n\t"                                                          \
       "ds_read_b32 v56, %[bp]" OFFP "\n\t"                                               \
@@ -166,29 +168,46 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
       "s_and_b64 exec, exec, vcc\n\t"                                                    \
       "s_cbranch_execz " L9 "f\n"                                                         \
       L1 ":\n\t"                                                                         \
-      SWEEP_MERGE_HALF1("v56", OFF1)                                                     \
+      SWEEP_MERGE_HALF1("v56", OFF1, CLAMP)                                                     \
       "s_cbranch_execz " L9 "f\n\t"                                                      \
-      SWEEP_MERGE_HALF2(OFF2, STEP2)                                                     \
+      SWEEP_MERGE_HALF2(OFF2, STEP2, CLAMP)                                                     \
       "s_cbranch_execnz " L1 "b\n"                                                        \
       L9 ":\n\t"                                                                         \
       "s_mov_b64 exec, %[odd]\n\t"                                                       \
       STEP1 "\n\t"                                                                       \
       "s_mov_b64 exec, %[sav]\n\t"                                                       \
       "s_waitcnt lgkmcnt(0)"
-__device__ __forceinline__ void sweep_merge_asm(int side, float& acc, unsigned& bp, float sp, float tp, float sc, float tc,
+// sel = side + 2 * noclamp (wave-uniform).  noclamp: the host has proved for this launch that no beam can reach the seabed
+// beyond r_max (mcl_host_update.h: launch_mbes -- depth, roll and pitch are the odometry's on every particle and the
+// map has a lowest point), so max(residual, (z - r_max) w) is the residual: one instruction per beam less.
+#define SWEEP_MERGE_SIDE0(L1, L9, CLAMP) \
+  SWEEP_MERGE_ASM_TEXT(" offset:48", " offset:64", " offset:80", " offset:96", "v_add_u32 %[bp], 32, %[bp]", "v_add_u32 %[bp], 16, %[bp]", L1, L9, CLAMP)
+#define SWEEP_MERGE_SIDE1(L1, L9, CLAMP) \
+  SWEEP_MERGE_ASM_TEXT(" offset:48", " offset:32", " offset:16", "", "v_subrev_u32 %[bp], 32, %[bp]", "v_subrev_u32 %[bp], 16, %[bp]", L1, L9, CLAMP)
+__device__ __forceinline__ void sweep_merge_asm(int sel, float& acc, unsigned& bp, float sp, float tp, float sc, float tc,
                                                 float dts) {
   float ep, d, ec, e2;
   unsigned long long sav, odd;
-  asm volatile("s_cmp_lg_u32 %[side], 0\n\t"
-               "s_cbranch_scc1 5f\n\t"
-               SWEEP_MERGE_ASM_TEXT(" offset:48", " offset:64", " offset:80", " offset:96", "v_add_u32 %[bp], 32, %[bp]", "v_add_u32 %[bp], 16, %[bp]", "1", "9") "\n\t"
-               "s_branch 6f\n"
-               "5:\n\t"
-               SWEEP_MERGE_ASM_TEXT(" offset:48", " offset:32", " offset:16", "", "v_subrev_u32 %[bp], 32, %[bp]", "v_subrev_u32 %[bp], 16, %[bp]", "2", "8") "\n"
-               "6:"
+  asm volatile("s_cmp_lt_u32 %[sel], 2\n\t"
+               "s_cbranch_scc0 52f\n\t"
+               "s_cmp_lg_u32 %[sel], 0\n\t"
+               "s_cbranch_scc1 51f\n\t"
+               SWEEP_MERGE_SIDE0("11", "19", SWEEP_CLAMP_ON) "\n\t"
+               "s_branch 60f\n"
+               "51:\n\t"
+               SWEEP_MERGE_SIDE1("21", "29", SWEEP_CLAMP_ON) "\n\t"
+               "s_branch 60f\n"
+               "52:\n\t"
+               "s_cmp_lg_u32 %[sel], 2\n\t"
+               "s_cbranch_scc1 53f\n\t"
+               SWEEP_MERGE_SIDE0("31", "39", SWEEP_CLAMP_OFF) "\n\t"
+               "s_branch 60f\n"
+               "53:\n\t"
+               SWEEP_MERGE_SIDE1("41", "49", SWEEP_CLAMP_OFF) "\n"
+               "60:"
                : [acc] "+v"(acc), [bp] "+v"(bp),
                  [ep] "=&v"(ep), [d] "=&v"(d), [ec] "=&v"(ec), [e2] "=&v"(e2), [sav] "=&s"(sav), [odd] "=&s"(odd)
-               : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts), [side] "s"(side)
+               : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts), [sel] "s"(sel)
                : "vcc", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
@@ -395,6 +414,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
                           ((!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) ? (side ? SWEEP_BIAS1 : SWEEP_BIAS0) : 0u);
   unsigned bp = sb_off + (unsigned)(ptr * 16);
   const unsigned bp_end = sb_off + (unsigned)(pend * 16);
+  const int msel = side + 2 * a.sweep_noclamp;
   const int pstep16 = pstep * 16;
   float tcur = stail[a.n_beams + side];   // tan of the pending beam (side-signed)
   float tnext = stail[a.n_beams + 2 + side];  // ... and of the one after it (SWEEP_TAN_AHEAD 2)
@@ -428,7 +448,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
       //  loop is rotated: e_cur of the NEXT beam is formed at the end of the body, one compare decides)
       float e_cur = fmaf(-tcur, tc, sc);
       if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-        sweep_merge_asm(side, acc, bp, sp, tp, sc, tc, dts);   // (side: wave-uniform)
+        sweep_merge_asm(msel, acc, bp, sp, tp, sc, tc, dts);   // (msel = side + 2 noclamp: wave-uniform)
       } else {
         // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes
         // sign: <= 0 at prev, >= 0 at cur); then on to the next beam of the table
@@ -1026,6 +1046,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
                           ((!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) ? (side ? SWEEP_BIAS1 : SWEEP_BIAS0) : 0u);
   unsigned bp = sb_off + (unsigned)(ptr * 16);
   const unsigned bp_end = sb_off + (unsigned)(pend * 16);
+  const int msel = side + 2 * a.sweep_noclamp;
   const int pstep16 = pstep * 16;
   float tcur = stail[a.n_beams + side];
   float tnext = stail[a.n_beams + 2 + side];
@@ -1049,7 +1070,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const float dts = t_cur - t_prev;
     float e_cur = fmaf(-tcur, t_cur, s_cur);
     if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-      sweep_merge_asm(side, acc, bp, s_prev, t_prev, s_cur, t_cur, dts);   // (side: wave-uniform)
+      sweep_merge_asm(msel, acc, bp, s_prev, t_prev, s_cur, t_cur, dts);   // (msel = side + 2 noclamp: wave-uniform)
     } else {
       while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
         const float e_prev = fmaf(-tcur, t_prev, s_prev);
