@@ -33,4 +33,5 @@ PY
   grep '^{"metric"' $S/bench_$m.log | tail -1 > profiles/${ROUND}_${m}_bench_only_main.json
 done
 cp $S/traffic.json profiles/${ROUND}_traffic.json
+bash tools/isa.sh /tmp/isa > /dev/null 2>&1 && grep -v 'rocprim::' /tmp/isa/resources.tsv > profiles/${ROUND}_isa_resources.tsv   # (the library's own kernels)
 ls -la profiles/${ROUND}_*
