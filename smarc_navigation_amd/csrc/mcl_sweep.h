@@ -992,8 +992,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     r.t = c ? x.t : y.t;
     return r;
   };
-  auto node = [&](u32 vid) {
-    const float4 v = ma.tin_vert[vid];
+  auto node_of = [&](u32 vid, const float4 v) {
     // v - O with O = Of + dO split once per lane: the difference of two fp32 numbers a swath apart is exact (or off by
     // one ulp of a <= 100 m difference), the sub-ulp rest of the sensor position follows -- no fp64 per node
     const float rx = (v.x - Oxf) - dOx, ry = (v.y - Oyf) - dOy, rz = v.z - oz;
@@ -1004,13 +1003,14 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     N.t = fmaf(tu, rx, fmaf(tv, ry, tz * rz));
     return N;
   };
+  auto node = [&](u32 vid) { return node_of(vid, ma.tin_vert[vid]); };
   TinNode A, Bn;
-  u32 nb;  // the triangle across the current exit edge
+  u32 nb, opv;  // the triangle across the current exit edge, and its vertex that is not on that edge
   float s_prev, t_prev, s_cur, t_cur;
   {
-    const uint4 tv3 = ma.tin_tri[2 * (size_t)T], tn3 = ma.tin_tri[2 * (size_t)T + 1];
+    const uint4 tv3 = ma.tin_tri[3 * (size_t)T], tn3 = ma.tin_tri[3 * (size_t)T + 1], to3 = ma.tin_tri[3 * (size_t)T + 2];
     const TinNode N0 = node(tv3.x), N1 = node(tv3.y), N2 = node(tv3.z);
-    const bool p0b = N0.d > 0.f, p1b = N1.d > 0.f, p2b = N2.d > 0.f;
+    const bool p0b = __float_as_int(N0.d) >= 0, p1b = __float_as_int(N1.d) >= 0, p2b = __float_as_int(N2.d) >= 0;   // (sides of the plane by the sign bit, like the walk)
     if (p0b == p1b && p1b == p2b) return false;
     const int L = (p0b != p1b && p0b != p2b) ? 0 : ((p1b != p0b && p1b != p2b) ? 1 : 2);
     // local vertices L, L+1, L+2; the plane crosses edge L (vL, vL+1) and edge L+2 (vL+2, vL)
@@ -1019,16 +1019,19 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const TinNode NN = sel(L == 0, N2, sel(L == 1, N0, N1));  // vL+2
     const u32 nbM = L == 0 ? tn3.x : (L == 1 ? tn3.y : tn3.z);  // across edge L
     const u32 nbN = L == 0 ? tn3.z : (L == 1 ? tn3.x : tn3.y);  // across edge L+2
+    const u32 opM = L == 0 ? to3.x : (L == 1 ? to3.y : to3.z);  // ... and the neighbours' vertices off those edges
+    const u32 opN = L == 0 ? to3.z : (L == 1 ? to3.x : to3.y);
     const float lm = NL.d * fast_rcp(NL.d - NM.d), ln = NL.d * fast_rcp(NL.d - NN.d);
     const float sm = fmaf(lm, NM.s - NL.s, NL.s), tm = fmaf(lm, NM.t - NL.t, NL.t);
     const float sn = fmaf(ln, NN.s - NL.s, NL.s), tn = fmaf(ln, NN.t - NL.t, NL.t);
     if (!(sm != sn)) return false;
     const bool far_m = sm > sn;
     const TinNode NF = sel(far_m, NM, NN);
-    const bool pl = NL.d > 0.f;
-    A = sel(pl, NF, NL);   // A: d <= 0, Bn: d > 0
+    const bool pl = __float_as_int(NL.d) >= 0;
+    A = sel(pl, NF, NL);   // (A, Bn: plane functions of opposite sign bits; along the walk A is the vertex found last)
     Bn = sel(pl, NL, NF);
     nb = far_m ? nbM : nbN;
+    opv = far_m ? opM : opN;
     s_cur = far_m ? sm : sn;
     t_cur = far_m ? tm : tn;
     s_prev = far_m ? sn : sm;
@@ -1038,7 +1041,6 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   float acc = 0.f;
   bool ok = true;
   const int max_steps = (int)(6.f * (s_stop + 4.f * res) * inv_res) + 64;  // (triangles may be much smaller than a cell)
-  int step = 0;
   // (the table is walked by LDS byte address: the merge loop of the main kernel is sweep_merge_asm, as in sweep_side)
   // (the assembly loop walks the table through immediate offsets, which cannot be negative: every table address is
   //  kept low by the side's bias -- sweep_merge_asm -- and (bp - sb_off) >> 4 is still the beam)
@@ -1062,20 +1064,28 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     bm.z = r.z;
     bm.w = r.w;
   }
-  for (;;) {
-    // the neighbour's record is in flight while the beams are resolved
+  // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the neighbour.  The new
+  // vertex of the slice takes the place of the one before last and the CALLER swaps the roles (the loop is unrolled by
+  // two).  Returns true when the walk is over.  EXITS: as in sweep_side, the tests that end a walk normally run every
+  // second step; the step count is the wave's.
+  const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc, const int step, auto EXITS) -> bool {
+    // the neighbour's record AND its vertex off the shared edge (known from the record of the triangle the walk is in:
+    // its third word) are in flight while the beams are resolved -- until round 4 the vertex was loaded after the
+    // record had arrived, an exposed memory latency per step
     const bool border = nb >= 0xfffffff0u;
     const size_t tq = border ? 0 : (size_t)nb;
-    const uint4 tv3 = ma.tin_tri[2 * tq], tn3 = ma.tin_tri[2 * tq + 1];
-    const float dts = t_cur - t_prev;
-    float e_cur = fmaf(-tcur, t_cur, s_cur);
+    const uint4 tv3 = ma.tin_tri[3 * tq], tn3 = ma.tin_tri[3 * tq + 1], to3 = ma.tin_tri[3 * tq + 2];
+    const u32 vidN = border ? 0u : opv;
+    const float4 vN = ma.tin_vert[vidN];
+    const float dts = tc - tp;
     if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-      sweep_merge_asm(msel, acc, bp, s_prev, t_prev, s_cur, t_cur, dts);   // (msel = side + 2 noclamp: wave-uniform)
+      sweep_merge_asm(msel, acc, bp, sp, tp, sc, tc, dts);   // (msel = side + 2 noclamp: wave-uniform)
     } else {
+      float e_cur = fmaf(-tcur, tc, sc);
       while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
-        const float e_prev = fmaf(-tcur, t_prev, s_prev);
+        const float e_prev = fmaf(-tcur, tp, sp);
         const float lam = mul_clamp01(e_prev, fast_rcp(e_prev - e_cur));
-        const float tau = fmaf(lam, dts, t_prev);
+        const float tau = fmaf(lam, dts, tp);
         if (EXPECT_ONLY) {
           exp_row[(int)(bp - sb_off) >> 4] = fminf(tau * bm.y, a.r_max);
         } else {
@@ -1090,45 +1100,60 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
         bm.y = r.y;
         bm.z = r.z;
         bm.w = r.w;
-        e_cur = fmaf(-tcur, t_cur, s_cur);
+        e_cur = fmaf(-tcur, tc, sc);
       }
     }
-    if (bp == bp_end) break;
-    if (s_cur > s_stop) break;
+    if (decltype(EXITS)::value) {
+      if (bp == bp_end) return true;
+      if (sc > s_stop) return true;
+    }
     if (border) {
       // the slice runs off the mesh.  Through the map's outer border: final if it cannot come back (same bound as in
       // sweep_side's second pass); through a hole or a ragged outline: not for the sweep
       const float sb = fast_sqrt(fmaxf(1.f - c2z * c2z, 0.f));
       const float lhs = sb * (a.sweep_slope + sb), rhs = 0.9f * (c2z - a.sweep_slope * sb);
       ok = (nb != 0xffffffffu) & (lhs < rhs * fabsf(nb == 0xfffffff0u ? P.c1[0] : P.c1[1]));
-      break;  // (ok: the beams left get r_max through the tail below)
+      return true;  // (ok: the beams left get r_max through the tail below)
     }
-    if (++step > max_steps) {
+    if (decltype(EXITS)::value && step > max_steps) {
       ok = false;
-      break;
+      return true;
     }
-    // the vertex of the neighbour that is not on the shared edge, and the vertex after it (orientation)
-    const int m = (tv3.x != A.id && tv3.x != Bn.id) ? 0 : ((tv3.y != A.id && tv3.y != Bn.id) ? 1 : 2);
-    const u32 vidN = m == 0 ? tv3.x : (m == 1 ? tv3.y : tv3.z);
+    // where the new vertex sits in the neighbour's record, and the vertex after it (orientation)
+    const int m = tv3.x == vidN ? 0 : (tv3.y == vidN ? 1 : 2);
     const u32 nextv = m == 0 ? tv3.y : (m == 1 ? tv3.z : tv3.x);
     const u32 nb_m = m == 0 ? tn3.x : (m == 1 ? tn3.y : tn3.z);   // across edge m = (N, next)
     const u32 nb_p = m == 0 ? tn3.z : (m == 1 ? tn3.x : tn3.y);   // across edge m+2 = (previous, N)
-    const TinNode N = node(vidN);
-    const bool pos = N.d > 0.f;
-    // pos: N replaces Bn, the exit edge is (A, N); else N replaces A, the exit edge is (N, Bn)
-    const u32 keep = pos ? A.id : Bn.id;
+    const u32 op_m = m == 0 ? to3.x : (m == 1 ? to3.y : to3.z);
+    const u32 op_p = m == 0 ? to3.z : (m == 1 ? to3.x : to3.y);
+    // the new vertex replaces the one on ITS side of the plane (sides by the sign bit of the plane function) and
+    // always takes the role of A; the one that stays moves to Bn only when it was A (five selects, as in sweep_side)
+    const float rx = (vN.x - Oxf) - dOx, ry = (vN.y - Oyf) - dOy, rz = vN.z - oz;
+    const float dN = fmaf(nx_, rx, fmaf(ny_, ry, nz_ * rz));
+    const bool keep_a = (__float_as_int(dN) ^ __float_as_int(A.d)) < 0;
+    const u32 keep = keep_a ? A.id : Bn.id;
     nb = nextv == keep ? nb_m : nb_p;
-    A = sel(pos, A, N);
-    Bn = sel(pos, N, Bn);
+    opv = nextv == keep ? op_m : op_p;
+    Bn.id = keep;
+    Bn.d = keep_a ? A.d : Bn.d;
+    Bn.s = keep_a ? A.s : Bn.s;
+    Bn.t = keep_a ? A.t : Bn.t;
+    A.id = vidN;
+    A.d = dN;
+    A.s = fmaf(su, rx, fmaf(sv, ry, sz * rz));
+    A.t = fmaf(tu, rx, fmaf(tv, ry, tz * rz));
     const float lam = A.d * fast_rcp(A.d - Bn.d);
-    s_prev = s_cur;
-    t_prev = t_cur;
-    s_cur = fmaf(lam, Bn.s - A.s, A.s);
-    t_cur = fmaf(lam, Bn.t - A.t, A.t);
-    if (!(t_cur > 0.f)) {
+    sp = fmaf(lam, Bn.s - A.s, A.s);
+    tp = fmaf(lam, Bn.t - A.t, A.t);
+    if (!(tp > 0.f)) {
       ok = false;
-      break;
+      return true;
     }
+    return false;
+  };
+  for (int step = 1;; step += 2) {
+    if (walk_step(s_prev, t_prev, s_cur, t_cur, step, std::true_type())) break;
+    if (walk_step(s_cur, t_cur, s_prev, t_prev, step + 1, std::false_type())) break;
   }
   if (ok && bp != bp_end) {
     ptr = (int)(bp - sb_off) >> 4;
