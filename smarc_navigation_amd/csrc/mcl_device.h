@@ -346,6 +346,34 @@ __device__ __forceinline__ void muldiv_u64(u64 C, u64 N, u64 T, u64& quo, u64& r
   quo = a;
   rem = r_lo;
 }
+// The same with the estimate's factor N / T (as a double) formed once by the caller: a block that divides thousands of
+// numbers by the same total pays one fp64 division, not one per number (the division and two of the three u64 -> f64
+// conversions were a third of the routine).  The estimate may be off by one more unit in the last place -- the
+// correction below brings the remainder into [0, T) either way, so quotient and remainder are EXACT and identical.
+__device__ __forceinline__ void muldiv_u64(u64 C, u64 N, u64 T, double n_over_t, u64& quo, u64& rem) {
+  const u64 a_lo = C * N, a_hi = __umul64hi(C, N);
+  u64 a = (u64)((double)C * n_over_t);
+  u64 p_lo = a * T, p_hi = __umul64hi(a, T);
+  u64 r_lo = a_lo - p_lo;
+  u64 r_hi = a_hi - p_hi - (a_lo < p_lo ? 1ull : 0ull);
+  for (int it = 0; it < 6; ++it) {
+    if ((long long)r_hi < 0) {  // R < 0 : a too big
+      --a;
+      u64 t = r_lo + T;
+      r_hi += (t < r_lo) ? 1ull : 0ull;
+      r_lo = t;
+    } else if (r_hi != 0 || r_lo >= T) {  // R >= T : a too small
+      ++a;
+      u64 t = r_lo - T;
+      r_hi -= (r_lo < T) ? 1ull : 0ull;
+      r_lo = t;
+    } else {
+      break;
+    }
+  }
+  quo = a;
+  rem = r_lo;
+}
 // (r << 53) > U * T   for r < T <= 2^64-1, U < 2^53.  Bit 63 of U selects ">=" instead of ">": that is the
 // only difference between naive_resample (resampling.py:116-131: `while resample_id > cdf[ind]`, i.e. the
 // first j with cdf_j >= pos) and systematic_resample (:161-167: the first j with pos < cs_j).

@@ -223,20 +223,21 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
       if (blockIdx.x == 0 && tid == 0) a.total_out[0] = T;
     }
     tile_scan_blocked(v, sh64);
+    const double n_over_t = (double)a.n_global_u / (double)T;   // (one fp64 division per thread, not one per weight)
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; ++k) {
       nc[k] = 0u;
       if (base + k < a.n) {
         u64 quo, rem;
-        muldiv_u64(v[k] + off, a.n_global_u, T, quo, rem);
+        muldiv_u64(v[k] + off, a.n_global_u, T, n_over_t, quo, rem);
         nc[k] = (u32)quo + (shl53_gt_mul(rem, a.u53, T) ? 1u : 0u);
         a.ncum[base + k] = nc[k];
       }
     }
     prev_tile = nc_start;
-    if (off != 0ull) {
+    if (off != 0ull && w == 0) {   // (only thread 0 looks at it)
       u64 quo, rem;
-      muldiv_u64(off, a.n_global_u, T, quo, rem);
+      muldiv_u64(off, a.n_global_u, T, n_over_t, quo, rem);
       prev_tile = (u32)quo + (shl53_gt_mul(rem, a.u53, T) ? 1u : 0u);
     }
   } else {
