@@ -341,7 +341,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       // (the assembly merge loop: log-likelihood launches with one lane per side on lattice meshes and TINs -- not on
       //  grids, whose cell walk has its own loop, and not in the -DSWEEP_MERGE_CXX A/B build)
       const int nsub_up = sweep_lanes_per_side(h, with_ranges, B);
-      const int ahead = (with_ranges && nsub_up == 1 && h->map_kind != 0 && !SWEEP_MERGE_CXX) ? 1 : SWEEP_TAN_AHEAD;
+      const int ahead = (h->map_kind == 0 || (with_ranges && nsub_up == 1 && !SWEEP_MERGE_CXX)) ? 1 : SWEEP_TAN_AHEAD;   // (grids: every kernel)
       RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max, nsub_up, ahead));
     } else if (with_ranges && h->ranges_pending) {
       RET_IF(upload(h, h->ranges_dev, h->ranges_host.data(), sizeof(float) * (size_t)B));

@@ -725,12 +725,11 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
   int step = 0;
   const float4* bp = sbeam + ptr;
   const float4* const bp_end = sbeam + pend;
+  // (every grid launch gets the table whose record b carries the tangent of the NEXT beam of its side -- `ahead` = 1,
+  //  mcl_host_update.h --: the pending tangent is all the state the loop keeps; the two-deep queue of the other C++
+  //  loops cost two moves per beam here)
   float tcur = stail[a.n_beams + side];       // tan of the pending beam (side-signed)
-  float tnext = stail[a.n_beams + 2 + side];  // ... and of the one after it
-  if (SUB && first > 0) {
-    tcur = bp[-2 * pstep].x;
-    tnext = bp[-pstep].x;
-  }
+  if (SUB && first > 0) tcur = bp[-pstep].x;
   float4 bm = bp[0];
   const float rc2z = fast_rcp(c2z);
   const float axay2 = 2.f * (ax * ay), axby2 = 2.f * fmaf(ax, by, ay * bx), bxby2 = 2.f * (bx * by);
@@ -797,8 +796,7 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
         const float dd = hw_max(fmaf(-tau, bm.y, bm.z), bm.w);
         acc = fmaf(dd, dd, acc);
       }
-      tcur = tnext;
-      tnext = bm.x;
+      tcur = bm.x;
       bp += pstep;
       bm = bp[0];
       e_cur = fmaf(-tcur, tc, sc);
