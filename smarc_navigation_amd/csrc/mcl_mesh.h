@@ -36,7 +36,7 @@ struct MeshDev {
   double slope_max = 0;   // steepest triangle, |grad h| (the fan sweep's tilt bound, mcl_sweep.h)
   // triangle adjacency for the fan sweep over an arbitrary height-field TIN (mcl_sweep.h: sweep_side_tin):
   // per triangle two uint4 {v0, v1, v2, -} {neighbour across v0v1, v1v2, v2v0 (0xffffffff: hole / ragged border,
-  // 0xfffffff0 / 0xfffffff1: the map's outer x / y border), -}, {the neighbours' vertices off the shared edges, -},
+  // 0xfffffff0 / 0xfffffff1: the map's outer x / y border), -},
   // per vertex one float4 (x, y, z, -).  tin_ok: every edge has at most two triangles and their third vertices lie
   // on opposite sides of it in the xy projection (no fold: the mesh is a height field), no vertical triangle.
   uint4* tin_tri = nullptr;
@@ -459,26 +459,6 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
           if (on_x) nb[e] = 0xfffffff0u;
           else if (on_y) nb[e] = 0xfffffff1u;
         }
-      }
-      // third word of a triangle's record: per edge the vertex of the NEIGHBOUR that is not on the edge ("wing") -- the
-      // walk knows the next vertex from the triangle it is in and loads it together with the neighbour's record,
-      // instead of after it (one exposed load per step less, mcl_sweep.h: sweep_side_tin)
-      {
-        std::vector<uint4> t3((size_t)nt * 3);
-        for (int64_t k = 0; k < nt; ++k) {
-          t3[3 * k] = tt[2 * k];
-          t3[3 * k + 1] = tt[2 * k + 1];
-          u32 opp[3] = {0u, 0u, 0u};
-          const u32* nb = &tt[2 * k + 1].x;
-          for (int e = 0; e < 3; ++e) {
-            if (nb[e] >= 0xfffffff0u) continue;
-            const u32 va = tris[3 * k + e], vb = tris[3 * k + (e + 1) % 3];
-            const u32* nv3 = &tt[2 * (size_t)nb[e]].x;
-            opp[e] = (nv3[0] != va && nv3[0] != vb) ? nv3[0] : ((nv3[1] != va && nv3[1] != vb) ? nv3[1] : nv3[2]);
-          }
-          t3[3 * k + 2] = make_uint4(opp[0], opp[1], opp[2], 0u);
-        }
-        tt.swap(t3);
       }
       std::vector<float4> vv((size_t)nv);
       for (int64_t i = 0; i < nv; ++i) vv[i] = make_float4(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2], 0.f);

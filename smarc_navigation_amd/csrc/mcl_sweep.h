@@ -1003,10 +1003,10 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   };
   auto node = [&](u32 vid) { return node_of(vid, ma.tin_vert[vid]); };
   TinNode A, Bn;
-  u32 nb, opv;  // the triangle across the current exit edge, and its vertex that is not on that edge
+  u32 nb;  // the triangle across the current exit edge
   float s_prev, t_prev, s_cur, t_cur;
   {
-    const uint4 tv3 = ma.tin_tri[3 * (size_t)T], tn3 = ma.tin_tri[3 * (size_t)T + 1], to3 = ma.tin_tri[3 * (size_t)T + 2];
+    const uint4 tv3 = ma.tin_tri[2 * (size_t)T], tn3 = ma.tin_tri[2 * (size_t)T + 1];
     const TinNode N0 = node(tv3.x), N1 = node(tv3.y), N2 = node(tv3.z);
     const bool p0b = __float_as_int(N0.d) >= 0, p1b = __float_as_int(N1.d) >= 0, p2b = __float_as_int(N2.d) >= 0;   // (sides of the plane by the sign bit, like the walk)
     if (p0b == p1b && p1b == p2b) return false;
@@ -1017,8 +1017,6 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const TinNode NN = sel(L == 0, N2, sel(L == 1, N0, N1));  // vL+2
     const u32 nbM = L == 0 ? tn3.x : (L == 1 ? tn3.y : tn3.z);  // across edge L
     const u32 nbN = L == 0 ? tn3.z : (L == 1 ? tn3.x : tn3.y);  // across edge L+2
-    const u32 opM = L == 0 ? to3.x : (L == 1 ? to3.y : to3.z);  // ... and the neighbours' vertices off those edges
-    const u32 opN = L == 0 ? to3.z : (L == 1 ? to3.x : to3.y);
     const float lm = NL.d * fast_rcp(NL.d - NM.d), ln = NL.d * fast_rcp(NL.d - NN.d);
     const float sm = fmaf(lm, NM.s - NL.s, NL.s), tm = fmaf(lm, NM.t - NL.t, NL.t);
     const float sn = fmaf(ln, NN.s - NL.s, NL.s), tn = fmaf(ln, NN.t - NL.t, NL.t);
@@ -1029,7 +1027,6 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     A = sel(pl, NF, NL);   // (A, Bn: plane functions of opposite sign bits; along the walk A is the vertex found last)
     Bn = sel(pl, NL, NF);
     nb = far_m ? nbM : nbN;
-    opv = far_m ? opM : opN;
     s_cur = far_m ? sm : sn;
     t_cur = far_m ? tm : tn;
     s_prev = far_m ? sn : sm;
@@ -1067,14 +1064,12 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   // two).  Returns true when the walk is over.  EXITS: as in sweep_side, the tests that end a walk normally run every
   // second step; the step count is the wave's.
   const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc, const int step, auto EXITS) -> bool {
-    // the neighbour's record AND its vertex off the shared edge (known from the record of the triangle the walk is in:
-    // its third word) are in flight while the beams are resolved -- until round 4 the vertex was loaded after the
-    // record had arrived, an exposed memory latency per step
+    // the neighbour's record is in flight while the beams are resolved.  (Carrying the neighbour's vertex off the shared
+    // edge in every record, so that the vertex could be loaded together with the record instead of after it, was built
+    // and measured in round 4: 48-byte records and three more registers cost what the shorter chain saved.)
     const bool border = nb >= 0xfffffff0u;
     const size_t tq = border ? 0 : (size_t)nb;
-    const uint4 tv3 = ma.tin_tri[3 * tq], tn3 = ma.tin_tri[3 * tq + 1], to3 = ma.tin_tri[3 * tq + 2];
-    const u32 vidN = border ? 0u : opv;
-    const float4 vN = ma.tin_vert[vidN];
+    const uint4 tv3 = ma.tin_tri[2 * tq], tn3 = ma.tin_tri[2 * tq + 1];
     const float dts = tc - tp;
     if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
       sweep_merge_asm(msel, acc, bp, sp, tp, sc, tc, dts);   // (msel = side + 2 noclamp: wave-uniform)
@@ -1117,13 +1112,13 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
       ok = false;
       return true;
     }
-    // where the new vertex sits in the neighbour's record, and the vertex after it (orientation)
-    const int m = tv3.x == vidN ? 0 : (tv3.y == vidN ? 1 : 2);
+    // the vertex of the neighbour that is not on the shared edge, and the vertex after it (orientation)
+    const int m = (tv3.x != A.id && tv3.x != Bn.id) ? 0 : ((tv3.y != A.id && tv3.y != Bn.id) ? 1 : 2);
+    const u32 vidN = m == 0 ? tv3.x : (m == 1 ? tv3.y : tv3.z);
+    const float4 vN = ma.tin_vert[vidN];
     const u32 nextv = m == 0 ? tv3.y : (m == 1 ? tv3.z : tv3.x);
     const u32 nb_m = m == 0 ? tn3.x : (m == 1 ? tn3.y : tn3.z);   // across edge m = (N, next)
     const u32 nb_p = m == 0 ? tn3.z : (m == 1 ? tn3.x : tn3.y);   // across edge m+2 = (previous, N)
-    const u32 op_m = m == 0 ? to3.x : (m == 1 ? to3.y : to3.z);
-    const u32 op_p = m == 0 ? to3.z : (m == 1 ? to3.x : to3.y);
     // the new vertex replaces the one on ITS side of the plane (sides by the sign bit of the plane function) and
     // always takes the role of A; the one that stays moves to Bn only when it was A (five selects, as in sweep_side)
     const float rx = (vN.x - Oxf) - dOx, ry = (vN.y - Oyf) - dOy, rz = vN.z - oz;
@@ -1131,7 +1126,6 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const bool keep_a = (__float_as_int(dN) ^ __float_as_int(A.d)) < 0;
     const u32 keep = keep_a ? A.id : Bn.id;
     nb = nextv == keep ? nb_m : nb_p;
-    opv = nextv == keep ? op_m : op_p;
     Bn.id = keep;
     Bn.d = keep_a ? A.d : Bn.d;
     Bn.s = keep_a ? A.s : Bn.s;
