@@ -34,9 +34,6 @@
 #pragma once
 #include "mcl_mbes.h"
 
-#ifndef SWEEP_PRIO
-#define SWEEP_PRIO 0
-#endif
 #ifndef SWEEP_THREADS
 #define SWEEP_THREADS 256
 #endif
@@ -1240,18 +1237,6 @@ __global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, SU
   extern __shared__ __attribute__((aligned(16))) unsigned char sweep_lds[];
   __shared__ float xacc[64 * (SUB ? SWEEP_MAX_WAVES : SWEEP_THREADS / 64)];
   __shared__ int xok[64 * (SUB ? SWEEP_MAX_WAVES : SWEEP_THREADS / 64)];
-#if SWEEP_PRIO == 1
-  if (blockIdx.x * 4 >= gridDim.x * 3) __builtin_amdgcn_s_setprio(1);
-#elif SWEEP_PRIO == 2
-  if (blockIdx.x * 4 >= gridDim.x * 3) __builtin_amdgcn_s_setprio(2);
-  else if (blockIdx.x * 4 >= gridDim.x * 2) __builtin_amdgcn_s_setprio(1);
-#elif SWEEP_PRIO == 3
-  if (blockIdx.x * 4 >= gridDim.x * 3) __builtin_amdgcn_s_setprio(3);
-  else if (blockIdx.x * 4 >= gridDim.x * 2) __builtin_amdgcn_s_setprio(2);
-  else if (blockIdx.x * 4 >= gridDim.x * 1) __builtin_amdgcn_s_setprio(1);
-#elif SWEEP_PRIO == 4
-  if (blockIdx.x * 8 >= gridDim.x * 7) __builtin_amdgcn_s_setprio(1);
-#endif
   // the table in LDS: four spare records | -1 (sentinel) | side 1's beams 0 .. b_split - 1 | a record in front of either
   // side's first beam (its .x: that beam's tangent, read by sweep_merge_asm) | side 0's beams | sentinel | tail sums.
   // Side 1 indexes it by beam from sbeam, side 0 from sbeam + 2 (sweep_lane); the merge statement reads up to three
