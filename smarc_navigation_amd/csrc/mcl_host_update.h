@@ -79,7 +79,7 @@ int sweep_lanes_per_side(const mcl_handle* h, bool with_ranges, int B) {
 
 // beam table of the fan sweep: side-signed tangent, secant, measured range, weight; and per beam the sum of the
 // squared normalised residuals against r_max over the beams from it to the end of its side (mcl_sweep.h)
-int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max, int nsub, int ahead) {
+int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max, int nsub) {
   // one device block, one copy per update: B records | B tail sums | B measured ranges (for the traversal kernels
   // that take the hand-overs)
   const size_t blk_floats = (size_t)B * 7 + 4;   // B records | B tail sums | B measured ranges | first / second tangent of either side | B tail sums per run
@@ -122,11 +122,10 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
     // the residual's constants: (range_b - r) w with r = min(t / cos a, r_max) is max(z w - t (w / cos a), (z - r_max) w);
     // an invalid beam has all three zero.  Expected-range calls (no measured ranges) keep 1 / cos a in .y
     const double sec = 1.0 / std::cos(ang);
-    // .x: the side-signed tangent of the beam `ahead` places further out on this beam's side -- 1 for the launches that
-    // take the assembly merge loop (mcl_sweep.h: sweep_merge_asm reads the next tangent where it lies), 2 (a two-deep
-    // queue, SWEEP_TAN_AHEAD) for every C++ merge loop
+    // .x: the side-signed tangent of the NEXT beam of this beam's side (+inf beyond the last): a merge loop reads the
+    // tangent it needs next where it lies, in the record it has just used (mcl_sweep.h)
     {
-      const int nb = b < h->b_split ? b - ahead : b + ahead;
+      const int nb = b < h->b_split ? b - 1 : b + 1;
       tb[b].x = (nb < 0 || nb >= B) ? INFINITY : (float)(std::tan((double)h->beam_cache[nb]) * (b < h->b_split ? -1.0 : 1.0));
     }
     tb[b].y = with_ranges ? (valid ? (float)(sec / sigma) : 0.f) : (float)sec;
@@ -338,11 +337,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     h->slice_now = !sweep && h->map_kind == 1 && !structured && h->mesh->cell_tri && h->sweep_angles_ok && h->env_slice != 0 &&
                    h->n < (1ll << 31);
     if (sweep) {
-      // (the assembly merge loop: log-likelihood launches with one lane per side on lattice meshes and TINs -- not on
-      //  grids, whose cell walk has its own loop, and not in the -DSWEEP_MERGE_CXX A/B build)
       const int nsub_up = sweep_lanes_per_side(h, with_ranges, B);
-      const int ahead = (h->map_kind == 0 || (with_ranges && nsub_up == 1 && !SWEEP_MERGE_CXX)) ? 1 : SWEEP_TAN_AHEAD;   // (grids: every kernel)
-      RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max, nsub_up, ahead));
+      RET_IF(upload_sweep_beams(h, with_ranges, B, sigma, r_max, nsub_up));
     } else if (with_ranges && h->ranges_pending) {
       RET_IF(upload(h, h->ranges_dev, h->ranges_host.data(), sizeof(float) * (size_t)B));
       h->ranges_ptr = h->ranges_dev;

@@ -116,7 +116,7 @@ struct MbesArgs {
   int* work_count;        // device counter, zeroed before every fast launch
   unsigned long long* stats;  // MBES_STATS builds: steps, exact tests, rays, retries
   // fan sweep (mcl_sweep.h): regularly triangulated meshes, ascending beam angles
-  const float4* sweep_beams;  // per beam: side-signed tan of the beam SWEEP_TAN_AHEAD places further out on its side (+inf beyond the last), w / cos a, z w, (z - r_max) w  (z measured range, w = 1 / sigma; invalid beam: zeros; expected-range calls: .y = 1 / cos a)
+  const float4* sweep_beams;  // per beam: side-signed tan of the NEXT beam of its side (+inf beyond the last), w / cos a, z w, (z - r_max) w  (z measured range, w = 1 / sigma; invalid beam: zeros; expected-range calls: .y = 1 / cos a)
   const float* sweep_tail_run;   // the same sums per run of a side's beams (SUB kernels stage these instead)
   const float* sweep_tan0;    // 4 floats behind the table: side-signed tan of the first beam of the + / - side, then of the second one (+inf: no such beam) -- staged in LDS with the table (as kernel arguments, selected by side, clang copied them to scratch)
   const float* sweep_tail;    // per beam: sum of ((range - r_max) * weight)^2 over this beam and the ones beyond it on its side

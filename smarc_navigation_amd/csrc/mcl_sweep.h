@@ -17,7 +17,7 @@
 // slice triangle by triangle -- on a lattice triangulation the triangle across edge (A, B) from (A, B, C) has
 // the third node A + B - C, so a step is one height load, one plane evaluation and a handful of selects --
 // and merges the ascending beam table against the polyline as it goes: every beam is resolved by one
-// 2-D segment intersection (~19 VALU) instead of a cell-by-cell march (~200 VALU in k_mbes_fast).  No LDS
+// 2-D segment intersection (~10 VALU) instead of a cell-by-cell march (~200 VALU in k_mbes_fast).  No LDS
 // tile, no groups: heights come through L1/L2 (the walks of a converged cloud share their lines).
 //
 // The map border (lattice maps, round 4: ONE pass): the sweep reads a copy of the height array inside a one-node ring
@@ -62,15 +62,11 @@
 #define SWEEP_TL_WAVES 65536
 __device__ unsigned long long g_sweep_tl[6 * SWEEP_TL_WAVES];
 #endif
-#ifndef SWEEP_TAN_AHEAD
-#define SWEEP_TAN_AHEAD 2   // record b carries the tangent of the beam this many places further out on its side
-#endif
-static_assert(SWEEP_TAN_AHEAD == 2, "the merge loops keep a two-deep tangent queue (tcur, tnext)");
 #ifndef SWEEP_SCHED_BARRIER
 #define SWEEP_SCHED_BARRIER 1   // (the grid's inner loop: pins the wait for a beam record to its first use)
 #endif
 #ifndef SWEEP_MERGE_CXX
-#define SWEEP_MERGE_CXX 0   // 1: every kernel takes the compiler's merge loop (tests/test_gpu_merge_asm.py builds that variant and compares bit for bit)
+#define SWEEP_MERGE_CXX 0   // 1: every kernel takes the compiler's merge loop (csrc/Makefile builds that variant, tests/test_gpu_zz_merge_asm.py compares the two bit for bit)
 #endif
 
 // v_max_f32 as the hardware does it (IEEE maxNum: a NaN operand loses).  fmaxf() adds a canonicalising v_max(x, x) in
@@ -88,8 +84,8 @@ __device__ __forceinline__ float hw_max(float x, float y) {
 //   dd = max(z w - tau (w / cos a), (z - r_max) w);  acc += dd^2;  next record;  e_cur = sc - T' tc
 // 10.5 VALU per beam + one ds_read_b128 (the compiler's version of the loop: 14 -- it rotates a tangent queue through
 // three registers per beam, and its own unrolling fetches two records into different registers and copies them back).
-// * The launches that take this loop get a table whose record b carries the tangent of the NEXT beam of its side
-//   (mcl_host_update.h: upload_sweep_beams, `ahead` = 1; every other kernel: 2, a two-deep queue).  The loop is unrolled
+// * Record b of the beam table carries the tangent of the NEXT beam of its side (mcl_host_update.h:
+//   upload_sweep_beams; rounds 2-3: of the beam after that, a two-deep queue in registers).  The loop is unrolled
 //   by two and alternates between TWO record tuples, A = v[60:63] and B = v[56:59]: the tangent of the beam pending in one
 //   half is the .x of the record the other half has just used, read where it lies -- no copy into a queue register.  A
 //   tuple is reloaded right after the one instruction that still needs its .x.
@@ -413,12 +409,8 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
   const unsigned bp_end = sb_off + (unsigned)(pend * 16);
   const int msel = side + 2 * a.sweep_noclamp;
   const int pstep16 = pstep * 16;
-  float tcur = stail[a.n_beams + side];   // tan of the pending beam (side-signed)
-  float tnext = stail[a.n_beams + 2 + side];  // ... and of the one after it (SWEEP_TAN_AHEAD 2)
-  if (SUB && first > 0) {   // (a later run of the side: its tangents are in the records two and one beams back)
-    tcur = sbeam[ptr - 2 * pstep].x;
-    tnext = sbeam[ptr - pstep].x;
-  }
+  float tcur = stail[a.n_beams + side];   // tan of the pending beam (side-signed): all the state the C++ loop keeps
+  if (SUB && first > 0) tcur = sbeam[ptr - pstep].x;   // (a later run of the side: in the record one beam back)
   sweep_rec bm;   // the pending beam's record
   {
     const float4 r = sbeam[ptr];
@@ -461,8 +453,7 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
             const float dd = hw_max(fmaf(-tau, bm.y, bm.z), bm.w);
             acc = fmaf(dd, dd, acc);
           }
-          tcur = tnext;
-          tnext = bm.x;
+          tcur = bm.x;
           bp += pstep16;
           const float4 r = sbeam[(int)(bp - sb_off) >> 4];
           bm.x = r.x;
@@ -722,9 +713,8 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
   int step = 0;
   const float4* bp = sbeam + ptr;
   const float4* const bp_end = sbeam + pend;
-  // (every grid launch gets the table whose record b carries the tangent of the NEXT beam of its side -- `ahead` = 1,
-  //  mcl_host_update.h --: the pending tangent is all the state the loop keeps; the two-deep queue of the other C++
-  //  loops cost two moves per beam here)
+  // (record b carries the tangent of the NEXT beam of its side: the pending tangent is all the state the loop keeps;
+  //  the two-deep queue of rounds 2-3 cost two moves per beam)
   float tcur = stail[a.n_beams + side];       // tan of the pending beam (side-signed)
   if (SUB && first > 0) tcur = bp[-pstep].x;
   float4 bm = bp[0];
@@ -1043,11 +1033,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   const int msel = side + 2 * a.sweep_noclamp;
   const int pstep16 = pstep * 16;
   float tcur = stail[a.n_beams + side];
-  float tnext = stail[a.n_beams + 2 + side];
-  if (SUB && first > 0) {
-    tcur = sbeam[ptr - 2 * pstep].x;
-    tnext = sbeam[ptr - pstep].x;
-  }
+  if (SUB && first > 0) tcur = sbeam[ptr - pstep].x;
   sweep_rec bm;   // the pending beam's record
   {
     const float4 r = sbeam[ptr];
@@ -1082,8 +1068,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
           const float dd = hw_max(fmaf(-tau, bm.y, bm.z), bm.w);
           acc = fmaf(dd, dd, acc);
         }
-        tcur = tnext;
-        tnext = bm.x;
+        tcur = bm.x;
         bp += pstep16;
         const float4 r = sbeam[(int)(bp - sb_off) >> 4];
         bm.x = r.x;
