@@ -295,6 +295,13 @@ int mcl_timing_get(mcl_handle* h, mcl_timing* out); /* syncs, returns and resets
  * angles), 0 ray traversal; handed_over = particles the sweep / slice passed on to the general kernel (paths 1, 2),
  * deferred_groups = groups of eight the fast traversal passed on to the general one.  Any pointer may be NULL. */
 int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64_t* deferred_groups);
+/* The order in which the last FUSED step's fan sweep visited the particles (syncs): slots[p] = state slot of the particle
+ * at position p (a wavefront of the sweep casts 64 consecutive positions); *sorted = 1 when the positions follow the
+ * spatial order the previous step's gather prepared (bins of x, y, yaw: DESIGN.md 5 "particle order"), 0 when they are
+ * the slots themselves (slots[] is then the identity).  Only the visiting order ever changes: state slots, RNG keys and
+ * keep / lost / dupes (auv_pf.py:183-198) do not, and no log-likelihood depends on it.  MCL_VISIT=0 switches the
+ * spatial order off, MCL_VISIT=1 forces it for shards of any size (default: >= 32 768 particles).  slots: n entries. */
+int mcl_mbes_visit_order(mcl_handle* h, uint32_t* slots, int32_t* sorted);
 
 #ifdef __cplusplus
 }

@@ -46,7 +46,7 @@ struct Params {
   // rows; map frame; models with z < rocks_depth kept) and the detections of the MBES receptors
   // (geometry_msgs/PoseArray in base_frame, toy_mbes_receptor.cpp:68-110; ekf_slam.cpp:41 names the topic parameter)
   std::string landmark_map_file = "", lm_detect_topic = "/landmarks_detected";
-  double rocks_depth = 1e300, landmark_std = 0.3, landmark_gate = 11.345, landmark_sync_tol = 0.5;
+  double rocks_depth = 1e300, landmark_std = 0.3, landmark_gate = 11.345, landmark_sync_tol = 1e-3, landmark_max_age = 0.5;
   int landmark_k = 1;
 };
 
@@ -284,13 +284,18 @@ class Core {
   }
   bool has_landmarks() const { return has_landmarks_; }
 
-  // Landmark detections of one ping (base_frame positions, toy_mbes_receptor.cpp:75-105).  With a bathymetric map they
-  // wait for their ping -- the next ping_scan / ping_points within landmark_sync_tol seconds adds their log-likelihood
-  // to the ping's (mcl_update_landmarks, accumulate = 1) before the resampling; without one they are a measurement
-  // update of their own followed by the resampling, like a GPS fix.
+  // Landmark detections of one ping (base_frame positions, toy_mbes_receptor.cpp:75-105: stamped with the ping's stamp,
+  // published AFTER the receptor has processed the ping).  The usual order -- the ping with this stamp, or a later one,
+  // has already been through ping_scan / ping_points --: a measurement update of their own followed by the resampling,
+  // like a GPS fix (detections and ranges are independent measurements of the same pose).  Ahead of their ping (a bag
+  // replayed by topic): held until the ping with the same stamp (within landmark_sync_tol: the stamps are copies of one
+  // another), whose likelihood they join before the resampling (mcl_update_landmarks, accumulate = 1).  Without a
+  // bathymetric map always an update of their own.  Detections older than landmark_max_age seconds of the filter's clock
+  // (the latest odometry stamp) are dropped: their base_frame positions describe a pose the cloud has long left.
   bool detections(double stamp, const double* xyz, int n_det) {
     if (old_time_ == 0.0 || !has_landmarks_ || n_det < 1) return true;
-    if (has_map_) {
+    if (time_ - stamp > p_.landmark_max_age) return true;
+    if (has_map_ && (!have_ping_ || stamp > last_ping_stamp_ + p_.landmark_sync_tol)) {
       pending_stamp_ = stamp;
       pending_det_.assign(xyz, xyz + (size_t)n_det * 3);
       return true;
@@ -397,13 +402,16 @@ class Core {
   mcl_handle* handle() { return h_; }
 
  private:
-  // right after an MBES update: the detections of this ping, if any, onto its likelihood (detections of another ping
-  // are dropped, never applied to the wrong one)
+  // right after an MBES update: detections that arrived ahead of THIS ping onto its likelihood; held detections of an
+  // earlier ping (which never came) are dropped -- never applied to another ping --, of a later one kept
   bool accumulate_pending(double ping_stamp) {
+    last_ping_stamp_ = ping_stamp;
+    have_ping_ = true;
     if (pending_det_.empty()) return true;
+    if (pending_stamp_ > ping_stamp + p_.landmark_sync_tol) return true;
     std::vector<double> det;
     det.swap(pending_det_);
-    if (std::fabs(ping_stamp - pending_stamp_) > p_.landmark_sync_tol) return true;
+    if (pending_stamp_ < ping_stamp - p_.landmark_sync_tol) return true;
     return check(mcl_update_landmarks(h_, det.data(), (int)(det.size() / 3), p_.landmark_std, p_.landmark_k, p_.landmark_gate,
                                       nullptr, 1));
   }
@@ -426,7 +434,8 @@ class Core {
   double time_ = 0.0, old_time_ = 0.0;
   bool diving_ = true, has_map_ = false;   // auv_pf.py:103
   bool has_landmarks_ = false;
-  double pending_stamp_ = 0.0;
+  double pending_stamp_ = 0.0, last_ping_stamp_ = 0.0;
+  bool have_ping_ = false;
   std::vector<double> pending_det_;
   std::vector<float> angles_, ranges_;
   std::string err_;

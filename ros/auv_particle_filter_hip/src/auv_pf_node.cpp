@@ -64,6 +64,7 @@ class AuvPfNode {
     pnh_.param("landmark_k", p.landmark_k, p.landmark_k);
     pnh_.param("landmark_gate", p.landmark_gate, p.landmark_gate);
     pnh_.param("landmark_sync_tol", p.landmark_sync_tol, p.landmark_sync_tol);
+    pnh_.param("landmark_max_age", p.landmark_max_age, p.landmark_max_age);
     pnh_.param("max_published_poses", max_poses_, 5000);
     if (max_poses_ < 1) max_poses_ = 1;   // (the stride of the thinned PoseArray divides by it)
 

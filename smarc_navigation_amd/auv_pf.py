@@ -50,11 +50,16 @@ DEFAULT_PARAMS = {
     # (n, 3), or a text file of x y z rows; map frame.  '' = no landmark map: detections ignored.
     # `lm_detect_topic`: geometry_msgs/PoseArray of detections in base_frame, positions only, as the MBES receptors
     # publish them (mbes_toy_processor/src/toy_mbes_receptor.cpp:68-110; consumer auv_ekf_slam/src/ekf_slam.cpp:41).
-    # A detection message is held for the ping it came from (the receptor stamps it with the ping's stamp and
-    # publishes it after processing the ping): the next MBES update within `landmark_sync_tol` seconds adds its
-    # log-likelihood to the ping's before the resampling; without a bathymetric map it is an update of its own.
+    # The receptor stamps a detection message with its ping's stamp and publishes it AFTER processing the ping, so in a
+    # live system it reaches the node when that ping's update and resampling are done: it is then a measurement update
+    # of its own, followed by the resampling (detections and ranges are independent measurements of the same pose).  A
+    # stream that delivers the detections first (a bag replayed by topic) has them wait for the ping with THEIR stamp
+    # (equal within `landmark_sync_tol` seconds: the stamps are copies of one another), whose likelihood they join
+    # before the resampling.  Without a bathymetric map a detection message is always an update of its own.  Detections
+    # older than `landmark_max_age` seconds of the filter's clock (the latest odometry stamp) are dropped: their
+    # base_frame positions describe a pose the cloud has long left.
     'landmark_map_file': '', 'rocks_depth': float('inf'), 'lm_detect_topic': '/landmarks_detected',
-    'landmark_std': 0.3, 'landmark_k': 1, 'landmark_gate': 11.345, 'landmark_sync_tol': 0.5,
+    'landmark_std': 0.3, 'landmark_k': 1, 'landmark_gate': 11.345, 'landmark_sync_tol': 1e-3, 'landmark_max_age': 0.5,
 }
 
 
@@ -250,7 +255,9 @@ class auv_pf(object):
         self.has_landmarks = False
         self.landmark_std, self.landmark_k = float(p['landmark_std']), int(p['landmark_k'])
         self.landmark_gate, self.landmark_sync_tol = float(p['landmark_gate']), float(p['landmark_sync_tol'])
-        self._pending_det = None   # (stamp, (n_det, 3) detections in base_frame) waiting for their ping
+        self.landmark_max_age = float(p['landmark_max_age'])
+        self._pending_det = None   # (stamp, (n_det, 3) detections in base_frame) that arrived AHEAD of their ping
+        self._last_ping_stamp = None
         if p['landmark_map_file']:
             self.set_landmarks(load_landmark_file(p['landmark_map_file'], float(p['rocks_depth'])))
 
@@ -341,17 +348,21 @@ class auv_pf(object):
 
     def lm_detect_cb(self, lm_msg):
         """geometry_msgs/PoseArray of detections in base_frame (toy_mbes_receptor.cpp:75-105: positions only, stamped
-        with the ping's stamp).  With a bathymetric map the detections wait for their ping (mbes_cb adds their
-        log-likelihood to the ping's: mcl_update_landmarks(accumulate = 1)); without one they are a measurement update
-        of their own, followed by the resampling like a GPS fix."""
+        with the ping's stamp, published after the receptor has processed the ping).  The usual order -- the ping with
+        this stamp (or a later one) has already been through mbes_cb --: a measurement update of its own followed by
+        the resampling, like a GPS fix.  Ahead of its ping: held until mbes_cb sees the ping with the same stamp, whose
+        likelihood it joins (mcl_update_landmarks(accumulate = 1)).  Never applied to another ping's likelihood."""
         det = np.array([[p.position.x, p.position.y, p.position.z] for p in lm_msg.poses], np.float64).reshape(-1, 3)
         if det.shape[0] == 0:
             return
         with self.lock:
             if not (self.old_time and self.has_landmarks):
                 return
-            if self.has_map:
-                self._pending_det = (self._stamp_of(lm_msg), det)
+            stamp = self._stamp_of(lm_msg)
+            if self.time - stamp > self.landmark_max_age:
+                return
+            if self.has_map and (self._last_ping_stamp is None or stamp > self._last_ping_stamp + self.landmark_sync_tol):
+                self._pending_det = (stamp, det)
                 return
             self.particles.update_landmarks(det, self.landmark_std, k=self.landmark_k, gate=self.landmark_gate,
                                             accumulate=False)
@@ -363,13 +374,18 @@ class auv_pf(object):
         return float(stamp.to_sec()) if stamp is not None else float(self.time)
 
     def _accumulate_pending_detections(self, ping_stamp):
-        """Called under the lock right after an MBES update: the detections of this ping, if any, onto its likelihood."""
+        """Called under the lock right after an MBES update: detections that arrived ahead of THIS ping onto its
+        likelihood; held detections of an earlier ping (which never came) are dropped, of a later one kept."""
+        ping_stamp = float(ping_stamp)
+        self._last_ping_stamp = ping_stamp
         if self._pending_det is None:
             return
         stamp, det = self._pending_det
+        if stamp > ping_stamp + self.landmark_sync_tol:
+            return   # (still ahead: its ping is yet to come)
         self._pending_det = None
-        if abs(float(ping_stamp) - stamp) > self.landmark_sync_tol:
-            return   # (detections of another ping: dropped, never applied to the wrong one)
+        if stamp < ping_stamp - self.landmark_sync_tol:
+            return   # (its ping never arrived: dropped, never applied to another ping)
         self.particles.update_landmarks(det, self.landmark_std, k=self.landmark_k, gate=self.landmark_gate,
                                         accumulate=True)
 

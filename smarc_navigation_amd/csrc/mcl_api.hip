@@ -115,6 +115,18 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
     if (const char* sv = getenv("MCL_SORT_VISITS")) h->env_sort = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_SWEEP")) h->env_sweep = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_SLICE")) h->env_slice = sv[0] == '1' ? 1 : 0;
+    if (const char* sv = getenv("MCL_VISIT")) h->env_visit = sv[0] == '1' ? 1 : 0;
+    if (const char* sv = getenv("MCL_VISIT_BINS")) {
+      int b[3] = {0, 0, 0};
+      if (sscanf(sv, "%d,%d,%d", &b[0], &b[1], &b[2]) == 3 && b[0] >= 1 && b[1] >= 1 && b[2] >= 1 &&
+          (long long)b[0] * b[1] * b[2] <= VISIT_MAX_BINS && (b[0] * b[1] * b[2]) % 64 == 0)
+        for (int c = 0; c < 3; ++c) h->visit_nb[c] = b[c];
+    }
+    if (const char* sv = getenv("MCL_VISIT_RANGE")) {
+      const double r = atof(sv);
+      if (r >= 0.5 && r <= 16.0) h->visit_range = (float)r;
+    }
+    if (const char* sv = getenv("MCL_VISIT_MIN_N")) h->visit_min_n = std::max(1ll, atoll(sv));
     if (const char* sv = getenv("MCL_SWEEP_NSUB")) h->env_nsub = (sv[0] == '2' || sv[0] == '4') ? sv[0] - '0' : 1;
     h->env_force_comm = on("MCL_FORCE_COMM");
     if (const char* ex = getenv("MCL_EXCHANGE")) h->exch_allgather = strcmp(ex, "allgather") == 0;
@@ -192,7 +204,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_buf[0], h->sweep_buf[1], h->defer_idx, h->reasons_dev, h->grid_pad, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_buf[0], h->sweep_buf[1], h->defer_idx, h->visit_okey, h->visit_hist, h->visit_binbase, h->visit_bintot, h->visit_par, h->reasons_dev, h->grid_pad, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev, h->lsx, h->xsend, h->xrecv};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -233,6 +245,7 @@ int mcl_init_particles(mcl_handle* h, const double* replay_normals) {
   }
   RET_IF(cancel_state_gather(h));
   h->uni_valid = false;
+  h->visit_ready = false;
   NoiseArgs a = noise_args(h, h->cfg.init_cov, 0u, 0u);
   t_begin(h, MCL_K_NOISE);
   k_add_noise<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, rp, 1);
@@ -728,6 +741,7 @@ int mcl_set_particles(mcl_handle* h, const double* soa) {
   RET_IF(set_device(h));
   RET_IF(cancel_state_gather(h));
   h->uni_valid = false;
+  h->visit_ready = false;
   HIPCHK(h, hipMemcpyAsync(h->state[h->cur], soa, sizeof(double) * 6 * (size_t)h->n, hipMemcpyHostToDevice,
                            h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1111,6 +1125,21 @@ int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64
   if (path) *path = h->sweep_now ? 1 : (h->slice_now ? 2 : 0);
   if (handed_over) *handed_over = (h->sweep_now || h->slice_now) ? cnt[1] : 0;
   if (deferred_groups) *deferred_groups = cnt[0];
+  return MCL_OK;
+}
+
+int mcl_mbes_visit_order(mcl_handle* h, uint32_t* slots, int32_t* sorted) {
+  if (!h || !slots) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (sorted) *sorted = h->pose_visit ? 1 : 0;
+  if (!h->pose_visit || !h->pose_dev) {
+    for (long long i = 0; i < h->n; ++i) slots[i] = (uint32_t)i;
+    return MCL_OK;
+  }
+  std::vector<MbesPose> rec((size_t)h->n);
+  HIPCHK(h, hipMemcpy(rec.data(), h->pose_dev, sizeof(MbesPose) * (size_t)h->n, hipMemcpyDeviceToHost));
+  for (long long i = 0; i < h->n; ++i) slots[i] = rec[(size_t)i].slot;
   return MCL_OK;
 }
 

@@ -38,6 +38,7 @@
 #define CTRL_T_QUANT (CTRL_WORK + 12)      // u32 tickets, self-resetting
 #define CTRL_T_EXPAND (CTRL_WORK + 16)
 #define CTRL_T_GATHER (CTRL_WORK + 20)
+#define CTRL_T_VISIT (CTRL_WORK + 24)
 #define CTRL_BYTES 1024
 
 namespace {
@@ -139,6 +140,18 @@ struct mcl_handle {
   hipStream_t copy_stream = nullptr;
   u32* defer_idx = nullptr;         // particles the sweep hands to k_mbes_cast<., ., 2>
   unsigned* reasons_dev = nullptr;  // -DSWEEP_REASONS builds: why the sweep declined (16 counters)
+  // spatial visiting order of the sweep (mcl_kernels.h: VisitArgs): prepared by the fused step's gather, used by the
+  // next fused predict
+  u32 *visit_okey = nullptr, *visit_hist = nullptr, *visit_binbase = nullptr, *visit_bintot = nullptr;
+  VisitPar* visit_par = nullptr;    // two entries: read / written alternately
+  unsigned visit_flip = 0;
+  bool gather_attr_set = false;     // k_resample_gather<true, true, true> may use its 112 KiB of dynamic LDS
+  bool visit_ready = false;         // okey / hist / binbase describe the slots of the current state
+  bool pose_visit = false;          // pose_dev lies in visiting order (written by the last fused predict)
+  int env_visit = -1;               // MCL_VISIT=0/1 forces the decision (tests, A/B)
+  int visit_nb[3] = {16, 16, 16};   // MCL_VISIT_BINS=x,y,yaw
+  float visit_range = 4.f;          // MCL_VISIT_RANGE: bins span mean +- range * sigma
+  long long visit_min_n = 32768;    // MCL_VISIT_MIN_N: smaller shards are visited in slot order
   int env_sweep = -1;               // MCL_SWEEP=0/1 forces the decision (tests, A/B)
   int env_nsub = 0;                 // MCL_SWEEP_NSUB=1/2/4 forces the lanes per particle side (A/B)
   bool sweep_now = false;           // decided by the first launch_mbes call of an update

@@ -518,12 +518,49 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   }
   a.ticket = ctrl_u32(h, CTRL_T_GATHER);
   const double* rp = replay_normals ? h->replay_dev : nullptr;
+  // the visiting order of the NEXT fan sweep (mcl_kernels.h: VisitArgs): after a swept update of a fused step, shards
+  // large enough for the order to pay
+  memset(&a.visit, 0, sizeof a.visit);
+  h->visit_ready = false;
+  // (the stash kernel -- mcl_resample.h -- takes the sums in a second pass: the fused step with resampling noise on
+  //  x, y, yaw only; it also prepares the visiting order)
+  const bool uni = a.uni_mask == 0x1cu;   // z, roll, pitch substituted: the lean kernel
+  const bool stash = with_moments && uni && a.nz.sq[2] == 0.0 && a.nz.sq[3] == 0.0 && a.nz.sq[4] == 0.0;
+  const bool visit = stash && !rp && h->sweep_now && h->env_visit != 0 && (h->env_visit == 1 || h->n >= h->visit_min_n);
+  if (visit) {
+    const int nb = h->visit_nb[0] * h->visit_nb[1] * h->visit_nb[2];
+    if (!h->visit_okey) {
+      HIPCHK(h, hipMalloc(&h->visit_okey, sizeof(u32) * (size_t)h->n));
+      HIPCHK(h, hipMalloc(&h->visit_hist, sizeof(u32) * (size_t)GATHER_MAX_GRID * VISIT_MAX_BINS));
+      HIPCHK(h, hipMalloc(&h->visit_binbase, sizeof(u32) * VISIT_MAX_BINS));
+      HIPCHK(h, hipMalloc(&h->visit_bintot, sizeof(u32) * VISIT_MAX_BINS));
+      HIPCHK(h, hipMalloc(&h->visit_par, sizeof(VisitPar) * 2));
+      HIPCHK(h, hipMemsetAsync(h->visit_par, 0, sizeof(VisitPar) * 2, h->stream));
+    }
+    a.visit.okey = h->visit_okey;
+    a.visit.hist = h->visit_hist;
+    a.visit.binbase = h->visit_binbase;
+    a.visit.bintot = h->visit_bintot;
+    a.visit.par_in = h->visit_par + (h->visit_flip & 1u);
+    a.visit.par_out = h->visit_par + ((h->visit_flip & 1u) ^ 1u);
+    h->visit_flip ^= 1u;
+    a.visit.nbx = h->visit_nb[0];
+    a.visit.nby = h->visit_nb[1];
+    a.visit.nbw = h->visit_nb[2];
+    a.visit.nb = nb;
+    a.visit.range = h->visit_range;
+  }
   t_begin(h, MCL_K_RESAMPLE);
   // one particle per thread up to 256 blocks (= 256 tickets), grid-stride beyond
   long long gg = (h->n + RS_BLOCK - 1) / RS_BLOCK;
   gg = gg < 1 ? 1 : (gg > GATHER_MAX_GRID ? GATHER_MAX_GRID : gg);
-  const bool uni = a.uni_mask == 0x1cu;   // z, roll, pitch substituted: the lean kernel
-  if (with_moments && uni)
+  if (stash) {
+    if (!h->gather_attr_set) {   // (more than 64 KiB of dynamic LDS has to be asked for, once per device)
+      HIPCHK(h, hipFuncSetAttribute((const void*)k_resample_gather<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GATHER_STASH_LDS));
+      h->gather_attr_set = true;
+    }
+    k_resample_gather<true, true, true><<<(unsigned)gg, RS_BLOCK, GATHER_STASH_LDS, h->stream>>>(a, rp);
+  } else if (with_moments && uni)
     k_resample_gather<true, true><<<(unsigned)gg, RS_BLOCK, 0, h->stream>>>(a, rp);
   else if (with_moments)
     k_resample_gather<true><<<(unsigned)gg, RS_BLOCK, 0, h->stream>>>(a, rp);
@@ -531,6 +568,10 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
     k_resample_gather<false, true><<<(unsigned)gg, RS_BLOCK, 0, h->stream>>>(a, rp);
   else
     k_resample_gather<false><<<(unsigned)gg, RS_BLOCK, 0, h->stream>>>(a, rp);
+  if (visit) {
+    k_visit_scan<<<(unsigned)(a.visit.nb / 64), 1024, 0, h->stream>>>(a.visit, (int)gg, ctrl_u32(h, CTRL_T_VISIT));
+    h->visit_ready = true;
+  }
   t_end(h);
   HIPCHK(h, hipGetLastError());
   h->cur ^= 1;
@@ -665,7 +706,8 @@ int alt_indices(mcl_handle* h, const double* uniforms, long long nu) {
   return MCL_OK;
 }
 int run_resample_alt(mcl_handle* h, const double* uniforms, long long nu, const double* replay_normals) {
-  h->uni_valid = false;  // (single shard only: no exchange; the new state carries resampling noise)
+  h->uni_valid = false;
+  h->visit_ready = false;  // (single shard only: no exchange; the new state carries resampling noise)
   RET_IF(alt_indices(h, uniforms, nu));
   // keep/lost/dupes for an arbitrary ancestor vector (auv_pf.py:183-198) + noise
   if (replay_normals) RET_IF(upload_replay(h, replay_normals));

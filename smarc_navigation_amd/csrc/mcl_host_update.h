@@ -395,6 +395,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   } seq_guard{h};
   t_begin(h, MCL_K_UPDATE_MBES);
   if (!pose_done) {
+    h->pose_visit = false;   // (the pose kernel below writes the records in slot order)
     // (the fused predict has already reset the control block and written poses, group records and worklist)
     if (a.max_slots)
       HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_BYTES, h->stream));  // slots + work and hand-over counters (one aligned fill)
@@ -626,6 +627,9 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
   a.zero_ptr = nullptr;
   a.zero_words = 0;
   a.skip_uniform = 0;
+  a.visit_okey = a.visit_base = a.visit_binbase = nullptr;
+  a.visit_nb = 0;
+  h->pose_visit = false;
   const double* rp = nullptr;
   if (h->cfg.rng_mode == MCL_RNG_REPLAY) {
     if (replay_normals) {
@@ -651,6 +655,15 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
     } else {
       a.zero_ptr = (unsigned long long*)h->ctrl;   // the kernel's first workgroup zeroes it: no memset launch
       a.zero_words = CTRL_BYTES / 8;
+      if (pose_for->sweep_beams && h->visit_ready) {
+        // the fan sweep visits the particles in the spatial order the last gather prepared: the records go to their
+        // sorted positions (the sweep writes log-likelihoods by the slot in the record)
+        a.visit_okey = h->visit_okey;
+        a.visit_base = h->visit_hist;
+        a.visit_binbase = h->visit_binbase;
+        a.visit_nb = h->visit_nb[0] * h->visit_nb[1] * h->visit_nb[2];
+        h->pose_visit = true;
+      }
     }
     if (lean)
       k_predict_pose<true><<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(state_ptrs(h->state[h->cur], h->n), h->n, a, *pose_for);

@@ -19,6 +19,39 @@ struct NoiseArgs {
   long long gid0;  // global id of local particle 0
 };
 
+// ------------------------------------------------------------------ spatial visiting order of the fan sweep
+// ("particle order").  The sweep runs one LANE per particle side, so a wave is as fast as its 64 particles
+// are alike; slots carry no spatial order (resampling leaves survivors where they are).  Only the VISITING order is
+// changed: the resample gather bins every particle it writes by (x, y, yaw) -- bins over mean +- VISIT_RANGE sigma of
+// the cloud one step earlier, extrapolated by one step of its drift -- and counts, per workgroup, how many of its
+// particles fell into each bin, handing every particle its rank inside (workgroup, bin); k_visit_scan turns the
+// count matrix into start positions; the predict kernel of the NEXT step writes the pose record of slot i to position
+// binbase[key] + colbase[workgroup of i][key] + rank (an exact counting sort: a bijection onto [0, n)) with the slot
+// in the record.  State slots, RNG keys (global ids) and keep / lost / dupes are untouched (auv_pf.py:183-198), and
+// by the determinism rule (mcl_mbes.h) the order in which particles are cast changes no log-likelihood.
+#define VISIT_MAX_BINS 4096
+#define VISIT_KEY_BITS 12
+#define VISIT_OWNER_SHIFT 10   // log2(RS_BLOCK): the gather workgroup of slot i is (i >> 10) % its grid
+#define VISIT_OWNER_MASK 255   // GATHER_MAX_GRID - 1 (a smaller grid covers every slot with its first pass: no wrap)
+struct VisitPar {    // written by the gather's last block for the next gather
+  double mean[3];    // x, y, wrapped yaw of the cloud the bins were derived from
+  double lo[3];      // lower edge of bin 0
+  float inv[3];      // bins per unit
+  int valid;
+};
+struct VisitArgs {
+  u32* okey;             // per slot: key | rank << VISIT_KEY_BITS        (nullptr: no visiting order)
+  u32* hist;             // [workgroup][nb]: counts, then (k_visit_scan, in place) exclusive positions inside the bin
+  u32* binbase;          // [nb] first position of every bin
+  u32* bintot;           // [nb] scratch
+  const VisitPar* par_in;
+  VisitPar* par_out;
+  int nbx, nby, nbw, nb; // bins per dimension, nb = nbx * nby * nbw <= VISIT_MAX_BINS, a multiple of 64
+  float range;           // bins span mean +- range * sigma
+};
+__device__ __forceinline__ u32 load_agent(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // 6 normals for particle gid (purpose 0 init / 2 resample-noise): two Philox blocks
 // Counter-based: a draw depends only on (gid, block, step, purpose, seed), so a pair whose two
 // covariances are zero is simply not evaluated (its products with sqrt(cov) = 0 are zero anyway);
@@ -77,6 +110,11 @@ struct PredictArgs {
   // the resample gather of the same call substitutes them -- they are not stored here and not read there (48 B x N of
   // HBM traffic per step); the host fills them in if the step fails between the two kernels
   int skip_uniform;
+  // visiting order (see VisitArgs): when set, the pose record of slot i goes to its sorted position
+  const u32* visit_okey;
+  const u32* visit_base;
+  const u32* visit_binbase;
+  int visit_nb;
 };
 // z, roll, pitch of every particle := the three constants (the deferred stores of a fused step that did not reach
 // its gather)

@@ -57,7 +57,7 @@ struct MbesPose {   // 48 B
   double um, vm;    // sensor origin in GLOBAL cell units (fp64: precise before the tile shift)
   float oz;
   float c1[3], c2[3];  // columns 1, 2 of R_map_sensor:  D_b = sin a_b * c1 - cos a_b * c2
-  float pad;
+  u32 slot;            // the particle's state slot: records may lie in VISITING order (mcl_kernels.h: VisitArgs), log-weights never
 };
 
 // Tile window of one group of MBES_WAVES consecutive particles, decided once per group by the pose kernel
@@ -188,7 +188,7 @@ __device__ __forceinline__ MbesPose make_pose(const PoseXform& T, double x, doub
   P.um = (o[0] - T.ox) * T.inv_res;
   P.vm = (o[1] - T.oy) * T.inv_res;
   P.oz = (float)o[2];
-  P.pad = 0.f;
+  P.slot = 0u;
   return P;
 }
 __device__ __forceinline__ PoseXform pose_xform(const MbesArgs& a) {
@@ -319,6 +319,7 @@ __global__ void __launch_bounds__(256) k_mbes_pose(MbesArgs a) {
       sincos(a.st[4][i], &sp, &cp);
       sincos(a.st[5][i], &sy, &cy);
       P = make_pose(T, a.st[0][i], a.st[1][i], a.st[2][i], sr, cr, sp, cp, sy, cy);
+      P.slot = (u32)i;
       a.pose[i] = P;
     }
     if (CLASSIFY) classify_group(a, P, valid, i);
@@ -343,6 +344,14 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_predict_pose(StatePtrs s, long lo
     P.um = P.vm = 0.0;
     P.oz = 0.f;
     if (valid) {
+      // where this slot's record goes: its place in the visiting order the last gather prepared (two loads, in flight
+      // during the arithmetic below), or the slot itself
+      u32 pos = (u32)i;
+      if (!CLASSIFY && a.visit_okey) {
+        const u32 ok = a.visit_okey[i], key = ok & ((1u << VISIT_KEY_BITS) - 1u);
+        const u32 owner = ((u32)i >> VISIT_OWNER_SHIFT) & VISIT_OWNER_MASK;
+        pos = a.visit_binbase[key] + a.visit_base[(size_t)owner * a.visit_nb + key] + (ok >> VISIT_KEY_BITS);
+      }
       u32x4 o = philox4x32((u32)(a.nz.gid0 + i), 0u, a.nz.step, 1u, a.nz.k0, a.nz.k1);
       double n0, n1, n5, unused;
       box_muller(o.x, o.y, n0, n1);
@@ -361,7 +370,8 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_predict_pose(StatePtrs s, long lo
       }
       s.c[5][i] = yaw_t;
       P = make_pose(T, x, y, a.z, sr, cr, sp, cp, sy, cy);
-      m.pose[i] = P;
+      P.slot = (u32)i;
+      m.pose[pos] = P;
     }
     if (CLASSIFY) classify_group(m, P, valid, i);
   }
@@ -901,11 +911,13 @@ __global__ void __launch_bounds__(MBES_THREADS, MAP == 1 ? MBES_MIN_WAVES_MESH -
     const long long grp = MODE == 1 ? (long long)a.worklist[it] : it;
     const long long j = grp * MBES_WAVES + w;  // position in the visiting order
     if (j >= n_eff) continue;
-    const long long i = perm ? (long long)perm[j] : j;  // the particle
+    const long long ip = perm ? (long long)perm[j] : j;  // the particle's pose record
     MbesPose P;
+    long long i;   // its state slot (== ip unless the records lie in visiting order)
     {
       // the record is wave-uniform: pin it in SGPRs
-      const MbesPose Pv = a.pose[i];
+      const MbesPose Pv = a.pose[ip];
+      i = (long long)(u32)__builtin_amdgcn_readfirstlane((int)Pv.slot);
       P.um = uniform_f64(Pv.um);
       P.vm = uniform_f64(Pv.vm);
       P.oz = uniform_f32(Pv.oz);

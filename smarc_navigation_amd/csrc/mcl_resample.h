@@ -399,16 +399,50 @@ struct GatherArgs {
   int recv_mode;
   StatePtrs recv;
   const double* shift_dev;
+  // MOMENTS: the visiting order of the NEXT fan sweep (mcl_kernels.h: VisitArgs); visit.okey == nullptr: none
+  VisitArgs visit;
 };
 // UNI: z, roll, pitch are the odometry's on every particle (a.uni_mask == 0x1c: the resample right after a predict --
 // every fused step): three state components are kernel arguments, not loads, and the three that are left fit the
 // register budget while in flight across the arithmetic (the generic kernel, with six, loads them after it)
-template <bool MOMENTS, bool UNI = false>
+// STASH (MOMENTS and UNI, resampling noise on x, y, yaw only -- every fused step of the launch files' covariances): the
+// loop does not accumulate.  It parks x, y, yaw of the particle it has just written in LDS (fp64, the first GATHER_STASH
+// particles of a thread = 1 M particles per shard; beyond, the second pass re-reads the state) and the 13 sums -- the
+// same additions in the same order -- are taken in a second pass, when the Philox / Box-Muller registers are dead:
+// the loop runs without its 26 accumulator registers (round 4: 128 VGPRs, the limit of a 16-wave workgroup, and
+// anything added to it spilled), and the second pass has room for the visiting order of the next fan sweep
+// (mcl_kernels.h: VisitArgs): key from (x, y, wrapped yaw) relative to the previous cloud's bins, rank inside
+// (workgroup, bin) from an LDS counter.
+#define GATHER_STASH 4
+#define GATHER_STASH_LDS (3 * GATHER_STASH * RS_BLOCK * sizeof(double) + VISIT_MAX_BINS * sizeof(u32))
+__device__ __forceinline__ void moments_add(double (&acc)[MOM_COUNT], const double (&v)[6], const double (&shift)[3], double& wy) {
+  const double dx = v[0] - shift[0], dy = v[1] - shift[1], dz = v[2] - shift[2];
+  acc[0] += dx;
+  acc[1] += dy;
+  acc[2] += dz;
+  acc[3] += v[3];
+  acc[4] += v[4];
+  acc[5] += v[5];
+  wy = wrap_pi(v[5]);
+  acc[6] += wy;
+  acc[7] += dx * dx;
+  acc[8] += dy * dy;
+  acc[9] += dz * dz;
+  acc[10] += dx * dy;
+  acc[11] += dx * dz;
+  acc[12] += dy * dz;
+}
+template <bool MOMENTS, bool UNI = false, bool STASH = false>
 __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, const double* __restrict__ replay) {
-  __shared__ double red[MOM_COUNT][RS_BLOCK / 64];
+  static_assert(!STASH || (MOMENTS && UNI), "the stash variant is the fused step's kernel");
+  __shared__ double red[MOM_COUNT + 1][RS_BLOCK / 64];
   __shared__ u32 last_sh;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gather_lds[];   // STASH: GATHER_STASH_LDS bytes
+  double* const stash = (double*)gather_lds;                                                 // [GATHER_STASH][3][RS_BLOCK]
+  u32* const vhist = (u32*)(gather_lds + 3 * GATHER_STASH * RS_BLOCK * sizeof(double));      // [VISIT_MAX_BINS]
   double acc[MOM_COUNT];
   double shift[3] = {0.0, 0.0, 0.0};
+  const bool visit = STASH && a.visit.okey != nullptr;
   if (MOMENTS) {
 #pragma unroll
     for (int c = 0; c < MOM_COUNT; ++c) acc[c] = 0.0;
@@ -416,9 +450,11 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
     for (int c = 0; c < 3; ++c)  // a member of the cloud, the same on every shard
       shift[c] = a.recv_mode ? a.shift_dev[c] : (((a.uni_mask >> c) & 1u) ? a.uni[c] : a.src.c[c][0]);
   }
+  if (visit)   // (read and written only after the barrier behind the loop)
+    for (int k = threadIdx.x; k < a.visit.nb; k += RS_BLOCK) vhist[k] = 0u;
   // The gather of a resampled cloud is a chain of three dependent, scattered loads per particle (zr -> dupes -> state)
   // in front of ~500 instructions of Philox / Box-Muller arithmetic that need none of them, and with four waves per
-  // SIMD (123 VGPRs) nothing else hides the chain (round 3: 70 % of the wave cycles waiting, rocprofv3 SQ_WAIT_ANY).
+  // SIMD nothing else hides the chain (round 3: 70 % of the wave cycles waiting, rocprofv3 SQ_WAIT_ANY).
   // The loop is therefore software-pipelined by hand: the state loads of THIS particle and the index load of the NEXT
   // one are issued before the arithmetic, the next particle's ancestor index after it.  (A batch of two particles per
   // iteration spilled 68 B per lane: 13 fp64 accumulators leave no room for a second state.)
@@ -432,6 +468,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
     src = a.recv_mode ? (surv ? i : (long long)r) : (surv ? a.goff + i : (long long)a.dupes[r]);
     from_recv = a.recv_mode && !surv;
   }
+  int it = 0;
   for (; i < a.n; i += stride) {
     const long long g = a.goff + i;
     double v[6];
@@ -468,37 +505,82 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
       v[c] = v[c] + a.nz.sq[c] * z[c];
       a.dst.c[c][i] = v[c];
     }
-    if (MOMENTS) {
-      const double dx = v[0] - shift[0], dy = v[1] - shift[1], dz = v[2] - shift[2];
-      acc[0] += dx;
-      acc[1] += dy;
-      acc[2] += dz;
-      acc[3] += v[3];
-      acc[4] += v[4];
-      acc[5] += v[5];
-      acc[6] += wrap_pi(v[5]);
-      acc[7] += dx * dx;
-      acc[8] += dy * dy;
-      acc[9] += dz * dz;
-      acc[10] += dx * dy;
-      acc[11] += dx * dz;
-      acc[12] += dy * dz;
+    if (STASH) {
+      if (it < GATHER_STASH) {
+        stash[(it * 3 + 0) * RS_BLOCK + threadIdx.x] = v[0];
+        stash[(it * 3 + 1) * RS_BLOCK + threadIdx.x] = v[1];
+        stash[(it * 3 + 2) * RS_BLOCK + threadIdx.x] = v[5];
+      }
+      ++it;
+    } else if (MOMENTS) {
+      double wy;
+      moments_add(acc, v, shift, wy);
     }
     src = srcn;
     from_recv = a.recv_mode && !survn;
   }
   if (!MOMENTS) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float vacc = 0.f;
+  if (STASH) {
+    // ---- second pass: the 13 sums (z, roll, pitch are the three constants: their noise covariances are zero) and the
+    // bins of the visiting order.  A record that is not valid yet is all zeros: every particle lands in bin 0 -- still
+    // a bijection -- and the bins follow a step later.
+    VisitPar vp;
+    float ox = 0.f, oy = 0.f, ow = 0.f;
+    if (visit) {
+      vp = *a.visit.par_in;
+      ox = (float)(vp.lo[0] - shift[0]) * vp.inv[0];
+      oy = (float)(vp.lo[1] - shift[1]) * vp.inv[1];
+      ow = (float)(vp.lo[2] - vp.mean[2]) * vp.inv[2];
+      __syncthreads();   // the counters are zero
+    }
+    int k = 0;
+    for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < a.n; j += stride, ++k) {
+      double v[6];
+      if (k < GATHER_STASH) {
+        v[0] = stash[(k * 3 + 0) * RS_BLOCK + threadIdx.x];
+        v[1] = stash[(k * 3 + 1) * RS_BLOCK + threadIdx.x];
+        v[5] = stash[(k * 3 + 2) * RS_BLOCK + threadIdx.x];
+      } else {
+        v[0] = a.dst.c[0][j];
+        v[1] = a.dst.c[1][j];
+        v[5] = a.dst.c[5][j];
+      }
+      v[2] = a.uni[2];
+      v[3] = a.uni[3];
+      v[4] = a.uni[4];
+      double wy;
+      moments_add(acc, v, shift, wy);
+      if (visit) {
+        const float dw = (float)(wy - vp.mean[2]);
+        vacc = fmaf(dw, dw, vacc);   // (the yaw spread the NEXT bins need: the 14th partial sum; fp32 is plenty)
+        // (fmaxf / min: a NaN coordinate lands in bin 0)
+        const int kx = min((int)fmaxf(fmaf((float)(v[0] - shift[0]), vp.inv[0], -ox), 0.f), a.visit.nbx - 1);
+        const int ky = min((int)fmaxf(fmaf((float)(v[1] - shift[1]), vp.inv[1], -oy), 0.f), a.visit.nby - 1);
+        const int kw = min((int)fmaxf(fmaf(dw, vp.inv[2], -ow), 0.f), a.visit.nbw - 1);
+        const u32 key = (u32)((kx * a.visit.nby + ky) * a.visit.nbw + kw);
+        const u32 rank = atomicAdd(&vhist[key], 1u);   // LDS: the particle's place among this workgroup's members of the bin
+        a.visit.okey[j] = key | (rank << VISIT_KEY_BITS);
+      }
+    }
+  }
 #pragma unroll
   for (int c = 0; c < MOM_COUNT; ++c) {
     const double s = wave_sum_dpp(acc[c]);   // (13 shuffle trees through LDS were half of this kernel's 9 us tail)
     if (lane == 0) red[c][w] = s;
   }
+  if (visit) {
+    const float s = wave_sum_dpp(vacc);
+    if (lane == 0) red[MOM_COUNT][w] = (double)s;
+  }
   __syncthreads();
+  if (visit)   // this workgroup's row of the count matrix (plain stores: read by the NEXT launch, k_visit_scan)
+    for (int k = threadIdx.x; k < a.visit.nb; k += RS_BLOCK) a.visit.hist[(size_t)blockIdx.x * a.visit.nb + k] = vhist[k];
   if (w == 0) {
     // wave 0: lanes 0..12 publish this block's 13 partial sums (ONE write-through store instruction), drain it,
     // then lane 0 draws the ticket -- no release fence: only these words are read inside the launch
-    if (lane < MOM_COUNT) {
+    if (lane < MOM_COUNT + (visit ? 1 : 0)) {
       double s = 0.0;
       for (int k = 0; k < RS_BLOCK / 64; ++k) s += red[lane][k];
       store_agent(&a.part[(size_t)lane * gridDim.x + blockIdx.x], s);
@@ -512,12 +594,115 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
   // wave c takes component c, lane l the blocks l, l + 64, ...; then the fixed shuffle tree
   // (no acquire fence -- an L1 invalidate, ~1.7 us --: the partials were stored write-through and drained before
   //  their block's ticket, and are read here by agent-scope loads, issued after the ticket's value has come back)
-  if (w < MOM_COUNT) {
+  if (w < MOM_COUNT + (visit ? 1 : 0)) {
     double s = 0.0;
     for (unsigned b = lane; b < gridDim.x; b += 64) s += load_agent(&a.part[(size_t)w * gridDim.x + b]);
     s = wave_sum_dpp(s);
-    if (lane == 0) a.sums_out[w] = s;
+    if (lane == 0) {
+      if (w < MOM_COUNT) a.sums_out[w] = s;
+      red[w][0] = s;
+    }
   }
   if (threadIdx.x < 3) a.sums_out[MOM_COUNT + threadIdx.x] = shift[threadIdx.x];
   if (threadIdx.x == 0) *a.ticket = 0u;
+  if (!visit) return;
+  // ---- bins of the next gather: mean +- range * sigma of THIS cloud, moved on by the drift since the previous one
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const VisitPar vp = *a.visit.par_in;
+    const double inv_n = 1.0 / (double)a.n;
+    const double m[3] = {red[0][0] * inv_n, red[1][0] * inv_n, red[6][0] * inv_n};   // about the shift / plain
+    const double dm = m[2] - vp.mean[2];
+    const double var[3] = {red[7][0] * inv_n - m[0] * m[0], red[8][0] * inv_n - m[1] * m[1], red[MOM_COUNT][0] * inv_n - dm * dm};
+    const double mean[3] = {shift[0] + m[0], shift[1] + m[1], m[2]};
+    const int nbin[3] = {a.visit.nbx, a.visit.nby, a.visit.nbw};
+    VisitPar o;
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      // (var = E[(v - ref)^2] - (E[v] - ref)^2 for any reference: the yaw's is the previous mean, x and y's the shift)
+      const double sd = sqrt(var[c] > 1e-18 ? var[c] : 1e-18);
+      const double drift = vp.valid ? mean[c] - vp.mean[c] : 0.0;
+      o.mean[c] = mean[c];
+      o.lo[c] = mean[c] + drift - (double)a.visit.range * sd;
+      o.inv[c] = (float)((double)nbin[c] / (2.0 * (double)a.visit.range * sd));
+      ok = ok && mean[c] == mean[c] && sd == sd && sd < 1e30;
+    }
+    o.valid = ok ? 1 : 0;
+    if (!ok) {   // (a cloud with NaN moments: start over from "no bins yet")
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        o.mean[c] = o.lo[c] = 0.0;
+        o.inv[c] = 0.f;
+      }
+    }
+    *a.visit.par_out = o;
+  }
+}
+
+// ------------------------------------------------------------------ visiting order: counts -> positions
+// hist[G][nb] (one row per gather workgroup) becomes, in place, the number of particles of EARLIER workgroups in the
+// same bin; binbase[b] = particles in bins < b.  One workgroup per 64 bins, wave r takes a run of ceil(G / 16) rows;
+// the workgroup that draws the last ticket scans the nb bin totals.
+__global__ void __launch_bounds__(1024) k_visit_scan(VisitArgs a, int G, u32* ticket) {
+  __shared__ u32 sh[16][64];
+  __shared__ u32 wsum[16];
+  __shared__ u32 last_sh;
+  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int bin = blockIdx.x * 64 + lane;
+  const int rpg = (G + 15) >> 4;
+  u32 v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int row = r * rpg + k;
+    v[k] = (k < rpg && row < G) ? a.hist[(size_t)row * a.nb + bin] : 0u;
+  }
+  u32 t = 0u;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const u32 x = v[k];
+    v[k] = t;
+    t += x;
+  }
+  sh[r][lane] = t;
+  __syncthreads();
+  u32 off = 0u, tot = 0u;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const u32 x = sh[k][lane];
+    off += k < r ? x : 0u;
+    tot += x;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int row = r * rpg + k;
+    if (k < rpg && row < G) a.hist[(size_t)row * a.nb + bin] = off + v[k];
+  }
+  if (r == 0) {
+    store_agent(&a.bintot[bin], tot);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) last_sh = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last_sh) return;
+  // exclusive scan of the bin totals (nb <= 4096: four per thread, blocked)
+  u32 x[4], run = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int b = threadIdx.x * 4 + k;
+    x[k] = b < a.nb ? load_agent(&a.bintot[b]) : 0u;
+    run += x[k];
+  }
+  const u32 incl = wave_scan_incl_dpp(run);
+  if (lane == 63) wsum[r] = incl;
+  __syncthreads();
+  u32 base = incl - run;
+  for (int k = 0; k < r; ++k) base += wsum[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int b = threadIdx.x * 4 + k;
+    if (b < a.nb) a.binbase[b] = base;
+    base += x[k];
+  }
+  if (threadIdx.x == 0) *ticket = 0u;
 }

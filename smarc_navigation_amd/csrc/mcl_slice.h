@@ -289,10 +289,14 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
         tB = fmaf(lam, tav - tbv, tbv);
       }
       if (!(tA > 0.f) && !(tB > 0.f)) continue;   // behind the sensor's own horizon (or NaN)
-      // tangents of the end points as seen from the sensor (an end point behind the horizon: beyond every beam)
+      // tangents of the end points as seen from the sensor.  An end point behind the horizon (t <= 0): the visible part
+      // of the segment runs from the other end to where it crosses t = 0, at s0 = (sA tB - sB tA) / (tB - tA), and the
+      // tangent s / t along it tends to +-infinity with the sign of s0 -- NOT of the hidden end point's own s (a steep
+      // sheet from (s, t) = (-1, -10) to (5, 10) crosses the horizon at s0 = +2 and covers the tangents [0.5, +inf))
       const float INF = __builtin_inff();
-      const float TA = tA > 0.f ? sA * __builtin_amdgcn_rcpf(tA) : (sA > 0.f ? INF : -INF);
-      const float TB = tB > 0.f ? sB * __builtin_amdgcn_rcpf(tB) : (sB > 0.f ? INF : -INF);
+      const float cross = sA * tB - sB * tA;   // sign of s0 when A is the hidden end, of -s0 when B is
+      const float TA = tA > 0.f ? sA * __builtin_amdgcn_rcpf(tA) : (cross > 0.f ? INF : -INF);
+      const float TB = tB > 0.f ? sB * __builtin_amdgcn_rcpf(tB) : (cross < 0.f ? INF : -INF);
       const float T_lo = fminf(TA, TB), T_hi = fmaxf(TA, TB);
       if (T_hi < tan_lo || T_lo > tan_hi) continue;
       // first beam with tan >= T_lo (minus a hair: rounding of the quotient).  The bucket's lower end is <= T_first, so

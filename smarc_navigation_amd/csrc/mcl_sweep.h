@@ -1167,9 +1167,11 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
     if (work) exp_row = a.exp_out + (size_t)(i - a.exp_first) * a.n_beams;
   }
   float acc = 0.f;
+  u32 slot = (u32)i;   // where the log-likelihood goes: the record's state slot (records may lie in visiting order)
   const float4* sside = sbeam + (side ? 0 : 2);   // (this side's records by beam index: k_mbes_sweep's table layout)
   if (work) {
     const MbesPose P = a.pose[i];
+    slot = EXPECT_ONLY ? (u32)i : P.slot;
     if (SURF == 5)
       ok = sweep_side_tin<EXPECT_ONLY, SUB>(a, P, sside, stail, side, sub, nsub, exp_row, acc);
     else if (SURF == 0)
@@ -1197,7 +1199,7 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
     }
     if (work && ok2 && !EXPECT_ONLY) {
       v = -0.5 * acc2 - (double)a.sweep_nvalid * a.lognorm;
-      a.lw[i] = v;
+      a.lw[slot] = v;
     }
     // hand-overs: one atomic per wave.  (The list's order is the waves' finishing order: k_mbes_cast<., ., 2> casts
     // every entry with arithmetic that depends on the particle alone -- mcl_mbes.h, the determinism rule.)

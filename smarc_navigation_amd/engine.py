@@ -248,6 +248,13 @@ class Engine(object):
         self._ck(self.lib.mcl_mbes_last_path(self.h, C.byref(p), C.byref(ho), C.byref(dg)))
         return int(p.value), int(ho.value), int(dg.value)
 
+    def mbes_visit_order(self):
+        """(slots, sorted): slots[p] = state slot of the particle the last fused step's sweep visited at position p."""
+        slots = np.empty(self.n, dtype=np.uint32)
+        srt = C.c_int32(0)
+        self._ck(self.lib.mcl_mbes_visit_order(self.h, _ptr(slots), C.byref(srt)))
+        return slots, bool(srt.value)
+
     def timing_get(self):
         t = Timing()
         self._ck(self.lib.mcl_timing_get(self.h, C.byref(t)))

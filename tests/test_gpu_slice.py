@@ -113,6 +113,24 @@ def test_slice_with_a_vertical_wall_and_a_floating_deck(eng, orc, monkeypatch):
            off=[0.3, -0.1, -0.2, 0.01, -0.02, 0.05])
 
 
+def test_slice_steep_sheet_that_passes_over_the_sensor(eng, orc, monkeypatch):
+    """A large steep sheet (a cliff face, a wreck's side) rising from 10 m below the sensor on its starboard side to 10 m
+    above it on its port side: in the fan plane a segment from (s, t) = (5, 10) to (-1, -10), whose hidden end lies on the
+    OTHER side of the nadir than the part the beams see (it crosses the sensor's horizon at s = +2 and covers every
+    tangent from 0.5 upward).  ADVICE r4: the beam run was taken from the hidden end's own sign and the sheet was missed."""
+    floor = [[-60, -60, -35], [60, -60, -35.5], [60, 60, -35], [-60, 60, -34.5]]
+    # sensor near (0, 0, -15) heading along +x: starboard = -y.  The sheet: y = -5 at z = -25 up to y = +1 at z = -5
+    sheet = [[-30, -5, -25], [30, -5, -25], [30, 1, -5], [-30, 1, -5]]
+    # ... and its mirror image on the port side, further out, so that both signs of the hidden end are exercised
+    sheet2 = [[-30, 9, -25], [30, 9, -25], [30, 3, -5], [-30, 3, -5]]
+    verts = np.array(floor + sheet + sheet2, np.float32)
+    tris = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7], [8, 9, 10], [8, 10, 11]], np.uint32)
+    soa = _cloud(96, 12, (1.0, 0.4, 0.5, 0.05, 0.05, 0.3), (0.0, 1.0, -15.0))
+    got, ref = _check(eng, orc, verts, tris, soa, 255, 80.0, monkeypatch, general=False, max_bad=3, half_swath=1.3)
+    assert (ref < 12.0).mean() > 0.25          # a good part of every fan ends on a sheet, metres from the sensor
+    assert (ref > 15.0).mean() > 0.05          # ... the beams between the sheets reach the floor
+
+
 @pytest.mark.parametrize('B', [512, 33, 2, 1])
 def test_slice_on_a_tin_cast_as_a_soup_vs_oracle(B, eng, orc, monkeypatch):
     origin = (-90.0, -80.0)

@@ -339,9 +339,11 @@ def _detections(rows, stamp):
 
 def test_ros_node_landmark_plumbing_with_a_recording_engine(ros, tmp_path, monkeypatch):
     """~landmark_map_file + ~lm_detect_topic: the map goes to set_landmarks (the provider's rocks_depth filter applied);
-    a detection message is held for its ping and becomes update_landmarks(accumulate=True) between that ping's
-    update_mbes and its resample; detections of another ping are dropped; without a bathymetric map a detection
-    message is an update of its own (accumulate=False) followed by the resampling."""
+    a detection message that arrives AFTER its ping -- the live order: toy_mbes_receptor.cpp:68-110 publishes once it has
+    processed the ping -- is an update of its own (accumulate=False) followed by the resampling; one that arrives ahead of
+    its ping is held for the ping with the same stamp and becomes update_landmarks(accumulate=True) between that ping's
+    update_mbes and its resample; it is never applied to another ping; old detections are dropped; without a bathymetric
+    map a detection message is always an update of its own."""
     node, rospy, tf, tf2_ros = ros
     from smarc_navigation_amd import engine as eng
     import rospy as rp
@@ -382,11 +384,40 @@ def test_ros_node_landmark_plumbing_with_a_recording_engine(ros, tmp_path, monke
     FakeEngine.calls = []
     rospy.subscribers['/sam/mbes_scan'].cb(scan)
     assert [c[0] for c in FakeEngine.calls] == ['update_mbes', 'resample']
-    # ---- stale detections (another ping's) are dropped, never applied to the wrong ping
+    # ---- the live order: the ping, THEN the detections the receptor made from it -> an update of their own
+    FakeEngine.calls = []
+    rospy.subscribers['/sam/mbes_scan'].cb(scan)
+    rospy.subscribers['/sam/mbes_detections'].cb(_detections(det, 100.02))
+    names = [c[0] for c in FakeEngine.calls]
+    assert names == ['update_mbes', 'resample', 'update_landmarks', 'resample'], names
+    assert FakeEngine.calls[2][2]['accumulate'] is False
+    # ---- the next ping does not see them again
+    FakeEngine.calls = []
+    rospy.subscribers['/sam/mbes_scan'].cb(scan)
+    assert [c[0] for c in FakeEngine.calls] == ['update_mbes', 'resample']
+    # ---- old detections (10 s behind the filter's clock) are dropped
     FakeEngine.calls = []
     rospy.subscribers['/sam/mbes_detections'].cb(_detections(det, 90.0))
     rospy.subscribers['/sam/mbes_scan'].cb(scan)
     assert [c[0] for c in FakeEngine.calls] == ['update_mbes', 'resample']
+    # ---- detections ahead of their ping wait for THAT ping: an earlier ping leaves them alone ...
+    FakeEngine.calls = []
+    rospy.subscribers['/sam/mbes_detections'].cb(_detections(det, 100.22))
+    rospy.subscribers['/sam/mbes_scan'].cb(scan)                         # (stamp 100.02)
+    assert [c[0] for c in FakeEngine.calls] == ['update_mbes', 'resample']
+    scan.header.stamp = rp.Time(100.22)
+    rospy.subscribers['/sam/mbes_scan'].cb(scan)
+    assert [c[0] for c in FakeEngine.calls][2:] == ['update_mbes', 'update_landmarks', 'resample']
+    assert FakeEngine.calls[3][2]['accumulate'] is True
+    # ---- ... and a held message whose ping never comes is dropped by the first later ping, not applied to it
+    FakeEngine.calls = []
+    rospy.subscribers['/sam/mbes_detections'].cb(_detections(det, 100.30))
+    scan.header.stamp = rp.Time(100.42)
+    rospy.subscribers['/sam/mbes_scan'].cb(scan)
+    scan.header.stamp = rp.Time(100.62)
+    rospy.subscribers['/sam/mbes_scan'].cb(scan)
+    assert [c[0] for c in FakeEngine.calls] == ['update_mbes', 'resample', 'update_mbes', 'resample']
+    scan.header.stamp = rp.Time(100.02)
     # ---- no bathymetric map: the detection message is a measurement update of its own
     p['map_grid_file'] = ''
     FakeEngine.calls = []

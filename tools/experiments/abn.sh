@@ -1,0 +1,11 @@
+#!/bin/bash
+# usage: tools/experiments/abn.sh v1 v2 ...   ("cur" = the in-tree library)
+for rep in 1 2 3; do
+  for v in "$@"; do
+    if [ $v = cur ]; then unset MCL_LIB; else export MCL_LIB=$PWD/tools/experiments/lib$v.so; fi
+    python bench.py --only-main --steps 200 --warmup 20 $AB_ARGS 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().split('\n')[-1])
+print('$v', d['ms_per_step'], 'main_us', d['roofline']['launch_us'], {k:round(v['avg_ms']*1000,1) for k,v in d['kernels'].items()})"
+  done
+done
