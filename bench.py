@@ -675,8 +675,11 @@ def worker(a, rank, world, local_rank):
         }
         if world > 1:
             sent, lost = e.exchange_stats()
+            ops, rounds = e.exchange_ops()
             nst = float(total_steps)
-            out['exchange'] = {'mode': os.environ.get('MCL_EXCHANGE', 'p2p (O(n) per rank: hand-over records + point-to-point surplus copies)'),
+            out['exchange'] = {'rank0_p2p_ops_per_exchange': round(ops / max(rounds, 1), 2), 'p2p_ops_bound': 2 * (world - 1),
+                               'phases_ms_per_step': {k: kernels[k]['ms_per_step'] for k in ('comm_records', 'pack', 'comm_p2p', 'comm_moments', 'comm') if k in kernels},
+'mode': os.environ.get('MCL_EXCHANGE', 'p2p (O(n) per rank: hand-over records + point-to-point surplus copies)'),
                                'rank0_states_sent_per_step': round(sent / nst, 1), 'rank0_lost_slots_per_step': round(lost / nst, 1),
                                'rank0_bytes_sent_per_step': round(24.0 * sent / nst, 1),
                                'bytes_sent_per_step_by_rank': [round(24.0 * x[0] / nst, 1) for x in ex_all] if ex_all else None,

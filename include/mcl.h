@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MCL_ABI_VERSION 2   /* 2: mcl_timing gained MCL_K_MBES_MAIN */
+#define MCL_ABI_VERSION 3   /* 2: mcl_timing gained MCL_K_MBES_MAIN; 3: the exchange's phases (MCL_K_COMM_RECORDS ... MCL_K_COMM_MOMENTS) */
 
 typedef struct mcl_handle mcl_handle;
 
@@ -103,7 +103,12 @@ enum mcl_kernel_id {
   MCL_K_MBES_MAIN = 9, /* the ONE dominant launch of an MBES update (first sweep pass, or the fast traversal kernel):
                           nested inside MCL_K_UPDATE_MBES, whose region also holds the memset, the pose kernel and the
                           (usually empty) hand-over launches */
-  MCL_K_COUNT = 10
+  /* the O(n)-per-rank resample exchange by phase; MCL_K_COMM keeps the all-gather scheme's transfers */
+  MCL_K_COMM_RECORDS = 10, /* all-reduce of the max-lw slots, all-gathers of the shard totals and hand-over records */
+  MCL_K_PACK = 11,         /* k_pack_dupes: surplus copies into per-copy records */
+  MCL_K_COMM_P2P = 12,     /* the ONE group of ncclSend / ncclRecv (at most one each per peer) */
+  MCL_K_COMM_MOMENTS = 13, /* all-reduce of the mean / covariance sums */
+  MCL_K_COUNT = 14
 };
 typedef struct mcl_timing {
   double ms[MCL_K_COUNT];       /* summed device milliseconds */
@@ -153,7 +158,16 @@ int mcl_set_map_mesh(mcl_handle* h, const float* verts, int64_t nv, const uint32
 int mcl_set_map_mesh_ex(mcl_handle* h, const float* verts, int64_t nv, const uint32_t* tris, int64_t nt,
                         uint32_t flags);
 /* ranges[b] <= 0 or NaN marks an invalid beam; beam b looks along (0, sin a_b, -cos a_b) in the
- * sensor frame; sensor_offset = x,y,z,roll,pitch,yaw of the sensor in base_link (NULL = zeros). */
+ * sensor frame; sensor_offset = x,y,z,roll,pitch,yaw of the sensor in base_link (NULL = zeros).
+ * Precision contract (state in fp64, ray-cast in fp32 -- SURVEY 8(d) allows it with a stated tolerance): against the
+ * fp64 definition (oracle/mcl_oracle.c) an expected range is within 1e-3 m and a log-likelihood within
+ *     |d lw| <= 1e-2   or   |d lw| <= 2e-4 |lw|
+ * -- the relative arm is this build's addition to SURVEY's absolute 1e-2: the sum of 512 squared residuals of a particle
+ * metres off the truth reaches |lw| ~ 2e4, where fp32 residuals alone are worth 1e-2 (measured: 1.2e-2).  Exceptions
+ * are the rays that graze a crest or an edge: fp32's last bit decides between the crest and the shadow behind it.
+ * Their NUMBER is bounded by the tests (a few per 10^4 rays on rough terrain) and so is their SIZE: each is, within
+ * 1e-3 m, an answer the fp64 definition itself gives when the sensor moves by 1 mm (tests/helpers.py:
+ * outliers_explained, lw_outliers_explained). */
 int mcl_update_mbes(mcl_handle* h, const float* ranges, const float* beam_angles, int32_t n_beams,
                     double sigma, double r_max, const double sensor_offset[6]);
 /* expected ranges of particles [first, first+count) x n_beams (host floats); parity/diagnostics */
@@ -279,6 +293,10 @@ int mcl_group_step_mbes(mcl_handle** shards, int32_t n_shards, const mcl_odom* o
  * mcl_get_last_offspring_cdf all-gather it on demand -- under RCCL that is a COLLECTIVE call (every rank makes it).
  * mcl_exchange_stats: particle states this shard sent to peers and lost slots it filled, summed since the last reset. */
 int mcl_exchange_stats(mcl_handle* h, int64_t* states_sent, int64_t* lost_slots, int32_t reset);
+/* Point-to-point operations (ncclSend + ncclRecv; device copies in a LOCAL group) this shard issued in `resamples`
+ * exchanges since the last reset.  A surplus copy travels as ONE record of its non-uniform components (x, y, yaw right
+ * after a predict) and the copies a peer needs are contiguous, so an exchange is at most 2 (world - 1) operations. */
+int mcl_exchange_ops(mcl_handle* h, int64_t* p2p_ops, int64_t* resamples, int32_t reset);
 /* The transfer plan of that exchange as pure host arithmetic (no device, no handle): given every shard's lost-slot
  * and surplus-copy counts, what `rank` sends to / receives from each peer r -- send_off / send_cnt: a range of rank's
  * packed surplus list; recv_off / recv_cnt: a range of rank's lost ranks; entry [rank] is the part that stays at home.
@@ -300,7 +318,7 @@ int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64
  * spatial order the previous step's gather prepared (bins of x, y, yaw: DESIGN.md 5 "particle order"), 0 when they are
  * the slots themselves (slots[] is then the identity).  Only the visiting order ever changes: state slots, RNG keys and
  * keep / lost / dupes (auv_pf.py:183-198) do not, and no log-likelihood depends on it.  MCL_VISIT=0 switches the
- * spatial order off, MCL_VISIT=1 forces it for shards of any size (default: >= 32 768 particles).  slots: n entries. */
+ * spatial order off, MCL_VISIT=1 forces it for shards of any size (default: >= 393 216 particles).  slots: n entries. */
 int mcl_mbes_visit_order(mcl_handle* h, uint32_t* slots, int32_t* sorted);
 
 #ifdef __cplusplus

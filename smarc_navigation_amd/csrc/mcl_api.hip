@@ -204,7 +204,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_buf[0], h->sweep_buf[1], h->defer_idx, h->visit_okey, h->visit_hist, h->visit_binbase, h->visit_bintot, h->visit_par, h->reasons_dev, h->grid_pad, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_buf[0], h->sweep_buf[1], h->defer_idx, h->visit_okey, h->visit_base, h->visit_cnt, h->visit_desc, h->visit_par, h->reasons_dev, h->grid_pad, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev, h->lsx, h->xsend, h->xrecv};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -926,6 +926,14 @@ int mcl_exchange_stats(mcl_handle* h, int64_t* states_sent, int64_t* lost_slots,
   if (states_sent) *states_sent = (int64_t)h->ex_sent;
   if (lost_slots) *lost_slots = (int64_t)h->ex_lost;
   if (reset) h->ex_sent = h->ex_lost = 0;
+  return MCL_OK;
+}
+
+int mcl_exchange_ops(mcl_handle* h, int64_t* p2p_ops, int64_t* resamples, int32_t reset) {
+  if (!h) return MCL_ERR_INVALID;
+  if (p2p_ops) *p2p_ops = (int64_t)h->ex_ops;
+  if (resamples) *resamples = (int64_t)h->ex_rounds;
+  if (reset) h->ex_ops = h->ex_rounds = 0;
   return MCL_OK;
 }
 

@@ -38,7 +38,6 @@
 #define CTRL_T_QUANT (CTRL_WORK + 12)      // u32 tickets, self-resetting
 #define CTRL_T_EXPAND (CTRL_WORK + 16)
 #define CTRL_T_GATHER (CTRL_WORK + 20)
-#define CTRL_T_VISIT (CTRL_WORK + 24)
 #define CTRL_BYTES 1024
 
 namespace {
@@ -142,16 +141,21 @@ struct mcl_handle {
   unsigned* reasons_dev = nullptr;  // -DSWEEP_REASONS builds: why the sweep declined (16 counters)
   // spatial visiting order of the sweep (mcl_kernels.h: VisitArgs): prepared by the fused step's gather, used by the
   // next fused predict
-  u32 *visit_okey = nullptr, *visit_hist = nullptr, *visit_binbase = nullptr, *visit_bintot = nullptr;
+  u32 *visit_okey = nullptr, *visit_base = nullptr;
+  unsigned short* visit_cnt = nullptr;
+  u64* visit_desc = nullptr;
+  u32 visit_epoch = 0;
   VisitPar* visit_par = nullptr;    // two entries: read / written alternately
   unsigned visit_flip = 0;
   bool gather_attr_set = false;     // k_resample_gather<true, true, true> may use its 112 KiB of dynamic LDS
   bool visit_ready = false;         // okey / hist / binbase describe the slots of the current state
   bool pose_visit = false;          // pose_dev lies in visiting order (written by the last fused predict)
   int env_visit = -1;               // MCL_VISIT=0/1 forces the decision (tests, A/B)
-  int visit_nb[3] = {16, 16, 16};   // MCL_VISIT_BINS=x,y,yaw
-  float visit_range = 4.f;          // MCL_VISIT_RANGE: bins span mean +- range * sigma
-  long long visit_min_n = 32768;    // MCL_VISIT_MIN_N: smaller shards are visited in slot order
+  int visit_nb[3] = {16, 32, 8};    // MCL_VISIT_BINS=x,y,yaw  (measured at 1 M x 512, sweep us: 8,8,8 277; 16,16,8 268; 16,16,16 265; 16,32,8 263)
+  float visit_range = 3.f;          // MCL_VISIT_RANGE: bins span mean +- range * sigma  (4: 260.5, 3: 257.2, 2.5: 257.1)
+  long long visit_min_n = 393216;   // MCL_VISIT_MIN_N: smaller shards are visited in slot order (the order costs ~20 us per step whatever
+                                    // the size -- a launch, a second gather pass, scattered record stores --: measured worth +5 us at
+                                    // 524 288 x 512, -9 us at 65 536 x 256)
   int env_sweep = -1;               // MCL_SWEEP=0/1 forces the decision (tests, A/B)
   int env_nsub = 0;                 // MCL_SWEEP_NSUB=1/2/4 forces the lanes per particle side (A/B)
   bool sweep_now = false;           // decided by the first launch_mbes call of an update
@@ -207,6 +211,8 @@ struct mcl_handle {
   std::vector<u32> ex_L, ex_S;   // per shard, filled by exchange_ls
   std::vector<u32> ex_Lpre, ex_Spre;
   unsigned long long ex_sent = 0, ex_lost = 0;  // particle states sent to peers / lost slots, summed over the resamples
+  unsigned long long ex_ops = 0, ex_rounds = 0; // point-to-point operations (sends + receives) issued, likewise; exchanges
+  int ex_nship = 6;                             // doubles per exchanged copy (3 right after a predict: x, y, yaw)
   bool cdf_global = false;       // ncum holds the GLOBAL offspring CDF (else only this shard's slice)
   std::vector<mcl_handle*> group;  // LOCAL group this shard was last resampled in (lazy CDF all-gather)
   // environment switches, read once in mcl_create (never on the per-measurement path)

@@ -31,7 +31,7 @@ int exchange_sums(mcl_handle** sh, int ns, int off, int cnt) {
   if (ns == 1) {
     mcl_handle* h = sh[0];
     if (h->comm) {
-      t_begin(h, MCL_K_COMM);
+      t_begin(h, MCL_K_COMM_MOMENTS);
       NCCLCHK(h, ncclAllReduce(h->scal + off, h->scal + off, cnt, ncclDouble, ncclSum, h->comm, h->stream));
       t_end(h);
     }

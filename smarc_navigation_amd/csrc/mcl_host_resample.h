@@ -91,7 +91,7 @@ int exchange_totals(mcl_handle** sh, int ns) {
   if (ns == 1) {
     mcl_handle* h = sh[0];
     if (h->comm) {
-      t_begin(h, MCL_K_COMM);
+      t_begin(h, MCL_K_COMM_RECORDS);
       NCCLCHK(h, ncclAllGather(h->totals + h->rank, h->totals, 1, ncclUint64, h->comm, h->stream));
       t_end(h);
     }
@@ -288,7 +288,7 @@ int exchange_ls(mcl_handle** sh, int ns) {
   const int world = sh[0]->world;
   if (ns == 1) {
     mcl_handle* h = sh[0];
-    t_begin(h, MCL_K_COMM);
+    t_begin(h, MCL_K_COMM_RECORDS);
     if (h->comm && world > 1)
       NCCLCHK(h, ncclAllGather(h->lsx + 4 * (size_t)h->rank, h->lsx, 4, ncclUint64, h->comm, h->stream));
     if (h->lsx_host_dev) {
@@ -366,13 +366,18 @@ int launch_pack(mcl_handle* h, u64 publish_seq) {
   a.rank = h->rank;
   a.world = h->world;
   a.cap = (u32)std::min<size_t>(h->xsend_cap, 0xffffffffull);
-  a.uni_mask = h->gather_uni_mask;
-  a.send = state_ptrs(h->xsend, (long long)h->xsend_cap);
-  a.recv = state_ptrs(h->xrecv, h->n);
+  a.nship = 0;
+  for (int c = 0; c < 6; ++c) {
+    a.ship[c] = 0;
+    if (!((h->gather_uni_mask >> c) & 1u)) a.ship[a.nship++] = c;
+  }
+  h->ex_nship = a.nship;
+  a.send = h->xsend;
+  a.recv = h->xrecv;
   a.host_words = publish_seq ? h->lsx_host_dev : nullptr;
   a.host_seq = publish_seq ? h->lsx_host_dev + 4 * (size_t)h->world : nullptr;
   a.seq = publish_seq;
-  t_begin(h, MCL_K_RESAMPLE);
+  t_begin(h, MCL_K_PACK);
   k_pack_dupes<<<(unsigned)std::min<long long>(grid_for(h->n), 512), MCL_BLOCK, 0, h->stream>>>(a);
   t_end(h);
   HIPCHK(h, hipGetLastError());
@@ -413,25 +418,27 @@ int exchange_dupes(mcl_handle** sh, int ns) {
   if (ns == 1) {
     mcl_handle* h = sh[0];
     h->ex_lost += h->ex_L[h->rank];
+    ++h->ex_rounds;
     if (!h->comm || h->world == 1) return MCL_OK;
     const int q = h->rank;
-    t_begin(h, MCL_K_COMM);
+    const size_t K = (size_t)h->ex_nship;
+    t_begin(h, MCL_K_COMM_P2P);
     NCCLCHK(h, ncclGroupStart());
     for (int r = 0; r < h->world; ++r) {
       if (r == q) continue;
       u32 lo, hi;
       ex_range(h, q, r, lo, hi);  // what I hold and r needs
+      // (ONE send and ONE receive per peer: a copy is one record of K doubles, the range a peer needs is contiguous)
       if (hi > lo) {
         h->ex_sent += hi - lo;
-        for (int c = 0; c < 6; ++c)
-          if (!((h->gather_uni_mask >> c) & 1u))
-            NCCLCHK(h, ncclSend(h->xsend + (size_t)c * h->xsend_cap + (lo - h->ex_Spre[q]), (size_t)(hi - lo), ncclDouble, r, h->comm, h->stream));
+        NCCLCHK(h, ncclSend(h->xsend + (size_t)(lo - h->ex_Spre[q]) * K, (size_t)(hi - lo) * K, ncclDouble, r, h->comm, h->stream));
+        ++h->ex_ops;
       }
       ex_range(h, r, q, lo, hi);  // what r holds and I need
-      if (hi > lo)
-        for (int c = 0; c < 6; ++c)
-          if (!((h->gather_uni_mask >> c) & 1u))
-            NCCLCHK(h, ncclRecv(h->xrecv + (size_t)c * h->n + (lo - h->ex_Lpre[q]), (size_t)(hi - lo), ncclDouble, r, h->comm, h->stream));
+      if (hi > lo) {
+        NCCLCHK(h, ncclRecv(h->xrecv + (size_t)(lo - h->ex_Lpre[q]) * K, (size_t)(hi - lo) * K, ncclDouble, r, h->comm, h->stream));
+        ++h->ex_ops;
+      }
     }
     NCCLCHK(h, ncclGroupEnd());
     t_end(h);
@@ -443,6 +450,7 @@ int exchange_dupes(mcl_handle** sh, int ns) {
     mcl_handle* D = sh[d];
     RET_IF(set_device(D));
     D->ex_lost += D->ex_L[d];
+    ++D->ex_rounds;
     for (int s = 0; s < ns; ++s) {
       if (s == d) continue;
       mcl_handle* S = sh[s];
@@ -450,11 +458,11 @@ int exchange_dupes(mcl_handle** sh, int ns) {
       ex_range(D, s, d, lo, hi);
       if (hi <= lo) continue;
       S->ex_sent += hi - lo;
-      for (int c = 0; c < 6; ++c)
-        if (!((D->gather_uni_mask >> c) & 1u))
-          HIPCHK(D, hipMemcpyAsync(D->xrecv + (size_t)c * D->n + (lo - D->ex_Lpre[d]),
-                                   S->xsend + (size_t)c * S->xsend_cap + (lo - S->ex_Spre[s]),
-                                   sizeof(double) * (size_t)(hi - lo), hipMemcpyDefault, D->stream));
+      ++S->ex_ops;
+      ++D->ex_ops;
+      const size_t K = (size_t)D->ex_nship;
+      HIPCHK(D, hipMemcpyAsync(D->xrecv + (size_t)(lo - D->ex_Lpre[d]) * K, S->xsend + (size_t)(lo - S->ex_Spre[s]) * K,
+                               sizeof(double) * (size_t)(hi - lo) * K, hipMemcpyDefault, D->stream));
     }
   }
   for (int d = 0; d < ns; ++d) HIPCHK(sh[d], hipStreamSynchronize(sh[d]->stream));
@@ -491,7 +499,16 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   const bool p2p = multi && !h->exch_allgather;
   a.src = (multi && !p2p) ? state_ptrs(h->state_glob, h->ng) : state_ptrs(h->state[h->cur], h->n);
   a.recv_mode = p2p ? 1 : 0;
-  a.recv = p2p ? state_ptrs(h->xrecv, h->n) : a.src;
+  a.recv_stride = 1;
+  a.recv = a.src;
+  if (p2p) {   // records of ex_nship doubles (k_pack_dupes): component c is word j of its copy's record
+    a.recv_stride = h->ex_nship;
+    int j = 0;
+    for (int c = 0; c < 6; ++c) {
+      a.recv.c[c] = h->xrecv + j;
+      if (!((h->gather_uni_mask >> c) & 1u)) ++j;
+    }
+  }
   a.shift_dev = p2p ? (const double*)(h->lsx + 1) : nullptr;
   a.dst = state_ptrs(h->state[h->cur ^ 1], h->n);
   a.n = h->n;
@@ -526,21 +543,25 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   //  x, y, yaw only; it also prepares the visiting order)
   const bool uni = a.uni_mask == 0x1cu;   // z, roll, pitch substituted: the lean kernel
   const bool stash = with_moments && uni && a.nz.sq[2] == 0.0 && a.nz.sq[3] == 0.0 && a.nz.sq[4] == 0.0;
-  const bool visit = stash && !rp && h->sweep_now && h->env_visit != 0 && (h->env_visit == 1 || h->n >= h->visit_min_n);
+  // (16-bit counts: at most 65 535 particles per gather workgroup)
+  const bool visit = stash && !rp && h->sweep_now && h->env_visit != 0 && (h->env_visit == 1 || h->n >= h->visit_min_n) &&
+                     h->n <= 65535ll * GATHER_MAX_GRID;
   if (visit) {
     const int nb = h->visit_nb[0] * h->visit_nb[1] * h->visit_nb[2];
     if (!h->visit_okey) {
       HIPCHK(h, hipMalloc(&h->visit_okey, sizeof(u32) * (size_t)h->n));
-      HIPCHK(h, hipMalloc(&h->visit_hist, sizeof(u32) * (size_t)GATHER_MAX_GRID * VISIT_MAX_BINS));
-      HIPCHK(h, hipMalloc(&h->visit_binbase, sizeof(u32) * VISIT_MAX_BINS));
-      HIPCHK(h, hipMalloc(&h->visit_bintot, sizeof(u32) * VISIT_MAX_BINS));
+      HIPCHK(h, hipMalloc(&h->visit_base, sizeof(u32) * (size_t)GATHER_MAX_GRID * VISIT_MAX_BINS));
+      HIPCHK(h, hipMalloc(&h->visit_cnt, sizeof(unsigned short) * (size_t)GATHER_MAX_GRID * VISIT_MAX_BINS));
+      HIPCHK(h, hipMalloc(&h->visit_desc, sizeof(u64) * (VISIT_MAX_BINS / 64)));
+      HIPCHK(h, hipMemsetAsync(h->visit_desc, 0, sizeof(u64) * (VISIT_MAX_BINS / 64), h->stream));
       HIPCHK(h, hipMalloc(&h->visit_par, sizeof(VisitPar) * 2));
       HIPCHK(h, hipMemsetAsync(h->visit_par, 0, sizeof(VisitPar) * 2, h->stream));
     }
     a.visit.okey = h->visit_okey;
-    a.visit.hist = h->visit_hist;
-    a.visit.binbase = h->visit_binbase;
-    a.visit.bintot = h->visit_bintot;
+    a.visit.cnt = h->visit_cnt;
+    a.visit.base = h->visit_base;
+    a.visit.desc = h->visit_desc;
+    a.visit.epoch = ++h->visit_epoch;
     a.visit.par_in = h->visit_par + (h->visit_flip & 1u);
     a.visit.par_out = h->visit_par + ((h->visit_flip & 1u) ^ 1u);
     h->visit_flip ^= 1u;
@@ -549,6 +570,14 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
     a.visit.nbw = h->visit_nb[2];
     a.visit.nb = nb;
     a.visit.range = h->visit_range;
+    a.visit.psq[0] = (float)std::sqrt(h->cfg.process_cov[0]);
+    a.visit.psq[1] = (float)std::sqrt(h->cfg.process_cov[1]);
+    a.visit.psq[2] = (float)std::sqrt(h->cfg.process_cov[5]);
+    a.visit.pstep = h->step_predict;
+    {
+      static const bool preview = !(getenv("MCL_VISIT_NOISE") && atoi(getenv("MCL_VISIT_NOISE")) == 0);   // (A/B switch)
+      if (!preview) a.visit.psq[0] = a.visit.psq[1] = a.visit.psq[2] = 0.f;
+    }
   }
   t_begin(h, MCL_K_RESAMPLE);
   // one particle per thread up to 256 blocks (= 256 tickets), grid-stride beyond
@@ -569,7 +598,7 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   else
     k_resample_gather<false><<<(unsigned)gg, RS_BLOCK, 0, h->stream>>>(a, rp);
   if (visit) {
-    k_visit_scan<<<(unsigned)(a.visit.nb / 64), 1024, 0, h->stream>>>(a.visit, (int)gg, ctrl_u32(h, CTRL_T_VISIT));
+    k_visit_scan<<<(unsigned)(a.visit.nb / 64), 1024, 0, h->stream>>>(a.visit, (int)gg);
     h->visit_ready = true;
   }
   t_end(h);
@@ -778,7 +807,7 @@ int run_resample(mcl_handle** sh, int ns, const double* uniforms, long long nu,
     RET_IF(ensure_max_slots(h0));
     t_end(h0);
     if (h0->comm && h0->world > 1) {
-      t_begin(h0, MCL_K_COMM);
+      t_begin(h0, MCL_K_COMM_RECORDS);
       NCCLCHK(h0, ncclAllReduce(ctrl_slots(h0), ctrl_slots(h0), MCL_MAX_SLOTS, ncclUint64, ncclMax, h0->comm, h0->stream));
       t_end(h0);
     }

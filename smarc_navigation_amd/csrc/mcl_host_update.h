@@ -627,7 +627,7 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
   a.zero_ptr = nullptr;
   a.zero_words = 0;
   a.skip_uniform = 0;
-  a.visit_okey = a.visit_base = a.visit_binbase = nullptr;
+  a.visit_okey = a.visit_base = nullptr;
   a.visit_nb = 0;
   h->pose_visit = false;
   const double* rp = nullptr;
@@ -659,8 +659,7 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
         // the fan sweep visits the particles in the spatial order the last gather prepared: the records go to their
         // sorted positions (the sweep writes log-likelihoods by the slot in the record)
         a.visit_okey = h->visit_okey;
-        a.visit_base = h->visit_hist;
-        a.visit_binbase = h->visit_binbase;
+        a.visit_base = h->visit_base;
         a.visit_nb = h->visit_nb[0] * h->visit_nb[1] * h->visit_nb[2];
         h->pose_visit = true;
       }

@@ -26,7 +26,7 @@ struct NoiseArgs {
 // the cloud one step earlier, extrapolated by one step of its drift -- and counts, per workgroup, how many of its
 // particles fell into each bin, handing every particle its rank inside (workgroup, bin); k_visit_scan turns the
 // count matrix into start positions; the predict kernel of the NEXT step writes the pose record of slot i to position
-// binbase[key] + colbase[workgroup of i][key] + rank (an exact counting sort: a bijection onto [0, n)) with the slot
+// base[workgroup of i][key] + rank (an exact counting sort: a bijection onto [0, n)) with the slot
 // in the record.  State slots, RNG keys (global ids) and keep / lost / dupes are untouched (auv_pf.py:183-198), and
 // by the determinism rule (mcl_mbes.h) the order in which particles are cast changes no log-likelihood.
 #define VISIT_MAX_BINS 4096
@@ -41,13 +41,19 @@ struct VisitPar {    // written by the gather's last block for the next gather
 };
 struct VisitArgs {
   u32* okey;             // per slot: key | rank << VISIT_KEY_BITS        (nullptr: no visiting order)
-  u32* hist;             // [workgroup][nb]: counts, then (k_visit_scan, in place) exclusive positions inside the bin
-  u32* binbase;          // [nb] first position of every bin
-  u32* bintot;           // [nb] scratch
+  unsigned short* cnt;   // [workgroup][nb]: particles of a gather workgroup per bin (<= 65 535: the host checks)
+  u32* base;             // [workgroup][nb]: (k_visit_scan) position of that workgroup's first particle of the bin
+  u64* desc;             // nb / 64 look-back descriptors of k_visit_scan: epoch << 32 | particles in the workgroup's 64 bins
+  u32 epoch;             // differs from launch to launch: stale descriptors are never valid
   const VisitPar* par_in;
   VisitPar* par_out;
   int nbx, nby, nbw, nb; // bins per dimension, nb = nbx * nby * nbw <= VISIT_MAX_BINS, a multiple of 64
   float range;           // bins span mean +- range * sigma
+  // the process noise the NEXT predict will add (Philox is counter-based: its draws are known now) -- the key is taken
+  // from where the particle will be cast, not from where the gather leaves it: sqrt of the x, y, yaw process
+  // covariances and the predict's step counter (a guess: any other next call only blurs the bins)
+  float psq[3];
+  u32 pstep;
 };
 __device__ __forceinline__ u32 load_agent(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -113,7 +119,6 @@ struct PredictArgs {
   // visiting order (see VisitArgs): when set, the pose record of slot i goes to its sorted position
   const u32* visit_okey;
   const u32* visit_base;
-  const u32* visit_binbase;
   int visit_nb;
 };
 // z, roll, pitch of every particle := the three constants (the deferred stores of a fused step that did not reach

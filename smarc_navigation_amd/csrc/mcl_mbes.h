@@ -344,13 +344,13 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_predict_pose(StatePtrs s, long lo
     P.um = P.vm = 0.0;
     P.oz = 0.f;
     if (valid) {
-      // where this slot's record goes: its place in the visiting order the last gather prepared (two loads, in flight
-      // during the arithmetic below), or the slot itself
+      // where this slot's record goes: its place in the visiting order the last gather prepared (two dependent loads,
+      // in flight during the arithmetic below), or the slot itself
       u32 pos = (u32)i;
       if (!CLASSIFY && a.visit_okey) {
         const u32 ok = a.visit_okey[i], key = ok & ((1u << VISIT_KEY_BITS) - 1u);
         const u32 owner = ((u32)i >> VISIT_OWNER_SHIFT) & VISIT_OWNER_MASK;
-        pos = a.visit_binbase[key] + a.visit_base[(size_t)owner * a.visit_nb + key] + (ok >> VISIT_KEY_BITS);
+        pos = a.visit_base[(size_t)owner * a.visit_nb + key] + (ok >> VISIT_KEY_BITS);
       }
       u32x4 o = philox4x32((u32)(a.nz.gid0 + i), 0u, a.nz.step, 1u, a.nz.k0, a.nz.k1);
       double n0, n1, n5, unused;

@@ -327,11 +327,15 @@ struct PackArgs {
   const u32* dupes;    // local ancestor index of every surplus copy
   const u64* lsx;      // hand-over records of every shard (device): word 0 of record r = L_r | S_r << 32
   int rank, world;
-  u32 cap;             // capacity of the send buffer (entries per component): copies beyond it are dropped, the host
-                       // sees S > cap in the same records, grows the buffer and packs again
-  unsigned uni_mask;   // components that are not shipped (the same value on every particle of the cloud)
-  StatePtrs send;      // [c][cap]
-  StatePtrs recv;      // [c][L]
+  u32 cap;             // capacity of the send buffer (copies): copies beyond it are dropped, the host sees S > cap in
+                       // the same records, grows the buffer and packs again
+  // A copy travels as ONE record of `nship` doubles -- the components that are not the same value on every particle of
+  // the cloud (x, y, yaw right after a predict; all six otherwise), ship[j] = component of word j -- so that the copies a
+  // peer needs, contiguous in the global dupes order, are ONE contiguous block: one ncclSend / ncclRecv per peer
+  int nship;
+  int ship[6];
+  double* send;        // [cap][nship]
+  double* recv;        // [L][nship]
   // when set, workgroup 0 first copies the records to pinned host memory and then writes the sequence word the host
   // spins on (system-scope release: the records are visible before it) -- a stream synchronisation costs the host tens
   // of microseconds of wake-up, this a few
@@ -364,15 +368,10 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_pack_dupes(PackArgs a) {
     const u32 anc = a.dupes[p];
     const u32 g = Spre + p;
     const bool self = g >= Lpre && g - Lpre < L;
+    double* rec = self ? a.recv + (size_t)(g - Lpre) * a.nship : a.send + (size_t)p * a.nship;
 #pragma unroll
-    for (int c = 0; c < 6; ++c)
-      if (!((a.uni_mask >> c) & 1u)) {
-        const double v = a.src.c[c][anc];
-        if (self)
-          a.recv.c[c][g - Lpre] = v;
-        else
-          a.send.c[c][p] = v;
-      }
+    for (int j = 0; j < 6; ++j)
+      if (j < a.nship) rec[j] = a.src.c[a.ship[j]][anc];
   }
 }
 // ------------------------------------------------------------------ K3: gather + noise (+ fused moments)
@@ -394,9 +393,11 @@ struct GatherArgs {
   unsigned uni_mask;
   double uni[6];
   // O(n) exchange: src is this shard's OWN pre-resample state (local indexing), zr holds LOCAL lost ranks and a lost
-  // slot reads recv.c[c][rank]; shift_dev = the position of global particle 0 (every rank has it from the hand-over
+  // slot reads its copy's record: recv.c[c] points at component c's word of record 0, records are recv_stride doubles
+  // apart (k_pack_dupes); shift_dev = the position of global particle 0 (every rank has it from the hand-over
   // records).  recv_mode 0: the look-up through the dupes list into src (single shard / all-gathered state).
   int recv_mode;
+  int recv_stride;
   StatePtrs recv;
   const double* shift_dev;
   // MOMENTS: the visiting order of the NEXT fan sweep (mcl_kernels.h: VisitArgs); visit.okey == nullptr: none
@@ -415,6 +416,14 @@ struct GatherArgs {
 // (workgroup, bin) from an LDS counter.
 #define GATHER_STASH 4
 #define GATHER_STASH_LDS (3 * GATHER_STASH * RS_BLOCK * sizeof(double) + VISIT_MAX_BINS * sizeof(u32))
+// Box-Muller in fast fp32 (v_log_f32, v_sin_f32 / v_cos_f32 take turns): the visiting order only needs the coming process
+// noise to a fraction of a bin
+__device__ __forceinline__ void box_muller_fast(u32 ua, u32 ub, float& n0, float& n1) {
+  const float u1 = ((float)(ua >> 8) + 0.5f) * (1.f / 16777216.f), u2 = (float)(ub >> 8) * (1.f / 16777216.f);
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), log2 in hardware
+  n0 = r * __builtin_amdgcn_cosf(u2);
+  n1 = r * __builtin_amdgcn_sinf(u2);
+}
 __device__ __forceinline__ void moments_add(double (&acc)[MOM_COUNT], const double (&v)[6], const double (&shift)[3], double& wy) {
   const double dx = v[0] - shift[0], dy = v[1] - shift[1], dz = v[2] - shift[2];
   acc[0] += dx;
@@ -465,7 +474,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
   bool from_recv = false;
   if (i < a.n) {
     const bool surv = r == ZR_SURVIVOR;
-    src = a.recv_mode ? (surv ? i : (long long)r) : (surv ? a.goff + i : (long long)a.dupes[r]);
+    src = a.recv_mode ? (surv ? i : (long long)r * a.recv_stride) : (surv ? a.goff + i : (long long)a.dupes[r]);
     from_recv = a.recv_mode && !surv;
   }
   int it = 0;
@@ -492,7 +501,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
     }
     // ... and its ancestor (rn has arrived by now): in flight during the stores and the moments
     const bool survn = rn == ZR_SURVIVOR;
-    const long long srcn = a.recv_mode ? (survn ? in : (long long)rn) : (survn ? a.goff + in : (long long)a.dupes[rn]);
+    const long long srcn = a.recv_mode ? (survn ? in : (long long)rn * a.recv_stride) : (survn ? a.goff + in : (long long)a.dupes[rn]);
     if (!UNI) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
@@ -555,10 +564,18 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
       if (visit) {
         const float dw = (float)(wy - vp.mean[2]);
         vacc = fmaf(dw, dw, vacc);   // (the yaw spread the NEXT bins need: the 14th partial sum; fp32 is plenty)
+        // where the next predict's noise will put the particle (auv_particle.py:40,47,65: the same Philox block as
+        // k_predict_pose, the normals in fast fp32) -- the common motion moves every particle alike
+        const u32x4 o = philox4x32((u32)(a.goff + j), 0u, a.visit.pstep, 1u, a.nz.k0, a.nz.k1);
+        float n0, n1, n5, unused;
+        box_muller_fast(o.x, o.y, n0, n1);
+        box_muller_fast(o.z, o.w, n5, unused);
+        const float px = fmaf(a.visit.psq[0], n0, (float)(v[0] - shift[0])), py = fmaf(a.visit.psq[1], n1, (float)(v[1] - shift[1]));
+        const float pw = fmaf(a.visit.psq[2], n5, dw);
         // (fmaxf / min: a NaN coordinate lands in bin 0)
-        const int kx = min((int)fmaxf(fmaf((float)(v[0] - shift[0]), vp.inv[0], -ox), 0.f), a.visit.nbx - 1);
-        const int ky = min((int)fmaxf(fmaf((float)(v[1] - shift[1]), vp.inv[1], -oy), 0.f), a.visit.nby - 1);
-        const int kw = min((int)fmaxf(fmaf(dw, vp.inv[2], -ow), 0.f), a.visit.nbw - 1);
+        const int kx = min((int)fmaxf(fmaf(px, vp.inv[0], -ox), 0.f), a.visit.nbx - 1);
+        const int ky = min((int)fmaxf(fmaf(py, vp.inv[1], -oy), 0.f), a.visit.nby - 1);
+        const int kw = min((int)fmaxf(fmaf(pw, vp.inv[2], -ow), 0.f), a.visit.nbw - 1);
         const u32 key = (u32)((kx * a.visit.nby + ky) * a.visit.nbw + kw);
         const u32 rank = atomicAdd(&vhist[key], 1u);   // LDS: the particle's place among this workgroup's members of the bin
         a.visit.okey[j] = key | (rank << VISIT_KEY_BITS);
@@ -575,8 +592,10 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
     if (lane == 0) red[MOM_COUNT][w] = (double)s;
   }
   __syncthreads();
-  if (visit)   // this workgroup's row of the count matrix (plain stores: read by the NEXT launch, k_visit_scan)
-    for (int k = threadIdx.x; k < a.visit.nb; k += RS_BLOCK) a.visit.hist[(size_t)blockIdx.x * a.visit.nb + k] = vhist[k];
+  if (visit) {   // this workgroup's row of the count matrix, two 16-bit counts per word (plain stores: read by the NEXT launch, k_visit_scan)
+    u32* row = (u32*)(a.visit.cnt + (size_t)blockIdx.x * a.visit.nb);
+    for (int k = threadIdx.x; 2 * k < a.visit.nb; k += RS_BLOCK) row[k] = vhist[2 * k] | (vhist[2 * k + 1] << 16);
+  }
   if (w == 0) {
     // wave 0: lanes 0..12 publish this block's 13 partial sums (ONE write-through store instruction), drain it,
     // then lane 0 draws the ticket -- no release fence: only these words are read inside the launch
@@ -641,13 +660,14 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
 }
 
 // ------------------------------------------------------------------ visiting order: counts -> positions
-// hist[G][nb] (one row per gather workgroup) becomes, in place, the number of particles of EARLIER workgroups in the
-// same bin; binbase[b] = particles in bins < b.  One workgroup per 64 bins, wave r takes a run of ceil(G / 16) rows;
-// the workgroup that draws the last ticket scans the nb bin totals.
-__global__ void __launch_bounds__(1024) k_visit_scan(VisitArgs a, int G, u32* ticket) {
+// cnt[G][nb] (one row per gather workgroup) -> base[G][nb]: position of the workgroup's first particle of the bin =
+// particles in earlier bins + particles of earlier workgroups in the same bin.  One workgroup per 64 bins (at most 64
+// of them: all resident), wave r takes a run of ceil(G / 16) rows; the particles in earlier bins come from a look-back
+// over the other workgroups' descriptors -- ONE wave reads all of them at once --, so there is no second pass and no
+// "last block".
+__global__ void __launch_bounds__(1024) k_visit_scan(VisitArgs a, int G) {
   __shared__ u32 sh[16][64];
-  __shared__ u32 wsum[16];
-  __shared__ u32 last_sh;
+  __shared__ u32 binbase[64];
   const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
   const int bin = blockIdx.x * 64 + lane;
   const int rpg = (G + 15) >> 4;
@@ -655,7 +675,7 @@ __global__ void __launch_bounds__(1024) k_visit_scan(VisitArgs a, int G, u32* ti
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int row = r * rpg + k;
-    v[k] = (k < rpg && row < G) ? a.hist[(size_t)row * a.nb + bin] : 0u;
+    v[k] = (k < rpg && row < G) ? (u32)a.cnt[(size_t)row * a.nb + bin] : 0u;
   }
   u32 t = 0u;
 #pragma unroll
@@ -673,36 +693,28 @@ __global__ void __launch_bounds__(1024) k_visit_scan(VisitArgs a, int G, u32* ti
     off += k < r ? x : 0u;
     tot += x;
   }
+  if (r == 0) {
+    // this workgroup's 64 bin totals -> its descriptor; the particles of the workgroups before it
+    const u32 incl = wave_scan_incl_dpp(tot);
+    const u32 mine = readlane63(incl);
+    const u64 tag = (u64)a.epoch << 32;
+    if (lane == 0) store_agent(&a.desc[blockIdx.x], tag | (u64)mine);
+    u32 before = 0u;
+    for (;;) {
+      const u64 d = lane < (int)blockIdx.x ? load_agent(&a.desc[lane]) : tag;
+      if (__ballot((d >> 32) == (u64)a.epoch) == ~0ull) {
+        before = wave_sum_dpp(lane < (int)blockIdx.x ? (u32)d : 0u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    binbase[lane] = before + incl - tot;
+  }
+  __syncthreads();
+  const u32 bb = binbase[lane] + off;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int row = r * rpg + k;
-    if (k < rpg && row < G) a.hist[(size_t)row * a.nb + bin] = off + v[k];
+    if (k < rpg && row < G) a.base[(size_t)row * a.nb + bin] = bb + v[k];
   }
-  if (r == 0) {
-    store_agent(&a.bintot[bin], tot);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) last_sh = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
-  }
-  __syncthreads();
-  if (!last_sh) return;
-  // exclusive scan of the bin totals (nb <= 4096: four per thread, blocked)
-  u32 x[4], run = 0u;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int b = threadIdx.x * 4 + k;
-    x[k] = b < a.nb ? load_agent(&a.bintot[b]) : 0u;
-    run += x[k];
-  }
-  const u32 incl = wave_scan_incl_dpp(run);
-  if (lane == 63) wsum[r] = incl;
-  __syncthreads();
-  u32 base = incl - run;
-  for (int k = 0; k < r; ++k) base += wsum[k];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int b = threadIdx.x * 4 + k;
-    if (b < a.nb) a.binbase[b] = base;
-    base += x[k];
-  }
-  if (threadIdx.x == 0) *ticket = 0u;
 }

@@ -238,6 +238,12 @@ class Engine(object):
         self._ck(self.lib.mcl_exchange_stats(self.h, C.byref(a), C.byref(b), 1 if reset else 0))
         return int(a.value), int(b.value)
 
+    def exchange_ops(self, reset=False):
+        """(point-to-point operations issued, exchanges) by the sharded resamples since the last reset"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._ck(self.lib.mcl_exchange_ops(self.h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return int(a.value), int(b.value)
+
     # ---- instrumentation
     def timing_enable(self, on=True):
         self._ck(self.lib.mcl_timing_enable(self.h, 1 if on else 0))

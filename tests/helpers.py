@@ -111,3 +111,86 @@ def replay(g, backend, check=None):
         if (k + 1) % 25 == 0 or k == n_steps - 1:
             out['ckpt_states'].append(backend.state())
     return out
+
+
+def outliers_explained(orc, omap, soa, ba, got, ref, r_max, m2o=None, off=None, tol=1e-3, delta=1e-3, label=''):
+    """The a15 tolerance contract where it is relaxed (fp32 expected range within 1e-3 m of the fp64 oracle).
+    A beam that grazes a crest or a triangle edge is ill-conditioned: the last bit of fp32 decides between the crest and
+    the shadow behind it, and the range jumps by metres.  Tests therefore tolerate a bounded NUMBER of rays beyond the
+    tolerance -- and this function bounds HOW FAR off such a ray may be: every ray further than `tol` from the oracle
+    must be, within `tol`, an answer the fp64 oracle itself gives when the sensor moves by `delta` (1 mm) along one of the
+    six axis directions (or lie between those answers when they span a continuous branch, grazing incidence without a
+    hit / miss flip).  Asserts it ray by ray; returns (number of outliers, their largest deviation from the unperturbed
+    oracle, the largest jump between neighbouring beams of the oracle's own profile at an outlier).  Only the particles
+    that own an outlier are cast again."""
+    m2o = np.identity(4) if m2o is None else m2o
+    off = [0.0] * 6 if off is None else off
+    err = np.abs(got - ref)
+    bad = err > tol
+    if not bad.any():
+        return 0, 0.0, 0.0
+    rows = np.unique(np.nonzero(bad)[0])
+    sub = np.ascontiguousarray(soa[:, rows])
+    cands = [ref[rows]]
+    for axis in range(3):
+        for sgn in (1.0, -1.0):
+            s = sub.copy()
+            s[axis] += sgn * delta
+            _, ex = orc.mbes_update(s, m2o, off, omap, ba, None, 0.2, r_max)
+            cands.append(ex)
+    cands = np.stack(cands)                                    # 7 x rows x B
+    g = got[rows]
+    lo, hi = cands.min(axis=0), cands.max(axis=0)
+    dist = np.abs(cands - g[None]).min(axis=0)
+    cont = (hi - lo) < 0.1
+    dev = np.where(cont, np.abs(g - np.clip(g, lo, hi)), dist)
+    b = bad[rows]
+    # the local shadow jump of the oracle's own range profile: an outlier sits where neighbouring beams differ by more
+    # than the outlier is off, or where the ray's own answer moves under the 1 mm shift
+    prof = ref[rows]
+    jump = np.zeros_like(prof)
+    if prof.shape[1] > 1:
+        d = np.abs(np.diff(prof, axis=1))
+        jump[:, :-1] = d
+        jump[:, 1:] = np.maximum(jump[:, 1:], d)
+    jump = np.maximum(jump, hi - lo)
+    worst = np.unravel_index(np.argmax(np.where(b, dev, -1.0)), dev.shape)
+    assert dev[b].max() <= tol, '%s ray (particle %d, beam %d): GPU %.5f m, oracle %.5f m, oracle under 1 mm shifts %s' % (
+        label, rows[worst[0]], worst[1], g[worst], prof[worst], np.array2string(cands[(slice(None),) + worst], precision=4))
+    unexplained = b & (err[rows] > jump + tol)
+    assert not unexplained.any(), '%s: %d outlier rays are further off than the local jump of the oracle profile' % (label, int(unexplained.sum()))
+    print('%s: %d of %d rays beyond %.0e m, the worst off by %.3e m; all are oracle answers under a 1 mm shift of the sensor '
+          '(local jump of the oracle profile there: up to %.2f m)' % (label, int(bad.sum()), err.size, tol, err[bad].max(), jump[b].max()))
+    return int(bad.sum()), float(err[bad].max()), float(jump[b].max())
+
+
+def lw_outliers_explained(orc, omap, soa, ba, ranges, sigma, r_max, lw_got, lw_ref, m2o=None, off=None, delta=1e-3, label=''):
+    """The log-likelihood side of the same contract (include/mcl.h, mcl_update_mbes: |d| <= 1e-2 or 2e-4 |lw|): a particle
+    outside it must own a ray that flips between a crest and its shadow, i.e. its log-likelihood must lie inside the
+    interval the fp64 oracle spans when the sensor moves by `delta` (1 mm) along the six axis directions -- widened by
+    the usual tolerance.  Asserts it for every such particle; returns their number."""
+    m2o = np.identity(4) if m2o is None else m2o
+    off = [0.0] * 6 if off is None else off
+    d = np.abs(lw_got - lw_ref)
+    out = ~((d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref)))
+    if not out.any():
+        return 0
+    rows = np.nonzero(out)[0]
+    sub = np.ascontiguousarray(soa[:, rows])
+    cands = [lw_ref[rows]]
+    for axis in range(3):
+        for sgn in (1.0, -1.0):
+            s = sub.copy()
+            s[axis] += sgn * delta
+            lw_c, _ = orc.mbes_update(s, m2o, off, omap, ba, ranges, sigma, r_max)
+            cands.append(lw_c)
+    cands = np.stack(cands)
+    lo, hi = cands.min(axis=0), cands.max(axis=0)
+    slack = 1e-2 + 2e-4 * np.maximum(np.abs(lo), np.abs(hi))
+    g = lw_got[rows]
+    inside = (g >= lo - slack) & (g <= hi + slack)
+    assert inside.all(), '%s: particle %d: log-likelihood %.4f outside the oracle interval [%.4f, %.4f] under 1 mm shifts' % (
+        label, rows[np.argmin(inside)], g[np.argmin(inside)], lo[np.argmin(inside)], hi[np.argmin(inside)])
+    print('%s: %d particles beyond the log-likelihood tolerance (worst |d| %.3e), each inside the oracle interval under a 1 mm '
+          'shift of the sensor (widest interval %.2f)' % (label, rows.size, d[out].max(), (hi - lo).max()))
+    return int(rows.size)

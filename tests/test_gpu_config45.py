@@ -92,6 +92,8 @@ def test_config4_eight_local_shards_of_524288_fused_steps_bitwise(exchange, monk
             print('config 4 (%s): 4096 of %d log-likelihoods vs oracle: max |d| %.3e, outside tolerance %d' % (
                 exchange, N, np.abs(lw1[pick] - lw_ref).max(), int((~ok).sum())))
             assert (~ok).sum() <= 8
+            from tests.helpers import lw_outliers_explained
+            lw_outliers_explained(orc, omap, sub, ba, ranges[0], SIGMA, R_MAX, lw1[pick], lw_ref, label='config 4')
             # indices are the exact systematic resample of the GPU's own log-weights
             ref_idx, _, _ = orc.systematic_fixed(lw1, 1, orc.native_u53(5, 0))
             assert np.array_equal(idx1, ref_idx)
@@ -101,6 +103,10 @@ def test_config4_eight_local_shards_of_524288_fused_steps_bitwise(exchange, monk
         print('config 4: %d of %d copied particles crossed a shard border (%.2f %% of the cloud per step)' % (
             sent, lost, 100.0 * sent / (steps * N)))
         assert sent < lost
+        # one send and one receive per peer and exchange at most (a copy travels as one record)
+        for e in many:
+            ops, rounds = e.exchange_ops()
+            assert rounds == steps and ops <= 2 * (len(many) - 1) * rounds, (ops, rounds)
 
 
 def test_config5_eight_local_shards_with_landmark_knn_bitwise():

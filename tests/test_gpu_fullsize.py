@@ -109,6 +109,8 @@ def _spot_check(e, orc, omap, soa, ba, ranges, r_max, pick, label):
     # a grazing ray may flip under fp32 (bounded in test_rough_terrain_...): tolerate isolated particles, report them
     print('%s: %d particles checked, max |dlw| %.3e, outside tolerance %d' % (label, pick.size, d.max(), int((~okm).sum())))
     assert (~okm).sum() <= max(2, pick.size // 500)
+    from tests.helpers import lw_outliers_explained
+    lw_outliers_explained(orc, omap, sub, ba, ranges, 0.2, r_max, lw[pick], lw_ref, label=label)
     for j in range(0, pick.size, max(1, pick.size // 16)):
         got = e.mbes_expected(int(pick[j]), 1, ba, r_max)[0]
         err = np.abs(got - ex_ref[j])

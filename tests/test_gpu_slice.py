@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from smarc_navigation_amd import synth
+from tests.helpers import outliers_explained
 
 pytestmark = pytest.mark.gpu
 
@@ -92,6 +93,7 @@ def _check(eng, orc, verts, tris, soa, B, r_max, monkeypatch, general=True, max_
     print('slice: max |expected range error| %.3e m over %d rays (%d beyond 1e-3), handed over %d of %d; vs traversal %.3e' % (
         err.max(), err.size, bad, path[1], n, np.abs(got - out['0'][0]).max()))
     assert bad <= max_bad, np.sort(err.ravel())[-5:]
+    outliers_explained(orc, mesh, soa, ba, got, ref, r_max, off=off, label='slice')
     lw_ref, _ = orc.mbes_update(soa, np.identity(4), off or [0] * 6, mesh, ba, ranges, 0.2, r_max)
     rel = np.abs(lw - lw_ref) / np.maximum(1.0, np.abs(lw_ref))
     if max_bad == 0:
@@ -235,3 +237,4 @@ def test_slice_fuzz_against_the_oracle(seed, eng, orc, monkeypatch):
     print('fuzz %d: %d triangles of ~%.1f m, %d beams, handed over %d of %d; max err %.2e, %d of %d rays beyond 1e-3' % (
         seed, nt, size, B, path[1], n, err.max(), bad, err.size))
     assert bad <= max(3, err.size // 2000), np.sort(err.ravel())[-6:]
+    outliers_explained(orc, mesh, soa, ba, got, ref, r_max, label='slice fuzz %d' % seed)

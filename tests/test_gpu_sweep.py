@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from smarc_navigation_amd import synth
+from tests.helpers import lw_outliers_explained, outliers_explained
 
 pytestmark = pytest.mark.gpu
 
@@ -202,6 +203,7 @@ def test_ridge_occludes_the_seabed_behind_it(eng, orc):
     flips = (err > 1e-3).sum()
     print('ridge: %d of %d rays differ by more than 1e-3 m (max %.3e)' % (flips, err.size, err.max()))
     assert flips <= max(2, err.size // 5000)
+    outliers_explained(orc, mesh, soa, ba, got, ref, 100.0, label='ridge')
 
 
 def test_fan_tilted_beyond_the_slope_bound_is_handed_over(eng, orc):
@@ -222,6 +224,7 @@ def test_fan_tilted_beyond_the_slope_bound_is_handed_over(eng, orc):
     _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, mesh, ba, None, 0.2, 100.0)
     err = np.abs(got - ref)
     assert (err > 1e-3).sum() <= max(2, err.size // 2000), err.max()
+    outliers_explained(orc, mesh, soa, ba, got, ref, 100.0, label='tilt hand-over')
 
 
 def test_beams_on_one_side_only_and_nadir_beam(eng, orc):
@@ -363,6 +366,7 @@ def test_grid_sweep_on_twisted_patches_and_grazing_beams(eng, orc, monkeypatch):
         bad = (err > 1e-3).sum()
         print('rough grid, %s: %d of %d rays differ by more than 1e-3 m (max %.3e)' % (name, bad, err.size, err.max()))
         assert bad <= max(4, err.size // 20000)
+        outliers_explained(orc, g, soa, ba, got, ref, 90.0, label='rough grid, ' + name)
     jumps = np.abs(np.diff(ref, axis=1)) > 1.0
     assert jumps.sum() > 50   # the scene really has shadow boundaries
 
@@ -399,6 +403,7 @@ def test_grid_cell_walk_agrees_with_the_traversal_on_millions_of_rays(rough, eng
     _, ref = orc.mbes_update(np.ascontiguousarray(soa[:, pick]), np.identity(4), [0] * 6, g, ba, None, 0.2, 90.0)
     err_o = np.abs(res[True][0][pick] - ref)
     assert (err_o > 1e-3).sum() <= max(4, err_o.size // 20000)
+    outliers_explained(orc, g, np.ascontiguousarray(soa[:, pick]), ba, res[True][0][pick], ref, 90.0, label='grid cell walk sample')
 
 
 def test_grid_ridge_occlusion_and_short_r_max(eng, orc):
@@ -422,6 +427,7 @@ def test_grid_ridge_occlusion_and_short_r_max(eng, orc):
         flips = (err > 1e-3).sum()
         print('grid ridge r_max %.0f: %d of %d rays differ (max %.3e)' % (r_max, flips, err.size, err.max()))
         assert flips <= max(2, err.size // 5000)
+        outliers_explained(orc, g, soa, ba, got, ref, r_max, label='grid ridge')
 
 
 # ------------------------------------------------------------------ arbitrary height-field TINs: SURF 5 (adjacency walk)
@@ -517,6 +523,7 @@ def test_two_sheets_overlapping_in_xy_are_not_swept(eng, orc, monkeypatch):
     _, ref1 = orc.mbes_update(sub, np.identity(4), [0] * 6, orc.Mesh(verts, tris), ba, None, 0.2, 80.0)
     assert (ref1 - ref > 3.0).mean() > 0.05
     assert (err > 1e-3).sum() <= max(2, err.size // 5000), err.max()
+    outliers_explained(orc, orc.Mesh(v2, t2), sub, ba, got, ref, 80.0, label='two-sheet mesh')
     # the same seabed alone IS swept at this size
     e1 = _engine(eng, soa, verts, tris)
     e1.mbes_expected(0, 8, ba, 80.0)
@@ -685,6 +692,7 @@ def test_sweep_fuzz_against_the_oracle(seed, eng, orc):
     print('fuzz %d %s res %.1f B %d tilt %.2f r_max %.0f: handed over %d/%d, max err %.2e, rays off %d/%d' % (
         seed, kind, res, B, tilt, r_max, handed, n, err.max(), bad, err.size))
     assert bad <= max(1, err.size // 5000)
+    outliers_explained(orc, omap, soa, ba, got, ref, r_max, m2o=m2o, off=off, label='fuzz %d' % seed)
     ranges = (ref[rs.randint(n)] + 0.2 * rs.randn(B)).astype(np.float32)
     ranges[rs.randint(B)] = 0.0
     e.update_mbes(ranges, ba, 0.2, r_max, off)
@@ -692,3 +700,51 @@ def test_sweep_fuzz_against_the_oracle(seed, eng, orc):
     d = np.abs(e.get_log_weights() - lw_ref)
     okm = (d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref))
     assert (~okm).sum() <= (1 if bad else 0) + n // 100
+    lw_outliers_explained(orc, omap, soa, ba, ranges, 0.2, r_max, e.get_log_weights(), lw_ref, m2o=m2o, off=off, label='fuzz %d' % seed)
+
+
+@pytest.mark.parametrize('tilt', ['pitch', 'roll'])
+def test_clamp_to_r_max_is_kept_when_the_map_frame_is_tilted(tilt, eng, orc, monkeypatch, capfd):
+    """The merge loop may leave the clamp of the expected range to r_max out only when the host PROVES it idle -- and the
+    proof needs an untilted map frame (mcl_host_update.h: with m2o[8] or m2o[9] non-zero the sensor's depth and the
+    beams' vertical components differ from particle to particle).  With a map frame tilted by a degree the proof must not
+    be attempted: the debug path reports `kept`, and the log-likelihoods agree with the oracle all the same; with the
+    same scene untilted the proof holds and the clamp is skipped."""
+    z, origin = _terrain(seed=41)
+    verts, tris = synth.mesh_from_grid(z, 1.0, origin)
+    n, B = 16384, 128
+    ba = synth.beam_angles(B)
+    monkeypatch.setenv('MCL_DEBUG_WORK', '1')
+    monkeypatch.setenv('MCL_SWEEP', '1')
+    seen = {}
+    for name, m2o in (('tilted', synth.rigid_matrix(0.5, -0.3, 0.0, 0.02 if tilt == 'roll' else 0.0, 0.02 if tilt == 'pitch' else 0.0, 0.3)),
+                      ('level', synth.rigid_matrix(0.5, -0.3, 0.0, 0.0, 0.0, 0.3))):
+        assert (m2o[2, 0] != 0.0 or m2o[2, 1] != 0.0) == (name == 'tilted')
+        e = eng.Engine(n, m2o=m2o, seed=3, init_cov=[1.0, 1.0, 0, 0, 0, 0.01], process_cov=[1e-4, 1e-4, 0, 0, 0, 1e-6],
+                       resample_cov=[1e-3, 1e-3, 0, 0, 0, 1e-5])
+        e.set_map_mesh(verts, tris)
+        e.init_particles()
+        q = orc.quat_from_euler(0.01, -0.01, 0.2)
+        ranges = (22.0 / np.cos(ba)).astype(np.float32)
+        capfd.readouterr()
+        # r_max far beyond the seabed: nothing can be clamped, the proof (when attempted) succeeds
+        e.step_mbes([1.0, 0.0, 0.0], 0.05, q, -2.0, 0.02, ranges, ba, 0.2, 500.0)
+        e.sync()
+        err_txt = capfd.readouterr().err
+        assert '[mbes] sweep handed over' in err_txt, err_txt
+        seen[name] = 'proved idle: skipped' in err_txt
+        assert ('kept' in err_txt) == (not seen[name])
+        # parity of that very update: the same predict through the plain calls, log-likelihoods against the oracle
+        e2 = eng.Engine(n, m2o=m2o, seed=3, init_cov=[1.0, 1.0, 0, 0, 0, 0.01], process_cov=[1e-4, 1e-4, 0, 0, 0, 1e-6],
+                        resample_cov=[1e-3, 1e-3, 0, 0, 0, 1e-5])
+        e2.set_map_mesh(verts, tris)
+        e2.init_particles()
+        e2.predict([1.0, 0.0, 0.0], 0.05, q, -2.0, 0.02)
+        soa = e2.get_particles()
+        pick = np.arange(0, n, 32)
+        lw_ref, _ = orc.mbes_update(np.ascontiguousarray(soa[:, pick]), m2o, [0] * 6, orc.Mesh(verts, tris), ba, ranges, 0.2, 500.0)
+        d = np.abs(e.get_log_weights()[pick] - lw_ref)
+        assert np.all((d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref))), (name, d.max())
+        e.close()
+        e2.close()
+    assert seen == {'tilted': False, 'level': True}, seen

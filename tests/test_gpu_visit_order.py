@@ -86,7 +86,7 @@ def test_filter_is_bitwise_the_same_with_and_without_the_visiting_order(kind, n,
 
 def test_a_wave_of_the_sweep_holds_spatial_neighbours(eng, terrain, monkeypatch):
     n = 262144
-    out, e = _run(eng, terrain, 'mesh', n, 6, '1', monkeypatch, keep=True)
+    out, e = _run(eng, terrain, 'mesh', n, 12, '1', monkeypatch, keep=True)
     # the order of step k was prepared from the state step k - 1 left: compare with THAT state
     slots, st = out[-1]['slots'], out[-2]['st']
     e.close()
@@ -98,7 +98,11 @@ def test_a_wave_of_the_sweep_holds_spatial_neighbours(eng, terrain, monkeypatch)
     in_order, in_slots = spread(pos), spread(st)
     print('spread of (x, y, yaw) inside a wave / spread of the cloud: visiting order %r, slot order %r' % (in_order.round(3), in_slots.round(3)))
     assert (in_slots > 0.8).all()           # slot order: a wave is a random sample of the cloud
-    assert (in_order < 0.35).all()          # 16 bins over 8 sigma: half a sigma wide, uniform inside
+    # visiting order: x is the major key (one bin: a third of a sigma wide or finer); at 64 particles per bin a wave still
+    # straddles a few (y, yaw) bins, the bins lag a contracting cloud by a step and the key anticipates the next predict's
+    # noise -- the VOLUME a wave's particles span is what shrinks, by an order of magnitude
+    assert in_order[0] < 0.5
+    assert np.prod(in_order) < 0.2 * np.prod(in_slots)
 
 
 def test_more_particles_per_thread_than_the_gather_parks_in_lds(eng, terrain, monkeypatch):
@@ -119,6 +123,7 @@ def test_hand_overs_keep_their_slot_under_the_visiting_order(eng, terrain, monke
     cov = dict(init_cov=[900.0, 900.0, 0.0, 0.0, 0.0, 0.5], process_cov=[1e-2, 1e-2, 0.0, 0.0, 0.0, 1e-4],
                resample_cov=[1.0, 1.0, 0.0, 0.0, 0.0, 1e-3])
     m2o = synth.rigid_matrix(ORIGIN[0] + 20.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    monkeypatch.setenv('MCL_VISIT_BINS', '16,16,16')
     a = _run(eng, terrain, 'mesh', 65536, 4, '1', monkeypatch, cov=cov, m2o=m2o, sigma=50.0)
     b = _run(eng, terrain, 'mesh', 65536, 4, '0', monkeypatch, cov=cov, m2o=m2o, sigma=50.0)
     assert a[-1]['sorted'] and min(s['handed'] for s in a[1:]) > 50, [s['handed'] for s in a]
