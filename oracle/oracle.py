@@ -33,8 +33,11 @@ class _Grid(C.Structure):
 
 
 def _load():
-    build()
-    L = C.CDLL(_SO)
+    # MCL_ORACLE_LIB: another build of the same source (tests/test_host_sanitizers.py: the ASan / UBSan build)
+    alt = os.environ.get('MCL_ORACLE_LIB')
+    if not alt:
+        build()
+    L = C.CDLL(alt or _SO)
     d, i, i64, u64, u32, vp = C.c_double, C.c_int, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p
     sig = {
         'orc_euler_from_quat': (None, [_f64p, _f64p]),

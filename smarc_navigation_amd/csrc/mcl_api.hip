@@ -35,34 +35,7 @@ const char* mcl_status_string(int s) {
 const char* mcl_last_error(const mcl_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 int mcl_matrix_from_tf(const double translation[3], const double quaternion[4], double m16[16]) {
-  if (!translation || !quaternion || !m16) return MCL_ERR_INVALID;
-  // quaternion_matrix (tf.transformations): scale by sqrt(2/|q|^2), outer product
-  const double* qi = quaternion;
-  const double nq = qi[0] * qi[0] + qi[1] * qi[1] + qi[2] * qi[2] + qi[3] * qi[3];
-  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  if (nq >= 2.220446049250313e-16 * 4.0) {
-    const double s = std::sqrt(2.0 / nq);
-    const double q[4] = {qi[0] * s, qi[1] * s, qi[2] * s, qi[3] * s};
-    double o[4][4];
-    for (int a = 0; a < 4; ++a)
-      for (int b = 0; b < 4; ++b) o[a][b] = q[a] * q[b];
-    R[0] = 1.0 - o[1][1] - o[2][2];
-    R[1] = o[0][1] - o[2][3];
-    R[2] = o[0][2] + o[1][3];
-    R[3] = o[0][1] + o[2][3];
-    R[4] = 1.0 - o[0][0] - o[2][2];
-    R[5] = o[1][2] - o[0][3];
-    R[6] = o[0][2] - o[1][3];
-    R[7] = o[1][2] + o[0][3];
-    R[8] = 1.0 - o[0][0] - o[1][1];
-  }
-  for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) m16[r * 4 + c] = R[r * 3 + c];
-    m16[r * 4 + 3] = translation[r];
-  }
-  m16[12] = m16[13] = m16[14] = 0.0;
-  m16[15] = 1.0;
-  return MCL_OK;
+  return matrix_from_tf_impl(translation, quaternion, m16);
 }
 
 int mcl_device_count(int* count) {
@@ -897,28 +870,7 @@ int mcl_group_step_mbes(mcl_handle** shards, int32_t ns, const mcl_odom* odom, d
 
 int mcl_exchange_plan(int32_t world, const uint32_t* lost, const uint32_t* surplus, int32_t rank, uint32_t* send_off,
                       uint32_t* send_cnt, uint32_t* recv_off, uint32_t* recv_cnt) {
-  if (world < 1 || !lost || !surplus || rank < 0 || rank >= world || !send_off || !send_cnt || !recv_off || !recv_cnt)
-    return MCL_ERR_INVALID;
-  std::vector<u32> Lpre((size_t)world + 1, 0u), Spre((size_t)world + 1, 0u);
-  unsigned long long tl = 0, ts = 0;
-  for (int r = 0; r < world; ++r) {
-    tl += lost[r];
-    ts += surplus[r];
-    if (tl > 0xffffffffull || ts > 0xffffffffull) return MCL_ERR_INVALID;
-    Lpre[r + 1] = (u32)tl;
-    Spre[r + 1] = (u32)ts;
-  }
-  if (tl != ts) return MCL_ERR_INVALID;   // every lost slot takes exactly one surplus copy
-  for (int r = 0; r < world; ++r) {
-    u32 lo, hi;
-    plan_range(Lpre.data(), Spre.data(), rank, r, lo, hi);   // what `rank` holds and r needs
-    send_off[r] = lo - Spre[rank];
-    send_cnt[r] = hi - lo;
-    plan_range(Lpre.data(), Spre.data(), r, rank, lo, hi);   // what r holds and `rank` needs
-    recv_off[r] = lo - Lpre[rank];
-    recv_cnt[r] = hi - lo;
-  }
-  return MCL_OK;
+  return exchange_plan_impl(world, lost, surplus, rank, send_off, send_cnt, recv_off, recv_cnt);
 }
 
 int mcl_exchange_stats(mcl_handle* h, int64_t* states_sent, int64_t* lost_slots, int32_t reset) {

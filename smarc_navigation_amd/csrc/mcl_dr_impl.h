@@ -5,6 +5,7 @@
 // arithmetic order is kept so that a replay agrees with the node to rounding.
 #pragma once
 #include <cmath>
+#include <cstring>
 #include "../../include/mcl_dr.h"
 
 struct mcl_dr {

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/mcl.h"
+#include "mcl_host_pure.h"
 #include "mcl_kernels.h"
 #include "mcl_mbes.h"
 #include "mcl_sweep.h"
@@ -317,67 +318,6 @@ void t_collect(mcl_handle* h) {
     h->ev_pool.push_back({r.a, r.b});
   }
   h->regions.clear();
-}
-
-// euler_from_quaternion(q,'sxyz') -- tf.transformations' published algorithm (auv_particle.py:50)
-void euler_from_quat(const double qin[4], double rpy[3]) {
-  double nq = qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3];
-  double M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  if (nq >= 2.220446049250313e-16 * 4.0) {
-    double s = std::sqrt(2.0 / nq);
-    double q[4] = {qin[0] * s, qin[1] * s, qin[2] * s, qin[3] * s};
-    double o[4][4];
-    for (int a = 0; a < 4; ++a)
-      for (int b = 0; b < 4; ++b) o[a][b] = q[a] * q[b];
-    M[0] = 1.0 - o[1][1] - o[2][2];
-    M[1] = o[0][1] - o[2][3];
-    M[2] = o[0][2] + o[1][3];
-    M[3] = o[0][1] + o[2][3];
-    M[4] = 1.0 - o[0][0] - o[2][2];
-    M[5] = o[1][2] - o[0][3];
-    M[6] = o[0][2] - o[1][3];
-    M[7] = o[1][2] + o[0][3];
-    M[8] = 1.0 - o[0][0] - o[1][1];
-  }
-  double cy = std::sqrt(M[0] * M[0] + M[3] * M[3]);
-  if (cy > 2.220446049250313e-16 * 4.0) {
-    rpy[0] = std::atan2(M[7], M[8]);
-    rpy[1] = std::atan2(-M[6], cy);
-    rpy[2] = std::atan2(M[3], M[0]);
-  } else {
-    rpy[0] = std::atan2(-M[5], M[4]);
-    rpy[1] = std::atan2(-M[6], cy);
-    rpy[2] = 0.0;
-  }
-}
-
-void philox_host(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t o[4]) {
-  for (int r = 0; r < 10; ++r) {
-    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-    c0 = n0;
-    c1 = n1;
-    c2 = n2;
-    c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  o[0] = c0;
-  o[1] = c1;
-  o[2] = c2;
-  o[3] = c3;
-}
-uint64_t native_u53(uint64_t seed, uint32_t step) {
-  uint32_t o[4];
-  philox_host(0xFFFFFFFFu, 0u, step, 3u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
-  return ((uint64_t)(o[0] >> 5) << 26) | (uint64_t)(o[1] >> 6);
-}
-
-int ceil_log2(long long n) {
-  int l = 0;
-  while ((1ll << l) < n) ++l;
-  return l;
 }
 
 NoiseArgs noise_args(const mcl_handle* h, const double cov[6], uint32_t purpose, uint32_t step) {

@@ -402,14 +402,6 @@ int phase_pack(mcl_handle* h, bool already_packed) {
   return launch_pack(h);
 }
 
-// the range of global dupes positions that shard `from` holds and shard `to` needs: [lo, hi).  Lpre / Spre: exclusive
-// prefix sums of the shards' lost-slot and surplus-copy counts (world + 1 entries).  Pure host arithmetic: also what
-// mcl_exchange_plan exposes, so the plan is property-tested without a GPU (tests/test_exchange_plan.py).
-void plan_range(const u32* Lpre, const u32* Spre, int from, int to, u32& lo, u32& hi) {
-  lo = std::max(Spre[from], Lpre[to]);
-  hi = std::min(Spre[from + 1], Lpre[to + 1]);
-  if (hi < lo) hi = lo;
-}
 void ex_range(const mcl_handle* h, int from, int to, u32& lo, u32& hi) {
   plan_range(h->ex_Lpre.data(), h->ex_Spre.data(), from, to, lo, hi);
 }

@@ -141,9 +141,19 @@ def outliers_explained(orc, omap, soa, ba, got, ref, r_max, m2o=None, off=None, 
     cands = np.stack(cands)                                    # 7 x rows x B
     g = got[rows]
     lo, hi = cands.min(axis=0), cands.max(axis=0)
-    dist = np.abs(cands - g[None]).min(axis=0)
-    cont = (hi - lo) < 0.1
-    dev = np.where(cont, np.abs(g - np.clip(g, lo, hi)), dist)
+    # candidates closer than 10 cm to one another span a continuous branch (grazing incidence: d range / d shift of 30
+    # and more, without a hit / miss flip): any value between them is an oracle answer for a shift below delta.  The
+    # seven candidates are clustered by that rule and the GPU value measured against the nearest cluster's interval
+    cs = np.sort(cands, axis=0)
+    cid = np.concatenate([np.zeros((1,) + cs.shape[1:], int), np.cumsum(np.diff(cs, axis=0) >= 0.1, axis=0)])
+    dev = np.full(g.shape, np.inf)
+    for k in range(cs.shape[0]):
+        mk = cid == k
+        if not mk.any():
+            break
+        clo = np.where(mk, cs, np.inf).min(axis=0)
+        chi = np.where(mk, cs, -np.inf).max(axis=0)
+        dev = np.minimum(dev, np.where(np.isfinite(clo), np.abs(g - np.clip(g, clo, chi)), np.inf))
     b = bad[rows]
     # the local shadow jump of the oracle's own range profile: an outlier sits where neighbouring beams differ by more
     # than the outlier is off, or where the ray's own answer moves under the 1 mm shift

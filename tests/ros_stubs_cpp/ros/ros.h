@@ -6,6 +6,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -38,6 +39,7 @@ struct Master {
   double now = 0.0;
   int spinner_threads = 0;
   std::string node_name;
+  std::mutex mu;   // publishing and logging are thread-safe in roscpp: so are they here (tests/host_san: four threads)
 };
 inline Master& master() {
   static Master m;
@@ -54,6 +56,7 @@ inline void logf(char level, const char* fmt, ...) {
   va_start(ap, fmt);
   std::vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
+  std::lock_guard<std::mutex> lk(master().mu);
   master().log.push_back(std::string(1, level) + " " + buf);
   std::fprintf(stderr, "[%c] %s\n", level, buf);
 }
@@ -67,6 +70,7 @@ class Publisher {
   explicit Publisher(const std::string& t) : topic_(t) {}
   template <class M>
   void publish(const M& m) const {
+    std::lock_guard<std::mutex> lk(stub::master().mu);
     stub::master().sent[topic_].push_back(std::make_shared<M>(m));
   }
 
