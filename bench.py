@@ -61,8 +61,9 @@ def parse(argv=None):
     ap.add_argument('--no-extra', action='store_true', help='skip the extra workload legs (N = 1 runs them by default)')
     ap.add_argument('--only-main', action='store_true', help='same as --no-extra --no-cpu-baseline (profiling runs)')
     ap.add_argument('--cpu-particles', type=int, default=0, help='oracle sample size (0 = auto)')
-    ap.add_argument('--rmse-particles', type=int, default=0,
-                    help='particles of the GPU-vs-oracle trajectory comparison (0 = the oracle sample; 1048576 = metric size)')
+    ap.add_argument('--rmse-particles', type=int, default=1048576,
+                    help='particles of the GPU-vs-oracle trajectory comparison (default: the metric\'s own size, ~100 s of host '
+                         'time on 16 threads; 0 = the cpu_baseline sample)')
     ap.add_argument('--no-overlap', action='store_true', help='in-line state all-gather (no second communicator)')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-spawned ranks: wall-clock limit, seconds')
     # launcher self-test (CPU, gloo): rendezvous + barrier + all-reduce only, no engine, no GPU
@@ -607,22 +608,25 @@ def worker(a, rank, world, local_rank):
                          'the warm-up -- extra.filter_tempered runs the same step on a filter that keeps a healthy spread (its dominant '
                          'launch takes ~20 %% longer: compare extra.filter_tempered.kernels.mbes_main with roofline.launch_us)' % SIGMA}
         # PMC-measured HBM traffic of the dominant kernel: collected offline (counters cannot be read inside
-        # this run) by tools/pmc_summarise.py into profiles/r04_traffic.json, attached ONLY when that file was
+        # this run) by tools/pmc_summarise.py into profiles/<round>_traffic.json, attached ONLY when that file was
         # taken at the kernel sources this library was built from and at this workload
         traffic, traffic_source, pmc = None, None, {}
         src = source_hash()
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r04_traffic.json')) as f:
-                tj = json.load(f)
+        import glob
+        for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):   # newest round first
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+            except (IOError, ValueError):
+                continue
+            rel = os.path.relpath(tpath, ROOT)
             if tj.get('source_hash') == src and P == 1048576 and B == 512 and world == 1:
                 pmc = tj.get(m['kind'], {})
                 traffic = pmc.get('traffic_bytes_per_launch')
-                traffic_source = 'offline: profiles/r04_traffic.json (rocprofv3 --pmc passes, kernel sources %s)' % src
+                traffic_source = 'offline: %s (rocprofv3 --pmc passes, kernel sources %s)' % (rel, src)
             elif tj.get('source_hash') != src:
-                traffic_source = 'none: profiles/r04_traffic.json is for kernel sources %s, this library is %s' % (
-                    tj.get('source_hash'), src)
-        except (IOError, ValueError):
-            pass
+                traffic_source = 'none: %s is for kernel sources %s, this library is %s' % (rel, tj.get('source_hash'), src)
+            break
         streaming = [k for k in ('predict', 'normalise', 'scan', 'resample', 'mean_cov') if k in kernels]
         out = {
             'metric': METRIC,
@@ -647,7 +651,9 @@ def worker(a, rank, world, local_rank):
             'config': {'workload': '%d particles/GPU x %d beams, %s, predict+MBES update+normalise+systematic '
                                    'resample+mean/cov per step' % (P, B, m['desc']),
                        'particles_per_gpu': P, 'beams': B, 'map': m['kind'], 'parallelism': 'particle-shard x%d' % world},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS,
+            # (the dominant kernel is bound by vector issue -- `frac` stays the HBM figure SURVEY 8(d)
+            #  defines, `frac_valu` is the share of the chip's vector-issue slots, from the offline PMC passes)
+            'roofline': {'bound': 'valu_issue' if dom == 'update_mbes' else 'hbm', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic,
                          'launch_us': round(dom_ms * 1e3, 2), 'time_source': dom_time_source,
                          'alg_bytes_per_launch': alg[dom],
@@ -663,6 +669,12 @@ def worker(a, rank, world, local_rank):
                          # for 2 cycles (MI355X_MICROARCH.md "Wave scheduling"), 1024 SIMDs at 2.4 GHz
                          'valu_issue_frac': (round(pmc['valu_insts_per_launch'] / (dom_ms * 1e-3) / (1024 * 2.4e9 / 2.0), 3)
                                              if pmc.get('valu_insts_per_launch') else None),
+                         'frac_valu': (round(pmc['valu_insts_per_launch'] / (dom_ms * 1e-3) / (1024 * 2.4e9 / 2.0), 3)
+                                       if pmc.get('valu_insts_per_launch') else None),
+                         'bound_note': 'valu_issue: the kernel moves ~61 MB and executes ~2e8 wave instructions per launch; `achieved` / '
+                                       '`peak` / `frac` are the HBM figures SURVEY 8(d) asks for (they move only with the instruction '
+                                       'count), frac_valu the share of the vector-issue slots (wave64 VALU = 2 cycles of a SIMD, 1 024 '
+                                       'SIMDs at 2.4 GHz)',
                          'streaming_ms_per_step': round(sum(kernels[k]['ms_per_step'] for k in streaming), 5),
                          'mbes_path': path_main,
                          'note': 'the MBES update is bound by vector / LDS issue, not by HBM (SURVEY 8d): its compulsory '
@@ -707,7 +719,7 @@ def worker(a, rank, world, local_rank):
         ref_xy, n_ref = allc.pop('_means'), allc.pop('_n')
         one.pop('_means'), one.pop('_n')
         if a.rmse_particles and a.rmse_particles != n_ref:
-            big = cpu_baseline(m, stream, ranges, ba, COV, 1048576, a.rmse_particles, cores, 1e9, max_steps=10)
+            big = cpu_baseline(m, stream, ranges, ba, COV, 1048576, a.rmse_particles, cores, 1e9, max_steps=6)
             ref_xy, n_ref = big.pop('_means'), big.pop('_n')
         g = engine.Engine(n_ref, seed=5, device=local_rank, **COV)
         attach_map(g, m)
@@ -764,6 +776,14 @@ def worker(a, rank, world, local_rank):
             except Exception as ex:  # a failing leg must not cost the headline line
                 extra[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
         out['extra'] = extra
+        # the numbers of the other legs where a reader of `value` sees them: the headline cloud has
+        # collapsed to the resampling noise; filter_tempered keeps a posterior decimetres wide on the same kernels
+        ft = extra.get('filter_tempered', {})
+        if ft.get('ms_per_step'):
+            out['value_healthy_cloud'] = round(1e3 / ft['ms_per_step'], 3)
+            out['value_healthy_cloud_what'] = ('steps/s of extra.filter_tempered: the same step on a filter whose posterior stays '
+                                               'decimetres wide (likelihood tempered by 1 / beams)')
+        out['extra_summary'] = {k: v.get('ms_per_step') for k, v in extra.items()}
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

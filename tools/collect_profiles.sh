@@ -1,11 +1,11 @@
 #!/bin/bash
-# tools/collect_profiles.sh -- copy what tools/profile_gpu.sh left under gpurun_out/prof_$ROUND/ into profiles/$ROUND_* (ROUND: r04)
+# tools/collect_profiles.sh -- copy what tools/profile_gpu.sh left under gpurun_out/prof_$ROUND/ into profiles/$ROUND_* (ROUND: r05)
 # (run in the build container after the gpurun call; profiles/ is what the judge reads, gpurun_out/ is scratch).
 # The raw counter rows are trimmed to the first 12 dispatches of the dominant kernel (the means over all ~200 are in
 # <round>_traffic.json): once per round, a few dozen KB.
 set -e
 cd "$(dirname "$0")/.."
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 S=gpurun_out/prof_$ROUND
 # gpurun MERGES into gpurun_out/: keep only the newest run's file(s) in every pass directory before summarising
 for d in $S/stats_* $S/pmc_*; do

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_summarise.py -- turn rocprofv3 --pmc CSV passes into profiles/r04_traffic.json.
+"""tools/pmc_summarise.py -- turn rocprofv3 --pmc CSV passes into profiles/<round>_traffic.json (ROUND=r05).
 
     python tools/pmc_summarise.py <dir with pmc_<map>_{fetch,write,sq}/.../*_counter_collection.csv> [out.json]
 
@@ -39,11 +39,12 @@ def mean_counter(d, pass_name, kernel_prefix, counter):
 def main():
     import bench
     d = sys.argv[1]
-    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'profiles', 'r04_traffic.json')
+    rnd = os.environ.get('ROUND', 'r05')
+    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'profiles', '%s_traffic.json' % rnd)
     res = {'_how': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (three separate passes) on '
                    '`python3 bench.py --map <m> --steps 4 --warmup 1 --only-main`, dominant kernel k_mbes_sweep<2,false,false> (mesh) / k_mbes_sweep<0,false,false> (grid): the fan sweep (one pass since round 4), '
                    'mean over dispatches; KB -> bytes x1024; FETCH_SIZE doubled (gfx950 reports half of a wide streaming read)',
-           '_round': 4, 'source_hash': bench.source_hash()}
+           '_round': int(rnd.lstrip('r')), 'source_hash': bench.source_hash()}
     for kind, prefix in (('mesh', 'void k_mbes_sweep<2, false, false>'), ('grid', 'void k_mbes_sweep<0, false, false>')):
         e = {}
         f, nf = mean_counter(d, 'pmc_%s_fetch' % kind, prefix, 'FETCH_SIZE')

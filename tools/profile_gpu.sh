@@ -1,10 +1,10 @@
 #!/bin/bash
 # tools/profile_gpu.sh -- run on the GPU box (gpurun): kernel-trace stats and the three PMC passes for the
-# mesh and grid workloads; results under gpurun_out/prof_${ROUND:-r04}/.  Counters are collected in their own runs
+# mesh and grid workloads; results under gpurun_out/prof_${ROUND:-r05}/.  Counters are collected in their own runs
 # (never together with a trace), the program itself follows `--` (no wrapper that would re-exec).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_${ROUND:-r04}
+O=$R/gpurun_out/prof_${ROUND:-r05}
 rm -rf $O && mkdir -p $O
 for m in mesh grid; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -- python3 $R/bench.py --map $m --steps 50 --warmup 5 --only-main > $O/bench_$m.log 2>&1
