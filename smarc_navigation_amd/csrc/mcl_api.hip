@@ -317,7 +317,8 @@ int mcl_set_map_mesh_ex(mcl_handle* h, const float* verts, int64_t nv, const uin
   if (h->mesh) mesh_free(h->mesh);
   h->mesh = nullptr;
   std::string err;
-  int rc = mesh_build(verts, nv, tris, nt, &h->mesh, &err);
+  // (a structured mesh is cast as a soup only on request: the slice's vertex records are built then)
+  int rc = mesh_build(verts, nv, tris, nt, (flags & (MCL_MESH_GENERAL | MCL_MESH_UNSTRUCTURED)) != 0, &h->mesh, &err);
   if (rc != MCL_OK) {
     h->err = err;
     return rc;

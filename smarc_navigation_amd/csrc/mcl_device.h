@@ -5,6 +5,14 @@
 #include <type_traits>
 
 #define MCL_WAVE 64
+// Single target.  Beyond wave64 / DPP / the sweep's assembly, the inter-workgroup hand-offs of mcl_resample.h rest on
+// gfx950's cache behaviour and not on the HIP memory model alone: partial sums and look-back descriptors are published
+// by ONE write-through (sc1) store, drained (s_waitcnt vmcnt(0)) before the relaxed ticket, and read by L1-bypassing
+// (sc1) loads -- no release / acquire fence (an agent-scope acquire is an L1 invalidate, ~1.7 us in a 30 us kernel;
+// MI355X_MICROARCH.md "inter-workgroup visibility").  Another architecture must not inherit that silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libmcl_hip.so's kernels are written for gfx950 (MI355X) only: compile with --offload-arch=gfx950"
+#endif
 #define MCL_PI 3.14159265358979323846
 
 typedef unsigned long long u64;

@@ -136,7 +136,7 @@ inline uint16_t float_to_half_dir(float x, int dir) {
   return h;
 }
 
-inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int64_t nt, MeshDev** out,
+inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int64_t nt, bool want_slice, MeshDev** out,
                       std::string* err) {
   *out = nullptr;
   double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
@@ -325,23 +325,6 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
     *err = "set_map_mesh: upload failed";
     mesh_free(m);
     return MCL_ERR_HIP;
-  }
-  // ---- fan slice (mcl_slice.h): the three vertices of every record's source triangle, map frame
-  {
-    std::vector<float4> ct(3 * std::max<size_t>(m->n_records, 1));
-    for (size_t r = 0; r < m->n_records; ++r) {
-      const u32 k = rec_tri[r];
-      for (int c = 0; c < 3; ++c) {
-        const float* v = verts + 3 * (size_t)tris[3 * (size_t)k + c];
-        ct[3 * r + c] = make_float4(v[0], v[1], v[2], 0.f);
-      }
-    }
-    if (hipMalloc(&m->cell_tri, sizeof(float4) * ct.size()) != hipSuccess ||
-        hipMemcpy(m->cell_tri, ct.data(), sizeof(float4) * ct.size(), hipMemcpyHostToDevice) != hipSuccess) {
-      *err = "set_map_mesh: device allocation failed";
-      mesh_free(m);
-      return MCL_ERR_ALLOC;
-    }
   }
   // ---- triangle adjacency (fan sweep over a TIN): edge -> the (at most two) triangles on it
   if (!any_vertical && nt < (1ll << 31) && nv < (1ll << 31)) {
@@ -568,6 +551,29 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
         mesh_free(m);
         return MCL_ERR_ALLOC;
       }
+    }
+  }
+  // ---- fan slice (mcl_slice.h): the three vertices of every record's source triangle, map frame -- 48 B per (cell,
+  // triangle) record, > 100 MB for a million triangles.  Only the fan slice reads them, and it never casts a structured
+  // mesh (the lattice sweep / the node-height traversal do) unless the caller forces the general path: built for
+  // everything else.  It is an optional accelerator: if its allocation fails the map still loads and the ray
+  // traversal casts what the slice would have (cell_tri == nullptr disables the slice, mcl_host_update.h).
+  if (!m->heights || want_slice) {
+    std::vector<float4> ct(3 * std::max<size_t>(m->n_records, 1));
+    for (size_t r = 0; r < m->n_records; ++r) {
+      const u32 k = rec_tri[r];
+      for (int c = 0; c < 3; ++c) {
+        const float* v = verts + 3 * (size_t)tris[3 * (size_t)k + c];
+        ct[3 * r + c] = make_float4(v[0], v[1], v[2], 0.f);
+      }
+    }
+    if (hipMalloc(&m->cell_tri, sizeof(float4) * ct.size()) != hipSuccess) {
+      (void)hipGetLastError();
+      m->cell_tri = nullptr;
+    } else if (hipMemcpy(m->cell_tri, ct.data(), sizeof(float4) * ct.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(m->cell_tri);
+      m->cell_tri = nullptr;
     }
   }
   *out = m;

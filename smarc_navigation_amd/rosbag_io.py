@@ -17,7 +17,8 @@ Message (de)serialisation: ROS 1 wire format (little endian; string = u32 length
 T[n] = items; time = u32 secs + u32 nsecs) for nav_msgs/Odometry, sensor_msgs/LaserScan, sensor_msgs/PointCloud2,
 geometry_msgs/PoseArray, std_msgs/Bool, into the plain message shapes of msgs.py; other types come back as RawMessage.
 The writer exists for tests and for exporting synthetic streams (write_bag): uncompressed or bz2 chunks, a connection
-record per topic, chunk-info and index records so that ROS's own tools accept the file."""
+record per topic carrying the full message definition, chunk-info and index records so that ROS's own tools accept the
+file."""
 import bz2
 import struct
 
@@ -195,6 +196,53 @@ def _enc_pointcloud2(m):
             struct.pack('<I', len(data)) + data + struct.pack('<B', 1 if getattr(m, 'is_dense', True) else 0))
 
 
+
+# ---- message definitions, as rosbag stores them in a connection header (`message_definition`: the .msg text followed by
+# the definitions of every message it depends on, separated by a line of 80 '=' and "MSG: <type>") -- rosbag's Python
+# reader and rqt_bag generate their classes from this text, so a bag without it is unreadable for ROS's own tools.  The
+# standard definitions of std_msgs / geometry_msgs / nav_msgs / sensor_msgs (ROS 1, comments shortened);
+# tests/test_rosbag_io.py recomputes every md5sum of TYPES from them with genmsg's rule.
+_SEP = '=' * 80 + '\n'
+MSG_TEXT = {
+    'std_msgs/Header': 'uint32 seq\ntime stamp\nstring frame_id\n',
+    'std_msgs/Bool': 'bool data\n',
+    'geometry_msgs/Point': 'float64 x\nfloat64 y\nfloat64 z\n',
+    'geometry_msgs/Quaternion': 'float64 x\nfloat64 y\nfloat64 z\nfloat64 w\n',
+    'geometry_msgs/Vector3': 'float64 x\nfloat64 y\nfloat64 z\n',
+    'geometry_msgs/Pose': 'Point position\nQuaternion orientation\n',
+    'geometry_msgs/Twist': 'Vector3  linear\nVector3  angular\n',
+    'geometry_msgs/PoseWithCovariance': '# row-major 6x6 covariance of (x, y, z, rotation about X, Y, Z)\nPose pose\nfloat64[36] covariance\n',
+    'geometry_msgs/TwistWithCovariance': '# row-major 6x6 covariance of (x, y, z, rotation about X, Y, Z)\nTwist twist\nfloat64[36] covariance\n',
+    'geometry_msgs/PoseArray': '# An array of poses with a header for global reference.\nHeader header\nPose[] poses\n',
+    'nav_msgs/Odometry': '# An estimate of a position and velocity in free space: pose in header.frame_id, twist in child_frame_id\n'
+                         'Header header\nstring child_frame_id\ngeometry_msgs/PoseWithCovariance pose\n'
+                         'geometry_msgs/TwistWithCovariance twist\n',
+    'sensor_msgs/LaserScan': '# Single scan from a planar laser range-finder\nHeader header\nfloat32 angle_min\nfloat32 angle_max\n'
+                             'float32 angle_increment\nfloat32 time_increment\nfloat32 scan_time\nfloat32 range_min\n'
+                             'float32 range_max\nfloat32[] ranges\nfloat32[] intensities\n',
+    'sensor_msgs/PointField': 'uint8 INT8    = 1\nuint8 UINT8   = 2\nuint8 INT16   = 3\nuint8 UINT16  = 4\nuint8 INT32   = 5\n'
+                              'uint8 UINT32  = 6\nuint8 FLOAT32 = 7\nuint8 FLOAT64 = 8\nstring name\nuint32 offset\nuint8  datatype\n'
+                              'uint32 count\n',
+    'sensor_msgs/PointCloud2': '# N-dimensional points; layout described by `fields`\nHeader header\nuint32 height\nuint32 width\n'
+                               'PointField[] fields\nbool    is_bigendian\nuint32  point_step\nuint32  row_step\nuint8[] data\n'
+                               'bool is_dense\n',
+}
+# dependencies in the order gendeps --cat lists them (depth first, each once)
+MSG_DEPS = {
+    'std_msgs/Bool': [],
+    'geometry_msgs/PoseArray': ['std_msgs/Header', 'geometry_msgs/Pose', 'geometry_msgs/Point', 'geometry_msgs/Quaternion'],
+    'nav_msgs/Odometry': ['std_msgs/Header', 'geometry_msgs/PoseWithCovariance', 'geometry_msgs/Pose', 'geometry_msgs/Point',
+                          'geometry_msgs/Quaternion', 'geometry_msgs/TwistWithCovariance', 'geometry_msgs/Twist', 'geometry_msgs/Vector3'],
+    'sensor_msgs/LaserScan': ['std_msgs/Header'],
+    'sensor_msgs/PointCloud2': ['std_msgs/Header', 'sensor_msgs/PointField'],
+}
+
+
+def message_definition(type_name):
+    """The full `message_definition` text of a connection header for one of the types in TYPES."""
+    return MSG_TEXT[type_name] + ''.join('\n' + _SEP + 'MSG: %s\n' % d + MSG_TEXT[d] for d in MSG_DEPS[type_name])
+
+
 # type name -> (md5sum of the ROS message definition, decoder, encoder)
 TYPES = {
     'nav_msgs/Odometry': ('cd5e73d190d741a2f92e81eda573aca7', _dec_odometry, _enc_odometry),
@@ -249,9 +297,12 @@ def _record(fields, data):
 
 
 class Bag(object):
-    """`for topic, msg, t in Bag(path).read_messages(topics=None)`: the messages in file order (rosbag writes them in
-    receive order; a chunk is a contiguous run); t = the record's receive time in seconds.  `connections`: topic ->
-    type name, filled as the file is read (connection records precede their messages)."""
+    """`for topic, msg, t in Bag(path).read_messages(topics=None)`: the messages ordered by their record (receive) time
+    like rosbag.Bag.read_messages -- which merges the connections' index entries by time, what the reference's
+    rosbag_handler.py:8-19 iterates --, messages of equal time in file order; `by_time=False` yields plain file order (a
+    chunk is a contiguous run; rosbag writes in receive order, so the two differ only for bags merged or re-indexed by
+    tools).  t = the record's receive time in seconds.  `connections`: topic -> type name, filled as the file is read
+    (connection records precede their messages)."""
 
     def __init__(self, path):
         with open(path, 'rb') as f:
@@ -267,7 +318,7 @@ class Bag(object):
         conns[cid] = (topic, ch.get('type', b'').decode('ascii'))
         self.connections[topic] = conns[cid][1]
 
-    def read_messages(self, topics=None, raw=False):
+    def read_messages(self, topics=None, raw=False, by_time=True):
         conns = {}
         want = None if topics is None else set(topics)
 
@@ -297,8 +348,13 @@ class Bag(object):
                     for item in inner(_records(body)):
                         yield item
 
-        for item in inner(_records(self.buf, len(MAGIC))):
-            yield item
+        if not by_time:
+            for item in inner(_records(self.buf, len(MAGIC))):
+                yield item
+            return
+        items = list(inner(_records(self.buf, len(MAGIC))))
+        for k in sorted(range(len(items)), key=lambda j: (items[j][2], j)):   # (stable: equal stamps keep the file's order)
+            yield items[k]
 
 
 def write_bag(path, messages, compression='none', chunk_messages=64):
@@ -306,6 +362,7 @@ def write_bag(path, messages, compression='none', chunk_messages=64):
     rosbag 2.0 file: bag header (padded to 4096 bytes), chunks of `chunk_messages` messages with their index records,
     then the connection and chunk-info records the bag header's index_pos points at."""
     messages = list(messages)
+    chunk_messages = max(int(chunk_messages), 1)
     conn_id, conn_recs = {}, {}
     for topic, typ, _, _ in messages:
         if topic not in conn_id:
@@ -314,11 +371,11 @@ def write_bag(path, messages, compression='none', chunk_messages=64):
             cid = len(conn_id)
             conn_id[topic] = cid
             ch = _field('topic', topic.encode()) + _field('type', typ.encode()) + _field('md5sum', TYPES[typ][0].encode()) + \
-                _field('message_definition', ('# %s (definition omitted)\n' % typ).encode())
+                _field('message_definition', message_definition(typ).encode())
             conn_recs[cid] = _record([('op', bytes([OP_CONNECTION])), ('conn', struct.pack('<I', cid)), ('topic', topic.encode())], ch)
     body = bytearray()
     chunk_infos = []
-    for c0 in range(0, len(messages), max(int(chunk_messages), 1)):
+    for c0 in range(0, len(messages), chunk_messages):
         part = messages[c0:c0 + chunk_messages]
         chunk, seen, index = bytearray(), set(), {}
         for topic, typ, msg, t in part:

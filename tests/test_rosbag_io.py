@@ -161,3 +161,63 @@ def test_rosbag_replay_equals_the_stream_replay_on_the_gpu(tmp_path):
     b = replay.replay(st, params, grid=grid, publish_every=1000)
     assert a['counts']['/sam/dr/odom'] == 100
     np.testing.assert_array_equal(a['pf_xyz'][-1], b['pf_xyz'][-1])
+
+
+def _genmsg_md5(rosbag_io, type_name, cache):
+    """genmsg.gentools.compute_md5: comments and blank lines dropped, constants first, a field of a message type written
+    as `<md5 of that type> <name>` (arrays of messages lose their brackets), builtin fields as `<type> <name>`."""
+    import hashlib
+    import re
+    if type_name in cache:
+        return cache[type_name]
+    builtin = {'bool', 'int8', 'uint8', 'int16', 'uint16', 'int32', 'uint32', 'int64', 'uint64', 'float32', 'float64', 'string',
+               'time', 'duration', 'char', 'byte'}
+    pkg = type_name.split('/')[0]
+    consts, fields = [], []
+    for line in rosbag_io.MSG_TEXT[type_name].split('\n'):
+        line = line.split('#')[0].strip()
+        if not line:
+            continue
+        if '=' in line:
+            t, rest = line.split(None, 1)
+            name, val = [x.strip() for x in rest.split('=', 1)]
+            consts.append('%s %s=%s' % (t, name, val))
+            continue
+        t, name = line.split()
+        base = re.sub(r'\[.*\]$', '', t)
+        if base in builtin:
+            fields.append('%s %s' % (t, name))
+        else:
+            full = 'std_msgs/Header' if base == 'Header' else (base if '/' in base else pkg + '/' + base)
+            fields.append('%s %s' % (_genmsg_md5(rosbag_io, full, cache), name))
+    cache[type_name] = hashlib.md5('\n'.join(consts + fields).encode()).hexdigest()
+    return cache[type_name]
+
+
+def test_embedded_message_definitions_have_the_md5sums_the_bag_declares():
+    """write_bag stores the full message definition in every connection header (rosbag's Python reader and rqt_bag
+    generate their classes from it): the md5sum of each, recomputed by genmsg's rule from the embedded text, is the one in
+    TYPES -- the published checksums of the ROS 1 standard messages."""
+    cache = {}
+    assert _genmsg_md5(rosbag_io, 'std_msgs/Header', cache) == '2176decaecbce78abc3b96ef049fabed'
+    for typ, (md5, _, _) in rosbag_io.TYPES.items():
+        assert _genmsg_md5(rosbag_io, typ, cache) == md5, typ
+        text = rosbag_io.message_definition(typ)
+        for dep in rosbag_io.MSG_DEPS[typ]:
+            assert ('\n' + '=' * 80 + '\nMSG: %s\n' % dep) in text
+
+
+def test_connection_headers_carry_the_definition_and_messages_come_back_in_time_order(tmp_path):
+    od = [msgs.Odometry() for _ in range(3)]
+    for k, o in enumerate(od):
+        o.header.stamp = msgs.Time(10.0 + k)
+    b = msgs.Bool(True)
+    # recorded out of time order (a merged bag): odom 12, bool 10.5, odom 10, odom 11
+    path = str(tmp_path / 'o.bag')
+    rosbag_io.write_bag(path, [('/o', 'nav_msgs/Odometry', od[2], 12.0), ('/d', 'std_msgs/Bool', b, 10.5),
+                         ('/o', 'nav_msgs/Odometry', od[0], 10.0), ('/o', 'nav_msgs/Odometry', od[1], 11.0)], chunk_messages=0)
+    raw = open(path, 'rb').read()
+    assert b'MSG: geometry_msgs/PoseWithCovariance' in raw and b'definition omitted' not in raw
+    bag = rosbag_io.Bag(path)
+    assert [round(t, 3) for _, _, t in bag.read_messages()] == [10.0, 10.5, 11.0, 12.0]            # rosbag's order
+    assert [round(t, 3) for _, _, t in bag.read_messages(by_time=False)] == [12.0, 10.5, 10.0, 11.0]   # the file's
