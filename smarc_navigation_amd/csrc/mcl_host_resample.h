@@ -528,7 +528,8 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   a.ticket = ctrl_u32(h, CTRL_T_GATHER);
   const double* rp = replay_normals ? h->replay_dev : nullptr;
   // the visiting order of the NEXT fan sweep (mcl_kernels.h: VisitArgs): after a swept update of a fused step, shards
-  // large enough for the order to pay
+  // large enough for the order to pay.  (The fan slice reads the records by slot too, but gains nothing from the order --
+  // measured 3.68 / 6.14 ms with and without on the two soups: one wave per particle, no lanes to keep together.)
   memset(&a.visit, 0, sizeof a.visit);
   h->visit_ready = false;
   // (the stash kernel -- mcl_resample.h -- takes the sums in a second pass: the fused step with resampling noise on

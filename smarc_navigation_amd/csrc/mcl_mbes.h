@@ -331,32 +331,41 @@ __global__ void __launch_bounds__(256) k_mbes_pose(MbesArgs a) {
 template <bool CLASSIFY>
 __global__ void __launch_bounds__(MCL_BLOCK) k_predict_pose(StatePtrs s, long long n, PredictArgs a, MbesArgs m) {
   const PoseXform T = pose_xform(m);
-  double sr, cr, sp, cp;
-  sincos(a.roll, &sr, &cr);
-  sincos(a.pitch, &sp, &cp);
   const long long n_pad = (n + 63) & ~63ll;
   if (!CLASSIFY && a.zero_ptr && blockIdx.x == 0)   // (this kernel does not touch the block; the update after it does)
     for (int k = threadIdx.x; k < a.zero_words; k += blockDim.x) a.zero_ptr[k] = 0ull;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_pad;
-       i += (long long)gridDim.x * blockDim.x) {
+  // where a slot's record goes: its place in the visiting order the last gather prepared -- okey[slot] -> base[owner][key]
+  // + rank, two DEPENDENT loads.  (Round 5, first version: both were waited for at the top of every iteration, two exposed
+  // memory latencies per particle with three waves per SIMD to hide them: +7 us.)  The key word of the NEXT iteration is
+  // loaded during this one's arithmetic, the table word is requested at the top and only added at the store.
+  const bool visit = !CLASSIFY && a.visit_okey != nullptr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  u32 ok_next = (visit && i < n) ? a.visit_okey[i] : 0u;
+  double sr, cr, sp, cp;
+  sincos(a.roll, &sr, &cr);
+  sincos(a.pitch, &sp, &cp);
+  for (; i < n_pad; i += stride) {
     const bool valid = i < n;
     MbesPose P;
     P.um = P.vm = 0.0;
     P.oz = 0.f;
     if (valid) {
-      // where this slot's record goes: its place in the visiting order the last gather prepared (two dependent loads,
-      // in flight during the arithmetic below), or the slot itself
-      u32 pos = (u32)i;
-      if (!CLASSIFY && a.visit_okey) {
-        const u32 ok = a.visit_okey[i], key = ok & ((1u << VISIT_KEY_BITS) - 1u);
-        const u32 owner = ((u32)i >> VISIT_OWNER_SHIFT) & VISIT_OWNER_MASK;
-        pos = a.visit_base[(size_t)owner * a.visit_nb + key] + (ok >> VISIT_KEY_BITS);
+      const u32 ok = ok_next;
+      u32 bv = 0u;
+      if (visit) {
+        const u32 key = ok & ((1u << VISIT_KEY_BITS) - 1u), owner = ((u32)i >> VISIT_OWNER_SHIFT) & VISIT_OWNER_MASK;
+        bv = a.visit_base[(size_t)owner * a.visit_nb + key];
+        if (i + stride < n) ok_next = a.visit_okey[i + stride];
       }
+      // (the yaw too -- the first state word the arithmetic needs: requested before the ~500 instructions of Philox /
+      //  Box-Muller, not 90 instructions before its use; x and y as well would cost the third wave per SIMD, 170 VGPRs)
+      const double w0 = s.c[5][i];
       u32x4 o = philox4x32((u32)(a.nz.gid0 + i), 0u, a.nz.step, 1u, a.nz.k0, a.nz.k1);
       double n0, n1, n5, unused;
       box_muller(o.x, o.y, n0, n1);
       box_muller(o.z, o.w, n5, unused);
-      const double yaw_t = wrap_pi(s.c[5][i] + a.wzdt + a.nz.sq[5] * n5);
+      const double yaw_t = wrap_pi(w0 + a.wzdt + a.nz.sq[5] * n5);
       double sy, cy;
       sincos(yaw_t, &sy, &cy);
       const double x = s.c[0][i] + ((cy * a.m0 - sy * a.m1) + a.nz.sq[0] * n0);
@@ -371,7 +380,7 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_predict_pose(StatePtrs s, long lo
       s.c[5][i] = yaw_t;
       P = make_pose(T, x, y, a.z, sr, cr, sp, cp, sy, cy);
       P.slot = (u32)i;
-      m.pose[pos] = P;
+      m.pose[visit ? bv + (ok >> VISIT_KEY_BITS) : (u32)i] = P;
     }
     if (CLASSIFY) classify_group(m, P, valid, i);
   }

@@ -114,8 +114,10 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
   for (long long i = (long long)blockIdx.x * SLICE_WAVES + w; i < a.n; i += (long long)gridDim.x * SLICE_WAVES) {
     if (EXPECT_ONLY && (i < a.exp_first || i >= a.exp_first + a.exp_count)) continue;
     MbesPose P;
+    u32 slot;   // the particle's state slot: the records may lie in visiting order (mcl_kernels.h: VisitArgs)
     {
       const MbesPose Pv = a.pose[i];   // wave-uniform: scalar registers
+      slot = EXPECT_ONLY ? (u32)i : (u32)__builtin_amdgcn_readfirstlane((int)Pv.slot);
       P.um = uniform_f64(Pv.um);
       P.vm = uniform_f64(Pv.vm);
       P.oz = uniform_f32(Pv.oz);
@@ -348,7 +350,7 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
       const int nv = wave_sum(nvalid);
       if (lane == 0) {
         const double v = -0.5 * accd - (double)nv * a.lognorm;
-        a.lw[i] = v;
+        a.lw[slot] = v;
         wmax = v > wmax ? v : wmax;  // NaN never wins
       }
     }

@@ -1,4 +1,5 @@
 #!/bin/bash
+# prev (tools/experiments/libprev.so) vs the in-tree library on the headline leg, interleaved
 for rep in 1 2 3; do
   for v in prev cur; do
     if [ $v = prev ]; then export MCL_LIB=$PWD/tools/experiments/libprev.so; else unset MCL_LIB; fi
