@@ -88,6 +88,7 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
     if (const char* sv = getenv("MCL_SORT_VISITS")) h->env_sort = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_SWEEP")) h->env_sweep = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_SLICE")) h->env_slice = sv[0] == '1' ? 1 : 0;
+    if (const char* sv = getenv("MCL_SLICE_GROUP")) h->env_slice_group = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_VISIT")) h->env_visit = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_VISIT_BINS")) {
       int b[3] = {0, 0, 0};
@@ -177,7 +178,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_buf[0], h->sweep_buf[1], h->defer_idx, h->visit_okey, h->visit_base, h->visit_cnt, h->visit_desc, h->visit_par, h->reasons_dev, h->grid_pad, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_buf[0], h->sweep_buf[1], h->defer_idx, h->visit_okey, h->visit_base, h->visit_cnt, h->visit_desc, h->visit_par, h->slice_loose, h->reasons_dev, h->grid_pad, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev, h->lsx, h->xsend, h->xrecv};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1085,7 +1086,17 @@ int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64
   HIPCHK(h, hipMemcpy(cnt, h->ctrl + CTRL_WORK, sizeof cnt, hipMemcpyDeviceToHost));
   if (path) *path = h->sweep_now ? 1 : (h->slice_now ? 2 : 0);
   if (handed_over) *handed_over = (h->sweep_now || h->slice_now) ? cnt[1] : 0;
-  if (deferred_groups) *deferred_groups = cnt[0];
+  if (deferred_groups) {
+    *deferred_groups = cnt[0];
+    if (h->slice_now && h->slice_group_ran && h->slice_loose) {
+      // the fan slice over groups of spatial neighbours: groups it left to the per-particle kernel
+      int loose = 0;
+      HIPCHK(h, hipMemcpy(&loose, h->ctrl + CTRL_LOOSE, sizeof loose, hipMemcpyDeviceToHost));
+      *deferred_groups = loose;
+    } else if (h->slice_now) {
+      *deferred_groups = -1;   // (no groups: every particle cast on its own)
+    }
+  }
   return MCL_OK;
 }
 

@@ -36,6 +36,7 @@
 #define CTRL_SLOTS 0                       // MCL_MAX_SLOTS u64
 #define CTRL_WORK (8 * MCL_MAX_SLOTS)      // int: groups deferred by the fast MBES kernel
 #define CTRL_DEFER (CTRL_WORK + 4)         // int: particles the fan sweep handed to the general kernel
+#define CTRL_LOOSE (CTRL_WORK + 8)         // int: groups the fan slice's group kernel left to the per-particle kernel
 #define CTRL_T_QUANT (CTRL_WORK + 12)      // u32 tickets, self-resetting
 #define CTRL_T_EXPAND (CTRL_WORK + 16)
 #define CTRL_T_GATHER (CTRL_WORK + 20)
@@ -162,6 +163,11 @@ struct mcl_handle {
   bool sweep_now = false;           // decided by the first launch_mbes call of an update
   bool slice_now = false;           // ... the fan slice (mcl_slice.h) casts it
   int env_slice = -1;               // MCL_SLICE=0 keeps the ray traversal on triangle soups (tests, A/B)
+  int env_slice_group = -1;         // MCL_SLICE_GROUP=0: the fan slice casts every particle on its own (no shared candidate lists)
+  u32* slice_loose = nullptr;       // k_mbes_slice_group: the groups of SLICE_G pose records it left to k_mbes_slice
+  bool slice_attr_set = false;
+  bool slice_group_ran = false;     // the last sliced update went through k_mbes_slice_group first
+  size_t slice_attr_bytes = 0;
   int sweep_nvalid = 0;
   float* grid = nullptr;
   float* grid_pad = nullptr;   // the same heights inside a one-node ring of NaNs (fan sweep: MbesArgs::grid_pad)

@@ -537,7 +537,7 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   const bool uni = a.uni_mask == 0x1cu;   // z, roll, pitch substituted: the lean kernel
   const bool stash = with_moments && uni && a.nz.sq[2] == 0.0 && a.nz.sq[3] == 0.0 && a.nz.sq[4] == 0.0;
   // (16-bit counts: at most 65 535 particles per gather workgroup)
-  const bool visit = stash && !rp && h->sweep_now && h->env_visit != 0 && (h->env_visit == 1 || h->n >= h->visit_min_n) &&
+  const bool visit = stash && !rp && (h->sweep_now || (h->slice_now && h->env_slice_group != 0)) && h->env_visit != 0 && (h->env_visit == 1 || h->n >= h->visit_min_n) &&
                      h->n <= 65535ll * GATHER_MAX_GRID;
   if (visit) {
     const int nb = h->visit_nb[0] * h->visit_nb[1] * h->visit_nb[2];

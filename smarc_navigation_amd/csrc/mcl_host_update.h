@@ -253,6 +253,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.host_count = nullptr;
   a.reasons = nullptr;
   a.slice = 0;
+  a.slice_loose = nullptr;
+  a.slice_loose_count = nullptr;
   a.grid_pad = nullptr;
   a.nyp = 0;
 #ifdef SWEEP_REASONS
@@ -515,7 +517,31 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     const int dgrid = (int)std::min<long long>(ngroups, wh_prev[1] == 0 ? 64 : 4096);
     if (with_ranges) {
       t_begin(h, MCL_K_MBES_MAIN);
-      k_mbes_slice<false><<<sgrid, SLICE_THREADS, lds, h->stream>>>(a);
+      // records in visiting order: groups of SLICE_G consecutive ones are spatial neighbours and share ONE candidate
+      // triangle list, staged in LDS (k_mbes_slice_group); what it leaves -- groups that are not tight, that overflow
+      // the staging area -- k_mbes_slice casts, by the list the group kernel leaves
+      a.slice_loose = nullptr;
+      h->slice_group_ran = false;
+      if (pose_done && h->pose_visit && h->env_slice_group != 0) {
+        const long long ngr = (h->n + SLICE_G - 1) / SLICE_G;
+        if (!h->slice_loose) HIPCHK(h, hipMalloc(&h->slice_loose, sizeof(u32) * (size_t)ngr));
+        a.slice_loose = h->slice_loose;
+        a.slice_loose_count = (int*)(h->ctrl + CTRL_LOOSE);   // (zeroed with the control block by this step's predict)
+        const size_t lds_g = (size_t)B * (2 + SLICE_G_WAVES) * sizeof(float) + (size_t)SLICE_G_TRIS * 9 * sizeof(float) +
+                             SLICE_G_HASH * sizeof(unsigned) + SLICE_LUT * sizeof(unsigned short);
+        if (!h->slice_attr_set || lds_g > h->slice_attr_bytes) {   // (more than 64 KiB of dynamic LDS has to be asked for)
+          HIPCHK(h, hipFuncSetAttribute((const void*)k_mbes_slice_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
+          h->slice_attr_set = true;
+          h->slice_attr_bytes = lds_g;
+        }
+        if (lds_g <= 160 * 1024) {
+          k_mbes_slice_group<<<(unsigned)std::min<long long>(ngr, 4096), SLICE_G_THREADS, lds_g, h->stream>>>(a);
+          h->slice_group_ran = true;
+        } else
+          a.slice_loose = nullptr;   // (a beam table too long for the staging layout: the per-particle kernel casts everything)
+      }
+      // (behind the group kernel it casts the few groups on its list: a small grid -- every workgroup builds the beam tables)
+      k_mbes_slice<false><<<a.slice_loose ? std::min(sgrid, 2048) : sgrid, SLICE_THREADS, lds, h->stream>>>(a);
       t_end(h);
       k_mbes_cast<1, false, 2><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);
     } else {
@@ -655,7 +681,7 @@ int do_predict(mcl_handle* h, const mcl_odom* od, double dt, const double* repla
     } else {
       a.zero_ptr = (unsigned long long*)h->ctrl;   // the kernel's first workgroup zeroes it: no memset launch
       a.zero_words = CTRL_BYTES / 8;
-      if (pose_for->sweep_beams && h->visit_ready) {
+      if ((pose_for->sweep_beams || (pose_for->slice && h->env_slice_group != 0)) && h->visit_ready) {
         // the fan sweep visits the particles in the spatial order the last gather prepared: the records go to their
         // sorted positions (the sweep writes log-likelihoods by the slot in the record)
         a.visit_okey = h->visit_okey;

@@ -131,6 +131,8 @@ struct MbesArgs {
   const int* n_dev;           // when set, the classify / cast kernels visit *n_dev entries of perm instead of a.n
   int* host_count;            // pinned host word (or nullptr): k_mbes_cast<.,.,2> leaves the hand-over count there
   int slice;                  // 1: this update is cast by the fan slice (mcl_slice.h)
+  u32* slice_loose;           // fan slice over groups of spatial neighbours (k_mbes_slice_group): the groups of SLICE_G records it leaves to k_mbes_slice (nullptr: k_mbes_slice casts everything)
+  int* slice_loose_count;     // ... their number (device counter in the control block, zeroed with it)
   unsigned* reasons;          // SWEEP_REASONS builds: 16 counters, why the sweep declined a particle side (or nullptr)
 };
 __device__ __forceinline__ long long mbes_count(const MbesArgs& a) { return a.n_dev ? (long long)*a.n_dev : a.n; }

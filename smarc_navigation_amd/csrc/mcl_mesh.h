@@ -566,6 +566,7 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
         const float* v = verts + 3 * (size_t)tris[3 * (size_t)k + c];
         ct[3 * r + c] = make_float4(v[0], v[1], v[2], 0.f);
       }
+      memcpy(&ct[3 * r].w, &k, 4);   // the source triangle's index in the first vertex's spare word (k_mbes_slice_group: a triangle recorded in several cells is staged once)
     }
     if (hipMalloc(&m->cell_tri, sizeof(float4) * ct.size()) != hipSuccess) {
       (void)hipGetLastError();

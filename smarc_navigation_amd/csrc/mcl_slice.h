@@ -46,6 +46,9 @@
 #ifndef SLICE_WAVES
 #define SLICE_WAVES 4   // particles per workgroup
 #endif
+#ifndef SLICE_G
+#define SLICE_G 36      // particles per group of k_mbes_slice_group (at the end of this file)
+#endif
 #define SLICE_THREADS (SLICE_WAVES * 64)
 #ifndef SLICE_LIST
 #define SLICE_LIST 511    // triangle records a wave's list holds per chunk of columns (2 KiB with its counter); more: the general kernel
@@ -74,28 +77,26 @@ template <bool EXPECT_ONLY>
 __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char slice_lds[];
   const int B = a.n_beams;
-  float* tanb = (float*)slice_lds;                   // B: ascending tangents
-  float* secb = tanb + B;                            // B: 1 / cos a
-  unsigned* rng_all = (unsigned*)(secb + B);         // SLICE_WAVES x B: nearest crossing per beam (float bits)
+  float2* tsb = (float2*)slice_lds;                  // B: (ascending tangent, 1 / cos a) -- one ds_read_b64 per beam
+  unsigned* rng_all = (unsigned*)(tsb + B);          // SLICE_WAVES x B: nearest crossing per beam (float bits)
   unsigned* tl_all = rng_all + (size_t)SLICE_WAVES * B;   // SLICE_WAVES x (SLICE_LIST + 1): the wave's triangle list, its length
   unsigned short* lut = (unsigned short*)(tl_all + (size_t)SLICE_WAVES * (SLICE_LIST + 1));   // SLICE_LUT: first beam at or beyond a tangent bucket's lower end
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     const float2 sc = a.beam_sc[b];
     const float sec = __builtin_amdgcn_rcpf(sc.y);
-    tanb[b] = sc.x * sec;
-    secb[b] = sec;
+    tsb[b] = make_float2(sc.x * sec, sec);
   }
   __syncthreads();
   // "first beam with tan >= T" without a bisection per segment: SLICE_LUT uniform buckets over the table's tangent
   // range, each holding the first beam at or beyond its lower end (built here by bisection, once per workgroup); a
   // query reads its bucket and scans forward -- one or two beams for a table that is uniform in angle
-  const float lut_lo = tanb[0], lut_w = fmaxf((tanb[B - 1] - tanb[0]) * (1.f / SLICE_LUT), 1e-12f), lut_iw = 1.f / lut_w;
+  const float lut_lo = tsb[0].x, lut_w = fmaxf((tsb[B - 1].x - tsb[0].x) * (1.f / SLICE_LUT), 1e-12f), lut_iw = 1.f / lut_w;
   for (int k = threadIdx.x; k < SLICE_LUT; k += blockDim.x) {
     const float T = lut_lo + (float)k * lut_w;
     int lo = 0, hi = B;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (tanb[mid] < T) lo = mid + 1; else hi = mid;
+      if (tsb[mid].x < T) lo = mid + 1; else hi = mid;
     }
     lut[k] = (unsigned short)lo;
   }
@@ -108,10 +109,15 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
   const MeshArgs& ma = a.mesh;
   const float cs = ma.cs, ics = 1.f / cs;
   const unsigned rmax_bits = __float_as_uint(a.r_max);
-  const float tan_lo = tanb[0], tan_hi = tanb[B - 1];
+  const float tan_lo = tsb[0].x, tan_hi = tsb[B - 1].x;
   const float2 sc_lo = a.beam_sc[0], sc_hi = a.beam_sc[B - 1];
   double wmax = -__builtin_inf();
-  for (long long i = (long long)blockIdx.x * SLICE_WAVES + w; i < a.n; i += (long long)gridDim.x * SLICE_WAVES) {
+  // (behind k_mbes_slice_group: only the members of the groups it left, by its list -- the list's length is read here)
+  const bool listed = !EXPECT_ONLY && a.slice_loose != nullptr;
+  const long long n_it = listed ? (long long)*a.slice_loose_count * SLICE_G : a.n;
+  for (long long it = (long long)blockIdx.x * SLICE_WAVES + w; it < n_it; it += (long long)gridDim.x * SLICE_WAVES) {
+    const long long i = listed ? (long long)a.slice_loose[it / SLICE_G] * SLICE_G + it % SLICE_G : it;
+    if (i >= a.n) continue;
     if (EXPECT_ONLY && (i < a.exp_first || i >= a.exp_first + a.exp_count)) continue;
     MbesPose P;
     u32 slot;   // the particle's state slot: the records may lie in visiting order (mcl_kernels.h: VisitArgs)
@@ -305,11 +311,15 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
       // its first beam is at or before the one wanted: scan forward (rounding of the bucket index: one bucket back)
       const float T_first = T_lo - 1e-6f * fmaxf(1.f, fabsf(T_lo)), T_last = T_hi + 1e-6f * fmaxf(1.f, fabsf(T_hi));
       int lo = (int)lut[min(max((int)((T_first - lut_lo) * lut_iw) - 1, 0), SLICE_LUT - 1)];
-      while (lo < B && tanb[lo] < T_first) ++lo;
+      while (lo < B && tsb[lo].x < T_first) ++lo;
       const float dts = tB - tA;
+      // (the beam's tangent and secant are requested one beam ahead: the loop was a chain of two dependent LDS reads per
+      //  beam -- ~20 cycles per instruction at 4 - 7 waves per SIMD)
+      float2 ts = tsb[min(lo, B - 1)];
       for (int b = lo; b < B; ++b) {
-        const float T = tanb[b];
+        const float T = ts.x, sec_b = ts.y;
         if (T > T_last) break;
+        ts = tsb[min(b + 1, B - 1)];
         // crossing of the half line s = t T with the segment A -> B: e = s - T t changes sign
         const float eA = fmaf(-T, tA, sA), eB = fmaf(-T, tB, sB);
         if ((eA > 0.f) == (eB > 0.f) && eA != 0.f && eB != 0.f) continue;
@@ -318,7 +328,7 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
         lam = fminf(fmaxf(lam, 0.f), 1.f);
         const float tau = fmaf(lam, dts, tA);
         if (!(tau > 0.f)) continue;
-        const float range = tau * secb[b];
+        const float range = tau * sec_b;
         if (range < a.r_max) lds_min_range(&rng[b], range);
       }
       }
@@ -357,4 +367,388 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
   }
   if (!EXPECT_ONLY && lane == 0 && a.max_slots && wmax > -__builtin_inf())
     atomicMax((unsigned long long*)&a.max_slots[(blockIdx.x * SLICE_WAVES + w) & (MCL_MAX_SLOTS - 1)], ordered_key(wmax));
+}
+
+// ------------------------------------------------------------------ the fan slice over GROUPS of spatial neighbours
+// With the visiting order (mcl_kernels.h: VisitArgs) 32 consecutive pose records are particles from one small bin of
+// (x, y, yaw): their fan planes cut almost the same cells and triangles.  k_mbes_slice spends 40 - 60 % of its time in
+// phase A -- a chain of dependent global loads per particle -- and fetches every triangle's vertices twice per particle
+// from L2; on an irregular mesh it also meets every triangle once per cell it overlaps (~2 records per triangle).  Here a
+// workgroup takes a GROUP of SLICE_G records:
+//   G0  wave 0, one lane per particle: the fan geometry of each, the group's spread about its first valid member
+//       (dO = largest distance between sensors, dn = largest difference of plane normals) and the union of the fans'
+//       extents.  A group that is not tight (dO + dn x reach > SLICE_G_DELTA cells) is left to k_mbes_slice;
+//   GA  all waves, lanes = columns of the cell grid along the reference member's trace, as in k_mbes_slice but ONCE per
+//       group and with every test widened by that spread: a cell passes if the REFERENCE plane comes within
+//       ext + dO + dn x (distance + box radius) of its box -- a superset of the cells any member's plane cuts;
+//       the records of the cells that pass are DEDUPLICATED by source triangle (an LDS hash set) and their vertices staged
+//       in LDS: 36 B per unique triangle, fetched once per group;
+//   B   every wave then casts its members one after another against the staged triangles with k_mbes_slice's own
+//       arithmetic, expression for expression (cut test, watertight segment end points, beam run, LDS minima): a member's
+//       result is the minimum over the triangles ITS plane cuts, and the staged set contains all of them -- the same bits
+//       as k_mbes_slice gives, whatever the group (tests/test_gpu_slice.py compares the two kernels bit for bit).
+// Groups that overflow the staging area (SLICE_G_TRIS unique triangles) or are not tight are appended to the list
+// a.slice_loose; k_mbes_slice, launched behind this kernel with that list, casts exactly their members.
+#ifndef SLICE_G
+#define SLICE_G 36            // particles per group: three per wave
+#endif
+#define SLICE_G_WAVES 12
+#define SLICE_G_THREADS (SLICE_G_WAVES * 64)
+#ifndef SLICE_G_TRIS
+#define SLICE_G_TRIS 896      // unique triangles a group may stage (31.5 KB)
+#endif
+#define SLICE_G_HASH 2048     // slots of the de-duplication set (a power of two > 2 x SLICE_G_TRIS)
+#ifndef SLICE_G_DELTA
+#define SLICE_G_DELTA 1.5f    // a group is tight if its members' planes stay within this many cells of the reference's over the fan
+#endif
+__global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArgs a) {   // (12 waves x 2 workgroups per CU = 6 waves per SIMD: <= 85 VGPRs, <= 80 KB of LDS)
+  extern __shared__ __attribute__((aligned(16))) unsigned char slice_lds[];
+  const int B = a.n_beams;
+  float2* tsb = (float2*)slice_lds;                  // B: (ascending tangent, 1 / cos a)
+  unsigned* rng_all = (unsigned*)(tsb + B);          // SLICE_G_WAVES x B
+  float* verts = (float*)(rng_all + (size_t)SLICE_G_WAVES * B);          // SLICE_G_TRIS x 9
+  unsigned* hset = (unsigned*)(verts + (size_t)SLICE_G_TRIS * 9);        // SLICE_G_HASH
+  unsigned short* lut = (unsigned short*)(hset + SLICE_G_HASH);          // SLICE_LUT
+  __shared__ float g_ref[24];     // the reference member's geometry and the group's widened extents
+  __shared__ int g_int[8];        // k_lo, k_hi, Im, Iq, major_x, tight, ntri
+  __shared__ unsigned g_ntri, g_ncand;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float2 sc = a.beam_sc[b];
+    const float sec = __builtin_amdgcn_rcpf(sc.y);
+    tsb[b] = make_float2(sc.x * sec, sec);
+  }
+  __syncthreads();
+  const float lut_lo = tsb[0].x, lut_w = fmaxf((tsb[B - 1].x - tsb[0].x) * (1.f / SLICE_LUT), 1e-12f), lut_iw = 1.f / lut_w;
+  for (int k = threadIdx.x; k < SLICE_LUT; k += blockDim.x) {
+    const float T = lut_lo + (float)k * lut_w;
+    int lo = 0, hi = B;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (tsb[mid].x < T) lo = mid + 1; else hi = mid;
+    }
+    lut[k] = (unsigned short)lo;
+  }
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned* rng = rng_all + (size_t)w * B;
+  const MeshArgs& ma = a.mesh;
+  const float cs = ma.cs, ics = 1.f / cs;
+  const unsigned rmax_bits = __float_as_uint(a.r_max);
+  const float tan_lo = tsb[0].x, tan_hi = tsb[B - 1].x;
+  const float2 sc_lo = a.beam_sc[0], sc_hi = a.beam_sc[B - 1];
+  double wmax = -__builtin_inf();
+  const long long ngroups = (a.n + SLICE_G - 1) / SLICE_G;
+  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const long long i0 = g * SLICE_G;
+    __syncthreads();   // (the previous group's staging area and flags are free)
+    for (int k = threadIdx.x; k < SLICE_G_HASH; k += blockDim.x) hset[k] = 0xffffffffu;
+    if (threadIdx.x == 0) g_ntri = g_ncand = 0u;
+    // ---- G0: wave 0, one lane per member
+    if (w == 0) {
+      const long long i = i0 + lane;
+      const bool in = lane < SLICE_G && i < a.n;
+      MbesPose P;
+      P.um = P.vm = 0.0;
+      P.oz = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) P.c1[r] = P.c2[r] = 0.f;
+      if (in) P = a.pose[i];
+      const float c2z = P.c2[2];
+      const float h1 = P.c1[0] * P.c1[0] + P.c1[1] * P.c1[1];
+      const bool ok = in && fabs(P.um) < 1e9 && fabs(P.vm) < 1e9 && c2z >= 0.5f && h1 >= 0.25f;   // (k_mbes_slice's own test)
+      const unsigned long long okm = __ballot(ok);
+      const int ref = okm ? __ffsll((long long)okm) - 1 : 0;
+      // the member's fan extents (k_mbes_slice: s_pos, s_neg, t_a, t_b)
+      const float oz = P.oz;
+      float s_pos = 0.f, s_neg = 0.f;
+      {
+        const float rate_hi = sc_hi.y * c2z - sc_hi.x * P.c1[2], rate_lo = sc_lo.y * c2z - sc_lo.x * P.c1[2];
+        const float rho_hi = rate_hi > 1e-4f ? fminf(a.r_max, fmaxf(oz - a.zmin_map, 0.f) * __builtin_amdgcn_rcpf(rate_hi)) : a.r_max;
+        const float rho_lo = rate_lo > 1e-4f ? fminf(a.r_max, fmaxf(oz - a.zmin_map, 0.f) * __builtin_amdgcn_rcpf(rate_lo)) : a.r_max;
+        s_pos = fmaxf(sc_hi.x, 0.f) * rho_hi + cs;
+        s_neg = fmaxf(-sc_lo.x, 0.f) * rho_lo + cs;
+      }
+      const float s_abs = fmaxf(s_pos, s_neg);
+      const float rc = __builtin_amdgcn_rcpf(fmaxf(c2z, 0.5f));
+      const float t_b = fminf(((oz - a.zmin_map) + fabsf(P.c1[2]) * s_abs) * rc, a.r_max) + cs;
+      const float t_a = fmaxf(((oz - a.zmax_map) - fabsf(P.c1[2]) * s_abs) * rc - cs, 0.f);
+      const float nx = P.c1[1] * P.c2[2] - P.c1[2] * P.c2[1], ny = P.c1[2] * P.c2[0] - P.c1[0] * P.c2[2],
+                  nz = P.c1[0] * P.c2[1] - P.c1[1] * P.c2[0];
+      // the reference member's values in every lane
+      const double um_r = __shfl(P.um, ref, 64), vm_r = __shfl(P.vm, ref, 64);
+      const float oz_r = __shfl(oz, ref, 64), nx_r = __shfl(nx, ref, 64), ny_r = __shfl(ny, ref, 64), nz_r = __shfl(nz, ref, 64);
+      // spread about the reference: sensor distance (metres) and normal difference
+      const float dux = (float)((P.um - um_r) * (double)cs), duy = (float)((P.vm - vm_r) * (double)cs), duz = oz - oz_r;
+      float dO = ok ? sqrtf(dux * dux + duy * duy + duz * duz) : 0.f;
+      float dn = ok ? sqrtf((nx - nx_r) * (nx - nx_r) + (ny - ny_r) * (ny - ny_r) + (nz - nz_r) * (nz - nz_r)) : 0.f;
+      float sp = ok ? s_pos : 0.f, sn = ok ? s_neg : 0.f, ta = ok ? t_a : 1e30f, tb = ok ? t_b : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        dO = fmaxf(dO, __shfl_xor(dO, o, 64));
+        dn = fmaxf(dn, __shfl_xor(dn, o, 64));
+        sp = fmaxf(sp, __shfl_xor(sp, o, 64));
+        sn = fmaxf(sn, __shfl_xor(sn, o, 64));
+        ta = fminf(ta, __shfl_xor(ta, o, 64));
+        tb = fmaxf(tb, __shfl_xor(tb, o, 64));
+      }
+      // (dn x reach: the furthest point of the union's fan region from the reference sensor; 1.25: the members' in-plane
+      //  axes differ too -- their (s, t) frames are turned against the reference's by at most dn)
+      const float reach = sqrtf(fmaxf(sp, sn) * fmaxf(sp, sn) + tb * tb);
+      const float delta = 1.25f * (dO + dn * reach) + 1e-3f;
+      if (lane == ref) {
+        g_ref[0] = P.c1[0]; g_ref[1] = P.c1[1]; g_ref[2] = P.c1[2];
+        g_ref[3] = P.c2[0]; g_ref[4] = P.c2[1]; g_ref[5] = P.c2[2];
+        g_ref[6] = oz; g_ref[7] = nx; g_ref[8] = ny; g_ref[9] = nz;
+        g_ref[10] = sp + delta; g_ref[11] = sn + delta;
+        g_ref[12] = fmaxf(ta - delta, 0.f); g_ref[13] = tb + delta;
+        g_ref[14] = dO; g_ref[15] = dn; g_ref[16] = delta;
+        const int Iu = (int)floor(P.um), Iv = (int)floor(P.vm);
+        g_int[0] = Iu; g_int[1] = Iv;
+        g_ref[17] = (float)(P.um - (double)Iu); g_ref[18] = (float)(P.vm - (double)Iv);
+        {   // the reference sensor in the map frame, fp32 part + rest (like every member's below)
+          const double Ox = ma.x0 + P.um * (double)cs, Oy = ma.y0 + P.vm * (double)cs;
+          const float Oxf = (float)Ox, Oyf = (float)Oy;
+          g_ref[19] = Oxf; g_ref[20] = (float)(Ox - (double)Oxf); g_ref[21] = Oyf; g_ref[22] = (float)(Oy - (double)Oyf);
+        }
+        g_int[5] = (okm != 0ull && delta <= SLICE_G_DELTA * cs) ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    bool tight = g_int[5] != 0;
+    if (tight) {
+      // ---- GA: the reference member's columns, every test widened by the group's spread; all waves, a chunk of 64
+      // columns per wave at a time
+      const float c1x = g_ref[0], c1y = g_ref[1], c2x = g_ref[3], c2y = g_ref[4], c2zr = g_ref[5];
+      const float ozr = g_ref[6], nxr = g_ref[7], nyr = g_ref[8], nzr = g_ref[9];
+      const float s_pos = g_ref[10], s_neg = g_ref[11], t_a = g_ref[12], t_b = g_ref[13];
+      const float dO = g_ref[14], dn = g_ref[15], delta = g_ref[16];
+      const float rOxf = g_ref[19], rdOx = g_ref[20], rOyf = g_ref[21], rdOy = g_ref[22];
+      (void)c2zr;
+      const bool major_x = fabsf(c1x) >= fabsf(c1y);
+      const float c1m = major_x ? c1x : c1y, c1q = major_x ? c1y : c1x;
+      const float c2m = major_x ? c2x : c2y, c2q = major_x ? c2y : c2x;
+      const int gm = major_x ? ma.gx : ma.gy, gq = major_x ? ma.gy : ma.gx;
+      const int Im = major_x ? g_int[0] : g_int[1], Iq = major_x ? g_int[1] : g_int[0];
+      const float fm = major_x ? g_ref[17] : g_ref[18], fq = major_x ? g_ref[18] : g_ref[17];
+      const float m0 = fminf(-s_neg * c1m, s_pos * c1m) + fminf(-t_a * c2m, -t_b * c2m) - delta;
+      const float m1 = fmaxf(-s_neg * c1m, s_pos * c1m) + fmaxf(-t_a * c2m, -t_b * c2m) + delta;
+      int k_lo = Im + (int)floorf(fm + m0 * ics), k_hi = Im + (int)floorf(fm + m1 * ics);
+      k_lo = max(k_lo, 0);
+      k_hi = min(k_hi, gm - 1);
+      const float rmq = c1q * __builtin_amdgcn_rcpf(c1m);
+      const float kq = c2m * rmq - c2q;
+      // GA1: lanes = columns; the records of the cells that pass go onto a candidate list in LDS.  The cell words of a column's rows are loaded in batches: one memory
+      // latency per batch, not one per row
+      unsigned* clist = rng_all;   // (the members' range slots are not in use yet: their area holds the list)
+      const u32 CL = (u32)(SLICE_G_WAVES * B);   // capacity in words
+      for (int cbase = k_lo + 64 * w; cbase <= k_hi; cbase += 64 * SLICE_G_WAVES) {
+        const int col = cbase + lane;
+        const bool col_ok = col <= k_hi;
+        const float ma0 = ((float)(col - Im) - fm) * cs, ma1 = ma0 + cs;
+        const float q0 = fminf(ma0 * rmq, ma1 * rmq) + fminf(t_a * kq, t_b * kq) - delta;
+        const float q1 = fmaxf(ma0 * rmq, ma1 * rmq) + fmaxf(t_a * kq, t_b * kq) + delta;
+        int r_lo = Iq + (int)floorf(fq + q0 * ics), r_hi = Iq + (int)floorf(fq + q1 * ics);
+        r_lo = max(r_lo, 0);
+        r_hi = col_ok ? min(r_hi, gq - 1) : r_lo - 1;
+        for (int rb = r_lo; __builtin_amdgcn_ballot_w64(rb <= r_hi) != 0ull; rb += SLICE_ROWS) {
+          uint2 info[SLICE_ROWS];
+#pragma unroll
+          for (int r = 0; r < SLICE_ROWS; ++r) {
+            const int row = rb + r;
+            const size_t c = major_x ? (size_t)col * ma.gy + row : (size_t)row * ma.gy + col;
+            info[r] = row <= r_hi ? ma.cell_info[c] : make_uint2(0u, 0u);
+          }
+#pragma unroll
+          for (int r = 0; r < SLICE_ROWS; ++r) {
+            const int row = rb + r;
+            u32 cnt = info[r].y >> 27;
+            if (cnt == 0u) continue;
+            const int ci = major_x ? col : row, cj = major_x ? row : col;
+            const u32 rs = info[r].y & 0x7ffffffu;
+            float zlo, zhi;
+            cell_zrange(info[r].x, zlo, zhi);
+            const float I0x = (float)(ci - g_int[0]) - g_ref[17], I0y = (float)(cj - g_int[1]) - g_ref[18];
+            const float cxm = (I0x + 0.5f) * cs, cym = (I0y + 0.5f) * cs, czm = 0.5f * (zlo + zhi) - ozr;
+            const float dist = nxr * cxm + nyr * cym + nzr * czm;
+            const float hz = 0.5f * (zhi - zlo);
+            const float ext = 0.5f * cs * (fabsf(nxr) + fabsf(nyr)) + (hz + 1e-3f) * fabsf(nzr) + 1e-4f;
+            // a member's plane: |n_p . (c - O_p)| <= |n_ref . (c - O_ref)| + dn |c - O_ref| + dO, and its own extent is
+            // within dn x (box radius) of the reference's
+            const float rad = sqrtf(0.5f * cs * cs + hz * hz);
+            const float wide = dO + dn * (sqrtf(cxm * cxm + cym * cym + czm * czm) + 2.f * rad) + 1e-3f;
+            if (!(fabsf(dist) <= ext + wide)) continue;
+            if (cnt == 31u) cnt = ma.cell_start[(size_t)ci * ma.gy + cj + 1] - rs;
+            const u32 pos = atomicAdd(&g_ncand, cnt);
+            for (u32 k = 0; k < cnt && pos + k < CL; ++k) clist[pos + k] = rs + k;
+          }
+        }
+      }
+      __syncthreads();
+      const u32 ncand = g_ncand;
+      if (ncand > CL) {
+        if (threadIdx.x == 0) g_ntri = SLICE_G_TRIS + 1u;   // (too many candidates: the group is left to k_mbes_slice)
+      } else {
+        // GA2: lanes = candidate records: the three vertices in one batch of loads; can ANY member's plane separate
+        // them?  Not if all three lie on one side of the reference plane by more than a member's plane can differ from it
+        // there (dO + dn x distance).  The survivors are de-duplicated by source triangle and staged
+        for (u32 k = threadIdx.x; k < ncand; k += SLICE_G_THREADS) {
+          const size_t r = clist[k];
+          const float4 v0 = ma.cell_tri[3 * r], v1 = ma.cell_tri[3 * r + 1], v2 = ma.cell_tri[3 * r + 2];
+          {
+            const float ax0 = (v0.x - rOxf) - rdOx, ay0 = (v0.y - rOyf) - rdOy, az0 = v0.z - ozr;
+            const float ax1 = (v1.x - rOxf) - rdOx, ay1 = (v1.y - rOyf) - rdOy, az1 = v1.z - ozr;
+            const float ax2 = (v2.x - rOxf) - rdOx, ay2 = (v2.y - rOyf) - rdOy, az2 = v2.z - ozr;
+            const float e0 = fmaf(nxr, ax0, fmaf(nyr, ay0, nzr * az0)), e1 = fmaf(nxr, ax1, fmaf(nyr, ay1, nzr * az1)),
+                        e2 = fmaf(nxr, ax2, fmaf(nyr, ay2, nzr * az2));
+            const float w0 = dO + dn * sqrtf(ax0 * ax0 + ay0 * ay0 + az0 * az0) + 1e-3f;
+            const float w1 = dO + dn * sqrtf(ax1 * ax1 + ay1 * ay1 + az1 * az1) + 1e-3f;
+            const float w2 = dO + dn * sqrtf(ax2 * ax2 + ay2 * ay2 + az2 * az2) + 1e-3f;
+            if ((e0 > w0 && e1 > w1 && e2 > w2) || (e0 < -w0 && e1 < -w1 && e2 < -w2)) continue;
+          }
+          const u32 tid = __float_as_uint(v0.w);
+          // first record of this triangle in the group?  (open addressing; the set is twice the staging capacity)
+          u32 hslot = (tid * 2654435761u) >> (32 - 11);
+          bool fresh = false;
+          for (int probe = 0; probe < SLICE_G_HASH; ++probe) {
+            const u32 prev = atomicCAS(&hset[hslot], 0xffffffffu, tid);
+            if (prev == 0xffffffffu) {
+              fresh = true;
+              break;
+            }
+            if (prev == tid) break;
+            hslot = (hslot + 1u) & (SLICE_G_HASH - 1);
+          }
+          if (!fresh) continue;
+          const u32 slot = atomicAdd(&g_ntri, 1u);
+          if (slot >= SLICE_G_TRIS) continue;   // (overflow: the group is handed to k_mbes_slice below)
+          float* vp = verts + 9 * (size_t)slot;
+          vp[0] = v0.x; vp[1] = v0.y; vp[2] = v0.z;
+          vp[3] = v1.x; vp[4] = v1.y; vp[5] = v1.z;
+          vp[6] = v2.x; vp[7] = v2.y; vp[8] = v2.z;
+        }
+      }
+    }
+    __syncthreads();
+    const u32 ntri = g_ntri;
+    tight = tight && ntri <= SLICE_G_TRIS;
+    if (!tight) {   // left to k_mbes_slice: onto its list (order irrelevant)
+      if (threadIdx.x == 0) a.slice_loose[atomicAdd(a.slice_loose_count, 1)] = (u32)g;
+      continue;
+    }
+    // ---- B: every wave casts its members against the staged triangles (k_mbes_slice's phases B1, B2 and 4)
+    for (int mbr = w; mbr < SLICE_G; mbr += SLICE_G_WAVES) {
+      const long long i = i0 + mbr;
+      if (i >= a.n) break;
+      MbesPose P;
+      u32 slot;
+      {
+        const MbesPose Pv = a.pose[i];   // wave-uniform: scalar registers
+        slot = (u32)__builtin_amdgcn_readfirstlane((int)Pv.slot);
+        P.um = uniform_f64(Pv.um);
+        P.vm = uniform_f64(Pv.vm);
+        P.oz = uniform_f32(Pv.oz);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          P.c1[r] = uniform_f32(Pv.c1[r]);
+          P.c2[r] = uniform_f32(Pv.c2[r]);
+        }
+      }
+      const float c2z = P.c2[2];
+      const float h1 = P.c1[0] * P.c1[0] + P.c1[1] * P.c1[1];
+      const bool sane = fabs(P.um) < 1e9 && fabs(P.vm) < 1e9;
+      if (!(sane && c2z >= 0.5f && h1 >= 0.25f)) {   // (NaN: declined) -> the general kernel, by the record's position
+        if (lane == 0) a.defer_idx[atomicAdd(a.defer_count, 1)] = (u32)i;
+        continue;
+      }
+      for (int b = lane; b < B; b += 64) rng[b] = rmax_bits;
+      const double Ox = ma.x0 + P.um * (double)cs, Oy = ma.y0 + P.vm * (double)cs;
+      const float Oxf = (float)Ox, Oyf = (float)Oy, dOx = (float)(Ox - (double)Oxf), dOy = (float)(Oy - (double)Oyf);
+      const float oz = P.oz;
+      const float nx = P.c1[1] * P.c2[2] - P.c1[2] * P.c2[1], ny = P.c1[2] * P.c2[0] - P.c1[0] * P.c2[2],
+                  nz = P.c1[0] * P.c2[1] - P.c1[1] * P.c2[0];
+      // one segment per staged triangle this member's plane separates (k_mbes_slice's arithmetic, expression for
+      // expression; the group-level test has left few triangles that no member cuts, so the list is not compacted first)
+      for (u32 it = lane; it < ntri; it += 64) {
+        const float* vp = verts + 9 * (size_t)it;
+        const float x0 = (vp[0] - Oxf) - dOx, y0 = (vp[1] - Oyf) - dOy, z0 = vp[2] - oz;
+        const float x1 = (vp[3] - Oxf) - dOx, y1 = (vp[4] - Oyf) - dOy, z1 = vp[5] - oz;
+        const float x2 = (vp[6] - Oxf) - dOx, y2 = (vp[7] - Oyf) - dOy, z2 = vp[8] - oz;
+        const float d0 = fmaf(nx, x0, fmaf(ny, y0, nz * z0)), d1 = fmaf(nx, x1, fmaf(ny, y1, nz * z1)),
+                    d2 = fmaf(nx, x2, fmaf(ny, y2, nz * z2));
+        const bool p0 = d0 > 0.f, p1 = d1 > 0.f, p2 = d2 > 0.f;
+        if (p0 == p1 && p1 == p2) continue;   // (not separated by this member's plane; NaN vertices: all false)
+        const int L = (p0 != p1 && p0 != p2) ? 0 : ((p1 != p0 && p1 != p2) ? 1 : 2);
+        const float xl = L == 0 ? x0 : (L == 1 ? x1 : x2), yl = L == 0 ? y0 : (L == 1 ? y1 : y2), zl = L == 0 ? z0 : (L == 1 ? z1 : z2);
+        const float xm = L == 0 ? x1 : x0, ym = L == 0 ? y1 : y0, zm = L == 0 ? z1 : z0;
+        const float xn = L == 2 ? x1 : x2, yn = L == 2 ? y1 : y2, zn = L == 2 ? z1 : z2;
+        const float dl = L == 0 ? d0 : (L == 1 ? d1 : d2), dm = L == 0 ? d1 : d0, dnn = L == 2 ? d1 : d2;
+        const float sl = fmaf(P.c1[0], xl, fmaf(P.c1[1], yl, P.c1[2] * zl)), tl = -fmaf(P.c2[0], xl, fmaf(P.c2[1], yl, c2z * zl));
+        const float sm = fmaf(P.c1[0], xm, fmaf(P.c1[1], ym, P.c1[2] * zm)), tm = -fmaf(P.c2[0], xm, fmaf(P.c2[1], ym, c2z * zm));
+        const float sn = fmaf(P.c1[0], xn, fmaf(P.c1[1], yn, P.c1[2] * zn)), tn = -fmaf(P.c2[0], xn, fmaf(P.c2[1], yn, c2z * zn));
+        const bool lpos = dl > 0.f;
+        float sA, tA, sB, tB;
+        {
+          const float db = lpos ? dm : dl, da = lpos ? dl : dm;
+          const float sbv = lpos ? sm : sl, sav = lpos ? sl : sm, tbv = lpos ? tm : tl, tav = lpos ? tl : tm;
+          const float lam = db * __builtin_amdgcn_rcpf(db - da);
+          sA = fmaf(lam, sav - sbv, sbv);
+          tA = fmaf(lam, tav - tbv, tbv);
+        }
+        {
+          const float db = lpos ? dnn : dl, da = lpos ? dl : dnn;
+          const float sbv = lpos ? sn : sl, sav = lpos ? sl : sn, tbv = lpos ? tn : tl, tav = lpos ? tl : tn;
+          const float lam = db * __builtin_amdgcn_rcpf(db - da);
+          sB = fmaf(lam, sav - sbv, sbv);
+          tB = fmaf(lam, tav - tbv, tbv);
+        }
+        if (!(tA > 0.f) && !(tB > 0.f)) continue;
+        const float INF = __builtin_inff();
+        const float cross = sA * tB - sB * tA;
+        const float TA = tA > 0.f ? sA * __builtin_amdgcn_rcpf(tA) : (cross > 0.f ? INF : -INF);
+        const float TB = tB > 0.f ? sB * __builtin_amdgcn_rcpf(tB) : (cross < 0.f ? INF : -INF);
+        const float T_lo = fminf(TA, TB), T_hi = fmaxf(TA, TB);
+        if (T_hi < tan_lo || T_lo > tan_hi) continue;
+        const float T_first = T_lo - 1e-6f * fmaxf(1.f, fabsf(T_lo)), T_last = T_hi + 1e-6f * fmaxf(1.f, fabsf(T_hi));
+        int lo = (int)lut[min(max((int)((T_first - lut_lo) * lut_iw) - 1, 0), SLICE_LUT - 1)];
+        while (lo < B && tsb[lo].x < T_first) ++lo;
+        const float dts = tB - tA;
+        float2 ts = tsb[min(lo, B - 1)];   // (requested one beam ahead, as in k_mbes_slice)
+        for (int b = lo; b < B; ++b) {
+          const float T = ts.x, sec_b = ts.y;
+          if (T > T_last) break;
+          ts = tsb[min(b + 1, B - 1)];
+          const float eA = fmaf(-T, tA, sA), eB = fmaf(-T, tB, sB);
+          if ((eA > 0.f) == (eB > 0.f) && eA != 0.f && eB != 0.f) continue;
+          const float den = eA - eB;
+          float lam = den != 0.f ? eA * __builtin_amdgcn_rcpf(den) : 0.f;
+          lam = fminf(fmaxf(lam, 0.f), 1.f);
+          const float tau = fmaf(lam, dts, tA);
+          if (!(tau > 0.f)) continue;
+          const float range = tau * sec_b;
+          if (range < a.r_max) lds_min_range(&rng[b], range);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      float acc = 0.f;
+      int nvalid = 0;
+      for (int b = lane; b < B; b += 64) {
+        const float e = __uint_as_float(rng[b]);
+        const float rm = a.ranges[b];
+        if (rm > 0.f) {  // NaN fails the test
+          const float d = (rm - e) * a.inv_sigma;
+          acc += d * d;
+          ++nvalid;
+        }
+      }
+      const double accd = wave_sum((double)acc);
+      const int nv = wave_sum(nvalid);
+      if (lane == 0) {
+        const double v = -0.5 * accd - (double)nv * a.lognorm;
+        a.lw[slot] = v;
+        wmax = v > wmax ? v : wmax;  // NaN never wins
+      }
+    }
+  }
+  if (lane == 0 && a.max_slots && wmax > -__builtin_inf())
+    atomicMax((unsigned long long*)&a.max_slots[(blockIdx.x * SLICE_G_WAVES + w) & (MCL_MAX_SLOTS - 1)], ordered_key(wmax));
 }

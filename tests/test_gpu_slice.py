@@ -238,3 +238,54 @@ def test_slice_fuzz_against_the_oracle(seed, eng, orc, monkeypatch):
         seed, nt, size, B, path[1], n, err.max(), bad, err.size))
     assert bad <= max(3, err.size // 2000), np.sort(err.ravel())[-6:]
     outliers_explained(orc, mesh, soa, ba, got, ref, r_max, label='slice fuzz %d' % seed)
+
+
+@pytest.mark.parametrize('kind', ['tin', 'regular'])
+def test_slice_over_groups_of_neighbours_equals_the_per_particle_slice_bitwise(kind, eng, monkeypatch):
+    """With the visiting order 36 consecutive pose records are spatial neighbours: k_mbes_slice_group builds ONE candidate
+    triangle list per group (every test widened by the group's spread), stages each triangle's vertices once in LDS and
+    casts the members with the per-particle kernel's own arithmetic.  A member's result is the minimum over the triangles
+    ITS plane cuts, and the staged set contains them all: the filter is bit for bit the one the per-particle kernel
+    runs -- log-weights, indices, states --, on the irregular TIN cast as a soup (a triangle lies in several cells: staged
+    once) and on the regular mesh, while most groups really take the group path."""
+    monkeypatch.delenv('MCL_SLICE', raising=False)
+    monkeypatch.setenv('MCL_VISIT', '1')
+    origin = (-64.0, -128.0)
+    z = synth.bathymetry_grid(256, 256, 1.0, origin, seed=3)
+    verts, tris = synth.mesh_tin(z, 1.0, origin, seed=7) if kind == 'tin' else synth.mesh_from_grid(z, 1.0, origin)
+    n, B, steps = 65536, 200, 5
+    stream = synth.odom_stream(steps)
+    ba = synth.beam_angles(B)
+    one = eng.Engine(1, rng_mode=eng.RNG_REPLAY)
+    one.set_map_mesh(verts, tris)
+    rs = np.random.RandomState(2)
+    pings = []
+    for k in range(steps):
+        one.set_particles(stream['truth'][k][:, None].copy())
+        pings.append((one.mbes_expected(0, 1, ba, 100.0)[0] + 0.2 * rs.randn(B)).astype(np.float32))
+    one.close()
+    res = {}
+    for group in ('1', '0'):
+        monkeypatch.setenv('MCL_SLICE_GROUP', group)
+        e = eng.Engine(n, seed=3, init_cov=[4.0, 4.0, 0, 0, 0, 0.02], process_cov=[1e-4, 1e-4, 0, 0, 0, 1e-6],
+                       resample_cov=[1e-2, 1e-2, 0, 0, 0, 1e-5])
+        e.set_map_mesh(verts, tris, general=True)
+        e.init_particles()
+        out = []
+        for k in range(steps):
+            e.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'], pings[k], ba, 0.2, 100.0)
+            path = e.mbes_last_path()
+            assert path[0] == 2, path
+            out.append((e.get_log_weights(), e.last_indices(), e.get_particles(), path))
+        e.close()
+        res[group] = out
+    ngroups = (n + 35) // 36
+    loose = [o[3][2] for o in res['1']]
+    print('%s: groups left to the per-particle kernel per step: %r of %d' % (kind, loose, ngroups))
+    assert loose[0] == -1                         # the first step has no visiting order: no groups
+    assert all(0 <= v < ngroups // 4 for v in loose[2:]), loose
+    assert all(o[3][2] == -1 for o in res['0'])
+    for k, (x, y) in enumerate(zip(res['1'], res['0'])):
+        assert np.array_equal(x[0], y[0]), (k, int((x[0] != y[0]).sum()))
+        assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]), k
+        assert x[3][1] == y[3][1]
