@@ -40,6 +40,7 @@
 #define CTRL_T_QUANT (CTRL_WORK + 12)      // u32 tickets, self-resetting
 #define CTRL_T_EXPAND (CTRL_WORK + 16)
 #define CTRL_T_GATHER (CTRL_WORK + 20)
+#define CTRL_T_VISIT (CTRL_WORK + 24)
 #define CTRL_BYTES 1024
 
 namespace {

@@ -665,11 +665,21 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
 // of them: all resident), wave r takes a run of ceil(G / 16) rows; the particles in earlier bins come from a look-back
 // over the other workgroups' descriptors -- ONE wave reads all of them at once --, so there is no second pass and no
 // "last block".
-__global__ void __launch_bounds__(1024) k_visit_scan(VisitArgs a, int G) {
+__global__ void __launch_bounds__(1024) k_visit_scan(VisitArgs a, int G, u32* ticket) {
   __shared__ u32 sh[16][64];
   __shared__ u32 binbase[64];
+  __shared__ u32 slice_sh;
   const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
-  const int bin = blockIdx.x * 64 + lane;
+  // (slices are handed out by a ticket, like k_cdf_expand's tiles: a workgroup only ever waits for slices that are
+  //  already running, whatever else shares the chip -- the shards of a LOCAL group launch their scans side by side)
+  if (threadIdx.x == 0) {
+    const u32 t = atomicAdd(ticket, 1u);
+    slice_sh = t;
+    if (t == gridDim.x - 1u) atomicExch(ticket, 0u);   // every ticket of this launch has been drawn
+  }
+  __syncthreads();
+  const u32 slice = slice_sh;
+  const int bin = (int)slice * 64 + lane;
   const int rpg = (G + 15) >> 4;
   u32 v[16];
 #pragma unroll
@@ -698,12 +708,12 @@ __global__ void __launch_bounds__(1024) k_visit_scan(VisitArgs a, int G) {
     const u32 incl = wave_scan_incl_dpp(tot);
     const u32 mine = readlane63(incl);
     const u64 tag = (u64)a.epoch << 32;
-    if (lane == 0) store_agent(&a.desc[blockIdx.x], tag | (u64)mine);
+    if (lane == 0) store_agent(&a.desc[slice], tag | (u64)mine);
     u32 before = 0u;
     for (;;) {
-      const u64 d = lane < (int)blockIdx.x ? load_agent(&a.desc[lane]) : tag;
+      const u64 d = lane < (int)slice ? load_agent(&a.desc[lane]) : tag;
       if (__ballot((d >> 32) == (u64)a.epoch) == ~0ull) {
-        before = wave_sum_dpp(lane < (int)blockIdx.x ? (u32)d : 0u);
+        before = wave_sum_dpp(lane < (int)slice ? (u32)d : 0u);
         break;
       }
       __builtin_amdgcn_s_sleep(1);
