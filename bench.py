@@ -67,6 +67,7 @@ def parse(argv=None):
     ap.add_argument('--no-overlap', action='store_true', help='in-line state all-gather (no second communicator)')
     ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-spawned ranks: wall-clock limit, seconds')
     # launcher self-test (CPU, gloo): rendezvous + barrier + all-reduce only, no engine, no GPU
+    ap.add_argument('--temper', action='store_true', help='experiments: the main leg with the likelihood tempered by 1 / beams (extra.filter_tempered\'s filter)')
     ap.add_argument('--dry-run', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--dry-run-fail-rank', type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument('--dry-run-hang-rank', type=int, default=-1, help=argparse.SUPPRESS)
@@ -526,7 +527,7 @@ def worker(a, rank, world, local_rank):
     def run(k0, k1):
         for k in range(k0, k1):
             e.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'],
-                        ranges[k], ba, SIGMA, R_MAX)
+                        ranges[k], ba, SIGMA * (math.sqrt(float(B)) if a.temper else 1.0), R_MAX)
 
     def max_over_ranks(x):
         if dist is None:

@@ -155,7 +155,7 @@ struct mcl_handle {
   bool pose_visit = false;          // pose_dev lies in visiting order (written by the last fused predict)
   int env_visit = -1;               // MCL_VISIT=0/1 forces the decision (tests, A/B)
   int visit_nb[3] = {16, 32, 8};    // MCL_VISIT_BINS=x,y,yaw  (measured at 1 M x 512, sweep us: 8,8,8 277; 16,16,8 268; 16,16,16 265; 16,32,8 263)
-  float visit_range = 3.f;          // MCL_VISIT_RANGE: bins span mean +- range * sigma  (4: 260.5, 3: 257.2, 2.5: 257.1)
+  float visit_range = 2.5f;         // MCL_VISIT_RANGE: bins span mean +- range * sigma  (headline sweep us -- 4: 260.5, 3: 257.2, 2.5: 257.1; the tempered filter -- 4: 300, 3: 294, 2: 288)
   long long visit_min_n = 393216;   // MCL_VISIT_MIN_N: smaller shards are visited in slot order (the order costs ~20 us per step whatever
                                     // the size -- a launch, a second gather pass, scattered record stores --: measured worth +5 us at
                                     // 524 288 x 512, -9 us at 65 536 x 256)
