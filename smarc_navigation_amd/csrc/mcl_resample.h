@@ -377,6 +377,8 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_pack_dupes(PackArgs a) {
 // ------------------------------------------------------------------ K3: gather + noise (+ fused moments)
 #define MOM_COUNT 13   // sum d(x,y,z), sum roll, pitch, yaw, sum wrap(yaw), sum dxx dyy dzz dxy dxz dyz
 #define GATHER_MAX_GRID 256
+static_assert(RS_BLOCK == (1 << VISIT_OWNER_SHIFT) && GATHER_MAX_GRID == VISIT_OWNER_MASK + 1,
+              "k_predict_pose finds the gather workgroup of a slot as (slot >> VISIT_OWNER_SHIFT) & VISIT_OWNER_MASK");
 struct GatherArgs {
   StatePtrs src;  // pre-resample state, GLOBAL indexing (state_glob when sharded)
   StatePtrs dst;  // this shard's slice of the new state

