@@ -289,3 +289,45 @@ def test_slice_over_groups_of_neighbours_equals_the_per_particle_slice_bitwise(k
         assert np.array_equal(x[0], y[0]), (k, int((x[0] != y[0]).sum()))
         assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]), k
         assert x[3][1] == y[3][1]
+
+
+def test_slice_groups_on_a_dispersed_cloud_and_an_odd_particle_count(eng, monkeypatch):
+    """A cloud a metre wide at 12 particles per bin (groups of neighbours whose planes differ by more than the group kernel
+    accepts over a 40 m fan: left to the per-particle kernel, by its list; the bitwise test above is the mostly-tight
+    case), 50 001 particles (the last group is partial), strongly tilted vehicles among
+    them (declined by both kernels: the general kernel casts them, by the record's slot): still bit for bit the
+    per-particle filter."""
+    monkeypatch.delenv('MCL_SLICE', raising=False)
+    monkeypatch.setenv('MCL_VISIT', '1')
+    origin = (-64.0, -128.0)
+    z = synth.bathymetry_grid(256, 256, 1.0, origin, seed=5)
+    verts, tris = synth.mesh_tin(z, 1.0, origin, seed=9)
+    n, B, steps = 50001, 96, 4
+    stream = synth.odom_stream(steps)
+    ba = synth.beam_angles(B)
+    res = {}
+    for group in ('1', '0'):
+        monkeypatch.setenv('MCL_SLICE_GROUP', group)
+        # (a flat likelihood -- sigma 30 m -- keeps the cloud as wide as the resampling noise makes it: ~1 m, 0.01 rad)
+        e = eng.Engine(n, seed=4, init_cov=[4.0, 4.0, 0, 0, 0, 0.001], process_cov=[1e-2, 1e-2, 0, 0, 0, 1e-6],
+                       resample_cov=[0.25, 0.25, 0, 0, 0, 1e-4])
+        e.set_map_mesh(verts, tris, general=True)
+        e.init_particles()
+        out = []
+        for k in range(steps):
+            q = __import__('oracle.oracle', fromlist=['x']).quat_from_euler(1.2 if k == 2 else 0.02, 0.01, 0.0)   # step 2: rolled by 69 degrees
+            e.step_mbes(stream['v'][k], stream['wz'][k], q, stream['z'][k], stream['dt'],
+                        (22.0 / np.cos(ba)).astype(np.float32), ba, 30.0, 100.0)
+            out.append((e.get_log_weights(), e.last_indices(), e.get_particles(), e.mbes_last_path()))
+        e.close()
+        res[group] = out
+    ngroups = (n + 35) // 36
+    loose = [o[3][2] for o in res['1']]
+    handed = [o[3][1] for o in res['1']]
+    print('dispersed cloud: groups left to the per-particle kernel per step %r of %d, handed to the general kernel %r' % (loose, ngroups, handed))
+    assert loose[0] == -1 and min(loose[1:]) > ngroups // 2      # most groups are not tight: cast from the list ...
+    assert handed[2] == n                                         # ... and the rolled step is declined altogether
+    for k, (x, y) in enumerate(zip(res['1'], res['0'])):
+        assert np.array_equal(x[0], y[0]), (k, int((x[0] != y[0]).sum()))
+        assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]), k
+        assert x[3][1] == y[3][1]
