@@ -315,9 +315,10 @@ int mcl_timing_get(mcl_handle* h, mcl_timing* out); /* syncs, returns and resets
  * neighbours the group form of the slice left to the per-particle kernel, or -1 when every particle was cast on its own
  * (no visiting order: DESIGN.md 5).  Any pointer may be NULL. */
 int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64_t* deferred_groups);
-/* The order in which the last FUSED step's fan sweep visited the particles (syncs): slots[p] = state slot of the particle
- * at position p (a wavefront of the sweep casts 64 consecutive positions); *sorted = 1 when the positions follow the
- * spatial order the previous step's gather prepared (bins of x, y, yaw: DESIGN.md 5 "particle order"), 0 when they are
+/* The order in which the last MBES update's fan sweep (or group slice) visited the particles (syncs): slots[p] = state
+ * slot of the particle at position p (a wavefront of the sweep casts 64 consecutive positions); *sorted = 1 when the
+ * positions follow the spatial order the previous resample prepared -- in a fused step, or in mcl_resample right after
+ * mcl_predict + mcl_update_mbes, the node's call sequence -- (bins of x, y, yaw: DESIGN.md 5 "particle order"), 0 when they are
  * the slots themselves (slots[] is then the identity).  Only the visiting order ever changes: state slots, RNG keys and
  * keep / lost / dupes (auv_pf.py:183-198) do not, and no log-likelihood depends on it.  MCL_VISIT=0 switches the
  * spatial order off, MCL_VISIT=1 forces it for shards of any size (default: >= 393 216 particles).  slots: n entries. */

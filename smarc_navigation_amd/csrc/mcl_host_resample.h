@@ -527,21 +527,22 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   }
   a.ticket = ctrl_u32(h, CTRL_T_GATHER);
   const double* rp = replay_normals ? h->replay_dev : nullptr;
-  // the visiting order of the NEXT fan sweep (mcl_kernels.h: VisitArgs): after a swept update of a fused step, shards
-  // large enough for the order to pay.  (The fan slice reads the records by slot too, but gains nothing from the order --
-  // measured 3.68 / 6.14 ms with and without on the two soups: one wave per particle, no lanes to keep together.)
+  // the visiting order of the NEXT fan sweep / group slice (mcl_kernels.h: VisitArgs)
   memset(&a.visit, 0, sizeof a.visit);
   h->visit_ready = false;
   // (the stash kernel -- mcl_resample.h -- takes the sums in a second pass: the fused step with resampling noise on
   //  x, y, yaw only; it also prepares the visiting order)
   const bool uni = a.uni_mask == 0x1cu;   // z, roll, pitch substituted: the lean kernel
-  const bool stash = with_moments && uni && a.nz.sq[2] == 0.0 && a.nz.sq[3] == 0.0 && a.nz.sq[4] == 0.0;
-  // (16-bit counts: at most 65 535 particles per gather workgroup)
-  // (the sweep gains 17 % of 0.3 ms from the order: shards of >= visit_min_n particles; the slice 30 - 45 % of milliseconds
-  //  -- its group kernel needs the order --: from 8 192 particles)
+  // Is a visiting order wanted for the next update?  (the sweep gains 17 % of 0.3 ms from it: shards of >= visit_min_n
+  // particles; the slice 30 - 45 % of milliseconds -- its group kernel needs the order --: from 8 192 particles)
   const bool by_size = h->sweep_now ? h->n >= h->visit_min_n : h->n >= 8192;
-  const bool visit = stash && !rp && (h->sweep_now || (h->slice_now && h->env_slice_group != 0)) && h->env_visit != 0 &&
-                     (h->env_visit == 1 || by_size) && h->n <= 65535ll * GATHER_MAX_GRID;
+  const bool order_ok = !rp && (h->sweep_now || (h->slice_now && h->env_slice_group != 0)) && h->env_visit != 0 &&
+                        (h->env_visit == 1 || by_size) && h->n <= 65535ll * GATHER_MAX_GRID;   // (16-bit counts per workgroup)
+  // (also for a plain mcl_resample right after predict + update -- the node's call sequence --: the sums are then a
+  //  by-product nobody reads, the visiting order is what the stash kernel is taken for)
+  const bool want_order = !with_moments && order_ok && h->world == 1 && !h->comm;
+  const bool stash = (with_moments || want_order) && uni && a.nz.sq[2] == 0.0 && a.nz.sq[3] == 0.0 && a.nz.sq[4] == 0.0;
+  const bool visit = stash && order_ok;
   if (visit) {
     const int nb = h->visit_nb[0] * h->visit_nb[1] * h->visit_nb[2];
     if (!h->visit_okey) {

@@ -253,6 +253,8 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.host_count = nullptr;
   a.reasons = nullptr;
   a.slice = 0;
+  a.visit_okey = a.visit_base = nullptr;
+  a.visit_nb = 0;
   a.slice_loose = nullptr;
   a.slice_loose_count = nullptr;
   a.grid_pad = nullptr;
@@ -397,7 +399,15 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   } seq_guard{h};
   t_begin(h, MCL_K_UPDATE_MBES);
   if (!pose_done) {
-    h->pose_visit = false;   // (the pose kernel below writes the records in slot order)
+    // (the pose kernel below writes the records in slot order -- or, when the last resample of separate calls prepared a
+    //  visiting order for these very slots and a sweep / group slice is about to read them, in that order)
+    h->pose_visit = false;
+    if (with_ranges && h->visit_ready && (sweep || (slice && h->env_slice_group != 0))) {
+      a.visit_okey = h->visit_okey;
+      a.visit_base = h->visit_base;
+      a.visit_nb = h->visit_nb[0] * h->visit_nb[1] * h->visit_nb[2];
+      h->pose_visit = true;
+    }
     // (the fused predict has already reset the control block and written poses, group records and worklist)
     if (a.max_slots)
       HIPCHK(h, hipMemsetAsync(h->ctrl, 0, CTRL_BYTES, h->stream));  // slots + work and hand-over counters (one aligned fill)

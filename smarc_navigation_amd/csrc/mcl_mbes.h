@@ -131,6 +131,11 @@ struct MbesArgs {
   const int* n_dev;           // when set, the classify / cast kernels visit *n_dev entries of perm instead of a.n
   int* host_count;            // pinned host word (or nullptr): k_mbes_cast<.,.,2> leaves the hand-over count there
   int slice;                  // 1: this update is cast by the fan slice (mcl_slice.h)
+  // visiting order (mcl_kernels.h: VisitArgs) for the stand-alone pose kernel: when set, k_mbes_pose<false> stores the record
+  // of slot i at its sorted position (the fused step's predict kernel does the same from its own arguments)
+  const u32* visit_okey;
+  const u32* visit_base;
+  int visit_nb;
   u32* slice_loose;           // fan slice over groups of spatial neighbours (k_mbes_slice_group): the groups of SLICE_G records it leaves to k_mbes_slice (nullptr: k_mbes_slice casts everything)
   int* slice_loose_count;     // ... their number (device counter in the control block, zeroed with it)
   unsigned* reasons;          // SWEEP_REASONS builds: 16 counters, why the sweep declined a particle side (or nullptr)
@@ -322,7 +327,13 @@ __global__ void __launch_bounds__(256) k_mbes_pose(MbesArgs a) {
       sincos(a.st[5][i], &sy, &cy);
       P = make_pose(T, a.st[0][i], a.st[1][i], a.st[2][i], sr, cr, sp, cp, sy, cy);
       P.slot = (u32)i;
-      a.pose[i] = P;
+      u32 pos = (u32)i;
+      if (!CLASSIFY && a.visit_okey) {   // the visiting order the last resample prepared (separate predict / update / resample calls)
+        const u32 ok = a.visit_okey[i], key = ok & ((1u << VISIT_KEY_BITS) - 1u);
+        const u32 owner = ((u32)i >> VISIT_OWNER_SHIFT) & VISIT_OWNER_MASK;
+        pos = a.visit_base[(size_t)owner * a.visit_nb + key] + (ok >> VISIT_KEY_BITS);
+      }
+      a.pose[pos] = P;
     }
     if (CLASSIFY) classify_group(a, P, valid, i);
   }

@@ -134,8 +134,10 @@ def test_hand_overs_keep_their_slot_under_the_visiting_order(eng, terrain, monke
 
 
 def test_separate_calls_between_fused_steps_fall_back_to_slot_order(eng, terrain, monkeypatch):
-    """set_particles / a plain resample invalidate the prepared order; a dt <= 0 step writes its poses in slot order and
-    (no predict in front of its gather: the plain gather kernel) prepares none for the step after it."""
+    """set_particles / a resample that is not preceded by a predict invalidate the prepared order; a dt <= 0 step has its
+    records written by the stand-alone pose kernel -- in the prepared order, like the node's separate calls -- but (no
+    predict in front of its gather: z, roll, pitch are not uniform, the plain gather kernel) prepares none for the step
+    after it."""
     monkeypatch.setenv('MCL_VISIT', '1')
     monkeypatch.setenv('MCL_SWEEP', '1')
     n = 32768
@@ -150,13 +152,50 @@ def test_separate_calls_between_fused_steps_fall_back_to_slot_order(eng, terrain
         return e.mbes_visit_order()[1]
     assert step(0) is False
     assert step(1) is True
-    assert step(2, dt=0.0) is False           # no predict: the pose kernel of the update writes the records
+    assert step(2, dt=0.0) is True            # no predict: the pose kernel of the update writes the records, in the prepared order
     assert step(3) is False
     assert step(4) is True
     e.set_particles(e.get_particles())
     assert step(0) is False
     assert step(1) is True
     e.update_mbes(ranges, ba, 0.2, 100.0)
-    e.resample()                              # the plain gather prepares nothing
+    e.resample()                              # no predict since the last gather: the plain gather kernel prepares nothing
     assert step(2) is False
     e.close()
+
+
+def test_separate_calls_take_the_visiting_order_too(eng, terrain, monkeypatch):
+    """The node's call sequence -- mcl_predict per odometry message, mcl_update_mbes + mcl_resample per ping -- prepares the
+    order in the plain resample (the stash kernel, its sums unused) and scatters the records in the stand-alone pose kernel:
+    bit for bit the same filter as without the order, the sweep's records in sorted order from the second ping on."""
+    n, steps = 65536, 4
+    stream = synth.odom_stream(steps)
+    B = 128
+    ba = synth.beam_angles(B)
+    res = {}
+    for visit in ('1', '0'):
+        monkeypatch.setenv('MCL_VISIT', visit)
+        monkeypatch.setenv('MCL_SWEEP', '1')
+        e = eng.Engine(n, seed=5, **COV)
+        _set_map(e, terrain, 'mesh')
+        e.init_particles()
+        rs = np.random.RandomState(4)
+        out = []
+        for k in range(steps):
+            for sub in range(3):   # three odometry messages per ping
+                e.predict(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'] / 3.0)
+            ranges = (21.0 / np.cos(ba) + 0.05 * rs.randn(B)).astype(np.float32)
+            e.update_mbes(ranges, ba, 0.2, 100.0)
+            slots, srt = e.mbes_visit_order()
+            lw = e.get_log_weights()
+            e.resample()
+            out.append(dict(lw=lw, idx=e.last_indices(), st=e.get_particles(), mc=e.mean_cov(), slots=slots, sorted=srt))
+        e.close()
+        res[visit] = out
+    assert [s['sorted'] for s in res['1']] == [False, True, True, True]
+    assert not any(s['sorted'] for s in res['0'])
+    for k, (x, y) in enumerate(zip(res['1'], res['0'])):
+        assert np.array_equal(x['lw'], y['lw']) and np.array_equal(x['idx'], y['idx']) and np.array_equal(x['st'], y['st']), k
+        for u, v in zip(x['mc'], y['mc']):
+            assert np.array_equal(np.asarray(u), np.asarray(v)), k
+        assert np.array_equal(np.sort(x['slots']), np.arange(n, dtype=np.uint32))
