@@ -354,6 +354,11 @@ def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, re
             e.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'], ranges[k], ba,
                         sig, R_MAX)
             return
+        if resample and os.environ.get('MCL_BENCH_CONFIG5_SEPARATE') != '1':
+            # config 5: the same step with the landmark k-NN likelihood of the ping on top (mcl_step_mbes_landmarks)
+            e.step_mbes_landmarks(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'], ranges[k], ba,
+                                  sig, R_MAX, dets[k], 0.3, k=4, gate=11.345)
+            return
         e.predict(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'])
         e.update_mbes(ranges[k], ba, sig, R_MAX)
         if landmarks is not None:

@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define MCL_ABI_VERSION 3   /* 2: mcl_timing gained MCL_K_MBES_MAIN; 3: the exchange's phases (MCL_K_COMM_RECORDS ... MCL_K_COMM_MOMENTS) */
+#define MCL_ABI_VERSION 4   /* 2: mcl_timing gained MCL_K_MBES_MAIN; 3: the exchange's phases (MCL_K_COMM_RECORDS ... MCL_K_COMM_MOMENTS);
+                               4: MCL_K_UPDATE_LANDMARKS, mcl_step_mbes_landmarks */
 
 typedef struct mcl_handle mcl_handle;
 
@@ -108,7 +109,8 @@ enum mcl_kernel_id {
   MCL_K_PACK = 11,         /* k_pack_dupes: surplus copies into per-copy records */
   MCL_K_COMM_P2P = 12,     /* the ONE group of ncclSend / ncclRecv (at most one each per peer) */
   MCL_K_COMM_MOMENTS = 13, /* all-reduce of the mean / covariance sums */
-  MCL_K_COUNT = 14
+  MCL_K_UPDATE_LANDMARKS = 14, /* k_landmark_update (until ABI 3 counted under MCL_K_UPDATE_MBES) */
+  MCL_K_COUNT = 15
 };
 typedef struct mcl_timing {
   double ms[MCL_K_COUNT];       /* summed device milliseconds */
@@ -238,6 +240,15 @@ int mcl_get_fixed_weights(mcl_handle* h, uint64_t* q, uint64_t* total);
 int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* ranges,
                   const float* beam_angles, int32_t n_beams, double sigma, double r_max,
                   const double sensor_offset[6]);
+/* The same step with the landmark observation of the ping on top (BASELINE config 5): after the MBES update,
+ * mcl_update_landmarks(det_xyz, n_det, lm_sigma, k, gate, lm_sensor_offset, accumulate = 1), then the resample and
+ * mean / cov -- the same particles, weights and moments, bit for bit, as mcl_predict + mcl_update_mbes +
+ * mcl_update_landmarks(accumulate) + mcl_resample leave, without the passes the separate calls need in between
+ * (z / roll / pitch stores, the pose kernel, the max-lw reduction, a second moments pass). */
+int mcl_step_mbes_landmarks(mcl_handle* h, const mcl_odom* odom, double dt, const float* ranges,
+                            const float* beam_angles, int32_t n_beams, double sigma, double r_max,
+                            const double sensor_offset[6], const double* det_xyz, int32_t n_det, double lm_sigma,
+                            int32_t k, double gate, const double lm_sensor_offset[6]);
 int mcl_sync(mcl_handle* h);
 /* mean/cov computed by the last mcl_step_mbes (syncs the stream) */
 int mcl_last_mean_cov(mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9]);
@@ -284,6 +295,11 @@ int mcl_group_mean_cov(mcl_handle** shards, int32_t n_shards, double mean6[6], d
 int mcl_group_step_mbes(mcl_handle** shards, int32_t n_shards, const mcl_odom* odom, double dt, const float* ranges,
                         const float* beam_angles, int32_t n_beams, double sigma, double r_max,
                         const double sensor_offset[6]);
+/* ... and mcl_step_mbes_landmarks over a LOCAL group (BASELINE config 5's step, shard for shard) */
+int mcl_group_step_mbes_landmarks(mcl_handle** shards, int32_t n_shards, const mcl_odom* odom, double dt,
+                                  const float* ranges, const float* beam_angles, int32_t n_beams, double sigma,
+                                  double r_max, const double sensor_offset[6], const double* det_xyz, int32_t n_det,
+                                  double lm_sigma, int32_t k, double gate, const double lm_sensor_offset[6]);
 /* Resample exchange between shards.  Default: O(n) per rank -- every shard expands its own slice of the
  * offspring CDF, the shards all-gather two integers each (lost slots L_r, surplus copies S_r), and rank q sends rank r
  * exactly the surplus copies whose positions in the global dupes order fall into r's lost ranks (ncclSend / ncclRecv in

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get('MCL_LIB', os.path.join(_HERE, 'libmcl_hip.so'))  # MCL_LIB: kernel-variant A/B runs
 
 MCL_K_NAMES = ['predict', 'update_gps', 'update_mbes', 'normalise', 'scan', 'resample', 'mean_cov', 'noise', 'comm',
-               'mbes_main', 'comm_records', 'pack', 'comm_p2p', 'comm_moments']
+               'mbes_main', 'comm_records', 'pack', 'comm_p2p', 'comm_moments', 'update_landmarks']
 
 
 class MclError(RuntimeError):
@@ -43,7 +43,7 @@ class DrOdom(C.Structure):
 
 
 class Timing(C.Structure):
-    _fields_ = [('ms', C.c_double * 14), ('launches', C.c_int64 * 14)]
+    _fields_ = [('ms', C.c_double * len(MCL_K_NAMES)), ('launches', C.c_int64 * len(MCL_K_NAMES))]
 
 
 # every symbol include/mcl.h, mcl_dr.h and mcl_map.h declare: name -> (restype, argtypes)
@@ -80,6 +80,7 @@ SYMBOLS = {
     'mcl_get_last_offspring_cdf': (C.c_int, [_vp, _vp]),
     'mcl_get_fixed_weights': (C.c_int, [_vp, _vp, _vp]),
     'mcl_step_mbes': (C.c_int, [_vp, C.POINTER(Odom), _d, _vp, _vp, _i32, _d, _d, _vp]),
+    'mcl_step_mbes_landmarks': (C.c_int, [_vp, C.POINTER(Odom), _d, _vp, _vp, _i32, _d, _d, _vp, _vp, _i32, _d, _i32, _d, _vp]),
     'mcl_sync': (C.c_int, [_vp]),
     'mcl_last_mean_cov': (C.c_int, [_vp, _vp, _vp, _vp]),
     'mcl_mean_history': (C.c_int, [_vp, _i64, _vp]),
@@ -94,6 +95,8 @@ SYMBOLS = {
     'mcl_group_resample': (C.c_int, [C.POINTER(_vp), _i32, _vp, _i64, C.POINTER(_vp)]),
     'mcl_group_mean_cov': (C.c_int, [C.POINTER(_vp), _i32, _vp, _vp, _vp]),
     'mcl_group_step_mbes': (C.c_int, [C.POINTER(_vp), _i32, C.POINTER(Odom), _d, _vp, _vp, _i32, _d, _d, _vp]),
+    'mcl_group_step_mbes_landmarks': (C.c_int, [C.POINTER(_vp), _i32, C.POINTER(Odom), _d, _vp, _vp, _i32, _d, _d, _vp,
+                                                _vp, _i32, _d, _i32, _d, _vp]),
     'mcl_exchange_stats': (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i32]),
     'mcl_exchange_ops': (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i32]),
     'mcl_exchange_plan': (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
@@ -138,7 +141,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.mcl_abi_version() != 3:
+    if lib.mcl_abi_version() != 4:
         raise ImportError('libmcl_hip.so ABI version mismatch')
     _lib = lib
     return lib

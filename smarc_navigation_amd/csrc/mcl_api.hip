@@ -441,36 +441,46 @@ int mcl_set_landmark_noise(mcl_handle* h, const double* cov6, const double Q6[6]
   return MCL_OK;
 }
 
-int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, double sigma, int32_t k, double gate,
-                         const double sensor_offset[6], int32_t accumulate) {
-  if (!h || !det_xyz || n_det < 1 || !(sigma > 0.0) || k < 1 || k > LM_MAX_K || !(gate > 0.0))
-    return fail(h, MCL_ERR_INVALID, "update_landmarks: bad argument (1 <= k <= 4)");
-  if (!h->landmarks) return fail(h, MCL_ERR_STATE, "update_landmarks: no feature map (call mcl_set_landmarks first)");
-  if (accumulate && !h->have_lw) return fail(h, MCL_ERR_STATE, "update_landmarks: nothing to accumulate onto");
+namespace {
+// one landmark observation (mcl_update_landmarks' arguments)
+struct LandmarkObs {
+  const double* det;
+  int n_det;
+  double sigma;
+  int k;
+  double gate;
+  const double* so;
+};
+// argument checks, the cell grid for this gate radius, the detections on the device.  (A grid rebuild drains the
+// stream -- the old arrays may still be read by a kernel in flight -- so the fused step calls this BEFORE its predict.)
+int landmarks_prepare(mcl_handle* h, const LandmarkObs& o, const char* who) {
+  if (!o.det || o.n_det < 1 || !(o.sigma > 0.0) || o.k < 1 || o.k > LM_MAX_K || !(o.gate > 0.0))
+    return fail(h, MCL_ERR_INVALID, std::string(who) + ": bad argument (1 <= k <= 4)");
+  if (!h->landmarks) return fail(h, MCL_ERR_STATE, std::string(who) + ": no feature map (call mcl_set_landmarks first)");
   RET_IF(set_device(h));
-  {
-    // the cell grid depends on the gate radius only: rebuild (and drain the stream first -- the old
-    // arrays may still be read by a kernel in flight) only when it changes
-    const double radius = landmark_gate_radius(h->landmarks, sigma, gate);
-    if (!(h->landmarks->built_for == radius && h->landmarks->lm)) {
-      std::string err;
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      int rc = landmarks_build(h->landmarks, radius, &err);
-      if (rc != MCL_OK) {
-        h->err = err;
-        return rc;
-      }
+  const double radius = landmark_gate_radius(h->landmarks, o.sigma, o.gate);
+  if (!(h->landmarks->built_for == radius && h->landmarks->lm)) {
+    std::string err;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int rc = landmarks_build(h->landmarks, radius, &err);
+    if (rc != MCL_OK) {
+      h->err = err;
+      return rc;
     }
   }
-  if (n_det > h->det_cap) {
+  if (o.n_det > h->det_cap) {
     if (h->det_dev) (void)hipFree(h->det_dev);
     h->det_dev = nullptr;
-    HIPCHK(h, hipMalloc(&h->det_dev, sizeof(double) * 3 * (size_t)n_det));
-    h->det_cap = n_det;
+    HIPCHK(h, hipMalloc(&h->det_dev, sizeof(double) * 3 * (size_t)o.n_det));
+    h->det_cap = o.n_det;
   }
-  RET_IF(upload(h, h->det_dev, det_xyz, sizeof(double) * 3 * (size_t)n_det));
+  return upload(h, h->det_dev, o.det, sizeof(double) * 3 * (size_t)o.n_det);
+}
+// the k-NN landmark likelihood of every particle.  fused: inside mcl_step_mbes_landmarks -- the predict kernel of the
+// same call may have left z, roll, pitch unstored (uni_deferred), and the kernel leaves max lw in the second slot set
+int landmarks_launch(mcl_handle* h, const LandmarkObs& o, bool accumulate, bool fused) {
   static const double zero6[6] = {0, 0, 0, 0, 0, 0};
-  const double* so = sensor_offset ? sensor_offset : zero6;
+  const double* so = o.so ? o.so : zero6;
   LandmarkArgs a;
   for (int c = 0; c < 6; ++c) a.st[c] = h->state[h->cur] + (size_t)c * h->n;
   a.n = h->n;
@@ -478,7 +488,7 @@ int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, do
   for (int q = 0; q < 3; ++q) a.off_t[q] = so[q];
   rot_rpy(so[3], so[4], so[5], a.off_R);
   a.det = h->det_dev;
-  a.n_det = n_det;
+  a.n_det = o.n_det;
   a.lm = h->landmarks->lm;
   a.cell_start = h->landmarks->cell_start;
   a.gx = h->landmarks->gx;
@@ -486,13 +496,16 @@ int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, do
   a.x0 = h->landmarks->x0;
   a.y0 = h->landmarks->y0;
   a.inv_cs = 1.0 / h->landmarks->cs;
-  a.inv_s2 = 1.0 / (sigma * sigma);
-  a.gate = gate;
-  landmark_noise_args(h->landmarks, sigma, a);
-  a.k = k;
+  a.inv_s2 = 1.0 / (o.sigma * o.sigma);
+  a.gate = o.gate;
+  landmark_noise_args(h->landmarks, o.sigma, a);
+  a.k = o.k;
   a.accumulate = accumulate ? 1 : 0;
   a.lw = h->lw;
-  t_begin(h, MCL_K_UPDATE_MBES);
+  a.uni_mask = (fused && h->uni_deferred) ? 0x1cu : 0u;
+  for (int c = 0; c < 3; ++c) a.uni[c] = h->uni_val[c];
+  a.max_slots = fused ? (u64*)(h->ctrl + CTRL_SLOTS2) : nullptr;   // (zeroed with the whole block by this step's predict / pose launch)
+  t_begin(h, MCL_K_UPDATE_LANDMARKS);
   long long blocks = (h->n + 255) / 256;   // (a wave per 64 particles, four waves per workgroup)
   if (blocks > 16384) blocks = 16384;
   if (a.maha)
@@ -503,9 +516,20 @@ int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, do
   HIPCHK(h, hipGetLastError());
   if (!accumulate) h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
   h->have_lw = true;
-  h->max_valid = false;
+  h->max_valid = fused;
+  if (fused) h->slot_set = 1;
   h->residual_k = -1;
   return MCL_OK;
+}
+}  // namespace
+
+int mcl_update_landmarks(mcl_handle* h, const double* det_xyz, int32_t n_det, double sigma, int32_t k, double gate,
+                         const double sensor_offset[6], int32_t accumulate) {
+  if (!h) return MCL_ERR_INVALID;
+  const LandmarkObs o = {det_xyz, n_det, sigma, k, gate, sensor_offset};
+  RET_IF(landmarks_prepare(h, o, "update_landmarks"));
+  if (accumulate && !h->have_lw) return fail(h, MCL_ERR_STATE, "update_landmarks: nothing to accumulate onto");
+  return landmarks_launch(h, o, accumulate != 0, false);
 }
 
 int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_det, double sigma, int32_t k_cand,
@@ -588,7 +612,7 @@ int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_
     le = hipMemsetAsync(aa.work_count, 0, sizeof(int), h->stream);
   }
   if (le == hipSuccess) {
-    t_begin(h, MCL_K_UPDATE_MBES);
+    t_begin(h, MCL_K_UPDATE_LANDMARKS);
     long long blocks = (h->n + LA_PER_BLOCK - 1) / LA_PER_BLOCK;
     if (blocks > 32768) blocks = 32768;
     // every particle: conflict-free answer or worklist entry; then the solver over the worklist (its grid
@@ -784,14 +808,18 @@ int mcl_get_fixed_weights(mcl_handle* h, uint64_t* q, uint64_t* total) {
   return MCL_OK;
 }
 
-int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* ranges, const float* beam_angles,
-                  int32_t B, double sigma, double r_max, const double sensor_offset[6]) {
+namespace {
+// the fused step of one handle (mcl_step_mbes; with a landmark observation: mcl_step_mbes_landmarks)
+int step_mbes_impl(mcl_handle* h, const mcl_odom* odom, double dt, const float* ranges, const float* beam_angles, int32_t B,
+                   double sigma, double r_max, const double sensor_offset[6], const LandmarkObs* lm, const char* who) {
   if (!h || !odom || !ranges || !beam_angles) return MCL_ERR_INVALID;
-  if (h->cfg.rng_mode != MCL_RNG_NATIVE) return fail(h, MCL_ERR_INVALID, "step_mbes: NATIVE rng only");
-  if (h->world > 1 && !h->comm) return fail(h, MCL_ERR_STATE, "step_mbes: multi-shard handle needs mcl_comm_init");
-  if (B < 1 || !(sigma > 0.0) || !(r_max > 0.0)) return fail(h, MCL_ERR_INVALID, "step_mbes: bad argument");
-  if (h->map_kind < 0) return fail(h, MCL_ERR_STATE, "step_mbes: no map (call mcl_set_map_grid/mesh first)");
+  const std::string w(who);
+  if (h->cfg.rng_mode != MCL_RNG_NATIVE) return fail(h, MCL_ERR_INVALID, w + ": NATIVE rng only");
+  if (h->world > 1 && !h->comm) return fail(h, MCL_ERR_STATE, w + ": multi-shard handle needs mcl_comm_init");
+  if (B < 1 || !(sigma > 0.0) || !(r_max > 0.0)) return fail(h, MCL_ERR_INVALID, w + ": bad argument");
+  if (h->map_kind < 0) return fail(h, MCL_ERR_STATE, w + ": no map (call mcl_set_map_grid/mesh first)");
   RET_IF(set_device(h));
+  if (lm) RET_IF(landmarks_prepare(h, *lm, who));
   // predict writes the MBES pose records of the new state in the same pass (the map and sensor offset are known here)
   // (the beam table first: the group classification in that kernel follows the two extreme beams)
   RET_IF(upload_beams(h, ranges, beam_angles, B));
@@ -801,8 +829,16 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
   const bool sys = h->cfg.resample_scheme == MCL_RESAMPLE_SYSTEMATIC || h->cfg.resample_scheme == MCL_RESAMPLE_NAIVE;
   // (systematic scheme: the gather of this call substitutes z, roll, pitch -- the predict kernel does not store them)
   RET_IF(do_predict(h, odom, dt, nullptr, &pa, &pose_done, sys));
-  int rc_u = h->fault_step ? fail(h, MCL_ERR_STATE, "step_mbes: injected fault after predict") : start_state_gather(h);
+  int rc_u = h->fault_step ? fail(h, MCL_ERR_STATE, w + ": injected fault after predict") : start_state_gather(h);
   if (rc_u == MCL_OK) rc_u = launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, pose_done);
+  if (rc_u == MCL_OK) {
+    h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
+    h->have_lw = true;
+    h->residual_k = -1;
+    // the landmark likelihood of the same ping on top (BASELINE config 5): reads the state the predict left (z, roll,
+    // pitch from the odometry when that kernel did not store them), leaves max lw in the second slot set
+    if (lm) rc_u = landmarks_launch(h, *lm, true, true);
+  }
   if (rc_u != MCL_OK) {
     const std::string keep = h->err;
     (void)cancel_state_gather(h);
@@ -810,9 +846,6 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
     h->err = keep;
     return rc_u;
   }
-  h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
-  h->have_lw = true;
-  h->residual_k = -1;
   // resample; the gather pass also accumulates the sums of update_loc_pose of the new state
   rc_u = run_resample(&h, 1, nullptr, 0, nullptr, sys);
   if (rc_u != MCL_OK) {
@@ -828,37 +861,47 @@ int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* r
   return MCL_OK;
 }
 
-int mcl_group_step_mbes(mcl_handle** shards, int32_t ns, const mcl_odom* odom, double dt, const float* ranges,
-                        const float* beam_angles, int32_t B, double sigma, double r_max, const double sensor_offset[6]) {
+int group_step_mbes_impl(mcl_handle** shards, int32_t ns, const mcl_odom* odom, double dt, const float* ranges,
+                         const float* beam_angles, int32_t B, double sigma, double r_max, const double sensor_offset[6],
+                         const LandmarkObs* lm, const char* who) {
   if (!shards || ns < 1 || !odom || !ranges || !beam_angles) return MCL_ERR_INVALID;
+  const std::string w(who);
   for (int s = 0; s < ns; ++s)
     if (!shards[s] || shards[s]->world != ns || shards[s]->rank != s)
-      return fail(shards[0], MCL_ERR_INVALID, "group_step_mbes: shards must be ranks 0..n-1 of one world");
-  if (B < 1 || !(sigma > 0.0) || !(r_max > 0.0)) return fail(shards[0], MCL_ERR_INVALID, "group_step_mbes: bad argument");
+      return fail(shards[0], MCL_ERR_INVALID, w + ": shards must be ranks 0..n-1 of one world");
+  if (B < 1 || !(sigma > 0.0) || !(r_max > 0.0)) return fail(shards[0], MCL_ERR_INVALID, w + ": bad argument");
   for (int s = 0; s < ns; ++s) {
     mcl_handle* h = shards[s];
-    if (h->cfg.rng_mode != MCL_RNG_NATIVE) return fail(h, MCL_ERR_INVALID, "group_step_mbes: NATIVE rng only");
-    if (h->map_kind < 0) return fail(h, MCL_ERR_STATE, "group_step_mbes: no map (call mcl_set_map_grid/mesh first)");
+    if (h->cfg.rng_mode != MCL_RNG_NATIVE) return fail(h, MCL_ERR_INVALID, w + ": NATIVE rng only");
+    if (h->map_kind < 0) return fail(h, MCL_ERR_STATE, w + ": no map (call mcl_set_map_grid/mesh first)");
     if (h->cfg.resample_scheme != MCL_RESAMPLE_SYSTEMATIC && h->cfg.resample_scheme != MCL_RESAMPLE_NAIVE)
-      return fail(h, MCL_ERR_UNSUPPORTED, "group_step_mbes: only the systematic scheme is sharded");
+      return fail(h, MCL_ERR_UNSUPPORTED, w + ": only the systematic scheme is sharded");
+    if (lm && !h->landmarks) return fail(h, MCL_ERR_STATE, w + ": no feature map (call mcl_set_landmarks first)");
+  }
+  for (int s = 0; s < ns; ++s) {
+    mcl_handle* h = shards[s];
     RET_IF(set_device(h));
+    if (lm) RET_IF(landmarks_prepare(h, *lm, who));
     // the same fused front half as mcl_step_mbes: predict writes the pose records, the sweep leaves max lw in the slots
     RET_IF(upload_beams(h, ranges, beam_angles, B));
     MbesArgs pa;
     RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, false, &pa));
     bool pose_done = false;
     int rc = do_predict(h, odom, dt, nullptr, &pa, &pose_done, true);
-    if (rc == MCL_OK && h->fault_step) rc = fail(h, MCL_ERR_STATE, "group_step_mbes: injected fault after predict");
+    if (rc == MCL_OK && h->fault_step) rc = fail(h, MCL_ERR_STATE, w + ": injected fault after predict");
     if (rc == MCL_OK) rc = launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, pose_done);
+    if (rc == MCL_OK) {
+      h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
+      h->have_lw = true;
+      h->residual_k = -1;
+      if (lm) rc = landmarks_launch(h, *lm, true, true);
+    }
     if (rc != MCL_OK) {
       const std::string keep = h->err;
       for (int t = 0; t <= s; ++t) (void)materialise_uniform(shards[t]);
       h->err = keep;
       return rc;
     }
-    h->weight_mode = MCL_WEIGHT_LOG_SHIFT;
-    h->have_lw = true;
-    h->residual_k = -1;
   }
   const int rc = run_resample(shards, ns, nullptr, 0, nullptr, true);
   if (rc != MCL_OK) {
@@ -868,6 +911,34 @@ int mcl_group_step_mbes(mcl_handle** shards, int32_t ns, const mcl_odom* odom, d
     return rc;
   }
   return collect_fused_moments(shards, ns);
+}
+}  // namespace
+
+int mcl_step_mbes(mcl_handle* h, const mcl_odom* odom, double dt, const float* ranges, const float* beam_angles,
+                  int32_t B, double sigma, double r_max, const double sensor_offset[6]) {
+  return step_mbes_impl(h, odom, dt, ranges, beam_angles, B, sigma, r_max, sensor_offset, nullptr, "step_mbes");
+}
+
+int mcl_step_mbes_landmarks(mcl_handle* h, const mcl_odom* odom, double dt, const float* ranges, const float* beam_angles,
+                            int32_t B, double sigma, double r_max, const double sensor_offset[6], const double* det_xyz,
+                            int32_t n_det, double lm_sigma, int32_t k, double gate, const double lm_sensor_offset[6]) {
+  const LandmarkObs o = {det_xyz, n_det, lm_sigma, k, gate, lm_sensor_offset};
+  return step_mbes_impl(h, odom, dt, ranges, beam_angles, B, sigma, r_max, sensor_offset, &o, "step_mbes_landmarks");
+}
+
+int mcl_group_step_mbes(mcl_handle** shards, int32_t ns, const mcl_odom* odom, double dt, const float* ranges,
+                        const float* beam_angles, int32_t B, double sigma, double r_max, const double sensor_offset[6]) {
+  return group_step_mbes_impl(shards, ns, odom, dt, ranges, beam_angles, B, sigma, r_max, sensor_offset, nullptr,
+                              "group_step_mbes");
+}
+
+int mcl_group_step_mbes_landmarks(mcl_handle** shards, int32_t ns, const mcl_odom* odom, double dt, const float* ranges,
+                                  const float* beam_angles, int32_t B, double sigma, double r_max,
+                                  const double sensor_offset[6], const double* det_xyz, int32_t n_det, double lm_sigma,
+                                  int32_t k, double gate, const double lm_sensor_offset[6]) {
+  const LandmarkObs o = {det_xyz, n_det, lm_sigma, k, gate, lm_sensor_offset};
+  return group_step_mbes_impl(shards, ns, odom, dt, ranges, beam_angles, B, sigma, r_max, sensor_offset, &o,
+                              "group_step_mbes_landmarks");
 }
 
 int mcl_exchange_plan(int32_t world, const uint32_t* lost, const uint32_t* surplus, int32_t rank, uint32_t* send_off,

@@ -41,7 +41,8 @@
 #define CTRL_T_EXPAND (CTRL_WORK + 16)
 #define CTRL_T_GATHER (CTRL_WORK + 20)
 #define CTRL_T_VISIT (CTRL_WORK + 24)
-#define CTRL_BYTES 1024
+#define CTRL_SLOTS2 1024                   // a second set of MCL_MAX_SLOTS u64: max lw after the fused landmark update
+#define CTRL_BYTES 2048
 
 namespace {
 
@@ -76,6 +77,7 @@ struct mcl_handle {
   unsigned char* ctrl = nullptr; // control block: max-lw slots | MBES work counter | kernel tickets (CTRL_* offsets)
   u32 epoch = 0;                 // look-back epoch (one per k_cdf_expand launch)
   bool max_valid = false;        // the slots hold max lw of the current log-weights
+  int slot_set = 0;              // ... which set: 0 = CTRL_SLOTS (MBES kernels, k_max_slots), 1 = CTRL_SLOTS2 (fused landmark update)
   bool pose_ready = false;       // pose_dev already holds the records of the current state (fused predict)
   u64* tile64 = nullptr;
   u32* tile32 = nullptr;
@@ -270,6 +272,7 @@ int fail(mcl_handle* h, int code, const char* msg) {
   if (h) h->err = msg;
   return code;
 }
+int fail(mcl_handle* h, int code, const std::string& msg) { return fail(h, code, msg.c_str()); }
 
 int grid_for(long long n, int block = MCL_BLOCK) {
   long long g = (n + block - 1) / block;

@@ -9,12 +9,13 @@ namespace {
 // resample pipeline, written over a set of shards so that the RCCL path (one shard per process)
 // and the LOCAL test group (several shards in one process) execute the same phases.
 // ------------------------------------------------------------------------------------------
-u64* ctrl_slots(mcl_handle* h) { return (u64*)(h->ctrl + CTRL_SLOTS); }
+u64* ctrl_slots(mcl_handle* h) { return (u64*)(h->ctrl + (h->slot_set ? CTRL_SLOTS2 : CTRL_SLOTS)); }
 u32* ctrl_u32(mcl_handle* h, int off) { return (u32*)(h->ctrl + off); }
 
 // max lw into the slots (unless the update kernel that wrote lw already did it)
 int ensure_max_slots(mcl_handle* h) {
   if (h->max_valid) return MCL_OK;
+  h->slot_set = 0;
   HIPCHK(h, hipMemsetAsync(h->ctrl + CTRL_SLOTS, 0, 8 * MCL_MAX_SLOTS, h->stream));
   k_max_slots<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->lw, h->n, ctrl_slots(h));
   HIPCHK(h, hipGetLastError());

@@ -317,7 +317,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
   a.groups = h->mbes_groups;
   a.work_count = (int*)(h->ctrl + CTRL_WORK);
   // the cast kernels leave max lw in the control block's slots: the normalisation needs no reduction pass
-  a.max_slots = (with_ranges && lw_out == h->lw) ? ctrl_slots(h) : nullptr;
+  a.max_slots = (with_ranges && lw_out == h->lw) ? (u64*)(h->ctrl + CTRL_SLOTS) : nullptr;
   // height grids and structured meshes: the pose kernel classifies the groups, k_mbes_fast casts the
   // eligible ones, k_mbes_cast<.,.,1> the worklist; triangle-record meshes keep the two-mode kernel
   const bool lean = true;  // every map kind: the pose kernel classifies the groups
@@ -418,7 +418,10 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
     else
       k_mbes_pose<false><<<grid_for(h->n), 256, 0, h->stream>>>(a);
   }
-  if (a.max_slots) h->max_valid = true;
+  if (a.max_slots) {
+    h->max_valid = true;
+    h->slot_set = 0;
+  }
   a.perm = nullptr;
   if (sweep) {
     const int nsub = sweep_lanes_per_side(h, with_ranges, B);

@@ -46,6 +46,12 @@ struct LandmarkArgs {
   int k;
   int accumulate;         // add to lw instead of overwriting
   double* lw;
+  // fused step (mcl_step_mbes_landmarks): the predict kernel of the same call has not stored z, roll, pitch (they are
+  // the odometry's on every particle: bit c of uni_mask set = component c is uni[c - 2]); the maximum of the
+  // accumulated lw goes to max_slots (ordered keys, MCL_MAX_SLOTS words) so that no k_max_slots pass follows
+  unsigned uni_mask;
+  double uni[3];
+  u64* max_slots;
 };
 
 // Cost of pairing a detection (already mapped to p = o + R z in the map frame) with landmark slot e, and
@@ -99,10 +105,11 @@ __device__ __forceinline__ double landmark_pair_cost(const LandmarkArgs& a, cons
 
 // sensor pose of particle i in the map frame (fp64): M = m2o * T(x,y,z) R(rpy) * T_off R_off
 __device__ __forceinline__ void landmark_sensor_pose(const LandmarkArgs& a, long long i, double Rs[9], double o[3]) {
-  const double x = a.st[0][i], y = a.st[1][i], z = a.st[2][i];
+  const bool uni = a.uni_mask == 0x1cu;   // (all three or none: do_predict's skip_uniform)
+  const double x = a.st[0][i], y = a.st[1][i], z = uni ? a.uni[0] : a.st[2][i];
   double sr, cr, sp, cp, sy, cy;
-  sincos(a.st[3][i], &sr, &cr);
-  sincos(a.st[4][i], &sp, &cp);
+  sincos(uni ? a.uni[1] : a.st[3][i], &sr, &cr);
+  sincos(uni ? a.uni[2] : a.st[4][i], &sp, &cp);
   sincos(a.st[5][i], &sy, &cy);
   const double Rp[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
                         sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
@@ -136,6 +143,7 @@ __global__ void __launch_bounds__(256) k_landmark_update(LandmarkArgs a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int sub = lane & (LM_SUB - 1), grp = lane >> 4;
   double (*ps)[64] = pose_s[w];
+  double wmax = -__builtin_inf();
   for (long long base = (blockIdx.x * 4ll + w) * 64; base < a.n; base += (long long)gridDim.x * 256) {
     {
       const long long i = base + lane;
@@ -243,12 +251,20 @@ __global__ void __launch_bounds__(256) k_landmark_update(LandmarkArgs a) {
         nvalid += __shfl_xor(nvalid, o2, 64);
       }
       if (sub == 0 && i < a.n) {
-        const double v = acc - (double)nvalid * a.lognorm;
-        a.lw[i] = a.accumulate ? a.lw[i] + v : v;
+        double v = acc - (double)nvalid * a.lognorm;
+        if (a.accumulate) v += a.lw[i];
+        a.lw[i] = v;
+        wmax = (v > wmax) ? v : wmax;   // NaN never wins (k_max_slots)
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // (the next pass rewrites the pose records)
+  }
+  if (a.max_slots) {
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, o2, 64));
+    if (lane == 0 && wmax > -__builtin_inf())
+      atomicMax((unsigned long long*)&a.max_slots[(blockIdx.x * 4 + w) & (MCL_MAX_SLOTS - 1)], ordered_key(wmax));
   }
 }
 

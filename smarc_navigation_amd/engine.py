@@ -213,6 +213,17 @@ class Engine(object):
         self._ck(self.lib.mcl_step_mbes(self.h, C.byref(od), float(dt), _ptr(r), _ptr(a), a.size, float(sigma),
                                         float(r_max), _ptr(so)))
 
+    def step_mbes_landmarks(self, v, wz, q, z, dt, ranges, beam_angles, sigma, r_max, det_xyz, lm_sigma, k=1, gate=11.345,
+                            sensor_offset=None, lm_sensor_offset=None):
+        """step_mbes with the landmark observation of the ping accumulated onto the MBES log-likelihood (BASELINE
+        config 5): mcl_step_mbes_landmarks"""
+        od = make_odom(v, wz, q, z)
+        r, a, so = _f32(ranges), _f32(beam_angles), _f64(sensor_offset)
+        d, lso = _f64(det_xyz), _f64(lm_sensor_offset)
+        self._ck(self.lib.mcl_step_mbes_landmarks(self.h, C.byref(od), float(dt), _ptr(r), _ptr(a), a.size, float(sigma),
+                                                  float(r_max), _ptr(so), _ptr(d), d.shape[0], float(lm_sigma), int(k),
+                                                  float(gate), _ptr(lso)))
+
     def sync(self):
         self._ck(self.lib.mcl_sync(self.h))
 
@@ -297,6 +308,20 @@ def group_step_mbes(engines, v, wz, q, z, dt, ranges, beam_angles, sigma, r_max,
     r, a, so = _f32(ranges), _f32(beam_angles), _f64(sensor_offset)
     _lib.check(lib.mcl_group_step_mbes(hs, ns, C.byref(od), float(dt), _ptr(r), _ptr(a), a.size, float(sigma),
                                        float(r_max), _ptr(so)), engines[0].h)
+
+
+def group_step_mbes_landmarks(engines, v, wz, q, z, dt, ranges, beam_angles, sigma, r_max, det_xyz, lm_sigma, k=1,
+                              gate=11.345, sensor_offset=None, lm_sensor_offset=None):
+    """group_step_mbes with the landmark observation of the ping on top (mcl_group_step_mbes_landmarks)"""
+    lib = _lib.load()
+    ns = len(engines)
+    hs = (C.c_void_p * ns)(*[e.h for e in engines])
+    od = make_odom(v, wz, q, z)
+    r, a, so = _f32(ranges), _f32(beam_angles), _f64(sensor_offset)
+    d, lso = _f64(det_xyz), _f64(lm_sensor_offset)
+    _lib.check(lib.mcl_group_step_mbes_landmarks(hs, ns, C.byref(od), float(dt), _ptr(r), _ptr(a), a.size, float(sigma),
+                                                 float(r_max), _ptr(so), _ptr(d), d.shape[0], float(lm_sigma), int(k),
+                                                 float(gate), _ptr(lso)), engines[0].h)
 
 
 def group_mean_cov(engines):

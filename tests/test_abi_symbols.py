@@ -27,7 +27,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), 'libmcl_hip.so does not export %s' % n
         assert n in _lib.SYMBOLS, 'ctypes table misses %s' % n
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.load().mcl_abi_version() == 3
+    assert _lib.load().mcl_abi_version() == 4
 
 
 def test_config_struct_matches_header_layout():
@@ -35,7 +35,7 @@ def test_config_struct_matches_header_layout():
     # 3*8 + 6*4 + 8 + 18*8 + 8 + 16*8
     assert ctypes.sizeof(_lib.Config) == 24 + 24 + 8 + 144 + 8 + 128
     assert ctypes.sizeof(_lib.Odom) == 8 * 10
-    assert ctypes.sizeof(_lib.Timing) == 14 * 16   # MCL_K_COUNT entries of (double ms, int64 launches)
+    assert ctypes.sizeof(_lib.Timing) == 15 * 16   # MCL_K_COUNT entries of (double ms, int64 launches)
 
 
 def test_no_silent_fallback_without_gpu(gpu_available):

@@ -156,6 +156,70 @@ def test_config5_eight_local_shards_with_landmark_knn_bitwise():
     np.testing.assert_allclose(eng.group_mean_cov(many)[0], one.mean_cov()[0], rtol=0, atol=1e-10)
 
 
+def test_config5_fused_step_equals_the_separate_calls_on_one_gpu_and_on_eight_shards():
+    """mcl_step_mbes_landmarks (one launch sequence: predict + pose records, fan sweep, landmark k-NN on top, resample
+    + moments) against mcl_predict + mcl_update_mbes + mcl_update_landmarks(accumulate) + mcl_resample, and against
+    mcl_group_step_mbes_landmarks over 8 shards of 524 288: log-weights, ancestor indices and particles bit for bit."""
+    from smarc_navigation_amd import engine as eng
+    verts, tris, _ = _mesh()
+    steps = 3
+    stream = synth.odom_stream(steps)
+    ba = synth.beam_angles(B)
+    ranges = _ranges(eng, verts, tris, stream['truth'], ba, 4)
+    lm = synth.landmark_map(4096, (-64.0, -354.0, 643.0, 353.0))
+    rs = np.random.RandomState(8)
+    dets = []
+    for k in range(steps):
+        t = stream['truth'][k]
+        T = synth.rigid_matrix(*t)
+        near = lm[np.argsort(np.sum((lm[:, :2] - t[:2]) ** 2, axis=1))[:16]]
+        dets.append((near - T[:3, 3]).dot(T[:3, :3]) + 0.05 * rs.randn(16, 3))
+    sep = eng.Engine(N, seed=5, **COV)
+    one = eng.Engine(N, seed=5, **COV)
+    many = [eng.Engine(NS, rank=r, world=SHARDS, n_global=N, global_offset=r * NS, seed=5, **COV) for r in range(SHARDS)]
+    for e in [sep, one] + many:
+        e.set_map_mesh(verts, tris)
+        e.set_landmarks(lm)
+        e.init_particles()
+    for k in range(steps):
+        od = (stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'])
+        sep.predict(*od)
+        sep.update_mbes(ranges[k], ba, SIGMA, R_MAX)
+        lw_mbes = sep.get_log_weights()
+        sep.update_landmarks(dets[k], 0.3, k=4, gate=11.345, accumulate=True)
+        lw_sep = sep.get_log_weights()
+        assert np.std(lw_sep - lw_mbes) > 0.5   # the landmark term is there and discriminates
+        sep.resample()
+        args = od + (ranges[k], ba, SIGMA, R_MAX, dets[k], 0.3)
+        one.step_mbes_landmarks(*args, k=4, gate=11.345)
+        eng.group_step_mbes_landmarks(many, *args, k=4, gate=11.345)
+        assert one.mbes_last_path()[0] == 1 and all(e.mbes_last_path()[0] == 1 for e in many)   # the fan sweep
+        lw1 = one.get_log_weights()
+        assert np.array_equal(lw1, lw_sep), k
+        assert np.array_equal(lw1, np.concatenate([e.get_log_weights() for e in many])), k
+        idx1 = one.last_indices()
+        assert np.array_equal(idx1, sep.last_indices()), k
+        assert np.array_equal(idx1, np.concatenate([e.last_indices() for e in many])), k
+        st1 = one.get_particles()
+        assert np.array_equal(st1, sep.get_particles()), k
+        assert np.array_equal(st1, np.concatenate([e.get_particles() for e in many], axis=1)), k
+        m1, y1, c1 = one.last_mean_cov()
+        ms, ys, cs = sep.mean_cov()
+        mm, ym, cm = many[0].last_mean_cov()
+        np.testing.assert_allclose(m1, ms, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(c1, cs, rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(mm, m1, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(cm, c1, rtol=1e-9, atol=1e-12)
+    # the landmark kernel has its own timing region (ABI 4)
+    one.timing_enable(True)
+    one.step_mbes_landmarks(*args, k=4, gate=11.345)
+    one.sync()
+    tim = one.timing_get()
+    one.timing_enable(False)
+    assert tim['update_landmarks'][1] == 1 and tim['update_landmarks'][0] > 0.0
+    assert tim['normalise'][0] < 0.05   # no max-lw reduction pass: the kernel left the maximum in the slots (ms)
+
+
 def test_metric_config_fused_step_trajectory_vs_oracle():
     """1 048 576 particles x 512 beams on the 999 698-triangle mesh, mcl_step_mbes x 5 against the oracle filter
     with the same Philox draws (the 'pose RMSE vs ref' of the metric at the metric's size).  Bound: BASELINE.md 4."""

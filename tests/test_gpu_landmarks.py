@@ -98,3 +98,72 @@ def test_update_landmarks_needs_a_feature_map():
     with pytest.raises(eng.MclError) as ei:
         e.update_landmarks(np.zeros((2, 3)), 0.5)
     assert ei.value.status == -5
+
+
+@pytest.mark.parametrize('mode', ['iso', 'maha'])
+def test_fused_landmark_step_on_a_grid_equals_the_separate_calls(mode):
+    """mcl_step_mbes_landmarks on a height grid at an odd particle count, isotropic and Mahalanobis, a sensor offset on
+    both sensors, including a dt = 0 step (the predict does not run: z, roll, pitch are read from the state) and a
+    ping without a single valid detection -- against the separate calls, bit for bit."""
+    from smarc_navigation_amd import engine as eng
+    n = 70001
+    z = synth.bathymetry_grid(256, 256, 1.0, (-64.0, -128.0), seed=3)
+    lm = synth.landmark_map(2048, (-60.0, -120.0, 180.0, 120.0))
+    stream = synth.odom_stream(5)
+    ba = synth.beam_angles(64)
+    rs = np.random.RandomState(1)
+    cov = dict(init_cov=[1.0, 1.0, 0.0, 0.0, 0.0, 0.02], process_cov=[1e-3, 1e-3, 0.0, 0.0, 0.0, 1e-5],
+               resample_cov=[1e-3, 1e-3, 0.0, 0.0, 0.0, 1e-5])
+    off, lm_off = [0.2, 0.0, -0.1, 0.0, 0.02, 0.0], [0.5, 0.1, 0.0, 0.0, 0.0, 0.03]
+    a = eng.Engine(n, seed=9, **cov)
+    b = eng.Engine(n, seed=9, **cov)
+    for e in (a, b):
+        e.set_map_grid(z, (-64.0, -128.0), 1.0)
+        e.set_landmarks(lm)
+        if mode == 'maha':
+            cov6 = np.tile([0.04, 0.0, 0.0, 0.09, 0.0, 0.01], (len(lm), 1))
+            e.set_landmark_noise(cov6, [0.09, 0.01, 0.0, 0.09, 0.0, 0.04])
+        e.init_particles()
+    for k in range(5):
+        t = stream['truth'][k]
+        T = synth.rigid_matrix(*t)
+        near = lm[np.argsort(np.sum((lm[:, :2] - t[:2]) ** 2, axis=1))[:12]]
+        det = (near - T[:3, 3]).dot(T[:3, :3]) + 0.05 * rs.randn(12, 3)
+        if k == 3:
+            det[:] = np.nan
+        ranges = (20.0 + rs.rand(64)).astype(np.float32)
+        dt = 0.0 if k == 2 else stream['dt']
+        od = (stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], dt)
+        a.predict(*od)
+        a.update_mbes(ranges, ba, 0.3, 100.0, sensor_offset=off)
+        a.update_landmarks(det, 0.3, k=3, gate=11.345, sensor_offset=lm_off, accumulate=True)
+        lw_a = a.get_log_weights()
+        a.resample()
+        b.step_mbes_landmarks(*od, ranges, ba, 0.3, 100.0, det, 0.3, k=3, gate=11.345, sensor_offset=off,
+                              lm_sensor_offset=lm_off)
+        assert np.array_equal(b.get_log_weights(), lw_a), k
+        assert np.array_equal(b.last_indices(), a.last_indices()), k
+        assert np.array_equal(b.get_particles(), a.get_particles()), k
+        np.testing.assert_allclose(b.last_mean_cov()[0], a.mean_cov()[0], rtol=0, atol=1e-10)
+
+
+def test_fused_landmark_step_argument_and_state_errors():
+    from smarc_navigation_amd import engine as eng
+    e = eng.Engine(256, seed=1)
+    z = np.full((32, 32), -20.0)
+    e.set_map_grid(z, (-16.0, -16.0), 1.0)
+    e.init_particles()
+    ba = synth.beam_angles(16)
+    r = np.full(16, 20.0, np.float32)
+    od = ([1.0, 0, 0], 0.0, [0, 0, 0, 1.0], -2.0, 0.1)
+    with pytest.raises(eng.MclError, match='no feature map'):
+        e.step_mbes_landmarks(*od, r, ba, 0.2, 100.0, np.zeros((2, 3)), 0.3)
+    e.set_landmarks(np.zeros((4, 3)))
+    with pytest.raises(eng.MclError, match='bad argument'):
+        e.step_mbes_landmarks(*od, r, ba, 0.2, 100.0, np.zeros((2, 3)), 0.3, k=9)
+    before = e.get_particles()
+    with pytest.raises(eng.MclError):
+        e.step_mbes_landmarks(*od, r, ba, -1.0, 100.0, np.zeros((2, 3)), 0.3)
+    assert np.array_equal(e.get_particles(), before)   # nothing ran
+    e.step_mbes_landmarks(*od, r, ba, 0.2, 100.0, np.zeros((2, 3)), 0.3)
+    assert np.all(np.isfinite(e.last_mean_cov()[0]))

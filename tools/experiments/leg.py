@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""One extra leg of bench.py alone (profiling runs): tools/experiments/leg.py config5 [steps]"""
+import json
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+import bench  # noqa: E402
+from smarc_navigation_amd import engine, synth  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'config5'
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+mesh = bench.build_map('mesh')
+kw = dict(P=524288, B=512, steps=steps, warmup=5)
+if name == 'config5':
+    kw['landmarks'] = (synth.landmark_map(4096, (-64.0, -354.0, 643.0, 353.0)), 16)
+out = bench.run_leg(engine, name, mesh, kw.pop('P'), kw.pop('B'), kw.pop('steps'), kw.pop('warmup'), **kw)
+print(json.dumps({k: out[k] for k in ('ms_per_step', 'kernels')}))

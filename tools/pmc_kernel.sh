@@ -6,8 +6,10 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 K=$1; shift
 O=/tmp/pmc_k; rm -rf $O; mkdir -p $O
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY --output-format csv -d $O/a -- python3 $R/bench.py "$@" --steps 4 --warmup 1 --only-main > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD --output-format csv -d $O/b -- python3 $R/bench.py "$@" --steps 4 --warmup 1 --only-main > /dev/null 2>&1
+# PMC_PROG="tools/experiments/leg.py config5 6": another program of the repo instead of bench.py's main leg
+if [ -n "$PMC_PROG" ]; then set -- $R/$PMC_PROG; else set -- $R/bench.py "$@" --steps 4 --warmup 1 --only-main; fi
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY --output-format csv -d $O/a -- python3 "$@" > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD --output-format csv -d $O/b -- python3 "$@" > /dev/null 2>&1
 python3 - $O "$K" <<'PY'
 import csv,glob,sys
 O,K=sys.argv[1:3]
