@@ -482,6 +482,7 @@ int landmarks_launch(mcl_handle* h, const LandmarkObs& o, bool accumulate, bool 
   static const double zero6[6] = {0, 0, 0, 0, 0, 0};
   const double* so = o.so ? o.so : zero6;
   LandmarkArgs a;
+  memset(&a, 0, sizeof a);
   for (int c = 0; c < 6; ++c) a.st[c] = h->state[h->cur] + (size_t)c * h->n;
   a.n = h->n;
   for (int q = 0; q < 12; ++q) a.m2o[q] = h->cfg.m2o[q];
@@ -491,6 +492,8 @@ int landmarks_launch(mcl_handle* h, const LandmarkObs& o, bool accumulate, bool 
   a.n_det = o.n_det;
   a.lm = h->landmarks->lm;
   a.cell_start = h->landmarks->cell_start;
+  a.nb_cell = h->landmarks->nb_cell;
+  a.nb_list = h->landmarks->nb_list;
   a.gx = h->landmarks->gx;
   a.gy = h->landmarks->gy;
   a.x0 = h->landmarks->x0;
@@ -578,6 +581,7 @@ int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_
   static const double zero6[6] = {0, 0, 0, 0, 0, 0};
   const double* so = sensor_offset ? sensor_offset : zero6;
   LandmarkAssignArgs aa;
+  memset(&aa, 0, sizeof aa);   // (uni_mask = 0, max_slots = nullptr: the state is read as stored)
   LandmarkArgs& a = aa.base;
   for (int c = 0; c < 6; ++c) a.st[c] = h->state[h->cur] + (size_t)c * h->n;
   a.n = h->n;
@@ -588,6 +592,8 @@ int mcl_update_landmarks_assign(mcl_handle* h, const double* det_xyz, int32_t n_
   a.n_det = n_det;
   a.lm = h->landmarks->lm;
   a.cell_start = h->landmarks->cell_start;
+  a.nb_cell = h->landmarks->nb_cell;
+  a.nb_list = h->landmarks->nb_list;
   a.gx = h->landmarks->gx;
   a.gy = h->landmarks->gy;
   a.x0 = h->landmarks->x0;

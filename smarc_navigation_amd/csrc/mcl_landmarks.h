@@ -34,6 +34,10 @@ struct LandmarkArgs {
   int n_det;
   const double* lm;       // landmarks in CELL order, 3 doubles each
   const u32* cell_start;  // gx*gy + 1
+  // the 3 x 3 neighbourhood of every query cell, flattened (k_landmark_update): nb_cell[(cx + 2) * (gy + 4) + cy + 2] =
+  // {first entry, count}; an entry = {x, y, z, slot (bits of the 4th double)} in the order the three row ranges are visited
+  const uint2* nb_cell;
+  const double4* nb_list;
   int gx, gy;
   double x0, y0, inv_cs;
   double inv_s2, gate, lognorm;  // lognorm = 3/2 log(2 pi) + 3 log(sigma)  (Mahalanobis mode: + 1/2 log det Q)
@@ -78,9 +82,8 @@ __device__ __forceinline__ void landmark_qm(const LandmarkArgs& a, const double 
   }
 }
 template <bool MAHA>
-__device__ __forceinline__ double landmark_pair_cost(const LandmarkArgs& a, const double Qm[6], double px, double py,
-                                                     double pz, u32 e, double* logdet) {
-  const double dx = px - a.lm[3 * (size_t)e], dy = py - a.lm[3 * (size_t)e + 1], dz = pz - a.lm[3 * (size_t)e + 2];
+__device__ __forceinline__ double landmark_pair_cost_d(const LandmarkArgs& a, const double Qm[6], double dx, double dy,
+                                                       double dz, u32 e, double* logdet) {
   if (!MAHA) {
     *logdet = 0.0;  // constant: folded into lognorm
     return (dx * dx + dy * dy + dz * dz) * a.inv_s2;
@@ -98,6 +101,12 @@ __device__ __forceinline__ double landmark_pair_cost(const LandmarkArgs& a, cons
   return quad / det;
 }
 
+template <bool MAHA>
+__device__ __forceinline__ double landmark_pair_cost(const LandmarkArgs& a, const double Qm[6], double px, double py,
+                                                     double pz, u32 e, double* logdet) {
+  const double dx = px - a.lm[3 * (size_t)e], dy = py - a.lm[3 * (size_t)e + 1], dz = pz - a.lm[3 * (size_t)e + 2];
+  return landmark_pair_cost_d<MAHA>(a, Qm, dx, dy, dz, e, logdet);
+}
 __device__ __forceinline__ double landmark_pair_cost(const LandmarkArgs& a, const double Qm[6], double px, double py,
                                                      double pz, u32 e, double* logdet) {
   return a.maha ? landmark_pair_cost<true>(a, Qm, px, py, pz, e, logdet) : landmark_pair_cost<false>(a, Qm, px, py, pz, e, logdet);
@@ -131,134 +140,98 @@ __device__ __forceinline__ void landmark_sensor_pose(const LandmarkArgs& a, long
            (Rmp[r * 3 + 0] * a.off_t[0] + Rmp[r * 3 + 1] * a.off_t[1] + Rmp[r * 3 + 2] * a.off_t[2]);
 }
 
-// Work layout (round 3): a wave takes 64 particles.  First every lane builds the sensor pose of ONE of them (three fp64
-// sincos, two 3x3 products, R Q R^T in Mahalanobis mode) and leaves it in LDS; then, sixteen times, the wave's 4 x 16
-// lanes answer the (<= 16 per pass) detections of four particles from those records.  (Rounds 1-2 let each of a
-// particle's 16 lanes rebuild the pose: half the kernel's instructions.)  The three cells of a grid row are
-// neighbours in the cell-ordered landmark array: one range per row, three per query, visited in the old order.
-#define LM_POSE_WORDS 18   // o[3], Rs[9], Qm[6]
+// Work layout (round 5): a lane owns a particle and walks the detections of the ping one after the other; the pose
+// (three fp64 sincos, two 3x3 products, R Q R^T in Mahalanobis mode) stays in registers.  The lanes of a wave ask
+// about the SAME detection from neighbouring poses, so in a converged or spatially ordered cloud they read the same
+// table entry and the same landmarks (one cache line per wave instead of sixteen), and the detection is a wave-
+// uniform operand.  (Rounds 3-4: 4 particles x 16 detections per wave pass, poses handed over through LDS, a
+// butterfly sum per particle: 2.4 x the instructions, lane utilisation 0.65, every lane on its own cache lines.)
+// One table load gives the flattened 3 x 3 neighbourhood of the query cell (rounds 1-4: six cell_start loads and
+// three loops); the entry of the NEXT detection is requested before the landmarks of this one are visited, so a
+// detection costs one memory round trip, not two.  The sum over the detections runs in their order, like the oracle's.
 template <bool MAHA>
 __global__ void __launch_bounds__(256) k_landmark_update(LandmarkArgs a) {
-  __shared__ double pose_s[4][LM_POSE_WORDS][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int sub = lane & (LM_SUB - 1), grp = lane >> 4;
-  double (*ps)[64] = pose_s[w];
+  const int ey = a.gy + 4;
+  const double cx_hi = (double)(a.gx + 1), cy_hi = (double)(a.gy + 1);
+  // the detections through the scalar cache (constant address space: written by a copy before this launch)
+  typedef const double __attribute__((address_space(4))) * cdp;
+  const cdp det = (cdp)(unsigned long long)a.det;
   double wmax = -__builtin_inf();
-  for (long long base = (blockIdx.x * 4ll + w) * 64; base < a.n; base += (long long)gridDim.x * 256) {
-    {
-      const long long i = base + lane;
-      if (i < a.n) {
-        double Rs[9], o[3];
-        landmark_sensor_pose(a, i, Rs, o);
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+    double Rs[9], o[3], Qm[6] = {0, 0, 0, 0, 0, 0};
+    landmark_sensor_pose(a, i, Rs, o);
+    if (MAHA) landmark_qm(a, Rs, Qm);
+    // detection d seen from this pose, and the table entry of its cell (cells beyond the one-cell border of the grid
+    // are clamped onto the empty outer ring of the table; NaN coordinates land there too)
+    auto query = [&](int d, double& px, double& py, double& pz, uint2& ent, bool& ok) {
+      const double zx = det[3 * d], zy = det[3 * d + 1], zz = det[3 * d + 2];   // (scalar loads: d is wave-uniform)
+      ok = zx == zx && zy == zy && zz == zz;   // NaN = invalid detection
+      px = o[0] + Rs[0] * zx + Rs[1] * zy + Rs[2] * zz;
+      py = o[1] + Rs[3] * zx + Rs[4] * zy + Rs[5] * zz;
+      pz = o[2] + Rs[6] * zx + Rs[7] * zy + Rs[8] * zz;
+      const double fx = fmin(fmax(floor((px - a.x0) * a.inv_cs), -2.0), cx_hi);
+      const double fy = fmin(fmax(floor((py - a.y0) * a.inv_cs), -2.0), cy_hi);
+      ent = a.nb_cell[(size_t)((int)fx + 2) * ey + ((int)fy + 2)];
+    };
+    double acc = 0.0;
+    int nvalid = 0;
+    double px, py, pz;
+    uint2 ent;
+    bool ok;
+    query(0, px, py, pz, ent, ok);
+    for (int d = 0; d < a.n_det; ++d) {
+      const double cpx = px, cpy = py, cpz = pz;
+      const uint2 cur = ent;
+      const bool cok = ok;
+      if (d + 1 < a.n_det) query(d + 1, px, py, pz, ent, ok);
+      if (!cok) continue;   // (wave-uniform)
+      double best[LM_MAX_K], bld[LM_MAX_K];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ps[k][lane] = o[k];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) ps[3 + k][lane] = Rs[k];
-        if (MAHA) {
-          double Qm[6];
-          landmark_qm(a, Rs, Qm);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) ps[12 + k][lane] = Qm[k];
-        }
+      for (int q = 0; q < LM_MAX_K; ++q) {
+        best[q] = __builtin_inf();
+        bld[q] = 0.0;
       }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (one wave: LDS runs in order; this is for the compiler)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int r = 0; r < 64 / 4; ++r) {
-      if (base + r * 4 >= a.n) break;   // (wave-uniform)
-      const int p = r * 4 + grp;
-      const long long i = base + p;
-      double acc = 0.0;
-      int nvalid = 0;
-      if (i < a.n) {
-        double o[3], Rs[9], Qm[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) o[k] = ps[k][p];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Rs[k] = ps[3 + k][p];
-        if (MAHA) {
-#pragma unroll
-          for (int k = 0; k < 6; ++k) Qm[k] = ps[12 + k][p];
-        }
-        for (int d = sub; d < a.n_det; d += LM_SUB) {
-          const double zx = a.det[3 * d], zy = a.det[3 * d + 1], zz = a.det[3 * d + 2];
-          if (!(zx == zx && zy == zy && zz == zz)) continue;  // NaN = invalid detection
-          const double px = o[0] + Rs[0] * zx + Rs[1] * zy + Rs[2] * zz;
-          const double py = o[1] + Rs[3] * zx + Rs[4] * zy + Rs[5] * zz;
-          const double pz = o[2] + Rs[6] * zx + Rs[7] * zy + Rs[8] * zz;
-          double best[LM_MAX_K], bld[LM_MAX_K];
+      for (u32 e = cur.x; e < cur.x + cur.y; ++e) {
+        const double4 l = a.nb_list[e];
+        double ld;
+        double m = landmark_pair_cost_d<MAHA>(a, Qm, cpx - l.x, cpy - l.y, cpz - l.z, (u32)__double_as_longlong(l.w), &ld);
+        if (m <= a.gate) {
+          // insert into the sorted k-best list
 #pragma unroll
           for (int q = 0; q < LM_MAX_K; ++q) {
-            best[q] = __builtin_inf();
-            bld[q] = 0.0;
-          }
-          const int cx = (int)floor((px - a.x0) * a.inv_cs), cyi = (int)floor((py - a.y0) * a.inv_cs);
-          const int iy0 = max(cyi - 1, 0), iy1 = min(cyi + 1, a.gy - 1);
-          // the three row ranges first (six independent loads), then the landmarks
-          u32 rb[3], re[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const int ix = cx - 1 + k;
-            const bool in = ix >= 0 && ix < a.gx && iy0 <= iy1;
-            const size_t c = (size_t)(in ? ix : 0) * a.gy;
-            rb[k] = in ? a.cell_start[c + iy0] : 0u;
-            re[k] = in ? a.cell_start[c + iy1 + 1] : 0u;
-          }
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-              for (u32 e = rb[k]; e < re[k]; ++e) {
-                double ld;
-                double m = landmark_pair_cost<MAHA>(a, Qm, px, py, pz, e, &ld);
-                if (m <= a.gate) {
-                  // insert into the sorted k-best list
-#pragma unroll
-                  for (int q = 0; q < LM_MAX_K; ++q) {
-                    if (m < best[q]) {
-                      const double t = best[q], tl = bld[q];
-                      best[q] = m;
-                      bld[q] = ld;
-                      m = t;
-                      ld = tl;
-                    }
-                  }
-                }
-              }
-            }
-          double lwd;
-          if (best[0] == __builtin_inf()) {
-            lwd = -0.5 * a.gate;
-          } else {
-            // log sum_k exp(-d_k^2 / 2) / sqrt(det S_k / det Q) over the k nearest inside the gate, anchored at the nearest
-            const double e0 = -0.5 * (best[0] + bld[0]);
-            lwd = e0;   // (one neighbour in the gate: exp(0) = 1, log(1) = 0 -- the same number without the calls)
-            if (a.k > 1 && best[1] != __builtin_inf()) {
-              double s = 0.0;
-#pragma unroll
-              for (int q = 0; q < LM_MAX_K; ++q)
-                if (q < a.k && best[q] != __builtin_inf()) s += exp(-0.5 * (best[q] + bld[q]) - e0);
-              lwd = e0 + log(s);
+            if (m < best[q]) {
+              const double t = best[q], tl = bld[q];
+              best[q] = m;
+              bld[q] = ld;
+              m = t;
+              ld = tl;
             }
           }
-          acc += lwd;
-          ++nvalid;
         }
       }
-      // reduce over the LM_SUB lanes of this particle
+      double lwd;
+      if (best[0] == __builtin_inf()) {
+        lwd = -0.5 * a.gate;
+      } else {
+        // log sum_k exp(-d_k^2 / 2) / sqrt(det S_k / det Q) over the k nearest inside the gate, anchored at the nearest
+        const double e0 = -0.5 * (best[0] + bld[0]);
+        lwd = e0;   // (one neighbour in the gate: exp(0) = 1, log(1) = 0 -- the same number without the calls)
+        if (a.k > 1 && best[1] != __builtin_inf()) {
+          double s = 0.0;
 #pragma unroll
-      for (int o2 = LM_SUB / 2; o2 > 0; o2 >>= 1) {
-        acc += __shfl_xor(acc, o2, 64);
-        nvalid += __shfl_xor(nvalid, o2, 64);
+          for (int q = 0; q < LM_MAX_K; ++q)
+            if (q < a.k && best[q] != __builtin_inf()) s += exp(-0.5 * (best[q] + bld[q]) - e0);
+          lwd = e0 + log(s);
+        }
       }
-      if (sub == 0 && i < a.n) {
-        double v = acc - (double)nvalid * a.lognorm;
-        if (a.accumulate) v += a.lw[i];
-        a.lw[i] = v;
-        wmax = (v > wmax) ? v : wmax;   // NaN never wins (k_max_slots)
-      }
+      acc += lwd;
+      ++nvalid;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();   // (the next pass rewrites the pose records)
+    double v = acc - (double)nvalid * a.lognorm;
+    if (a.accumulate) v += a.lw[i];
+    a.lw[i] = v;
+    wmax = (v > wmax) ? v : wmax;   // NaN never wins (k_max_slots)
   }
   if (a.max_slots) {
 #pragma unroll
@@ -552,6 +525,8 @@ struct LandmarkDev {
   double* lm = nullptr;
   u32* cell_start = nullptr;
   u32* orig = nullptr;      // cell-ordered slot -> index in the caller's landmark list
+  uint2* nb_cell = nullptr;   // (gx + 4) x (gy + 4): flattened 3 x 3 neighbourhood of a query cell (k_landmark_update)
+  double4* nb_list = nullptr;
   int gx = 0, gy = 0;
   double x0 = 0, y0 = 0, cs = 0;
   double built_for = -1.0;  // gate radius the grid was built for
@@ -568,6 +543,8 @@ inline void landmarks_free(LandmarkDev* L) {
   if (L->lm) (void)hipFree(L->lm);
   if (L->cell_start) (void)hipFree(L->cell_start);
   if (L->orig) (void)hipFree(L->orig);
+  if (L->nb_cell) (void)hipFree(L->nb_cell);
+  if (L->nb_list) (void)hipFree(L->nb_list);
   if (L->lmcov) (void)hipFree(L->lmcov);
   delete L;
 }
@@ -627,6 +604,49 @@ inline int landmarks_build(LandmarkDev* L, double r, std::string* err) {
       hipMemcpy(L->cell_start, start.data(), sizeof(u32) * (nc + 1), hipMemcpyHostToDevice) != hipSuccess) {
     *err = "update_landmarks: upload failed";
     return MCL_ERR_HIP;
+  }
+  // the neighbourhood table: for every query cell (-2 .. gx + 1) x (-2 .. gy + 1) the landmarks of the cells
+  // (cx - 1 .. cx + 1) x (cy - 1 .. cy + 1) that exist, column by column and in cell order within a column -- the
+  // order in which the three row ranges of cell_start are walked (the assignment kernels still walk those)
+  {
+    const int ex = L->gx + 4, ey = L->gy + 4;
+    std::vector<uint2> nb((size_t)ex * ey);
+    std::vector<double4> list;
+    list.reserve(9 * n + 1);
+    for (int qx = -2; qx <= L->gx + 1; ++qx)
+      for (int qy = -2; qy <= L->gy + 1; ++qy) {
+        const int iy0 = std::max(qy - 1, 0), iy1 = std::min(qy + 1, L->gy - 1);
+        const size_t first = list.size();
+        for (int k = 0; k < 3 && iy0 <= iy1; ++k) {
+          const int ix = qx - 1 + k;
+          if (ix < 0 || ix >= L->gx) continue;
+          for (u32 e = start[(size_t)ix * L->gy + iy0]; e < start[(size_t)ix * L->gy + iy1 + 1]; ++e) {
+            double4 v;
+            v.x = sorted[3 * (size_t)e];
+            v.y = sorted[3 * (size_t)e + 1];
+            v.z = sorted[3 * (size_t)e + 2];
+            const long long bits = (long long)e;
+            memcpy(&v.w, &bits, sizeof v.w);
+            list.push_back(v);
+          }
+        }
+        nb[(size_t)(qx + 2) * ey + (qy + 2)] = make_uint2((u32)first, (u32)(list.size() - first));
+      }
+    if (list.empty()) list.push_back(double4{0, 0, 0, 0});
+    if (L->nb_cell) (void)hipFree(L->nb_cell);
+    if (L->nb_list) (void)hipFree(L->nb_list);
+    L->nb_cell = nullptr;
+    L->nb_list = nullptr;
+    if (hipMalloc(&L->nb_cell, sizeof(uint2) * nb.size()) != hipSuccess ||
+        hipMalloc(&L->nb_list, sizeof(double4) * list.size()) != hipSuccess) {
+      *err = "update_landmarks: device allocation failed";
+      return MCL_ERR_ALLOC;
+    }
+    if (hipMemcpy(L->nb_cell, nb.data(), sizeof(uint2) * nb.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(L->nb_list, list.data(), sizeof(double4) * list.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      *err = "update_landmarks: upload failed";
+      return MCL_ERR_HIP;
+    }
   }
   if (L->lmcov) (void)hipFree(L->lmcov);
   L->lmcov = nullptr;
