@@ -540,7 +540,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
         if (!h->slice_loose) HIPCHK(h, hipMalloc(&h->slice_loose, sizeof(u32) * (size_t)ngr));
         a.slice_loose = h->slice_loose;
         a.slice_loose_count = (int*)(h->ctrl + CTRL_LOOSE);   // (zeroed with the control block by this step's predict)
-        const size_t lds_g = (size_t)B * (2 + SLICE_G_WAVES) * sizeof(float) + (size_t)SLICE_G_TRIS * 9 * sizeof(float) +
+        const size_t lds_g = (size_t)B * (3 + SLICE_G_WAVES) * sizeof(float) + (size_t)SLICE_G_TRIS * 9 * sizeof(float) +
                              SLICE_G_HASH * sizeof(unsigned) + SLICE_LUT * sizeof(unsigned short);
         if (!h->slice_attr_set || lds_g > h->slice_attr_bytes) {   // (more than 64 KiB of dynamic LDS has to be asked for)
           HIPCHK(h, hipFuncSetAttribute((const void*)k_mbes_slice_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));

@@ -398,6 +398,7 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
 #define SLICE_G_TRIS 896      // unique triangles a group may stage (31.5 KB)
 #endif
 #define SLICE_G_HASH 2048     // slots of the de-duplication set (a power of two > 2 x SLICE_G_TRIS)
+#define SLICE_G_QUEUE 128     // phase B: cut triangles waiting per wave (u16; 12 x 256 B inside the idle hash set)
 #ifndef SLICE_G_DELTA
 #define SLICE_G_DELTA 1.5f    // a group is tight if its members' planes stay within this many cells of the reference's over the fan
 #endif
@@ -409,6 +410,8 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
   float* verts = (float*)(rng_all + (size_t)SLICE_G_WAVES * B);          // SLICE_G_TRIS x 9
   unsigned* hset = (unsigned*)(verts + (size_t)SLICE_G_TRIS * 9);        // SLICE_G_HASH
   unsigned short* lut = (unsigned short*)(hset + SLICE_G_HASH);          // SLICE_LUT
+  float* rmeas = (float*)(lut + SLICE_LUT);                              // B: the ping's measured ranges
+  __shared__ MbesPose g_pose[SLICE_G];   // the members' records (G0 has them in registers: phase B reads them from here)
   __shared__ float g_ref[24];     // the reference member's geometry and the group's widened extents
   __shared__ int g_int[8];        // k_lo, k_hi, Im, Iq, major_x, tight, ntri
   __shared__ unsigned g_ntri, g_ncand;
@@ -416,6 +419,7 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
     const float2 sc = a.beam_sc[b];
     const float sec = __builtin_amdgcn_rcpf(sc.y);
     tsb[b] = make_float2(sc.x * sec, sec);
+    rmeas[b] = a.ranges[b];
   }
   __syncthreads();
   const float lut_lo = tsb[0].x, lut_w = fmaxf((tsb[B - 1].x - tsb[0].x) * (1.f / SLICE_LUT), 1e-12f), lut_iw = 1.f / lut_w;
@@ -452,7 +456,10 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
       P.oz = 0.f;
 #pragma unroll
       for (int r = 0; r < 3; ++r) P.c1[r] = P.c2[r] = 0.f;
-      if (in) P = a.pose[i];
+      if (in) {
+        P = a.pose[i];
+        g_pose[lane] = P;
+      }
       const float c2z = P.c2[2];
       const float h1 = P.c1[0] * P.c1[0] + P.c1[1] * P.c1[1];
       const bool ok = in && fabs(P.um) < 1e9 && fabs(P.vm) < 1e9 && c2z >= 0.5f && h1 >= 0.25f;   // (k_mbes_slice's own test)
@@ -639,10 +646,14 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
     for (int mbr = w; mbr < SLICE_G; mbr += SLICE_G_WAVES) {
       const long long i = i0 + mbr;
       if (i >= a.n) break;
+#ifdef SLICE_EXP_NOB
+      if (lane == 0) a.lw[a.pose[i].slot] = 0.0;
+      if (i >= 0) continue;
+#endif
       MbesPose P;
       u32 slot;
       {
-        const MbesPose Pv = a.pose[i];   // wave-uniform: scalar registers
+        const MbesPose Pv = g_pose[mbr];   // wave-uniform: scalar registers
         slot = (u32)__builtin_amdgcn_readfirstlane((int)Pv.slot);
         P.um = uniform_f64(Pv.um);
         P.vm = uniform_f64(Pv.vm);
@@ -667,8 +678,11 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
       const float nx = P.c1[1] * P.c2[2] - P.c1[2] * P.c2[1], ny = P.c1[2] * P.c2[0] - P.c1[0] * P.c2[2],
                   nz = P.c1[0] * P.c2[1] - P.c1[1] * P.c2[0];
       // one segment per staged triangle this member's plane separates (k_mbes_slice's arithmetic, expression for
-      // expression; the group-level test has left few triangles that no member cuts, so the list is not compacted first)
-      for (u32 it = lane; it < ntri; it += 64) {
+      // expression).  The staged set is the union over the group: a member's own plane cuts well under half of it, so
+      // the triangles are TESTED 64 at a time (nine LDS words, three dot products) and the ones that are cut queue up in
+      // LDS; whenever 64 are waiting, the wave builds their segments and walks their beam runs with every lane busy
+      // (rounds before: every lane carried its triangle through the whole body or idled -- lane utilisation 0.43).
+      auto cast_tri = [&](u32 it) {
         const float* vp = verts + 9 * (size_t)it;
         const float x0 = (vp[0] - Oxf) - dOx, y0 = (vp[1] - Oyf) - dOy, z0 = vp[2] - oz;
         const float x1 = (vp[3] - Oxf) - dOx, y1 = (vp[4] - Oyf) - dOy, z1 = vp[5] - oz;
@@ -676,7 +690,7 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
         const float d0 = fmaf(nx, x0, fmaf(ny, y0, nz * z0)), d1 = fmaf(nx, x1, fmaf(ny, y1, nz * z1)),
                     d2 = fmaf(nx, x2, fmaf(ny, y2, nz * z2));
         const bool p0 = d0 > 0.f, p1 = d1 > 0.f, p2 = d2 > 0.f;
-        if (p0 == p1 && p1 == p2) continue;   // (not separated by this member's plane; NaN vertices: all false)
+        if (p0 == p1 && p1 == p2) return;   // (not separated by this member's plane; NaN vertices: all false)
         const int L = (p0 != p1 && p0 != p2) ? 0 : ((p1 != p0 && p1 != p2) ? 1 : 2);
         const float xl = L == 0 ? x0 : (L == 1 ? x1 : x2), yl = L == 0 ? y0 : (L == 1 ? y1 : y2), zl = L == 0 ? z0 : (L == 1 ? z1 : z2);
         const float xm = L == 0 ? x1 : x0, ym = L == 0 ? y1 : y0, zm = L == 0 ? z1 : z0;
@@ -701,13 +715,13 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
           sB = fmaf(lam, sav - sbv, sbv);
           tB = fmaf(lam, tav - tbv, tbv);
         }
-        if (!(tA > 0.f) && !(tB > 0.f)) continue;
+        if (!(tA > 0.f) && !(tB > 0.f)) return;
         const float INF = __builtin_inff();
         const float cross = sA * tB - sB * tA;
         const float TA = tA > 0.f ? sA * __builtin_amdgcn_rcpf(tA) : (cross > 0.f ? INF : -INF);
         const float TB = tB > 0.f ? sB * __builtin_amdgcn_rcpf(tB) : (cross < 0.f ? INF : -INF);
         const float T_lo = fminf(TA, TB), T_hi = fmaxf(TA, TB);
-        if (T_hi < tan_lo || T_lo > tan_hi) continue;
+        if (T_hi < tan_lo || T_lo > tan_hi) return;
         const float T_first = T_lo - 1e-6f * fmaxf(1.f, fabsf(T_lo)), T_last = T_hi + 1e-6f * fmaxf(1.f, fabsf(T_hi));
         int lo = (int)lut[min(max((int)((T_first - lut_lo) * lut_iw) - 1, 0), SLICE_LUT - 1)];
         while (lo < B && tsb[lo].x < T_first) ++lo;
@@ -715,6 +729,9 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
         float2 ts = tsb[min(lo, B - 1)];   // (requested one beam ahead, as in k_mbes_slice)
         for (int b = lo; b < B; ++b) {
           const float T = ts.x, sec_b = ts.y;
+#ifdef SLICE_EXP_NORUN
+          if (b > lo) break;
+#endif
           if (T > T_last) break;
           ts = tsb[min(b + 1, B - 1)];
           const float eA = fmaf(-T, tA, sA), eB = fmaf(-T, tB, sB);
@@ -727,13 +744,48 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
           const float range = tau * sec_b;
           if (range < a.r_max) lds_min_range(&rng[b], range);
         }
+      };
+      unsigned short* queue = (unsigned short*)hset + (size_t)w * SLICE_G_QUEUE;   // (the hash set is idle in this phase)
+      u32 qn = 0;   // wave-uniform
+      for (u32 base = 0; base < ntri || qn > 0u; base += 64) {
+        const u32 it = base + lane;
+        bool cut = false;
+        if (it < ntri) {
+          const float* vp = verts + 9 * (size_t)it;
+          const float x0 = (vp[0] - Oxf) - dOx, y0 = (vp[1] - Oyf) - dOy, z0 = vp[2] - oz;
+          const float x1 = (vp[3] - Oxf) - dOx, y1 = (vp[4] - Oyf) - dOy, z1 = vp[5] - oz;
+          const float x2 = (vp[6] - Oxf) - dOx, y2 = (vp[7] - Oyf) - dOy, z2 = vp[8] - oz;
+          const float d0 = fmaf(nx, x0, fmaf(ny, y0, nz * z0)), d1 = fmaf(nx, x1, fmaf(ny, y1, nz * z1)),
+                      d2 = fmaf(nx, x2, fmaf(ny, y2, nz * z2));
+          const bool p0 = d0 > 0.f, p1 = d1 > 0.f, p2 = d2 > 0.f;
+          cut = !(p0 == p1 && p1 == p2);
+        }
+        const unsigned long long cm = __ballot(cut);
+        if (cut) queue[qn + (u32)__builtin_amdgcn_mbcnt_hi((u32)(cm >> 32), __builtin_amdgcn_mbcnt_lo((u32)cm, 0u))] = (unsigned short)it;
+        qn += (u32)__popcll(cm);
+        // 64 waiting, or the last triangles of the group: one pass of the body (ONE call site: the body is long)
+        if (qn >= 64u || (base + 64u >= ntri && qn > 0u)) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const u32 take = min(qn, 64u);
+          qn -= take;
+          const bool act = (u32)lane < take;
+          const u32 t = queue[qn + (act ? (u32)lane : 0u)];
+          __builtin_amdgcn_wave_barrier();   // (read before the next pass writes behind qn)
+#ifndef SLICE_EXP_NOBODY
+          if (act) cast_tri(t);
+#else
+          if (act && t == 0xffffu) cast_tri(t);
+#endif
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       float acc = 0.f;
       int nvalid = 0;
       for (int b = lane; b < B; b += 64) {
         const float e = __uint_as_float(rng[b]);
-        const float rm = a.ranges[b];
+        const float rm = rmeas[b];
         if (rm > 0.f) {  // NaN fails the test
           const float d = (rm - e) * a.inv_sigma;
           acc += d * d;
