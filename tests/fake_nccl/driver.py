@@ -22,6 +22,7 @@ SIGMA, R_MAX, B = 0.2, 100.0, 128
 def main():
     W, NS, exchange = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     with_lm = len(sys.argv) > 4 and sys.argv[4] == 'landmarks'
+    absent = len(sys.argv) > 4 and sys.argv[4] == 'absent'   # rank W-1 stays away from the start-up self-test
     N = W * NS
     os.environ['MCL_EXCHANGE'] = exchange
     # the preload must really be in front of librccl
@@ -67,7 +68,8 @@ def main():
     one.close()
 
     # ---- W ranks, one thread each
-    uid = [eng.comm_unique_id(), eng.comm_unique_id()]
+    uid = [eng.comm_unique_id(), eng.comm_unique_id(), eng.comm_unique_id()]
+    gate = threading.Barrier(W)
     out = [None] * W
     err = [None] * W
 
@@ -78,6 +80,21 @@ def main():
             e.set_landmarks(lm)
             e.comm_init(uid[0])
             res = dict(ranks=e.comm_ranks(), steps=[])
+            if absent:
+                # a peer that never shows up: the others get MCL_ERR_COMM back (not a hang), abort, and everybody starts
+                # again under a fresh id
+                if r != W - 1:
+                    try:
+                        e.comm_selftest(20000)
+                        raise AssertionError('self-test passed without rank %d' % (W - 1))
+                    except eng.MclError as ex:
+                        assert ex.status == -6 and 'comm_selftest' in str(ex), (ex.status, str(ex))   # MCL_ERR_COMM
+                        res['selftest_error'] = str(ex)
+                gate.wait()
+                e.comm_shutdown(abort=True)
+                gate.wait()
+                e.comm_init(uid[2])
+                res['ranks'] = e.comm_ranks()
             e.comm_selftest(20000)
             e.init_particles()
             for k in range(steps):

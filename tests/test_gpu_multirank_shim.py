@@ -27,8 +27,8 @@ def fake_nccl():
     return LIB
 
 
-def _run(lib, *args):
-    env = dict(os.environ, LD_PRELOAD=lib, FAKE_NCCL_TIMEOUT_S='60')
+def _run(lib, *args, timeout_s=60):
+    env = dict(os.environ, LD_PRELOAD=lib, FAKE_NCCL_TIMEOUT_S=str(timeout_s))
     env.pop('MCL_FORCE_COMM', None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'fake_nccl', 'driver.py')] + [str(a) for a in args],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
@@ -53,6 +53,12 @@ def test_ranks_over_the_all_gather_exchange_with_the_overlap_communicator(fake_n
 def test_ranks_with_the_visiting_order_and_the_landmark_step(fake_nccl):
     """shards above the visiting order's threshold (393 216), BASELINE config 5's fused step"""
     _run(fake_nccl, 2, 393216, 'p2p', 'landmarks')
+
+
+def test_a_rank_that_stays_away_from_the_self_test_is_an_error_not_a_hang(fake_nccl):
+    """mcl_comm_selftest with a peer missing returns MCL_ERR_COMM; abort + re-initialisation under a fresh id, then the
+    filter runs as if nothing had happened"""
+    _run(fake_nccl, 3, 20000, 'p2p', 'absent', timeout_s=5)
 
 
 def test_the_double_itself_rejects_what_rccl_would_hang_on(fake_nccl):
