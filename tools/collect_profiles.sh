@@ -32,6 +32,10 @@ PY
   done
   grep '^{"metric"' $S/bench_$m.log | tail -1 > profiles/${ROUND}_${m}_bench_only_main.json
 done
+for m in config5 soup; do
+  f=$(ls -t $S/stats_$m/*/*_kernel_stats.csv 2>/dev/null | head -1)
+  if [ -n "$f" ]; then cp $f profiles/${ROUND}_${m}_kernel_stats.csv; fi
+done
 cp $S/traffic.json profiles/${ROUND}_traffic.json
 bash tools/isa.sh /tmp/isa > /dev/null 2>&1 && grep -v 'rocprim::' /tmp/isa/resources.tsv > profiles/${ROUND}_isa_resources.tsv   # (the library's own kernels)
 ls -la profiles/${ROUND}_*
