@@ -884,16 +884,22 @@ int group_step_mbes_impl(mcl_handle** shards, int32_t ns, const mcl_odom* odom, 
       return fail(h, MCL_ERR_UNSUPPORTED, w + ": only the systematic scheme is sharded");
     if (lm && !h->landmarks) return fail(h, MCL_ERR_STATE, w + ": no feature map (call mcl_set_landmarks first)");
   }
+  // everything that can fail before a kernel is queued, for EVERY shard first: a later shard's failure must not find
+  // earlier shards with a predict in flight whose z / roll / pitch stores were deferred to the gather
   for (int s = 0; s < ns; ++s) {
     mcl_handle* h = shards[s];
     RET_IF(set_device(h));
     if (lm) RET_IF(landmarks_prepare(h, *lm, who));
-    // the same fused front half as mcl_step_mbes: predict writes the pose records, the sweep leaves max lw in the slots
     RET_IF(upload_beams(h, ranges, beam_angles, B));
+  }
+  for (int s = 0; s < ns; ++s) {
+    mcl_handle* h = shards[s];
+    // the same fused front half as mcl_step_mbes: predict writes the pose records, the sweep leaves max lw in the slots
+    int rc = set_device(h);
     MbesArgs pa;
-    RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, false, &pa));
+    if (rc == MCL_OK) rc = launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, false, &pa);
     bool pose_done = false;
-    int rc = do_predict(h, odom, dt, nullptr, &pa, &pose_done, true);
+    if (rc == MCL_OK) rc = do_predict(h, odom, dt, nullptr, &pa, &pose_done, true);
     if (rc == MCL_OK && h->fault_step) rc = fail(h, MCL_ERR_STATE, w + ": injected fault after predict");
     if (rc == MCL_OK) rc = launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, pose_done);
     if (rc == MCL_OK) {
