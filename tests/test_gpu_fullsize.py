@@ -61,6 +61,47 @@ def test_full_size_mbes_update_spot_check_vs_oracle(kind):
     assert np.median(np.hypot(soa[0, best] - 30.0, soa[1, best] + 12.0)) < 0.3
 
 
+@pytest.mark.parametrize('kind', ['mesh', 'grid', 'mesh_general', 'mesh_tin'])
+def test_full_size_log_likelihood_is_additive_over_the_beams_of_a_ping(kind):
+    """A size-independent property over ALL 1 048 576 particles (no oracle needed): the log-likelihood of a ping is the
+    sum over its valid beams, so the ping's even beams alone plus its odd beams alone give the whole ping -- for every
+    particle, whatever path cast it (the sweep resolves a side's beams in one merge: an invalid beam must neither move a
+    neighbour's expected range nor be counted), up to the fp32 summation order; and a ping without a valid beam weighs
+    nothing."""
+    from smarc_navigation_amd import engine as eng
+    ba = synth.beam_angles(B)
+    soa = _cloud(4)
+    e = eng.Engine(N, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    if kind == 'grid':
+        origin = (-64.0, -256.0)
+        e.set_map_grid(synth.bathymetry_grid(512, 512, 1.0, origin, seed=3), origin, 1.0)
+    else:
+        origin = (-64.0, -354.0)
+        z = synth.bathymetry_grid(708, 708, 1.0, origin, seed=3)
+        if kind == 'mesh_tin':
+            verts, tris = synth.mesh_tin(z, 1.0, origin, seed=7)
+        else:
+            verts, tris = synth.mesh_from_grid(z, 1.0, origin)
+        e.set_map_mesh(verts, tris, general=(kind == 'mesh_general'))
+    rs = np.random.RandomState(5)
+    ranges = (18.0 + 6.0 * rs.rand(B)).astype(np.float32)
+    ranges[rs.choice(B, 9, replace=False)] = np.nan   # a few beams without a return
+    parts = []
+    for keep in (slice(None), slice(0, None, 2), slice(1, None, 2), slice(0, 0)):
+        r = np.zeros(B, np.float32)
+        r[keep] = ranges[keep]
+        e.update_mbes(r, ba, 0.2, 100.0)
+        parts.append(e.get_log_weights())
+    whole, even, odd, none = parts
+    assert np.all(np.isfinite(whole)) and np.std(whole) > 1.0
+    assert np.array_equal(none, np.zeros(N))
+    d = np.abs(whole - (even + odd))
+    tol = 1e-3 + 2e-6 * np.abs(whole)
+    print('%s: additivity over beams, max |d| %.3e at |lw| up to %.3e' % (kind, d.max(), np.abs(whole).max()))
+    assert np.all(d <= tol), (d.max(), np.abs(whole)[np.argmax(d - tol)])
+
+
 def test_full_size_resample_properties_and_shard_invariance():
     from smarc_navigation_amd import engine as eng
     rs = np.random.RandomState(9)
