@@ -83,6 +83,10 @@ def main():
             if absent:
                 # a peer that never shows up: the others get MCL_ERR_COMM back (not a hang), abort, and everybody starts
                 # again under a fresh id
+                gate.wait()
+                if r == 0:
+                    ctypes.CDLL(None).fake_nccl_set_timeout(3)   # (only the self-test below waits in vain)
+                gate.wait()
                 if r != W - 1:
                     try:
                         e.comm_selftest(20000)
@@ -91,6 +95,8 @@ def main():
                         assert ex.status == -6 and 'comm_selftest' in str(ex), (ex.status, str(ex))   # MCL_ERR_COMM
                         res['selftest_error'] = str(ex)
                 gate.wait()
+                if r == 0:
+                    ctypes.CDLL(None).fake_nccl_set_timeout(0)
                 e.comm_shutdown(abort=True)
                 gate.wait()
                 e.comm_init(uid[2])

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -61,8 +62,10 @@ struct World {
   World* split_child = nullptr;                      // ncclCommSplit: the communicator being made
 };
 
+std::atomic<int> g_timeout_s{0};   // fake_nccl_set_timeout(); 0 = FAKE_NCCL_TIMEOUT_S or 120
 int timeout_s() {
-  static const int t = getenv("FAKE_NCCL_TIMEOUT_S") ? atoi(getenv("FAKE_NCCL_TIMEOUT_S")) : 120;
+  static const int env = getenv("FAKE_NCCL_TIMEOUT_S") ? atoi(getenv("FAKE_NCCL_TIMEOUT_S")) : 120;
+  const int t = g_timeout_s.load() > 0 ? g_timeout_s.load() : env;
   return t > 0 ? t : 120;
 }
 
@@ -378,5 +381,7 @@ ncclResult_t ncclRecv(void* recv, size_t count, ncclDataType_t type, int peer, n
 
 // marker the test driver checks: the preload really is in front of librccl
 int fake_nccl_present(void) { return 1; }
+// waits that begin after this call give up after `seconds` (0 = back to FAKE_NCCL_TIMEOUT_S)
+void fake_nccl_set_timeout(int seconds) { g_timeout_s.store(seconds); }
 
 }  // extern "C"
