@@ -398,6 +398,7 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
 #define SLICE_G_TRIS 896      // unique triangles a group may stage (31.5 KB)
 #endif
 #define SLICE_G_HASH 2048     // slots of the de-duplication set (a power of two > 2 x SLICE_G_TRIS)
+#define SLICE_G_RSLOTS 8      // phase GA1: row slots per column (threads per column of the trace)
 #define SLICE_G_QUEUE 128     // phase B: cut triangles waiting per wave (u16; 12 x 256 B inside the idle hash set)
 #ifndef SLICE_G_DELTA
 #define SLICE_G_DELTA 1.5f    // a group is tight if its members' planes stay within this many cells of the reference's over the fan
@@ -544,12 +545,13 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
       k_hi = min(k_hi, gm - 1);
       const float rmq = c1q * __builtin_amdgcn_rcpf(c1m);
       const float kq = c2m * rmq - c2q;
-      // GA1: lanes = columns; the records of the cells that pass go onto a candidate list in LDS.  The cell words of a column's rows are loaded in batches: one memory
-      // latency per batch, not one per row
+      // GA1: a thread per (column, row slot) -- 96 columns x 8 row slots per pass, so the cell words of the whole trace are
+      // ONE round of loads over all twelve waves (until late in round 5: lanes = columns, two or three waves busy, a
+      // column's rows in batches of four); the records of the cells that pass go onto a candidate list in LDS
       unsigned* clist = rng_all;   // (the members' range slots are not in use yet: their area holds the list)
       const u32 CL = (u32)(SLICE_G_WAVES * B);   // capacity in words
-      for (int cbase = k_lo + 64 * w; cbase <= k_hi; cbase += 64 * SLICE_G_WAVES) {
-        const int col = cbase + lane;
+      for (int cbase = k_lo; cbase <= k_hi; cbase += SLICE_G_THREADS / SLICE_G_RSLOTS) {
+        const int col = cbase + (int)(threadIdx.x / SLICE_G_RSLOTS);
         const bool col_ok = col <= k_hi;
         const float ma0 = ((float)(col - Im) - fm) * cs, ma1 = ma0 + cs;
         const float q0 = fminf(ma0 * rmq, ma1 * rmq) + fminf(t_a * kq, t_b * kq) - delta;
@@ -557,37 +559,28 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
         int r_lo = Iq + (int)floorf(fq + q0 * ics), r_hi = Iq + (int)floorf(fq + q1 * ics);
         r_lo = max(r_lo, 0);
         r_hi = col_ok ? min(r_hi, gq - 1) : r_lo - 1;
-        for (int rb = r_lo; __builtin_amdgcn_ballot_w64(rb <= r_hi) != 0ull; rb += SLICE_ROWS) {
-          uint2 info[SLICE_ROWS];
-#pragma unroll
-          for (int r = 0; r < SLICE_ROWS; ++r) {
-            const int row = rb + r;
-            const size_t c = major_x ? (size_t)col * ma.gy + row : (size_t)row * ma.gy + col;
-            info[r] = row <= r_hi ? ma.cell_info[c] : make_uint2(0u, 0u);
-          }
-#pragma unroll
-          for (int r = 0; r < SLICE_ROWS; ++r) {
-            const int row = rb + r;
-            u32 cnt = info[r].y >> 27;
-            if (cnt == 0u) continue;
-            const int ci = major_x ? col : row, cj = major_x ? row : col;
-            const u32 rs = info[r].y & 0x7ffffffu;
-            float zlo, zhi;
-            cell_zrange(info[r].x, zlo, zhi);
-            const float I0x = (float)(ci - g_int[0]) - g_ref[17], I0y = (float)(cj - g_int[1]) - g_ref[18];
-            const float cxm = (I0x + 0.5f) * cs, cym = (I0y + 0.5f) * cs, czm = 0.5f * (zlo + zhi) - ozr;
-            const float dist = nxr * cxm + nyr * cym + nzr * czm;
-            const float hz = 0.5f * (zhi - zlo);
-            const float ext = 0.5f * cs * (fabsf(nxr) + fabsf(nyr)) + (hz + 1e-3f) * fabsf(nzr) + 1e-4f;
-            // a member's plane: |n_p . (c - O_p)| <= |n_ref . (c - O_ref)| + dn |c - O_ref| + dO, and its own extent is
-            // within dn x (box radius) of the reference's
-            const float rad = sqrtf(0.5f * cs * cs + hz * hz);
-            const float wide = dO + dn * (sqrtf(cxm * cxm + cym * cym + czm * czm) + 2.f * rad) + 1e-3f;
-            if (!(fabsf(dist) <= ext + wide)) continue;
-            if (cnt == 31u) cnt = ma.cell_start[(size_t)ci * ma.gy + cj + 1] - rs;
-            const u32 pos = atomicAdd(&g_ncand, cnt);
-            for (u32 k = 0; k < cnt && pos + k < CL; ++k) clist[pos + k] = rs + k;
-          }
+        for (int row = r_lo + (int)(threadIdx.x % SLICE_G_RSLOTS); row <= r_hi; row += SLICE_G_RSLOTS) {
+          const size_t c = major_x ? (size_t)col * ma.gy + row : (size_t)row * ma.gy + col;
+          const uint2 info = ma.cell_info[c];
+          u32 cnt = info.y >> 27;
+          if (cnt == 0u) continue;
+          const int ci = major_x ? col : row, cj = major_x ? row : col;
+          const u32 rs = info.y & 0x7ffffffu;
+          float zlo, zhi;
+          cell_zrange(info.x, zlo, zhi);
+          const float I0x = (float)(ci - g_int[0]) - g_ref[17], I0y = (float)(cj - g_int[1]) - g_ref[18];
+          const float cxm = (I0x + 0.5f) * cs, cym = (I0y + 0.5f) * cs, czm = 0.5f * (zlo + zhi) - ozr;
+          const float dist = nxr * cxm + nyr * cym + nzr * czm;
+          const float hz = 0.5f * (zhi - zlo);
+          const float ext = 0.5f * cs * (fabsf(nxr) + fabsf(nyr)) + (hz + 1e-3f) * fabsf(nzr) + 1e-4f;
+          // a member's plane: |n_p . (c - O_p)| <= |n_ref . (c - O_ref)| + dn |c - O_ref| + dO, and its own extent is
+          // within dn x (box radius) of the reference's
+          const float rad = sqrtf(0.5f * cs * cs + hz * hz);
+          const float wide = dO + dn * (sqrtf(cxm * cxm + cym * cym + czm * czm) + 2.f * rad) + 1e-3f;
+          if (!(fabsf(dist) <= ext + wide)) continue;
+          if (cnt == 31u) cnt = ma.cell_start[(size_t)ci * ma.gy + cj + 1] - rs;
+          const u32 pos = atomicAdd(&g_ncand, cnt);
+          for (u32 k = 0; k < cnt && pos + k < CL; ++k) clist[pos + k] = rs + k;
         }
       }
       __syncthreads();
