@@ -72,6 +72,23 @@
 __device__ __forceinline__ void lds_min_range(unsigned* slot, float range) {
   __hip_atomic_fetch_min(slot, __float_as_uint(range), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// One beam of a segment's run, WITHOUT branches: the crossing of the half line s = t T with the segment A -> B (e = s - T t
+// changes sign) as a range into the beam's LDS minimum; a beam the segment does not cross, a crossing behind the sensor or
+// beyond r_max stores +inf, which a minimum ignores (the slots start at r_max).  (Until late in round 5 the three tests
+// were `continue`s: the compiler built a nest of exec-mask regions around them, ~25 scalar and ~25 vector instructions
+// and five branches per beam; the arithmetic is unchanged.)
+__device__ __forceinline__ void slice_beam(unsigned* slot, float T, float sec_b, float sA, float tA, float sB, float tB,
+                                           float dts, float r_max) {
+  const float eA = fmaf(-T, tA, sA), eB = fmaf(-T, tB, sB);
+  const bool miss = (eA > 0.f) == (eB > 0.f) && eA != 0.f && eB != 0.f;
+  const float den = eA - eB;
+  float lam = den != 0.f ? eA * __builtin_amdgcn_rcpf(den) : 0.f;
+  lam = fminf(fmaxf(lam, 0.f), 1.f);
+  const float tau = fmaf(lam, dts, tA);
+  const float range = tau * sec_b;
+  const bool ok = !miss & (tau > 0.f) & (range < r_max);   // (NaN anywhere: not ok)
+  __hip_atomic_fetch_min(slot, ok ? __float_as_uint(range) : 0x7f800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 template <bool EXPECT_ONLY>
 __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
@@ -320,16 +337,7 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
         const float T = ts.x, sec_b = ts.y;
         if (T > T_last) break;
         ts = tsb[min(b + 1, B - 1)];
-        // crossing of the half line s = t T with the segment A -> B: e = s - T t changes sign
-        const float eA = fmaf(-T, tA, sA), eB = fmaf(-T, tB, sB);
-        if ((eA > 0.f) == (eB > 0.f) && eA != 0.f && eB != 0.f) continue;
-        const float den = eA - eB;
-        float lam = den != 0.f ? eA * __builtin_amdgcn_rcpf(den) : 0.f;
-        lam = fminf(fmaxf(lam, 0.f), 1.f);
-        const float tau = fmaf(lam, dts, tA);
-        if (!(tau > 0.f)) continue;
-        const float range = tau * sec_b;
-        if (range < a.r_max) lds_min_range(&rng[b], range);
+        slice_beam(&rng[b], T, sec_b, sA, tA, sB, tB, dts, a.r_max);
       }
       }
       cbase += per_chunk;
@@ -729,15 +737,7 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
 #endif
           if (T > T_last) break;
           ts = tsb[min(b + 1, B - 1)];
-          const float eA = fmaf(-T, tA, sA), eB = fmaf(-T, tB, sB);
-          if ((eA > 0.f) == (eB > 0.f) && eA != 0.f && eB != 0.f) continue;
-          const float den = eA - eB;
-          float lam = den != 0.f ? eA * __builtin_amdgcn_rcpf(den) : 0.f;
-          lam = fminf(fmaxf(lam, 0.f), 1.f);
-          const float tau = fmaf(lam, dts, tA);
-          if (!(tau > 0.f)) continue;
-          const float range = tau * sec_b;
-          if (range < a.r_max) lds_min_range(&rng[b], range);
+          slice_beam(&rng[b], T, sec_b, sA, tA, sB, tB, dts, a.r_max);
         }
       };
       unsigned short* queue = (unsigned short*)hset + (size_t)w * SLICE_G_QUEUE;   // (the hash set is idle in this phase)
