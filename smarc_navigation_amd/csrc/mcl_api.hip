@@ -451,9 +451,20 @@ struct LandmarkObs {
   double gate;
   const double* so;
 };
+int landmarks_upload(mcl_handle* h, const LandmarkObs& o) {
+  if (o.n_det > h->det_cap) {
+    if (h->det_dev) (void)hipFree(h->det_dev);
+    h->det_dev = nullptr;
+    HIPCHK(h, hipMalloc(&h->det_dev, sizeof(double) * 3 * (size_t)o.n_det));
+    h->det_cap = o.n_det;
+  }
+  return upload(h, h->det_dev, o.det, sizeof(double) * 3 * (size_t)o.n_det);
+}
 // argument checks, the cell grid for this gate radius, the detections on the device.  (A grid rebuild drains the
 // stream -- the old arrays may still be read by a kernel in flight -- so the fused step calls this BEFORE its predict.)
-int landmarks_prepare(mcl_handle* h, const LandmarkObs& o, const char* who) {
+// ride: the fused step -- the detections are not copied here; they wait for the beam table's staged copy of the same
+// step (upload_sweep_beams; landmarks_launch copies them itself if the update took a path without that table)
+int landmarks_prepare(mcl_handle* h, const LandmarkObs& o, const char* who, bool ride = false) {
   if (!o.det || o.n_det < 1 || !(o.sigma > 0.0) || o.k < 1 || o.k > LM_MAX_K || !(o.gate > 0.0))
     return fail(h, MCL_ERR_INVALID, std::string(who) + ": bad argument (1 <= k <= 4)");
   if (!h->landmarks) return fail(h, MCL_ERR_STATE, std::string(who) + ": no feature map (call mcl_set_landmarks first)");
@@ -468,19 +479,29 @@ int landmarks_prepare(mcl_handle* h, const LandmarkObs& o, const char* who) {
       return rc;
     }
   }
-  if (o.n_det > h->det_cap) {
-    if (h->det_dev) (void)hipFree(h->det_dev);
-    h->det_dev = nullptr;
-    HIPCHK(h, hipMalloc(&h->det_dev, sizeof(double) * 3 * (size_t)o.n_det));
-    h->det_cap = o.n_det;
+  h->det_ride = nullptr;
+  h->det_ride_dev = nullptr;
+  if (ride) {
+    h->det_ride = o.det;
+    h->det_ride_n = o.n_det;
+    return MCL_OK;
   }
-  return upload(h, h->det_dev, o.det, sizeof(double) * 3 * (size_t)o.n_det);
+  return landmarks_upload(h, o);
 }
 // the k-NN landmark likelihood of every particle.  fused: inside mcl_step_mbes_landmarks -- the predict kernel of the
 // same call may have left z, roll, pitch unstored (uni_deferred), and the kernel leaves max lw in the second slot set
 int landmarks_launch(mcl_handle* h, const LandmarkObs& o, bool accumulate, bool fused) {
   static const double zero6[6] = {0, 0, 0, 0, 0, 0};
   const double* so = o.so ? o.so : zero6;
+  // the detections: where the beam table's copy of this step left them, or (an update without that table: no sweep)
+  // copied now
+  const double* det = h->det_ride_dev;
+  if (!det) {
+    RET_IF(landmarks_upload(h, o));
+    det = h->det_dev;
+  }
+  h->det_ride = nullptr;
+  h->det_ride_dev = nullptr;
   LandmarkArgs a;
   memset(&a, 0, sizeof a);
   for (int c = 0; c < 6; ++c) a.st[c] = h->state[h->cur] + (size_t)c * h->n;
@@ -488,7 +509,7 @@ int landmarks_launch(mcl_handle* h, const LandmarkObs& o, bool accumulate, bool 
   for (int q = 0; q < 12; ++q) a.m2o[q] = h->cfg.m2o[q];
   for (int q = 0; q < 3; ++q) a.off_t[q] = so[q];
   rot_rpy(so[3], so[4], so[5], a.off_R);
-  a.det = h->det_dev;
+  a.det = det;
   a.n_det = o.n_det;
   a.lm = h->landmarks->lm;
   a.cell_start = h->landmarks->cell_start;
@@ -825,10 +846,10 @@ int step_mbes_impl(mcl_handle* h, const mcl_odom* odom, double dt, const float* 
   if (B < 1 || !(sigma > 0.0) || !(r_max > 0.0)) return fail(h, MCL_ERR_INVALID, w + ": bad argument");
   if (h->map_kind < 0) return fail(h, MCL_ERR_STATE, w + ": no map (call mcl_set_map_grid/mesh first)");
   RET_IF(set_device(h));
-  if (lm) RET_IF(landmarks_prepare(h, *lm, who));
   // predict writes the MBES pose records of the new state in the same pass (the map and sensor offset are known here)
   // (the beam table first: the group classification in that kernel follows the two extreme beams)
   RET_IF(upload_beams(h, ranges, beam_angles, B));
+  if (lm) RET_IF(landmarks_prepare(h, *lm, who, true));   // (after upload_beams: it forgets detections an earlier call left waiting)
   MbesArgs pa;
   RET_IF(launch_mbes(h, true, B, sigma, r_max, sensor_offset, h->lw, nullptr, 0, 0, false, &pa));
   bool pose_done = false;
@@ -889,8 +910,8 @@ int group_step_mbes_impl(mcl_handle** shards, int32_t ns, const mcl_odom* odom, 
   for (int s = 0; s < ns; ++s) {
     mcl_handle* h = shards[s];
     RET_IF(set_device(h));
-    if (lm) RET_IF(landmarks_prepare(h, *lm, who));
     RET_IF(upload_beams(h, ranges, beam_angles, B));
+    if (lm) RET_IF(landmarks_prepare(h, *lm, who, true));
   }
   for (int s = 0; s < ns; ++s) {
     mcl_handle* h = shards[s];

@@ -182,6 +182,11 @@ struct mcl_handle {
   LandmarkDev* landmarks = nullptr;
   double* det_dev = nullptr;
   int det_cap = 0;
+  // fused landmark step: the detections ride in the per-ping beam table's staged copy (its own stream, under the previous
+  // step's kernels) instead of a copy on the compute stream in front of the predict
+  const double* det_ride = nullptr;      // host detections waiting for the next table upload (3 x det_ride_n doubles)
+  int det_ride_n = 0, det_ride_cap = 0;  // ... their count; room for them behind either table buffer
+  const double* det_ride_dev = nullptr;  // where that upload put them (device), until the landmark kernel is launched
   int map_kind = -1;  // 0 grid, 1 mesh
   bool mesh_heightfield = false;
   bool force_general_mesh = false;  // MCL_MESH_GENERAL / MCL_MESH_UNSTRUCTURED: no structured-mesh fast path

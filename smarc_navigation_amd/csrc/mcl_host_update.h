@@ -7,6 +7,8 @@ namespace {
 
 // ------------------------------------------------------------------------------------------ MBES
 int upload_beams(mcl_handle* h, const float* ranges, const float* beam_angles, int B) {
+  h->det_ride = nullptr;   // (detections of a fused landmark step that failed before its table upload: the caller's buffer is gone)
+  h->det_ride_dev = nullptr;
   if (B > h->beams_cap) {
     if (h->beam_sc) (void)hipFree(h->beam_sc);
     if (h->ranges_dev) (void)hipFree(h->ranges_dev);
@@ -82,8 +84,13 @@ int sweep_lanes_per_side(const mcl_handle* h, bool with_ranges, int B) {
 int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, double r_max, int nsub) {
   // one device block, one copy per update: B records | B tail sums | B measured ranges (for the traversal kernels
   // that take the hand-overs)
-  const size_t blk_floats = (size_t)B * 7 + 4;   // B records | B tail sums | B measured ranges | first / second tangent of either side | B tail sums per run
-  if (B > h->sweep_cap) {
+  const size_t tab_floats = ((size_t)B * 7 + 4 + 1) & ~(size_t)1;   // B records | B tail sums | B measured ranges | first / second tangent of either side | B tail sums per run (| pad to 8 bytes)
+  const bool grow_ride = h->det_ride && h->det_ride_n > h->det_ride_cap;
+  if (grow_ride) h->det_ride_cap = std::max(h->det_ride_n, 16);
+  const size_t blk_floats = tab_floats + 6 * (size_t)h->det_ride_cap;   // | the ping's landmark detections (fp64), when they ride along
+  if (B > h->sweep_cap || grow_ride) {
+    const size_t cap_b = (size_t)std::max(B, h->sweep_cap);
+    const size_t alloc_floats = ((cap_b * 7 + 4 + 1) & ~(size_t)1) + 6 * (size_t)h->det_ride_cap;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->copy_stream) HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     for (int k = 0; k < 2; ++k) {
@@ -91,13 +98,13 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
       if (h->sweep_stage[k]) (void)hipHostFree(h->sweep_stage[k]);
       h->sweep_buf[k] = nullptr;
       h->sweep_stage[k] = nullptr;
-      HIPCHK(h, hipMalloc(&h->sweep_buf[k], sizeof(float) * blk_floats));
-      HIPCHK(h, hipHostMalloc(&h->sweep_stage[k], sizeof(float) * blk_floats, hipHostMallocDefault));
+      HIPCHK(h, hipMalloc(&h->sweep_buf[k], sizeof(float) * alloc_floats));
+      HIPCHK(h, hipHostMalloc(&h->sweep_stage[k], sizeof(float) * alloc_floats, hipHostMallocDefault));
       if (!h->ev_stage[k]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_stage[k], hipEventDisableTiming));
       h->stage_used[k] = false;
     }
     if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    h->sweep_cap = B;
+    h->sweep_cap = std::max(h->sweep_cap, B);
   }
   const int sel = (h->sweep_sel ^= 1);
   h->sweep_beams = h->sweep_buf[sel];
@@ -112,6 +119,12 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
   float* tail = blk.data() + (size_t)B * 4;
   float* rng = tail + B;
   for (int b = 0; b < B; ++b) tail[b] = 0.f;
+  h->det_ride_dev = nullptr;
+  if (h->det_ride) {
+    memcpy(blk.data() + tab_floats, h->det_ride, sizeof(double) * 3 * (size_t)h->det_ride_n);
+    h->det_ride_dev = (const double*)((const float*)h->sweep_buf[sel] + tab_floats);
+    h->det_ride = nullptr;
+  }
   const float rmaxf = (float)r_max;
   int nvalid = 0;
   for (int b = 0; b < B; ++b) {
@@ -163,7 +176,8 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
   // just before (later on the same stream, so certainly enough -- whatever an error path did to the alternation): it
   // then runs under that step's normalise / scan / gather kernels.  The compute stream waits for the copy.
   if (h->ev_upd[0] && h->upd_seq >= 1) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_upd[(h->upd_seq - 1) & 3], 0));
-  HIPCHK(h, hipMemcpyAsync(h->sweep_beams, blk.data(), sizeof(float) * blk_floats, hipMemcpyHostToDevice, h->copy_stream));
+  HIPCHK(h, hipMemcpyAsync(h->sweep_beams, blk.data(), sizeof(float) * (h->det_ride_dev ? blk_floats : tab_floats), hipMemcpyHostToDevice,
+                           h->copy_stream));
   HIPCHK(h, hipEventRecord(h->ev_stage[sel], h->copy_stream));
   h->stage_used[sel] = true;
   HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_stage[sel], 0));

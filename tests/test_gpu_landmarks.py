@@ -100,13 +100,13 @@ def test_update_landmarks_needs_a_feature_map():
     assert ei.value.status == -5
 
 
-@pytest.mark.parametrize('mode', ['iso', 'maha'])
-def test_fused_landmark_step_on_a_grid_equals_the_separate_calls(mode):
+@pytest.mark.parametrize('mode,n', [('iso', 70001), ('maha', 70001), ('iso', 3001)])
+def test_fused_landmark_step_on_a_grid_equals_the_separate_calls(mode, n):
     """mcl_step_mbes_landmarks on a height grid at an odd particle count, isotropic and Mahalanobis, a sensor offset on
     both sensors, including a dt = 0 step (the predict does not run: z, roll, pitch are read from the state) and a
-    ping without a single valid detection -- against the separate calls, bit for bit."""
+    ping without a single valid detection -- against the separate calls, bit for bit.  (70 001 particles: the fan sweep,
+    whose staged beam-table copy carries the detections; 3 001: the ray traversal, where the landmark launch copies them.)"""
     from smarc_navigation_amd import engine as eng
-    n = 70001
     z = synth.bathymetry_grid(256, 256, 1.0, (-64.0, -128.0), seed=3)
     lm = synth.landmark_map(2048, (-60.0, -120.0, 180.0, 120.0))
     stream = synth.odom_stream(5)
