@@ -460,7 +460,7 @@ int landmarks_upload(mcl_handle* h, const LandmarkObs& o) {
   }
   return upload(h, h->det_dev, o.det, sizeof(double) * 3 * (size_t)o.n_det);
 }
-// argument checks, the cell grid for this gate radius, the detections on the device.  (A grid rebuild drains the
+// argument checks and the cell grid for this gate radius.  (A grid rebuild drains the
 // stream -- the old arrays may still be read by a kernel in flight -- so the fused step calls this BEFORE its predict.)
 // ride: the fused step -- the detections are not copied here; they wait for the beam table's staged copy of the same
 // step (upload_sweep_beams; landmarks_launch copies them itself if the update took a path without that table)
@@ -484,9 +484,8 @@ int landmarks_prepare(mcl_handle* h, const LandmarkObs& o, const char* who, bool
   if (ride) {
     h->det_ride = o.det;
     h->det_ride_n = o.n_det;
-    return MCL_OK;
   }
-  return landmarks_upload(h, o);
+  return MCL_OK;   // (landmarks_launch copies detections that did not ride)
 }
 // the k-NN landmark likelihood of every particle.  fused: inside mcl_step_mbes_landmarks -- the predict kernel of the
 // same call may have left z, roll, pitch unstored (uni_deferred), and the kernel leaves max lw in the second slot set
