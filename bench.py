@@ -55,7 +55,7 @@ def parse(argv=None):
     ap.add_argument('--total-particles', type=int, default=4194304, help='total particles (strong scaling)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--beams', type=int, default=512)
-    ap.add_argument('--map', default='mesh', choices=['grid', 'mesh', 'mesh-general', 'mesh-adjacency', 'mesh-tin', 'mesh-soup'])
+    ap.add_argument('--map', default='mesh', choices=['grid', 'mesh', 'mesh-general', 'mesh-adjacency', 'mesh-tin', 'mesh-tin-shuffled', 'mesh-soup'])
     ap.add_argument('--mesh-general', action='store_true', help='same as --map mesh-general')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the extra workload legs (N = 1 runs them by default)')
@@ -150,11 +150,14 @@ def build_map(kind):
                     desc='512x512 fp32 height grid, 1 m cells')
     origin = (-64.0, -354.0)
     z = synth.bathymetry_grid(708, 708, 1.0, origin, seed=3)
-    if kind in ('mesh-tin', 'mesh-soup'):
+    if kind in ('mesh-tin', 'mesh-tin-shuffled', 'mesh-soup'):
         verts, tris = synth.mesh_tin(z, 1.0, origin, seed=7)
         desc = '%d-triangle irregular TIN (708x708 nodes jittered in xy, random diagonals)' % tris.shape[0]
         if kind == 'mesh-soup':
             desc += ', cast as an arbitrary triangle soup (MCL_MESH_GENERAL: no height-field assumption)'
+        if kind == 'mesh-tin-shuffled':
+            verts, tris = synth.mesh_shuffle(verts, tris, seed=9)
+            desc += ', handed over in RANDOM order (vertices renumbered, triangles permuted, corners rotated, every second winding reversed)'
 
     else:
         verts, tris = synth.mesh_from_grid(z, 1.0, origin)
@@ -169,8 +172,8 @@ def build_map(kind):
     nt, nv = tris.shape[0], verts.shape[0]
     if kind == 'mesh':
         mb, what = 4 * z.size, '708 x 708 fp32 node heights (structured mesh: no triangle records are read)'
-    elif kind in ('mesh-tin', 'mesh-adjacency'):
-        mb, what = 32 * nt + 16 * nv, '32 B adjacency record per triangle + 16 B per vertex'
+    elif kind in ('mesh-tin', 'mesh-tin-shuffled', 'mesh-adjacency'):
+        mb, what = 96 * nt, 'three 32 B half-edge records per triangle (adjacency walk)'
     else:
         mb, what = 16 * nt + 16 * nv + 8 * (nt // 2), '>= 16 B vertex-id record per triangle + 16 B per vertex + 8 B per cell (fan slice)'
     return dict(kind=kind, z=z, origin=origin, res=1.0, verts=verts, tris=tris, bytes=mb, bytes_what=what, desc=desc)
@@ -654,8 +657,10 @@ def worker(a, rank, world, local_rank):
                               'is repeated until >= %d steps are timed; value / ms_per_step are the MEDIAN block, '
                               'first_block_ms the first one; the per-phase HIP events (kernels, roofline.launch_us) are '
                               'recorded on one further block after them' % MIN_TIMED_STEPS},
-            'config': {'workload': '%d particles/GPU x %d beams, %s, predict+MBES update+normalise+systematic '
-                                   'resample+mean/cov per step' % (P, B, m['desc']),
+            'config': {'workload': '%d particles/GPU x %d beams, %s%s, predict+MBES update+normalise+systematic '
+                                   'resample+mean/cov per step' % (P, B, m['desc'], (
+                                       ' -- RECOGNISED AS A LATTICE by mesh_build: swept on its 708 x 708 node heights, no triangle record '
+                                       'is read (an irregular TIN of the same size: value_tin / extra.mesh_tin)') if m['kind'] == 'mesh' else ''),
                        'particles_per_gpu': P, 'beams': B, 'map': m['kind'], 'parallelism': 'particle-shard x%d' % world},
             # (the dominant kernel is bound by vector issue -- `frac` stays the HBM figure SURVEY 8(d)
             #  defines, `frac_valu` is the share of the chip's vector-issue slots, from the offline PMC passes)
@@ -758,8 +763,15 @@ def worker(a, rank, world, local_rank):
             legs.append(('mesh_soup_irregular', dict(m=build_map('mesh-soup'), P=1048576, B=512, steps=10, warmup=2)))
         if a.map != 'mesh-adjacency':
             legs.append(('mesh_adjacency', dict(m=build_map('mesh-adjacency'), P=1048576, B=512, steps=20, warmup=3)))
+        # the path of a REAL survey mesh: an irregular height-field TIN through the adjacency walk (k_mbes_sweep<5,...>) --
+        # as generated (row-major), in random input order (mesh_build's Morton pass must make the two alike), and on a
+        # filter that keeps a healthy spread (the realistic deployment point)
+        tin = m if a.map == 'mesh-tin' else build_map('mesh-tin')
         if a.map != 'mesh-tin':
-            legs.append(('mesh_tin', dict(m=build_map('mesh-tin'), P=1048576, B=512, steps=20, warmup=3)))
+            legs.append(('mesh_tin', dict(m=tin, P=1048576, B=512, steps=20, warmup=3)))
+        if a.map != 'mesh-tin-shuffled':
+            legs.append(('mesh_tin_shuffled', dict(m=build_map('mesh-tin-shuffled'), P=1048576, B=512, steps=20, warmup=3)))
+        legs.append(('mesh_tin_tempered', dict(m=tin, P=1048576, B=512, steps=30, warmup=10, sigma=SIGMA * math.sqrt(512.0))))
         # global-localisation regime: sigma = 50 m cloud that nothing collapses (no resample).  Particles are
         # initialised around the odom origin (auv_particle.py:24), so the map <- odom transform puts that
         # origin 250 m inside the map; 'cloud_wide_at_border' leaves it 64 m from the western border, where
@@ -792,6 +804,15 @@ def worker(a, rank, world, local_rank):
             out['value_healthy_cloud'] = round(1e3 / ft['ms_per_step'], 3)
             out['value_healthy_cloud_what'] = ('steps/s of extra.filter_tempered: the same step on a filter whose posterior stays '
                                                'decimetres wide (likelihood tempered by 1 / beams)')
+        # ... and the general height-field mesh: `value` is the LATTICE special case (a triangulated regular grid is recognised
+        # and swept on its node heights, no triangle record read); an irregular TIN takes the adjacency walk
+        for key, leg, what in (('value_tin', 'mesh_tin', 'an irregular height-field TIN (the adjacency sweep k_mbes_sweep<5,...>), collapsed cloud like `value`'),
+                               ('value_tin_shuffled_input', 'mesh_tin_shuffled', 'the same TIN handed over in random vertex / triangle order'),
+                               ('value_tin_healthy_cloud', 'mesh_tin_tempered', 'the TIN with a posterior that stays decimetres wide: the realistic deployment point')):
+            lg = extra.get(leg, {})
+            if lg.get('ms_per_step'):
+                out[key] = round(1e3 / lg['ms_per_step'], 3)
+                out[key + '_what'] = 'steps/s of extra.%s: %s' % (leg, what)
         out['extra_summary'] = {k: v.get('ms_per_step') for k, v in extra.items()}
     if rank == 0:
         print(json.dumps(out))

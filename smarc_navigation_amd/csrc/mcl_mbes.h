@@ -76,8 +76,8 @@ struct MeshArgs {
   const uint2* cell_info;  // x = half2(zmin, zmax) conservative, y = start | count << 27
   int gx, gy;
   float cs;
-  const uint4* tin_tri;    // fan sweep over a TIN: {v0, v1, v2, -} {neighbours across v0v1, v1v2, v2v0, -} per triangle
-  const float4* tin_vert;  // (x, y, z, -) per vertex, map frame
+  const uint4* tin_he;     // fan sweep over a TIN: one 32-byte record per half-edge {x, y, z of the opposite vertex, next_a | next_b, -, -, -} (mcl_mesh.h)
+  u32 tin_he_bytes;        // ... its size (read through a raw buffer)
   const float4* cell_tri;  // fan slice (mcl_slice.h): the three vertices (x, y, z, -), map frame, of every (cell, triangle) record, indexed like `tri`
   double x0, y0;           // map-frame position of cell (0, 0)'s corner
 };

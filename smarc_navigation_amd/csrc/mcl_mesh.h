@@ -34,13 +34,19 @@ struct MeshDev {
   size_t n_vertical = 0;  // triangles whose xy projection is degenerate (cannot be a height field)
   int diag_mode = 0;      // structured: 1 = every cell split along 00-11, 2 = along 10-01, 0 = mixed (LSB per cell)
   double slope_max = 0;   // steepest triangle, |grad h| (the fan sweep's tilt bound, mcl_sweep.h)
-  // triangle adjacency for the fan sweep over an arbitrary height-field TIN (mcl_sweep.h: sweep_side_tin):
-  // per triangle two uint4 {v0, v1, v2, -} {neighbour across v0v1, v1v2, v2v0 (0xffffffff: hole / ragged border,
-  // 0xfffffff0 / 0xfffffff1: the map's outer x / y border), -},
-  // per vertex one float4 (x, y, z, -).  tin_ok: every edge has at most two triangles and their third vertices lie
-  // on opposite sides of it in the xy projection (no fold: the mesh is a height field), no vertical triangle.
-  uint4* tin_tri = nullptr;
-  float4* tin_vert = nullptr;
+  // triangle adjacency for the fan sweep over an arbitrary height-field TIN (mcl_sweep.h: sweep_side_tin): ONE 32-byte
+  // record per half-edge h = 3 T + e (T: the triangle's number in Morton order of its xy centroid, e: its edge
+  // (v_e, v_e+1), every triangle taken counter-clockwise in xy) -- what a walk that ENTERS T through that edge needs:
+  //   {x, y, z of the vertex opposite the edge (v_e+2),
+  //    next_a: the half-edge on the far side of edge e+2 = (v_e+2, v_e), next_b: of edge e+1 = (v_e+1, v_e+2), -, -, -}
+  // (0xffffffff: hole / ragged border, 0xfffffff0 / 0xfffffff1: the map's outer x / y border).  One dependent load per
+  // step of the walk, no vertex ids: which of the two exits a slice takes is decided by the side of the plane the new
+  // vertex lies on (rounds 3-5: a 32-byte triangle record and then the vertex it named, 16 bytes, a second dependent
+  // load; input order -- the walk's neighbours megabytes apart when the caller's triangles come in no spatial order).
+  // tin_ok: every edge has at most two triangles and their third vertices lie on opposite sides of it in the xy
+  // projection (no fold: the mesh is a height field), no vertical triangle, no two triangles overlapping in xy.
+  uint4* tin_he = nullptr;
+  size_t tin_he_bytes = 0;
   bool tin_ok = false;
   // fan slice over an arbitrary triangle soup (mcl_slice.h): per (cell, triangle) record the three vertices of its source
   // triangle in MAP-FRAME coordinates, 3 float4 {x, y, z, -}, same indexing as `tri`.  (Absolute, not cell-relative: a
@@ -80,8 +86,7 @@ inline void mesh_free(MeshDev* m) {
   if (m->tri_mt) (void)hipFree(m->tri_mt);
   if (m->heights) (void)hipFree(m->heights);
   if (m->heights_pad) (void)hipFree(m->heights_pad);
-  if (m->tin_tri) (void)hipFree(m->tin_tri);
-  if (m->tin_vert) (void)hipFree(m->tin_vert);
+  if (m->tin_he) (void)hipFree(m->tin_he);
   if (m->cell_tri) (void)hipFree(m->cell_tri);
   delete m;
 }
@@ -253,6 +258,38 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
     if (std::fabs(nz) <= 1e-4 * std::sqrt(nx * nx + ny * ny + nz * nz)) any_vertical = true;
   }
   if (any_vertical) rec_mt.resize(rec.size());
+  // ---- locality pass for the adjacency walk (mcl_sweep.h: sweep_side_tin): triangles renumbered by the Morton code of
+  // their xy centroid (16 bits per axis over the bounding box; ties by input order), so that the records a walk loads
+  // one after the other -- and the walks of a wave's 64 neighbouring particles -- lie in the cache lines their
+  // neighbours have just touched, whatever order the caller's arrays come in.  (96 nt < 2^31: the table is read
+  // through a raw buffer with 32-bit byte offsets.)
+  const bool want_tin = !any_vertical && nt > 0 && nt < (1ll << 31) / 96 && nv < (1ll << 31);
+  std::vector<u32> new_of_old;
+  if (want_tin) {
+    auto spread = [](u32 v) {   // 16 bits -> every second bit of 32
+      v &= 0xffffu;
+      v = (v | (v << 8)) & 0x00ff00ffu;
+      v = (v | (v << 4)) & 0x0f0f0f0fu;
+      v = (v | (v << 2)) & 0x33333333u;
+      v = (v | (v << 1)) & 0x55555555u;
+      return v;
+    };
+    const double qx = 65535.0 / std::max(xmax - xmin, 1e-30), qy = 65535.0 / std::max(ymax - ymin, 1e-30);
+    std::vector<uint64_t> key((size_t)nt);
+    for (int64_t k = 0; k < nt; ++k) {
+      double cx = 0.0, cy = 0.0;
+      for (int c = 0; c < 3; ++c) {
+        cx += verts[3 * (size_t)tris[3 * k + c]];
+        cy += verts[3 * (size_t)tris[3 * k + c] + 1];
+      }
+      const u32 ix = (u32)std::min(65535.0, std::max(0.0, (cx / 3.0 - xmin) * qx));
+      const u32 iy = (u32)std::min(65535.0, std::max(0.0, (cy / 3.0 - ymin) * qy));
+      key[(size_t)k] = ((uint64_t)(spread(ix) | (spread(iy) << 1)) << 32) | (uint64_t)k;
+    }
+    std::sort(key.begin(), key.end());
+    new_of_old.resize((size_t)nt);
+    for (int64_t r = 0; r < nt; ++r) new_of_old[(size_t)(key[(size_t)r] & 0xffffffffull)] = (u32)r;
+  }
   for (int64_t k = 0; k < nt; ++k) {
     int a0, a1, b0, b1;
     cell_range(k, a0, a1, b0, b1);
@@ -284,7 +321,7 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
           rec[r + 0] = make_float4((float)px, (float)py, (float)pd, 0.f);
           rec[r + 1] = make_float4((float)lx, (float)ly, (float)(by / det), (float)(-bx / det));
           float tid;  // (the source triangle's index rides in the record's spare word: sweep_side_tin's start)
-          const u32 k32 = (u32)k;
+          const u32 k32 = want_tin ? new_of_old[(size_t)k] : (u32)k;   // (its number in the half-edge table's order)
           memcpy(&tid, &k32, 4);
           rec[r + 2] = make_float4((float)(-ay / det), (float)(ax / det), tid, 0.f);
         } else {
@@ -327,16 +364,17 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
     return MCL_ERR_HIP;
   }
   // ---- triangle adjacency (fan sweep over a TIN): edge -> the (at most two) triangles on it
-  if (!any_vertical && nt < (1ll << 31) && nv < (1ll << 31)) {
+  if (want_tin) {
     bool ok = true;
     std::unordered_map<uint64_t, int64_t> edge_first;  // undirected edge -> 3 * triangle + local edge of the first owner
     edge_first.reserve((size_t)nt * 2);
-    std::vector<uint4> tt(2 * (size_t)nt);
+    // twin[3 k + e]: the half-edge (3 * triangle + ITS edge) on the far side of edge e = (v_e, v_e+1) of triangle k,
+    // input numbering and input winding; ccw[k]: the triangle's xy projection is counter-clockwise as given
+    std::vector<u32> twin(3 * (size_t)nt, 0xffffffffu);
+    std::vector<unsigned char> ccw((size_t)nt, 1);
     double g2 = 0.0;
     for (int64_t k = 0; k < nt && ok; ++k) {
       const u32 v[3] = {tris[3 * k], tris[3 * k + 1], tris[3 * k + 2]};
-      tt[2 * k] = make_uint4(v[0], v[1], v[2], 0u);
-      tt[2 * k + 1] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0u);
       if (v[0] == v[1] || v[1] == v[2] || v[0] == v[2]) ok = false;
       // slope of the triangle's plane
       const float* p0 = verts + 3 * (size_t)v[0];
@@ -346,6 +384,7 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
       const double bx = (double)p2[0] - p0[0], by = (double)p2[1] - p0[1], bz = (double)p2[2] - p0[2];
       const double nz = ax * by - ay * bx, nx = ay * bz - az * by, ny = az * bx - ax * bz;
       if (nz == 0.0) ok = false; else g2 = std::max(g2, (nx * nx + ny * ny) / (nz * nz));
+      ccw[(size_t)k] = nz > 0.0;
     }
     for (int64_t k = 0; k < nt && ok; ++k)
       for (int e = 0; e < 3 && ok; ++e) {
@@ -368,10 +407,8 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
           const double sc = ex * ((double)pc[1] - pa[1]) - ey * ((double)pc[0] - pa[0]);
           const double sd = ex * ((double)pd[1] - pa[1]) - ey * ((double)pd[0] - pa[0]);
           if (!(sc * sd < 0.0)) ok = false;
-          u32* nb1 = &tt[2 * k + 1].x;
-          u32* nb2 = &tt[2 * k2 + 1].x;
-          nb1[e] = (u32)k2;
-          nb2[e2] = (u32)k;
+          twin[3 * (size_t)k + e] = (u32)(3 * k2 + e2);
+          twin[3 * (size_t)k2 + e2] = (u32)(3 * k + e);
           it->second = -1;
         }
       }
@@ -429,28 +466,48 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
       // the bounding box: 0xfffffff0 for an x side, 0xfffffff1 for a y side -- a slice that leaves there cannot
       // come back, mcl_sweep.h) or anywhere else (a hole, a ragged outline: 0xffffffff)
       const double eb = 1e-6 * std::max(1.0, std::max(xmax - xmin, ymax - ymin));
-      for (int64_t k = 0; k < nt; ++k) {
-        u32* nb = &tt[2 * k + 1].x;
-        for (int e = 0; e < 3; ++e) {
-          if (nb[e] != 0xffffffffu) continue;
+      // the half-edge on the far side of input edge e of input triangle k, in the table's numbering: the table takes
+      // every triangle counter-clockwise in xy -- a clockwise one as (v0, v2, v1): its table edge j is its input edge
+      // 2 - j reversed, its table vertex j its input vertex (3 - j) % 3
+      auto far_side = [&](int64_t k, int e) -> u32 {
+        const u32 t = twin[3 * (size_t)k + e];
+        if (t == 0xffffffffu) {
           const float* pa = verts + 3 * (size_t)tris[3 * k + e];
           const float* pb = verts + 3 * (size_t)tris[3 * k + (e + 1) % 3];
           const bool on_x = (std::fabs(pa[0] - xmin) <= eb && std::fabs(pb[0] - xmin) <= eb) ||
                             (std::fabs(pa[0] - xmax) <= eb && std::fabs(pb[0] - xmax) <= eb);
           const bool on_y = (std::fabs(pa[1] - ymin) <= eb && std::fabs(pb[1] - ymin) <= eb) ||
                             (std::fabs(pa[1] - ymax) <= eb && std::fabs(pb[1] - ymax) <= eb);
-          if (on_x) nb[e] = 0xfffffff0u;
-          else if (on_y) nb[e] = 0xfffffff1u;
+          return on_x ? 0xfffffff0u : (on_y ? 0xfffffff1u : 0xffffffffu);
+        }
+        const u32 k2 = t / 3u, e2 = t % 3u;
+        return 3u * new_of_old[k2] + (ccw[k2] ? e2 : 2u - e2);
+      };
+      std::vector<uint4> he(2 * 3 * (size_t)nt);
+      for (int64_t k = 0; k < nt; ++k) {
+        const bool c = ccw[(size_t)k] != 0;
+        for (int j = 0; j < 3; ++j) {   // table edge j of this triangle
+          // table vertices: j -> input vertex (c ? j : (3 - j) % 3); table edge j = (tv_j, tv_j+1) = input edge (c ? j : 2 - j)
+          const auto tv = [&](int q) { return tris[3 * k + (c ? q % 3 : (3 - q % 3) % 3)]; };
+          const auto te = [&](int q) { return c ? q % 3 : 2 - q % 3; };
+          const float* po = verts + 3 * (size_t)tv(j + 2);
+          const u32 na = far_side(k, te(j + 2)), nb = far_side(k, te(j + 1));
+          u32 bx, by, bz;
+          memcpy(&bx, po, 4);
+          memcpy(&by, po + 1, 4);
+          memcpy(&bz, po + 2, 4);
+          const size_t h = 3 * (size_t)new_of_old[(size_t)k] + j;
+          he[2 * h] = make_uint4(bx, by, bz, na);
+          he[2 * h + 1] = make_uint4(nb, 0u, 0u, 0u);
         }
       }
-      std::vector<float4> vv((size_t)nv);
-      for (int64_t i = 0; i < nv; ++i) vv[i] = make_float4(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2], 0.f);
-      if (hipMalloc(&m->tin_tri, sizeof(uint4) * tt.size()) == hipSuccess &&
-          hipMalloc(&m->tin_vert, sizeof(float4) * vv.size()) == hipSuccess &&
-          hipMemcpy(m->tin_tri, tt.data(), sizeof(uint4) * tt.size(), hipMemcpyHostToDevice) == hipSuccess &&
-          hipMemcpy(m->tin_vert, vv.data(), sizeof(float4) * vv.size(), hipMemcpyHostToDevice) == hipSuccess) {
+      m->tin_he_bytes = sizeof(uint4) * he.size();
+      if (hipMalloc(&m->tin_he, m->tin_he_bytes) == hipSuccess &&
+          hipMemcpy(m->tin_he, he.data(), m->tin_he_bytes, hipMemcpyHostToDevice) == hipSuccess) {
         m->tin_ok = true;
         m->slope_max = std::sqrt(g2);
+      } else {
+        (void)hipGetLastError();
       }
     }
   }
@@ -590,8 +647,8 @@ inline MeshArgs mesh_args(const MeshDev* m) {
   ma.gx = m->gx;
   ma.gy = m->gy;
   ma.cs = (float)m->cs;
-  ma.tin_tri = m->tin_tri;
-  ma.tin_vert = m->tin_vert;
+  ma.tin_he = m->tin_he;
+  ma.tin_he_bytes = (u32)m->tin_he_bytes;
   ma.cell_tri = m->cell_tri;
   ma.x0 = m->x0;
   ma.y0 = m->y0;

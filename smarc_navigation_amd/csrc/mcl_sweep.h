@@ -868,9 +868,11 @@ __device__ __forceinline__ bool sweep_side_grid(const MbesArgs& a, const MbesPos
 }
 
 // ------------------------------------------------------------------ arbitrary height-field TINs (SURF 5)
-// The same sweep without the lattice: the triangle across an edge comes from the adjacency table built by
-// mesh_build (mcl_mesh.h: two uint4 per triangle -- vertex ids, neighbour ids), nodes are vertex records (x, y, z).
-// Per step: the neighbour's record (32 B), the one vertex of it that is not on the shared edge (16 B, dependent),
+// The same sweep without the lattice: the triangle across an edge comes from the half-edge table built by
+// mesh_build (mcl_mesh.h: one 32-byte record per half-edge, triangles in Morton order of their centroids): entering
+// a triangle through half-edge h, record h holds the vertex the slice meets next (x, y, z) and the two half-edges it
+// can leave through.  Per step: that ONE record (rounds 3-5: a triangle record, then the vertex it named -- two
+// dependent loads and a dozen selects on vertex ids),
 // plane function and in-plane coordinates from map-frame coordinates (the sensor position, fp64, is subtracted as an
 // fp32 part and its sub-ulp rest: vertices are fp32 inputs, the sensor is not).  The walk ends at a mesh border: the map's outer border (the
 // beams left return r_max, under the rule of the second pass above) or a hole / ragged outline (hand-over).
@@ -965,36 +967,47 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   const float su = sg * P.c1[0], sv = sg * P.c1[1], sz = sg * P.c1[2];
   const float tu = -P.c2[0], tv = -P.c2[1], tz = -c2z;
   struct TinNode {
-    u32 id;
     float d, s, t;
   };
   // (member-wise: a select between whole structs goes through scratch)
   const auto sel = [](bool c, const TinNode& x, const TinNode& y) {
     TinNode r;
-    r.id = c ? x.id : y.id;
     r.d = c ? x.d : y.d;
     r.s = c ? x.s : y.s;
     r.t = c ? x.t : y.t;
     return r;
   };
-  auto node_of = [&](u32 vid, const float4 v) {
+  auto node_of = [&](const uint4 v) {
     // v - O with O = Of + dO split once per lane: the difference of two fp32 numbers a swath apart is exact (or off by
     // one ulp of a <= 100 m difference), the sub-ulp rest of the sensor position follows -- no fp64 per node
-    const float rx = (v.x - Oxf) - dOx, ry = (v.y - Oyf) - dOy, rz = v.z - oz;
+    const float rx = (__uint_as_float(v.x) - Oxf) - dOx, ry = (__uint_as_float(v.y) - Oyf) - dOy, rz = __uint_as_float(v.z) - oz;
     TinNode N;
-    N.id = vid;
     N.d = fmaf(nx_, rx, fmaf(ny_, ry, nz_ * rz));
     N.s = fmaf(su, rx, fmaf(sv, ry, sz * rz));
     N.t = fmaf(tu, rx, fmaf(tv, ry, tz * rz));
     return N;
   };
-  auto node = [&](u32 vid) { return node_of(vid, ma.tin_vert[vid]); };
+  // the half-edge table (mcl_mesh.h: MeshDev::tin_he) as a raw buffer: record h at byte 32 h; a border code
+  // (h >= 0xfffffff0) is beyond num_records whatever the shift leaves of it and reads zeros -- no select, no 64-bit
+  // address arithmetic
+  const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ma.tin_he, 0, (int)ma.tin_he_bytes, 0x00020000);
+  const auto he_xyzn = [&](u32 h) {   // {x, y, z of the vertex opposite half-edge h, next_a}
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (int)(h << 5), 0, 0));
+  };
+  const auto he_nb = [&](u32 h) {     // next_b
+    return (u32)__builtin_amdgcn_raw_buffer_load_b32(hrsrc, (int)(h << 5) + 16, 0, 0);
+  };
   TinNode A, Bn;
-  u32 nb;  // the triangle across the current exit edge
+  u32 nb;    // the half-edge through which the slice enters the next triangle (or a border code)
+  bool ao;   // is A the ORIGIN of that half-edge (in the next triangle's own counter-clockwise order)?
   float s_prev, t_prev, s_cur, t_cur;
   {
-    const uint4 tv3 = ma.tin_tri[2 * (size_t)T], tn3 = ma.tin_tri[2 * (size_t)T + 1];
-    const TinNode N0 = node(tv3.x), N1 = node(tv3.y), N2 = node(tv3.z);
+    // triangle T through its three records: 3 T + e holds the vertex opposite edge e, v_e+2, and -- next_a -- the
+    // half-edge on the far side of edge e + 2.  So vertex j comes from record (j + 1) % 3 and the far side of edge j
+    // from the same record
+    const uint4 q0 = he_xyzn(3u * T), q1 = he_xyzn(3u * T + 1u), q2 = he_xyzn(3u * T + 2u);
+    const TinNode N0 = node_of(q1), N1 = node_of(q2), N2 = node_of(q0);
+    const u32 f0 = q1.w, f1 = q2.w, f2 = q0.w;   // far side of edge 0 = (v0, v1), 1 = (v1, v2), 2 = (v2, v0)
     const bool p0b = __float_as_int(N0.d) >= 0, p1b = __float_as_int(N1.d) >= 0, p2b = __float_as_int(N2.d) >= 0;   // (sides of the plane by the sign bit, like the walk)
     if (p0b == p1b && p1b == p2b) return false;
     const int L = (p0b != p1b && p0b != p2b) ? 0 : ((p1b != p0b && p1b != p2b) ? 1 : 2);
@@ -1002,8 +1015,8 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const TinNode NL = sel(L == 0, N0, sel(L == 1, N1, N2));
     const TinNode NM = sel(L == 0, N1, sel(L == 1, N2, N0));  // vL+1
     const TinNode NN = sel(L == 0, N2, sel(L == 1, N0, N1));  // vL+2
-    const u32 nbM = L == 0 ? tn3.x : (L == 1 ? tn3.y : tn3.z);  // across edge L
-    const u32 nbN = L == 0 ? tn3.z : (L == 1 ? tn3.x : tn3.y);  // across edge L+2
+    const u32 nbM = L == 0 ? f0 : (L == 1 ? f1 : f2);  // across edge L
+    const u32 nbN = L == 0 ? f2 : (L == 1 ? f0 : f1);  // across edge L+2
     const float lm = NL.d * fast_rcp(NL.d - NM.d), ln = NL.d * fast_rcp(NL.d - NN.d);
     const float sm = fmaf(lm, NM.s - NL.s, NL.s), tm = fmaf(lm, NM.t - NL.t, NL.t);
     const float sn = fmaf(ln, NN.s - NL.s, NL.s), tn = fmaf(ln, NN.t - NL.t, NL.t);
@@ -1014,6 +1027,9 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     A = sel(pl, NF, NL);   // (A, Bn: plane functions of opposite sign bits; along the walk A is the vertex found last)
     Bn = sel(pl, NL, NF);
     nb = far_m ? nbM : nbN;
+    // the neighbour runs the shared edge the other way round (both counter-clockwise): out through edge L = (vL, vL+1)
+    // its half-edge starts at vL+1 = NF, out through edge L+2 = (vL+2, vL) at vL = NL
+    ao = far_m == pl;
     s_cur = far_m ? sm : sn;
     t_cur = far_m ? tm : tn;
     s_prev = far_m ? sn : sm;
@@ -1047,12 +1063,10 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   // two).  Returns true when the walk is over.  EXITS: as in sweep_side, the tests that end a walk normally run every
   // second step; the step count is the wave's.
   const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc, const int step, auto EXITS) -> bool {
-    // the neighbour's record is in flight while the beams are resolved.  (Carrying the neighbour's vertex off the shared
-    // edge in every record, so that the vertex could be loaded together with the record instead of after it, was built
-    // and measured in round 4: 48-byte records and three more registers cost what the shorter chain saved.)
-    const bool border = nb >= 0xfffffff0u;
-    const size_t tq = border ? 0 : (size_t)nb;
-    const uint4 tv3 = ma.tin_tri[2 * tq], tn3 = ma.tin_tri[2 * tq + 1];
+    // the entered half-edge's record is in flight while the beams are resolved: the vertex the slice meets next and
+    // the two half-edges it can leave through -- ONE dependent load per step
+    const uint4 hq = he_xyzn(nb);
+    const u32 hb = he_nb(nb);
     const float dts = tc - tp;
     if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
       sweep_merge_asm(msel, acc, bp, sp, tp, sc, tc, dts);   // (msel = side + 2 noclamp: wave-uniform)
@@ -1082,7 +1096,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
       if (bp == bp_end) return true;
       if (sc > s_stop) return true;
     }
-    if (border) {
+    if (nb >= 0xfffffff0u) {
       // the slice runs off the mesh.  Through the map's outer border: final if it cannot come back (same bound as in
       // sweep_side's second pass); through a hole or a ragged outline: not for the sweep
       const float sb = fast_sqrt(fmaxf(1.f - c2z * c2z, 0.f));
@@ -1094,25 +1108,20 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
       ok = false;
       return true;
     }
-    // the vertex of the neighbour that is not on the shared edge, and the vertex after it (orientation)
-    const int m = (tv3.x != A.id && tv3.x != Bn.id) ? 0 : ((tv3.y != A.id && tv3.y != Bn.id) ? 1 : 2);
-    const u32 vidN = m == 0 ? tv3.x : (m == 1 ? tv3.y : tv3.z);
-    const float4 vN = ma.tin_vert[vidN];
-    const u32 nextv = m == 0 ? tv3.y : (m == 1 ? tv3.z : tv3.x);
-    const u32 nb_m = m == 0 ? tn3.x : (m == 1 ? tn3.y : tn3.z);   // across edge m = (N, next)
-    const u32 nb_p = m == 0 ? tn3.z : (m == 1 ? tn3.x : tn3.y);   // across edge m+2 = (previous, N)
     // the new vertex replaces the one on ITS side of the plane (sides by the sign bit of the plane function) and
-    // always takes the role of A; the one that stays moves to Bn only when it was A (five selects, as in sweep_side)
-    const float rx = (vN.x - Oxf) - dOx, ry = (vN.y - Oyf) - dOy, rz = vN.z - oz;
+    // always takes the role of A; the one that stays moves to Bn only when it was A (three selects).  The slice
+    // leaves through the edge that joins the new vertex to the one that stays: the entered half-edge runs a -> b,
+    // the new vertex N is opposite; a stays -> out through (N, a), whose far side is next_a and ends in N = A;
+    // b stays -> out through (b, N), next_b, which starts in N = A
+    const float rx = (__uint_as_float(hq.x) - Oxf) - dOx, ry = (__uint_as_float(hq.y) - Oyf) - dOy, rz = __uint_as_float(hq.z) - oz;
     const float dN = fmaf(nx_, rx, fmaf(ny_, ry, nz_ * rz));
     const bool keep_a = (__float_as_int(dN) ^ __float_as_int(A.d)) < 0;
-    const u32 keep = keep_a ? A.id : Bn.id;
-    nb = nextv == keep ? nb_m : nb_p;
-    Bn.id = keep;
+    const bool stays_a = keep_a == ao;   // the vertex that stays is the half-edge's origin
+    nb = stays_a ? hq.w : hb;
+    ao = !stays_a;
     Bn.d = keep_a ? A.d : Bn.d;
     Bn.s = keep_a ? A.s : Bn.s;
     Bn.t = keep_a ? A.t : Bn.t;
-    A.id = vidN;
     A.d = dN;
     A.s = fmaf(su, rx, fmaf(sv, ry, sz * rz));
     A.t = fmaf(tu, rx, fmaf(tv, ry, tz * rz));

@@ -168,6 +168,26 @@ def mesh_tin(z, res, origin, seed=7, jitter=0.25):
     return verts, tris
 
 
+def mesh_shuffle(verts, tris, seed=9):
+    """The same surface handed over the way a mesh file from a survey tool may hold it: vertices renumbered by a
+    random permutation, triangles in random order, each triangle's corners rotated at random and every second
+    one's winding reversed.  Geometry unchanged."""
+    rs = np.random.RandomState(seed)
+    nv, nt = verts.shape[0], tris.shape[0]
+    pv = rs.permutation(nv)                 # new position of old vertex i: where[i]
+    where = np.empty(nv, dtype=np.int64)
+    where[pv] = np.arange(nv)
+    v2 = np.ascontiguousarray(verts[pv])
+    t2 = where[tris.astype(np.int64)]
+    t2 = t2[rs.permutation(nt)]
+    rot = rs.randint(0, 3, nt)
+    idx = (np.arange(3)[None, :] + rot[:, None]) % 3
+    t2 = np.take_along_axis(t2, idx, axis=1)
+    flip = rs.rand(nt) < 0.5
+    t2[flip] = t2[flip][:, ::-1]
+    return v2, np.ascontiguousarray(t2.astype(np.uint32))
+
+
 def landmark_map(n=4096, extent=(-64.0, -256.0, 448.0, 256.0), z_range=(-24.0, -16.0), seed=6):
     """Feature map of BASELINE config 5: n landmarks uniform over the map (seed 6)."""
     rs = np.random.RandomState(seed)

@@ -174,7 +174,8 @@ def outliers_explained(orc, omap, soa, ba, got, ref, r_max, m2o=None, off=None, 
     return int(bad.sum()), float(err[bad].max()), float(jump[b].max())
 
 
-def lw_outliers_explained(orc, omap, soa, ba, ranges, sigma, r_max, lw_got, lw_ref, m2o=None, off=None, delta=1e-3, label=''):
+def lw_outliers_explained(orc, omap, soa, ba, ranges, sigma, r_max, lw_got, lw_ref, m2o=None, off=None, delta=1e-3, label='',
+                          select=None):
     """The log-likelihood side of the same contract (include/mcl.h, mcl_update_mbes: |d| <= 1e-2 or 2e-4 |lw|): a particle
     outside it must own a ray that flips between a crest and its shadow, i.e. its log-likelihood must lie inside the
     interval the fp64 oracle spans when the sensor moves by `delta` (1 mm) along the six axis directions -- widened by
@@ -182,7 +183,7 @@ def lw_outliers_explained(orc, omap, soa, ba, ranges, sigma, r_max, lw_got, lw_r
     m2o = np.identity(4) if m2o is None else m2o
     off = [0.0] * 6 if off is None else off
     d = np.abs(lw_got - lw_ref)
-    out = ~((d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref)))
+    out = ~((d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref))) if select is None else np.asarray(select, bool)
     if not out.any():
         return 0
     rows = np.nonzero(out)[0]
@@ -204,3 +205,46 @@ def lw_outliers_explained(orc, omap, soa, ba, ranges, sigma, r_max, lw_got, lw_r
     print('%s: %d particles beyond the log-likelihood tolerance (worst |d| %.3e), each inside the oracle interval under a 1 mm '
           'shift of the sensor (widest interval %.2f)' % (label, rows.size, d[out].max(), (hi - lo).max()))
     return int(rows.size)
+
+
+LIVE_SPAN = 30.0   # a particle's fixed-point weight q = floor(exp(lw - max) 2^s) is non-zero only for lw > max - s ln 2 (s = 63 - ceil(log2 N) = 43 at N = 2^20 -> 29.8); 30 covers every N >= 2^20
+
+
+def live_particle_contract(orc, omap, soa, ba, ranges, sigma, r_max, lw_got, lw_ref, lw_max, m2o=None, off=None, label='',
+                           allow=None):
+    """The a15 contract WHERE IT BITES (include/mcl.h beside mcl_update_mbes): the relative arm of the
+    log-likelihood tolerance (2e-4 |lw|) may only ever matter for particles that cannot receive offspring.  For every
+    checked particle that is LIVE -- log-likelihood within LIVE_SPAN of the cloud's maximum `lw_max`, in the GPU's or in
+    the oracle's arithmetic: its fixed-point weight is non-zero -- the absolute bound |d lw| <= 1e-2 must
+    hold on its own.  The only exception is a particle that owns a ray grazing a crest (the last bit of fp32 decides
+    between the crest and its shadow): it must lie inside the oracle's own interval under 1 mm shifts of the sensor, and
+    there may be at most `allow` of them (default: 1 per 2 000 live particles, at least 1).  Prints the measured maximum
+    on the live set; returns (live particles, max |d| among them, exceptions)."""
+    d = np.abs(lw_got - lw_ref)
+    live = (lw_got >= lw_max - LIVE_SPAN) | (lw_ref >= lw_max - LIVE_SPAN)
+    n_live = int(live.sum())
+    if n_live == 0:
+        print('%s: no live particle (lw >= max - %.0f) among the %d checked' % (label, LIVE_SPAN, d.size))
+        return 0, 0.0, 0
+    viol = live & ~(d <= 1e-2)
+    within = d[live & ~viol]
+    print('%s: %d live particles (lw >= max - %.0f) of %d checked: max |dlw| %.3e on the live set (bound 1e-2)%s' % (
+        label, n_live, LIVE_SPAN, d.size, within.max() if within.size else 0.0,
+        '' if not viol.any() else '; %d beyond it (worst %.3e) -- must own a grazing ray' % (int(viol.sum()), d[viol].max())))
+    n_exc = 0
+    if viol.any():
+        allow = max(1, n_live // 2000) if allow is None else allow
+        assert viol.sum() <= allow, '%s: %d live particles beyond |dlw| <= 1e-2 (allowed %d)' % (label, int(viol.sum()), allow)
+        n_exc = lw_outliers_explained(orc, omap, soa, ba, ranges, sigma, r_max, lw_got, lw_ref, m2o=m2o, off=off,
+                                      label=label + ' (live)', select=viol)
+    return n_live, float(within.max()) if within.size else 0.0, n_exc
+
+
+def live_picks(lw, count, seed=0):
+    """Indices of up to `count` LIVE particles of a cloud (lw >= max - LIVE_SPAN): the best ones and a random draw of the rest."""
+    live = np.flatnonzero(lw >= np.max(lw) - LIVE_SPAN)
+    if live.size <= count:
+        return live
+    best = live[np.argsort(lw[live])[-(count // 4):]]
+    rest = np.setdiff1d(live, best)
+    return np.concatenate([best, np.random.RandomState(seed).choice(rest, count - best.size, replace=False)])
