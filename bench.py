@@ -71,6 +71,9 @@ def parse(argv=None):
     ap.add_argument('--dry-run', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--dry-run-fail-rank', type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument('--dry-run-hang-rank', type=int, default=-1, help=argparse.SUPPRESS)
+    # tests/test_gpu_bench_multirank.py: rank R of the REAL worker dies (SIGKILL) before step K of the first timed block
+    ap.add_argument('--test-kill-rank', type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument('--test-kill-step', type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
     if a.mesh_general:
         a.map = 'mesh-general'
@@ -459,6 +462,16 @@ class stdout_to_stderr(object):
         return False
 
 
+def rccl_library():
+    """Who answers the nccl* calls of this process: librccl, or the test double of tests/fake_nccl (LD_PRELOAD) -- a line
+    produced over the double measures the host code's call sequence on one device, not a transport."""
+    import ctypes
+    try:
+        return 'TEST DOUBLE tests/fake_nccl (LD_PRELOAD): not RCCL, not a measurement' if ctypes.CDLL(None).fake_nccl_present() == 1 else 'librccl'
+    except (AttributeError, OSError):
+        return 'librccl'
+
+
 def setup_comm(e, engine, dist, rank, world, want_overlap):
     """RCCL communicator(s) of the data path.  The overlapped state all-gather drives two communicators
     on two streams; a self-test with a deadline runs that exact pattern first, and if any rank does not
@@ -534,6 +547,8 @@ def worker(a, rank, world, local_rank):
 
     def run(k0, k1):
         for k in range(k0, k1):
+            if rank == a.test_kill_rank and k == a.warmup + a.test_kill_step:
+                os.kill(os.getpid(), 9)   # (test hook: a rank that vanishes in the middle of the timed block)
             e.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'],
                         ranges[k], ba, SIGMA * (math.sqrt(float(B)) if a.temper else 1.0), R_MAX)
 
@@ -648,7 +663,7 @@ def worker(a, rank, world, local_rank):
             'higher_is_better': True, 'scaling': a.scaling,
             'vs_baseline': None, 'dtype': 'f64 state / f32 ray-cast', 'data': 'synthetic',
             'steps_per_s': round(1e3 / ms_per_step, 3), 'particles_total': total_particles, 'cloud': cloud,
-            'rccl_ranks': rccl_ranks, 'overlapped_state_gather': bool(has_overlap),
+            'rccl_ranks': rccl_ranks, 'overlapped_state_gather': bool(has_overlap), 'rccl_library': rccl_library(),
             'launcher': 'bench.py' if os.environ.get('MCL_BENCH_SPAWNED') == '1' else ('external' if world > 1 else 'none'),
             'timed': {'blocks': nblocks, 'steps_per_block': a.steps, 'steps_total': n_timed,
                       'ms_per_step_median': round(pctl(block_ms, 50), 4), 'ms_per_step_p95': round(pctl(block_ms, 95), 4),
@@ -831,6 +846,10 @@ def main():
     world = int(env_world) if env_world is not None else 1
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('MCL_BENCH_ONE_DEVICE') == '1':
+        # test hook (tests/test_gpu_bench_multirank.py): every rank on device 0 -- only possible with the librccl test
+        # double preloaded (RCCL itself refuses two ranks on one device); the JSON line says which library answered
+        local_rank = 0
     if world != a.gpus:
         sys.stderr.write('bench: WORLD_SIZE=%d but --gpus %d: refusing to measure a different rank count\n' % (world, a.gpus))
         sys.exit(2)

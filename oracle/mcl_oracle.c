@@ -456,6 +456,57 @@ double orc_det_exp(double x) {
   return p * scale;
 }
 
+/* exp(x) = p 2^k, p in [2^-1/2, 2^1/2]: orc_det_exp's own sequence without the final scaling (mcl_device.h:
+ * det_exp_parts).  NaN, +-inf, |x| > 1e11: p = 0. */
+static double orc_det_exp_parts(double x, int64_t* ki) {
+  *ki = 0;
+  if (!(x >= -1.0e11) || !(x <= 1.0e11)) return 0.0;
+  const double LOG2E = 1.44269504088896338700e+00;
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  double k = rint(x * LOG2E);
+  double r = fma(-k, LN2_HI, x);
+  r = fma(-k, LN2_LO, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  *ki = (int64_t)k;
+  return p;
+}
+/* The integer exponent the fixed-point weights of log-likelihoods are taken relative to (mcl_device.h:
+ * weight_exponent): K = rint(m log2 e) + 1 for the cloud's largest log-likelihood m; q_i = floor(exp(lw_i) 2^(s - K)).
+ * A shard that quantises at the exponent K_r <= K of its OWN maximum holds the cloud's weights shifted left by K - K_r,
+ * exactly (floor(floor(x) / 2^d) = floor(x / 2^d)): the build's one-collective normalisation rests on this. */
+#define ORC_K_NONE (-((int64_t)1 << 40))
+int64_t orc_weight_exponent(double m_lw) {
+  if (m_lw == -INFINITY) return ORC_K_NONE;
+  if (!(m_lw >= -1.0e11)) return -((int64_t)1 << 38);
+  if (!(m_lw <= 1.0e11)) return (int64_t)1 << 38;
+  return (int64_t)rint(m_lw * 1.44269504088896338700e+00) + 1;
+}
+uint64_t orc_quantise_log_weight(double lw, int64_t K, int s) {
+  if (K == ORC_K_NONE) return (uint64_t)1 << s;
+  int64_t ki;
+  const double p = orc_det_exp_parts(lw, &ki);
+  const int64_t e = ki - K + (int64_t)s;
+  if (p == 0.0 || e < -1000 || e > 62) return 0;
+  uint64_t bits = (uint64_t)(e + 1023) << 52;
+  double scale;
+  memcpy(&scale, &bits, 8);
+  return (uint64_t)(p * scale);
+}
+
 static int ceil_log2_i64(int64_t n) {
   int l = 0;
   while (((int64_t)1 << l) < n) ++l;
@@ -476,6 +527,18 @@ uint64_t orc_fixed_weights(int n, const double* lw, int mode, int64_t n_global, 
 /* shard form: the caller supplies the GLOBAL max log-weight (all-reduce max over shards) */
 uint64_t orc_fixed_weights_m(int n, const double* lw, int mode, int64_t n_global, double m_lw, uint64_t* q,
                              double* w_lin) {
+  if (mode == 1) {
+    /* log-likelihoods: relative to the integer exponent of the maximum (above); w_lin: the weights as doubles */
+    const int s1 = 63 - ceil_log2_i64(n_global);
+    const int64_t K = orc_weight_exponent(m_lw);
+    uint64_t tot1 = 0;
+    for (int i = 0; i < n; ++i) {
+      q[i] = orc_quantise_log_weight(lw[i], K, s1);
+      tot1 += q[i];
+      if (w_lin) w_lin[i] = ldexp((double)q[i], -s1);
+    }
+    return tot1;
+  }
   double* w = (double*)malloc(sizeof(double) * (size_t)n);
   for (int i = 0; i < n; ++i) {
     if (mode == 0)

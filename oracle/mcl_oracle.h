@@ -64,12 +64,16 @@ void orc_mean_cov(int n, const double* state, double mean6[6], double* yaw_mean,
 /* ==== Fixed-point weight / systematic-resample SPEC (what the HIP path must match bit-exactly;
  * DESIGN.md "Resampling arithmetic").  Deterministic, order-free (integer sums). */
 double orc_det_exp(double x);
-/* mode 0 (GPS/reference): w = det_exp(lw) + 1e-200;  mode 1 (MBES/log domain): w = det_exp(lw - max lw).
- * q_i = floor(w_i / mw * 2^(63 - ceil_log2(n_global))), mw = weight of the max-lw particle.
+/* mode 0 (GPS/reference): w = det_exp(lw) + 1e-200, q_i = floor(w_i / mw * 2^s), mw = weight of the max-lw particle,
+ * s = 63 - ceil_log2(n_global);  mode 1 (MBES/log domain): q_i = floor(exp(lw_i) 2^(s - K)), K = the integer exponent of
+ * the largest log-likelihood (orc_weight_exponent) -- a shard that only knows its own maximum quantises at its own
+ * exponent and shifts (orc_quantise_log_weight; mcl_device.h: quantise_log_weight).
  * Multi-shard: pass m_lw_global via lw of all shards (the caller concatenates).  Returns T = sum q. */
 uint64_t orc_fixed_weights(int n, const double* lw, int mode, int64_t n_global, uint64_t* q,
                            double* w_lin);
 double orc_max(int n, const double* v);
+int64_t orc_weight_exponent(double m_lw);
+uint64_t orc_quantise_log_weight(double lw, int64_t K, int s);
 uint64_t orc_fixed_weights_m(int n, const double* lw, int mode, int64_t n_global, double m_lw_global,
                              uint64_t* q, double* w_lin);
 /* ncum[j] = #{ i in [0,N) : (U53 + i*2^53) * T < C_j * N * 2^53 },  C = inclusive scan of q

@@ -61,6 +61,8 @@ def _load():
         'orc_det_exp': (d, [d]),
         'orc_fixed_weights': (u64, [i, _f64p, i, i64, _u64p, vp]),
         'orc_fixed_weights_m': (u64, [i, _f64p, i, i64, d, _u64p, vp]),
+        'orc_weight_exponent': (i64, [d]),
+        'orc_quantise_log_weight': (u64, [d, i64, i]),
         'orc_systematic_ncum': (None, [i, _u64p, u64, u64, i64, u64, _u32p]),
         'orc_indices_from_ncum': (None, [i64, _u32p, i64, i64, _i32p]),
         'orc_philox4x32': (None, [u32, u32, u32, u32, u32, u32, _u32p]),
@@ -231,6 +233,20 @@ def fixed_weights_shard(lw, mode, n_global, m_lw_global):
     q = np.zeros(lw.size, np.uint64)
     tot = _L.orc_fixed_weights_m(lw.size, lw, int(mode), int(n_global), float(m_lw_global), q, None)
     return q, int(tot)
+
+
+def weight_exponent(m_lw):
+    """The integer exponent K log-likelihood weights are quantised relative to (mcl_device.h: weight_exponent)."""
+    return int(_L.orc_weight_exponent(float(m_lw)))
+
+
+def fixed_weights_own_exponent(lw, n_global):
+    """A shard of a cloud spread over several processes: its log-likelihood weights at the exponent of its OWN maximum
+    (what mcl_resample.h: k_quantise_tiles leaves when it fills a shard record).  Returns (q, K_r); the cloud's weights
+    are q >> (max_r K_r - K_r)."""
+    lw = _c(lw)
+    q, _ = fixed_weights_shard(lw, 1, n_global, float(np.max(lw)) if lw.size else -np.inf)
+    return q, weight_exponent(float(np.max(lw)) if lw.size else -np.inf)
 
 
 def systematic_ncum(q, u53, c_offset=0, total=None, n_global=None):

@@ -33,7 +33,10 @@ import auv_pf as ref_pf  # noqa: E402  (reference)
 
 from smarc_navigation_amd import synth  # noqa: E402
 
-OUT = os.path.join(REPO, 'tests', 'golden')
+import manifest  # noqa: E402  (this directory: where to write, and the fixture hashes)
+
+OUT = manifest.golden_dir()
+WRITTEN = []
 
 
 def make_node(n, init_cov, motion_cov, res_cov, meas_std, m2o, utm2map):
@@ -160,6 +163,7 @@ def run_scenario(name, n, n_steps, seed, init_cov, motion_cov, res_cov, meas_std
         weights_raw=np.array(cap['weights_raw']), weights_norm=np.array(cap['weights_norm']),
         indices=np.array(cap['indices']))
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    WRITTEN.append(name + '.npz')
     ref_pf.residual_resample = ref_resampling.residual_resample
     print('%-28s n=%d steps=%d fixes=%d final mean=(%.4f, %.4f)' % (name, n, n_steps, fix_ptr,
                                                                    means[-1][0], means[-1][1]))
@@ -216,6 +220,7 @@ def gen_resampling():
             cases.append(tag)
     out['cases'] = np.array(cases)
     np.savez_compressed(os.path.join(OUT, 'resampling_kat.npz'), **out)
+    WRITTEN.append('resampling_kat.npz')
     print('resampling_kat: %d cases' % len(cases))
 
 
@@ -295,6 +300,7 @@ def gen_particle_kat():
     out['mt_in'] = np.array([1.5, -2.5, 0.25, q[3, 0], q[3, 1], q[3, 2], q[3, 3]])
     out['mt_M'] = ref_particle.matrix_from_tf(t)
     np.savez_compressed(os.path.join(OUT, 'particle_kat.npz'), **out)
+    WRITTEN.append('particle_kat.npz')
     print('particle_kat written')
 
 
@@ -318,6 +324,7 @@ def main():
                  [0.5, 0.5, 1e-3, 1e-5, 1e-5, 1e-4], 0.7, 20, 'systematic')
     gen_resampling()
     gen_particle_kat()
+    manifest.record(OUT, WRITTEN, 'oracle/ref_harness/gen_golden.py', needs_reference=True)
 
 
 if __name__ == '__main__':

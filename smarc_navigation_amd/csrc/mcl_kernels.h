@@ -198,17 +198,17 @@ __global__ void __launch_bounds__(1024) k_max_final(const double* __restrict__ p
 }
 
 // ------------------------------------------------------------------ K3/K4: fixed-point weights
-// q_i = floor(w_i / mw * 2^s), w_i = det_exp(lw_i) + 1e-200 (mode 0) or det_exp(lw_i - m) (mode 1),
-// mw = weight of the max-lw particle.  Integer sums are exact and order-free, so the CDF is
-// identical for any grid shape / GPU count.
-__device__ __forceinline__ u64 quantise_weight(double lw, double m_lw, int mode, double scale) {
+// q_i = floor(w_i / mw * 2^s), w_i = det_exp(lw_i) + 1e-200 (mode 0: GPS, auv_pf.py:165), mw = weight of the max-lw
+// particle; mode 1 (log-likelihoods): floor(exp(lw_i) 2^(s - K)), K the integer exponent of the maximum
+// (mcl_device.h: quantise_log_weight).  Integer sums are exact and order-free, so the CDF is identical for any grid
+// shape / GPU count.
+__device__ __forceinline__ u64 quantise_weight(double lw, double m_lw, int mode, double scale, int s) {
   double w, mw;
   if (mode == 0) {
     w = det_exp(lw) + 1.e-200;
     mw = det_exp(m_lw) + 1.e-200;
   } else if (mode == 1) {
-    w = (m_lw == -__builtin_inf()) ? 1.0 : det_exp(lw - m_lw);
-    mw = 1.0;
+    return quantise_log_weight(lw, weight_exponent(m_lw), s);
   } else {  // mode 2: `lw` already holds linear weights, m_lw their maximum
     w = lw > 0.0 ? lw : 0.0;
     mw = m_lw;
@@ -219,7 +219,7 @@ __device__ __forceinline__ u64 quantise_weight(double lw, double m_lw, int mode,
 // pass 1: per-tile sums of q (tile = MCL_SCAN_TILE consecutive particles)
 __global__ void __launch_bounds__(MCL_BLOCK) k_q_tile_sums(const double* __restrict__ lw, long long n,
                                                            const double* __restrict__ m_lw, int mode,
-                                                           double scale, u64* __restrict__ q,
+                                                           double scale, int s, u64* __restrict__ q,
                                                            u64* __restrict__ tile_sum) {
   __shared__ u64 sh[16];
   const double m = m_lw[0];
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_q_tile_sums(const double* __restr
     for (int k = 0; k < MCL_SCAN_ITEMS; ++k) {
       long long i = base + (long long)k * MCL_BLOCK + threadIdx.x;
       if (i < n) {
-        u64 qi = quantise_weight(lw[i], m, mode, scale);
+        u64 qi = quantise_weight(lw[i], m, mode, scale, s);
         q[i] = qi;
         acc += qi;
       }
@@ -293,12 +293,14 @@ struct CdfArgs {
   int rank, world;
   u64 n_global;
   u64 u53;
+  const u64* shift;    // q is at the shard's own exponent: the cloud's weights are q >> shift[0] (nullptr: q as it is)
 };
 __global__ void __launch_bounds__(MCL_BLOCK) k_offspring_cdf(const u64* __restrict__ q, long long n,
                                                              const u64* __restrict__ tile_off, CdfArgs a,
                                                              u32* __restrict__ ncum) {
   __shared__ u64 sh[16];
   u64 shard_off = 0, T = 0;
+  const u32 qshift = a.shift ? (u32)a.shift[0] : 0u;
   for (int r = 0; r < a.world; ++r) {
     u64 t = a.totals[r];
     if (r < a.rank) shard_off += t;
@@ -308,7 +310,7 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_offspring_cdf(const u64* __restri
     const long long base = tile * MCL_SCAN_TILE + (long long)threadIdx.x * MCL_SCAN_ITEMS;
     u64 v[MCL_SCAN_ITEMS];
 #pragma unroll
-    for (int k = 0; k < MCL_SCAN_ITEMS; ++k) v[k] = (base + k < n) ? q[base + k] : 0ull;
+    for (int k = 0; k < MCL_SCAN_ITEMS; ++k) v[k] = (base + k < n) ? shift_weight(q[base + k], qshift) : 0ull;
     tile_scan_blocked(v, sh);
     const u64 off = shard_off + tile_off[tile];
 #pragma unroll
@@ -433,13 +435,14 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_indices(const u32* __restrict__ n
 // gather by explicit indices (used by the non-systematic schemes): dst[i] = src[idx[i]]
 __global__ void __launch_bounds__(MCL_BLOCK) k_normalised_weights(const u64* __restrict__ q, long long n,
                                                                   const u64* __restrict__ totals, int world,
-                                                                  double* __restrict__ w) {
+                                                                  const u64* __restrict__ shift, double* __restrict__ w) {
   u64 T = 0;
   for (int r = 0; r < world; ++r) T += totals[r];
   const double inv = 1.0 / (double)T;
+  const u32 d = shift ? (u32)shift[0] : 0u;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)
-    w[i] = (double)q[i] * inv;
+    w[i] = (double)shift_weight(q[i], d) * inv;
 }
 
 // ------------------------------------------------------------------ K6: mean / covariance

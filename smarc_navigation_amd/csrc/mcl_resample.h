@@ -54,11 +54,23 @@ struct QuantArgs {
   const double* m_lw;  // the (all-reduced) maximum
   int mode;
   double scale;
+  int s;               // log2 of scale
   u64* q;
   u64* tile_sum;   // gridDim.x entries
+  // one shard of a cloud spread over several processes: the maximum in `slots` is the SHARD's, the weights
+  // are taken at the shard's own exponent, and the kernel leaves what the other shards need to put them on the
+  // cloud's exponent WITHOUT another pass: the number of weights with bit b set, b = 0 .. 63 -- the shard's total at
+  // any right shift d is sum_{b >= d} count_b 2^(b - d) -- per tile (tile_bits, 64 u16 each: the tile offsets at the
+  // shift that turns out to apply) and for the shard (rec[1 + b], accumulated by atomics: zero before the launch,
+  // zeroed again by k_shift_scan); rec[0] = the shard's exponent (biased).  nullptr: none of this.
+  u64* rec;
+  unsigned short* tile_bits;
 };
+#define SHREC_WORDS 65                       // a shard's record: exponent, 64 bit counts
+#define SHREC_BIAS (1ll << 41)
 __global__ void __launch_bounds__(MCL_BLOCK) k_quantise_tiles(QuantArgs a) {
   __shared__ u64 sh[16];
+  __shared__ u32 bc[64];
   const long long tile = blockIdx.x;  // the grid is exactly the number of tiles
   const long long base = tile * MCL_SCAN_TILE;
   // (the log-weights first: their loads are in flight while the maximum is read from the 64 slots -- two memory
@@ -69,19 +81,112 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_quantise_tiles(QuantArgs a) {
     const long long i = base + (long long)k * MCL_BLOCK + threadIdx.x;
     lwv[k] = i < a.n ? a.lw[i] : 0.0;
   }
+  if (a.rec && threadIdx.x < 64) bc[threadIdx.x] = 0u;
   const double m = a.slots ? max_from_slots(a.slots) : a.m_lw[0];
   u64 acc = 0;
+  u64 qv[MCL_SCAN_ITEMS];
 #pragma unroll
   for (int k = 0; k < MCL_SCAN_ITEMS; ++k) {
     const long long i = base + (long long)k * MCL_BLOCK + threadIdx.x;
+    qv[k] = 0ull;
     if (i < a.n) {
-      const u64 qi = quantise_weight(lwv[k], m, a.mode, a.scale);
+      const u64 qi = quantise_weight(lwv[k], m, a.mode, a.scale, a.s);
       a.q[i] = qi;
       acc += qi;
+      qv[k] = qi;
     }
+  }
+  if (a.rec) {
+    // bit counts: one ballot per (bit, item), lane b keeps bit b's count of the wave; only up to the wave's highest bit
+    const int lane = threadIdx.x & 63;
+    u64 any = 0ull;
+#pragma unroll
+    for (int k = 0; k < MCL_SCAN_ITEMS; ++k) any |= qv[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o, MCL_WAVE);
+    const int top = any ? 63 - __builtin_clzll(any) : -1;   // (wave-uniform)
+    u32 mine = 0u;
+    for (int b = 0; b <= top; ++b) {
+      u32 c = 0u;
+#pragma unroll
+      for (int k = 0; k < MCL_SCAN_ITEMS; ++k) c += (u32)__popcll(__ballot((qv[k] >> b) & 1ull));
+      mine = lane == b ? c : mine;
+    }
+    __syncthreads();   // (bc zeroed)
+    if (mine) atomicAdd(&bc[lane], mine);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const u32 c = bc[threadIdx.x];
+      a.tile_bits[tile * 64 + threadIdx.x] = (unsigned short)c;   // (<= 1 024 weights per tile)
+      if (c) atomicAdd((unsigned long long*)&a.rec[1 + threadIdx.x], (unsigned long long)c);
+    }
+    if (tile == 0 && threadIdx.x == 0) a.rec[0] = (u64)(weight_exponent(m) + SHREC_BIAS);
   }
   acc = block_sum(acc, sh);
   if (threadIdx.x == 0) a.tile_sum[tile] = acc;
+}
+
+// After the all-gather of the shards' records (ONE collective where rounds 1-5 had an all-reduce of the maximum and,
+// dependent on it, an all-gather of the totals): the cloud's exponent K = max K_r, every shard's shift d_r = K - K_r and
+// total at that shift, this shard's shift (-> shift_out, read by k_cdf_expand / k_offspring_cdf: q >> d on the fly) and
+// its exclusive tile offsets at that shift from the per-tile bit counts; its record's accumulators are zeroed for the
+// next resample.  One block.
+struct ShiftArgs {
+  u64* recs;           // world x SHREC_WORDS (all-gathered)
+  int rank, world;
+  const unsigned short* tile_bits;
+  long long ntiles;
+  u64* tile_off;       // out: exclusive offsets of this shard's tiles at the cloud's exponent
+  u64* totals;         // out: world totals at the cloud's exponent
+  u64* shift_out;      // out: this shard's shift (0 .. 64)
+};
+__device__ __forceinline__ u64 sum_at_shift(const u64* cnt /*64*/, u32 d) {
+  u64 t = 0ull;
+  for (u32 b = d; b < 64u; ++b) t += cnt[b] << (b - d);
+  return t;
+}
+__global__ void __launch_bounds__(1024) k_shift_scan(ShiftArgs a) {
+  __shared__ u64 sh[16];
+  __shared__ u64 carry_sh;
+  __shared__ u32 d_sh;
+  u64 K = 0ull;
+  for (int r = 0; r < a.world; ++r) {
+    const u64 k = a.recs[(size_t)r * SHREC_WORDS];
+    K = k > K ? k : K;
+  }
+  for (int r = threadIdx.x; r < a.world; r += blockDim.x) {
+    const u64 dd = K - a.recs[(size_t)r * SHREC_WORDS];
+    const u32 d = dd > 64ull ? 64u : (u32)dd;
+    a.totals[r] = sum_at_shift(a.recs + (size_t)r * SHREC_WORDS + 1, d);
+    if (r == a.rank) {
+      d_sh = d;
+      a.shift_out[0] = (u64)d;
+    }
+  }
+  if (threadIdx.x == 0) carry_sh = 0ull;
+  __syncthreads();
+  const u32 d = d_sh;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (long long base = 0; base < a.ntiles; base += blockDim.x) {
+    const long long i = base + threadIdx.x;
+    u64 v = 0ull;
+    if (i < a.ntiles) {
+      const unsigned short* tb = a.tile_bits + i * 64;
+      for (u32 b = d; b < 64u; ++b) v += (u64)tb[b] << (b - d);
+    }
+    const u64 incl = wave_scan_incl(v);
+    if (lane == 63) sh[w] = incl;
+    __syncthreads();
+    u64 woff = 0ull;
+    for (int k = 0; k < w; ++k) woff += sh[k];
+    const u64 carry = carry_sh;
+    if (i < a.ntiles) a.tile_off[i] = carry + woff + incl - v;  // exclusive
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry_sh = carry + woff + incl;
+    __syncthreads();
+  }
+  // (every read of this shard's own record is behind the barriers above)
+  if (threadIdx.x < 64) a.recs[(size_t)a.rank * SHREC_WORDS + 1 + threadIdx.x] = 0ull;
 }
 
 // ------------------------------------------------------------------ decoupled look-back (u32 sums)
@@ -154,6 +259,7 @@ struct ExpandArgs {
   int rank, world;
   u64* ls_out;           // 4 words: L | S << 32, then x, y, z of local particle 0 as doubles
   const double* p0[3];
+  const u64* shift;      // FROM_Q over one shard of several processes: q is at the shard's own exponent, the cloud's weights are q >> shift[0] (k_shift_scan); nullptr: q as it is
   int p0_z_uniform;      // the fused step has not stored z yet (k_predict_pose, skip_uniform): it is the odometry's ...
   double p0_z;           // ... depth on every particle -- the shift's z component is this value, not a stale state word
 };
@@ -182,8 +288,9 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
     const long long fine0 = tile * RS_FINE;
     // (this tile's weights first: in flight while every block adds the tile sums up)
     u64 v[RS_ITEMS];
+    const u32 qshift = a.shift ? (u32)a.shift[0] : 0u;
 #pragma unroll
-    for (int k = 0; k < RS_ITEMS; ++k) v[k] = (base + k < a.n) ? a.q[base + k] : 0ull;
+    for (int k = 0; k < RS_ITEMS; ++k) v[k] = (base + k < a.n) ? shift_weight(a.q[base + k], qshift) : 0ull;
     u64 off = 0ull, T = 0ull;
     if (a.totals) {
       // one shard of several: the weight before the shard and the global total from the all-gathered shard totals

@@ -12,8 +12,26 @@
 // Semantics are SYNCHRONOUS (the caller's stream is drained before and after every operation): stricter than RCCL's
 // stream-ordered asynchrony, so a data-flow bug cannot hide behind timing; overlap is not modelled.
 // Reductions are taken in rank order.  Waits time out after FAKE_NCCL_TIMEOUT_S (default 120 s) with ncclSystemError.
+//
+// Two transports behind the same checks.  THREADS (default): the ranks are threads of one process, bytes move by device
+// copies.  PROCESSES (FAKE_NCCL_SHM=1 when the unique id is made; the id carries the choice to the other ranks): the ranks
+// are separate processes -- `python bench.py --gpus 2` under LD_PRELOAD, every rank on device 0 -- that meet in one POSIX
+// shared-memory segment: a header (process-shared robust mutex + condition variable, the posted operations, one mailbox
+// per (source, destination) pair) and one staging slot per rank; a contribution travels device -> the sender's slot ->
+// the receiver's device.  A rank that dies is noticed (its pid is polled, a mutex it held comes back EOWNERDEAD) and every
+// waiting rank returns ncclSystemError instead of hanging.  The segment's name is unlinked as soon as every rank has
+// mapped it.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+
+#include <errno.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -26,6 +44,14 @@
 #include <mutex>
 #include <string>
 #include <vector>
+
+// -DFAKE_NCCL_HOST_ONLY (tests/test_fake_nccl_processes.py, CPU): "device" pointers are host pointers and a copy is a
+// memcpy -- the rendezvous, matching, mailbox and dead-rank logic of the double itself, without a GPU
+#ifdef FAKE_NCCL_HOST_ONLY
+#define hipMemcpy(dst, src, bytes, kind) (memcpy((dst), (src), (bytes)), hipSuccess)
+#define hipMemcpyAsync(dst, src, bytes, kind, stream) (memcpy((dst), (src), (bytes)), hipSuccess)
+#define hipStreamSynchronize(stream) (hipSuccess)
+#endif
 
 namespace {
 
@@ -109,10 +135,340 @@ thread_local std::vector<std::pair<ncclComm_t, Op>> t_ops;
 
 }  // namespace
 
+struct ShmWorld;
 struct ncclComm {
-  World* w;
+  World* w;        // threads of one process ...
   int rank;
+  ShmWorld* sw;    // ... or processes that meet in shared memory (then w == nullptr)
 };
+
+// ------------------------------------------------------------------ ranks as PROCESSES: the shared-memory transport
+namespace {
+
+constexpr int SHM_MAX_RANKS = 16;
+constexpr int SHM_MAIL_DEPTH = 8;
+
+struct ShmOp {   // what a rank posted for the collective everybody is in
+  int kind;
+  size_t count;
+  int type, op;
+};
+struct ShmPost {   // a posted send: where its bytes lie in the sender's slot
+  size_t offset, count;
+  int type;
+};
+struct ShmMail {   // sends of one (source, destination) pair in posting order
+  unsigned long long tail, head;   // posted / consumed so far
+  ShmPost d[SHM_MAIL_DEPTH];
+};
+struct ShmHdr {
+  pthread_mutex_t m;
+  pthread_cond_t cv;
+  int n, arrived, joined, left, aborted, mismatch, splits;
+  long gen;
+  size_t slot_bytes, data_off;
+  int pid[SHM_MAX_RANKS];
+  ShmOp posted[SHM_MAX_RANKS];
+  ShmMail mail[SHM_MAX_RANKS][SHM_MAX_RANKS];
+};
+}  // namespace
+
+struct ShmWorld {
+  ShmHdr* h = nullptr;
+  size_t map_bytes = 0;
+  std::string name;
+  unsigned char* slot(int r) const { return (unsigned char*)h + h->data_off + (size_t)r * h->slot_bytes; }
+};
+
+namespace {
+
+size_t shm_slot_bytes() {
+  const char* e = getenv("FAKE_NCCL_SLOT_MB");
+  const long mb = e ? atol(e) : 256;   // (sparse: tmpfs only backs the pages a run touches)
+  return (size_t)(mb > 0 ? mb : 256) << 20;
+}
+size_t shm_total(int n, size_t slot) { return ((sizeof(ShmHdr) + 4095) & ~(size_t)4095) + (size_t)n * slot; }
+
+// lock; a mutex whose owner died comes back EOWNERDEAD: the world is broken, say so to everybody
+void shm_lock(ShmHdr* h) {
+  const int rc = pthread_mutex_lock(&h->m);
+  if (rc == EOWNERDEAD) {
+    pthread_mutex_consistent(&h->m);
+    h->aborted = 1;
+    pthread_cond_broadcast(&h->cv);
+  }
+}
+void shm_unlock(ShmHdr* h) { pthread_mutex_unlock(&h->m); }
+
+// wait (mutex held) until pred() or abort or timeout; polls the other ranks' pids so that a killed rank ends the wait
+template <typename F>
+bool shm_wait(ShmHdr* h, F pred) {
+  timespec t0;
+  clock_gettime(CLOCK_REALTIME, &t0);
+  const long limit = timeout_s();
+  while (!pred() && !h->aborted) {
+    timespec now;
+    clock_gettime(CLOCK_REALTIME, &now);
+    if (now.tv_sec - t0.tv_sec > limit) return false;
+    for (int r = 0; r < h->n; ++r)
+      if (h->pid[r] > 0 && kill(h->pid[r], 0) != 0 && errno == ESRCH) {
+        fprintf(stderr, "[fake_nccl] rank process %d (rank %d) is gone\n", h->pid[r], r);
+        h->aborted = 1;
+        pthread_cond_broadcast(&h->cv);
+        return false;
+      }
+    timespec until = now;
+    until.tv_nsec += 100000000L;   // 0.1 s
+    if (until.tv_nsec >= 1000000000L) { until.tv_nsec -= 1000000000L; until.tv_sec += 1; }
+    const int rc = pthread_cond_timedwait(&h->cv, &h->m, &until);
+    if (rc == EOWNERDEAD) {
+      pthread_mutex_consistent(&h->m);
+      h->aborted = 1;
+      pthread_cond_broadcast(&h->cv);
+    }
+  }
+  return !h->aborted;
+}
+
+bool shm_barrier(ShmHdr* h) {   // mutex held
+  const long g = h->gen;
+  if (++h->arrived == h->n) {
+    h->arrived = 0;
+    ++h->gen;
+    pthread_cond_broadcast(&h->cv);
+    return !h->aborted;
+  }
+  return shm_wait(h, [&] { return h->gen != g; });
+}
+
+// segments this process made whose names may still exist (a rank that never joined): removed at exit
+std::mutex g_names_m;
+std::vector<std::string> g_names;
+void shm_unlink_leftovers() {
+  std::lock_guard<std::mutex> lk(g_names_m);
+  for (const std::string& n : g_names) shm_unlink(n.c_str());
+}
+
+ShmWorld* shm_create(const std::string& name, int n) {
+  const size_t slot = shm_slot_bytes(), total = shm_total(n, slot);
+  const int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0) return nullptr;
+  if (ftruncate(fd, (off_t)total) != 0) {
+    close(fd);
+    shm_unlink(name.c_str());
+    return nullptr;
+  }
+  void* p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) {
+    shm_unlink(name.c_str());
+    return nullptr;
+  }
+  ShmHdr* h = (ShmHdr*)p;   // (a fresh segment is zero-filled)
+  pthread_mutexattr_t ma;
+  pthread_mutexattr_init(&ma);
+  pthread_mutexattr_setpshared(&ma, PTHREAD_PROCESS_SHARED);
+  pthread_mutexattr_setrobust(&ma, PTHREAD_MUTEX_ROBUST);
+  pthread_mutex_init(&h->m, &ma);
+  pthread_condattr_t ca;
+  pthread_condattr_init(&ca);
+  pthread_condattr_setpshared(&ca, PTHREAD_PROCESS_SHARED);
+  pthread_cond_init(&h->cv, &ca);
+  h->slot_bytes = slot;
+  h->data_off = (sizeof(ShmHdr) + 4095) & ~(size_t)4095;
+  __sync_synchronize();
+  h->n = n;   // (last: a rank that attaches waits for it)
+  {
+    std::lock_guard<std::mutex> lk(g_names_m);
+    if (g_names.empty()) atexit(shm_unlink_leftovers);
+    g_names.push_back(name);
+  }
+  ShmWorld* w = new ShmWorld;
+  w->h = h;
+  w->map_bytes = total;
+  w->name = name;
+  return w;
+}
+
+// n == 0: take the rank count from the header once it is there
+ShmWorld* shm_attach(const std::string& name, int n) {
+  int fd = -1;
+  for (int tries = 0; tries < 50 * timeout_s() && fd < 0; ++tries) {   // (the creator may still be on its way)
+    fd = shm_open(name.c_str(), O_RDWR, 0600);
+    if (fd < 0) usleep(20000);
+  }
+  if (fd < 0) return nullptr;
+  struct stat st;
+  for (int tries = 0; tries < 500; ++tries) {   // (created but not sized yet)
+    if (fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(ShmHdr)) break;
+    usleep(10000);
+  }
+  const size_t total = (size_t)st.st_size;
+  if (total < sizeof(ShmHdr)) {
+    close(fd);
+    return nullptr;
+  }
+  void* p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return nullptr;
+  ShmHdr* h = (ShmHdr*)p;
+  for (int tries = 0; tries < 500 && *(volatile int*)&h->n == 0; ++tries) usleep(10000);   // (header not initialised yet)
+  if (h->n == 0 || (n && h->n != n)) {
+    munmap(p, total);
+    return nullptr;
+  }
+  ShmWorld* w = new ShmWorld;
+  w->h = h;
+  w->map_bytes = total;
+  w->name = name;
+  return w;
+}
+
+// every rank joins: pid table, rendezvous, then the name goes away (the mappings stay)
+ncclResult_t shm_join(ShmWorld* w, int rank) {
+  ShmHdr* h = w->h;
+  shm_lock(h);
+  h->pid[rank] = (int)getpid();
+  const bool last = ++h->joined == h->n;
+  const bool ok = shm_barrier(h);
+  shm_unlock(h);
+  if (last) shm_unlink(w->name.c_str());
+  return ok ? ncclSuccess : ncclSystemError;
+}
+
+bool same_shape(const ShmOp& a, const Op& b) { return a.kind == b.kind && a.count == b.count && a.type == (int)b.type && a.op == (int)b.op; }
+
+ncclResult_t shm_collective(ncclComm_t c, const Op& o) {
+  ShmWorld* w = c->sw;
+  ShmHdr* h = w->h;
+  const size_t bytes = o.count * type_bytes(o.type);
+  if (type_bytes(o.type) == 0) return ncclInvalidArgument;
+  if (bytes > h->slot_bytes) {
+    fprintf(stderr, "[fake_nccl] rank %d: a contribution of %zu bytes exceeds the staging slot (FAKE_NCCL_SLOT_MB)\n", c->rank, bytes);
+    return ncclInvalidArgument;
+  }
+  if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;   // my contribution is final
+  if (bytes && hipMemcpy(w->slot(c->rank), o.send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+  shm_lock(h);
+  h->posted[c->rank] = ShmOp{o.kind, o.count, (int)o.type, (int)o.op};
+  if (!shm_barrier(h)) { shm_unlock(h); return ncclSystemError; }
+  for (int r = 0; r < h->n; ++r)
+    if (!same_shape(h->posted[r], o)) h->mismatch = 1;
+  const bool bad = h->mismatch != 0;
+  shm_unlock(h);
+  ncclResult_t rc = ncclSuccess;
+  if (!bad && bytes) {
+    if (o.kind == 1) {
+      std::vector<unsigned char> acc(w->slot(0), w->slot(0) + bytes);
+      for (int r = 1; r < h->n; ++r) {
+        if (o.type == ncclFloat64) reduce_into((double*)acc.data(), (const double*)w->slot(r), o.count, o.op);
+        else if (o.type == ncclUint64) reduce_into((unsigned long long*)acc.data(), (const unsigned long long*)w->slot(r), o.count, o.op);
+        else if (o.type == ncclInt32) reduce_into((int*)acc.data(), (const int*)w->slot(r), o.count, o.op);
+        else if (o.type == ncclUint32) reduce_into((unsigned*)acc.data(), (const unsigned*)w->slot(r), o.count, o.op);
+        else rc = ncclInvalidArgument;
+      }
+      if (rc == ncclSuccess && hipMemcpy(o.recv, acc.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
+    } else {
+      for (int r = 0; r < h->n && rc == ncclSuccess; ++r) {
+        void* dst = (unsigned char*)o.recv + (size_t)r * bytes;
+        if (r == c->rank && dst == o.send) continue;   // (in place: my own block is where it belongs)
+        if (hipMemcpy(dst, w->slot(r), bytes, hipMemcpyHostToDevice) != hipSuccess) rc = ncclUnhandledCudaError;
+      }
+    }
+  }
+  shm_lock(h);
+  bool ok = shm_barrier(h);   // nobody overwrites its slot before everybody has read it
+  if (ok && c->rank == 0) h->mismatch = 0;
+  ok = ok && shm_barrier(h);
+  shm_unlock(h);
+  if (!ok) return ncclSystemError;
+  if (bad) {
+    fprintf(stderr, "[fake_nccl] rank %d: collective called with different count / type / op on different ranks\n", c->rank);
+    return ncclInvalidArgument;
+  }
+  return rc;
+}
+
+// the point-to-point operations of one group (all on one communicator: what the product posts): every send is staged and
+// posted before any receive waits
+ncclResult_t shm_p2p(std::vector<std::pair<ncclComm_t, Op>>& ops, size_t first, size_t last) {
+  ncclResult_t rc = ncclSuccess;
+  size_t cursor = 0;
+  struct Mine { ShmWorld* w; int rank, peer; unsigned long long seq; size_t count; };
+  std::vector<Mine> mine;
+  for (size_t k = first; k < last; ++k) {
+    const Op& o = ops[k].second;
+    if (o.kind != 3) continue;
+    ncclComm_t c = ops[k].first;
+    ShmWorld* w = c->sw;
+    ShmHdr* h = w->h;
+    const size_t bytes = o.count * type_bytes(o.type);
+    if (o.peer < 0 || o.peer >= h->n || type_bytes(o.type) == 0) return ncclInvalidArgument;
+    if (cursor + bytes > h->slot_bytes) {
+      fprintf(stderr, "[fake_nccl] rank %d: the sends of one group exceed the staging slot (FAKE_NCCL_SLOT_MB)\n", c->rank);
+      return ncclInvalidArgument;
+    }
+    if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
+    if (bytes && hipMemcpy(w->slot(c->rank) + cursor, o.send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    shm_lock(h);
+    ShmMail& q = h->mail[c->rank][o.peer];
+    if (q.tail - q.head >= (unsigned long long)SHM_MAIL_DEPTH) {
+      shm_unlock(h);
+      fprintf(stderr, "[fake_nccl] rank %d: more than %d sends to rank %d in flight\n", c->rank, SHM_MAIL_DEPTH, o.peer);
+      return ncclInvalidArgument;
+    }
+    q.d[q.tail % SHM_MAIL_DEPTH] = ShmPost{cursor, o.count, (int)o.type};
+    mine.push_back(Mine{w, c->rank, o.peer, q.tail, o.count});
+    ++q.tail;
+    pthread_cond_broadcast(&h->cv);
+    shm_unlock(h);
+    cursor += (bytes + 255) & ~(size_t)255;
+  }
+  for (size_t k = first; k < last && rc == ncclSuccess; ++k) {
+    const Op& o = ops[k].second;
+    if (o.kind != 4) continue;
+    ncclComm_t c = ops[k].first;
+    ShmWorld* w = c->sw;
+    ShmHdr* h = w->h;
+    if (o.peer < 0 || o.peer >= h->n || type_bytes(o.type) == 0) return ncclInvalidArgument;
+    if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
+    shm_lock(h);
+    ShmMail& q = h->mail[o.peer][c->rank];
+    if (!shm_wait(h, [&] { return q.tail > q.head; })) {
+      shm_unlock(h);
+      fprintf(stderr, "[fake_nccl] rank %d: ncclRecv from %d of %zu elements never met a send\n", c->rank, o.peer, o.count);
+      return ncclSystemError;
+    }
+    const ShmPost p = q.d[q.head % SHM_MAIL_DEPTH];
+    shm_unlock(h);
+    if (p.count != o.count || p.type != (int)o.type) {
+      fprintf(stderr, "[fake_nccl] rank %d: ncclRecv from %d expects %zu elements, the send has %zu\n", c->rank, o.peer, o.count, p.count);
+      rc = ncclInvalidArgument;
+    } else if (o.count) {
+      if (hipMemcpy(o.recv, w->slot(o.peer) + p.offset, o.count * type_bytes(o.type), hipMemcpyHostToDevice) != hipSuccess)
+        rc = ncclUnhandledCudaError;
+    }
+    shm_lock(h);
+    ++q.head;   // (consumed -- also a mismatched one: its sender must not wait for ever)
+    pthread_cond_broadcast(&h->cv);
+    shm_unlock(h);
+  }
+  // my sends are complete when their receivers have copied
+  for (const Mine& s : mine) {
+    ShmHdr* h = s.w->h;
+    shm_lock(h);
+    ShmMail& q = h->mail[s.rank][s.peer];
+    const bool ok = shm_wait(h, [&] { return q.head > s.seq; });
+    shm_unlock(h);
+    if (!ok) {
+      fprintf(stderr, "[fake_nccl] ncclSend to %d of %zu elements never met a receive\n", s.peer, s.count);
+      if (rc == ncclSuccess) rc = ncclSystemError;
+    }
+  }
+  return rc;
+}
+
+}  // namespace
 
 namespace {
 
@@ -240,13 +596,14 @@ ncclResult_t run_ops(std::vector<std::pair<ncclComm_t, Op>>& ops) {
   ncclResult_t rc = ncclSuccess;
   size_t k = 0;
   while (k < ops.size() && rc == ncclSuccess) {
+    const bool shm = ops[k].first->sw != nullptr;
     if (ops[k].second.kind <= 2) {
-      rc = run_collective(ops[k].first, ops[k].second);
+      rc = shm ? shm_collective(ops[k].first, ops[k].second) : run_collective(ops[k].first, ops[k].second);
       ++k;
     } else {
       size_t e = k;
-      while (e < ops.size() && ops[e].second.kind >= 3) ++e;
-      rc = run_p2p(ops, k, e);
+      while (e < ops.size() && ops[e].second.kind >= 3 && (ops[e].first->sw != nullptr) == shm) ++e;
+      rc = shm ? shm_p2p(ops, k, e) : run_p2p(ops, k, e);
       k = e;
     }
   }
@@ -255,8 +612,8 @@ ncclResult_t run_ops(std::vector<std::pair<ncclComm_t, Op>>& ops) {
 }
 
 ncclResult_t submit(ncclComm_t c, const Op& o) {
-  if (!c || !c->w) return ncclInvalidArgument;
-  if (c->w->aborted) return ncclSystemError;
+  if (!c || (!c->w && !c->sw)) return ncclInvalidArgument;
+  if (c->sw ? c->sw->h->aborted != 0 : c->w->aborted) return ncclSystemError;
   t_ops.push_back({c, o});
   if (t_depth > 0) return ncclSuccess;
   return run_ops(t_ops);
@@ -270,13 +627,30 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
   if (!id) return ncclInvalidArgument;
   memset(id, 0, sizeof *id);
   std::lock_guard<std::mutex> lk(g_reg_m);
-  snprintf(id->internal, sizeof id->internal, "fake-nccl-%llu", g_next_id++);
+  const char* shm = getenv("FAKE_NCCL_SHM");
+  if (shm && shm[0] == '1')   // ranks as processes: the id names the shared-memory segment they will meet in
+    snprintf(id->internal, sizeof id->internal, "/fake-nccl-shm-%d-%llu", (int)getpid(), g_next_id++);
+  else
+    snprintf(id->internal, sizeof id->internal, "fake-nccl-%llu", g_next_id++);
   return ncclSuccess;
 }
 
 ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
   if (!comm || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
   const std::string key(id.internal, strnlen(id.internal, sizeof id.internal));
+  if (key.compare(0, 15, "/fake-nccl-shm-") == 0) {
+    if (nranks > SHM_MAX_RANKS) return ncclInvalidArgument;
+    // rank 0 makes the segment, the others wait for it
+    ShmWorld* sw = rank == 0 ? shm_create(key, nranks) : shm_attach(key, nranks);
+    if (!sw) {
+      fprintf(stderr, "[fake_nccl] rank %d: no shared-memory segment %s (%s)\n", rank, key.c_str(), strerror(errno));
+      return ncclSystemError;
+    }
+    const ncclResult_t rc = shm_join(sw, rank);
+    if (rc != ncclSuccess) return rc;
+    *comm = new ncclComm{nullptr, rank, sw};
+    return ncclSuccess;
+  }
   World* w;
   {
     std::lock_guard<std::mutex> lk(g_reg_m);
@@ -294,7 +668,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   std::unique_lock<std::mutex> lk(w->m);
   if (!barrier(w, lk)) return ncclSystemError;   // (RCCL's init is a rendezvous of all ranks too)
   lk.unlock();
-  *comm = new ncclComm{w, rank};
+  *comm = new ncclComm{w, rank, nullptr};
   return ncclSuccess;
 }
 
@@ -302,6 +676,23 @@ ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newc
   if (!comm || !newcomm) return ncclInvalidArgument;
   (void)key;
   if (color != 0) return ncclInvalidArgument;   // (the product splits into ONE colour, ranks kept)
+  if (comm->sw) {
+    // the child: a segment of its own, named after the parent and the number of splits so far; rank 0 makes it
+    ShmHdr* h = comm->sw->h;
+    shm_lock(h);
+    const int k = h->splits;
+    bool ok = shm_barrier(h);
+    if (ok && comm->rank == 0) ++h->splits;
+    shm_unlock(h);
+    if (!ok) return ncclSystemError;
+    const std::string name = comm->sw->name + "-s" + std::to_string(k);
+    ShmWorld* sw = comm->rank == 0 ? shm_create(name, h->n) : shm_attach(name, h->n);
+    if (!sw) return ncclSystemError;
+    const ncclResult_t rc = shm_join(sw, comm->rank);
+    if (rc != ncclSuccess) return rc;
+    *newcomm = new ncclComm{nullptr, comm->rank, sw};
+    return ncclSuccess;
+  }
   World* w = comm->w;
   std::unique_lock<std::mutex> lk(w->m);
   if (comm->rank == 0) {
@@ -314,12 +705,27 @@ ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newc
   if (!barrier(w, lk)) return ncclSystemError;
   World* c = w->split_child;
   if (!barrier(w, lk)) return ncclSystemError;
-  *newcomm = new ncclComm{c, comm->rank};
+  *newcomm = new ncclComm{c, comm->rank, nullptr};
   return ncclSuccess;
 }
 
 static ncclResult_t leave(ncclComm_t comm, bool abort) {
   if (!comm) return ncclSuccess;
+  if (comm->sw) {
+    ShmHdr* h = comm->sw->h;
+    shm_lock(h);
+    if (abort) {
+      h->aborted = 1;
+      pthread_cond_broadcast(&h->cv);
+    }
+    ++h->left;
+    h->pid[comm->rank] = 0;   // (gone on purpose: not a dead rank)
+    shm_unlock(h);
+    munmap((void*)h, comm->sw->map_bytes);
+    delete comm->sw;
+    delete comm;
+    return ncclSuccess;
+  }
   World* w = comm->w;
   bool last;
   {

@@ -1,7 +1,8 @@
 """world_size-2 (and 3) CPU tests (gloo): the particle-sharded resample algorithm gives bit-identical particles to
 the unsharded filter, in both exchange patterns libmcl_hip.so runs over RCCL:
-  * all-gather: local weights, all-reduce(max), shard totals all-gather, offspring-CDF all-gather, state all-gather,
-    per-slot reassign (MCL_EXCHANGE=allgather);
+  * all-gather: local weights at the shard's own exponent, ONE all-gather of the shards' records (exponent + bit counts:
+    maximum and totals in one latency, exact), offspring-CDF all-gather, state all-gather, per-slot reassign
+    (MCL_EXCHANGE=allgather);
   * O(n) per rank (default): every shard expands its OWN CDF slice, the shards all-gather {lost slots, surplus
     copies}, and rank q sends rank r exactly the surplus copies whose positions in the global dupes order fall into
     r's lost ranks (point-to-point).
@@ -19,6 +20,33 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def _bit_counts(q):
+    """how many of the weights have bit b set, b = 0 .. 63 (mcl_resample.h: k_quantise_tiles' shard record)"""
+    q = np.asarray(q, dtype=np.uint64)
+    return [int(np.count_nonzero((q >> np.uint64(b)) & np.uint64(1))) for b in range(64)]
+
+
+def _one_collective_normalisation(dist, torch, orc, lw, rank, world, n):
+    """The sharded normalisation as libmcl_hip.so runs it since round 6 (mcl_host_resample.h: phase_quantise_shard,
+    exchange_shard_records, phase_shift_scan): every shard quantises at the exponent of its OWN maximum, ONE all-gather
+    of {exponent, 64 bit counts} per shard, and from it -- exactly -- the cloud's exponent, every shard's shift and
+    every shard's total at that shift (sum_{b >= d} count_b 2^(b - d)).  Rounds 1-5: an all-reduce of the maximum and,
+    dependent on it, an all-gather of the totals.  Returns (q at the cloud's exponent, totals of all shards)."""
+    q_own, K_r = orc.fixed_weights_own_exponent(lw, n)
+    rec = torch.tensor([K_r] + _bit_counts(q_own), dtype=torch.int64)
+    recs = [torch.zeros(65, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(recs, rec)                      # THE collective
+    K = max(int(r[0]) for r in recs)
+    totals = []
+    for r in recs:
+        d = min(K - int(r[0]), 64)
+        totals.append(sum(int(r[1 + b]) << (b - d) for b in range(d, 64)))
+    d = min(K - K_r, 64)
+    q = np.zeros_like(q_own) if d >= 64 else (q_own >> np.uint64(d))
+    assert int(q.sum(dtype=np.uint64)) == totals[rank]   # the bit counts give the shifted total exactly
+    return q, totals
 
 
 def _unsharded(lw, soa, u53, mode):
@@ -45,14 +73,8 @@ def _worker(rank, world, port, n, seed, ret):
         nl = n // world
         sl = slice(rank * nl, (rank + 1) * nl)
         lw, soa = lw_all[sl].copy(), np.ascontiguousarray(soa_all[:, sl])
-        # C1: all-reduce(max) of the local max log-weight
-        m = torch.tensor([float(np.max(lw))], dtype=torch.float64)  # exact, order-free
-        dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        q, tot = orc.fixed_weights_shard(lw, 1, n, float(m[0]))
-        # all-gather of the shard totals (u64 carried as int64 bit patterns)
-        tl = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(tl, torch.tensor([np.uint64(tot).astype(np.int64)], dtype=torch.int64))
-        totals = [int(np.int64(t[0]).astype(np.uint64)) for t in tl]
+        # C1: ONE all-gather of the shards' records {exponent of the local maximum, bit counts of the local weights}
+        q, totals = _one_collective_normalisation(dist, torch, orc, lw, rank, world, n)
         T, off = sum(totals), sum(totals[:rank])
         ncum_loc = orc.systematic_ncum(q, u53, off, T, n)
         # C2: all-gather of the offspring CDF and of the pre-resample state
@@ -94,12 +116,7 @@ def _worker_p2p(rank, world, port, n, seed, spread, ret):
         nl = n // world
         sl = slice(rank * nl, (rank + 1) * nl)
         lw, soa = lw_all[sl].copy(), np.ascontiguousarray(soa_all[:, sl])
-        m = torch.tensor([float(np.max(lw))], dtype=torch.float64)
-        dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        q, tot = orc.fixed_weights_shard(lw, 1, n, float(m[0]))
-        tl = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(tl, torch.tensor([np.uint64(tot).astype(np.int64)], dtype=torch.int64))
-        totals = [int(np.int64(t[0]).astype(np.uint64)) for t in tl]
+        q, totals = _one_collective_normalisation(dist, torch, orc, lw, rank, world, n)
         T, off = sum(totals), sum(totals[:rank])
         # ---- local expansion: the shard's own CDF slice, the CDF value just before the shard
         ncum_loc = orc.systematic_ncum(q, u53, off, T, n).astype(np.int64)
