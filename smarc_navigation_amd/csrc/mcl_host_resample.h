@@ -94,7 +94,7 @@ int phase_quantise(mcl_handle* h, bool from_slots, bool fused_next = false) {
 
 // ---- one shard per process: "maximum, then totals" in ONE collective.  The shard quantises at the
 // exponent of its OWN maximum and leaves, beside the weights, how many of them have each bit set; the all-gather of
-// those records (65 words per rank) tells every rank the cloud's exponent, every shard's shift and -- exactly -- every
+// those records (exponent + 8 x 64 partial bit counts: 4 KiB per rank) tells every rank the cloud's exponent, every shard's shift and -- exactly -- every
 // shard's total at that shift; k_shift_scan turns them into the totals / tile offsets / shift the CDF kernels read.
 // Weight modes other than log-likelihoods (GPS: linear weights relative to the maximum's) keep the two-step form.
 bool one_collective(const mcl_handle* h) { return h->comm && h->weight_mode == MCL_WEIGHT_LOG_SHIFT; }
@@ -127,7 +127,7 @@ int phase_quantise_shard(mcl_handle* h) {
   a.rec = mine;
   a.tile_bits = h->tile_bits;
   h->shrec_dirty = true;
-  k_quantise_tiles<<<(unsigned)h->ntiles_loc, MCL_BLOCK, 0, h->stream>>>(a);
+  k_quantise_shard<<<(unsigned)h->ntiles_loc, MCL_SCAN_TILE, 0, h->stream>>>(a);
   t_end(h);
   HIPCHK(h, hipGetLastError());
   return MCL_OK;

@@ -66,11 +66,11 @@ struct QuantArgs {
   u64* rec;
   unsigned short* tile_bits;
 };
-#define SHREC_WORDS 65                       // a shard's record: exponent, 64 bit counts
+#define SHREC_COPIES 8                       // the bit counts are accumulated in 8 copies (workgroup & 7): 512 workgroups' atomics on 64 words of four cache lines cost 10 us, on 512 words one
+#define SHREC_WORDS (1 + 64 * SHREC_COPIES)  // a shard's record: exponent, 8 x 64 bit counts (to be added up)
 #define SHREC_BIAS (1ll << 41)
 __global__ void __launch_bounds__(MCL_BLOCK) k_quantise_tiles(QuantArgs a) {
   __shared__ u64 sh[16];
-  __shared__ u32 bc[64];
   const long long tile = blockIdx.x;  // the grid is exactly the number of tiles
   const long long base = tile * MCL_SCAN_TILE;
   // (the log-weights first: their loads are in flight while the maximum is read from the 64 slots -- two memory
@@ -81,49 +81,61 @@ __global__ void __launch_bounds__(MCL_BLOCK) k_quantise_tiles(QuantArgs a) {
     const long long i = base + (long long)k * MCL_BLOCK + threadIdx.x;
     lwv[k] = i < a.n ? a.lw[i] : 0.0;
   }
-  if (a.rec && threadIdx.x < 64) bc[threadIdx.x] = 0u;
   const double m = a.slots ? max_from_slots(a.slots) : a.m_lw[0];
   u64 acc = 0;
-  u64 qv[MCL_SCAN_ITEMS];
 #pragma unroll
   for (int k = 0; k < MCL_SCAN_ITEMS; ++k) {
     const long long i = base + (long long)k * MCL_BLOCK + threadIdx.x;
-    qv[k] = 0ull;
     if (i < a.n) {
       const u64 qi = quantise_weight(lwv[k], m, a.mode, a.scale, a.s);
       a.q[i] = qi;
       acc += qi;
-      qv[k] = qi;
     }
-  }
-  if (a.rec) {
-    // bit counts: one ballot per (bit, item), lane b keeps bit b's count of the wave; only up to the wave's highest bit
-    const int lane = threadIdx.x & 63;
-    u64 any = 0ull;
-#pragma unroll
-    for (int k = 0; k < MCL_SCAN_ITEMS; ++k) any |= qv[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o, MCL_WAVE);
-    const int top = any ? 63 - __builtin_clzll(any) : -1;   // (wave-uniform)
-    u32 mine = 0u;
-    for (int b = 0; b <= top; ++b) {
-      u32 c = 0u;
-#pragma unroll
-      for (int k = 0; k < MCL_SCAN_ITEMS; ++k) c += (u32)__popcll(__ballot((qv[k] >> b) & 1ull));
-      mine = lane == b ? c : mine;
-    }
-    __syncthreads();   // (bc zeroed)
-    if (mine) atomicAdd(&bc[lane], mine);
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      const u32 c = bc[threadIdx.x];
-      a.tile_bits[tile * 64 + threadIdx.x] = (unsigned short)c;   // (<= 1 024 weights per tile)
-      if (c) atomicAdd((unsigned long long*)&a.rec[1 + threadIdx.x], (unsigned long long)c);
-    }
-    if (tile == 0 && threadIdx.x == 0) a.rec[0] = (u64)(weight_exponent(m) + SHREC_BIAS);
   }
   acc = block_sum(acc, sh);
   if (threadIdx.x == 0) a.tile_sum[tile] = acc;
+}
+
+// The same for ONE SHARD of a cloud spread over several processes (QuantArgs::rec): weights at the shard's own exponent
+// and the bit counts.  One weight per thread, 16 waves per tile: the counting is 63 ballots per wave (walk the word from
+// its top bit down: a shift and a sign test per bit), lane b keeps bit b's count -- a few hundred instructions per wave,
+// which need the chip's waves side by side, not four tiles' worth in a row per wave (the first version, inside
+// k_quantise_tiles with four weights per thread: + 13 us at 524 288 particles, latency of two waves per SIMD).
+__global__ void __launch_bounds__(MCL_SCAN_TILE) k_quantise_shard(QuantArgs a) {
+  __shared__ u32 bc[64];
+  const long long tile = blockIdx.x;
+  const long long i = tile * MCL_SCAN_TILE + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const double lw = i < a.n ? a.lw[i] : 0.0;
+  if (threadIdx.x < 64) bc[threadIdx.x] = 0u;
+  const double m = max_from_slots(a.slots);
+  u64 q = 0ull;
+  if (i < a.n) {
+    q = quantise_weight(lw, m, a.mode, a.scale, a.s);
+    a.q[i] = q;
+  }
+  u64 any = q;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o, MCL_WAVE);
+  const int top = any ? 63 - __builtin_clzll(any) : -1;   // (wave-uniform)
+  u32 mine = 0u;
+  if (top >= 0) {
+    long long x = (long long)(q << (63 - top));   // bit `top` in the sign position
+    for (int b = top; b >= 0; --b) {
+      const u32 c = (u32)__popcll(__ballot(x < 0));
+      mine = lane == b ? c : mine;
+      x <<= 1;
+    }
+  }
+  __syncthreads();   // (bc zeroed)
+  if (mine) atomicAdd(&bc[lane], mine);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const u32 c = bc[threadIdx.x];
+    a.tile_bits[tile * 64 + threadIdx.x] = (unsigned short)c;   // (<= 1 024 weights per tile)
+    if (c) atomicAdd((unsigned long long*)&a.rec[1 + 64 * (tile & (SHREC_COPIES - 1)) + threadIdx.x], (unsigned long long)c);
+  }
+  if (tile == 0 && threadIdx.x == 0) a.rec[0] = (u64)(weight_exponent(m) + SHREC_BIAS);
 }
 
 // After the all-gather of the shards' records (ONE collective where rounds 1-5 had an all-reduce of the maximum and,
@@ -140,53 +152,72 @@ struct ShiftArgs {
   u64* totals;         // out: world totals at the cloud's exponent
   u64* shift_out;      // out: this shard's shift (0 .. 64)
 };
-__device__ __forceinline__ u64 sum_at_shift(const u64* cnt /*64*/, u32 d) {
-  u64 t = 0ull;
-  for (u32 b = d; b < 64u; ++b) t += cnt[b] << (b - d);
-  return t;
-}
 __global__ void __launch_bounds__(1024) k_shift_scan(ShiftArgs a) {
   __shared__ u64 sh[16];
   __shared__ u64 carry_sh;
   __shared__ u32 d_sh;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   u64 K = 0ull;
   for (int r = 0; r < a.world; ++r) {
     const u64 k = a.recs[(size_t)r * SHREC_WORDS];
     K = k > K ? k : K;
   }
-  for (int r = threadIdx.x; r < a.world; r += blockDim.x) {
+  // a wave per shard: lane b holds count_b 2^(b - d), the shard's total at its shift is their sum
+  for (int r = w; r < a.world; r += 16) {
     const u64 dd = K - a.recs[(size_t)r * SHREC_WORDS];
     const u32 d = dd > 64ull ? 64u : (u32)dd;
-    a.totals[r] = sum_at_shift(a.recs + (size_t)r * SHREC_WORDS + 1, d);
-    if (r == a.rank) {
-      d_sh = d;
-      a.shift_out[0] = (u64)d;
+    u64 c = 0ull;
+#pragma unroll
+    for (int k = 0; k < SHREC_COPIES; ++k) c += a.recs[(size_t)r * SHREC_WORDS + 1 + 64 * k + lane];
+    const u64 t = wave_sum((u32)lane >= d ? c << ((u32)lane - d) : 0ull);
+    if (lane == 0) {
+      a.totals[r] = t;
+      if (r == a.rank) {
+        d_sh = d;
+        a.shift_out[0] = (u64)d;
+      }
     }
   }
   if (threadIdx.x == 0) carry_sh = 0ull;
   __syncthreads();
   const u32 d = d_sh;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (long long base = 0; base < a.ntiles; base += blockDim.x) {
-    const long long i = base + threadIdx.x;
+  // two threads per tile, 32 bit counts each (four 16-byte loads in flight at once), 512 tiles per round
+  const int half = threadIdx.x & 1;
+  for (long long base = 0; base < a.ntiles; base += blockDim.x / 2) {
+    const long long i = base + (threadIdx.x >> 1);
     u64 v = 0ull;
     if (i < a.ntiles) {
-      const unsigned short* tb = a.tile_bits + i * 64;
-      for (u32 b = d; b < 64u; ++b) v += (u64)tb[b] << (b - d);
+      const uint4* tb = (const uint4*)(a.tile_bits + i * 64 + half * 32);
+      uint4 x[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = tb[j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 wds[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u32 b0 = (u32)(half * 32 + j * 8 + k * 2);
+          const u64 c0 = wds[k] & 0xffffu, c1 = wds[k] >> 16;
+          v += b0 >= d ? c0 << (b0 - d) : 0ull;
+          v += b0 + 1u >= d ? c1 << (b0 + 1u - d) : 0ull;
+        }
+      }
     }
-    const u64 incl = wave_scan_incl(v);
+    v += __shfl_xor(v, 1, MCL_WAVE);   // the tile's sum in both of its threads
+    const u64 mine = half ? 0ull : v;  // ... counted once
+    const u64 incl = wave_scan_incl(mine);
     if (lane == 63) sh[w] = incl;
     __syncthreads();
     u64 woff = 0ull;
     for (int k = 0; k < w; ++k) woff += sh[k];
     const u64 carry = carry_sh;
-    if (i < a.ntiles) a.tile_off[i] = carry + woff + incl - v;  // exclusive
+    if (i < a.ntiles && !half) a.tile_off[i] = carry + woff + incl - v;  // exclusive
     __syncthreads();
     if (threadIdx.x == blockDim.x - 1) carry_sh = carry + woff + incl;
     __syncthreads();
   }
   // (every read of this shard's own record is behind the barriers above)
-  if (threadIdx.x < 64) a.recs[(size_t)a.rank * SHREC_WORDS + 1 + threadIdx.x] = 0ull;
+  if (threadIdx.x < 64 * SHREC_COPIES) a.recs[(size_t)a.rank * SHREC_WORDS + 1 + threadIdx.x] = 0ull;
 }
 
 // ------------------------------------------------------------------ decoupled look-back (u32 sums)

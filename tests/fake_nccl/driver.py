@@ -73,6 +73,11 @@ def main():
     out = [None] * W
     err = [None] * W
 
+    def counters():
+        out = (ctypes.c_ulonglong * 3)()
+        ctypes.CDLL(None).fake_nccl_counters(out)
+        return list(out)
+
     def rank_main(r):
         try:
             e = eng.Engine(NS, rank=r, world=W, n_global=N, global_offset=r * NS, seed=5, **COV)
@@ -109,7 +114,17 @@ def main():
                     e.sync()
                     e.comm_shutdown()
                     e.comm_init(uid[1])
+                c0 = counters() if r == 0 else None
                 step(e, k)
+                if r == 0:
+                    # the exchange's budget: a fused step asks rank 0 for at most THREE collectives -- the
+                    # shards' records (maximum and totals in one), the hand-over records, the moments -- and one group of
+                    # point-to-point operations; the all-gather scheme: records, CDF (+ state when it did not travel under
+                    # the update), moments
+                    e.sync()
+                    c1 = counters()
+                    res.setdefault('collectives_per_step', []).append(c1[0] - c0[0])
+                    res.setdefault('p2p_groups_per_step', []).append(c1[1] - c0[1])
                 res['steps'].append(dict(lw=e.get_log_weights(), idx=e.last_indices(), st=e.get_particles(),
                                          mc=e.last_mean_cov()))
             res['ops'] = e.exchange_ops()
@@ -159,8 +174,11 @@ def main():
         for o, rounds in ops:
             assert rounds == steps and o <= 2 * (W - 1) * rounds, ops
         assert 0 < sent < lost, (sent, lost)
+    cps, gps = out[0]['collectives_per_step'], out[0]['p2p_groups_per_step']
+    if exchange == 'p2p':
+        assert max(cps) <= 3 and max(gps) <= 1, (cps, gps)   # records, hand-over records, moments + one p2p group
     print(json.dumps(dict(ok=True, world=W, per_rank=NS, exchange=exchange, landmarks=with_lm, p2p_ops=[o for o, _ in ops],
-                          states_sent=sent, lost_slots=lost)))
+                          states_sent=sent, lost_slots=lost, collectives_per_step=cps, p2p_groups_per_step=gps)))
     return 0
 
 

@@ -88,6 +88,9 @@ struct World {
   World* split_child = nullptr;                      // ncclCommSplit: the communicator being made
 };
 
+// what rank 0 of this process has been asked for so far (fake_nccl_counters): collectives, groups of point-to-point
+// operations, point-to-point operations -- the per-step budget of the product's exchange is asserted on these
+std::atomic<unsigned long long> g_n_coll{0}, g_n_groups{0}, g_n_p2p{0};
 std::atomic<int> g_timeout_s{0};   // fake_nccl_set_timeout(); 0 = FAKE_NCCL_TIMEOUT_S or 120
 int timeout_s() {
   static const int env = getenv("FAKE_NCCL_TIMEOUT_S") ? atoi(getenv("FAKE_NCCL_TIMEOUT_S")) : 120;
@@ -339,6 +342,7 @@ ncclResult_t shm_join(ShmWorld* w, int rank) {
 bool same_shape(const ShmOp& a, const Op& b) { return a.kind == b.kind && a.count == b.count && a.type == (int)b.type && a.op == (int)b.op; }
 
 ncclResult_t shm_collective(ncclComm_t c, const Op& o) {
+  if (c->rank == 0) ++g_n_coll;
   ShmWorld* w = c->sw;
   ShmHdr* h = w->h;
   const size_t bytes = o.count * type_bytes(o.type);
@@ -392,6 +396,10 @@ ncclResult_t shm_collective(ncclComm_t c, const Op& o) {
 // the point-to-point operations of one group (all on one communicator: what the product posts): every send is staged and
 // posted before any receive waits
 ncclResult_t shm_p2p(std::vector<std::pair<ncclComm_t, Op>>& ops, size_t first, size_t last) {
+  if (ops[first].first->rank == 0) {
+    ++g_n_groups;
+    g_n_p2p += last - first;
+  }
   ncclResult_t rc = ncclSuccess;
   size_t cursor = 0;
   struct Mine { ShmWorld* w; int rank, peer; unsigned long long seq; size_t count; };
@@ -475,6 +483,7 @@ namespace {
 bool same_shape(const Op& a, const Op& b) { return a.kind == b.kind && a.count == b.count && a.type == b.type && a.op == b.op; }
 
 ncclResult_t run_collective(ncclComm_t c, const Op& o) {
+  if (c->rank == 0) ++g_n_coll;
   World* w = c->w;
   const size_t bytes = o.count * type_bytes(o.type);
   if (type_bytes(o.type) == 0) return ncclInvalidArgument;
@@ -531,6 +540,10 @@ ncclResult_t run_collective(ncclComm_t c, const Op& o) {
 // the point-to-point operations of one group: every send is posted before any receive waits, so two ranks that send
 // to each other and then receive from each other do not deadlock (nccl.h: grouped send / recv progress together)
 ncclResult_t run_p2p(std::vector<std::pair<ncclComm_t, Op>>& ops, size_t first, size_t last) {
+  if (ops[first].first->rank == 0) {
+    ++g_n_groups;
+    g_n_p2p += last - first;
+  }
   std::vector<Post*> mine;
   ncclResult_t rc = ncclSuccess;
   for (size_t k = first; k < last; ++k) {
@@ -787,6 +800,12 @@ ncclResult_t ncclRecv(void* recv, size_t count, ncclDataType_t type, int peer, n
 
 // marker the test driver checks: the preload really is in front of librccl
 int fake_nccl_present(void) { return 1; }
+// {collectives, point-to-point groups, point-to-point operations} rank 0 of this process has issued so far
+void fake_nccl_counters(unsigned long long out[3]) {
+  out[0] = g_n_coll.load();
+  out[1] = g_n_groups.load();
+  out[2] = g_n_p2p.load();
+}
 // waits that begin after this call give up after `seconds` (0 = back to FAKE_NCCL_TIMEOUT_S)
 void fake_nccl_set_timeout(int seconds) { g_timeout_s.store(seconds); }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One extra leg of bench.py alone (profiling runs): tools/experiments/leg.py config5 [steps]"""
+"""One extra leg of bench.py alone (profiling runs): tools/experiments/leg.py config5|config4|config4_rccl [steps]"""
 import json
 import os
 import sys
@@ -13,5 +13,7 @@ mesh = bench.build_map('mesh')
 kw = dict(P=524288, B=512, steps=steps, warmup=5)
 if name == 'config5':
     kw['landmarks'] = (synth.landmark_map(4096, (-64.0, -354.0, 643.0, 353.0)), 16)
+if name == 'config4_rccl':   # the sharded pipeline over a 1-rank RCCL communicator (bench.py: config4_shard_rccl_1rank)
+    kw['rccl_1rank'] = True
 out = bench.run_leg(engine, name, mesh, kw.pop('P'), kw.pop('B'), kw.pop('steps'), kw.pop('warmup'), **kw)
 print(json.dumps({k: out[k] for k in ('ms_per_step', 'kernels')}))
