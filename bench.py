@@ -273,6 +273,75 @@ def cpu_baseline(m, stream, ranges, beam_angles, cov, n_full, n_sample, threads,
                        'scaled linearly to %d particles' % (n, beam_angles.size, steps, threads, per_step, n_full))
 
 
+# BASELINE.md section 2 (Row A of SURVEY 8(d)(ii)): the reference's own Python, measured in the BUILD container through the
+# oracle harness (oracle/ref_harness: the reference's modules imported behind stubs).  It never travels to the GPU box in
+# any form, so these are constants with their hardware label, not measurements of this run.
+REFERENCE_PYTHON = {
+    'hardware': 'build container: 8 vCPU x86-64, Python 3.10.12, numpy 2.2.6, scipy 1.15.3, single thread (the reference has no parallelism)',
+    'measured_by': 'oracle/ref_harness (the reference modules imported unmodified); BASELINE.md section 2',
+    'motion_pred_us_per_particle': 45.0, 'motion_pred_ref': 'auv_particle_filter/scripts/auv_particle.py:38-70',
+    'compute_weight_us_per_particle': 146.0, 'compute_weight_ref': 'auv_particle_filter/scripts/auv_particle.py:100-106',
+    'predict_only_n128_ms_per_step': 7.0,
+    'gps_update_residual_resample_reassign_noise_n128_ms': 25.0,
+    'systematic_resample_n65536_ms': 37.0, 'residual_resample_n65536_ms': 25.0, 'resample_ref': 'auv_particle_filter/scripts/resampling.py:135-168 / :27-76',
+    'systematic_resample_n1048576_s': 1.09, 'residual_resample_n1048576_s': 0.97,
+    'full_step_n1048576': 'EXTRAPOLATED, not runnable: ~45 s predict + ~146 s GPS update + the O(N^2) keep / lost / dupes lists '
+                          '(auv_pf.py:183-187); the reference has no MBES update at all',
+}
+
+
+def cpu_leg_baseline(engine_mod, m, P, B, device, landmarks=None, budget_s=4.0):
+    """the oracle (C restatement) on this box's host cores for an extra leg's configuration -- one thread
+    and all granted threads, each on a bounded sample (<= budget_s of CPU work per measurement, at least one step),
+    scaled linearly to the leg's particle count.  Steps/s of the LEG'S OWN configuration (not 1 M-normalised)."""
+    import numpy as np
+    from oracle import oracle as orc
+    from smarc_navigation_amd import synth
+    steps = 3
+    stream = synth.odom_stream(steps)
+    ba = synth.beam_angles(B)
+    ranges = make_ranges(engine_mod, m, stream['truth'], ba, SIGMA, R_MAX, device=device)
+    amap = orc.Grid(m['z'], m['origin'], m['res']) if m['kind'] == 'grid' else orc.Mesh(m['verts'], m['tris'])
+    dets = None
+    if landmarks is not None:
+        lm_xyz, n_det = landmarks
+        rs = np.random.RandomState(8)
+        dets = []
+        for k in range(steps):
+            t = stream['truth'][k]
+            T = synth.rigid_matrix(*t)
+            near = lm_xyz[np.argsort(np.sum((lm_xyz[:, :2] - t[:2]) ** 2, axis=1))[:n_det]]
+            dets.append((near - T[:3, 3]).dot(T[:3, :3]) + 0.05 * rs.randn(n_det, 3))
+    out = {'unit': 'steps/s', 'kind': 'port', 'of': '%d particles x %d beams' % (P, B)}
+    cores = host_cores()
+    for label, threads, n in (('1thread', 1, min(P, 2048)), ('all', cores, min(P, max(2048 * min(cores, 32), 65536)))):
+        threads = orc.set_threads(threads)
+        soa = np.zeros((6, n))
+        orc.add_noise(soa, COV['init_cov'], orc.native_normals(n, 0, 5, 0, 0))
+        t0 = time.perf_counter()
+        done = 0
+        for k in range(steps):
+            orc.predict(soa, stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'],
+                        COV['process_cov'], orc.native_normals(n, 0, 5, 1, k))
+            lw, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, amap, ba, ranges[k], SIGMA, R_MAX, want_expected=False)
+            if dets is not None:
+                lw = lw + orc.landmark_update(soa, np.identity(4), [0] * 6, landmarks[0], dets[k], 0.3, k=4, gate=11.345)
+            idx, _, _ = orc.systematic_fixed(lw, 1, orc.native_u53(5, k))
+            lost, dupes = orc.lost_dupes(idx)
+            orc.reassign(soa, lost, dupes)
+            orc.add_noise(soa, COV['resample_cov'], orc.native_normals(n, 0, 5, 2, k))
+            orc.mean_cov(soa)
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        per_step = (time.perf_counter() - t0) / done
+        out['value' if label == 'all' else 'value_1thread'] = round((n / float(P)) / per_step, 5)
+        out['cores' if label == 'all' else 'cores_1thread'] = threads
+        out['sample' if label == 'all' else 'sample_1thread'] = '%d particles x %d step(s) on %d thread(s), %.2f s/step, scaled linearly to %d' % (
+            n, done, threads, per_step, P)
+    return out
+
+
 def alg_bytes(P, B, map_bytes, world):
     """Algorithmic (compulsory) HBM bytes per step of each phase.  The fused step keeps
     z, roll, pitch (the odometry's on every particle) out of the predict's stores and the gather's loads: 24 B less each
@@ -404,7 +473,7 @@ def run_leg(engine, name, m, P, B, steps, warmup, device=0, x0=0.0, cov=None, re
     out = dict(mbes_path=path, workload='%d particles x %d beams, %s%s%s' % (
         P, B, m['desc'], '' if resample else ', predict + MBES update only (no resample: the cloud keeps its width)',
         '' if landmarks is None else ', + %d detections x %d landmarks k-NN (k=4) per ping' % (landmarks[1], len(landmarks[0]))),
-        steps=steps, ms_per_step=round(ms, 4), steps_per_s=round(1e3 / ms, 2),
+        steps=steps, warmup=warmup, ms_per_step=round(ms, 4), steps_per_s=round(1e3 / ms, 2),
         kernels={k: round(v[0] / n_tim, 5) for k, v in tim.items() if v[1]},
         kernels_note='HIP-event regions of the %d steps that follow the timed block; ms_per_step is wall clock without events' % n_tim)
     if cloud:
@@ -761,13 +830,14 @@ def worker(a, rank, world, local_rank):
         out['pose_rmse_vs_oracle_at'] = '%d particles x %d beams x %d steps (GPU filter vs oracle, same Philox draws)' % (
             n_ref, B, len(ref_xy))
         allc['pose_rmse_vs_oracle_m'] = rm
+        allc['reference_python'] = REFERENCE_PYTHON
         out['cpu_baseline'] = allc
     if rank == 0 and world == 1 and not a.no_extra:
         extra = {}
         legs = []
         mesh = m if a.map == 'mesh' else build_map('mesh')
         if a.map != 'grid':
-            legs.append(('grid', dict(m=build_map('grid'), P=1048576, B=512, steps=30, warmup=5)))
+            legs.append(('grid', dict(m=build_map('grid'), P=1048576, B=512, steps=50, warmup=40)))
         # a filter that keeps a healthy spread: the 512 beams of a ping share ONE error budget (likelihood tempered by
         # 1 / B: sigma_eff = sigma sqrt(B) = 4.5 m), so the posterior stays decimetres wide instead of collapsing to
         # the resampling noise -- the same kernels, the same launches, lanes of a wave no longer walk the same triangles
@@ -777,15 +847,18 @@ def worker(a, rank, world, local_rank):
         if a.map != 'mesh-soup':
             legs.append(('mesh_soup_irregular', dict(m=build_map('mesh-soup'), P=1048576, B=512, steps=10, warmup=2)))
         if a.map != 'mesh-adjacency':
-            legs.append(('mesh_adjacency', dict(m=build_map('mesh-adjacency'), P=1048576, B=512, steps=20, warmup=3)))
+            legs.append(('mesh_adjacency', dict(m=build_map('mesh-adjacency'), P=1048576, B=512, steps=50, warmup=40)))
+        # (the surface legs run 40 steps before their 50 timed ones: like the headline's median block they time the filter's
+        #  steady state -- rounds 1-5 timed steps 3 .. 22, on which the cloud is still contracting and a sweep launch takes
+        #  15 % longer; every leg records its `steps` and `warmup`)
         # the path of a REAL survey mesh: an irregular height-field TIN through the adjacency walk (k_mbes_sweep<5,...>) --
         # as generated (row-major), in random input order (mesh_build's Morton pass must make the two alike), and on a
         # filter that keeps a healthy spread (the realistic deployment point)
         tin = m if a.map == 'mesh-tin' else build_map('mesh-tin')
         if a.map != 'mesh-tin':
-            legs.append(('mesh_tin', dict(m=tin, P=1048576, B=512, steps=20, warmup=3)))
+            legs.append(('mesh_tin', dict(m=tin, P=1048576, B=512, steps=50, warmup=40)))
         if a.map != 'mesh-tin-shuffled':
-            legs.append(('mesh_tin_shuffled', dict(m=build_map('mesh-tin-shuffled'), P=1048576, B=512, steps=20, warmup=3)))
+            legs.append(('mesh_tin_shuffled', dict(m=build_map('mesh-tin-shuffled'), P=1048576, B=512, steps=50, warmup=40)))
         legs.append(('mesh_tin_tempered', dict(m=tin, P=1048576, B=512, steps=30, warmup=10, sigma=SIGMA * math.sqrt(512.0))))
         # global-localisation regime: sigma = 50 m cloud that nothing collapses (no resample).  Particles are
         # initialised around the odom origin (auv_particle.py:24), so the map <- odom transform puts that
@@ -805,12 +878,25 @@ def worker(a, rank, world, local_rank):
         legs.append(('config4_shard_rccl_1rank', dict(m=mesh, P=524288, B=512, steps=30, warmup=5, rccl_1rank=True)))
         legs.append(('config5_shard', dict(m=mesh, P=524288, B=512, steps=30, warmup=5,
                                            landmarks=(synth.landmark_map(4096, (-64.0, -354.0, 643.0, 353.0)), 16))))
+        cpu_todo = []
+        cpu_legs = () if a.no_cpu_baseline else ('grid', 'config2', 'config4_shard', 'config5_shard', 'mesh_tin')   # "at every config"
         for name, kw in legs:
             try:
+                lm, lP, lB, lland = kw['m'], kw['P'], kw['B'], kw.get('landmarks')
                 extra[name] = run_leg(engine, name, kw.pop('m'), kw.pop('P'), kw.pop('B'), kw.pop('steps'), kw.pop('warmup'),
                                       device=local_rank, **kw)
+                if name in cpu_legs:
+                    cpu_todo.append((name, lm, lP, lB, lland))
             except Exception as ex:  # a failing leg must not cost the headline line
-                extra[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+                extra.setdefault(name, {})['error'] = '%s: %s' % (type(ex).__name__, ex)
+        # (the oracle's legs AFTER every GPU leg: its OpenMP workers keep spinning on the granted cores for a while after a
+        #  parallel region, and a host-latency-bound GPU leg right behind one -- config4_shard_rccl_1rank -- measured 0.43 ms
+        #  instead of 0.26)
+        for name, lm, lP, lB, lland in cpu_todo:
+            try:
+                extra[name]['cpu_baseline'] = cpu_leg_baseline(engine, lm, lP, lB, local_rank, landmarks=lland)
+            except Exception as ex:
+                extra[name]['cpu_baseline'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
         out['extra'] = extra
         # the numbers of the other legs where a reader of `value` sees them: the headline cloud has
         # collapsed to the resampling noise; filter_tempered keeps a posterior decimetres wide on the same kernels

@@ -47,6 +47,7 @@ struct Params {
   // (geometry_msgs/PoseArray in base_frame, toy_mbes_receptor.cpp:68-110; ekf_slam.cpp:41 names the topic parameter)
   std::string landmark_map_file = "", lm_detect_topic = "/landmarks_detected";
   double rocks_depth = 1e300, landmark_std = 0.3, landmark_gate = 11.345, landmark_sync_tol = 1e-3, landmark_max_age = 0.5;
+  bool landmark_late_drop = false;   // ~landmark_late = 'drop': detections that arrive AFTER their ping are ignored (default 'update': an update + resampling of their own -- two resamplings, two doses of resampling noise, per ping)
   int landmark_k = 1;
 };
 
@@ -300,6 +301,7 @@ class Core {
       pending_det_.assign(xyz, xyz + (size_t)n_det * 3);
       return true;
     }
+    if (p_.landmark_late_drop && has_map_) return true;   // (after its ping; one resampling per ping asked for)
     return check(mcl_update_landmarks(h_, xyz, n_det, p_.landmark_std, p_.landmark_k, p_.landmark_gate, nullptr, 0)) &&
            check(mcl_resample(h_, nullptr, 0, nullptr));
   }

@@ -65,6 +65,11 @@ class AuvPfNode {
     pnh_.param("landmark_gate", p.landmark_gate, p.landmark_gate);
     pnh_.param("landmark_sync_tol", p.landmark_sync_tol, p.landmark_sync_tol);
     pnh_.param("landmark_max_age", p.landmark_max_age, p.landmark_max_age);
+    {
+      std::string late = "update";
+      pnh_.param("landmark_late", late, late);
+      p.landmark_late_drop = late == "drop";
+    }
     pnh_.param("max_published_poses", max_poses_, 5000);
     if (max_poses_ < 1) max_poses_ = 1;   // (the stride of the thinned PoseArray divides by it)
 

@@ -58,8 +58,14 @@ DEFAULT_PARAMS = {
     # before the resampling.  Without a bathymetric map a detection message is always an update of its own.  Detections
     # older than `landmark_max_age` seconds of the filter's clock (the latest odometry stamp) are dropped: their
     # base_frame positions describe a pose the cloud has long left.
+    # NOTE (live order): a detection message that follows its ping is its OWN update + resampling, so with a receptor
+    # running the filter resamples -- and adds `resampling_noise_covariance` -- TWICE per ping (once for the ranges, once
+    # for the detections); choose the resampling noise for that rate.  `landmark_late` = 'drop' ignores detections that
+    # arrive after their ping instead (one resampling per ping; detections then only count when they come ahead of
+    # their ping and join its likelihood).
     'landmark_map_file': '', 'rocks_depth': float('inf'), 'lm_detect_topic': '/landmarks_detected',
     'landmark_std': 0.3, 'landmark_k': 1, 'landmark_gate': 11.345, 'landmark_sync_tol': 1e-3, 'landmark_max_age': 0.5,
+    'landmark_late': 'update',
 }
 
 
@@ -256,6 +262,9 @@ class auv_pf(object):
         self.landmark_std, self.landmark_k = float(p['landmark_std']), int(p['landmark_k'])
         self.landmark_gate, self.landmark_sync_tol = float(p['landmark_gate']), float(p['landmark_sync_tol'])
         self.landmark_max_age = float(p['landmark_max_age'])
+        self.landmark_late = str(p['landmark_late'])
+        if self.landmark_late not in ('update', 'drop'):
+            raise ValueError("landmark_late must be 'update' or 'drop', not %r" % self.landmark_late)
         self._pending_det = None   # (stamp, (n_det, 3) detections in base_frame) that arrived AHEAD of their ping
         self._last_ping_stamp = None
         if p['landmark_map_file']:
@@ -364,6 +373,8 @@ class auv_pf(object):
             if self.has_map and (self._last_ping_stamp is None or stamp > self._last_ping_stamp + self.landmark_sync_tol):
                 self._pending_det = (stamp, det)
                 return
+            if self.landmark_late == 'drop' and self.has_map:
+                return   # (after its ping, and the node is asked for ONE resampling per ping)
             self.particles.update_landmarks(det, self.landmark_std, k=self.landmark_k, gate=self.landmark_gate,
                                             accumulate=False)
             self.resample(self.particles)

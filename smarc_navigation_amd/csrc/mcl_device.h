@@ -161,17 +161,33 @@ __device__ __forceinline__ double ordered_value(u64 k) {
 // relaxed agent-scope accesses (global_load/store ... sc1): L2-served, never a stale per-CU L1 line.
 // One naturally aligned 8-byte word written by ONE store is its own hand-off granule (value + tag):
 // no fence is needed to read it from another CU (MI355X_MICROARCH.md, inter-workgroup visibility).
+// -DMCL_FENCED=1 (csrc/Makefile: libmcl_hip_fenced.so, test infrastructure): the same hand-offs by the HIP memory model's
+// book -- release stores, acquire loads, a device-scope fence on either side of every ticket -- whatever they cost.
+// tests/test_gpu_zz_fenced.py runs the filter through both builds, bit for bit: if a driver, a partition mode or a
+// compiler ever breaks what the fence-free form rests on, the two part ways there instead of in the field.
+#ifndef MCL_FENCED
+#define MCL_FENCED 0
+#endif
+#if MCL_FENCED
+#define MCL_ORDER_LOAD __ATOMIC_ACQUIRE
+#define MCL_ORDER_STORE __ATOMIC_RELEASE
+#define MCL_TICKET_FENCE() __threadfence()
+#else
+#define MCL_ORDER_LOAD __ATOMIC_RELAXED
+#define MCL_ORDER_STORE __ATOMIC_RELAXED
+#define MCL_TICKET_FENCE() ((void)0)
+#endif
 __device__ __forceinline__ u64 load_agent(const u64* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, MCL_ORDER_LOAD, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void store_agent(u64* p, u64 v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p, v, MCL_ORDER_STORE, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ double load_agent(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, MCL_ORDER_LOAD, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void store_agent(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p, v, MCL_ORDER_STORE, __HIP_MEMORY_SCOPE_AGENT);
 }
 // max over the slots an update kernel filled (one wave; every lane gets the result)
 __device__ __forceinline__ double max_from_slots(const u64* slots) {

@@ -610,7 +610,7 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   // particles; the slice 30 - 45 % of milliseconds -- its group kernel needs the order --: from 8 192 particles)
   const bool by_size = h->sweep_now ? h->n >= h->visit_min_n : h->n >= 8192;
   const bool order_ok = !rp && (h->sweep_now || (h->slice_now && h->env_slice_group != 0)) && h->env_visit != 0 &&
-                        (h->env_visit == 1 || by_size) && h->n <= 65535ll * GATHER_MAX_GRID;   // (16-bit counts per workgroup)
+                        (h->env_visit == 1 || by_size) && h->n <= 63ll * GATHER_MAX_GRID * RS_BLOCK;   // (16-bit counts per (workgroup, bin): a workgroup takes whole chunks of RS_BLOCK slots -- at most 63 of them, 64 512 particles, all of which land in ONE bin on a first gather -- ADVICE r5)
   // (also for a plain mcl_resample right after predict + update -- the node's call sequence --: the sums are then a
   //  by-product nobody reads, the visiting order is what the stash kernel is taken for)
   const bool want_order = !with_moments && order_ok && h->world == 1 && !h->comm;

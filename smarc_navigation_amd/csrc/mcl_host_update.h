@@ -86,11 +86,14 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
   // that take the hand-overs)
   const size_t tab_floats = ((size_t)B * 7 + 4 + 1) & ~(size_t)1;   // B records | B tail sums | B measured ranges | first / second tangent of either side | B tail sums per run (| pad to 8 bytes)
   const bool grow_ride = h->det_ride && h->det_ride_n > h->det_ride_cap;
-  if (grow_ride) h->det_ride_cap = std::max(h->det_ride_n, 16);
-  const size_t blk_floats = tab_floats + 6 * (size_t)h->det_ride_cap;   // | the ping's landmark detections (fp64), when they ride along
+  // (the new capacities are COMMITTED only when both buffers of both halves exist -- ADVICE r5: a failed allocation
+  //  used to leave null buffers behind capacities that said there was room, and the next fused landmark step built its
+  //  table through a null pinned pointer)
+  const int ride_cap = grow_ride ? std::max(h->det_ride_n, 16) : h->det_ride_cap;
+  const size_t blk_floats = tab_floats + 6 * (size_t)ride_cap;   // | the ping's landmark detections (fp64), when they ride along
   if (B > h->sweep_cap || grow_ride) {
     const size_t cap_b = (size_t)std::max(B, h->sweep_cap);
-    const size_t alloc_floats = ((cap_b * 7 + 4 + 1) & ~(size_t)1) + 6 * (size_t)h->det_ride_cap;
+    const size_t alloc_floats = ((cap_b * 7 + 4 + 1) & ~(size_t)1) + 6 * (size_t)ride_cap;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->copy_stream) HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     for (int k = 0; k < 2; ++k) {
@@ -98,13 +101,18 @@ int upload_sweep_beams(mcl_handle* h, bool with_ranges, int B, double sigma, dou
       if (h->sweep_stage[k]) (void)hipHostFree(h->sweep_stage[k]);
       h->sweep_buf[k] = nullptr;
       h->sweep_stage[k] = nullptr;
+      h->stage_used[k] = false;
+    }
+    h->sweep_cap = 0;       // (nothing is allocated from here until every allocation below has succeeded)
+    h->det_ride_cap = 0;
+    for (int k = 0; k < 2; ++k) {
       HIPCHK(h, hipMalloc(&h->sweep_buf[k], sizeof(float) * alloc_floats));
       HIPCHK(h, hipHostMalloc(&h->sweep_stage[k], sizeof(float) * alloc_floats, hipHostMallocDefault));
       if (!h->ev_stage[k]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_stage[k], hipEventDisableTiming));
-      h->stage_used[k] = false;
     }
     if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    h->sweep_cap = std::max(h->sweep_cap, B);
+    h->sweep_cap = (int)cap_b;
+    h->det_ride_cap = ride_cap;
   }
   const int sel = (h->sweep_sel ^= 1);
   h->sweep_beams = h->sweep_buf[sel];
@@ -556,12 +564,16 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
         a.slice_loose_count = (int*)(h->ctrl + CTRL_LOOSE);   // (zeroed with the control block by this step's predict)
         const size_t lds_g = (size_t)B * (3 + SLICE_G_WAVES) * sizeof(float) + (size_t)SLICE_G_TRIS * 9 * sizeof(float) +
                              SLICE_G_HASH * sizeof(unsigned) + SLICE_LUT * sizeof(unsigned short);
-        if (!h->slice_attr_set || lds_g > h->slice_attr_bytes) {   // (more than 64 KiB of dynamic LDS has to be asked for)
+        // does the group kernel's staging layout fit this ping's beam table?  Decided BEFORE anything is asked of the
+        // runtime (hipFuncSetAttribute itself fails beyond the device's limit, and the kernel's static
+        // __shared__ -- member poses, reference plane, counters: a conservative 4 KiB -- counts against the same 160 KiB)
+        const bool fits = lds_g + 4096 <= (size_t)160 * 1024;
+        if (fits && (!h->slice_attr_set || lds_g > h->slice_attr_bytes)) {   // (more than 64 KiB of dynamic LDS has to be asked for)
           HIPCHK(h, hipFuncSetAttribute((const void*)k_mbes_slice_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
           h->slice_attr_set = true;
           h->slice_attr_bytes = lds_g;
         }
-        if (lds_g <= 160 * 1024) {
+        if (fits) {
           k_mbes_slice_group<<<(unsigned)std::min<long long>(ngr, 4096), SLICE_G_THREADS, lds_g, h->stream>>>(a);
           h->slice_group_ran = true;
         } else

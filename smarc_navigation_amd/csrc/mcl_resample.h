@@ -304,7 +304,9 @@ __global__ void __launch_bounds__(RS_BLOCK) k_cdf_expand(ExpandArgs a) {
   __shared__ u32 tile_sh, zex_sh, agg_sh, heavy_n;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) {
+    MCL_TICKET_FENCE();
     const u32 t = atomicAdd(a.ticket, 1u);
+    MCL_TICKET_FENCE();
     tile_sh = t;
     heavy_n = 0u;
     if (t == gridDim.x - 1u) atomicExch(a.ticket, 0u);  // every ticket of this launch has been drawn
@@ -745,7 +747,9 @@ __global__ void __launch_bounds__(RS_BLOCK) k_resample_gather(GatherArgs a, cons
       store_agent(&a.part[(size_t)lane * gridDim.x + blockIdx.x], s);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MCL_TICKET_FENCE();
     if (lane == 0) last_sh = (atomicAdd(a.ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    MCL_TICKET_FENCE();
   }
   __syncthreads();
   if (!last_sh) return;
@@ -813,7 +817,9 @@ __global__ void __launch_bounds__(1024) k_visit_scan(VisitArgs a, int G, u32* ti
   // (slices are handed out by a ticket, like k_cdf_expand's tiles: a workgroup only ever waits for slices that are
   //  already running, whatever else shares the chip -- the shards of a LOCAL group launch their scans side by side)
   if (threadIdx.x == 0) {
+    MCL_TICKET_FENCE();
     const u32 t = atomicAdd(ticket, 1u);
+    MCL_TICKET_FENCE();
     slice_sh = t;
     if (t == gridDim.x - 1u) atomicExch(ticket, 0u);   // every ticket of this launch has been drawn
   }

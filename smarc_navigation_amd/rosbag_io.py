@@ -255,6 +255,7 @@ TYPES = {
 
 # ------------------------------------------------------------------ records
 def _parse_fields(b):
+    b = bytes(b)   # (a record's header or a connection record's data: small; may arrive as a view of the file)
     out, o = {}, 0
     while o < len(b):
         if o + 4 > len(b):
@@ -277,12 +278,12 @@ def _records(buf, start=0):
         hl, = struct.unpack_from('<I', buf, o)
         if o + 4 + hl + 4 > len(buf):
             return
-        head = _parse_fields(buf[o + 4:o + 4 + hl])
+        head = _parse_fields(bytes(buf[o + 4:o + 4 + hl]))
         dl, = struct.unpack_from('<I', buf, o + 4 + hl)
         d0 = o + 8 + hl
         if d0 + dl > len(buf):
             return
-        yield head, buf[d0:d0 + dl]
+        yield head, buf[d0:d0 + dl]   # (buf a memoryview: a view, not a copy)
         o = d0 + dl
 
 
@@ -335,26 +336,33 @@ class Bag(object):
                     if want is not None and topic not in want:
                         continue
                     secs, nsecs = struct.unpack('<II', head['time'])
-                    dec = TYPES.get(typ)
-                    yield topic, (dec[1](data) if dec and not raw else RawMessage(typ, bytes(data))), secs + 1e-9 * nsecs
+                    yield topic, typ, data, secs + 1e-9 * nsecs
                 elif op == OP_CHUNK:
                     comp = head.get('compression', b'none')
                     if comp == b'none':
                         body = data
                     elif comp == b'bz2':
-                        body = bz2.decompress(data)
+                        body = memoryview(bz2.decompress(data))
                     else:
                         raise BagError('chunk compression %r is not supported (none and bz2 are)' % comp.decode('ascii', 'replace'))
                     for item in inner(_records(body)):
                         yield item
 
+        def decode(topic, typ, data, t):
+            dec = TYPES.get(typ)
+            return topic, (dec[1](bytes(data)) if dec and not raw else RawMessage(typ, bytes(data))), t
+
+        view = memoryview(self.buf)
         if not by_time:
-            for item in inner(_records(self.buf, len(MAGIC))):
-                yield item
+            for item in inner(_records(view, len(MAGIC))):
+                yield decode(*item)
             return
-        items = list(inner(_records(self.buf, len(MAGIC))))
-        for k in sorted(range(len(items)), key=lambda j: (items[j][2], j)):   # (stable: equal stamps keep the file's order)
-            yield items[k]
+        # ordered by time WITHOUT decoding first: the first pass keeps (topic, type, a VIEW of the record's
+        # bytes, time) -- a few dozen bytes per message on top of the file itself (a bz2 chunk's decompressed body is
+        # kept while its views are alive) --, messages are decoded one at a time as they are yielded
+        items = list(inner(_records(view, len(MAGIC))))
+        for k in sorted(range(len(items)), key=lambda j: (items[j][3], j)):   # (stable: equal stamps keep the file's order)
+            yield decode(*items[k])
 
 
 def write_bag(path, messages, compression='none', chunk_messages=64):

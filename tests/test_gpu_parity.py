@@ -106,7 +106,7 @@ def test_trajectory_replay_residual_node_as_written(eng):
 def test_all_resampler_kats_vs_reference(eng):
     """stratified / multinomial / residual / naive golden vectors (resampling.py) through the GPU."""
     g = helpers.load('resampling_kat')
-    counts = {}
+    counts, worst, total = {}, {}, {}
     for tag in g['cases']:
         w = g[tag + '_w']
         n = w.size
@@ -122,9 +122,15 @@ def test_all_resampler_kats_vs_reference(eng):
             if name == 'residual_resample' or n <= 4096:
                 assert np.array_equal(idx, ref), key
             else:  # N = 65536: allow the reference's own fp64 cumsum rounding
-                assert np.count_nonzero(idx != ref) <= 2, key
+                miss = int(np.count_nonzero(idx != ref))
+                worst[name] = max(worst.get(name, 0), miss)
+                total[name] = total.get(name, 0) + miss
+                assert miss <= 2, key
             counts[name] = counts.get(name, 0) + 1
     assert min(counts.values()) >= 20, counts
+    # what the bound of 2 actually costs: the observed mismatches against the reference's fp64 indices
+    print('N = 65 536 cases: index mismatches vs the reference, worst case per scheme %r, summed over all cases %r' % (worst, total))
+    assert sum(total.values()) <= 8, total
 
 
 @pytest.mark.parametrize('scheme', ['STRATIFIED', 'MULTINOMIAL', 'RESIDUAL'])

@@ -291,6 +291,44 @@ def test_slice_over_groups_of_neighbours_equals_the_per_particle_slice_bitwise(k
         assert x[3][1] == y[3][1]
 
 
+def test_slice_beam_tables_too_long_for_the_group_kernel_fall_back_instead_of_failing(eng, monkeypatch):
+    """the group kernel stages the ping's beam table in LDS beside the triangles; at 2 040 - 2 048 beams
+    (the sweep / slice accept up to 2 048) its dynamic LDS exceeds what hipFuncSetAttribute grants, and from ~1 990 its
+    static __shared__ pushes the launch over 160 KiB.  The host now decides BEFORE asking the runtime: such a ping is cast
+    by the per-particle kernel -- the fused step succeeds and equals the MCL_SLICE_GROUP=0 filter bit for bit -- while a
+    table that fits still takes the group kernel."""
+    monkeypatch.delenv('MCL_SLICE', raising=False)
+    monkeypatch.setenv('MCL_VISIT', '1')
+    origin = (-64.0, -128.0)
+    z = synth.bathymetry_grid(256, 256, 1.0, origin, seed=3)
+    verts, tris = synth.mesh_tin(z, 1.0, origin, seed=7)
+    n, steps = 8192, 3
+    stream = synth.odom_stream(steps)
+    for B, grouped in ((2048, False), (2000, False), (1500, True)):
+        ba = synth.beam_angles(B)
+        ranges = (22.0 / np.cos(ba)).astype(np.float32)
+        res = {}
+        for group in ('1', '0'):
+            monkeypatch.setenv('MCL_SLICE_GROUP', group)
+            e = eng.Engine(n, seed=3, init_cov=[1.0, 1.0, 0, 0, 0, 0.01], process_cov=[1e-4, 1e-4, 0, 0, 0, 1e-6],
+                           resample_cov=[1e-2, 1e-2, 0, 0, 0, 1e-5])
+            e.set_map_mesh(verts, tris, general=True)
+            e.init_particles()
+            out = []
+            for k in range(steps):
+                e.step_mbes(stream['v'][k], stream['wz'][k], stream['q'][k], stream['z'][k], stream['dt'], ranges, ba, 2.0, 100.0)
+                path = e.mbes_last_path()
+                assert path[0] == 2, path
+                out.append((e.get_log_weights(), e.last_indices(), path[2]))
+            e.close()
+            res[group] = out
+        loose = [o[2] for o in res['1']]
+        print('%d beams: groups left to the per-particle kernel per step %r' % (B, loose))
+        assert (loose[-1] >= 0) == grouped, (B, loose)   # -1: the group kernel did not run
+        for x, y in zip(res['1'], res['0']):
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]), B
+
+
 def test_slice_groups_on_a_dispersed_cloud_and_an_odd_particle_count(eng, monkeypatch):
     """A cloud a metre wide at 12 particles per bin (groups of neighbours whose planes differ by more than the group kernel
     accepts over a 40 m fan: left to the per-particle kernel, by its list; the bitwise test above is the mostly-tight
