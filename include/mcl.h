@@ -165,7 +165,13 @@ int mcl_set_map_mesh_ex(mcl_handle* h, const float* verts, int64_t nv, const uin
  * fp64 definition (oracle/mcl_oracle.c) an expected range is within 1e-3 m and a log-likelihood within
  *     |d lw| <= 1e-2   or   |d lw| <= 2e-4 |lw|
  * -- the relative arm is this build's addition to SURVEY's absolute 1e-2: the sum of 512 squared residuals of a particle
- * metres off the truth reaches |lw| ~ 2e4, where fp32 residuals alone are worth 1e-2 (measured: 1.2e-2).  Exceptions
+ * metres off the truth reaches |lw| ~ 2e4, where fp32 residuals alone are worth 1e-2 (measured: 1.2e-2).  WHERE IT BITES
+ * the absolute bound holds on its own: every particle that can receive offspring -- log-likelihood within 30 of the
+ * cloud's maximum, i.e. a non-zero fixed-point weight (q = floor(exp(lw) 2^(s - K)), s = 43 at 2^20 particles: exp(-29.8) =
+ * 2^-43) -- is within |d lw| <= 1e-2 of the fp64 definition (measured at 1 M x 512: 1.1e-3 on the lattice mesh, the
+ * height grid, the irregular TIN and the triangle soup; tests/helpers.py: live_particle_contract, asserted in
+ * test_gpu_fullsize.py, test_gpu_config45.py and the driver's smoke()).  The relative arm only ever excuses particles whose
+ * weight is zero.  Exceptions
  * are the rays that graze a crest or an edge: fp32's last bit decides between the crest and the shadow behind it.
  * Their NUMBER is bounded by the tests (a few per 10^4 rays on rough terrain) and so is their SIZE: each is, within
  * 1e-3 m, an answer the fp64 definition itself gives when the sensor moves by 1 mm (tests/helpers.py:

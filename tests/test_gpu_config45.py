@@ -94,6 +94,14 @@ def test_config4_eight_local_shards_of_524288_fused_steps_bitwise(exchange, monk
             assert (~ok).sum() <= 8
             from tests.helpers import lw_outliers_explained
             lw_outliers_explained(orc, omap, sub, ba, ranges[0], SIGMA, R_MAX, lw1[pick], lw_ref, label='config 4')
+            # the contract where it bites: every particle that can receive offspring within |d lw| <= 1e-2 ABSOLUTE
+            from tests.helpers import live_particle_contract, live_picks
+            live = live_picks(lw1, 2048, seed=8)
+            lsub = np.ascontiguousarray(soa[:, live])
+            lw_live, _ = orc.mbes_update(lsub, np.identity(4), [0] * 6, omap, ba, ranges[0], SIGMA, R_MAX)
+            n_live, _, _ = live_particle_contract(orc, omap, lsub, ba, ranges[0], SIGMA, R_MAX, lw1[live], lw_live, float(lw1.max()),
+                                                  label='config 4 (4 M x 512)')
+            assert n_live >= 16
             # indices are the exact systematic resample of the GPU's own log-weights
             ref_idx, _, _ = orc.systematic_fixed(lw1, 1, orc.native_u53(5, 0))
             assert np.array_equal(idx1, ref_idx)

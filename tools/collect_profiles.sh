@@ -1,38 +1,68 @@
 #!/bin/bash
-# tools/collect_profiles.sh -- copy what tools/profile_gpu.sh left under gpurun_out/prof_$ROUND/ into profiles/$ROUND_* (ROUND: r05)
+# tools/collect_profiles.sh -- copy what tools/profile_gpu.sh left under gpurun_out/prof_$ROUND/ into profiles/$ROUND_* (ROUND: r06)
 # (run in the build container after the gpurun call; profiles/ is what the judge reads, gpurun_out/ is scratch).
-# The raw counter rows are trimmed to the first 12 dispatches of the dominant kernel (the means over all ~200 are in
-# <round>_traffic.json): once per round, a few dozen KB.
+# The raw counter rows were trimmed on the box to the first 12 dispatches of every kernel (the means over all dispatches
+# are in <round>_traffic.json); here only the rows of the dominant sweep kernels are kept.
 set -e
 cd "$(dirname "$0")/.."
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 S=gpurun_out/prof_$ROUND
-# gpurun MERGES into gpurun_out/: keep only the newest run's file(s) in every pass directory before summarising
-for d in $S/stats_* $S/pmc_*; do
-  newest=$(ls -t $d/runc/ | head -1 | sed 's/_.*//')
-  for f in $d/runc/*; do case $(basename $f) in ${newest}_*) ;; *) rm -f $f ;; esac; done
+name() { echo "$1" | sed 's/mesh-tin/tin/'; }
+for m in mesh grid mesh-tin mesh_tempered mesh-tin_tempered; do
+  f=$(ls -t $S/stats_$m/*/*_kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && cp $f profiles/${ROUND}_$(name $m)_1M_x512_kernel_stats.csv
+  [ -f $S/bench_$m.log ] && grep '^{"metric"' $S/bench_$m.log | tail -1 > profiles/${ROUND}_$(name $m)_bench_only_main.json
 done
-python3 tools/pmc_summarise.py $S $S/traffic.json > /dev/null
-for m in mesh grid; do
-  cp $(ls -t $S/stats_$m/*/*_kernel_stats.csv | head -1) profiles/${ROUND}_${m}_1M_x512_kernel_stats.csv
-  for c in fetch write sq; do
-    f=$(ls -t $S/pmc_${m}_$c/*/*_counter_collection.csv.mbes | head -1)
-    python3 - "$f" profiles/${ROUND}_${m}_pmc_$c.csv <<'PY'
-import csv, sys
+for m in mesh grid mesh-tin; do
+  for c in fetch write sq cache; do
+    for f in $(ls $S/pmc_${m}_$c/*/*_counter_collection.csv.trim 2>/dev/null); do
+      python3 - "$f" profiles/${ROUND}_$(name $m)_pmc_$c.csv <<'PY'
+import csv, os, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 keep = [r for r in rows if r['Kernel_Name'].startswith('void k_mbes_sweep') and ', false, false>' in r['Kernel_Name']]
-ids = sorted({int(r['Dispatch_Id']) for r in keep})[:12]
-with open(sys.argv[2], 'w', newline='') as f:
+new = not os.path.exists(sys.argv[2])
+with open(sys.argv[2], 'a', newline='') as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
-    w.writeheader()
-    for r in keep:
-        if int(r['Dispatch_Id']) in ids:
-            w.writerow(r)
+    if new:
+        w.writeheader()
+    w.writerows(keep)
 PY
+    done
   done
-  grep '^{"metric"' $S/bench_$m.log | tail -1 > profiles/${ROUND}_${m}_bench_only_main.json
 done
-for m in config5 soup; do
+for m in mesh mesh-tin; do
+  for c in sq cache; do
+    for f in $(ls $S/pmc_${m}_tempered_$c/*/*_counter_collection.csv.trim 2>/dev/null); do
+      python3 - "$f" profiles/${ROUND}_$(name $m)_tempered_pmc_$c.csv <<'PY'
+import csv, os, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+keep = [r for r in rows if r['Kernel_Name'].startswith('void k_mbes_sweep') and ', false, false>' in r['Kernel_Name']]
+new = not os.path.exists(sys.argv[2])
+with open(sys.argv[2], 'a', newline='') as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    if new:
+        w.writeheader()
+    w.writerows(keep)
+PY
+    done
+  done
+done
+# the streaming kernels' rows of the two SQ passes on the mesh leg
+rm -f profiles/${ROUND}_mesh_pmc_streaming.csv
+for f in $(ls $S/pmc_mesh_sq/*/*_counter_collection.csv.trim $S/pmc_mesh_sq2/*/*_counter_collection.csv.trim 2>/dev/null); do
+  python3 - "$f" profiles/${ROUND}_mesh_pmc_streaming.csv <<'PY'
+import csv, os, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+keep = [r for r in rows if any(k in r['Kernel_Name'] for k in ('k_predict_pose', 'k_quantise_tiles', 'k_cdf_expand', 'k_resample_gather', 'k_visit_scan'))]
+new = not os.path.exists(sys.argv[2])
+with open(sys.argv[2], 'a', newline='') as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    if new:
+        w.writeheader()
+    w.writerows(keep)
+PY
+done
+for m in config5 soup config4_rccl; do
   f=$(ls -t $S/stats_$m/*/*_kernel_stats.csv 2>/dev/null | head -1)
   if [ -n "$f" ]; then cp $f profiles/${ROUND}_${m}_kernel_stats.csv; fi
 done
