@@ -874,8 +874,8 @@ def worker(a, rank, world, local_rank):
         # back after about a second (MI355X_MICROARCH.md, DVFS) -- what a long replay sees
         legs.append(('sustained_3000_steps', dict(m=mesh, P=1048576, B=512, steps=3000, warmup=20)))
         legs.append(('config2', dict(m=build_map('grid'), P=65536, B=256, steps=200, warmup=20)))
-        legs.append(('config4_shard', dict(m=mesh, P=524288, B=512, steps=30, warmup=5)))
-        legs.append(('config4_shard_rccl_1rank', dict(m=mesh, P=524288, B=512, steps=30, warmup=5, rccl_1rank=True)))
+        legs.append(('config4_shard', dict(m=mesh, P=524288, B=512, steps=100, warmup=10)))
+        legs.append(('config4_shard_rccl_1rank', dict(m=mesh, P=524288, B=512, steps=100, warmup=10, rccl_1rank=True)))   # (100 steps each: their DIFFERENCE -- the exchange at one rank, ~16 us -- is what the two are read for)
         legs.append(('config5_shard', dict(m=mesh, P=524288, B=512, steps=30, warmup=5,
                                            landmarks=(synth.landmark_map(4096, (-64.0, -354.0, 643.0, 353.0)), 16))))
         cpu_todo = []
