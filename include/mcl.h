@@ -256,7 +256,11 @@ int mcl_step_mbes_landmarks(mcl_handle* h, const mcl_odom* odom, double dt, cons
                             const double sensor_offset[6], const double* det_xyz, int32_t n_det, double lm_sigma,
                             int32_t k, double gate, const double lm_sensor_offset[6]);
 int mcl_sync(mcl_handle* h);
-/* mean/cov computed by the last mcl_step_mbes (syncs the stream) */
+/* mean/cov computed by the last mcl_step_mbes (syncs the stream).  One process per GPU (mcl_comm_init): the sums of a fused
+ * step travel with the NEXT step's shard records instead of an all-reduce of their own, so right after a step they may still
+ * lie shard by shard -- mcl_last_mean_cov and mcl_mean_history then complete them with one all-reduce: COLLECTIVE calls in
+ * that case, to be made by every rank (like mcl_get_last_indices after the O(n) exchange).  MCL_MOMENTS_RIDE=0 (read at the
+ * first sharded resample) restores the all-reduce after every step. */
 int mcl_last_mean_cov(mcl_handle* h, double mean6[6], double* yaw_mean, double cov9[9]);
 /* mean poses (6 doubles each, oldest first) of the last `last_k` mean/cov evaluations (<= 4096 are
  * kept in a pinned ring): lets a caller score a whole asynchronous run without per-step syncs */

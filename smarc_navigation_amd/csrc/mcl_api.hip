@@ -717,6 +717,7 @@ int mcl_last_mean_cov(mcl_handle* h, double mean6[6], double* yaw_mean, double c
   if (!h || !mean6 || !cov9) return MCL_ERR_INVALID;
   if (!h->have_meancov) return fail(h, MCL_ERR_STATE, "last_mean_cov: nothing computed yet");
   RET_IF(set_device(h));
+  RET_IF(flush_pending_moments(h));   // (one process per GPU: the last fused step's sums may still be per shard -- a collective)
   HIPCHK(h, hipStreamSynchronize(h->stream));
   finish_mean_cov(h, mean6, yaw_mean, cov9);
   return MCL_OK;
@@ -726,6 +727,7 @@ int mcl_mean_history(mcl_handle* h, int64_t last_k, double* mean6_out) {
   if (!h || !mean6_out || last_k < 1) return MCL_ERR_INVALID;
   if (last_k > h->mean_count || last_k > MEAN_RING) return fail(h, MCL_ERR_INVALID, "mean_history: not that many results kept");
   RET_IF(set_device(h));
+  RET_IF(flush_pending_moments(h));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   for (long long k = 0; k < last_k; ++k) {
     double yaw, cov9[9];
@@ -1179,9 +1181,11 @@ int mcl_comm_selftest(mcl_handle* h, int32_t timeout_ms) {
 int mcl_comm_shutdown(mcl_handle* h, int32_t abort) {
   if (!h) return MCL_ERR_INVALID;
   RET_IF(set_device(h));
+  if (!abort) RET_IF(flush_pending_moments(h));   // (while the communicator is still there)
   if (!abort && h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
   if (!abort && h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   comm_teardown(h, abort != 0);
+  (void)flush_pending_moments(h);   // (aborted with an entry open: it is marked NaN)
   return MCL_OK;
 }
 

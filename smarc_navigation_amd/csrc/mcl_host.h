@@ -221,6 +221,10 @@ struct mcl_handle {
   unsigned short* tile_bits = nullptr;   // device: ntiles_loc x 64 bit counts of this shard's tiles
   const u64* qshift_cur = nullptr;       // the shift the weights in `q` are read with (nullptr: none) -- set by every resample
   bool shrec_dirty = false;              // a launch that accumulates into the record is queued and k_shift_scan (which zeroes it) is not
+  // the fused step's moments ride with the NEXT step's records instead of an all-reduce of their own:
+  bool moments_ride = false;             // this gather writes its 13 sums into the shard's record (set by phase_gather)
+  bool mom_pending = false;              // a ring entry is reserved whose sums still lie, per shard, in the records
+  long long mom_pending_entry = -1;      // ... which one (index into the result ring, before the modulo)
   u64* lsx = nullptr;            // device, world x 4 words
   u64* lsx_host = nullptr;       // pinned, world x 4 words + the sequence word k_publish_ls writes last
   u64* lsx_host_dev = nullptr;   // its device-side address

@@ -69,11 +69,47 @@ int run_mean_cov_async(mcl_handle** sh, int ns) {
   }
   return MCL_OK;
 }
+// A fused step's moments that still lie, shard by shard, in the records (they ride with the next step's all-gather):
+// somebody wants them NOW -- a reader, a shutdown, a step that takes another path.  One all-reduce, like rounds 1-5 did
+// after every step.  In a multi-process run this makes the reader a COLLECTIVE call (include/mcl.h).
+int flush_pending_moments(mcl_handle* h) {
+  if (!h->mom_pending) return MCL_OK;
+  h->mom_pending = false;
+  double* slot = h->host_pin + RING_STRIDE * (h->mom_pending_entry % MEAN_RING);
+  if (!h->comm || !h->shrec) {   // (the communicator is gone: the entry cannot be completed)
+    for (int k = 0; k < 16; ++k) slot[k] = NAN;
+    return MCL_OK;
+  }
+  RET_IF(set_device(h));
+  const double* mine = (const double*)(h->shrec + (size_t)h->rank * SHREC_WORDS + SHREC_MOM);
+  t_begin(h, MCL_K_COMM_MOMENTS);
+  HIPCHK(h, hipMemcpyAsync(h->scal + 32 + MOM_COUNT, mine + MOM_COUNT, sizeof(double) * 3, hipMemcpyDeviceToDevice, h->stream));
+  NCCLCHK(h, ncclAllReduce(mine, h->scal + 32, MOM_COUNT, ncclDouble, ncclSum, h->comm, h->stream));
+  t_end(h);
+  t_begin(h, MCL_K_MEAN_COV);
+  HIPCHK(h, hipMemcpyAsync(slot, h->scal + 32, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
+  t_end(h);
+  return MCL_OK;
+}
+
 // the sums k_resample_gather<true> left in scal[32..47]: reduce over the shards, queue the copy to the ring
 int collect_fused_moments(mcl_handle** sh, int ns) {
   if (ns == 1 && sh[0]->moments_direct) {
     sh[0]->mean_count++;
     sh[0]->have_meancov = true;
+    return MCL_OK;
+  }
+  if (ns == 1 && sh[0]->moments_ride) {
+    // no collective now: the sums wait in the record; the ring entry is reserved, k_shift_scan of the next step (or a
+    // flush) fills it
+    mcl_handle* h = sh[0];
+    RET_IF(flush_pending_moments(h));   // (an older entry that no records exchange came for)
+    double* slot = h->host_pin + RING_STRIDE * (h->mean_count % MEAN_RING);
+    slot[16] = 1.0;
+    h->mom_pending = true;
+    h->mom_pending_entry = h->mean_count;
+    h->mean_count++;
+    h->have_meancov = true;
     return MCL_OK;
   }
   RET_IF(exchange_sums(sh, ns, 32, MOM_COUNT));

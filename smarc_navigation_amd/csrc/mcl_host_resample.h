@@ -149,10 +149,13 @@ int phase_shift_scan(mcl_handle* h) {
   a.tile_off = h->tile64;
   a.totals = h->totals;
   a.shift_out = h->shrec + (size_t)h->world * SHREC_WORDS;
+  // the last fused step's moments came with the records: their sum goes straight into the ring entry reserved for them
+  a.mom_out = (h->mom_pending && h->host_pin_dev) ? h->host_pin_dev + RING_STRIDE * (h->mom_pending_entry % MEAN_RING) : nullptr;
   t_begin(h, MCL_K_SCAN);
   k_shift_scan<<<1, 1024, 0, h->stream>>>(a);
   t_end(h);
   HIPCHK(h, hipGetLastError());
+  if (a.mom_out) h->mom_pending = false;
   h->shrec_dirty = false;
   h->qshift_cur = a.shift_out;
   return MCL_OK;
@@ -584,6 +587,11 @@ int phase_gather(mcl_handle* h, const double* replay_normals, bool with_moments)
   a.add_noise = 1;
   a.part = h->part;
   a.sums_out = h->scal + 32;
+  // one process per GPU, log-likelihood weights: the sums go into the shard's record and travel with the NEXT step's
+  // all-gather (collect_fused_moments reserves their ring entry; a reader that comes first flushes them by an all-reduce)
+  static const bool ride_env = !(getenv("MCL_MOMENTS_RIDE") && atoi(getenv("MCL_MOMENTS_RIDE")) == 0);   // (A/B switch)
+  h->moments_ride = with_moments && ride_env && one_collective(h) && h->shrec && h->host_pin_dev && h->qshift_cur != nullptr;
+  if (h->moments_ride) a.sums_out = (double*)(h->shrec + (size_t)h->rank * SHREC_WORDS + SHREC_MOM);
   // (single shard: the gather reads straight from the pre-resample state; after a predict z, roll, pitch are the same
   //  three numbers on every particle, so they are substituted instead of read -- bit-identical, 24 B x N less traffic)
   a.uni_mask = multi ? h->gather_uni_mask : (h->uni_valid ? 0x1cu : 0u);

@@ -67,7 +67,8 @@ struct QuantArgs {
   unsigned short* tile_bits;
 };
 #define SHREC_COPIES 8                       // the bit counts are accumulated in 8 copies (workgroup & 7): 512 workgroups' atomics on 64 words of four cache lines cost 10 us, on 512 words one
-#define SHREC_WORDS (1 + 64 * SHREC_COPIES)  // a shard's record: exponent, 8 x 64 bit counts (to be added up)
+#define SHREC_MOM (1 + 64 * SHREC_COPIES)    // ... then the 13 sums of update_loc_pose (+ 3 shift words) the shard's LAST fused step left: they ride with this step's record
+#define SHREC_WORDS (SHREC_MOM + 16)         // a shard's record: exponent, 8 x 64 bit counts (to be added up), 16 moment words
 #define SHREC_BIAS (1ll << 41)
 __global__ void __launch_bounds__(MCL_BLOCK) k_quantise_tiles(QuantArgs a) {
   __shared__ u64 sh[16];
@@ -151,6 +152,7 @@ struct ShiftArgs {
   u64* tile_off;       // out: exclusive offsets of this shard's tiles at the cloud's exponent
   u64* totals;         // out: world totals at the cloud's exponent
   u64* shift_out;      // out: this shard's shift (0 .. 64)
+  double* mom_out;     // the PREVIOUS fused step's moments ride in the records (words SHREC_MOM ...): their sum over the shards, in rank order, goes here (16 doubles of the pinned result ring); nullptr: none pending
 };
 __global__ void __launch_bounds__(1024) k_shift_scan(ShiftArgs a) {
   __shared__ u64 sh[16];
@@ -177,6 +179,17 @@ __global__ void __launch_bounds__(1024) k_shift_scan(ShiftArgs a) {
         a.shift_out[0] = (u64)d;
       }
     }
+  }
+  if (a.mom_out && threadIdx.x >= 1024 - 16) {
+    // (the last 16 threads: 13 sums added in rank order -- every rank gets the same bits --, the shift words are the
+    //  same on every rank: this shard's own)
+    const int c = threadIdx.x - (1024 - 16);
+    double v = 0.0;
+    if (c < 13)
+      for (int r = 0; r < a.world; ++r) v += __longlong_as_double((long long)a.recs[(size_t)r * SHREC_WORDS + SHREC_MOM + c]);
+    else
+      v = __longlong_as_double((long long)a.recs[(size_t)a.rank * SHREC_WORDS + SHREC_MOM + c]);
+    a.mom_out[c] = v;
   }
   if (threadIdx.x == 0) carry_sh = 0ull;
   __syncthreads();
