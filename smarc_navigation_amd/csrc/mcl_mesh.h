@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/mcl.h"
+#include "mcl_halfedge.h"
 #include "mcl_mbes.h"
 
 struct MeshDev {
@@ -265,31 +266,7 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
   // through a raw buffer with 32-bit byte offsets.)
   const bool want_tin = !any_vertical && nt > 0 && nt < (1ll << 31) / 96 && nv < (1ll << 31);
   std::vector<u32> new_of_old;
-  if (want_tin) {
-    auto spread = [](u32 v) {   // 16 bits -> every second bit of 32
-      v &= 0xffffu;
-      v = (v | (v << 8)) & 0x00ff00ffu;
-      v = (v | (v << 4)) & 0x0f0f0f0fu;
-      v = (v | (v << 2)) & 0x33333333u;
-      v = (v | (v << 1)) & 0x55555555u;
-      return v;
-    };
-    const double qx = 65535.0 / std::max(xmax - xmin, 1e-30), qy = 65535.0 / std::max(ymax - ymin, 1e-30);
-    std::vector<uint64_t> key((size_t)nt);
-    for (int64_t k = 0; k < nt; ++k) {
-      double cx = 0.0, cy = 0.0;
-      for (int c = 0; c < 3; ++c) {
-        cx += verts[3 * (size_t)tris[3 * k + c]];
-        cy += verts[3 * (size_t)tris[3 * k + c] + 1];
-      }
-      const u32 ix = (u32)std::min(65535.0, std::max(0.0, (cx / 3.0 - xmin) * qx));
-      const u32 iy = (u32)std::min(65535.0, std::max(0.0, (cy / 3.0 - ymin) * qy));
-      key[(size_t)k] = ((uint64_t)(spread(ix) | (spread(iy) << 1)) << 32) | (uint64_t)k;
-    }
-    std::sort(key.begin(), key.end());
-    new_of_old.resize((size_t)nt);
-    for (int64_t r = 0; r < nt; ++r) new_of_old[(size_t)(key[(size_t)r] & 0xffffffffull)] = (u32)r;
-  }
+  if (want_tin) halfedge::morton_order(verts, tris, nt, xmin, xmax, ymin, ymax, new_of_old);
   for (int64_t k = 0; k < nt; ++k) {
     int a0, a1, b0, b1;
     cell_range(k, a0, a1, b0, b1);
@@ -365,53 +342,12 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
   }
   // ---- triangle adjacency (fan sweep over a TIN): edge -> the (at most two) triangles on it
   if (want_tin) {
-    bool ok = true;
-    std::unordered_map<uint64_t, int64_t> edge_first;  // undirected edge -> 3 * triangle + local edge of the first owner
-    edge_first.reserve((size_t)nt * 2);
-    // twin[3 k + e]: the half-edge (3 * triangle + ITS edge) on the far side of edge e = (v_e, v_e+1) of triangle k,
-    // input numbering and input winding; ccw[k]: the triangle's xy projection is counter-clockwise as given
-    std::vector<u32> twin(3 * (size_t)nt, 0xffffffffu);
-    std::vector<unsigned char> ccw((size_t)nt, 1);
+    // (the local tests, the adjacency and the table itself: mcl_halfedge.h -- device-free, also compiled and walked on the
+    //  CPU under the host sanitizers)
+    std::vector<u32> twin;
+    std::vector<unsigned char> ccw;
     double g2 = 0.0;
-    for (int64_t k = 0; k < nt && ok; ++k) {
-      const u32 v[3] = {tris[3 * k], tris[3 * k + 1], tris[3 * k + 2]};
-      if (v[0] == v[1] || v[1] == v[2] || v[0] == v[2]) ok = false;
-      // slope of the triangle's plane
-      const float* p0 = verts + 3 * (size_t)v[0];
-      const float* p1 = verts + 3 * (size_t)v[1];
-      const float* p2 = verts + 3 * (size_t)v[2];
-      const double ax = (double)p1[0] - p0[0], ay = (double)p1[1] - p0[1], az = (double)p1[2] - p0[2];
-      const double bx = (double)p2[0] - p0[0], by = (double)p2[1] - p0[1], bz = (double)p2[2] - p0[2];
-      const double nz = ax * by - ay * bx, nx = ay * bz - az * by, ny = az * bx - ax * bz;
-      if (nz == 0.0) ok = false; else g2 = std::max(g2, (nx * nx + ny * ny) / (nz * nz));
-      ccw[(size_t)k] = nz > 0.0;
-    }
-    for (int64_t k = 0; k < nt && ok; ++k)
-      for (int e = 0; e < 3 && ok; ++e) {
-        const u32 a = tris[3 * k + e], b = tris[3 * k + (e + 1) % 3];
-        const uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
-        auto it = edge_first.find(key);
-        if (it == edge_first.end()) {
-          edge_first.emplace(key, 3 * k + e);
-        } else if (it->second < 0) {
-          ok = false;  // a third triangle on this edge
-        } else {
-          const int64_t k2 = it->second / 3;
-          const int e2 = (int)(it->second % 3);
-          // the two third vertices must lie on opposite sides of the edge in the xy projection (no fold)
-          const float* pa = verts + 3 * (size_t)a;
-          const float* pb = verts + 3 * (size_t)b;
-          const float* pc = verts + 3 * (size_t)tris[3 * k + (e + 2) % 3];
-          const float* pd = verts + 3 * (size_t)tris[3 * k2 + (e2 + 2) % 3];
-          const double ex = (double)pb[0] - pa[0], ey = (double)pb[1] - pa[1];
-          const double sc = ex * ((double)pc[1] - pa[1]) - ey * ((double)pc[0] - pa[0]);
-          const double sd = ex * ((double)pd[1] - pa[1]) - ey * ((double)pd[0] - pa[0]);
-          if (!(sc * sd < 0.0)) ok = false;
-          twin[3 * (size_t)k + e] = (u32)(3 * k2 + e2);
-          twin[3 * (size_t)k2 + e2] = (u32)(3 * k + e);
-          it->second = -1;
-        }
-      }
+    bool ok = halfedge::adjacency(verts, tris, nt, twin, ccw, g2);
     // ---- GLOBAL single-valuedness.  The edge tests above are local: two sheets that overlap in xy without sharing an
     // edge (a seabed and a wreck floating above it) pass them, and a walk by adjacency would never meet the upper
     // sheet.  Two triangles whose xy projections overlap with positive area are both recorded in some common cell
@@ -462,46 +398,10 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
       }
     }
     if (ok) {
-      // an edge without a second triangle: on the OUTER border of a rectangular map (both ends on the same side of
-      // the bounding box: 0xfffffff0 for an x side, 0xfffffff1 for a y side -- a slice that leaves there cannot
-      // come back, mcl_sweep.h) or anywhere else (a hole, a ragged outline: 0xffffffff)
-      const double eb = 1e-6 * std::max(1.0, std::max(xmax - xmin, ymax - ymin));
-      // the half-edge on the far side of input edge e of input triangle k, in the table's numbering: the table takes
-      // every triangle counter-clockwise in xy -- a clockwise one as (v0, v2, v1): its table edge j is its input edge
-      // 2 - j reversed, its table vertex j its input vertex (3 - j) % 3
-      auto far_side = [&](int64_t k, int e) -> u32 {
-        const u32 t = twin[3 * (size_t)k + e];
-        if (t == 0xffffffffu) {
-          const float* pa = verts + 3 * (size_t)tris[3 * k + e];
-          const float* pb = verts + 3 * (size_t)tris[3 * k + (e + 1) % 3];
-          const bool on_x = (std::fabs(pa[0] - xmin) <= eb && std::fabs(pb[0] - xmin) <= eb) ||
-                            (std::fabs(pa[0] - xmax) <= eb && std::fabs(pb[0] - xmax) <= eb);
-          const bool on_y = (std::fabs(pa[1] - ymin) <= eb && std::fabs(pb[1] - ymin) <= eb) ||
-                            (std::fabs(pa[1] - ymax) <= eb && std::fabs(pb[1] - ymax) <= eb);
-          return on_x ? 0xfffffff0u : (on_y ? 0xfffffff1u : 0xffffffffu);
-        }
-        const u32 k2 = t / 3u, e2 = t % 3u;
-        return 3u * new_of_old[k2] + (ccw[k2] ? e2 : 2u - e2);
-      };
-      std::vector<uint4> he(2 * 3 * (size_t)nt);
-      for (int64_t k = 0; k < nt; ++k) {
-        const bool c = ccw[(size_t)k] != 0;
-        for (int j = 0; j < 3; ++j) {   // table edge j of this triangle
-          // table vertices: j -> input vertex (c ? j : (3 - j) % 3); table edge j = (tv_j, tv_j+1) = input edge (c ? j : 2 - j)
-          const auto tv = [&](int q) { return tris[3 * k + (c ? q % 3 : (3 - q % 3) % 3)]; };
-          const auto te = [&](int q) { return c ? q % 3 : 2 - q % 3; };
-          const float* po = verts + 3 * (size_t)tv(j + 2);
-          const u32 na = far_side(k, te(j + 2)), nb = far_side(k, te(j + 1));
-          u32 bx, by, bz;
-          memcpy(&bx, po, 4);
-          memcpy(&by, po + 1, 4);
-          memcpy(&bz, po + 2, 4);
-          const size_t h = 3 * (size_t)new_of_old[(size_t)k] + j;
-          he[2 * h] = make_uint4(bx, by, bz, na);
-          he[2 * h + 1] = make_uint4(nb, 0u, 0u, 0u);
-        }
-      }
-      m->tin_he_bytes = sizeof(uint4) * he.size();
+      std::vector<halfedge::Rec> he;
+      halfedge::build_table(verts, tris, nt, twin, ccw, new_of_old, xmin, xmax, ymin, ymax, he);
+      static_assert(sizeof(halfedge::Rec) == 2 * sizeof(uint4), "the device reads a half-edge record as two 16-byte words");
+      m->tin_he_bytes = sizeof(halfedge::Rec) * he.size();
       if (hipMalloc(&m->tin_he, m->tin_he_bytes) == hipSuccess &&
           hipMemcpy(m->tin_he, he.data(), m->tin_he_bytes, hipMemcpyHostToDevice) == hipSuccess) {
         m->tin_ok = true;

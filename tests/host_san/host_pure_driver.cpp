@@ -2,6 +2,10 @@
 // AddressSanitizer + UBSan (make -C smarc_navigation_amd/csrc host-asan): mcl_host_pure.h (transfer plan of the resample
 // exchange, matrix_from_tf, euler_from_quat, Philox on the host), mcl_dr_impl.h (the dead-reckoning integrator, every
 // callback of sam_dead_reckoning/scripts/dr_node.py) and pf_core.hpp's parsers, driven with random and hostile inputs.
+// Round 6: mcl_halfedge.h -- the half-edge table of the TIN sweep -- built from random jittered meshes handed over in random
+// order with mixed windings, its invariants checked record by record, and WALKED on the CPU by the kernel's own rule
+// (mcl_sweep.h: sweep_side_tin -- the new vertex replaces the end on its side of the plane; which of next_a / next_b is
+// taken follows from that and from one bit of state) from every triangle a random vertical plane cuts to the mesh border.
 // Exit code 0 and no sanitizer report = pass; the properties checked here are the ones tests/test_exchange_plan.py and
 // tests/test_dr_golden.py check through the real library.
 #include <cstdio>
@@ -9,6 +13,7 @@
 #include <random>
 
 #include "../../smarc_navigation_amd/csrc/mcl_host_pure.h"
+#include "../../smarc_navigation_amd/csrc/mcl_halfedge.h"
 #include "../../smarc_navigation_amd/csrc/mcl_dr_impl.h"
 #include "auv_particle_filter_hip/pf_core.hpp"
 
@@ -20,8 +25,203 @@
     }                                                                       \
   } while (0)
 
+
+// ---- a jittered TIN over a (nx x ny)-node grid, every cell split along a random diagonal (synth.mesh_tin), then shuffled:
+// vertices renumbered, triangles permuted, corners rotated, half of the windings reversed (synth.mesh_shuffle)
+static void random_tin(std::mt19937_64& rng, int nx, int ny, std::vector<float>& verts, std::vector<uint32_t>& tris) {
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  std::vector<float> v0((size_t)nx * ny * 3);
+  for (int i = 0; i < nx; ++i)
+    for (int j = 0; j < ny; ++j) {
+      const bool inner = i > 0 && j > 0 && i < nx - 1 && j < ny - 1;
+      float* p = &v0[3 * ((size_t)i * ny + j)];
+      p[0] = (float)(i + (inner ? 0.25 * U(rng) : 0.0)) * 1.5f - 7.f;
+      p[1] = (float)(j + (inner ? 0.25 * U(rng) : 0.0)) * 1.5f + 3.f;
+      p[2] = (float)(-20.0 + 2.0 * std::sin(0.4 * i) * std::cos(0.3 * j) + 0.3 * U(rng));
+    }
+  std::vector<uint32_t> t0;
+  for (int i = 0; i + 1 < nx; ++i)
+    for (int j = 0; j + 1 < ny; ++j) {
+      const uint32_t a = (uint32_t)(i * ny + j), b = a + (uint32_t)ny, c = a + 1u, d = b + 1u;   // 00, 10, 01, 11
+      if (rng() & 1u) { t0.insert(t0.end(), {a, b, d}); t0.insert(t0.end(), {a, d, c}); }
+      else { t0.insert(t0.end(), {a, b, c}); t0.insert(t0.end(), {b, d, c}); }
+    }
+  const size_t nv = (size_t)nx * ny, nt = t0.size() / 3;
+  std::vector<uint32_t> perm(nv), where(nv), torder(nt);
+  for (size_t k = 0; k < nv; ++k) perm[k] = (uint32_t)k;
+  for (size_t k = 0; k < nt; ++k) torder[k] = (uint32_t)k;
+  std::shuffle(perm.begin(), perm.end(), rng);
+  std::shuffle(torder.begin(), torder.end(), rng);
+  for (size_t k = 0; k < nv; ++k) where[perm[k]] = (uint32_t)k;
+  verts.resize(3 * nv);
+  for (size_t k = 0; k < nv; ++k)
+    for (int c = 0; c < 3; ++c) verts[3 * k + c] = v0[3 * (size_t)perm[k] + c];
+  tris.resize(3 * nt);
+  for (size_t k = 0; k < nt; ++k) {
+    uint32_t v[3] = {where[t0[3 * (size_t)torder[k]]], where[t0[3 * (size_t)torder[k] + 1]], where[t0[3 * (size_t)torder[k] + 2]]};
+    const int rot = (int)(rng() % 3);
+    uint32_t w[3] = {v[rot], v[(rot + 1) % 3], v[(rot + 2) % 3]};
+    if (rng() & 1u) std::swap(w[1], w[2]);   // winding reversed
+    for (int c = 0; c < 3; ++c) tris[3 * k + c] = w[c];
+  }
+}
+
+static int check_halfedge_tables(std::mt19937_64& rng) {
+  using halfedge::Rec;
+  for (int trial = 0; trial < 40; ++trial) {
+    const int nx = 3 + (int)(rng() % 14), ny = 3 + (int)(rng() % 11);
+    std::vector<float> verts;
+    std::vector<uint32_t> tris;
+    random_tin(rng, nx, ny, verts, tris);
+    const int64_t nt = (int64_t)tris.size() / 3;
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (size_t i = 0; i < verts.size() / 3; ++i) {
+      xmin = std::min(xmin, (double)verts[3 * i]); xmax = std::max(xmax, (double)verts[3 * i]);
+      ymin = std::min(ymin, (double)verts[3 * i + 1]); ymax = std::max(ymax, (double)verts[3 * i + 1]);
+    }
+    std::vector<uint32_t> new_of_old, twin;
+    std::vector<unsigned char> ccw;
+    std::vector<Rec> he;
+    double g2 = 0.0;
+    halfedge::morton_order(verts.data(), tris.data(), nt, xmin, xmax, ymin, ymax, new_of_old);
+    {   // a permutation
+      std::vector<unsigned char> seen((size_t)nt, 0);
+      for (int64_t k = 0; k < nt; ++k) {
+        CHECK(new_of_old[(size_t)k] < (uint32_t)nt && !seen[new_of_old[(size_t)k]]);
+        seen[new_of_old[(size_t)k]] = 1;
+      }
+    }
+    CHECK(halfedge::adjacency(verts.data(), tris.data(), nt, twin, ccw, g2));
+    halfedge::build_table(verts.data(), tris.data(), nt, twin, ccw, new_of_old, xmin, xmax, ymin, ymax, he);
+    CHECK((int64_t)he.size() == 3 * nt);
+    auto vert = [&](uint32_t T, int j, float out[3]) {   // table vertex j of table triangle T: the record of edge j + 1 holds it
+      const Rec& r = he[3 * (size_t)T + (size_t)((j + 1) % 3)];
+      std::memcpy(out, &r.x, 12);
+    };
+    size_t borders = 0;
+    for (uint32_t T = 0; T < (uint32_t)nt; ++T) {
+      float v[3][3];
+      for (int j = 0; j < 3; ++j) vert(T, j, v[j]);
+      // counter-clockwise in xy
+      const double area = ((double)v[1][0] - v[0][0]) * ((double)v[2][1] - v[0][1]) - ((double)v[1][1] - v[0][1]) * ((double)v[2][0] - v[0][0]);
+      CHECK(area > 0.0);
+      for (int e = 0; e < 3; ++e) {
+        const Rec& r = he[3 * (size_t)T + e];
+        // next_a: across edge e + 2 = (v_e+2, v_e): the far half-edge runs v_e -> v_e+2; next_b: across (v_e+1, v_e+2): v_e+2 -> v_e+1
+        const uint32_t nxt[2] = {r.next_a, r.next_b};
+        const int from[2] = {e % 3, (e + 2) % 3}, to[2] = {(e + 2) % 3, (e + 1) % 3};
+        for (int s = 0; s < 2; ++s) {
+          if (nxt[s] >= 0xfffffff0u) {
+            CHECK(nxt[s] == halfedge::BORDER_X || nxt[s] == halfedge::BORDER_Y);   // (this mesh has no holes)
+            ++borders;
+            continue;
+          }
+          CHECK(nxt[s] < 3u * (uint32_t)nt);
+          const uint32_t T2 = nxt[s] / 3u;
+          const int e2 = (int)(nxt[s] % 3u);
+          CHECK(T2 != T);
+          float a[3], b[3];
+          vert(T2, e2, a);
+          vert(T2, (e2 + 1) % 3, b);
+          CHECK(std::memcmp(a, v[from[s]], 12) == 0 && std::memcmp(b, v[to[s]], 12) == 0);
+        }
+      }
+    }
+    CHECK(borders == (size_t)(2 * (nx - 1) + 2 * (ny - 1)) * 2);   // (every border edge is named by two records of its triangle)
+    // ---- walk: a vertical plane through a random interior point, outward on both sides from the triangle under it, by the
+    // kernel's rule.  Every step must cross an edge whose ends lie on opposite sides of the plane, s must not decrease
+    // (the slice of a height field by a vertical plane is a graph over s), and the walk must end at the OUTER border.
+    std::uniform_real_distribution<double> U01(0.0, 1.0);
+    long total_steps = 0;
+    for (int w = 0; w < 20; ++w) {
+      const double px = xmin + (0.2 + 0.6 * U01(rng)) * (xmax - xmin), py = ymin + (0.2 + 0.6 * U01(rng)) * (ymax - ymin);
+      const double ang = 6.283185307179586 * U01(rng);
+      const double c1x = std::cos(ang), c1y = std::sin(ang);      // across-track axis (s); plane normal = (-c1y, c1x, 0)
+      auto d_of = [&](const float* p) { return -c1y * ((double)p[0] - px) + c1x * ((double)p[1] - py); };
+      auto s_of = [&](const float* p) { return c1x * ((double)p[0] - px) + c1y * ((double)p[1] - py); };
+      // the triangle that contains (px, py)
+      int64_t T0 = -1;
+      for (uint32_t T = 0; T < (uint32_t)nt && T0 < 0; ++T) {
+        float v[3][3];
+        for (int j = 0; j < 3; ++j) vert(T, j, v[j]);
+        bool in = true;
+        for (int j = 0; j < 3 && in; ++j) {
+          const float* a = v[j];
+          const float* b = v[(j + 1) % 3];
+          in = ((double)b[0] - a[0]) * (py - a[1]) - ((double)b[1] - a[1]) * (px - a[0]) >= 0.0;
+        }
+        if (in) T0 = T;
+      }
+      CHECK(T0 >= 0);
+      for (int side = 0; side < 2; ++side) {
+        const double sg = side ? -1.0 : 1.0;
+        float v[3][3];
+        double d[3];
+        for (int j = 0; j < 3; ++j) {
+          vert((uint32_t)T0, j, v[j]);
+          d[j] = d_of(v[j]);
+        }
+        const bool p0 = d[0] >= 0, p1 = d[1] >= 0, p2 = d[2] >= 0;
+        if (p0 == p1 && p1 == p2) continue;   // (the plane grazes a vertex: the kernel declines too)
+        const int L = (p0 != p1 && p0 != p2) ? 0 : ((p1 != p0 && p1 != p2) ? 1 : 2);
+        const int M = (L + 1) % 3, N = (L + 2) % 3;
+        // crossings on edge L = (vL, vL+1) and edge L+2 = (vL+2, vL); this side leaves through the one further out
+        const double lm = d[L] / (d[L] - d[M]), ln = d[L] / (d[L] - d[N]);
+        const double sm = sg * (s_of(v[L]) + lm * (s_of(v[M]) - s_of(v[L]))), sn = sg * (s_of(v[L]) + ln * (s_of(v[N]) - s_of(v[L])));
+        if (sm == sn) continue;
+        const bool far_m = sm > sn;
+        const bool pl = d[L] >= 0;
+        // far side of edge j of T0: next_a of record (j + 1) % 3
+        const uint32_t fM = he[3 * (size_t)T0 + (size_t)((L + 1) % 3)].next_a, fN = he[3 * (size_t)T0 + (size_t)((L + 2 + 1) % 3)].next_a;
+        uint32_t nb = far_m ? fM : fN;
+        double Ad, Bd, As, Bs;   // A: found last (NF when pl), B: the other end of the exit edge
+        {
+          const int F = far_m ? M : N;
+          Ad = pl ? d[F] : d[L]; Bd = pl ? d[L] : d[F];
+          As = pl ? sg * s_of(v[F]) : sg * s_of(v[L]); Bs = pl ? sg * s_of(v[L]) : sg * s_of(v[F]);
+        }
+        bool ao = far_m == pl;
+        double s_prev = far_m ? sm : sn;
+        int steps = 0;
+        while (nb < 0xfffffff0u) {
+          CHECK(++steps <= 3 * nt);
+          CHECK((Ad >= 0) != (Bd >= 0));                 // the exit edge is cut by the plane
+          const Rec& r = he[nb];
+          float pN[3];
+          std::memcpy(pN, &r.x, 12);
+          const double dN = d_of(pN), sN = sg * s_of(pN);
+          const bool keep_a = (dN >= 0) != (Ad >= 0);    // the new vertex replaces the end on ITS side
+          const bool stays_a = keep_a == ao;
+          nb = stays_a ? r.next_a : r.next_b;
+          ao = !stays_a;
+          if (keep_a) { Bd = Ad; Bs = As; }
+          Ad = dN; As = sN;
+          const double lam = Ad / (Ad - Bd);
+          const double s_new = As + lam * (Bs - As);
+          CHECK(s_new >= s_prev - 1e-9);                  // outward, never back
+          s_prev = s_new;
+        }
+        CHECK(nb == halfedge::BORDER_X || nb == halfedge::BORDER_Y);
+        total_steps += steps;
+      }
+    }
+    CHECK(total_steps >= 20);   // (the walks did cross triangles)
+    // ---- meshes the walk must refuse: a triangle listed twice (three faces on an edge), a folded pair
+    {
+      std::vector<uint32_t> dup(tris);
+      dup.insert(dup.end(), tris.begin(), tris.begin() + 3);
+      CHECK(!halfedge::adjacency(verts.data(), dup.data(), nt + 1, twin, ccw, g2));
+      std::vector<float> fv = {0, 0, 0, 1, 0, 0, 0, 1, 0, 0.2f, 0.2f, 1};   // two triangles on edge (0,1), third vertices on the SAME side
+      std::vector<uint32_t> ft = {0, 1, 2, 1, 0, 3};
+      CHECK(!halfedge::adjacency(fv.data(), ft.data(), 2, twin, ccw, g2));
+    }
+  }
+  return 0;
+}
+
 int main() {
   std::mt19937_64 rng(12345);
+  if (check_halfedge_tables(rng) != 0) return 1;
   // ---- transfer plan: for random worlds, what q sends r is what r receives from q, and every lost slot is filled once
   for (int trial = 0; trial < 2000; ++trial) {
     const int world = 1 + (int)(rng() % 9);

@@ -5,7 +5,12 @@ AddressSanitizer + UBSan and ThreadSanitizer (`make -C smarc_navigation_amd/csrc
 
   * the device-free arithmetic of the library (mcl_host_pure.h: transfer plan of the resample exchange, matrix_from_tf,
     euler_from_quat, host Philox; mcl_dr_impl.h: every callback of the dead-reckoning integrator; pf_core.hpp's
-    parsers) under random and hostile inputs;
+    parsers) under random and hostile inputs; round 6: mcl_halfedge.h -- the half-edge table of the TIN sweep built from
+    random jittered meshes in random order and mixed windings, its invariants checked record by record (Morton
+    permutation, every triangle counter-clockwise, next_a / next_b name the half-edges that run the shared edges the
+    other way round, border codes) and WALKED on the CPU by the kernel's own rule from random points along random
+    vertical planes to the map border (every exit edge cut by the plane, s never decreases); meshes with three faces on
+    an edge or a folded pair refused;
   * the roscpp node, compiled UNCHANGED against the stand-in ROS, over a recording engine whose state is unsynchronised
     like the real handle's, with odometry / GPS + dive / pings + detections / timer arriving from four threads at once:
     ThreadSanitizer must see no race (the node's mutex is what the reference lacks), ASan no overrun of any buffer
