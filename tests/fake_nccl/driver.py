@@ -197,8 +197,9 @@ def main():
     if exchange == 'p2p':
         # records (maximum + totals + the previous step's moments), hand-over records; the moments' own all-reduce only
         # when a reader asks before the next step -- three steps back to back: 2 collectives each
-        assert max(cps) <= 2 and max(gps) <= 1, (cps, gps)
-        assert out[0]['tail_collectives'] <= 6, out[0]['tail_collectives']
+        ride = os.environ.get('MCL_MOMENTS_RIDE') != '0'   # (0: the all-reduce of the moments after every step, as in rounds 1-5)
+        assert max(cps) <= (2 if ride else 3) and max(gps) <= 1, (cps, gps)
+        assert out[0]['tail_collectives'] <= (6 if ride else 9), out[0]['tail_collectives']
     print(json.dumps(dict(ok=True, world=W, per_rank=NS, exchange=exchange, landmarks=with_lm, p2p_ops=[o for o, _ in ops],
                           states_sent=sent, lost_slots=lost, collectives_per_step=cps, p2p_groups_per_step=gps,
                           tail_collectives=out[0]['tail_collectives'])))

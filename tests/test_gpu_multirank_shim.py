@@ -27,8 +27,8 @@ def fake_nccl():
     return LIB
 
 
-def _run(lib, *args, timeout_s=60):
-    env = dict(os.environ, LD_PRELOAD=lib, FAKE_NCCL_TIMEOUT_S=str(timeout_s))
+def _run(lib, *args, timeout_s=60, **env_extra):
+    env = dict(os.environ, LD_PRELOAD=lib, FAKE_NCCL_TIMEOUT_S=str(timeout_s), **env_extra)
     env.pop('MCL_FORCE_COMM', None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'fake_nccl', 'driver.py')] + [str(a) for a in args],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
@@ -47,8 +47,15 @@ def test_ranks_over_the_exchange_of_copies_equal_the_unsharded_filter(fake_nccl,
     # the latency chain of a sharded step: TWO collectives -- the shards' records (maximum AND totals: one
     # latency where rounds 1-5 had two; the previous step's moments ride in them), the hand-over records -- and one group of
     # sends / receives; the moments' own all-reduce only when a reader comes before the next step
-    assert max(res['collectives_per_step']) <= 2 and max(res['p2p_groups_per_step']) <= 1, res
-    assert res['tail_collectives'] <= 6, res
+    assert max(res['collectives_per_step']) == 2 and max(res['p2p_groups_per_step']) <= 1, res
+    assert res['tail_collectives'] == 6, res
+
+
+def test_moments_all_reduced_after_every_step_when_asked_for(fake_nccl):
+    """MCL_MOMENTS_RIDE=0: the step's moments are all-reduced at its end (rounds 1-5) instead of riding with the next step's
+    records -- three collectives per step, the same filter bit for bit"""
+    res = _run(fake_nccl, 3, 30000, 'p2p', MCL_MOMENTS_RIDE='0')
+    assert max(res['collectives_per_step']) == 3 and res['tail_collectives'] == 9, res
 
 
 def test_ranks_over_the_all_gather_exchange_with_the_overlap_communicator(fake_nccl):
