@@ -60,7 +60,9 @@ enum mcl_comm_mode {
 
 enum mcl_weight_mode {
   MCL_WEIGHT_LINEAR_FLOOR = 0, /* w = exp(lw) + 1e-200   (auv_pf.py:165, GPS update) */
-  MCL_WEIGHT_LOG_SHIFT = 1,    /* w = exp(lw - max lw)   (MBES update, log domain) */
+  MCL_WEIGHT_LOG_SHIFT = 1,    /* w = exp(lw) 2^-K, K = rint(max lw x log2 e) + 1: relative to the power of two next above the largest
+                                * weight -- in (2^-3/2, 2^-1/2] of it -- so that a shard can form its weights before the cloud's maximum is
+                                * known (MBES update, log domain; rounds 1-5: exp(lw - max lw)) */
   MCL_WEIGHT_LINEAR = 2        /* the values ARE linear weights (mcl_resample_indices) */
 };
 
@@ -239,6 +241,8 @@ int mcl_get_log_weights(mcl_handle* h, double* lw);
 int mcl_set_log_weights(mcl_handle* h, const double* lw, int32_t weight_mode);
 int mcl_get_last_indices(mcl_handle* h, int32_t* idx);      /* FilterPy-style ancestor indices, n */
 int mcl_get_last_offspring_cdf(mcl_handle* h, uint32_t* ncum); /* n_global cumulative offspring counts */
+/* the fixed-point weights of the last resample, q_i = floor(w_i 2^s), s = 63 - ceil(log2 n_global), this shard's n of them, and
+ * their total over ALL shards: the integers every resampling decision was taken on (identical for any tiling / sharding) */
 int mcl_get_fixed_weights(mcl_handle* h, uint64_t* q, uint64_t* total);
 
 /* ---- one fused filter step, fully asynchronous on the handle's stream (bench / production):
