@@ -80,9 +80,10 @@ __device__ __forceinline__ float hw_max(float x, float y) {
 // The merge loop of the lattice sweep in assembly (gfx950): the beams of ONE segment (sp, tp) -> (sc, tc).  The arithmetic
 // is the C++ loop's, instruction for instruction (sweep_side keeps that loop for the sub-fan and expected-range kernels,
 // and tests/test_gpu_zz_merge_asm.py compares a build that takes it everywhere, bit for bit):
-//   e_prev = sp - T tp;  lam = clamp(e_prev / (e_prev - e_cur));  tau = tp + lam dts;
+//   D = dss - T dts;  tau = med3(num / D, tp, tc)   (seg_tau below: dss = sc - sp, num = tp dss - sp dts per segment);
 //   dd = max(z w - tau (w / cos a), (z - r_max) w);  acc += dd^2;  next record;  e_cur = sc - T' tc
-// 10.5 VALU per beam + one ds_read_b128 (the compiler's version of the loop: 14 -- it rotates a tangent queue through
+// 8 VALU per beam (9 with the clamp to r_max) + one ds_read_b128 -- rounds 4-5: 9 / 10 with lam = e_prev / (e_prev - e_cur)
+// clamped to [0, 1] and tau = tp + lam dts (the compiler's version of that loop: 14 -- it rotates a tangent queue through
 // three registers per beam, and its own unrolling fetches two records into different registers and copies them back).
 // * Record b of the beam table carries the tangent of the NEXT beam of its side (mcl_host_update.h:
 //   upload_sweep_beams; rounds 2-3: of the beam after that, a two-deep queue in registers).  The loop is unrolled
@@ -116,8 +117,7 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
 #define SWEEP_PREV_OFF 48u   // ... and the record one place back towards the nadir is at bp + 48 on either side
 // first half: the pending beam's tangent in TAN, its record in A = v[60:63] (.x: the next beam's tangent); fetches B
 #define SWEEP_MERGE_HALF1(TAN, OFF1, CLAMP)                                                     \
-      "v_fma_f32 %[ep], -" TAN ", %[tp], %[sp]\n\t"                                      \
-      "v_sub_f32 %[d], %[ep], %[ec]\n\t"                                                 \
+      "v_fma_f32 %[d], -" TAN ", %[dts], %[dss]\n\t"                                     \
       "s_waitcnt lgkmcnt(0)\n\t"                                                         \
       "v_fma_f32 %[e2], -v60, %[tc], %[sc]\n\t"                                          \
       "ds_read_b128 v[56:59], %[bp]" OFF1 "\n\t"                                         \
@@ -125,16 +125,15 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
       "v_cmp_le_f32 vcc, 0, %[e2]\n\t"                                                   \
       "s_andn2_b64 vcc, exec, vcc\n\t"                                                   \
       "s_or_b64 %[odd], %[odd], vcc\n\t"                                                 \
-      "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"                                       \
-      "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"                                        \
+      "v_mul_f32 %[ep], %[num], %[d]\n\t"                                                \
+      "v_med3_f32 %[ep], %[ep], %[tp], %[tc]\n\t"                                        \
       "v_fma_f32 %[ep], -%[ep], v61, v62\n\t"                                            \
       CLAMP("v_max_f32 %[ep], %[ep], v63\n\t")                                           \
       "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"                                              \
       "s_andn2_b64 exec, exec, vcc\n\t"
 // second half: the pending beam's tangent in A.x = v60, its record in B = v[56:59]; fetches A, moves bp by two records
 #define SWEEP_MERGE_HALF2(OFF2, STEP2, CLAMP)                                                   \
-      "v_fma_f32 %[ep], -v60, %[tp], %[sp]\n\t"                                          \
-      "v_sub_f32 %[d], %[ep], %[e2]\n\t"                                                 \
+      "v_fma_f32 %[d], -v60, %[dts], %[dss]\n\t"                                         \
       "s_waitcnt lgkmcnt(0)\n\t"                                                         \
       "v_fma_f32 %[ec], -v56, %[tc], %[sc]\n\t"                                          \
       "ds_read_b128 v[60:63], %[bp]" OFF2 "\n\t"                                         \
@@ -142,8 +141,8 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
       "v_rcp_f32 %[d], %[d]\n\t"                                                         \
       "v_cmp_le_f32 vcc, 0, %[ec]\n\t"                                                   \
       "s_nop 0\n\t"                                                                      \
-      "v_mul_f32_e64 %[ep], %[ep], %[d] clamp\n\t"                                       \
-      "v_fma_f32 %[ep], %[ep], %[dts], %[tp]\n\t"                                        \
+      "v_mul_f32 %[ep], %[num], %[d]\n\t"                                                \
+      "v_med3_f32 %[ep], %[ep], %[tp], %[tc]\n\t"                                        \
       "v_fma_f32 %[ep], -%[ep], v57, v58\n\t"                                            \
       CLAMP("v_max_f32 %[ep], %[ep], v59\n\t")                                           \
       "v_fmac_f32 %[acc], %[ep], %[ep]\n\t"                                              \
@@ -177,8 +176,8 @@ typedef float sweep_rec __attribute__((ext_vector_type(4)));   // {side-signed t
   SWEEP_MERGE_ASM_TEXT(" offset:48", " offset:64", " offset:80", " offset:96", "v_add_u32 %[bp], 32, %[bp]", "v_add_u32 %[bp], 16, %[bp]", L1, L9, CLAMP)
 #define SWEEP_MERGE_SIDE1(L1, L9, CLAMP) \
   SWEEP_MERGE_ASM_TEXT(" offset:48", " offset:32", " offset:16", "", "v_subrev_u32 %[bp], 32, %[bp]", "v_subrev_u32 %[bp], 16, %[bp]", L1, L9, CLAMP)
-__device__ __forceinline__ void sweep_merge_asm(int sel, float& acc, unsigned& bp, float sp, float tp, float sc, float tc,
-                                                float dts) {
+__device__ __forceinline__ void sweep_merge_asm(int sel, float& acc, unsigned& bp, float dss, float num, float tp, float sc,
+                                                float tc, float dts) {
   float ep, d, ec, e2;
   unsigned long long sav, odd;
   asm volatile("s_cmp_lt_u32 %[sel], 2\n\t"
@@ -200,7 +199,7 @@ __device__ __forceinline__ void sweep_merge_asm(int sel, float& acc, unsigned& b
                "60:"
                : [acc] "+v"(acc), [bp] "+v"(bp),
                  [ep] "=&v"(ep), [d] "=&v"(d), [ec] "=&v"(ec), [e2] "=&v"(e2), [sav] "=&s"(sav), [odd] "=&s"(odd)
-               : [sp] "v"(sp), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts), [sel] "s"(sel)
+               : [dss] "v"(dss), [num] "v"(num), [tp] "v"(tp), [sc] "v"(sc), [tc] "v"(tc), [dts] "v"(dts), [sel] "s"(sel)
                : "vcc", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
@@ -208,6 +207,14 @@ __device__ __forceinline__ void sweep_merge_asm(int sel, float& acc, unsigned& b
 // in sweep_merge_asm, so that every kernel resolves a degenerate beam (0 / 0) alike.  (s_nop: an operand may come
 // straight from v_rcp_f32, and gfx950 wants one instruction between a transcendental and the first use of its result --
 // the compiler's hazard pass cannot see into an asm statement.)
+// The crossing of the half line s = T t with the segment (sp, tp) -> (sc, tc), as its t: with ds = sc - sp, dt = tc - tp,
+//   tau = (tp ds - sp dt) / (ds - T dt) = num / D,   num a constant of the segment, D one fma per beam
+// -- taken between the segment's ends by v_med3_f32 (a beam that runs along its segment: D -> 0, any t of the segment is
+// right; D = 0, num = 0: NaN -> med3 returns the smaller end).  Rounds 2-5 formed lam = e_prev / (e_prev - e_cur) clamped to
+// [0, 1] and tau = tp + lam dt: one instruction more per beam.  The same three instructions in sweep_merge_asm.
+__device__ __forceinline__ float seg_tau(float num, float D, float tp, float tc) {
+  return __builtin_amdgcn_fmed3f(num * __builtin_amdgcn_rcpf(D), tp, tc);
+}
 __device__ __forceinline__ float mul_clamp01(float x, float y) {
   float r;
   asm("s_nop 0\n\tv_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(y));
@@ -432,19 +439,18 @@ __device__ __forceinline__ bool sweep_side(const MbesArgs& a, const MbesPose& P,
     //  4 ny < 2^23 -- checked on the host --: the full-rate 24-bit multiply)
     const float hN = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(grsrc, __mul24(ni, ny4) + ((nj << 2) + g0b), 0, 0));
     const float dts = tc - tp;
+    const float dss = sc - sp, num = fmaf(tp, dss, -(sp * dts));   // (the segment's constants of seg_tau)
     {
       // (no end-of-table test: the record beyond the last beam has tan a = +inf and tc > 0, so e_cur = -inf.  The
       //  loop is rotated: e_cur of the NEXT beam is formed at the end of the body, one compare decides)
       float e_cur = fmaf(-tcur, tc, sc);
       if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-        sweep_merge_asm(msel, acc, bp, sp, tp, sc, tc, dts);   // (msel = side + 2 noclamp: wave-uniform)
+        sweep_merge_asm(msel, acc, bp, dss, num, tp, sc, tc, dts);   // (msel = side + 2 noclamp: wave-uniform)
       } else {
         // one beam on the segment (prev -> cur): the crossing of the half line s = t tan a with the chord (e changes
         // sign: <= 0 at prev, >= 0 at cur); then on to the next beam of the table
         while (e_cur >= 0.f && (!SUB || bp != bp_end)) {   // until the pending beam passes beyond this vertex
-          const float e_prev = fmaf(-tcur, tp, sp);
-          const float lam = mul_clamp01(e_prev, fast_rcp(e_prev - e_cur));
-          const float tau = fmaf(lam, dts, tp);
+          const float tau = seg_tau(num, fmaf(-tcur, dts, dss), tp, tc);
           // range = t / cos a, beyond r_max (or NaN): r_max.  The table carries the residual's constants
           // (mcl_host_update.h: upload_sweep_beams): (range_b - r) w = max(z w - t (w / cos a), (z - r_max) w)
           if (EXPECT_ONLY) {
@@ -1068,14 +1074,13 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const uint4 hq = he_xyzn(nb);
     const u32 hb = he_nb(nb);
     const float dts = tc - tp;
+    const float dss = sc - sp, num = fmaf(tp, dss, -(sp * dts));   // (the segment's constants of seg_tau)
     if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-      sweep_merge_asm(msel, acc, bp, sp, tp, sc, tc, dts);   // (msel = side + 2 noclamp: wave-uniform)
+      sweep_merge_asm(msel, acc, bp, dss, num, tp, sc, tc, dts);   // (msel = side + 2 noclamp: wave-uniform)
     } else {
       float e_cur = fmaf(-tcur, tc, sc);
       while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
-        const float e_prev = fmaf(-tcur, tp, sp);
-        const float lam = mul_clamp01(e_prev, fast_rcp(e_prev - e_cur));
-        const float tau = fmaf(lam, dts, tp);
+        const float tau = seg_tau(num, fmaf(-tcur, dts, dss), tp, tc);
         if (EXPECT_ONLY) {
           exp_row[(int)(bp - sb_off) >> 4] = fminf(tau * bm.y, a.r_max);
         } else {
