@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOT = ('k_mbes_sweep', 'k_mbes_fast', 'k_mbes_cast', 'k_mbes_pose', 'k_mbes_classify', 'k_predict', 'k_quantise_tiles',
-       'k_cdf_expand', 'k_resample_gather', 'k_pack_dupes', 'k_offspring_cdf', 'k_gps_logw', 'k_landmark_update',
+       'k_quantise_shard', 'k_shift_scan', 'k_visit_scan', 'k_cdf_expand', 'k_resample_gather', 'k_pack_dupes', 'k_offspring_cdf', 'k_gps_logw', 'k_landmark_update',
        'k_mean_partial', 'k_cov_partial', 'k_max_slots')
 
 
