@@ -216,31 +216,6 @@ __device__ __forceinline__ u64 quantise_weight(double lw, double m_lw, int mode,
   return (u64)((w / mw) * scale);
 }
 
-// pass 1: per-tile sums of q (tile = MCL_SCAN_TILE consecutive particles)
-__global__ void __launch_bounds__(MCL_BLOCK) k_q_tile_sums(const double* __restrict__ lw, long long n,
-                                                           const double* __restrict__ m_lw, int mode,
-                                                           double scale, int s, u64* __restrict__ q,
-                                                           u64* __restrict__ tile_sum) {
-  __shared__ u64 sh[16];
-  const double m = m_lw[0];
-  for (long long tile = blockIdx.x; tile * MCL_SCAN_TILE < n; tile += gridDim.x) {
-    const long long base = tile * MCL_SCAN_TILE;
-    u64 acc = 0;
-#pragma unroll
-    for (int k = 0; k < MCL_SCAN_ITEMS; ++k) {
-      long long i = base + (long long)k * MCL_BLOCK + threadIdx.x;
-      if (i < n) {
-        u64 qi = quantise_weight(lw[i], m, mode, scale, s);
-        q[i] = qi;
-        acc += qi;
-      }
-    }
-    acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) tile_sum[tile] = acc;
-    __syncthreads();
-  }
-}
-
 // pass 2: exclusive scan of the tile sums in one block (T = u64 or u32); total -> total_out[0]
 template <class T>
 __global__ void __launch_bounds__(1024) k_scan_tile_sums(T* __restrict__ tile_sum, long long ntiles,

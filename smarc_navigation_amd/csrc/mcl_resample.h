@@ -121,9 +121,9 @@ __global__ void __launch_bounds__(MCL_SCAN_TILE) k_quantise_shard(QuantArgs a) {
   const int top = any ? 63 - __builtin_clzll(any) : -1;   // (wave-uniform)
   u32 mine = 0u;
   if (top >= 0) {
-    long long x = (long long)(q << (63 - top));   // bit `top` in the sign position
+    u64 x = q << (63 - top);   // bit `top` in the top position
     for (int b = top; b >= 0; --b) {
-      const u32 c = (u32)__popcll(__ballot(x < 0));
+      const u32 c = (u32)__popcll(__ballot((long long)x < 0));
       mine = lane == b ? c : mine;
       x <<= 1;
     }

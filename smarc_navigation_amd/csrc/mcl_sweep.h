@@ -203,10 +203,6 @@ __device__ __forceinline__ void sweep_merge_asm(int sel, float& acc, unsigned& b
                : "vcc", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
-// a * b clamped to [0, 1] by the multiplier's output modifier (NaN -> 0): the same instruction in the C++ merge loops and
-// in sweep_merge_asm, so that every kernel resolves a degenerate beam (0 / 0) alike.  (s_nop: an operand may come
-// straight from v_rcp_f32, and gfx950 wants one instruction between a transcendental and the first use of its result --
-// the compiler's hazard pass cannot see into an asm statement.)
 // The crossing of the half line s = T t with the segment (sp, tp) -> (sc, tc), as its t: with ds = sc - sp, dt = tc - tp,
 //   tau = (tp ds - sp dt) / (ds - T dt) = num / D,   num a constant of the segment, D one fma per beam
 // -- taken between the segment's ends by v_med3_f32 (a beam that runs along its segment: D -> 0, any t of the segment is
@@ -214,11 +210,6 @@ __device__ __forceinline__ void sweep_merge_asm(int sel, float& acc, unsigned& b
 // [0, 1] and tau = tp + lam dt: one instruction more per beam.  The same three instructions in sweep_merge_asm.
 __device__ __forceinline__ float seg_tau(float num, float D, float tp, float tc) {
   return __builtin_amdgcn_fmed3f(num * __builtin_amdgcn_rcpf(D), tp, tc);
-}
-__device__ __forceinline__ float mul_clamp01(float x, float y) {
-  float r;
-  asm("s_nop 0\n\tv_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(y));
-  return r;
 }
 
 struct SweepNode {
