@@ -182,6 +182,16 @@ def build_map(kind):
     return dict(kind=kind, z=z, origin=origin, res=1.0, verts=verts, tris=tris, bytes=mb, bytes_what=what, desc=desc)
 
 
+def punch_hole(m, x, y, radius=0.8):
+    """The mesh without the triangles whose centroid lies within `radius` of (x, y): a data gap (mesh_build: border edges
+    inside the bounding box; a slice that reaches one ends the adjacency walk and the particle is handed over)."""
+    import numpy as np
+    c = m['verts'][m['tris'].astype(np.int64)].mean(axis=1)
+    gone = np.hypot(c[:, 0] - x, c[:, 1] - y) < radius
+    return dict(m, tris=np.ascontiguousarray(m['tris'][~gone]),
+                desc=m['desc'] + ', %d triangles around (%g, %g) missing' % (int(gone.sum()), x, y))
+
+
 def attach_map(e, m):
     if m['kind'] == 'grid':
         e.set_map_grid(m['z'], m['origin'], m['res'])
@@ -360,10 +370,12 @@ def mbes_path(e, P):
     """Which kernels cast the last MBES update (mcl_mbes_last_path): the fan sweep (regularly triangulated
     meshes) or the ray traversal, and how much of the cloud the first stage passed on to the general kernels."""
     path, handed, deferred = e.mbes_last_path()
+    by_slice, by_trav = e.mbes_last_handover()
     return {'algorithm': {1: 'fan sweep (mcl_sweep.h: k_mbes_sweep)', 2: 'fan slice (mcl_slice.h: k_mbes_slice)'}.get(
                 path, 'ray traversal (mcl_mbes.h: k_mbes_fast)'),
             'dominant_launch': {1: 'k_mbes_sweep<SURF,false>', 2: 'k_mbes_slice<false>'}.get(path, 'k_mbes_fast<SURF,false>'),
-            'particles_handed_to_traversal': handed if path in (1, 2) else None,
+            'particles_handed_to_traversal': by_trav if path in (1, 2) else None,
+            'particles_handed_to_fan_slice': by_slice if path == 1 else None,
             'groups_deferred_to_general_kernel': deferred, 'of_particles': P}
 
 
@@ -860,6 +872,10 @@ def worker(a, rank, world, local_rank):
         if a.map != 'mesh-tin-shuffled':
             legs.append(('mesh_tin_shuffled', dict(m=build_map('mesh-tin-shuffled'), P=1048576, B=512, steps=50, warmup=40)))
         legs.append(('mesh_tin_tempered', dict(m=tin, P=1048576, B=512, steps=30, warmup=10, sigma=SIGMA * math.sqrt(512.0))))
+        # ... and the same TIN with a data gap of ten triangles under the swath of the timed steps: every particle's slice runs
+        # into it, the sweep hands the whole cloud over -- to the fan slice (mcl_host_update.h; round 5 / MCL_HANDOVER_SLICE=0:
+        # to the ray traversal, 21 ms per step).  The worst case of a survey mesh with gaps, not its average.
+        legs.append(('mesh_tin_hole_under_swath', dict(m=punch_hole(tin, 1.0, 10.0), P=1048576, B=512, steps=20, warmup=10)))
         # global-localisation regime: sigma = 50 m cloud that nothing collapses (no resample).  Particles are
         # initialised around the odom origin (auv_particle.py:24), so the map <- odom transform puts that
         # origin 250 m inside the map; 'cloud_wide_at_border' leaves it 64 m from the western border, where

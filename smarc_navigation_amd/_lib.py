@@ -103,6 +103,7 @@ SYMBOLS = {
     'mcl_timing_enable': (C.c_int, [_vp, _i32]),
     'mcl_timing_get': (C.c_int, [_vp, C.POINTER(Timing)]),
     'mcl_mbes_last_path': (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'mcl_mbes_last_handover': (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'mcl_mbes_visit_order': (C.c_int, [_vp, _vp, C.POINTER(C.c_int32)]),
     # include/mcl_dr.h: the dead-reckoning integrator (host only)
     'mcl_dr_create': (C.c_int, [C.POINTER(DrConfig), C.POINTER(_vp)]),

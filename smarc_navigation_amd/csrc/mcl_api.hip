@@ -89,6 +89,7 @@ int mcl_create(const mcl_config* cfg, mcl_handle** out) {
     if (const char* sv = getenv("MCL_SWEEP")) h->env_sweep = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_SLICE")) h->env_slice = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_SLICE_GROUP")) h->env_slice_group = sv[0] == '1' ? 1 : 0;
+    if (const char* sv = getenv("MCL_HANDOVER_SLICE")) h->env_handover_slice = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_VISIT")) h->env_visit = sv[0] == '1' ? 1 : 0;
     if (const char* sv = getenv("MCL_VISIT_BINS")) {
       int b[3] = {0, 0, 0};
@@ -178,7 +179,7 @@ int mcl_destroy(mcl_handle* h) {
   if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
   void* bufs[] = {h->state[0], h->state[1], h->state_glob, h->lw, h->wnorm, h->q, h->ncum, h->zcum, h->zr, h->dupes32, h->desc, h->ctrl,
                   h->tile64, h->tile32, h->part, h->scal, h->totals, h->idx, h->replay_dev, h->pose7,
-                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_buf[0], h->sweep_buf[1], h->defer_idx, h->visit_okey, h->visit_base, h->visit_cnt, h->visit_desc, h->visit_par, h->slice_loose, h->reasons_dev, h->grid_pad, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
+                  h->beam_sc, h->ranges_dev, h->exp_dev, h->grid, h->pose_dev, h->mbes_worklist, h->mbes_groups, h->sort_keys, h->sort_keys_out, h->sort_idx, h->mbes_perm, h->sort_tmp, h->sweep_buf[0], h->sweep_buf[1], h->defer_idx, h->defer2_idx, h->visit_okey, h->visit_base, h->visit_cnt, h->visit_desc, h->visit_par, h->slice_loose, h->reasons_dev, h->grid_pad, h->lm_worklist, h->cq, h->u53, h->cnt, h->first,
                   h->flags, h->fcum, h->copies, h->ccum, h->dupes, h->cs, h->chunk, h->uni_dev, h->lsx, h->xsend, h->xrecv, h->shrec, h->tile_bits};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1208,6 +1209,20 @@ int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64
       *deferred_groups = -1;   // (no groups: every particle cast on its own)
     }
   }
+  return MCL_OK;
+}
+
+int mcl_mbes_last_handover(mcl_handle* h, int64_t* by_slice, int64_t* by_traversal) {
+  if (!h) return MCL_ERR_INVALID;
+  RET_IF(set_device(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int first = 0, second = 0;
+  HIPCHK(h, hipMemcpy(&first, h->ctrl + CTRL_DEFER, sizeof first, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(&second, h->ctrl + CTRL_DEFER2, sizeof second, hipMemcpyDeviceToHost));
+  const bool staged = h->sweep_now && h->handover_slice_now;
+  if (!h->sweep_now && !h->slice_now) first = 0;
+  if (by_slice) *by_slice = staged ? first - second : 0;
+  if (by_traversal) *by_traversal = staged ? second : first;
   return MCL_OK;
 }
 

@@ -10,6 +10,16 @@
 //   word 4 (next_b): the half-edge on the far side of edge e+1 = (v_e+1, v_e+2)
 //   word 5 .. 7: unused
 // (0xffffffff: hole / ragged border, 0xfffffff0 / 0xfffffff1: the map's outer x / y border.)
+//
+// HOLES THE WALK CAN CROSS (link_holes): behind the 3 nt half-edge records follow RIM records, one per edge of every small
+// closed hole -- a data gap of a survey: a boundary loop of at most RIM_MAX edges that runs clockwise around empty space
+// and touches the map's outer border nowhere.  The far side of such an edge names its rim record (index >= 3 nt) instead
+// of HOLE:
+//   word 0 .. 2: x, y, z of the edge's ORIGIN a (the interior half-edge runs a -> b, the hole on its right)
+//   word 3: the rim record of the next edge around the hole (it starts at b)
+//   word 4: the interior half-edge itself -- the walk re-enters the mesh THROUGH it
+// A slice that reaches the hole goes around its rim once, finds the nearest edge further out that the fan plane cuts,
+// lets the beams that look into the gap miss, and walks on from there (mcl_sweep.h: sweep_side_tin, SURF 6).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -144,6 +154,84 @@ inline void build_table(const float* verts, const uint32_t* tris, int64_t nt, co
       he[3 * (size_t)new_of_old[(size_t)k] + j] = r;
     }
   }
+}
+
+// Rim records for the holes a walk can cross (see the top of the file).  Boundary loops are traced through the table itself
+// (the far side of edge j of triangle T is next_a of record 3 T + (j + 1) % 3 and next_b of record 3 T + (j + 2) % 3; its
+// origin is the vertex of record 3 T + (j + 1) % 3): from a boundary half-edge a -> b the next one around the same empty
+// face starts at b and is found by turning about b through the triangles of its fan -- which pairs the edges properly
+// even where two fans touch in a vertex.  With the mesh on the left a loop runs CLOCKWISE around a hole and counter-
+// clockwise around a piece of mesh; crossing a hole by its own rim alone is exact only if nothing else lies in it, so
+// holes are linked only when the mesh has ONE counter-clockwise loop (one edge-connected piece, no islands).  Returns the
+// number of rim records appended; he keeps its first 3 nt records in place.
+constexpr int RIM_MAX = 48;
+inline size_t link_holes(std::vector<Rec>& he, int64_t nt) {
+  const size_t nhe = 3 * (size_t)nt;
+  if (he.size() != nhe) return 0;
+  auto far_of = [&](size_t T, int j) -> uint32_t& { return he[3 * T + (size_t)((j + 1) % 3)].next_a; };
+  auto far_of_b = [&](size_t T, int j) -> uint32_t& { return he[3 * T + (size_t)((j + 2) % 3)].next_b; };
+  auto origin = [&](size_t T, int j) -> const Rec& { return he[3 * T + (size_t)((j + 1) % 3)]; };
+  auto fl = [](uint32_t w) {
+    float f;
+    std::memcpy(&f, &w, 4);
+    return (double)f;
+  };
+  std::vector<unsigned char> seen(nhe, 0);
+  struct Loop {
+    size_t first, len;
+  };
+  std::vector<uint32_t> edges;   // the boundary half-edges (3 T + j), loop after loop
+  std::vector<Loop> holes;
+  int outlines = 0;
+  for (size_t h0 = 0; h0 < nhe; ++h0) {
+    if (seen[h0] || far_of(h0 / 3, (int)(h0 % 3)) < 0xfffffff0u) continue;
+    const size_t first = edges.size();
+    bool on_border = false;
+    double area2 = 0.0;
+    size_t h = h0;
+    for (size_t guard = 0;; ++guard) {
+      if (guard > nhe || seen[h]) return 0;   // (cannot happen on a table that passed adjacency())
+      seen[h] = 1;
+      edges.push_back((uint32_t)h);
+      const size_t T = h / 3;
+      const int j = (int)(h % 3);
+      on_border |= far_of(T, j) != HOLE;
+      const Rec& a = origin(T, j);
+      const Rec& b = origin(T, (j + 1) % 3);
+      area2 += fl(a.x) * fl(b.y) - fl(b.x) * fl(a.y);
+      // the next boundary edge around this face: turn about b
+      size_t g = 3 * T + (size_t)((j + 1) % 3);
+      for (size_t turn = 0; far_of(g / 3, (int)(g % 3)) < 0xfffffff0u; ++turn) {
+        if (turn > nhe) return 0;
+        const uint32_t t = far_of(g / 3, (int)(g % 3));   // runs (end of g) -> b in the neighbour
+        g = 3 * (size_t)(t / 3u) + (size_t)((t % 3u + 1u) % 3u);
+      }
+      h = g;
+      if (h == h0) break;
+    }
+    if (area2 > 0.0)
+      ++outlines;
+    else if (!on_border && edges.size() - first <= (size_t)RIM_MAX)
+      holes.push_back(Loop{first, edges.size() - first});
+  }
+  if (outlines != 1 || holes.empty()) return 0;
+  size_t nrim = 0;
+  for (const Loop& L : holes) nrim += L.len;
+  if ((nhe + nrim) * sizeof(Rec) >= (size_t)1 << 31) return 0;   // (the device addresses the table by 32-bit byte offsets)
+  he.reserve(nhe + nrim);
+  for (const Loop& L : holes) {
+    const size_t base = he.size();
+    for (size_t q = 0; q < L.len; ++q) {
+      const uint32_t h = edges[L.first + q];
+      const size_t T = h / 3;
+      const int j = (int)(h % 3);
+      const Rec a = origin(T, j);
+      he.push_back(Rec{a.x, a.y, a.z, (uint32_t)(base + (q + 1) % L.len), h, 0, 0, 0});
+      far_of(T, j) = (uint32_t)(base + q);
+      far_of_b(T, j) = (uint32_t)(base + q);
+    }
+  }
+  return nrim;
 }
 
 }  // namespace halfedge

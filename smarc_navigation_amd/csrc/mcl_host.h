@@ -41,6 +41,7 @@
 #define CTRL_T_EXPAND (CTRL_WORK + 16)
 #define CTRL_T_GATHER (CTRL_WORK + 20)
 #define CTRL_T_VISIT (CTRL_WORK + 24)
+#define CTRL_DEFER2 (CTRL_WORK + 28)       // int: particles the fan slice, as the TIN sweep's hand-over kernel, handed on to the general kernel
 #define CTRL_SLOTS2 1024                   // a second set of MCL_MAX_SLOTS u64: max lw after the fused landmark update
 #define CTRL_BYTES 2048
 
@@ -143,6 +144,8 @@ struct mcl_handle {
   int sweep_sel = 0;
   hipStream_t copy_stream = nullptr;
   u32* defer_idx = nullptr;         // particles the sweep hands to k_mbes_cast<., ., 2>
+  u32* defer2_idx = nullptr;        // TIN with holes: what the fan slice -- the sweep's hand-over kernel there -- declines in turn
+  int env_handover_slice = -1;      // MCL_HANDOVER_SLICE=0: the ray traversal takes the TIN sweep's hand-overs even on meshes with holes (A/B)
   unsigned* reasons_dev = nullptr;  // -DSWEEP_REASONS builds: why the sweep declined (16 counters)
   // spatial visiting order of the sweep (mcl_kernels.h: VisitArgs): prepared by the fused step's gather, used by the
   // next fused predict
@@ -165,6 +168,7 @@ struct mcl_handle {
   int env_nsub = 0;                 // MCL_SWEEP_NSUB=1/2/4 forces the lanes per particle side (A/B)
   bool sweep_now = false;           // decided by the first launch_mbes call of an update
   bool slice_now = false;           // ... the fan slice (mcl_slice.h) casts it
+  bool handover_slice_now = false;  // the last update's sweep hand-overs went through the fan slice first (TIN with holes)
   int env_slice = -1;               // MCL_SLICE=0 keeps the ray traversal on triangle soups (tests, A/B)
   int env_slice_group = -1;         // MCL_SLICE_GROUP=0: the fan slice casts every particle on its own (no shared candidate lists)
   u32* slice_loose = nullptr;       // k_mbes_slice_group: the groups of SLICE_G pose records it left to k_mbes_slice

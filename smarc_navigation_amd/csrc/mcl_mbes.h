@@ -78,6 +78,7 @@ struct MeshArgs {
   float cs;
   const uint4* tin_he;     // fan sweep over a TIN: one 32-byte record per half-edge {x, y, z of the opposite vertex, next_a | next_b, -, -, -} (mcl_mesh.h)
   u32 tin_he_bytes;        // ... its size (read through a raw buffer)
+  u32 tin_nhe;             // ... its half-edge records (3 x triangles); behind them the rim records of the holes the walk crosses (mcl_halfedge.h)
   const float4* cell_tri;  // fan slice (mcl_slice.h): the three vertices (x, y, z, -), map frame, of every (cell, triangle) record, indexed like `tri`
   double x0, y0;           // map-frame position of cell (0, 0)'s corner
 };
@@ -131,6 +132,8 @@ struct MbesArgs {
   const int* n_dev;           // when set, the classify / cast kernels visit *n_dev entries of perm instead of a.n
   int* host_count;            // pinned host word (or nullptr): k_mbes_cast<.,.,2> leaves the hand-over count there
   int slice;                  // 1: this update is cast by the fan slice (mcl_slice.h)
+  const u32* in_list;         // fan slice as the HAND-OVER kernel of the TIN sweep (round 6): it casts the *in_count pose records in_list names
+  const int* in_count;        //   (the sweep's hand-over list; nullptr: all a.n records) and hands what it declines on through defer_idx / defer_count
   // visiting order (mcl_kernels.h: VisitArgs) for the stand-alone pose kernel: when set, k_mbes_pose<false> stores the record
   // of slot i at its sorted position (the fused step's predict kernel does the same from its own arguments)
   const u32* visit_okey;

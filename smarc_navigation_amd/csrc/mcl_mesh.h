@@ -49,6 +49,8 @@ struct MeshDev {
   uint4* tin_he = nullptr;
   size_t tin_he_bytes = 0;
   bool tin_ok = false;
+  size_t tin_rims = 0;      // rim records behind the 3 nt half-edge records: the edges of the holes the walk crosses by itself (mcl_halfedge.h: link_holes)
+  bool tin_holes = false;   // some edge of the TIN has no triangle on its far side and does not lie on the bounding box: a hole or a ragged outline (walks that reach it hand their particle over)
   // fan slice over an arbitrary triangle soup (mcl_slice.h): per (cell, triangle) record the three vertices of its source
   // triangle in MAP-FRAME coordinates, 3 float4 {x, y, z, -}, same indexing as `tri`.  (Absolute, not cell-relative: a
   // vertex has the same bits in every record it appears in, so the slices of two triangles that share an edge meet in
@@ -401,6 +403,10 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
       std::vector<halfedge::Rec> he;
       halfedge::build_table(verts, tris, nt, twin, ccw, new_of_old, xmin, xmax, ymin, ymax, he);
       static_assert(sizeof(halfedge::Rec) == 2 * sizeof(uint4), "the device reads a half-edge record as two 16-byte words");
+      const bool link = !(getenv("MCL_TIN_RIMS") && atoi(getenv("MCL_TIN_RIMS")) == 0);   // (0: no hole is crossed -- A/B, tests)
+      m->tin_rims = link ? halfedge::link_holes(he, nt) : 0;
+      m->tin_holes = m->tin_rims != 0;
+      for (size_t q = 0; q < 3 * (size_t)nt && !m->tin_holes; ++q) m->tin_holes = he[q].next_a == halfedge::HOLE || he[q].next_b == halfedge::HOLE;
       m->tin_he_bytes = sizeof(halfedge::Rec) * he.size();
       if (hipMalloc(&m->tin_he, m->tin_he_bytes) == hipSuccess &&
           hipMemcpy(m->tin_he, he.data(), m->tin_he_bytes, hipMemcpyHostToDevice) == hipSuccess) {
@@ -549,6 +555,7 @@ inline MeshArgs mesh_args(const MeshDev* m) {
   ma.cs = (float)m->cs;
   ma.tin_he = m->tin_he;
   ma.tin_he_bytes = (u32)m->tin_he_bytes;
+  ma.tin_nhe = (u32)(m->tin_he_bytes / sizeof(halfedge::Rec) - m->tin_rims);
   ma.cell_tri = m->cell_tri;
   ma.x0 = m->x0;
   ma.y0 = m->y0;

