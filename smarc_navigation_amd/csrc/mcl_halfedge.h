@@ -18,6 +18,8 @@
 //   word 0 .. 2: x, y, z of the edge's ORIGIN a (the interior half-edge runs a -> b, the hole on its right)
 //   word 3: the rim record of the next edge around the hole (it starts at b)
 //   word 4: the interior half-edge itself -- the walk re-enters the mesh THROUGH it
+//   word 5, 6: the first rim record of this hole and the number of its edges (the records of a hole lie together, in rim order:
+//              the walk reads them by index -- loads that do not wait for one another)
 // A slice that reaches the hole goes around its rim once, finds the nearest edge further out that the fan plane cuts,
 // lets the beams that look into the gap miss, and walks on from there (mcl_sweep.h: sweep_side_tin, SURF 6).
 #pragma once
@@ -226,7 +228,7 @@ inline size_t link_holes(std::vector<Rec>& he, int64_t nt) {
       const size_t T = h / 3;
       const int j = (int)(h % 3);
       const Rec a = origin(T, j);
-      he.push_back(Rec{a.x, a.y, a.z, (uint32_t)(base + (q + 1) % L.len), h, 0, 0, 0});
+      he.push_back(Rec{a.x, a.y, a.z, (uint32_t)(base + (q + 1) % L.len), h, (uint32_t)base, (uint32_t)L.len, 0});
       far_of(T, j) = (uint32_t)(base + q);
       far_of_b(T, j) = (uint32_t)(base + q);
     }

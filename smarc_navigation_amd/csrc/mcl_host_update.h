@@ -536,13 +536,17 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       s2.defer_count = (int*)(h->ctrl + CTRL_DEFER2);
       s2.slice_loose = nullptr;
       s2.host_count = wh_cur + 2;   // (pinned: how many particles the SWEEP handed over -- the cast below reports what the slice handed on)
-      const bool few_h = wh_prev[2] == 0;
+      // (both kernels stride over their lists and every workgroup of them builds the ping's beam tables first -- 0.5 ms for
+      //  4 096 workgroups that then find a handful of particles: the grids follow the count of two updates ago, doubled,
+      //  and never fall below 512 workgroups -- those without work leave at once, mcl_slice.h -- so that the first two
+      //  updates of a cloud that runs into a ragged outline all at once are not cast by 64)
+      const long long h_prev = 2ll * std::max(wh_prev[2], 0);
       const size_t lds_s = ((size_t)B * (2 + SLICE_WAVES) + (size_t)SLICE_WAVES * (SLICE_LIST + 1)) * sizeof(float) + SLICE_LUT * sizeof(unsigned short);
       const size_t lds_g = (size_t)B * (3 + SLICE_G_WAVES) * sizeof(float) + (size_t)SLICE_G_TRIS * 9 * sizeof(float) +
                            SLICE_G_HASH * sizeof(unsigned) + SLICE_LUT * sizeof(unsigned short);
       const bool fits = lds_g + 4096 <= (size_t)160 * 1024 && h->env_slice_group != 0;
-      // (usually the list is empty: both launches small unless the last update handed particles over)
-      const unsigned hgrid = few_h ? 64u : 4096u;
+      const unsigned hgrid = (unsigned)std::min<long long>(std::max<long long>((h_prev + SLICE_G - 1) / SLICE_G, 512), 4096);
+      const unsigned pgrid = (unsigned)std::min<long long>(std::max<long long>((h_prev + SLICE_WAVES - 1) / SLICE_WAVES, 512), 2048);
       if (fits) {
         if (!h->slice_attr_set || lds_g > h->slice_attr_bytes) {
           HIPCHK(h, hipFuncSetAttribute((const void*)k_mbes_slice_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
@@ -553,7 +557,7 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
         s2.slice_loose_count = (int*)(h->ctrl + CTRL_LOOSE);
         k_mbes_slice_group<<<(unsigned)std::min<long long>(ngr, hgrid), SLICE_G_THREADS, lds_g, h->stream>>>(s2);
       }
-      k_mbes_slice<false><<<few_h ? 64u : 2048u, SLICE_THREADS, lds_s, h->stream>>>(s2);
+      k_mbes_slice<false><<<pgrid, SLICE_THREADS, lds_s, h->stream>>>(s2);
       d.perm = h->defer2_idx;
       d.n_dev = s2.defer_count;
       k_mbes_cast<1, false, 2><<<dgrid, MBES_THREADS, 0, h->stream>>>(d);

@@ -98,6 +98,14 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
   unsigned* rng_all = (unsigned*)(tsb + B);          // SLICE_WAVES x B: nearest crossing per beam (float bits)
   unsigned* tl_all = rng_all + (size_t)SLICE_WAVES * B;   // SLICE_WAVES x (SLICE_LIST + 1): the wave's triangle list, its length
   unsigned short* lut = (unsigned short*)(tl_all + (size_t)SLICE_WAVES * (SLICE_LIST + 1));   // SLICE_LUT: first beam at or beyond a tangent bucket's lower end
+  if (!EXPECT_ONLY && a.in_list) {
+    // the TIN sweep's hand-over kernel: mostly there is nothing on the list -- a workgroup without work leaves before it
+    // builds the tables (the host sizes the grid by the count of two updates ago; a cloud that runs into a ragged
+    // outline all at once still finds workgroups enough)
+    const long long n0 = a.slice_loose ? (long long)*a.slice_loose_count * SLICE_G : (long long)*a.in_count;
+    if (a.host_count && blockIdx.x == 0 && threadIdx.x == 0) *a.host_count = *a.in_count;   // (the sweep's hand-over count: sizes these launches two updates on)
+    if ((long long)blockIdx.x * SLICE_WAVES >= n0) return;
+  }
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     const float2 sc = a.beam_sc[b];
     const float sec = __builtin_amdgcn_rcpf(sc.y);
@@ -134,7 +142,6 @@ __global__ void __launch_bounds__(SLICE_THREADS, 4) k_mbes_slice(MbesArgs a) {
   // (as the TIN sweep's hand-over kernel: positions run over the sweep's list, in_list[p] is the pose record)
   const long long n_in = a.in_list ? (long long)*a.in_count : a.n;
   const long long n_it = listed ? (long long)*a.slice_loose_count * SLICE_G : n_in;
-  if (a.in_list && a.host_count && blockIdx.x == 0 && threadIdx.x == 0) *a.host_count = (int)n_in;   // (the sweep's hand-over count: sizes these launches two updates on)
   for (long long it = (long long)blockIdx.x * SLICE_WAVES + w; it < n_it; it += (long long)gridDim.x * SLICE_WAVES) {
     const long long p_in = listed ? (long long)a.slice_loose[it / SLICE_G] * SLICE_G + it % SLICE_G : it;
     if (p_in >= n_in) continue;
@@ -431,6 +438,7 @@ __global__ void __launch_bounds__(SLICE_G_THREADS, 6) k_mbes_slice_group(MbesArg
   __shared__ float g_ref[24];     // the reference member's geometry and the group's widened extents
   __shared__ int g_int[8];        // k_lo, k_hi, Im, Iq, major_x, tight, ntri
   __shared__ unsigned g_ntri, g_ncand;
+  if (a.in_list && (long long)blockIdx.x * SLICE_G >= (long long)*a.in_count) return;   // (hand-over kernel: nothing for this workgroup -- before the tables)
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     const float2 sc = a.beam_sc[b];
     const float sec = __builtin_amdgcn_rcpf(sc.y);

@@ -44,13 +44,16 @@
 #ifndef SWEEP_MIN_WAVES_TIN
 #define SWEEP_MIN_WAVES_TIN 6
 #endif
+#define SWEEP_TIN_GAPS 12   // gaps a side of a fan crosses by their rims before the particle is handed over (mcl_sweep.h: sweep_side_tin<.., HOLES>)
 #ifndef SWEEP_MIN_WAVES
 #define SWEEP_MIN_WAVES 8   // waves per SIMD the register budget is held to (<= 64 VGPRs)
 #endif
 
 // why a lane declined its particle: 1 position / tilt / footprint, 5 no nadir hit inside r_max, 6-8 degenerate start,
 // 9 sensor under a grid's surface, 10 border the slice may re-cross, 11 step limit, 12 seabed above the horizon,
-// 13 TIN: hole or ragged outline.  -DSWEEP_REASONS counts them in MbesArgs::reasons[code] (tools/sweep_reasons.py).
+// 13 TIN: hole without rim records or ragged outline, 14 TIN: no way on from a rim (or more than SWEEP_TIN_GAPS gaps on one
+// side), 15 TIN: the slice dips under a beam that looked into a gap, 4 TIN: nadir in a gap / off the mesh.
+// -DSWEEP_REASONS counts them in MbesArgs::reasons[code] (tools/sweep_reasons.py).
 #ifdef SWEEP_REASONS
 #define SWEEP_NOTE(code) do { if (a.reasons) atomicAdd(&a.reasons[(code) & 15], 1u); } while (0)
 #else
@@ -952,10 +955,10 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   s_stop += 2.f * res;
   // (no footprint test: the walk goes from triangle to triangle through the adjacency table and ends at the mesh's
   //  border -- at the OUTER border of a rectangular map for good, under the rule of sweep_side's second pass)
-  if (!pre) return false;
+  if (!pre) SWEEP_FAIL(1);
   u32 T = 0xffffffffu;
   const float r0 = tin_nadir(a, I0, J0, ul, vl, oz, -P.c2[0], -P.c2[1], -c2z, T);
-  if (!(r0 < a.r_max) || T == 0xffffffffu) return false;
+  if (!(r0 < a.r_max) || T == 0xffffffffu) SWEEP_FAIL(4);
   if (none) return true;
   // plane and in-plane coordinates from (x - Ox, y - Oy, z - Oz) in metres
   const double Ox = ma.x0 + P.um * (double)ma.cs, Oy = ma.y0 + P.vm * (double)ma.cs;
@@ -1007,7 +1010,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const TinNode N0 = node_of(q1), N1 = node_of(q2), N2 = node_of(q0);
     const u32 f0 = q1.w, f1 = q2.w, f2 = q0.w;   // far side of edge 0 = (v0, v1), 1 = (v1, v2), 2 = (v2, v0)
     const bool p0b = __float_as_int(N0.d) >= 0, p1b = __float_as_int(N1.d) >= 0, p2b = __float_as_int(N2.d) >= 0;   // (sides of the plane by the sign bit, like the walk)
-    if (p0b == p1b && p1b == p2b) return false;
+    if (p0b == p1b && p1b == p2b) SWEEP_FAIL(6);
     const int L = (p0b != p1b && p0b != p2b) ? 0 : ((p1b != p0b && p1b != p2b) ? 1 : 2);
     // local vertices L, L+1, L+2; the plane crosses edge L (vL, vL+1) and edge L+2 (vL+2, vL)
     const TinNode NL = sel(L == 0, N0, sel(L == 1, N1, N2));
@@ -1018,7 +1021,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     const float lm = NL.d * fast_rcp(NL.d - NM.d), ln = NL.d * fast_rcp(NL.d - NN.d);
     const float sm = fmaf(lm, NM.s - NL.s, NL.s), tm = fmaf(lm, NM.t - NL.t, NL.t);
     const float sn = fmaf(ln, NN.s - NL.s, NL.s), tn = fmaf(ln, NN.t - NL.t, NL.t);
-    if (!(sm != sn)) return false;
+    if (!(sm != sn)) SWEEP_FAIL(7);
     const bool far_m = sm > sn;
     const TinNode NF = sel(far_m, NM, NN);
     const bool pl = __float_as_int(NL.d) >= 0;
@@ -1032,7 +1035,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     t_cur = far_m ? tm : tn;
     s_prev = far_m ? sn : sm;
     t_prev = far_m ? tn : tm;
-    if (!(t_cur > 0.f)) return false;
+    if (!(t_cur > 0.f)) SWEEP_FAIL(8);
   }
   float acc = 0.f;
   bool ok = true;
@@ -1057,6 +1060,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     bm.w = r.w;
   }
   float gap_tan = -__builtin_inff();   // (HOLES) the largest tangent of a gap some beam of this lane looked into
+  int gaps = 0;                        // (HOLES) gaps crossed on this side
   // the beams of the segment (dss, num, tp) -> (sc, tc): sweep_merge_asm, or -- expected ranges, runs of a side's beams, the
   // compiler-built variant -- the same loop in C++
   const auto merge = [&](const int sel_, const float dss, const float num, const float tp, const float sc, const float tc, const float dts) {
@@ -1106,20 +1110,26 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
         const float sb = fast_sqrt(fmaxf(1.f - c2z * c2z, 0.f));
         const float lhs = sb * (a.sweep_slope + sb), rhs = 0.9f * (c2z - a.sweep_slope * sb);
         ok = (nb != 0xffffffffu) & (lhs < rhs * fabsf(nb == 0xfffffff0u ? P.c1[0] : P.c1[1]));
+        if (!ok) SWEEP_NOTE(nb == 0xffffffffu ? 13 : 10);
         return true;  // (ok: the beams left get r_max through the tail below)
       }
       // A HOLE WITH A RIM (mcl_halfedge.h: link_holes): nb names the rim record of the edge the slice has just reached --
       // hq is that record.  Once around the rim: of the edges the fan plane cuts, the nearest one further out is where
       // the slice meets the mesh again (nothing lies inside a linked hole).
+      // (the hole's records lie together in rim order: read by index, the loads do not wait for one another)
       const u32 k0 = nb;
-      u32 cur = hq.w, best = 0xffffffffu;
-      uint4 qc = he_xyzn(cur);
-      TinNode Nc = node_of(qc), BA = Nc, BB = Nc;
+      const u32 rbase = (u32)__builtin_amdgcn_raw_buffer_load_b32(hrsrc, (int)(k0 << 5) + 20, 0, 0);
+      const u32 rlen = (u32)__builtin_amdgcn_raw_buffer_load_b32(hrsrc, (int)(k0 << 5) + 24, 0, 0);
+      u32 pos = k0 - rbase + 1u;
+      pos -= pos >= rlen ? rlen : 0u;
+      u32 cur = rbase + pos, best = 0xffffffffu;
+      TinNode Nc = node_of(he_xyzn(cur)), BA = Nc, BB = Nc;
       float bs = __builtin_inff(), bt = 0.f;
-      for (int g = 0; g < halfedge::RIM_MAX && cur != k0; ++g) {
-        const u32 nxt = qc.w;
-        const uint4 qn = he_xyzn(nxt);
-        const TinNode Nn = node_of(qn);
+      for (u32 g = 2; g <= rlen; ++g) {   // edges (v_k0+1, v_k0+2) ... (v_k0-1, v_k0): every edge of the rim but the one reached
+        pos += 1u;
+        pos -= pos >= rlen ? rlen : 0u;
+        const u32 nxt = rbase + pos;
+        const TinNode Nn = node_of(he_xyzn(nxt));
         if ((__float_as_int(Nc.d) ^ __float_as_int(Nn.d)) < 0) {
           const float lam = Nc.d * fast_rcp(Nc.d - Nn.d);
           const float sx = fmaf(lam, Nn.s - Nc.s, Nc.s), tx = fmaf(lam, Nn.t - Nc.t, Nc.t);
@@ -1131,10 +1141,12 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
           BB = sel(take, Nn, BB);
         }
         cur = nxt;
-        qc = qn;
         Nc = Nn;
       }
-      if (best == 0xffffffffu || !(bt > 0.f)) {
+      // (a slice through a rim vertex can find the two cuts there in either order and go back and forth between the gap and
+      //  a sliver: a side crosses SWEEP_TIN_GAPS gaps at most)
+      if (best == 0xffffffffu || !(bt > 0.f) || ++gaps > SWEEP_TIN_GAPS) {
+        SWEEP_NOTE(14);
         ok = false;
         return true;
       }
@@ -1160,6 +1172,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
       hb = he_nb(nb);
     }
     if (decltype(EXITS)::value && step > max_steps) {
+      SWEEP_NOTE(11);
       ok = false;
       return true;
     }
@@ -1186,6 +1199,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     // (HOLES: ... and not at a smaller tangent than a gap a beam looked into -- gap_tan = -inf until then: the fma is
     //  + inf for t > 0 and NaN or - inf otherwise, and v_min returns the number)
     if (!((HOLES ? fminf(tp, fmaf(-gap_tan, tp, sp)) : tp) > 0.f)) {
+      SWEEP_NOTE(tp > 0.f ? 15 : 12);
       ok = false;
       return true;
     }

@@ -304,6 +304,8 @@ static int check_hole_rims(std::mt19937_64& rng) {
     for (size_t k = nhe; k < nhe + nrim; ++k) {
       const Rec& r = he[k];
       CHECK(r.next_a >= nhe && r.next_a < nhe + nrim && r.next_b < nhe);
+      CHECK(r.pad0 >= nhe && r.pad1 >= 3 && r.pad1 <= (uint32_t)halfedge::RIM_MAX && k >= r.pad0 && k < (size_t)r.pad0 + r.pad1);   // the hole's records lie together ...
+      CHECK(r.next_a == r.pad0 + (uint32_t)((k - r.pad0 + 1) % r.pad1) && he[r.next_a].pad0 == r.pad0 && he[r.next_a].pad1 == r.pad1);   // ... in rim order
       const uint32_t h = r.next_b, T = h / 3u;
       const int j = (int)(h % 3u);
       CHECK(he[3 * (size_t)T + (size_t)((j + 1) % 3)].next_a == (uint32_t)k && he[3 * (size_t)T + (size_t)((j + 2) % 3)].next_b == (uint32_t)k);
