@@ -50,6 +50,7 @@ struct MeshDev {
   size_t tin_he_bytes = 0;
   bool tin_ok = false;
   size_t tin_rims = 0;      // rim records behind the 3 nt half-edge records: the edges of the holes the walk crosses by itself (mcl_halfedge.h: link_holes)
+  u32* cell_rim = nullptr;   // per cell of the cell grid: the first rim record of the linked hole whose bounding box reaches into the cell (0xffffffff: none, 0xfffffffe: more than one) -- where a walk starts whose nadir ray falls into a gap
   bool tin_holes = false;   // some edge of the TIN has no triangle on its far side and does not lie on the bounding box: a hole or a ragged outline (walks that reach it hand their particle over)
   // fan slice over an arbitrary triangle soup (mcl_slice.h): per (cell, triangle) record the three vertices of its source
   // triangle in MAP-FRAME coordinates, 3 float4 {x, y, z, -}, same indexing as `tri`.  (Absolute, not cell-relative: a
@@ -90,6 +91,7 @@ inline void mesh_free(MeshDev* m) {
   if (m->heights) (void)hipFree(m->heights);
   if (m->heights_pad) (void)hipFree(m->heights_pad);
   if (m->tin_he) (void)hipFree(m->tin_he);
+  if (m->cell_rim) (void)hipFree(m->cell_rim);
   if (m->cell_tri) (void)hipFree(m->cell_tri);
   delete m;
 }
@@ -407,9 +409,33 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
       m->tin_rims = link ? halfedge::link_holes(he, nt) : 0;
       m->tin_holes = m->tin_rims != 0;
       for (size_t q = 0; q < 3 * (size_t)nt && !m->tin_holes; ++q) m->tin_holes = he[q].next_a == halfedge::HOLE || he[q].next_b == halfedge::HOLE;
+      std::vector<uint32_t> cell_rim;
+      if (m->tin_rims) {
+        // which hole may lie under a sensor: every cell the hole's bounding box reaches into names the hole's first rim
+        // record (the walk itself decides by parity whether its nadir ray goes through THAT hole, mcl_sweep.h)
+        cell_rim.assign(nc, 0xffffffffu);
+        for (size_t k = 3 * (size_t)nt; k < he.size(); k += he[k].pad1) {
+          float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f;
+          for (size_t q = k; q < k + he[k].pad1; ++q) {
+            float x, y;
+            memcpy(&x, &he[q].x, 4);
+            memcpy(&y, &he[q].y, 4);
+            bx0 = std::min(bx0, x), bx1 = std::max(bx1, x), by0 = std::min(by0, y), by1 = std::max(by1, y);
+          }
+          const int i0 = std::max(0, (int)std::floor((bx0 - m->x0) / m->cs) - 1), i1 = std::min(m->gx - 1, (int)std::floor((bx1 - m->x0) / m->cs) + 1);
+          const int j0 = std::max(0, (int)std::floor((by0 - m->y0) / m->cs) - 1), j1 = std::min(m->gy - 1, (int)std::floor((by1 - m->y0) / m->cs) + 1);
+          for (int i = i0; i <= i1; ++i)
+            for (int j = j0; j <= j1; ++j) {
+              uint32_t& c = cell_rim[(size_t)i * m->gy + j];
+              c = c == 0xffffffffu ? (uint32_t)k : 0xfffffffeu;
+            }
+        }
+      }
       m->tin_he_bytes = sizeof(halfedge::Rec) * he.size();
       if (hipMalloc(&m->tin_he, m->tin_he_bytes) == hipSuccess &&
-          hipMemcpy(m->tin_he, he.data(), m->tin_he_bytes, hipMemcpyHostToDevice) == hipSuccess) {
+          hipMemcpy(m->tin_he, he.data(), m->tin_he_bytes, hipMemcpyHostToDevice) == hipSuccess &&
+          (cell_rim.empty() || (hipMalloc(&m->cell_rim, 4 * cell_rim.size()) == hipSuccess &&
+                                hipMemcpy(m->cell_rim, cell_rim.data(), 4 * cell_rim.size(), hipMemcpyHostToDevice) == hipSuccess))) {
         m->tin_ok = true;
         m->slope_max = std::sqrt(g2);
       } else {
@@ -555,6 +581,7 @@ inline MeshArgs mesh_args(const MeshDev* m) {
   ma.cs = (float)m->cs;
   ma.tin_he = m->tin_he;
   ma.tin_he_bytes = (u32)m->tin_he_bytes;
+  ma.cell_rim = m->cell_rim;
   ma.tin_nhe = (u32)(m->tin_he_bytes / sizeof(halfedge::Rec) - m->tin_rims);
   ma.cell_tri = m->cell_tri;
   ma.x0 = m->x0;

@@ -958,8 +958,11 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   if (!pre) SWEEP_FAIL(1);
   u32 T = 0xffffffffu;
   const float r0 = tin_nadir(a, I0, J0, ul, vl, oz, -P.c2[0], -P.c2[1], -c2z, T);
-  if (!(r0 < a.r_max) || T == 0xffffffffu) SWEEP_FAIL(4);
-  if (none) return true;
+  // (HOLES: no triangle under the sensor may mean that its nadir ray goes through a linked hole -- the walk then starts
+  //  at the hole's rim, below)
+  const bool in_gap = HOLES && T == 0xffffffffu && ma.cell_rim != nullptr;
+  if ((!(r0 < a.r_max) || T == 0xffffffffu) && !in_gap) SWEEP_FAIL(4);
+  if (none && !in_gap) return true;
   // plane and in-plane coordinates from (x - Ox, y - Oy, z - Oz) in metres
   const double Ox = ma.x0 + P.um * (double)ma.cs, Oy = ma.y0 + P.vm * (double)ma.cs;
   const float Oxf = (float)Ox, Oyf = (float)Oy, dOx = (float)(Ox - (double)Oxf), dOy = (float)(Oy - (double)Oyf);
@@ -998,11 +1001,71 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   const auto he_nb = [&](u32 h) {     // next_b
     return (u32)__builtin_amdgcn_raw_buffer_load_b32(hrsrc, (int)(h << 5) + 16, 0, 0);
   };
+  // Once around the rim of a linked hole (mcl_halfedge.h: its `cnt` edges from the one at place `pos` of the rim records
+  // rbase .. rbase + rlen - 1, read by index: the loads do not wait for one another): of the edges the fan plane cuts beyond
+  // s_min, the nearest -- its rim record, its two ends (the interior half-edge runs CA -> CB), the cut (cs, ct) -- and how many
+  // there are.
+  struct RimCut {
+    u32 best, cuts;
+    float cs, ct;
+    TinNode CA, CB;
+  };
+  const auto rim_cut = [&](const u32 rbase, const u32 rlen, u32 pos, const u32 cnt, const float s_min, const bool strict) {
+    RimCut r;
+    r.best = 0xffffffffu;
+    r.cuts = 0u;
+    r.cs = __builtin_inff();
+    r.ct = 0.f;
+    pos -= pos >= rlen ? rlen : 0u;
+    u32 cur = rbase + pos;
+    TinNode Nc = node_of(he_xyzn(cur));
+    r.CA = Nc;
+    r.CB = Nc;
+    for (u32 g = 0; g < cnt; ++g) {
+      pos += 1u;
+      pos -= pos >= rlen ? rlen : 0u;
+      const u32 nxt = rbase + pos;
+      const TinNode Nn = node_of(he_xyzn(nxt));
+      if ((__float_as_int(Nc.d) ^ __float_as_int(Nn.d)) < 0) {
+        const float lam = Nc.d * fast_rcp(Nc.d - Nn.d);
+        const float sx = fmaf(lam, Nn.s - Nc.s, Nc.s), tx = fmaf(lam, Nn.t - Nc.t, Nc.t);
+        const bool beyond = strict ? sx > s_min : sx >= s_min;
+        r.cuts += beyond ? 1u : 0u;
+        const bool take = beyond && sx < r.cs;
+        r.cs = take ? sx : r.cs;
+        r.ct = take ? tx : r.ct;
+        r.best = take ? cur : r.best;
+        r.CA = sel(take, Nc, r.CA);
+        r.CB = sel(take, Nn, r.CB);
+      }
+      cur = nxt;
+      Nc = Nn;
+    }
+    return r;
+  };
   TinNode A, Bn;
   u32 nb;    // the half-edge through which the slice enters the next triangle (or a border code)
   bool ao;   // is A the ORIGIN of that half-edge (in the next triangle's own counter-clockwise order)?
   float s_prev, t_prev, s_cur, t_cur;
-  {
+  if (HOLES && in_gap) {
+    // the nadir ray found no triangle: does it go through a linked hole?  The sensor's cell names the candidate (mcl_mesh.h:
+    // cell_rim); the fan plane cuts its rim an even number of times, and the ray -- s = 0 -- runs between two cuts, through
+    // the gap, exactly when an ODD number of them lies on this side's s > 0.  Then the nearest is where this side's slice
+    // meets the mesh, and the beams up to its tangent look into the gap.  (Both sides of a particle test the same rim:
+    // they agree, up to a cut at s = 0 to rounding -- one side then declines and the particle is handed over.)
+    const u32 rb = ma.cell_rim[(size_t)I0 * ma.gy + J0];
+    if (rb >= 0xfffffffeu) SWEEP_FAIL(4);
+    const u32 rlen = (u32)__builtin_amdgcn_raw_buffer_load_b32(hrsrc, (int)(rb << 5) + 24, 0, 0);
+    const RimCut rc = rim_cut(rb, rlen, 0u, rlen, 0.f, true);
+    if (!(rc.cuts & 1u) || !(rc.ct > 0.f)) SWEEP_FAIL(4);
+    if (none) return true;
+    A = rc.CA;
+    Bn = rc.CB;
+    ao = true;
+    nb = he_nb(rc.best);
+    s_cur = s_prev = rc.cs;   // (the walk's first segment is the point on the rim: the beams up to it are taken by the gap, below)
+    t_cur = t_prev = rc.ct;
+  } else {
     // triangle T through its three records: 3 T + e holds the vertex opposite edge e, v_e+2, and -- next_a -- the
     // half-edge on the far side of edge e + 2.  So vertex j comes from record (j + 1) % 3 and the far side of edge j
     // from the same record
@@ -1087,6 +1150,20 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
       }
     }
   };
+  // (HOLES) the beams that look into a gap whose far rim the slice meets at (xs, xt) -- tangents up to xs / xt, by the merge's
+  // own test against that point scaled by a power of two (the next segment starts there: no beam between the two tests) --
+  // hit nothing: each takes its clamp value (z - r_max) w, what the tail sums hold for the beams beyond the end of a walk.
+  // By the merge itself, on a segment so far away that every crossing lies beyond r_max (always the statement WITH the
+  // clamp).  Such a beam runs on UNDER the seabed beyond the hole: should the slice ever dip below it again -- a later vertex
+  // at a smaller tangent -- it would come up against the seabed from below, which the merge cannot know: gap_tan
+  // remembers the tangent, and the walk's t > 0 test carries the comparison.
+  const auto gap_beams = [&](const float xs, const float xt) {
+    const float K = 0x1p60f;
+    const unsigned bp_in = bp;
+    merge(msel & 1, 1.f, 1.f, xt * K, xs * K, xt * K, 0.f);
+    gap_tan = bp != bp_in ? fmaxf(gap_tan, xs * fast_rcp(xt)) : gap_tan;
+  };
+  if (HOLES && in_gap) gap_beams(s_cur, t_cur);   // (the nadir ray goes through a gap: the beams from the nadir to the rim)
   // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the neighbour.  The new
   // vertex of the slice takes the place of the one before last and the CALLER swaps the roles (the loop is unrolled by
   // two).  Returns true when the walk is over.  EXITS: as in sweep_side, the tests that end a walk normally run every
@@ -1116,33 +1193,12 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
       // A HOLE WITH A RIM (mcl_halfedge.h: link_holes): nb names the rim record of the edge the slice has just reached --
       // hq is that record.  Once around the rim: of the edges the fan plane cuts, the nearest one further out is where
       // the slice meets the mesh again (nothing lies inside a linked hole).
-      // (the hole's records lie together in rim order: read by index, the loads do not wait for one another)
       const u32 k0 = nb;
       const u32 rbase = (u32)__builtin_amdgcn_raw_buffer_load_b32(hrsrc, (int)(k0 << 5) + 20, 0, 0);
       const u32 rlen = (u32)__builtin_amdgcn_raw_buffer_load_b32(hrsrc, (int)(k0 << 5) + 24, 0, 0);
-      u32 pos = k0 - rbase + 1u;
-      pos -= pos >= rlen ? rlen : 0u;
-      u32 cur = rbase + pos, best = 0xffffffffu;
-      TinNode Nc = node_of(he_xyzn(cur)), BA = Nc, BB = Nc;
-      float bs = __builtin_inff(), bt = 0.f;
-      for (u32 g = 2; g <= rlen; ++g) {   // edges (v_k0+1, v_k0+2) ... (v_k0-1, v_k0): every edge of the rim but the one reached
-        pos += 1u;
-        pos -= pos >= rlen ? rlen : 0u;
-        const u32 nxt = rbase + pos;
-        const TinNode Nn = node_of(he_xyzn(nxt));
-        if ((__float_as_int(Nc.d) ^ __float_as_int(Nn.d)) < 0) {
-          const float lam = Nc.d * fast_rcp(Nc.d - Nn.d);
-          const float sx = fmaf(lam, Nn.s - Nc.s, Nc.s), tx = fmaf(lam, Nn.t - Nc.t, Nc.t);
-          const bool take = sx >= sc && sx < bs;
-          bs = take ? sx : bs;
-          bt = take ? tx : bt;
-          best = take ? cur : best;
-          BA = sel(take, Nc, BA);
-          BB = sel(take, Nn, BB);
-        }
-        cur = nxt;
-        Nc = Nn;
-      }
+      const RimCut rc = rim_cut(rbase, rlen, k0 - rbase + 1u, rlen - 1u, sc, false);   // (every edge of the rim but the one reached)
+      const u32 best = rc.best;
+      const float bs = rc.cs, bt = rc.ct;
       // (a slice through a rim vertex can find the two cuts there in either order and go back and forth between the gap and
       //  a sliver: a side crosses SWEEP_TIN_GAPS gaps at most)
       if (best == 0xffffffffu || !(bt > 0.f) || ++gaps > SWEEP_TIN_GAPS) {
@@ -1150,22 +1206,13 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
         ok = false;
         return true;
       }
-      // the beams that look into the gap -- tangents up to the far rim's -- hit nothing: each takes its clamp value
-      // (z - r_max) w, what the tail sums hold for the beams beyond the end of a walk.  By the merge itself, on a segment
-      // so far away that every crossing lies beyond r_max (the statement with the clamp, whatever the launch's).
-      const float tan_x = bs * fast_rcp(bt);
-      const unsigned bp_in = bp;
-      merge(msel & 1, 1.f, 1.f, 1e30f, tan_x * 1e30f, 1e30f, 0.f);
+      gap_beams(bs, bt);   // the beams that look into the gap miss
       if (decltype(EXITS)::value && bp == bp_end) return true;
-      // ... and such a beam runs on UNDER the seabed beyond the hole: should the slice ever dip below it again -- a later
-      // vertex at a smaller tangent -- the beam would come up against the seabed from below, which the merge cannot
-      // know: not for the sweep (the test rides on the walk's own t > 0 test below)
-      gap_tan = bp != bp_in ? fmaxf(gap_tan, tan_x) : gap_tan;
-      // on from the far rim: in through the interior half-edge of that edge, which runs from its origin BA to BB
+      // on from the far rim: in through the interior half-edge of that edge, which runs from its origin CA to CB
       sc = bs;
       tc = bt;
-      A = BA;
-      Bn = BB;
+      A = rc.CA;
+      Bn = rc.CB;
       ao = true;
       nb = he_nb(best);
       hq = he_xyzn(nb);

@@ -563,39 +563,46 @@ def _sharded_filter_is_bitwise(eng, orc, verts, tris, ranges, ba, steps=3):
     return split, n
 
 
-def test_tin_hole_under_the_swath_is_crossed_by_its_rim(eng, orc, monkeypatch):
-    """A data gap in the TIN right under the vehicle, every slice runs into it.  mesh_build links the rims of small closed
-    holes (mcl_halfedge.h: link_holes) and the walk crosses them (k_mbes_sweep<6,...>): around the rim once, on from the
-    nearest cut further out, the beams that look into the gap miss.  Only particles whose NADIR falls into the gap are
-    still handed over.  Checked: expected ranges ray by ray and log-likelihoods under the live-particle contract
-    against the oracle (brute force over the triangles that are there), and the determinism rule through three fused
-    rounds of 4 shards against the unsharded filter."""
+@pytest.mark.parametrize('over', ['beside', 'above'])
+def test_tin_hole_under_the_swath_is_crossed_by_its_rim(over, eng, orc, monkeypatch):
+    """A data gap in the TIN under the vehicle's swath ('beside': 3 m across-track, every slice runs into it) or right under
+    the vehicle ('above': every nadir ray goes through it).  mesh_build links the rims of small closed holes
+    (mcl_halfedge.h: link_holes) and the walk crosses them (k_mbes_sweep<6,...>): around the rim once, on from the nearest
+    cut further out, the beams that look into the gap miss; a walk whose nadir ray finds no triangle starts at the rim of
+    the hole its cell names, if the ray does go through that hole (parity of the cuts).  Checked: expected ranges ray by
+    ray and log-likelihoods under the live-particle contract against the oracle (brute force over the triangles that
+    are there), and the determinism rule through three fused rounds of 4 shards against the unsharded filter."""
     from tests.helpers import live_particle_contract
     verts, holes = _tin_with_a_gap(36, 6)
     n, B = 4096, 128
-    soa = _cloud(n, 12, (0.5, 0.5, 0.05, 0.01, 0.01, 0.05), (0.0, 0.0, -2.0))
+    centre = (0.0, 0.0, -2.0) if over == 'beside' else (1.0, 3.0, -2.0)
+    soa = _cloud(n, 12, (0.5, 0.5, 0.05, 0.01, 0.01, 0.05 if over == 'beside' else 3.0), centre)
     ba = synth.beam_angles(B)
     omap = orc.Mesh(verts, holes)
     _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, None, 0.2, 80.0)
     assert (ref >= 80.0).mean() > 0.005          # beams do look into the gap
+    if over == 'above':
+        assert (ref[:, B // 2] >= 80.0).mean() > 0.7      # ... the nadir beams of most particles
     e = _engine(eng, soa, verts, holes)
     got = e.mbes_expected(0, n, ba, 80.0)
     path, handed, _ = e.mbes_last_path()
     err = np.abs(got - ref)
-    print('gap under the swath, rims linked: handed over %d of %d; max |expected range error| %.2e m, rays off %d of %d (%d rays into the gap)' % (
-        handed, n, err.max(), int((err > 1e-3).sum()), err.size, int((ref >= 80.0).sum())))
+    print('gap %s the vehicle, rims linked: handed over %d of %d; max |expected range error| %.2e m, rays off %d of %d (%d rays into the gap)' % (
+        over, handed, n, err.max(), int((err > 1e-3).sum()), err.size, int((ref >= 80.0).sum())))
     assert path == 1 and handed < n // 8
     assert (err > 1e-3).sum() <= err.size // 20000 + 2
-    outliers_explained(orc, omap, soa, ba, got, ref, 80.0, label='gap under the swath')
+    outliers_explained(orc, omap, soa, ba, got, ref, 80.0, label='gap %s the vehicle' % over)
     ranges = (ref[0] + 0.05 * np.random.RandomState(3).randn(B)).astype(np.float32)
+    ranges[ref[0] >= 80.0] = 0.0                 # (a beam that found nothing reports no range)
     lw_ref, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, ranges, 0.8, 80.0)
     e.update_mbes(ranges, ba, 0.8, 80.0)
     assert e.mbes_last_path()[1] == handed       # the same particles whatever is asked of the sweep
-    live_particle_contract(orc, omap, soa, ba, ranges, 0.8, 80.0, e.get_log_weights(), lw_ref, lw_ref.max(), label='gap under the swath, crossed')
+    live_particle_contract(orc, omap, soa, ba, ranges, 0.8, 80.0, e.get_log_weights(), lw_ref, lw_ref.max(), label='gap %s the vehicle, crossed' % over)
     e.close()
-    split, n = _sharded_filter_is_bitwise(eng, orc, verts, holes, ranges, ba)
-    print('sharded, gap crossed: (sweep handed over, cast by the slice, by the traversal) per step %r of %d' % (split, n))
-    assert all(h < n // 4 for h, _, _ in split)
+    if over == 'beside':
+        split, n = _sharded_filter_is_bitwise(eng, orc, verts, holes, ranges, ba)
+        print('sharded, gap crossed: (sweep handed over, cast by the slice, by the traversal) per step %r of %d' % (split, n))
+        assert all(h < n // 4 for h, _, _ in split)
 
 
 def test_tin_hole_without_rim_records_goes_through_the_fan_slice(eng, orc, monkeypatch):
