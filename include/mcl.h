@@ -341,7 +341,7 @@ int mcl_timing_get(mcl_handle* h, mcl_timing* out); /* syncs, returns and resets
 /* Which kernels cast the last MBES update (syncs): path = 1 fan sweep (mcl_sweep.h: height grids, regularly triangulated
  * meshes, height-field TINs; ascending beam angles), 2 fan slice (mcl_slice.h: every other triangle mesh, ascending beam
  * angles), 0 ray traversal; handed_over = particles the sweep / slice passed on to the general kernel (paths 1, 2),
- * deferred_groups = groups of eight the fast traversal passed on to the general one (path 0); path 2: groups of 36 spatial
+ * deferred_groups = groups of eight the fast traversal passed on to the general one (path 0); path 2: groups of 60 spatial
  * neighbours the group form of the slice left to the per-particle kernel, or -1 when every particle was cast on its own
  * (no visiting order: DESIGN.md 5).  Any pointer may be NULL. */
 int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64_t* deferred_groups);

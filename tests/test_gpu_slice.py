@@ -279,7 +279,7 @@ def test_slice_over_groups_of_neighbours_equals_the_per_particle_slice_bitwise(k
             out.append((e.get_log_weights(), e.last_indices(), e.get_particles(), path))
         e.close()
         res[group] = out
-    ngroups = (n + 35) // 36
+    ngroups = (n + 59) // 60   # (mcl_slice.h: SLICE_G)
     loose = [o[3][2] for o in res['1']]
     print('%s: groups left to the per-particle kernel per step: %r of %d' % (kind, loose, ngroups))
     assert loose[0] == -1                         # the first step has no visiting order: no groups
@@ -359,7 +359,7 @@ def test_slice_groups_on_a_dispersed_cloud_and_an_odd_particle_count(eng, monkey
             out.append((e.get_log_weights(), e.last_indices(), e.get_particles(), e.mbes_last_path()))
         e.close()
         res[group] = out
-    ngroups = (n + 35) // 36
+    ngroups = (n + 59) // 60   # (mcl_slice.h: SLICE_G)
     loose = [o[3][2] for o in res['1']]
     handed = [o[3][1] for o in res['1']]
     print('dispersed cloud: groups left to the per-particle kernel per step %r of %d, handed to the general kernel %r' % (loose, ngroups, handed))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One extra leg of bench.py alone (profiling runs): tools/experiments/leg.py config5|config4|config4_rccl [steps]"""
+"""One extra leg of bench.py alone (profiling runs): tools/experiments/leg.py config5|config4|config4_rccl|tin_hole [steps]"""
 import json
 import os
 import sys
@@ -15,5 +15,8 @@ if name == 'config5':
     kw['landmarks'] = (synth.landmark_map(4096, (-64.0, -354.0, 643.0, 353.0)), 16)
 if name == 'config4_rccl':   # the sharded pipeline over a 1-rank RCCL communicator (bench.py: config4_shard_rccl_1rank)
     kw['rccl_1rank'] = True
+if name == 'tin_hole':       # the irregular TIN with a data gap under the swath (bench.py: mesh_tin_hole_under_swath): k_mbes_sweep<6, ...>
+    mesh = bench.punch_hole(bench.build_map('mesh-tin'), 1.0, 10.0)
+    kw.update(P=1048576, warmup=40)
 out = bench.run_leg(engine, name, mesh, kw.pop('P'), kw.pop('B'), kw.pop('steps'), kw.pop('warmup'), **kw)
 print(json.dumps({k: out[k] for k in ('ms_per_step', 'kernels')}))
