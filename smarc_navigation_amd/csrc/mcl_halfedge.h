@@ -162,11 +162,12 @@ inline void build_table(const float* verts, const uint32_t* tris, int64_t nt, co
 // (the far side of edge j of triangle T is next_a of record 3 T + (j + 1) % 3 and next_b of record 3 T + (j + 2) % 3; its
 // origin is the vertex of record 3 T + (j + 1) % 3): from a boundary half-edge a -> b the next one around the same empty
 // face starts at b and is found by turning about b through the triangles of its fan -- which pairs the edges properly
-// even where two fans touch in a vertex.  With the mesh on the left a loop runs CLOCKWISE around a hole and counter-
+// where two fans touch in a vertex each keeps to itself (pinched holes come out as ONE loop, a triangle that hangs on a rim
+// by a vertex as a piece of its own).  With the mesh on the left a loop runs CLOCKWISE around a hole and counter-
 // clockwise around a piece of mesh; crossing a hole by its own rim alone is exact only if nothing else lies in it, so
-// holes are linked only when the mesh has ONE counter-clockwise loop (one edge-connected piece, no islands).  Returns the
-// number of rim records appended; he keeps its first 3 nt records in place.
-constexpr int RIM_MAX = 48;
+// a hole that contains a piece of mesh (an island) is not linked.  Returns the number of rim records appended; he keeps its
+// first 3 nt records in place.
+constexpr int RIM_MAX = 256;   // (a search around the rim costs ~ 30 VALU per edge and lane: 256 edges, a gap 12 m across at 1 m resolution, is about one walk -- a tenth of what the hand-over costs)
 inline size_t link_holes(std::vector<Rec>& he, int64_t nt) {
   const size_t nhe = 3 * (size_t)nt;
   if (he.size() != nhe) return 0;
@@ -181,15 +182,15 @@ inline size_t link_holes(std::vector<Rec>& he, int64_t nt) {
   std::vector<unsigned char> seen(nhe, 0);
   struct Loop {
     size_t first, len;
+    double area2;
+    float bx0, bx1, by0, by1;
   };
   std::vector<uint32_t> edges;   // the boundary half-edges (3 T + j), loop after loop
-  std::vector<Loop> holes;
-  int outlines = 0;
+  std::vector<Loop> holes, pieces;   // clockwise loops that may be linked; counter-clockwise loops (outlines of pieces of mesh)
   for (size_t h0 = 0; h0 < nhe; ++h0) {
     if (seen[h0] || far_of(h0 / 3, (int)(h0 % 3)) < 0xfffffff0u) continue;
-    const size_t first = edges.size();
+    Loop L{edges.size(), 0, 0.0, 3e38f, -3e38f, 3e38f, -3e38f};
     bool on_border = false;
-    double area2 = 0.0;
     size_t h = h0;
     for (size_t guard = 0;; ++guard) {
       if (guard > nhe || seen[h]) return 0;   // (cannot happen on a table that passed adjacency())
@@ -200,7 +201,9 @@ inline size_t link_holes(std::vector<Rec>& he, int64_t nt) {
       on_border |= far_of(T, j) != HOLE;
       const Rec& a = origin(T, j);
       const Rec& b = origin(T, (j + 1) % 3);
-      area2 += fl(a.x) * fl(b.y) - fl(b.x) * fl(a.y);
+      L.area2 += fl(a.x) * fl(b.y) - fl(b.x) * fl(a.y);
+      L.bx0 = std::min(L.bx0, (float)fl(a.x)), L.bx1 = std::max(L.bx1, (float)fl(a.x));
+      L.by0 = std::min(L.by0, (float)fl(a.y)), L.by1 = std::max(L.by1, (float)fl(a.y));
       // the next boundary edge around this face: turn about b
       size_t g = 3 * T + (size_t)((j + 1) % 3);
       for (size_t turn = 0; far_of(g / 3, (int)(g % 3)) < 0xfffffff0u; ++turn) {
@@ -211,12 +214,46 @@ inline size_t link_holes(std::vector<Rec>& he, int64_t nt) {
       h = g;
       if (h == h0) break;
     }
-    if (area2 > 0.0)
-      ++outlines;
-    else if (!on_border && edges.size() - first <= (size_t)RIM_MAX)
-      holes.push_back(Loop{first, edges.size() - first});
+    L.len = edges.size() - L.first;
+    if (L.area2 > 0.0)
+      pieces.push_back(L);
+    else if (!on_border && L.len <= (size_t)RIM_MAX)
+      holes.push_back(L);
   }
-  if (outlines != 1 || holes.empty()) return 0;
+  if (pieces.empty() || holes.empty()) return 0;
+  // a piece of mesh other than the one with the largest outline may lie INSIDE a hole (an island; a triangle that hangs on
+  // the rim by one vertex): that hole is not linked.  One point of the piece -- the centroid of the triangle of its first
+  // boundary edge -- against the hole's polygon (bounding box first, then the crossing number).
+  if (pieces.size() > 1) {
+    size_t big = 0;
+    for (size_t q = 1; q < pieces.size(); ++q)
+      if (pieces[q].area2 > pieces[big].area2) big = q;
+    std::vector<unsigned char> bad(holes.size(), 0);
+    for (size_t q = 0; q < pieces.size(); ++q) {
+      if (q == big) continue;
+      const size_t T = edges[pieces[q].first] / 3;
+      double px = 0.0, py = 0.0;
+      for (int j = 0; j < 3; ++j) px += fl(origin(T, j).x) / 3.0, py += fl(origin(T, j).y) / 3.0;
+      for (size_t k = 0; k < holes.size(); ++k) {
+        const Loop& H = holes[k];
+        if (bad[k] || px < H.bx0 || px > H.bx1 || py < H.by0 || py > H.by1) continue;
+        bool in = false;
+        for (size_t e = 0; e < H.len; ++e) {
+          const uint32_t hh = edges[H.first + e];
+          const Rec& a = origin(hh / 3, (int)(hh % 3));
+          const Rec& b = origin(hh / 3, (int)((hh % 3 + 1) % 3));
+          const double ax = fl(a.x), ay = fl(a.y), bx = fl(b.x), by = fl(b.y);
+          if ((ay > py) != (by > py) && px < ax + (py - ay) * (bx - ax) / (by - ay)) in = !in;
+        }
+        bad[k] = in;
+      }
+    }
+    size_t w = 0;
+    for (size_t k = 0; k < holes.size(); ++k)
+      if (!bad[k]) holes[w++] = holes[k];
+    holes.resize(w);
+    if (holes.empty()) return 0;
+  }
   size_t nrim = 0;
   for (const Loop& L : holes) nrim += L.len;
   if ((nhe + nrim) * sizeof(Rec) >= (size_t)1 << 31) return 0;   // (the device addresses the table by 32-bit byte offsets)
