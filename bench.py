@@ -192,6 +192,25 @@ def punch_hole(m, x, y, radius=0.8):
                 desc=m['desc'] + ', %d triangles around (%g, %g) missing' % (int(gone.sum()), x, y))
 
 
+def punch_gaps(m, tile=6.0, seed=11):
+    """The mesh with one data gap per tile x tile metres of map, at a random place in its tile, 0.8 .. 5 m across (the outer
+    ring of tiles stays intact: a gap that reaches the outline is a ragged border, not a hole) -- a survey with holes
+    everywhere: at tile = 6 m about 13 % of the triangles are missing and every ping looks into a few of the gaps."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    c = m['verts'][m['tris'].astype(np.int64)].mean(axis=1)
+    x0, y0 = m['origin']
+    t = (np.floor((c[:, 0] - x0) / tile).astype(np.int64), np.floor((c[:, 1] - y0) / tile).astype(np.int64))
+    nt = int(t[0].max()) + 1, int(t[1].max()) + 1
+    cx = x0 + tile * (np.arange(nt[0])[:, None] + 0.3 + 0.4 * rs.rand(nt[0], nt[1]))
+    cy = y0 + tile * (np.arange(nt[1])[None, :] + 0.3 + 0.4 * rs.rand(nt[0], nt[1]))
+    rad = 0.4 + 2.1 * rs.rand(nt[0], nt[1]) ** 2
+    gone = np.hypot(c[:, 0] - cx[t], c[:, 1] - cy[t]) < rad[t]
+    gone &= (t[0] > 0) & (t[1] > 0) & (t[0] < nt[0] - 1) & (t[1] < nt[1] - 1)
+    return dict(m, tris=np.ascontiguousarray(m['tris'][~gone]),
+                desc=m['desc'] + ', %d triangles missing in %d gaps' % (int(gone.sum()), (nt[0] - 2) * (nt[1] - 2)))
+
+
 def attach_map(e, m):
     if m['kind'] == 'grid':
         e.set_map_grid(m['z'], m['origin'], m['res'])
@@ -876,6 +895,8 @@ def worker(a, rank, world, local_rank):
         # into it, the sweep hands the whole cloud over -- to the fan slice (mcl_host_update.h; round 5 / MCL_HANDOVER_SLICE=0:
         # to the ray traversal, 21 ms per step).  The worst case of a survey mesh with gaps, not its average.
         legs.append(('mesh_tin_hole_under_swath', dict(m=punch_hole(tin, 1.0, 10.0), P=1048576, B=512, steps=20, warmup=10)))
+        # ... and with gaps EVERYWHERE (one per 6 x 6 m, 13 % of the triangles missing): every particle's slice crosses several
+        legs.append(('mesh_tin_gaps_everywhere', dict(m=punch_gaps(tin), P=1048576, B=512, steps=50, warmup=40)))
         # global-localisation regime: sigma = 50 m cloud that nothing collapses (no resample).  Particles are
         # initialised around the odom origin (auv_particle.py:24), so the map <- odom transform puts that
         # origin 250 m inside the map; 'cloud_wide_at_border' leaves it 64 m from the western border, where

@@ -22,7 +22,7 @@ def _cloud(seed):
     return soa
 
 
-@pytest.mark.parametrize('kind', ['mesh', 'grid', 'mesh_general', 'mesh_tin', 'mesh_tin_shuffled', 'mesh_soup_irregular'])
+@pytest.mark.parametrize('kind', ['mesh', 'grid', 'mesh_general', 'mesh_tin', 'mesh_tin_shuffled', 'mesh_tin_gaps', 'mesh_soup_irregular'])
 def test_full_size_mbes_update_spot_check_vs_oracle(kind):
     from smarc_navigation_amd import engine as eng
     from oracle import oracle as orc
@@ -35,8 +35,11 @@ def test_full_size_mbes_update_spot_check_vs_oracle(kind):
     else:
         origin = (-64.0, -354.0)
         z = synth.bathymetry_grid(708, 708, 1.0, origin, seed=3)
-        if kind in ('mesh_tin', 'mesh_tin_shuffled', 'mesh_soup_irregular'):   # an irregular height-field TIN: the adjacency sweep (or, forced, the fan slice)
+        if kind in ('mesh_tin', 'mesh_tin_shuffled', 'mesh_tin_gaps', 'mesh_soup_irregular'):   # an irregular height-field TIN: the adjacency sweep (or, forced, the fan slice)
             verts, tris = synth.mesh_tin(z, 1.0, origin, seed=7)
+            if kind == 'mesh_tin_gaps':   # ... with a data gap per 6 x 6 m (bench.py: punch_gaps; 13 % of the triangles missing): the walk crosses them by their rims
+                import bench
+                tris = bench.punch_gaps(dict(verts=verts, tris=tris, origin=origin, desc=''))['tris']
             if kind == 'mesh_tin_shuffled':   # ... in random vertex / triangle order (mesh_build's Morton pass)
                 verts, tris = synth.mesh_shuffle(verts, tris, seed=9)
         else:
@@ -52,6 +55,7 @@ def test_full_size_mbes_update_spot_check_vs_oracle(kind):
     truth = np.array([[30.0], [-12.0], [-2.2], [0.015], [-0.02], [0.0]])
     _, ex = orc.mbes_update(truth, np.identity(4), [0] * 6, omap, ba, None, 0.2, 100.0)
     ranges = (ex[0] + 0.2 * np.random.RandomState(2).randn(B)).astype(np.float32)
+    ranges[ex[0] >= 100.0] = 0.0    # (a beam that found nothing reports no range: only the TIN with gaps has such beams)
     e.update_mbes(ranges, ba, 0.2, 100.0)
     lw = e.get_log_weights()
     pick = np.random.RandomState(3).choice(N, 1024, replace=False)
@@ -59,9 +63,22 @@ def test_full_size_mbes_update_spot_check_vs_oracle(kind):
     lw_ref, ex_ref = orc.mbes_update(sub, np.identity(4), [0] * 6, omap, ba, ranges, 0.2, 100.0)
     d = np.abs(lw[pick] - lw_ref)
     print('%s: full-size spot check, max |dlw| = %.3e (|lw| up to %.0f)' % (kind, d.max(), np.abs(lw_ref).max()))
-    assert np.all((d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref)))
-    path = e.mbes_last_path()[0]
+    okm = (d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref))
+    if kind == 'mesh_tin_gaps':
+        # a surface with gaps is not continuous: a ray within rounding of a rim hits the seabed in one arithmetic and looks into
+        # the gap in the other (here: 20 m against r_max, half of (80 / 0.2)^2 in the log-likelihood) -- every ping has ~ 70 rim
+        # passages per particle.  Such particles must be FEW and each must carry an answer the oracle itself gives under a
+        # 1 mm shift of the sensor
+        from tests.helpers import lw_outliers_explained
+        assert (~okm).sum() <= pick.size // 25, int((~okm).sum())
+        lw_outliers_explained(orc, omap, sub, ba, ranges, 0.2, 100.0, lw[pick], lw_ref, label='mesh_tin_gaps 1 M x 512')
+    else:
+        assert np.all(okm)
+    path, handed, _ = e.mbes_last_path()
     assert path == {'mesh_general': 2, 'mesh_soup_irregular': 2}.get(kind, 1), path   # fan sweep (1) / fan slice (2)
+    if kind == 'mesh_tin_gaps':
+        print('mesh_tin_gaps: the sweep handed over %d of %d particles (%d beams of the ping look into a gap)' % (handed, N, int((ex[0] >= 100.0).sum())))
+        assert handed < N // 20
     # the contract where it bites: the particles that can receive offspring (lw >= max - 30) within |d| <= 1e-2 ABSOLUTE
     live = live_picks(lw, 1024, seed=6)
     lsub = np.ascontiguousarray(soa[:, live])
@@ -73,7 +90,8 @@ def test_full_size_mbes_update_spot_check_vs_oracle(kind):
     assert np.abs(got[0] - ex_ref[0]).max() <= 1e-3
     # the update discriminates: the best particles are the ones nearest to the truth
     best = np.argsort(lw)[-100:]
-    assert np.median(np.hypot(soa[0, best] - 30.0, soa[1, best] + 12.0)) < 0.3
+    # (with gaps the likelihood has cliffs -- a valid beam of a displaced particle falls into a gap -- and the hundred best spread wider)
+    assert np.median(np.hypot(soa[0, best] - 30.0, soa[1, best] + 12.0)) < (0.8 if kind == 'mesh_tin_gaps' else 0.3)
 
 
 @pytest.mark.parametrize('kind', ['mesh', 'grid', 'mesh_general', 'mesh_tin'])

@@ -16,20 +16,7 @@ from smarc_navigation_amd import engine, synth  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 check = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 P, B = 1048576, 512
-m = bench.build_map('mesh-tin')
-rs = np.random.RandomState(11)
-c = m['verts'][m['tris'].astype(np.int64)].mean(axis=1)
-# one gap per 6 x 6 m tile, at a random place in it (never two that touch: the tiles' margins), random radius
-x0, y0 = m['origin']
-tile = (np.floor((c[:, 0] - x0) / 6.0).astype(np.int64), np.floor((c[:, 1] - y0) / 6.0).astype(np.int64))
-nt = int(tile[0].max()) + 1, int(tile[1].max()) + 1
-cx = x0 + 6.0 * (np.arange(nt[0])[:, None] + 0.3 + 0.4 * rs.rand(nt[0], nt[1]))
-cy = y0 + 6.0 * (np.arange(nt[1])[None, :] + 0.3 + 0.4 * rs.rand(nt[0], nt[1]))
-rad = 0.4 + 1.0 * rs.rand(nt[0], nt[1]) ** 2 * 2.1
-gone = np.hypot(c[:, 0] - cx[tile], c[:, 1] - cy[tile]) < rad[tile]
-# keep the map's outer ring of tiles intact (a gap that reaches the outline is a ragged border, not a hole)
-gone &= (tile[0] > 0) & (tile[1] > 0) & (tile[0] < nt[0] - 1) & (tile[1] < nt[1] - 1)
-m = dict(m, tris=np.ascontiguousarray(m['tris'][~gone]), desc=m['desc'] + ', %d triangles missing in %d gaps' % (int(gone.sum()), nt[0] * nt[1]))
+m = bench.punch_gaps(bench.build_map('mesh-tin'))
 print(m['desc'], flush=True)
 stream = synth.odom_stream(steps)
 ba = synth.beam_angles(B)
