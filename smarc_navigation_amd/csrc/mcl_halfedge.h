@@ -12,14 +12,21 @@
 // (0xffffffff: hole / ragged border, 0xfffffff0 / 0xfffffff1: the map's outer x / y border.)
 //
 // HOLES THE WALK CAN CROSS (link_holes): behind the 3 nt half-edge records follow RIM records, one per edge of every small
-// closed hole -- a data gap of a survey: a boundary loop of at most RIM_MAX edges that runs clockwise around empty space
-// and touches the map's outer border nowhere.  The far side of such an edge names its rim record (index >= 3 nt) instead
+// closed hole -- a data gap of a survey: a boundary loop that runs clockwise around empty space, touches the map's outer
+// border nowhere and has no piece of mesh inside.  The far side of such an edge names its rim record (index >= 3 nt) instead
 // of HOLE:
 //   word 0 .. 2: x, y, z of the edge's ORIGIN a (the interior half-edge runs a -> b, the hole on its right)
 //   word 3: the rim record of the next edge around the hole (it starts at b)
 //   word 4: the interior half-edge itself -- the walk re-enters the mesh THROUGH it
 //   word 5, 6: the first rim record of this hole and the number of its edges (the records of a hole lie together, in rim order:
 //              the walk reads them by index -- loads that do not wait for one another)
+//   word 7: for a rim of more than RIM_CHUNK_MIN edges the first of its CHUNK records (behind all rim records: {centre x, y, z
+//           and radius of a sphere around RIM_CHUNK consecutive edges} -- the walk tests the fan plane against the spheres and
+//           goes through the edges of those it cuts); top bit: the rim is the mesh's OUTLINE
+// The ragged OUTLINE of a survey (every outline edge that is not on the bounding box) is linked the same way when no other piece
+// of mesh lies outside it: a slice that leaves through it either finds a cut further out -- a bay of the outline: it walks on
+// from there -- or none: then nothing lies beyond, and the beams left miss.  Its edges on the bounding box keep their border
+// codes and are marked in word 3 (top bit): no way back in through them.
 // A slice that reaches the hole goes around its rim once, finds the nearest edge further out that the fan plane cuts,
 // lets the beams that look into the gap miss, and walks on from there (mcl_sweep.h: sweep_side_tin, SURF 6).
 #pragma once
@@ -165,12 +172,21 @@ inline void build_table(const float* verts, const uint32_t* tris, int64_t nt, co
 // where two fans touch in a vertex each keeps to itself (pinched holes come out as ONE loop, a triangle that hangs on a rim
 // by a vertex as a piece of its own).  With the mesh on the left a loop runs CLOCKWISE around a hole and counter-
 // clockwise around a piece of mesh; crossing a hole by its own rim alone is exact only if nothing else lies in it, so
-// a hole that contains a piece of mesh (an island) is not linked.  Returns the number of rim records appended; he keeps its
-// first 3 nt records in place.
-constexpr int RIM_MAX = 256;   // (a search around the rim costs ~ 30 VALU per edge and lane: 256 edges, a gap 12 m across at 1 m resolution, is about one walk -- a tenth of what the hand-over costs)
-inline size_t link_holes(std::vector<Rec>& he, int64_t nt) {
+// a hole that contains a piece of mesh (an island) is not linked.  Returns what was appended; he keeps its first 3 nt
+// records in place.
+constexpr int RIM_CHUNK = 16;       // a long rim is searched by chunks of so many consecutive edges, each inside a bounding sphere
+constexpr int RIM_CHUNK_MIN = 48;   // ... rims of up to so many edges are searched edge by edge
+constexpr uint32_t RIM_ON_BOX = 0x80000000u;   // word 3 of a rim record: this edge of the OUTLINE lies on the bounding box (no way back in through it)
+constexpr uint32_t RIM_EXTERIOR = 0x80000000u; // word 7 of a rim record: the rim is the mesh's outline, the empty space beyond it unbounded
+struct Links {
+  size_t nrim = 0, nchunk = 0;   // rim records behind the 3 nt half-edge records, chunk records behind those
+  size_t holes = 0;              // linked holes
+  bool outline = false;          // the outline is linked as well
+};
+inline Links link_holes(std::vector<Rec>& he, int64_t nt) {
+  Links out;
   const size_t nhe = 3 * (size_t)nt;
-  if (he.size() != nhe) return 0;
+  if (he.size() != nhe) return out;
   auto far_of = [&](size_t T, int j) -> uint32_t& { return he[3 * T + (size_t)((j + 1) % 3)].next_a; };
   auto far_of_b = [&](size_t T, int j) -> uint32_t& { return he[3 * T + (size_t)((j + 2) % 3)].next_b; };
   auto origin = [&](size_t T, int j) -> const Rec& { return he[3 * T + (size_t)((j + 1) % 3)]; };
@@ -184,21 +200,21 @@ inline size_t link_holes(std::vector<Rec>& he, int64_t nt) {
     size_t first, len;
     double area2;
     float bx0, bx1, by0, by1;
+    bool on_box, ragged;   // has an edge on the bounding box / an edge that is not
   };
   std::vector<uint32_t> edges;   // the boundary half-edges (3 T + j), loop after loop
-  std::vector<Loop> holes, pieces;   // clockwise loops that may be linked; counter-clockwise loops (outlines of pieces of mesh)
+  std::vector<Loop> holes, pieces;   // clockwise loops (holes); counter-clockwise loops (outlines of pieces of mesh)
   for (size_t h0 = 0; h0 < nhe; ++h0) {
     if (seen[h0] || far_of(h0 / 3, (int)(h0 % 3)) < 0xfffffff0u) continue;
-    Loop L{edges.size(), 0, 0.0, 3e38f, -3e38f, 3e38f, -3e38f};
-    bool on_border = false;
+    Loop L{edges.size(), 0, 0.0, 3e38f, -3e38f, 3e38f, -3e38f, false, false};
     size_t h = h0;
     for (size_t guard = 0;; ++guard) {
-      if (guard > nhe || seen[h]) return 0;   // (cannot happen on a table that passed adjacency())
+      if (guard > nhe || seen[h]) return out;   // (cannot happen on a table that passed adjacency())
       seen[h] = 1;
       edges.push_back((uint32_t)h);
       const size_t T = h / 3;
       const int j = (int)(h % 3);
-      on_border |= far_of(T, j) != HOLE;
+      (far_of(T, j) != HOLE ? L.on_box : L.ragged) = true;
       const Rec& a = origin(T, j);
       const Rec& b = origin(T, (j + 1) % 3);
       L.area2 += fl(a.x) * fl(b.y) - fl(b.x) * fl(a.y);
@@ -207,7 +223,7 @@ inline size_t link_holes(std::vector<Rec>& he, int64_t nt) {
       // the next boundary edge around this face: turn about b
       size_t g = 3 * T + (size_t)((j + 1) % 3);
       for (size_t turn = 0; far_of(g / 3, (int)(g % 3)) < 0xfffffff0u; ++turn) {
-        if (turn > nhe) return 0;
+        if (turn > nhe) return out;
         const uint32_t t = far_of(g / 3, (int)(g % 3));   // runs (end of g) -> b in the neighbour
         g = 3 * (size_t)(t / 3u) + (size_t)((t % 3u + 1u) % 3u);
       }
@@ -217,60 +233,105 @@ inline size_t link_holes(std::vector<Rec>& he, int64_t nt) {
     L.len = edges.size() - L.first;
     if (L.area2 > 0.0)
       pieces.push_back(L);
-    else if (!on_border && L.len <= (size_t)RIM_MAX)
+    else if (!L.on_box)
       holes.push_back(L);
   }
-  if (pieces.empty() || holes.empty()) return 0;
+  if (pieces.empty()) return out;
+  auto inside = [&](const Loop& H, double px, double py) {   // crossing number against the loop's polygon
+    if (px < H.bx0 || px > H.bx1 || py < H.by0 || py > H.by1) return false;
+    bool in = false;
+    for (size_t e = 0; e < H.len; ++e) {
+      const uint32_t hh = edges[H.first + e];
+      const Rec& a = origin(hh / 3, (int)(hh % 3));
+      const Rec& b = origin(hh / 3, (int)((hh % 3 + 1) % 3));
+      const double ax = fl(a.x), ay = fl(a.y), bx = fl(b.x), by = fl(b.y);
+      if ((ay > py) != (by > py) && px < ax + (py - ay) * (bx - ax) / (by - ay)) in = !in;
+    }
+    return in;
+  };
   // a piece of mesh other than the one with the largest outline may lie INSIDE a hole (an island; a triangle that hangs on
-  // the rim by one vertex): that hole is not linked.  One point of the piece -- the centroid of the triangle of its first
-  // boundary edge -- against the hole's polygon (bounding box first, then the crossing number).
-  if (pieces.size() > 1) {
-    size_t big = 0;
-    for (size_t q = 1; q < pieces.size(); ++q)
-      if (pieces[q].area2 > pieces[big].area2) big = q;
+  // the rim by one vertex): that hole is not linked -- or OUTSIDE the largest outline: then the outline is not.  One point
+  // of the piece, the centroid of the triangle of its first boundary edge, against the polygons.
+  size_t big = 0;
+  for (size_t q = 1; q < pieces.size(); ++q)
+    if (pieces[q].area2 > pieces[big].area2) big = q;
+  bool outline_ok = pieces[big].ragged;   // (an outline that lies on the bounding box all around needs no records: the border codes say it all)
+  {
     std::vector<unsigned char> bad(holes.size(), 0);
     for (size_t q = 0; q < pieces.size(); ++q) {
       if (q == big) continue;
       const size_t T = edges[pieces[q].first] / 3;
       double px = 0.0, py = 0.0;
       for (int j = 0; j < 3; ++j) px += fl(origin(T, j).x) / 3.0, py += fl(origin(T, j).y) / 3.0;
-      for (size_t k = 0; k < holes.size(); ++k) {
-        const Loop& H = holes[k];
-        if (bad[k] || px < H.bx0 || px > H.bx1 || py < H.by0 || py > H.by1) continue;
-        bool in = false;
-        for (size_t e = 0; e < H.len; ++e) {
-          const uint32_t hh = edges[H.first + e];
-          const Rec& a = origin(hh / 3, (int)(hh % 3));
-          const Rec& b = origin(hh / 3, (int)((hh % 3 + 1) % 3));
-          const double ax = fl(a.x), ay = fl(a.y), bx = fl(b.x), by = fl(b.y);
-          if ((ay > py) != (by > py) && px < ax + (py - ay) * (bx - ax) / (by - ay)) in = !in;
-        }
-        bad[k] = in;
-      }
+      if (!inside(pieces[big], px, py)) outline_ok = false;
+      for (size_t k = 0; k < holes.size(); ++k)
+        if (!bad[k] && inside(holes[k], px, py)) bad[k] = 1;
     }
     size_t w = 0;
     for (size_t k = 0; k < holes.size(); ++k)
       if (!bad[k]) holes[w++] = holes[k];
     holes.resize(w);
-    if (holes.empty()) return 0;
   }
-  size_t nrim = 0;
-  for (const Loop& L : holes) nrim += L.len;
-  if ((nhe + nrim) * sizeof(Rec) >= (size_t)1 << 31) return 0;   // (the device addresses the table by 32-bit byte offsets)
-  he.reserve(nhe + nrim);
-  for (const Loop& L : holes) {
+  std::vector<Loop> rims(holes);
+  if (outline_ok) rims.push_back(pieces[big]);
+  if (rims.empty()) return out;
+  size_t nrim = 0, nchunk = 0;
+  for (const Loop& L : rims) {
+    nrim += L.len;
+    if (L.len > (size_t)RIM_CHUNK_MIN) nchunk += (L.len + RIM_CHUNK - 1) / RIM_CHUNK;
+  }
+  if ((nhe + nrim + nchunk) * sizeof(Rec) >= (size_t)1 << 31) return out;   // (the device addresses the table by 32-bit byte offsets)
+  he.reserve(nhe + nrim + nchunk);
+  size_t cbase = nhe + nrim;   // chunk records follow ALL rim records
+  std::vector<Rec> chunks;
+  for (size_t r = 0; r < rims.size(); ++r) {
+    const Loop& L = rims[r];
+    const bool exterior = outline_ok && r + 1 == rims.size();
     const size_t base = he.size();
+    const bool chunked = L.len > (size_t)RIM_CHUNK_MIN;
+    const uint32_t w7 = (chunked ? (uint32_t)(cbase + chunks.size()) : 0u) | (exterior ? RIM_EXTERIOR : 0u);
     for (size_t q = 0; q < L.len; ++q) {
       const uint32_t h = edges[L.first + q];
       const size_t T = h / 3;
       const int j = (int)(h % 3);
       const Rec a = origin(T, j);
-      he.push_back(Rec{a.x, a.y, a.z, (uint32_t)(base + (q + 1) % L.len), h, (uint32_t)base, (uint32_t)L.len, 0});
-      far_of(T, j) = (uint32_t)(base + q);
-      far_of_b(T, j) = (uint32_t)(base + q);
+      const bool on_box = far_of(T, j) != HOLE;
+      he.push_back(Rec{a.x, a.y, a.z, (uint32_t)(base + (q + 1) % L.len) | (on_box ? RIM_ON_BOX : 0u), h, (uint32_t)base, (uint32_t)L.len, w7});
+      if (!on_box) {   // (an edge on the bounding box keeps its border code: a slice that leaves through it ends under the old rule)
+        far_of(T, j) = (uint32_t)(base + q);
+        far_of_b(T, j) = (uint32_t)(base + q);
+      }
     }
+    if (chunked)
+      for (size_t c0 = 0; c0 < L.len; c0 += RIM_CHUNK) {
+        // the sphere around vertices c0 .. c0 + RIM_CHUNK (the ends of the chunk's edges), a millimetre wider
+        const size_t n = std::min<size_t>(RIM_CHUNK, L.len - c0) + 1;
+        double cx = 0, cy = 0, cz = 0, rr = 0;
+        for (size_t q = 0; q < n; ++q) {
+          const Rec& v = he[base + (c0 + q) % L.len];
+          cx += fl(v.x) / n, cy += fl(v.y) / n, cz += fl(v.z) / n;
+        }
+        const float fcx = (float)cx, fcy = (float)cy, fcz = (float)cz;
+        for (size_t q = 0; q < n; ++q) {
+          const Rec& v = he[base + (c0 + q) % L.len];
+          const double dx = fl(v.x) - fcx, dy = fl(v.y) - fcy, dz = fl(v.z) - fcz;
+          rr = std::max(rr, std::sqrt(dx * dx + dy * dy + dz * dz));
+        }
+        const float fr = (float)(rr * (1.0 + 1e-5) + 1e-3);
+        Rec c{0, 0, 0, 0, 0, 0, 0, 0};
+        std::memcpy(&c.x, &fcx, 4);
+        std::memcpy(&c.y, &fcy, 4);
+        std::memcpy(&c.z, &fcz, 4);
+        std::memcpy(&c.next_a, &fr, 4);
+        chunks.push_back(c);
+      }
   }
-  return nrim;
+  he.insert(he.end(), chunks.begin(), chunks.end());
+  out.nrim = nrim;
+  out.nchunk = chunks.size();
+  out.holes = holes.size();
+  out.outline = outline_ok;
+  return out;
 }
 
 }  // namespace halfedge

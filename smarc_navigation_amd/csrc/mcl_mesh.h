@@ -49,6 +49,7 @@ struct MeshDev {
   uint4* tin_he = nullptr;
   size_t tin_he_bytes = 0;
   bool tin_ok = false;
+  size_t tin_nhe = 0;       // half-edge records (3 x triangles); behind them rim records, behind those chunk records (mcl_halfedge.h)
   size_t tin_rims = 0;      // rim records behind the 3 nt half-edge records: the edges of the holes the walk crosses by itself (mcl_halfedge.h: link_holes)
   u32* cell_rim = nullptr;   // per cell of the cell grid: the first rim record of the linked hole whose bounding box reaches into the cell (0xffffffff: none, 0xfffffffe: more than one) -- where a walk starts whose nadir ray falls into a gap
   bool tin_holes = false;   // some edge of the TIN has no triangle on its far side and does not lie on the bounding box: a hole or a ragged outline (walks that reach it hand their particle over)
@@ -406,7 +407,9 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
       halfedge::build_table(verts, tris, nt, twin, ccw, new_of_old, xmin, xmax, ymin, ymax, he);
       static_assert(sizeof(halfedge::Rec) == 2 * sizeof(uint4), "the device reads a half-edge record as two 16-byte words");
       const bool link = !(getenv("MCL_TIN_RIMS") && atoi(getenv("MCL_TIN_RIMS")) == 0);   // (0: no hole is crossed -- A/B, tests)
-      m->tin_rims = link ? halfedge::link_holes(he, nt) : 0;
+      const halfedge::Links links = link ? halfedge::link_holes(he, nt) : halfedge::Links();
+      m->tin_rims = links.nrim;
+      m->tin_nhe = 3 * (size_t)nt;
       m->tin_holes = m->tin_rims != 0;
       for (size_t q = 0; q < 3 * (size_t)nt && !m->tin_holes; ++q) m->tin_holes = he[q].next_a == halfedge::HOLE || he[q].next_b == halfedge::HOLE;
       std::vector<uint32_t> cell_rim;
@@ -414,7 +417,8 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
         // which hole may lie under a sensor: every cell the hole's bounding box reaches into names the hole's first rim
         // record (the walk itself decides by parity whether its nadir ray goes through THAT hole, mcl_sweep.h)
         cell_rim.assign(nc, 0xffffffffu);
-        for (size_t k = 3 * (size_t)nt; k < he.size(); k += he[k].pad1) {
+        for (size_t k = 3 * (size_t)nt; k < 3 * (size_t)nt + links.nrim; k += he[k].pad1) {
+          if (he[k].pad2 & halfedge::RIM_EXTERIOR) continue;   // (the outline: a sensor beyond it is off the mesh)
           float bx0 = 3e38f, bx1 = -3e38f, by0 = 3e38f, by1 = -3e38f;
           for (size_t q = k; q < k + he[k].pad1; ++q) {
             float x, y;
@@ -582,7 +586,7 @@ inline MeshArgs mesh_args(const MeshDev* m) {
   ma.tin_he = m->tin_he;
   ma.tin_he_bytes = (u32)m->tin_he_bytes;
   ma.cell_rim = m->cell_rim;
-  ma.tin_nhe = (u32)(m->tin_he_bytes / sizeof(halfedge::Rec) - m->tin_rims);
+  ma.tin_nhe = (u32)m->tin_nhe;
   ma.cell_tri = m->cell_tri;
   ma.x0 = m->x0;
   ma.y0 = m->y0;

@@ -1001,35 +1001,31 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   const auto he_nb = [&](u32 h) {     // next_b
     return (u32)__builtin_amdgcn_raw_buffer_load_b32(hrsrc, (int)(h << 5) + 16, 0, 0);
   };
-  // Once around the rim of a linked hole (mcl_halfedge.h: its `cnt` edges from the one at place `pos` of the rim records
-  // rbase .. rbase + rlen - 1, read by index: the loads do not wait for one another): of the edges the fan plane cuts beyond
-  // s_min, the nearest -- its rim record, its two ends (the interior half-edge runs CA -> CB), the cut (cs, ct) -- and how many
-  // there are.
+  // Along the rim of a linked hole or of the outline (mcl_halfedge.h): `cnt` edges from the one at place `pos` of the rim
+  // records rbase .. rbase + rlen - 1, read by index (loads that do not wait for one another).  Of the edges the fan plane
+  // cuts beyond s_min -- not the edge `skip` the slice came through, not an edge of the outline on the bounding box (word 3,
+  // top bit: no way in through it) -- the nearest is kept in r: its rim record, its two ends (the interior half-edge runs
+  // CA -> CB), the cut (cs, ct); r.cuts counts them.
   struct RimCut {
     u32 best, cuts;
     float cs, ct;
     TinNode CA, CB;
   };
-  const auto rim_cut = [&](const u32 rbase, const u32 rlen, u32 pos, const u32 cnt, const float s_min, const bool strict) {
-    RimCut r;
-    r.best = 0xffffffffu;
-    r.cuts = 0u;
-    r.cs = __builtin_inff();
-    r.ct = 0.f;
+  const auto rim_edges = [&](RimCut& r, const u32 rbase, const u32 rlen, u32 pos, const u32 cnt, const float s_min, const bool strict, const u32 skip) {
     pos -= pos >= rlen ? rlen : 0u;
     u32 cur = rbase + pos;
-    TinNode Nc = node_of(he_xyzn(cur));
-    r.CA = Nc;
-    r.CB = Nc;
+    uint4 qc = he_xyzn(cur);
+    TinNode Nc = node_of(qc);
     for (u32 g = 0; g < cnt; ++g) {
       pos += 1u;
       pos -= pos >= rlen ? rlen : 0u;
       const u32 nxt = rbase + pos;
-      const TinNode Nn = node_of(he_xyzn(nxt));
+      const uint4 qn = he_xyzn(nxt);
+      const TinNode Nn = node_of(qn);
       if ((__float_as_int(Nc.d) ^ __float_as_int(Nn.d)) < 0) {
         const float lam = Nc.d * fast_rcp(Nc.d - Nn.d);
         const float sx = fmaf(lam, Nn.s - Nc.s, Nc.s), tx = fmaf(lam, Nn.t - Nc.t, Nc.t);
-        const bool beyond = strict ? sx > s_min : sx >= s_min;
+        const bool beyond = (strict ? sx > s_min : sx >= s_min) && cur != skip && (int)qc.w >= 0;
         r.cuts += beyond ? 1u : 0u;
         const bool take = beyond && sx < r.cs;
         r.cs = take ? sx : r.cs;
@@ -1039,7 +1035,33 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
         r.CB = sel(take, Nn, r.CB);
       }
       cur = nxt;
+      qc = qn;
       Nc = Nn;
+    }
+  };
+  // ... the whole rim: edge by edge, or -- a long rim: chunk records from `cbase`, each the sphere around RIM_CHUNK consecutive
+  // edges -- only the chunks whose sphere the plane cuts and that do not lie entirely before s_min
+  const auto rim_cut = [&](const u32 rbase, const u32 rlen, const u32 cbase, const float s_min, const bool strict, const u32 skip) {
+    RimCut r;
+    r.best = 0xffffffffu;
+    r.cuts = 0u;
+    r.cs = __builtin_inff();
+    r.ct = 0.f;
+    r.CA.d = r.CA.s = r.CA.t = 0.f;
+    r.CB = r.CA;
+    if (cbase == 0u) {
+      rim_edges(r, rbase, rlen, 0u, rlen, s_min, strict, skip);
+    } else {
+      const u32 nch = (rlen + halfedge::RIM_CHUNK - 1) / halfedge::RIM_CHUNK;
+      for (u32 c = 0; c < nch; ++c) {
+        const uint4 q = he_xyzn(cbase + c);
+        const TinNode N = node_of(q);
+        const float R = __uint_as_float(q.w);
+        if (fabsf(N.d) <= R && N.s + R >= s_min) {
+          const u32 p0 = c * halfedge::RIM_CHUNK;
+          rim_edges(r, rbase, rlen, p0, min((u32)halfedge::RIM_CHUNK, rlen - p0), s_min, strict, skip);
+        }
+      }
     }
     return r;
   };
@@ -1055,8 +1077,8 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     // they agree, up to a cut at s = 0 to rounding -- one side then declines and the particle is handed over.)
     const u32 rb = ma.cell_rim[(size_t)I0 * ma.gy + J0];
     if (rb >= 0xfffffffeu) SWEEP_FAIL(4);
-    const u32 rlen = (u32)__builtin_amdgcn_raw_buffer_load_b32(hrsrc, (int)(rb << 5) + 24, 0, 0);
-    const RimCut rc = rim_cut(rb, rlen, 0u, rlen, 0.f, true);
+    const uint4 rw = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (int)(rb << 5) + 16, 0, 0));   // {half-edge, first record, edges, chunks | outline}
+    const RimCut rc = rim_cut(rb, rw.z, rw.w & 0x7fffffffu, 0.f, true, 0xffffffffu);
     if (!(rc.cuts & 1u) || !(rc.ct > 0.f)) SWEEP_FAIL(4);
     if (none) return true;
     A = rc.CA;
@@ -1194,11 +1216,11 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
       // hq is that record.  Once around the rim: of the edges the fan plane cuts, the nearest one further out is where
       // the slice meets the mesh again (nothing lies inside a linked hole).
       const u32 k0 = nb;
-      const u32 rbase = (u32)__builtin_amdgcn_raw_buffer_load_b32(hrsrc, (int)(k0 << 5) + 20, 0, 0);
-      const u32 rlen = (u32)__builtin_amdgcn_raw_buffer_load_b32(hrsrc, (int)(k0 << 5) + 24, 0, 0);
-      const RimCut rc = rim_cut(rbase, rlen, k0 - rbase + 1u, rlen - 1u, sc, false);   // (every edge of the rim but the one reached)
+      const uint4 rw = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (int)(k0 << 5) + 16, 0, 0));   // {half-edge, first record, edges, chunks | outline}
+      const RimCut rc = rim_cut(rw.y, rw.z, rw.w & 0x7fffffffu, sc, false, k0);   // (every edge of the rim but the one reached)
       const u32 best = rc.best;
       const float bs = rc.cs, bt = rc.ct;
+      if (best == 0xffffffffu && (int)rw.w < 0) return true;   // beyond the OUTLINE and no way back in: nothing lies further out -- the beams left get r_max through the tail below
       // (a slice through a rim vertex can find the two cuts there in either order and go back and forth between the gap and
       //  a sliver: a side crosses SWEEP_TIN_GAPS gaps at most)
       if (best == 0xffffffffu || !(bt > 0.f) || ++gaps > SWEEP_TIN_GAPS) {

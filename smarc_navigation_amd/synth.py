@@ -188,6 +188,46 @@ def mesh_shuffle(verts, tris, seed=9):
     return v2, np.ascontiguousarray(t2.astype(np.uint32))
 
 
+def mesh_ragged(verts, tris, seed=13, band=3.0, p_gone=0.45, bays=6, bay_width=(2.0, 6.0), bay_depth=(10.0, 40.0), keep=None):
+    """The same surface with the OUTLINE of a real survey: the triangles within `band` metres of the bounding box are removed
+    at random (a sawtooth border), `bays` rectangular bays are cut in from the sides, and of what is left the largest
+    edge-connected piece is kept (the scraps of a ragged border would lie outside the outline).  keep = (x, y): a bay is
+    re-drawn until it stays a bay's width clear of that point.  Returns the triangle array (the vertices stay)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    rs = np.random.RandomState(seed)
+    t = tris.astype(np.int64)
+    c = verts[t].mean(axis=1)
+    x0, y0, x1, y1 = verts[:, 0].min(), verts[:, 1].min(), verts[:, 0].max(), verts[:, 1].max()
+    edge = np.minimum(np.minimum(c[:, 0] - x0, x1 - c[:, 0]), np.minimum(c[:, 1] - y0, y1 - c[:, 1]))
+    gone = (edge < band) & (rs.rand(len(t)) < p_gone)
+    for _ in range(bays):
+        for _try in range(20):
+            w = rs.uniform(*bay_width)
+            dep = rs.uniform(*bay_depth)
+            side = rs.randint(4)
+            if side < 2:
+                y = rs.uniform(y0 + 0.1 * (y1 - y0), y1 - 0.1 * (y1 - y0))
+                box = (x0 - 1, x0 + dep, y - w / 2, y + w / 2) if side == 0 else (x1 - dep, x1 + 1, y - w / 2, y + w / 2)
+            else:
+                x = rs.uniform(x0 + 0.1 * (x1 - x0), x1 - 0.1 * (x1 - x0))
+                box = (x - w / 2, x + w / 2, y0 - 1, y0 + dep) if side == 2 else (x - w / 2, x + w / 2, y1 - dep, y1 + 1)
+            if keep is None or not (box[0] - w < keep[0] < box[1] + w and box[2] - w < keep[1] < box[3] + w):
+                break
+        gone |= (c[:, 0] > box[0]) & (c[:, 0] < box[1]) & (c[:, 1] > box[2]) & (c[:, 1] < box[3])
+    t = t[~gone]
+    # triangles that share an edge: sort the 3 n undirected edges, equal neighbours in the order are pairs
+    e = np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]])
+    e.sort(axis=1)
+    key = e[:, 0] * (verts.shape[0] + 1) + e[:, 1]
+    order = np.argsort(key, kind='stable')
+    same = key[order][1:] == key[order][:-1]
+    a, b = order[:-1][same] % len(t), order[1:][same] % len(t)
+    ncomp, lab = connected_components(coo_matrix((np.ones(a.size), (a, b)), shape=(len(t), len(t))), directed=False)
+    big = np.argmax(np.bincount(lab))
+    return np.ascontiguousarray(t[lab == big].astype(np.uint32))
+
+
 def landmark_map(n=4096, extent=(-64.0, -256.0, 448.0, 256.0), z_range=(-24.0, -16.0), seed=6):
     """Feature map of BASELINE config 5: n landmarks uniform over the map (seed 6)."""
     rs = np.random.RandomState(seed)

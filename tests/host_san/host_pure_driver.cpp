@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <unordered_map>
 
 #include "../../smarc_navigation_amd/csrc/mcl_host_pure.h"
 #include "../../smarc_navigation_amd/csrc/mcl_halfedge.h"
@@ -219,19 +220,23 @@ static int check_halfedge_tables(std::mt19937_64& rng) {
   return 0;
 }
 
-// ---- holes the walk crosses (mcl_halfedge.h: link_holes): random TINs with gaps punched into them -- clusters of triangles
-// removed around interior points, sometimes two gaps that merge, sometimes one that reaches the outline, sometimes an
-// island left inside.  The rim records must close into loops around empty space, name the interior half-edge they belong
-// to and be named by it; a walk by the kernel's rule (sweep_side_tin<.., HOLES>) that reaches a rim goes around it once and
-// takes the nearest cut further out: between the two cuts NO triangle may lie under the slice (brute force over all
-// triangles), and the walk must still end at the outer border, never going back in s.
+// ---- holes and outlines the walk crosses (mcl_halfedge.h: link_holes): random TINs with gaps punched into them -- discs of
+// triangles removed around interior points (sometimes merged, sometimes large: a rim long enough for chunk records), a ring
+// (an island inside a hole), and RAGGED OUTLINES: border triangles removed at random and bays cut deep into the mesh, the
+// largest edge-connected piece kept.  Checked: the rim records (loops in rim order around empty space, naming the interior
+// half-edge that names them; box edges of the outline flagged and left with their border code; every vertex of a chunk
+// inside its sphere); and WALKS by the kernel's rule (sweep_side_tin<.., HOLES>): at a rim the nearest cut further out --
+// found through the chunk spheres exactly as by brute force over every edge --, NO triangle between the two cuts, s never
+// decreasing; beyond the outline with no cut left, no triangle anywhere further along the line; an island's hole never linked.
 static int check_hole_rims(std::mt19937_64& rng) {
   using halfedge::Rec;
   std::uniform_real_distribution<double> U01(0.0, 1.0);
-  int linked_meshes = 0, refused = 0;
-  long crossings = 0;
-  for (int trial = 0; trial < 60; ++trial) {
-    const int nx = 9 + (int)(rng() % 12), ny = 9 + (int)(rng() % 10);
+  int linked_meshes = 0, refused = 0, outline_meshes = 0, chunked_meshes = 0;
+  long crossings = 0, bays = 0, finals = 0;
+  for (int trial = 0; trial < 96; ++trial) {
+    const int kind = trial % 8;   // 0-2 discs, 3 a disc at the outline, 4 ring (island), 5-6 ragged outline + bays (+ discs), 7 a large hole
+    const bool large = kind == 7, ragged = kind == 5 || kind == 6;
+    const int nx = (large || ragged ? 22 : 9) + (int)(rng() % 10), ny = (large || ragged ? 20 : 9) + (int)(rng() % 10);
     std::vector<float> verts;
     std::vector<uint32_t> all, tris;
     random_tin(rng, nx, ny, verts, all);
@@ -240,25 +245,84 @@ static int check_hole_rims(std::mt19937_64& rng) {
       xmin = std::min(xmin, (double)verts[3 * i]); xmax = std::max(xmax, (double)verts[3 * i]);
       ymin = std::min(ymin, (double)verts[3 * i + 1]); ymax = std::max(ymax, (double)verts[3 * i + 1]);
     }
-    // gaps: 1 .. 3 discs; kind 1: one disc at the outline (a ragged border, not a hole); kind 2: a ring (an island inside)
-    const int kind = trial % 5 == 3 ? 1 : (trial % 5 == 4 ? 2 : 0);
-    const int ndisc = 1 + (int)(rng() % 3);
+    const int ndisc = large ? 1 : 1 + (int)(rng() % 3);
     double cx[3], cy[3], rad[3];
     for (int q = 0; q < ndisc; ++q) {
-      cx[q] = xmin + (0.25 + 0.5 * U01(rng)) * (xmax - xmin);
-      cy[q] = ymin + (0.25 + 0.5 * U01(rng)) * (ymax - ymin);
-      rad[q] = 0.8 + 1.2 * U01(rng);
+      cx[q] = xmin + (0.3 + 0.4 * U01(rng)) * (xmax - xmin);
+      cy[q] = ymin + (0.3 + 0.4 * U01(rng)) * (ymax - ymin);
+      rad[q] = large ? 6.5 + 1.5 * U01(rng) : 0.8 + 1.2 * U01(rng);
     }
-    if (kind == 1) cx[0] = xmin + 0.3;
+    if (kind == 3) cx[0] = xmin + 0.3;
+    // bays: rectangles cut in from a side (ragged kinds)
+    double bay[3][4];
+    const int nbay = ragged ? 1 + (int)(rng() % 3) : 0;
+    for (int q = 0; q < nbay; ++q) {
+      const double w = 1.6 + 2.0 * U01(rng), dep = 4.0 + 6.0 * U01(rng);
+      if (rng() & 1u) {   // from the left or right side
+        const double y = ymin + (0.2 + 0.6 * U01(rng)) * (ymax - ymin);
+        const bool left = rng() & 1u;
+        bay[q][0] = left ? xmin - 1 : xmax - dep; bay[q][1] = left ? xmin + dep : xmax + 1; bay[q][2] = y - w / 2; bay[q][3] = y + w / 2;
+      } else {
+        const double x = xmin + (0.2 + 0.6 * U01(rng)) * (xmax - xmin);
+        const bool low = rng() & 1u;
+        bay[q][0] = x - w / 2; bay[q][1] = x + w / 2; bay[q][2] = low ? ymin - 1 : ymax - dep; bay[q][3] = low ? ymin + dep : ymax + 1;
+      }
+    }
     for (size_t k = 0; k < all.size() / 3; ++k) {
       double mx = 0, my = 0;
       for (int c = 0; c < 3; ++c) { mx += verts[3 * (size_t)all[3 * k + c]] / 3.0; my += verts[3 * (size_t)all[3 * k + c] + 1] / 3.0; }
       bool gone = false;
       for (int q = 0; q < ndisc; ++q) {
         const double r = std::hypot(mx - cx[q], my - cy[q]);
-        gone |= (kind == 2 && q == 0) ? (r > 1.2 && r < 3.0) : r < rad[q];
+        gone |= (kind == 4 && q == 0) ? (r > 1.2 && r < 3.0) : (ragged && q > 0 ? false : r < rad[q]);
+      }
+      for (int q = 0; q < nbay; ++q) gone |= mx > bay[q][0] && mx < bay[q][1] && my > bay[q][2] && my < bay[q][3];
+      if (ragged) {
+        const double e = std::min(std::min(mx - xmin, xmax - mx), std::min(my - ymin, ymax - my));
+        gone |= e < 1.7 && U01(rng) < 0.45;
       }
       if (!gone) tris.insert(tris.end(), all.begin() + 3 * (long)k, all.begin() + 3 * (long)k + 3);
+    }
+    if (ragged) {
+      // keep the largest edge-connected piece (the scraps a ragged border leaves would lie OUTSIDE the outline)
+      const size_t n = tris.size() / 3;
+      std::unordered_map<uint64_t, std::vector<uint32_t>> by_edge;
+      for (size_t k = 0; k < n; ++k)
+        for (int e = 0; e < 3; ++e) {
+          const uint32_t a = tris[3 * k + e], b = tris[3 * k + (e + 1) % 3];
+          by_edge[a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a].push_back((uint32_t)k);
+        }
+      std::vector<int> comp(n, -1);
+      int ncomp = 0, bestc = 0;
+      size_t bestn = 0;
+      for (size_t k0 = 0; k0 < n; ++k0) {
+        if (comp[k0] >= 0) continue;
+        std::vector<uint32_t> stack{(uint32_t)k0};
+        comp[k0] = ncomp;
+        size_t cnt = 0;
+        while (!stack.empty()) {
+          const uint32_t k = stack.back();
+          stack.pop_back();
+          ++cnt;
+          for (int e = 0; e < 3; ++e) {
+            const uint32_t a = tris[3 * (size_t)k + e], b = tris[3 * (size_t)k + (e + 1) % 3];
+            for (uint32_t k2 : by_edge[a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a])
+              if (comp[k2] < 0) { comp[k2] = ncomp; stack.push_back(k2); }
+          }
+        }
+        if (cnt > bestn) { bestn = cnt; bestc = ncomp; }
+        ++ncomp;
+      }
+      std::vector<uint32_t> kept;
+      for (size_t k = 0; k < n; ++k)
+        if (comp[k] == bestc) kept.insert(kept.end(), tris.begin() + 3 * (long)k, tris.begin() + 3 * (long)k + 3);
+      tris.swap(kept);
+      // (the bounding box is the kept piece's own)
+      xmin = ymin = 1e300; xmax = ymax = -1e300;
+      for (uint32_t v : tris) {
+        xmin = std::min(xmin, (double)verts[3 * (size_t)v]); xmax = std::max(xmax, (double)verts[3 * (size_t)v]);
+        ymin = std::min(ymin, (double)verts[3 * (size_t)v + 1]); ymax = std::max(ymax, (double)verts[3 * (size_t)v + 1]);
+      }
     }
     const int64_t nt = (int64_t)tris.size() / 3;
     std::vector<uint32_t> new_of_old, twin;
@@ -269,8 +333,9 @@ static int check_hole_rims(std::mt19937_64& rng) {
     CHECK(halfedge::adjacency(verts.data(), tris.data(), nt, twin, ccw, g2));
     halfedge::build_table(verts.data(), tris.data(), nt, twin, ccw, new_of_old, xmin, xmax, ymin, ymax, he);
     const size_t nhe = 3 * (size_t)nt;
-    const size_t nrim = halfedge::link_holes(he, nt);
-    CHECK(he.size() == nhe + nrim);
+    const halfedge::Links links = halfedge::link_holes(he, nt);
+    const size_t nrim = links.nrim;
+    CHECK(he.size() == nhe + nrim + links.nchunk);
     auto xyz = [&](const Rec& r, float out[3]) { std::memcpy(out, &r.x, 12); };
     auto vert = [&](uint32_t T, int j, float out[3]) { xyz(he[3 * (size_t)T + (size_t)((j + 1) % 3)], out); };
     auto inside_some_triangle = [&](double px, double py) {
@@ -284,59 +349,77 @@ static int check_hole_rims(std::mt19937_64& rng) {
       }
       return false;
     };
-    if (kind == 2) {
+    if (kind == 4 && inside_some_triangle(cx[0], cy[0])) {
       // an island inside a hole: THAT hole may not be linked (others of the same mesh may): the island's point lies inside
-      // no linked rim polygon
-      if (inside_some_triangle(cx[0], cy[0])) {
-        for (size_t k = nhe; k < nhe + nrim; k += he[k].pad1) {
-          bool in = false;
-          for (size_t q = k; q < k + he[k].pad1; ++q) {
-            float a[3], b[3];
-            xyz(he[q], a);
-            xyz(he[he[q].next_a], b);
-            if ((a[1] > cy[0]) != (b[1] > cy[0]) && cx[0] < a[0] + (cy[0] - a[1]) * ((double)b[0] - a[0]) / ((double)b[1] - a[1])) in = !in;
-          }
-          CHECK(!in);
+      // no linked hole's rim polygon
+      for (size_t k = nhe; k < nhe + nrim; k += he[k].pad1) {
+        if (he[k].pad2 & halfedge::RIM_EXTERIOR) continue;
+        bool in = false;
+        for (size_t q = k; q < k + he[k].pad1; ++q) {
+          float a[3], b[3];
+          xyz(he[q], a);
+          xyz(he[he[q].next_a & 0x7fffffffu], b);
+          if ((a[1] > cy[0]) != (b[1] > cy[0]) && cx[0] < a[0] + (cy[0] - a[1]) * ((double)b[0] - a[0]) / ((double)b[1] - a[1])) in = !in;
         }
-        ++refused;
+        CHECK(!in);
       }
+      ++refused;
     }
     if (nrim == 0) continue;
     ++linked_meshes;
+    outline_meshes += links.outline ? 1 : 0;
+    chunked_meshes += links.nchunk ? 1 : 0;
     // ---- the records
-    std::vector<unsigned char> in_loop(nrim, 0);
     for (size_t k = nhe; k < nhe + nrim; ++k) {
       const Rec& r = he[k];
-      CHECK(r.next_a >= nhe && r.next_a < nhe + nrim && r.next_b < nhe);
-      CHECK(r.pad0 >= nhe && r.pad1 >= 3 && r.pad1 <= (uint32_t)halfedge::RIM_MAX && k >= r.pad0 && k < (size_t)r.pad0 + r.pad1);   // the hole's records lie together ...
-      CHECK(r.next_a == r.pad0 + (uint32_t)((k - r.pad0 + 1) % r.pad1) && he[r.next_a].pad0 == r.pad0 && he[r.next_a].pad1 == r.pad1);   // ... in rim order
+      const uint32_t nxt = r.next_a & 0x7fffffffu;
+      const bool on_box = (r.next_a & halfedge::RIM_ON_BOX) != 0, ext = (r.pad2 & halfedge::RIM_EXTERIOR) != 0;
+      CHECK(nxt >= nhe && nxt < nhe + nrim && r.next_b < nhe);
+      CHECK(r.pad0 >= nhe && r.pad1 >= 3 && k >= r.pad0 && k < (size_t)r.pad0 + r.pad1);             // the rim's records lie together ...
+      CHECK(nxt == r.pad0 + (uint32_t)((k - r.pad0 + 1) % r.pad1) && he[nxt].pad0 == r.pad0 && he[nxt].pad1 == r.pad1 && he[nxt].pad2 == r.pad2);   // ... in rim order
+      CHECK(!on_box || ext);                                                                          // only the outline has edges on the box
       const uint32_t h = r.next_b, T = h / 3u;
       const int j = (int)(h % 3u);
-      CHECK(he[3 * (size_t)T + (size_t)((j + 1) % 3)].next_a == (uint32_t)k && he[3 * (size_t)T + (size_t)((j + 2) % 3)].next_b == (uint32_t)k);
+      const uint32_t far_a = he[3 * (size_t)T + (size_t)((j + 1) % 3)].next_a, far_b = he[3 * (size_t)T + (size_t)((j + 2) % 3)].next_b;
+      CHECK(far_a == far_b);
+      if (on_box) CHECK(far_a == halfedge::BORDER_X || far_a == halfedge::BORDER_Y); else CHECK(far_a == (uint32_t)k);
       float a[3], b[3], ra[3], rb[3];
       vert(T, j, a);
       vert(T, (j + 1) % 3, b);
       xyz(r, ra);
-      xyz(he[r.next_a], rb);
+      xyz(he[nxt], rb);
       CHECK(std::memcmp(a, ra, 12) == 0 && std::memcmp(b, rb, 12) == 0);   // the edge a -> b, the next rim edge starts at b
-      // the hole is on the RIGHT of a -> b: a point just right of the edge's middle lies in no triangle
+      // empty space on the RIGHT of a -> b: a point just right of the edge's middle lies in no triangle
       const double ex = (double)b[0] - a[0], ey = (double)b[1] - a[1], el = std::hypot(ex, ey);
       CHECK(!inside_some_triangle(0.5 * (a[0] + b[0]) + 1e-3 * ey / el, 0.5 * (a[1] + b[1]) - 1e-3 * ex / el));
-      // closes within RIM_MAX edges
-      size_t q = k;
-      int len = 0;
-      do {
-        q = he[q].next_a;
-        CHECK(++len <= halfedge::RIM_MAX);
-      } while (q != k);
-      in_loop[k - nhe] = 1;
+      const uint32_t cb = r.pad2 & 0x7fffffffu;
+      CHECK((cb != 0) == (r.pad1 > (uint32_t)halfedge::RIM_CHUNK_MIN));
+      if (cb) {   // the vertex lies in the sphere of its chunk (and, as the end of the last edge before it, of the one before)
+        CHECK(cb >= nhe + nrim && cb + (r.pad1 + halfedge::RIM_CHUNK - 1) / halfedge::RIM_CHUNK <= he.size());
+        const size_t pos = k - r.pad0, nch = (r.pad1 + halfedge::RIM_CHUNK - 1) / halfedge::RIM_CHUNK;
+        const size_t c1 = pos / halfedge::RIM_CHUNK, c0 = pos % halfedge::RIM_CHUNK == 0 ? (c1 + nch - 1) % nch : c1;
+        for (size_t c : {c0, c1}) {
+          float cc[3], R;
+          xyz(he[cb + c], cc);
+          std::memcpy(&R, &he[cb + c].next_a, 4);
+          CHECK(std::sqrt(((double)ra[0] - cc[0]) * ((double)ra[0] - cc[0]) + ((double)ra[1] - cc[1]) * ((double)ra[1] - cc[1]) + ((double)ra[2] - cc[2]) * ((double)ra[2] - cc[2])) <= R);
+        }
+      }
     }
-    // no HOLE code may be left on an edge of a linked loop, and every code left belongs to the outline or to a long loop
-    // ---- walks that cross
-    for (int w = 0; w < 30; ++w) {
-      // through a gap: a point of the disc's neighbourhood, any direction
-      const int q0 = (int)(rng() % (unsigned)ndisc);
-      const double px = cx[q0] + 3.0 * (U01(rng) - 0.5), py = cy[q0] + 3.0 * (U01(rng) - 0.5);
+    // no rim code on an edge of a loop that was not linked
+    // ---- walks
+    int final_checks = 0;
+    for (int w = 0; w < 24; ++w) {
+      double px, py;
+      if (ragged && (w & 1)) {   // near the outline
+        px = xmin + (0.1 + 0.8 * U01(rng)) * (xmax - xmin);
+        py = ymin + (0.1 + 0.8 * U01(rng)) * (ymax - ymin);
+      } else {
+        const int q0 = (int)(rng() % (unsigned)ndisc);
+        const double reach = large ? 18.0 : 3.0;
+        px = cx[q0] + reach * (U01(rng) - 0.5);
+        py = cy[q0] + reach * (U01(rng) - 0.5);
+      }
       const double ang = 6.283185307179586 * U01(rng);
       const double c1x = std::cos(ang), c1y = std::sin(ang);
       auto d_of = [&](const float* p) { return -c1y * ((double)p[0] - px) + c1x * ((double)p[1] - py); };
@@ -350,7 +433,7 @@ static int check_hole_rims(std::mt19937_64& rng) {
           in = ((double)v[(j + 1) % 3][0] - v[j][0]) * (py - v[j][1]) - ((double)v[(j + 1) % 3][1] - v[j][1]) * (px - v[j][0]) >= 0.0;
         if (in) T0 = T;
       }
-      if (T0 < 0) continue;   // (the point fell into a gap: the kernel hands such a particle over)
+      if (T0 < 0) continue;   // (the point fell into a gap or off the mesh)
       for (int side = 0; side < 2; ++side) {
         const double sg = side ? -1.0 : 1.0;
         float v[3][3];
@@ -379,38 +462,61 @@ static int check_hole_rims(std::mt19937_64& rng) {
         bool ao = far_m == pl;
         double s_prev = far_m ? sm : sn;
         int steps = 0;
-        bool gave_up = false;
-        while (nb < 0xfffffff0u) {
+        bool ended = false;
+        while (nb < 0xfffffff0u && !ended) {
           CHECK(++steps <= 3 * nt + 64);
           if (nb >= nhe) {
-            // a rim: once around, the nearest cut further out
-            const uint32_t k0 = nb;
-            uint32_t cur = he[k0].next_a, best = 0xffffffffu;
-            float pc[3];
-            xyz(he[cur], pc);
-            double dc = d_of(pc), scc = sg * s_of(pc), bs = 1e300, bAd = 0, bBd = 0, bAs = 0, bBs = 0;
-            for (int g = 0; g < halfedge::RIM_MAX && cur != k0; ++g) {
-              const uint32_t nxt = he[cur].next_a;
-              float pn[3];
-              xyz(he[nxt], pn);
-              const double dn = d_of(pn), sn2 = sg * s_of(pn);
-              if ((dc >= 0) != (dn >= 0)) {
-                const double lam = dc / (dc - dn), sx = scc + lam * (sn2 - scc);
-                if (sx >= s_prev && sx < bs) { bs = sx; best = cur; bAd = dc; bBd = dn; bAs = scc; bBs = sn2; }
+            CHECK(nb < nhe + nrim);
+            // a rim: the nearest cut further out, not through the edge reached, not through an edge on the box -- by
+            // brute force over every edge, and through the chunk spheres as the kernel goes
+            const uint32_t k0 = nb, rbase = he[k0].pad0, rlen = he[k0].pad1, cb = he[k0].pad2 & 0x7fffffffu;
+            const bool ext = (he[k0].pad2 & halfedge::RIM_EXTERIOR) != 0;
+            uint32_t best[2] = {0xffffffffu, 0xffffffffu};
+            double bs[2] = {1e300, 1e300}, bAd = 0, bBd = 0, bAs = 0, bBs = 0;
+            for (int pass = 0; pass < (cb ? 2 : 1); ++pass) {
+              for (uint32_t e = 0; e < rlen; ++e) {
+                const uint32_t cur = rbase + e, nxt = rbase + (e + 1) % rlen;
+                if (cur == k0 || (he[cur].next_a & halfedge::RIM_ON_BOX)) continue;
+                if (pass == 1) {   // is this edge's chunk visited?
+                  const Rec& c = he[cb + e / halfedge::RIM_CHUNK];
+                  float cc[3], R;
+                  xyz(c, cc);
+                  std::memcpy(&R, &c.next_a, 4);
+                  if (!(std::fabs(d_of(cc)) <= R && sg * s_of(cc) + R >= s_prev)) continue;
+                }
+                float pc[3], pn[3];
+                xyz(he[cur], pc);
+                xyz(he[nxt], pn);
+                const double dc = d_of(pc), dn = d_of(pn), sc2 = sg * s_of(pc), sn2 = sg * s_of(pn);
+                if ((dc >= 0) == (dn >= 0)) continue;
+                const double lam = dc / (dc - dn), sx = sc2 + lam * (sn2 - sc2);
+                if (sx >= s_prev && sx < bs[pass]) {
+                  bs[pass] = sx; best[pass] = cur;
+                  if (pass == 0) { bAd = dc; bBd = dn; bAs = sc2; bBs = sn2; }
+                }
               }
-              cur = nxt; dc = dn; scc = sn2;
             }
-            if (best == 0xffffffffu) { gave_up = true; break; }   // (a cut through a rim vertex, to rounding: the kernel hands over)
-            // nothing between the two cuts
+            if (cb) CHECK(best[1] == best[0]);
+            if (best[0] == 0xffffffffu) {
+              if (!ext) break;   // (a cut through a rim vertex, to rounding: the kernel hands over)
+              // beyond the outline for good: no triangle further along the line
+              if (final_checks < 8) {
+                ++final_checks;
+                for (double sx = s_prev + 0.05; sx < 80.0; sx += 0.2) CHECK(!inside_some_triangle(px + sg * sx * c1x, py + sg * sx * c1y));
+                ++finals;
+              }
+              ended = true;
+              break;
+            }
             for (int m = 1; m < 8; ++m) {
-              const double sm2 = s_prev + (bs - s_prev) * m / 8.0;
+              const double sm2 = s_prev + (bs[0] - s_prev) * m / 8.0;
               CHECK(!inside_some_triangle(px + sg * sm2 * c1x, py + sg * sm2 * c1y));
             }
-            ++crossings;
-            s_prev = bs;
+            (ext ? bays : crossings) += 1;
+            s_prev = bs[0];
             Ad = bAd; Bd = bBd; As = bAs; Bs = bBs;
             ao = true;
-            nb = he[best].next_b;
+            nb = he[best[0]].next_b;
             CHECK(nb < nhe);
           }
           CHECK((Ad >= 0) != (Bd >= 0));
@@ -429,17 +535,12 @@ static int check_hole_rims(std::mt19937_64& rng) {
           CHECK(s_new >= s_prev - 1e-9);
           s_prev = s_new;
         }
-        if (gave_up) continue;
-        // the walk ends at the outer border -- or at an edge that was NOT linked (a gap that reaches the outline, a long rim)
-        CHECK(nb == halfedge::BORDER_X || nb == halfedge::BORDER_Y || nb == halfedge::HOLE);
-        if (kind == 0 && nb == halfedge::HOLE) {
-          // (all gaps interior and short: every hole must have been linked -- unless two discs merged into a long rim)
-        }
       }
     }
   }
-  std::fprintf(stderr, "hole rims: %d meshes linked, %ld gaps crossed, %d meshes with an island\n", linked_meshes, crossings, refused);
-  CHECK(linked_meshes >= 20 && crossings >= 200 && refused >= 4);
+  std::fprintf(stderr, "rims: %d meshes linked (%d with their outline, %d with chunk records), %ld holes crossed, %ld bays of an outline crossed, %ld exits beyond an outline verified empty, %d islands refused\n",
+               linked_meshes, outline_meshes, chunked_meshes, crossings, bays, finals, refused);
+  CHECK(linked_meshes >= 40 && crossings >= 200 && refused >= 4 && outline_meshes >= 12 && chunked_meshes >= 12 && bays >= 10 && finals >= 50);
   return 0;
 }
 

@@ -537,10 +537,12 @@ def _tin_with_a_gap(seed_z, seed_tin, at=(1.0, 3.0), radius=1.5):
     return verts, np.ascontiguousarray(tris[~gone])
 
 
-def _sharded_filter_is_bitwise(eng, orc, verts, tris, ranges, ba, steps=3):
+def _sharded_filter_is_bitwise(eng, orc, verts, tris, ranges, ba, steps=3, centre=None):
     """4 shards of 8 192 against the 32 768-particle filter through `steps` predict / update / resample rounds: bit for bit."""
     shards, n = 4, 32768
     cov = dict(init_cov=[0.25, 0.25, 0, 0, 0, 0.01], process_cov=[1e-3, 1e-3, 0, 0, 0, 1e-5], resample_cov=[0.01, 0.01, 0, 0, 0, 1e-4], seed=9)
+    if centre is not None:   # (the filter starts at the odometry's origin: the map <- odom transform puts that where the scene is)
+        cov['m2o'] = synth.rigid_matrix(centre[0], centre[1], 0.0, 0.0, 0.0, 0.0)
     one = eng.Engine(n, **cov)
     many = [eng.Engine(n // shards, rank=r, world=shards, n_global=n, global_offset=r * (n // shards), **cov) for r in range(shards)]
     q = orc.quat_from_euler(0.01, 0.02, 0.3)
@@ -603,6 +605,58 @@ def test_tin_hole_under_the_swath_is_crossed_by_its_rim(over, eng, orc, monkeypa
         split, n = _sharded_filter_is_bitwise(eng, orc, verts, holes, ranges, ba)
         print('sharded, gap crossed: (sweep handed over, cast by the slice, by the traversal) per step %r of %d' % (split, n))
         assert all(h < n // 4 for h, _, _ in split)
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_tin_with_a_ragged_outline_and_bays_is_walked_to_its_end(seed, eng, orc, monkeypatch):
+    """The outline of a real survey: border triangles missing at random, bays cut in from the sides (synth.mesh_ragged), the
+    vehicle 12 m inside the southern outline with a bay across its swath.  mesh_build links the outline like a hole's rim
+    (chunk records: spheres around 16 edges each): a slice that leaves through it either meets the mesh again across a bay
+    -- the beams that look into the bay miss -- or finds no cut further out and ends there, the beams left missing.  Every
+    ray against the oracle's brute force; with MCL_TIN_RIMS=0 the same particles are handed over instead (and agree);
+    seeds 2, 3: the mesh in random input order."""
+    from tests.helpers import live_particle_contract
+    z, origin = _terrain(seed=37 + seed)
+    verts, tris = synth.mesh_tin(z, 1.0, origin, seed=6 + seed)
+    centre = (8.0 * seed - 10.0, origin[1] + 12.0, -2.0)
+    tris = synth.mesh_ragged(verts, tris, seed=20 + seed, band=3.0, bays=10, bay_width=(2.0, 5.0), bay_depth=(8.0, 30.0), keep=centre[:2])
+    if seed >= 2:
+        verts, tris = synth.mesh_shuffle(verts, tris, seed=seed)
+    n, B = 2048, 192
+    soa = _cloud(n, 12, (2.0, 1.0, 0.05, 0.02, 0.02, 0.3 if seed % 2 else 3.0), centre)
+    ba = synth.beam_angles(B)
+    omap = orc.Mesh(verts, tris)
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, None, 0.2, 80.0)
+    handed = {}
+    got = {}
+    for rims in ('1', '0'):
+        monkeypatch.setenv('MCL_TIN_RIMS', rims)
+        e = _engine(eng, soa, verts, tris)
+        got[rims] = e.mbes_expected(0, n, ba, 80.0)
+        path, handed[rims], _ = e.mbes_last_path()
+        assert path == 1
+        e.close()
+    err = np.abs(got['1'] - ref)
+    miss = ref >= 80.0
+    print('ragged outline %d: outline linked: handed over %d of %d (not linked: %d); max |expected range error| %.2e m, rays off %d of %d; %d rays miss (%.0f %%)' % (
+        seed, handed['1'], n, handed['0'], err.max(), int((err > 1e-3).sum()), err.size, int(miss.sum()), 100.0 * miss.mean()))
+    assert handed['0'] > n // 2 and handed['1'] < n // 10
+    assert 0.02 < miss.mean() < 0.7
+    assert (err > 1e-3).sum() <= err.size // 20000 + 2
+    outliers_explained(orc, omap, soa, ba, got['1'], ref, 80.0, label='ragged outline %d' % seed)
+    assert np.abs(got['1'] - got['0']).max() <= 1e-3 or (np.abs(got['1'] - got['0']) > 1e-3).sum() <= 4
+    monkeypatch.setenv('MCL_TIN_RIMS', '1')
+    ranges = (ref[0] + 0.05 * np.random.RandomState(3).randn(B)).astype(np.float32)
+    ranges[ref[0] >= 80.0] = 0.0
+    lw_ref, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, ranges, 0.8, 80.0)
+    e = _engine(eng, soa, verts, tris)
+    e.update_mbes(ranges, ba, 0.8, 80.0)
+    live_particle_contract(orc, omap, soa, ba, ranges, 0.8, 80.0, e.get_log_weights(), lw_ref, lw_ref.max(), label='ragged outline %d' % seed,
+                           allow=max(1, n // 200))
+    e.close()
+    if seed == 0:
+        split, n = _sharded_filter_is_bitwise(eng, orc, verts, tris, ranges, ba, centre=centre)
+        print('sharded at the ragged outline: (sweep handed over, cast by the slice, by the traversal) per step %r of %d' % (split, n))
 
 
 def test_tin_hole_without_rim_records_goes_through_the_fan_slice(eng, orc, monkeypatch):
