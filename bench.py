@@ -894,7 +894,7 @@ def worker(a, rank, world, local_rank):
         # ... and the same TIN with a data gap of ten triangles under the swath of the timed steps: every particle's slice runs
         # into it, the sweep hands the whole cloud over -- to the fan slice (mcl_host_update.h; round 5 / MCL_HANDOVER_SLICE=0:
         # to the ray traversal, 21 ms per step).  The worst case of a survey mesh with gaps, not its average.
-        legs.append(('mesh_tin_hole_under_swath', dict(m=punch_hole(tin, 1.0, 10.0), P=1048576, B=512, steps=20, warmup=10)))
+        legs.append(('mesh_tin_hole_under_swath', dict(m=punch_hole(tin, 1.0, 10.0), P=1048576, B=512, steps=50, warmup=40)))
         # ... and with gaps EVERYWHERE (one per 6 x 6 m, 13 % of the triangles missing): every particle's slice crosses several
         # ... and with the OUTLINE of a real survey (border triangles missing at random, bays cut in from the sides: synth.mesh_ragged), the
         # track 24 m inside the southern outline: one side of every fan runs out over the outline and across the bays

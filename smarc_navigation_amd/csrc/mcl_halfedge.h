@@ -21,8 +21,9 @@
 //   word 5, 6: the first rim record of this hole and the number of its edges (the records of a hole lie together, in rim order:
 //              the walk reads them by index -- loads that do not wait for one another)
 //   word 7: for a rim of more than RIM_CHUNK_MIN edges the first of its CHUNK records (behind all rim records: {centre x, y, z
-//           and radius of a sphere around RIM_CHUNK consecutive edges} -- the walk tests the fan plane against the spheres and
-//           goes through the edges of those it cuts); top bit: the rim is the mesh's OUTLINE
+//           and radius of a sphere around RIM_CHUNK consecutive edges}, and behind a rim's chunk records one such record per
+//           RIM_CHUNK of them, the sphere around theirs -- the walk tests the fan plane against the spheres, two levels, and
+//           goes through the edges of the chunks it cuts); top bit: the rim is the mesh's OUTLINE
 // The ragged OUTLINE of a survey (every outline edge that is not on the bounding box) is linked the same way when no other piece
 // of mesh lies outside it: a slice that leaves through it either finds a cut further out -- a bay of the outline: it walks on
 // from there -- or none: then nothing lies beyond, and the beams left miss.  Its edges on the bounding box keep their border
@@ -278,7 +279,10 @@ inline Links link_holes(std::vector<Rec>& he, int64_t nt) {
   size_t nrim = 0, nchunk = 0;
   for (const Loop& L : rims) {
     nrim += L.len;
-    if (L.len > (size_t)RIM_CHUNK_MIN) nchunk += (L.len + RIM_CHUNK - 1) / RIM_CHUNK;
+    if (L.len > (size_t)RIM_CHUNK_MIN) {
+      const size_t nch = (L.len + RIM_CHUNK - 1) / RIM_CHUNK;
+      nchunk += nch + (nch + RIM_CHUNK - 1) / RIM_CHUNK;
+    }
   }
   if ((nhe + nrim + nchunk) * sizeof(Rec) >= (size_t)1 << 31) return out;   // (the device addresses the table by 32-bit byte offsets)
   he.reserve(nhe + nrim + nchunk);
@@ -325,6 +329,28 @@ inline Links link_holes(std::vector<Rec>& he, int64_t nt) {
         std::memcpy(&c.next_a, &fr, 4);
         chunks.push_back(c);
       }
+    if (chunked) {
+      // ... and behind a rim's chunk records one record per RIM_CHUNK of THEM: the sphere around their spheres
+      const size_t c_first = chunks.size() - (L.len + RIM_CHUNK - 1) / RIM_CHUNK, nch = chunks.size() - c_first;
+      for (size_t g0 = 0; g0 < nch; g0 += RIM_CHUNK) {
+        const size_t n = std::min<size_t>(RIM_CHUNK, nch - g0);
+        double cx = 0, cy = 0, cz = 0, rr = 0;
+        for (size_t q = 0; q < n; ++q) cx += fl(chunks[c_first + g0 + q].x) / n, cy += fl(chunks[c_first + g0 + q].y) / n, cz += fl(chunks[c_first + g0 + q].z) / n;
+        const float fcx = (float)cx, fcy = (float)cy, fcz = (float)cz;
+        for (size_t q = 0; q < n; ++q) {
+          const Rec& v = chunks[c_first + g0 + q];
+          const double dx = fl(v.x) - fcx, dy = fl(v.y) - fcy, dz = fl(v.z) - fcz;
+          rr = std::max(rr, std::sqrt(dx * dx + dy * dy + dz * dz) + fl(v.next_a));
+        }
+        const float fr = (float)(rr * (1.0 + 1e-5) + 1e-3);
+        Rec c{0, 0, 0, 0, 0, 0, 0, 0};
+        std::memcpy(&c.x, &fcx, 4);
+        std::memcpy(&c.y, &fcy, 4);
+        std::memcpy(&c.z, &fcz, 4);
+        std::memcpy(&c.next_a, &fr, 4);
+        chunks.push_back(c);
+      }
+    }
   }
   he.insert(he.end(), chunks.begin(), chunks.end());
   out.nrim = nrim;

@@ -396,6 +396,16 @@ static int check_hole_rims(std::mt19937_64& rng) {
       CHECK((cb != 0) == (r.pad1 > (uint32_t)halfedge::RIM_CHUNK_MIN));
       if (cb) {   // the vertex lies in the sphere of its chunk (and, as the end of the last edge before it, of the one before)
         CHECK(cb >= nhe + nrim && cb + (r.pad1 + halfedge::RIM_CHUNK - 1) / halfedge::RIM_CHUNK <= he.size());
+        {   // ... and the chunk's sphere in the sphere of its group of chunks
+          const size_t nch2 = (r.pad1 + halfedge::RIM_CHUNK - 1) / halfedge::RIM_CHUNK, ch = (k - r.pad0) / halfedge::RIM_CHUNK;
+          CHECK(cb + nch2 + ch / halfedge::RIM_CHUNK < he.size());
+          float c0v[3], c1v[3], R0, R1;
+          xyz(he[cb + ch], c0v);
+          xyz(he[cb + nch2 + ch / halfedge::RIM_CHUNK], c1v);
+          std::memcpy(&R0, &he[cb + ch].next_a, 4);
+          std::memcpy(&R1, &he[cb + nch2 + ch / halfedge::RIM_CHUNK].next_a, 4);
+          CHECK(std::sqrt(((double)c0v[0] - c1v[0]) * ((double)c0v[0] - c1v[0]) + ((double)c0v[1] - c1v[1]) * ((double)c0v[1] - c1v[1]) + ((double)c0v[2] - c1v[2]) * ((double)c0v[2] - c1v[2])) + R0 <= R1);
+        }
         const size_t pos = k - r.pad0, nch = (r.pad1 + halfedge::RIM_CHUNK - 1) / halfedge::RIM_CHUNK;
         const size_t c1 = pos / halfedge::RIM_CHUNK, c0 = pos % halfedge::RIM_CHUNK == 0 ? (c1 + nch - 1) % nch : c1;
         for (size_t c : {c0, c1}) {
@@ -477,12 +487,16 @@ static int check_hole_rims(std::mt19937_64& rng) {
               for (uint32_t e = 0; e < rlen; ++e) {
                 const uint32_t cur = rbase + e, nxt = rbase + (e + 1) % rlen;
                 if (cur == k0 || (he[cur].next_a & halfedge::RIM_ON_BOX)) continue;
-                if (pass == 1) {   // is this edge's chunk visited?
-                  const Rec& c = he[cb + e / halfedge::RIM_CHUNK];
-                  float cc[3], R;
-                  xyz(c, cc);
-                  std::memcpy(&R, &c.next_a, 4);
-                  if (!(std::fabs(d_of(cc)) <= R && sg * s_of(cc) + R >= s_prev)) continue;
+                if (pass == 1) {   // is this edge's chunk visited?  (two levels: its chunk's sphere and the sphere around 16 chunks)
+                  const uint32_t nch = (rlen + halfedge::RIM_CHUNK - 1) / halfedge::RIM_CHUNK, ch = e / halfedge::RIM_CHUNK;
+                  bool visit = true;
+                  for (const uint32_t rec : {cb + nch + ch / halfedge::RIM_CHUNK, cb + ch}) {
+                    float cc[3], R;
+                    xyz(he[rec], cc);
+                    std::memcpy(&R, &he[rec].next_a, 4);
+                    visit = visit && std::fabs(d_of(cc)) <= R && sg * s_of(cc) + R >= s_prev;
+                  }
+                  if (!visit) continue;
                 }
                 float pc[3], pn[3];
                 xyz(he[cur], pc);
