@@ -346,10 +346,12 @@ int mcl_timing_get(mcl_handle* h, mcl_timing* out); /* syncs, returns and resets
  * (no visiting order: DESIGN.md 5).  Any pointer may be NULL. */
 int mcl_mbes_last_path(mcl_handle* h, int32_t* path, int64_t* handed_over, int64_t* deferred_groups);
 /* Who cast the particles the last MBES update's first stage handed over (syncs).  On a height-field TIN with HOLES (an
- * edge with no triangle behind it inside the bounding box: data gaps, a ragged outline) a slice that reaches one ends the
- * adjacency walk, and the fan slice (mcl_slice.h: any soup, exact across gaps) casts those particles before the ray
- * traversal is asked: by_slice = particles it cast, by_traversal = particles that reached the general kernel (on every
- * other map: all of handed_over).  MCL_HANDOVER_SLICE=0 sends them all to the traversal (A/B).  Any pointer may be NULL. */
+ * edge with no triangle behind it inside the bounding box: data gaps, a ragged outline) the adjacency walk goes on through
+ * empty space wherever mesh_build could link the rim (DESIGN.md 5 "Holes and the outline"); where it could not (a hole
+ * with an island, MCL_TIN_RIMS=0) a slice that reaches the edge ends the walk, and the fan slice (mcl_slice.h: any soup,
+ * exact across gaps) casts those particles before the ray traversal is asked: by_slice = particles it cast,
+ * by_traversal = particles that reached the general kernel (on every other map: all of handed_over).
+ * MCL_HANDOVER_SLICE=0 sends them all to the traversal (A/B).  Any pointer may be NULL. */
 int mcl_mbes_last_handover(mcl_handle* h, int64_t* by_slice, int64_t* by_traversal);
 /* The order in which the last MBES update's fan sweep (or group slice) visited the particles (syncs): slots[p] = state
  * slot of the particle at position p (a wavefront of the sweep casts 64 consecutive positions); *sorted = 1 when the

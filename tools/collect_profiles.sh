@@ -62,7 +62,7 @@ with open(sys.argv[2], 'a', newline='') as f:
     w.writerows(keep)
 PY
 done
-for m in config5 soup config4_rccl tin_hole; do
+for m in config5 soup config4_rccl tin_hole tin_ragged; do
   f=$(ls -t $S/stats_$m/*/*_kernel_stats.csv 2>/dev/null | head -1)
   if [ -n "$f" ]; then cp $f profiles/${ROUND}_${m}_kernel_stats.csv; fi
 done

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One extra leg of bench.py alone (profiling runs): tools/experiments/leg.py config5|config4|config4_rccl|tin_hole [steps]"""
+"""One extra leg of bench.py alone (profiling runs): tools/experiments/leg.py config5|config4|config4_rccl|tin_hole|tin_ragged [steps]"""
 import json
 import os
 import sys
@@ -18,5 +18,9 @@ if name == 'config4_rccl':   # the sharded pipeline over a 1-rank RCCL communica
 if name == 'tin_hole':       # the irregular TIN with a data gap under the swath (bench.py: mesh_tin_hole_under_swath): k_mbes_sweep<6, ...>
     mesh = bench.punch_hole(bench.build_map('mesh-tin'), 1.0, 10.0)
     kw.update(P=1048576, warmup=40)
+if name == 'tin_ragged':     # ... with a ragged outline and bays, the track 24 m inside it (bench.py: mesh_tin_ragged_outline)
+    tin = bench.build_map('mesh-tin')
+    mesh = dict(tin, tris=synth.mesh_ragged(tin['verts'], tin['tris']), desc=tin['desc'] + ', ragged outline')
+    kw.update(P=1048576, warmup=40, m2o=synth.rigid_matrix(100.0, -330.0, 0.0, 0.0, 0.0, 0.0))
 out = bench.run_leg(engine, name, mesh, kw.pop('P'), kw.pop('B'), kw.pop('steps'), kw.pop('warmup'), **kw)
 print(json.dumps({k: out[k] for k in ('ms_per_step', 'kernels')}))

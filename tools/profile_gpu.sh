@@ -41,6 +41,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_config5 -- pyth
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_soup -- python3 $R/bench.py --map mesh-soup --steps 10 --warmup 2 --only-main > $O/bench_soup.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_config4_rccl -- python3 $R/tools/experiments/leg.py config4_rccl 30 > $O/bench_config4_rccl.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_tin_hole -- python3 $R/tools/experiments/leg.py tin_hole 50 > $O/bench_tin_hole.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_tin_ragged -- python3 $R/tools/experiments/leg.py tin_ragged 50 > $O/bench_tin_ragged.log 2>&1
 cd $R && ROUND=${ROUND:-r06} python3 tools/pmc_summarise.py $O $O/traffic.json > $O/summarise.log 2>&1
 # keep only what is small enough to travel back: the stats CSVs, the kernels' counter rows (first dispatches), the summary
 for f in $(find $O -name "*counter_collection.csv"); do python3 - $f <<'PY'
