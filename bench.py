@@ -898,9 +898,8 @@ def worker(a, rank, world, local_rank):
         # ... and with gaps EVERYWHERE (one per 6 x 6 m, 13 % of the triangles missing): every particle's slice crosses several
         # ... and with the OUTLINE of a real survey (border triangles missing at random, bays cut in from the sides: synth.mesh_ragged), the
         # track 24 m inside the southern outline: one side of every fan runs out over the outline and across the bays
-        from smarc_navigation_amd import synth as _synth
-        legs.append(('mesh_tin_ragged_outline', dict(m=dict(tin, tris=_synth.mesh_ragged(tin['verts'], tin['tris']), desc=tin['desc'] + ', ragged outline with six bays (synth.mesh_ragged), the track 24 m inside it'),
-                                                     P=1048576, B=512, steps=50, warmup=40, m2o=_synth.rigid_matrix(100.0, -330.0, 0.0, 0.0, 0.0, 0.0))))
+        legs.append(('mesh_tin_ragged_outline', dict(m=dict(tin, tris=synth.mesh_ragged(tin['verts'], tin['tris']), desc=tin['desc'] + ', ragged outline with six bays (synth.mesh_ragged), the track 24 m inside it'),
+                                                     P=1048576, B=512, steps=50, warmup=40, m2o=synth.rigid_matrix(100.0, -330.0, 0.0, 0.0, 0.0, 0.0))))
         legs.append(('mesh_tin_gaps_everywhere', dict(m=punch_gaps(tin), P=1048576, B=512, steps=50, warmup=40)))
         # global-localisation regime: sigma = 50 m cloud that nothing collapses (no resample).  Particles are
         # initialised around the odom origin (auv_particle.py:24), so the map <- odom transform puts that
