@@ -659,6 +659,79 @@ def test_tin_with_a_ragged_outline_and_bays_is_walked_to_its_end(seed, eng, orc,
         print('sharded at the ragged outline: (sweep handed over, cast by the slice, by the traversal) per step %r of %d' % (split, n))
 
 
+@pytest.mark.parametrize('seed', range(24))
+def test_tin_rims_fuzz_against_the_oracle(seed, eng, orc):
+    """Random scenes for the walk through empty space: an irregular TIN with discs of triangles missing (a few or many, small
+    or one large enough for chunk records), every fourth scene a ring (an island in a hole: not linked, handed over), every
+    second a ragged outline with bays; random input order; the vehicle over a gap, beside one, at the outline or beyond it,
+    level or tilted; 9 .. 257 beams.  Every ray equals the fp64 oracle's brute force over the triangles that are there
+    within 1e-3 m, up to isolated rays that graze a rim or a crest and that the oracle itself moves under a 1 mm shift;
+    log-likelihoods under the usual contract."""
+    rs = np.random.RandomState(9000 + seed)
+    res = float(rs.choice([0.5, 1.0, 2.0]))
+    nx, ny = int(120 / res) + rs.randint(0, 20), int(110 / res) + rs.randint(0, 20)
+    origin = (-0.5 * nx * res + rs.uniform(-3, 3), -0.5 * ny * res + rs.uniform(-3, 3))
+    z = synth.bathymetry_grid(nx, ny, res, origin, seed=300 + seed, depth=-rs.uniform(12.0, 30.0), swell=rs.uniform(0.0, 3.0), fbm_amp=rs.uniform(0.1, 0.8))
+    verts, tris = synth.mesh_tin(z, res, origin, seed=seed, jitter=float(rs.choice([0.1, 0.25])))
+    c = verts[tris.astype(np.int64)].mean(axis=1)
+    gone = np.zeros(len(tris), bool)
+    spots = []
+    for _ in range(int(rs.choice([1, 3, 12, 40]))):
+        p = (rs.uniform(-40, 40), rs.uniform(-40, 40))
+        r = rs.uniform(0.6, 3.0) * res if seed % 6 else rs.uniform(8.0, 12.0)
+        spots.append(p)
+        gone |= np.hypot(c[:, 0] - p[0], c[:, 1] - p[1]) < r
+    if seed % 4 == 3:     # a ring: an island inside
+        p = spots[0]
+        rr = np.hypot(c[:, 0] - p[0], c[:, 1] - p[1])
+        gone = (gone & ~(rr < 12.0 * res)) | ((rr > 2.5 * res) & (rr < 6.0 * res))
+    tris = np.ascontiguousarray(tris[~gone])
+    ragged = seed % 2 == 1
+    if ragged:
+        tris = synth.mesh_ragged(verts, tris, seed=seed, band=3.0 * res, bays=6, bay_width=(2.0 * res, 5.0 * res), bay_depth=(8.0, 30.0))
+    if seed % 3:
+        verts, tris = synth.mesh_shuffle(verts, tris, seed=seed)
+    n = 256
+    B = int(rs.choice([9, 64, 257]))
+    tilt = rs.choice([0.0, 0.03, 0.1])
+    where = seed % 4
+    if where == 0:        # over / beside a gap
+        centre = [spots[0][0] + rs.uniform(-2, 2), spots[0][1] + rs.uniform(-2, 2)]
+    elif where == 1:      # at the (ragged) outline
+        centre = [rs.uniform(-30, 30), origin[1] + rs.uniform(2.0, 14.0)]
+    elif where == 2:      # anywhere
+        centre = [rs.uniform(-30, 30), rs.uniform(-30, 30)]
+    else:                 # at the western outline, partly beyond it
+        centre = [origin[0] + rs.uniform(-2.0, 8.0), rs.uniform(-30, 30)]
+    soa = _cloud(n, 70 + seed, (3.0, 3.0, 0.5, tilt, tilt, 3.0), centre + [-rs.uniform(0.5, 5.0)])
+    ba = synth.beam_angles(B, rs.uniform(0.6, 1.3))
+    r_max = float(rs.choice([40.0, 80.0, 150.0]))
+    e = eng.Engine(n, rng_mode=eng.RNG_REPLAY)
+    e.set_particles(soa)
+    e.set_map_mesh(verts, tris)
+    omap = orc.Mesh(verts, tris)
+    got = e.mbes_expected(0, n, ba, r_max)
+    path, handed, _ = e.mbes_last_path()
+    assert path == 1
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, None, 0.2, r_max)
+    err = np.abs(got - ref)
+    bad = int((err > 1e-3).sum())
+    print('rims fuzz %d res %.1f B %d tilt %.2f r_max %.0f %d gaps%s%s, vehicle %s: handed over %d/%d, rays that miss %.0f %%, max err %.2e, rays off %d/%d' % (
+        seed, res, B, tilt, r_max, len(spots), ' + ring' if seed % 4 == 3 else '', ' + ragged outline' if ragged else '',
+        ['at a gap', 'at the southern outline', 'anywhere', 'at the western outline'][where], handed, n, 100.0 * (ref >= r_max).mean(), err.max(), bad, err.size))
+    assert bad <= max(3, err.size // 4000)
+    outliers_explained(orc, omap, soa, ba, got, ref, r_max, label='rims fuzz %d' % seed)
+    ranges = (ref[rs.randint(n)] + 0.2 * rs.randn(B)).astype(np.float32)
+    ranges[ranges >= r_max] = 0.0
+    ranges[rs.randint(B)] = 0.0
+    e.update_mbes(ranges, ba, 0.3, r_max)
+    lw_ref, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, ranges, 0.3, r_max)
+    d = np.abs(e.get_log_weights() - lw_ref)
+    okm = (d <= 1e-2) | (d <= 2e-4 * np.abs(lw_ref))
+    assert (~okm).sum() <= bad + n // 50, int((~okm).sum())
+    lw_outliers_explained(orc, omap, soa, ba, ranges, 0.3, r_max, e.get_log_weights(), lw_ref, label='rims fuzz %d' % seed)
+
+
 def test_tin_hole_without_rim_records_goes_through_the_fan_slice(eng, orc, monkeypatch):
     """The same gap with the rims NOT linked (MCL_TIN_RIMS=0: what a hole too long for rim records, a ragged outline or a
     mesh with islands gets): the sweep hands the whole cloud over -- on a mesh with holes to the FAN SLICE first
