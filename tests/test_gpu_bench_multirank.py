@@ -32,7 +32,7 @@ def fake_nccl():
 
 def _bench(lib, args, timeout=900, **env_extra):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MCL_FORCE_COMM')}
-    env.update(LD_PRELOAD=lib, FAKE_NCCL_SHM='1', FAKE_NCCL_TIMEOUT_S='20', MCL_BENCH_ONE_DEVICE='1', **env_extra)
+    env.update(dict(dict(LD_PRELOAD=lib, FAKE_NCCL_SHM='1', FAKE_NCCL_TIMEOUT_S='20', MCL_BENCH_ONE_DEVICE='1'), **env_extra))
     t0 = time.time()
     p = subprocess.run([sys.executable, BENCH] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        timeout=timeout, universal_newlines=True)
@@ -62,6 +62,23 @@ def test_two_real_ranks_of_the_bench_worker_on_one_gpu(fake_nccl, exchange):
         assert ex['mode'] == 'allgather' and ex['phases_ms_per_step'].get('comm', 0) > 0
     assert d['pose_rmse_m'] < 1.0   # the sharded filter tracks the truth
     assert 'roofline' in d and d['roofline']['kernel'] == 'update_mbes'
+
+
+def test_eight_real_ranks_of_the_bench_worker_on_one_gpu(fake_nccl):
+    """The size of the driver's last SCALE run: `python bench.py --gpus 8`, eight real processes on the one GPU (65 536
+    particles each), the point-to-point exchange among eight peers.  One line, rank 0's; every rank reports lost slots."""
+    rc, out, err, el = _bench(fake_nccl, ['--gpus', '8', '--steps', '5', '--warmup', '2', '--only-main', '--particles', '65536'], FAKE_NCCL_TIMEOUT_S='60')
+    assert rc == 0, err[-4000:]
+    lines = [l for l in out.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    print({k: d[k] for k in ('value', 'ms_per_step', 'rccl_ranks', 'particles_total')}, d['exchange']['lost_slots_per_step_by_rank'])
+    assert d['n_gpus'] == 8 and d['rccl_ranks'] == 8 and d['particles_total'] == 8 * 65536 and d['scaling'] == 'weak'
+    assert math.isfinite(d['value']) and d['value'] > 0
+    ex = d['exchange']
+    assert len(ex['lost_slots_per_step_by_rank']) == 8 and all(x > 0 for x in ex['lost_slots_per_step_by_rank'])
+    assert ex['rank0_p2p_ops_per_exchange'] <= ex['p2p_ops_bound'] == 14   # one send + one receive per peer
+    assert d['pose_rmse_m'] < 1.0
 
 
 def test_external_launcher_form_with_two_real_ranks(fake_nccl):
