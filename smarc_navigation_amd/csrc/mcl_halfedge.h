@@ -183,6 +183,7 @@ struct Links {
   size_t nrim = 0, nchunk = 0;   // rim records behind the 3 nt half-edge records, chunk records behind those
   size_t holes = 0;              // linked holes
   bool outline = false;          // the outline is linked as well
+  size_t outline_base = 0;       // ... its first rim record
 };
 inline Links link_holes(std::vector<Rec>& he, int64_t nt) {
   Links out;
@@ -292,6 +293,7 @@ inline Links link_holes(std::vector<Rec>& he, int64_t nt) {
     const Loop& L = rims[r];
     const bool exterior = outline_ok && r + 1 == rims.size();
     const size_t base = he.size();
+    if (exterior) out.outline_base = base;
     const bool chunked = L.len > (size_t)RIM_CHUNK_MIN;
     const uint32_t w7 = (chunked ? (uint32_t)(cbase + chunks.size()) : 0u) | (exterior ? RIM_EXTERIOR : 0u);
     for (size_t q = 0; q < L.len; ++q) {

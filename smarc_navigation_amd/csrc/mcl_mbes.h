@@ -79,6 +79,7 @@ struct MeshArgs {
   const uint4* tin_he;     // fan sweep over a TIN: one 32-byte record per half-edge {x, y, z of the opposite vertex, next_a | next_b, -, -, -} (mcl_mesh.h)
   u32 tin_he_bytes;        // ... its size (read through a raw buffer)
   const u32* cell_rim;     // ... per cell: first rim record of the linked hole that may lie under a sensor there (0xffffffff none, 0xfffffffe several), or nullptr
+  u32 tin_outline;         // ... first rim record of the outline when it is linked, else 0
   u32 tin_nhe;             // ... its half-edge records (3 x triangles); behind them the rim records of the holes the walk crosses (mcl_halfedge.h)
   const float4* cell_tri;  // fan slice (mcl_slice.h): the three vertices (x, y, z, -), map frame, of every (cell, triangle) record, indexed like `tri`
   double x0, y0;           // map-frame position of cell (0, 0)'s corner

@@ -50,6 +50,7 @@ struct MeshDev {
   size_t tin_he_bytes = 0;
   bool tin_ok = false;
   size_t tin_nhe = 0;       // half-edge records (3 x triangles); behind them rim records, behind those chunk records (mcl_halfedge.h)
+  size_t tin_outline = 0;   // first rim record of the OUTLINE when it is linked (a sensor beyond it starts its walk there), else 0
   size_t tin_rims = 0;      // rim records behind the 3 nt half-edge records: the edges of the holes the walk crosses by itself (mcl_halfedge.h: link_holes)
   u32* cell_rim = nullptr;   // per cell of the cell grid: the first rim record of the linked hole whose bounding box reaches into the cell (0xffffffff: none, 0xfffffffe: more than one) -- where a walk starts whose nadir ray falls into a gap
   bool tin_holes = false;   // some edge of the TIN has no triangle on its far side and does not lie on the bounding box: a hole or a ragged outline (walks that reach it hand their particle over)
@@ -410,6 +411,7 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
       const halfedge::Links links = link ? halfedge::link_holes(he, nt) : halfedge::Links();
       m->tin_rims = links.nrim;
       m->tin_nhe = 3 * (size_t)nt;
+      m->tin_outline = links.outline ? links.outline_base : 0;
       m->tin_holes = m->tin_rims != 0;
       for (size_t q = 0; q < 3 * (size_t)nt && !m->tin_holes; ++q) m->tin_holes = he[q].next_a == halfedge::HOLE || he[q].next_b == halfedge::HOLE;
       std::vector<uint32_t> cell_rim;
@@ -587,6 +589,7 @@ inline MeshArgs mesh_args(const MeshDev* m) {
   ma.tin_he_bytes = (u32)m->tin_he_bytes;
   ma.cell_rim = m->cell_rim;
   ma.tin_nhe = (u32)m->tin_nhe;
+  ma.tin_outline = (u32)m->tin_outline;
   ma.cell_tri = m->cell_tri;
   ma.x0 = m->x0;
   ma.y0 = m->y0;

@@ -934,6 +934,9 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   const int nx = a.nx, ny = a.ny, B = a.n_beams;  // (cells + 1 of the cell grid: the mesh's bounding box)
   bool pre = P.um >= 0.0 && P.um < (double)(nx - 1) && P.vm >= 0.0 && P.vm < (double)(ny - 1);  // (NaN: false)
   const float c2z = P.c2[2];
+  // (HOLES, the outline linked: a sensor beyond the bounding box -- the vehicle has left the map and looks back in -- is no
+  //  reason to decline: its walk starts where the fan plane meets the outline, below)
+  const bool off_box = HOLES && !pre && ma.tin_outline != 0u && fabs(P.um) < 1e6 && fabs(P.vm) < 1e6 && c2z >= a.sweep_c2z_min;
   pre = pre & (c2z >= a.sweep_c2z_min);
   const double fum = pre ? floor(P.um) : 1.0, fvm = pre ? floor(P.vm) : 1.0;
   const int I0 = (int)fum, J0 = (int)fvm;
@@ -955,12 +958,12 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   s_stop += 2.f * res;
   // (no footprint test: the walk goes from triangle to triangle through the adjacency table and ends at the mesh's
   //  border -- at the OUTER border of a rectangular map for good, under the rule of sweep_side's second pass)
-  if (!pre) SWEEP_FAIL(1);
+  if (!pre && !off_box) SWEEP_FAIL(1);
   u32 T = 0xffffffffu;
-  const float r0 = tin_nadir(a, I0, J0, ul, vl, oz, -P.c2[0], -P.c2[1], -c2z, T);
-  // (HOLES: no triangle under the sensor may mean that its nadir ray goes through a linked hole -- the walk then starts
-  //  at the hole's rim, below)
-  const bool in_gap = HOLES && T == 0xffffffffu && ma.cell_rim != nullptr;
+  const float r0 = off_box ? a.r_max : tin_nadir(a, I0, J0, ul, vl, oz, -P.c2[0], -P.c2[1], -c2z, T);
+  // (HOLES: no triangle under the sensor may mean that its nadir ray goes through a linked hole, or past the linked
+  //  outline -- the walk then starts at the rim, below)
+  const bool in_gap = HOLES && T == 0xffffffffu && (ma.cell_rim != nullptr || ma.tin_outline != 0u);
   if ((!(r0 < a.r_max) || T == 0xffffffffu) && !in_gap) SWEEP_FAIL(4);
   if (none && !in_gap) return true;
   // plane and in-plane coordinates from (x - Ox, y - Oy, z - Oz) in metres
@@ -1011,7 +1014,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     float cs, ct;
     TinNode CA, CB;
   };
-  const auto rim_edges = [&](RimCut& r, const u32 rbase, const u32 rlen, u32 pos, const u32 cnt, const float s_min, const bool strict, const u32 skip) {
+  const auto rim_edges = [&](RimCut& r, const u32 rbase, const u32 rlen, u32 pos, const u32 cnt, const float s_min, const bool strict, const u32 skip, const bool box_too) {
     pos -= pos >= rlen ? rlen : 0u;
     u32 cur = rbase + pos;
     uint4 qc = he_xyzn(cur);
@@ -1025,7 +1028,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
       if ((__float_as_int(Nc.d) ^ __float_as_int(Nn.d)) < 0) {
         const float lam = Nc.d * fast_rcp(Nc.d - Nn.d);
         const float sx = fmaf(lam, Nn.s - Nc.s, Nc.s), tx = fmaf(lam, Nn.t - Nc.t, Nc.t);
-        const bool beyond = (strict ? sx > s_min : sx >= s_min) && cur != skip && (int)qc.w >= 0;
+        const bool beyond = (strict ? sx > s_min : sx >= s_min) && cur != skip && (box_too || (int)qc.w >= 0);
         r.cuts += beyond ? 1u : 0u;
         const bool take = beyond && sx < r.cs;
         r.cs = take ? sx : r.cs;
@@ -1041,7 +1044,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   };
   // ... the whole rim: edge by edge, or -- a long rim: chunk records from `cbase`, each the sphere around RIM_CHUNK consecutive
   // edges -- only the chunks whose sphere the plane cuts and that do not lie entirely before s_min
-  const auto rim_cut = [&](const u32 rbase, const u32 rlen, const u32 cbase, const float s_min, const bool strict, const u32 skip) {
+  const auto rim_cut = [&](const u32 rbase, const u32 rlen, const u32 cbase, const float s_min, const bool strict, const u32 skip, const bool box_too) {
     RimCut r;
     r.best = 0xffffffffu;
     r.cuts = 0u;
@@ -1050,7 +1053,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     r.CA.d = r.CA.s = r.CA.t = 0.f;
     r.CB = r.CA;
     if (cbase == 0u) {
-      rim_edges(r, rbase, rlen, 0u, rlen, s_min, strict, skip);
+      rim_edges(r, rbase, rlen, 0u, rlen, s_min, strict, skip, box_too);
     } else {
       // (two levels: behind the rim's chunk records one record per RIM_CHUNK of them -- a scan of every chunk of a
       //  3 000-edge outline is 180 loads that wait for one another's branch: 1.3 ms per launch at 1 M particles)
@@ -1068,7 +1071,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
         for (u32 c = g * halfedge::RIM_CHUNK; c < c1; ++c) {
           if (!cuts_sphere(cbase + c)) continue;
           const u32 p0 = c * halfedge::RIM_CHUNK;
-          rim_edges(r, rbase, rlen, p0, min((u32)halfedge::RIM_CHUNK, rlen - p0), s_min, strict, skip);
+          rim_edges(r, rbase, rlen, p0, min((u32)halfedge::RIM_CHUNK, rlen - p0), s_min, strict, skip, box_too);
         }
       }
     }
@@ -1078,24 +1081,32 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   u32 nb;    // the half-edge through which the slice enters the next triangle (or a border code)
   bool ao;   // is A the ORIGIN of that half-edge (in the next triangle's own counter-clockwise order)?
   float s_prev, t_prev, s_cur, t_cur;
+  bool blind = false;   // (HOLES) a sensor beyond the outline whose fan plane meets no mesh on this side: every beam misses
   if (HOLES && in_gap) {
     // the nadir ray found no triangle: does it go through a linked hole?  The sensor's cell names the candidate (mcl_mesh.h:
     // cell_rim); the fan plane cuts its rim an even number of times, and the ray -- s = 0 -- runs between two cuts, through
     // the gap, exactly when an ODD number of them lies on this side's s > 0.  Then the nearest is where this side's slice
     // meets the mesh, and the beams up to its tangent look into the gap.  (Both sides of a particle test the same rim:
     // they agree, up to a cut at s = 0 to rounding -- one side then declines and the particle is handed over.)
-    const u32 rb = ma.cell_rim[(size_t)I0 * ma.gy + J0];
-    if (rb >= 0xfffffffeu) SWEEP_FAIL(4);
+    // No hole named for the cell (or a sensor beyond the bounding box) and the OUTLINE linked: is the sensor beyond it?  Then
+    // an EVEN number of cuts lies on this side -- none: this side of the fan sees no seabed at all; else the nearest is where
+    // its slice runs onto the mesh (through an edge on the bounding box as well: word 3's mark only bars the way BACK in).
+    u32 rb = (!off_box && ma.cell_rim != nullptr) ? ma.cell_rim[(size_t)I0 * ma.gy + J0] : 0xffffffffu;
+    const bool beyond = rb == 0xffffffffu;
+    if (beyond) rb = ma.tin_outline;
+    if (rb >= 0xfffffffeu || rb == 0u) SWEEP_FAIL(4);
     const uint4 rw = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (int)(rb << 5) + 16, 0, 0));   // {half-edge, first record, edges, chunks | outline}
-    const RimCut rc = rim_cut(rb, rw.z, rw.w & 0x7fffffffu, 0.f, true, 0xffffffffu);
-    if (!(rc.cuts & 1u) || !(rc.ct > 0.f)) SWEEP_FAIL(4);
+    const RimCut rc = rim_cut(rb, rw.z, rw.w & 0x7fffffffu, 0.f, true, 0xffffffffu, beyond);
+    if (((rc.cuts & 1u) != 0u) == beyond) SWEEP_FAIL(4);   // (inside the outline and no triangle: a hole that is not linked; outside the named hole)
     if (none) return true;
+    blind = rc.cuts == 0u;
+    if (!blind && !(rc.ct > 0.f)) SWEEP_FAIL(4);
     A = rc.CA;
     Bn = rc.CB;
     ao = true;
-    nb = he_nb(rc.best);
-    s_cur = s_prev = rc.cs;   // (the walk's first segment is the point on the rim: the beams up to it are taken by the gap, below)
-    t_cur = t_prev = rc.ct;
+    nb = blind ? 0xfffffff0u : he_nb(rc.best);
+    s_cur = s_prev = blind ? 0.f : rc.cs;   // (the walk's first segment is the point on the rim: the beams up to it are taken by the gap, below)
+    t_cur = t_prev = blind ? 1.f : rc.ct;
   } else {
     // triangle T through its three records: 3 T + e holds the vertex opposite edge e, v_e+2, and -- next_a -- the
     // half-edge on the far side of edge e + 2.  So vertex j comes from record (j + 1) % 3 and the far side of edge j
@@ -1194,7 +1205,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     merge(msel & 1, 1.f, 1.f, xt * K, xs * K, xt * K, 0.f);
     gap_tan = bp != bp_in ? fmaxf(gap_tan, xs * fast_rcp(xt)) : gap_tan;
   };
-  if (HOLES && in_gap) gap_beams(s_cur, t_cur);   // (the nadir ray goes through a gap: the beams from the nadir to the rim)
+  if (HOLES && in_gap && !blind) gap_beams(s_cur, t_cur);   // (the nadir ray goes through a gap: the beams from the nadir to the rim)
   // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the neighbour.  The new
   // vertex of the slice takes the place of the one before last and the CALLER swaps the roles (the loop is unrolled by
   // two).  Returns true when the walk is over.  EXITS: as in sweep_side, the tests that end a walk normally run every
@@ -1221,12 +1232,12 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
         if (!ok) SWEEP_NOTE(nb == 0xffffffffu ? 13 : 10);
         return true;  // (ok: the beams left get r_max through the tail below)
       }
-      // A HOLE WITH A RIM (mcl_halfedge.h: link_holes): nb names the rim record of the edge the slice has just reached --
-      // hq is that record.  Once around the rim: of the edges the fan plane cuts, the nearest one further out is where
-      // the slice meets the mesh again (nothing lies inside a linked hole).
+      // A LINKED RIM (mcl_halfedge.h: link_holes -- a hole's, or the outline's): nb names the rim record of the edge the slice
+      // has just reached.  Along the rim: of the edges the fan plane cuts, the nearest one further out is where the slice
+      // meets the mesh again (nothing lies in the space a linked rim bounds).
       const u32 k0 = nb;
       const uint4 rw = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (int)(k0 << 5) + 16, 0, 0));   // {half-edge, first record, edges, chunks | outline}
-      const RimCut rc = rim_cut(rw.y, rw.z, rw.w & 0x7fffffffu, sc, false, k0);   // (every edge of the rim but the one reached)
+      const RimCut rc = rim_cut(rw.y, rw.z, rw.w & 0x7fffffffu, sc, false, k0, false);   // (every edge of the rim but the one reached)
       const u32 best = rc.best;
       const float bs = rc.cs, bt = rc.ct;
       if (best == 0xffffffffu && (int)rw.w < 0) return true;   // beyond the OUTLINE and no way back in: nothing lies further out -- the beams left get r_max through the tail below
@@ -1283,9 +1294,11 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     }
     return false;
   };
-  for (int step = 1;; step += 2) {
-    if (walk_step(s_prev, t_prev, s_cur, t_cur, step, std::true_type())) break;
-    if (walk_step(s_cur, t_cur, s_prev, t_prev, step + 1, std::false_type())) break;
+  if (!(HOLES && blind)) {
+    for (int step = 1;; step += 2) {
+      if (walk_step(s_prev, t_prev, s_cur, t_cur, step, std::true_type())) break;
+      if (walk_step(s_cur, t_cur, s_prev, t_prev, step + 1, std::false_type())) break;
+    }
   }
   if (ok && bp != bp_end) {
     ptr = (int)(bp - sb_off) >> 4;

@@ -232,7 +232,7 @@ static int check_hole_rims(std::mt19937_64& rng) {
   using halfedge::Rec;
   std::uniform_real_distribution<double> U01(0.0, 1.0);
   int linked_meshes = 0, refused = 0, outline_meshes = 0, chunked_meshes = 0;
-  long crossings = 0, bays = 0, finals = 0;
+  long crossings = 0, bays = 0, finals = 0, outside_starts = 0, blinds = 0;
   for (int trial = 0; trial < 96; ++trial) {
     const int kind = trial % 8;   // 0-2 discs, 3 a disc at the outline, 4 ring (island), 5-6 ragged outline + bays (+ discs), 7 a large hole
     const bool large = kind == 7, ragged = kind == 5 || kind == 6;
@@ -421,7 +421,12 @@ static int check_hole_rims(std::mt19937_64& rng) {
     int final_checks = 0;
     for (int w = 0; w < 24; ++w) {
       double px, py;
-      if (ragged && (w & 1)) {   // near the outline
+      if (ragged && (w & 3) == 3) {   // around the outline, beyond the bounding box as well
+        const double e = -4.0 + 7.0 * U01(rng);   // metres inside (+) / outside (-) a random side
+        const int sd = (int)(rng() % 4);
+        px = sd == 0 ? xmin + e : (sd == 1 ? xmax - e : xmin + U01(rng) * (xmax - xmin));
+        py = sd == 2 ? ymin + e : (sd == 3 ? ymax - e : ymin + U01(rng) * (ymax - ymin));
+      } else if (ragged && (w & 1)) {   // near the outline
         px = xmin + (0.1 + 0.8 * U01(rng)) * (xmax - xmin);
         py = ymin + (0.1 + 0.8 * U01(rng)) * (ymax - ymin);
       } else {
@@ -443,9 +448,77 @@ static int check_hole_rims(std::mt19937_64& rng) {
           in = ((double)v[(j + 1) % 3][0] - v[j][0]) * (py - v[j][1]) - ((double)v[(j + 1) % 3][1] - v[j][1]) * (px - v[j][0]) >= 0.0;
         if (in) T0 = T;
       }
-      if (T0 < 0) continue;   // (the point fell into a gap or off the mesh)
+      if (T0 < 0 && !links.outline) continue;   // (the point fell into a gap or off the mesh)
+      // the nearest cut of a rim beyond s_min (strictly, or not), not through the edge `k0`, through an edge on the box only if
+      // box_too -- by brute force over every edge, and through the two levels of chunk spheres as the kernel goes: the same edge
+      struct RimHit { uint32_t best; int cuts; double bs, Ad, Bd, As, Bs; };
+      auto rim_search = [&](double sg, uint32_t k0, uint32_t rbase, uint32_t rlen, uint32_t cb, double s_min, bool strict, bool box_too, RimHit& hit) -> int {
+        uint32_t best[2] = {0xffffffffu, 0xffffffffu};
+        double bs[2] = {1e300, 1e300};
+        hit.cuts = 0;
+        hit.Ad = hit.Bd = hit.As = hit.Bs = 0;
+        for (int pass = 0; pass < (cb ? 2 : 1); ++pass) {
+          for (uint32_t e = 0; e < rlen; ++e) {
+            const uint32_t cur = rbase + e, nxt = rbase + (e + 1) % rlen;
+            if (cur == k0 || (!box_too && (he[cur].next_a & halfedge::RIM_ON_BOX))) continue;
+            if (pass == 1) {   // is this edge's chunk visited?  (two levels: its chunk's sphere and the sphere around 16 chunks)
+              const uint32_t nch = (rlen + halfedge::RIM_CHUNK - 1) / halfedge::RIM_CHUNK, ch = e / halfedge::RIM_CHUNK;
+              bool visit = true;
+              for (const uint32_t rec : {cb + nch + ch / halfedge::RIM_CHUNK, cb + ch}) {
+                float cc[3], R;
+                xyz(he[rec], cc);
+                std::memcpy(&R, &he[rec].next_a, 4);
+                visit = visit && std::fabs(d_of(cc)) <= R && sg * s_of(cc) + R >= s_min;
+              }
+              if (!visit) continue;
+            }
+            float pc[3], pn[3];
+            xyz(he[cur], pc);
+            xyz(he[nxt], pn);
+            const double dc = d_of(pc), dn = d_of(pn), sc2 = sg * s_of(pc), sn2 = sg * s_of(pn);
+            if ((dc >= 0) == (dn >= 0)) continue;
+            const double lam = dc / (dc - dn), sx = sc2 + lam * (sn2 - sc2);
+            if (!(strict ? sx > s_min : sx >= s_min)) continue;
+            if (pass == 0) ++hit.cuts;
+            if (sx < bs[pass]) {
+              bs[pass] = sx; best[pass] = cur;
+              if (pass == 0) { hit.Ad = dc; hit.Bd = dn; hit.As = sc2; hit.Bs = sn2; }
+            }
+          }
+        }
+        if (cb) CHECK(best[1] == best[0]);
+        hit.best = best[0];
+        hit.bs = bs[0];
+        return 0;
+      };
       for (int side = 0; side < 2; ++side) {
         const double sg = side ? -1.0 : 1.0;
+        uint32_t nb;
+        double Ad, Bd, As, Bs, s_prev;
+        bool ao;
+        if (T0 < 0) {
+          // no triangle under the point and the outline linked: beyond it?  Then an even number of its edges -- box edges too --
+          // is cut on this side: none: nothing to see; else the walk starts at the nearest
+          const uint32_t ob = (uint32_t)links.outline_base;
+          RimHit hit;
+          if (rim_search(sg, 0xffffffffu, ob, he[ob].pad1, he[ob].pad2 & 0x7fffffffu, 0.0, true, true, hit)) return 1;
+          if (hit.cuts & 1) continue;   // (inside the outline: a hole -- the kernel asks the cell grid, or hands over)
+          if (hit.cuts == 0) {
+            if (final_checks < 12) {
+              ++final_checks;
+              for (double sx = 0.05; sx < 80.0; sx += 0.2) CHECK(!inside_some_triangle(px + sg * sx * c1x, py + sg * sx * c1y));
+              ++blinds;
+            }
+            continue;
+          }
+          for (int m = 1; m < 12; ++m) CHECK(!inside_some_triangle(px + sg * hit.bs * m / 12.0 * c1x, py + sg * hit.bs * m / 12.0 * c1y));
+          ++outside_starts;
+          s_prev = hit.bs;
+          Ad = hit.Ad; Bd = hit.Bd; As = hit.As; Bs = hit.Bs;
+          ao = true;
+          nb = he[hit.best].next_b;
+          CHECK(nb < nhe);
+        } else {
         float v[3][3];
         double d[3];
         for (int j = 0; j < 3; ++j) {
@@ -462,55 +535,28 @@ static int check_hole_rims(std::mt19937_64& rng) {
         const bool far_m = sm > sn;
         const bool pl = d[L] >= 0;
         const uint32_t fM = he[3 * (size_t)T0 + (size_t)((L + 1) % 3)].next_a, fN = he[3 * (size_t)T0 + (size_t)((L + 2 + 1) % 3)].next_a;
-        uint32_t nb = far_m ? fM : fN;
-        double Ad, Bd, As, Bs;
+        nb = far_m ? fM : fN;
         {
           const int F = far_m ? M : N;
           Ad = pl ? d[F] : d[L]; Bd = pl ? d[L] : d[F];
           As = pl ? sg * s_of(v[F]) : sg * s_of(v[L]); Bs = pl ? sg * s_of(v[L]) : sg * s_of(v[F]);
         }
-        bool ao = far_m == pl;
-        double s_prev = far_m ? sm : sn;
+        ao = far_m == pl;
+        s_prev = far_m ? sm : sn;
+        }
         int steps = 0;
         bool ended = false;
         while (nb < 0xfffffff0u && !ended) {
           CHECK(++steps <= 3 * nt + 64);
           if (nb >= nhe) {
             CHECK(nb < nhe + nrim);
-            // a rim: the nearest cut further out, not through the edge reached, not through an edge on the box -- by
-            // brute force over every edge, and through the chunk spheres as the kernel goes
+            // a rim: the nearest cut further out, not through the edge reached, not through an edge on the box
             const uint32_t k0 = nb, rbase = he[k0].pad0, rlen = he[k0].pad1, cb = he[k0].pad2 & 0x7fffffffu;
             const bool ext = (he[k0].pad2 & halfedge::RIM_EXTERIOR) != 0;
-            uint32_t best[2] = {0xffffffffu, 0xffffffffu};
-            double bs[2] = {1e300, 1e300}, bAd = 0, bBd = 0, bAs = 0, bBs = 0;
-            for (int pass = 0; pass < (cb ? 2 : 1); ++pass) {
-              for (uint32_t e = 0; e < rlen; ++e) {
-                const uint32_t cur = rbase + e, nxt = rbase + (e + 1) % rlen;
-                if (cur == k0 || (he[cur].next_a & halfedge::RIM_ON_BOX)) continue;
-                if (pass == 1) {   // is this edge's chunk visited?  (two levels: its chunk's sphere and the sphere around 16 chunks)
-                  const uint32_t nch = (rlen + halfedge::RIM_CHUNK - 1) / halfedge::RIM_CHUNK, ch = e / halfedge::RIM_CHUNK;
-                  bool visit = true;
-                  for (const uint32_t rec : {cb + nch + ch / halfedge::RIM_CHUNK, cb + ch}) {
-                    float cc[3], R;
-                    xyz(he[rec], cc);
-                    std::memcpy(&R, &he[rec].next_a, 4);
-                    visit = visit && std::fabs(d_of(cc)) <= R && sg * s_of(cc) + R >= s_prev;
-                  }
-                  if (!visit) continue;
-                }
-                float pc[3], pn[3];
-                xyz(he[cur], pc);
-                xyz(he[nxt], pn);
-                const double dc = d_of(pc), dn = d_of(pn), sc2 = sg * s_of(pc), sn2 = sg * s_of(pn);
-                if ((dc >= 0) == (dn >= 0)) continue;
-                const double lam = dc / (dc - dn), sx = sc2 + lam * (sn2 - sc2);
-                if (sx >= s_prev && sx < bs[pass]) {
-                  bs[pass] = sx; best[pass] = cur;
-                  if (pass == 0) { bAd = dc; bBd = dn; bAs = sc2; bBs = sn2; }
-                }
-              }
-            }
-            if (cb) CHECK(best[1] == best[0]);
+            RimHit hit;
+            if (rim_search(sg, k0, rbase, rlen, cb, s_prev, false, false, hit)) return 1;
+            const uint32_t best[1] = {hit.best};
+            const double bs[1] = {hit.bs}, bAd = hit.Ad, bBd = hit.Bd, bAs = hit.As, bBs = hit.Bs;
             if (best[0] == 0xffffffffu) {
               if (!ext) break;   // (a cut through a rim vertex, to rounding: the kernel hands over)
               // beyond the outline for good: no triangle further along the line
@@ -552,9 +598,9 @@ static int check_hole_rims(std::mt19937_64& rng) {
       }
     }
   }
-  std::fprintf(stderr, "rims: %d meshes linked (%d with their outline, %d with chunk records), %ld holes crossed, %ld bays of an outline crossed, %ld exits beyond an outline verified empty, %d islands refused\n",
-               linked_meshes, outline_meshes, chunked_meshes, crossings, bays, finals, refused);
-  CHECK(linked_meshes >= 40 && crossings >= 200 && refused >= 4 && outline_meshes >= 12 && chunked_meshes >= 12 && bays >= 10 && finals >= 50);
+  std::fprintf(stderr, "rims: %d meshes linked (%d with their outline, %d with chunk records), %ld holes crossed, %ld bays of an outline crossed, %ld exits beyond an outline verified empty, %ld walks started beyond an outline, %ld sides beyond one that see nothing, %d islands refused\n",
+               linked_meshes, outline_meshes, chunked_meshes, crossings, bays, finals, outside_starts, blinds, refused);
+  CHECK(linked_meshes >= 40 && crossings >= 200 && refused >= 4 && outline_meshes >= 12 && chunked_meshes >= 12 && bays >= 10 && finals >= 50 && outside_starts >= 30 && blinds >= 10);
   return 0;
 }
 

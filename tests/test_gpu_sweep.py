@@ -659,6 +659,63 @@ def test_tin_with_a_ragged_outline_and_bays_is_walked_to_its_end(seed, eng, orc,
         print('sharded at the ragged outline: (sweep handed over, cast by the slice, by the traversal) per step %r of %d' % (split, n))
 
 
+@pytest.mark.parametrize('where', ['beyond the box', 'in the sawtooth', 'in a bay'])
+def test_vehicle_beyond_a_ragged_outline_looks_back_in(where, eng, orc, monkeypatch):
+    """The vehicle has left the surveyed area (a lawn-mower turn): every sensor beyond the outline -- beyond the bounding
+    box, in the sawtooth band between outline and box, or in a bay.  With the outline linked the walk starts where the fan
+    plane runs onto the mesh (an even number of cuts on a side: beyond the outline; none: that side sees no seabed at all),
+    the beams from the nadir to there missing; without (MCL_TIN_RIMS=0) every particle is handed over.  Rays against the
+    oracle's brute force; log-likelihoods under the live-particle contract."""
+    from tests.helpers import live_particle_contract
+    z, origin = _terrain(seed=47)
+    verts, tris0 = synth.mesh_tin(z, 1.0, origin, seed=16)
+    tris = synth.mesh_ragged(verts, tris0, seed=31, band=3.0, bays=8, bay_width=(3.0, 6.0), bay_depth=(10.0, 30.0))
+    c = verts[tris.astype(np.int64)].mean(axis=1)
+    if where == 'beyond the box':
+        centre = (5.0, origin[1] - 4.0, -2.0)
+        spread = (2.0, 1.0)
+    elif where == 'in the sawtooth':
+        centre = (-20.0, origin[1] + 1.2, -2.0)
+        spread = (6.0, 0.6)
+    else:   # the middle of the widest gap of the southern rows: a bay
+        row = c[(c[:, 1] > origin[1] + 5.0) & (c[:, 1] < origin[1] + 7.0), 0]
+        xs = np.sort(row)
+        k = np.argmax(np.diff(xs))
+        assert xs[k + 1] - xs[k] > 2.5
+        centre = (0.5 * (xs[k] + xs[k + 1]), origin[1] + 6.0, -2.0)
+        spread = (0.4, 1.0)
+    n, B = 2048, 192
+    soa = _cloud(n, 12, (spread[0], spread[1], 0.05, 0.02, 0.02, 3.0), centre)
+    ba = synth.beam_angles(B)
+    omap = orc.Mesh(verts, tris)
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, None, 0.2, 80.0)
+    off_mesh = ref[:, B // 2] >= 80.0          # the nadir beam finds nothing
+    handed, got = {}, {}
+    for rims in ('1', '0'):
+        monkeypatch.setenv('MCL_TIN_RIMS', rims)
+        e = _engine(eng, soa, verts, tris)
+        got[rims] = e.mbes_expected(0, n, ba, 80.0)
+        path, handed[rims], _ = e.mbes_last_path()
+        assert path == 1
+        e.close()
+    err = np.abs(got['1'] - ref)
+    print('vehicle %s: %d of %d sensors off the mesh; outline linked: handed over %d (not linked: %d); max |expected range error| %.2e m, rays off %d of %d; %.0f %% of the rays miss' % (
+        where, int(off_mesh.sum()), n, handed['1'], handed['0'], err.max(), int((err > 1e-3).sum()), err.size, 100.0 * (ref >= 80.0).mean()))
+    assert off_mesh.mean() > 0.5
+    assert handed['0'] >= off_mesh.sum() and handed['1'] < n // 10
+    assert (err > 1e-3).sum() <= err.size // 20000 + 2
+    outliers_explained(orc, omap, soa, ba, got['1'], ref, 80.0, label='vehicle ' + where)
+    monkeypatch.setenv('MCL_TIN_RIMS', '1')
+    best = int(np.argmin((ref >= 80.0).sum(axis=1)))
+    ranges = (ref[best] + 0.05 * np.random.RandomState(3).randn(B)).astype(np.float32)
+    ranges[ref[best] >= 80.0] = 0.0
+    lw_ref, _ = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, ranges, 0.8, 80.0)
+    e = _engine(eng, soa, verts, tris)
+    e.update_mbes(ranges, ba, 0.8, 80.0)
+    live_particle_contract(orc, omap, soa, ba, ranges, 0.8, 80.0, e.get_log_weights(), lw_ref, lw_ref.max(), label='vehicle ' + where, allow=max(1, n // 200))
+    e.close()
+
+
 @pytest.mark.parametrize('seed', range(24))
 def test_tin_rims_fuzz_against_the_oracle(seed, eng, orc):
     """Random scenes for the walk through empty space: an irregular TIN with discs of triangles missing (a few or many, small
