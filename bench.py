@@ -900,6 +900,9 @@ def worker(a, rank, world, local_rank):
         # track 24 m inside the southern outline: one side of every fan runs out over the outline and across the bays
         legs.append(('mesh_tin_ragged_outline', dict(m=dict(tin, tris=synth.mesh_ragged(tin['verts'], tin['tris']), desc=tin['desc'] + ', ragged outline with six bays (synth.mesh_ragged), the track 24 m inside it'),
                                                      P=1048576, B=512, steps=50, warmup=40, m2o=synth.rigid_matrix(100.0, -330.0, 0.0, 0.0, 0.0, 0.0))))
+        # ... and the vehicle OFF that map, 6 m beyond the bounding box (a lawn-mower turn outside the surveyed area): every sensor
+        # looks back in over the outline -- the walk starts where the fan plane runs onto the mesh
+        legs.append(('mesh_tin_vehicle_off_the_map', dict(m=legs[-1][1]['m'], P=1048576, B=512, steps=50, warmup=40, m2o=synth.rigid_matrix(100.0, -360.0, 0.0, 0.0, 0.0, 0.0))))
         legs.append(('mesh_tin_gaps_everywhere', dict(m=punch_gaps(tin), P=1048576, B=512, steps=50, warmup=40)))
         # global-localisation regime: sigma = 50 m cloud that nothing collapses (no resample).  Particles are
         # initialised around the odom origin (auv_particle.py:24), so the map <- odom transform puts that
