@@ -185,7 +185,7 @@ struct Links {
   bool outline = false;          // the outline is linked as well
   size_t outline_base = 0;       // ... its first rim record
 };
-inline Links link_holes(std::vector<Rec>& he, int64_t nt) {
+inline Links link_holes(std::vector<Rec>& he, int64_t nt, bool box_outline = false) {
   Links out;
   const size_t nhe = 3 * (size_t)nt;
   if (he.size() != nhe) return out;
@@ -257,7 +257,7 @@ inline Links link_holes(std::vector<Rec>& he, int64_t nt) {
   size_t big = 0;
   for (size_t q = 1; q < pieces.size(); ++q)
     if (pieces[q].area2 > pieces[big].area2) big = q;
-  bool outline_ok = pieces[big].ragged;   // (an outline that lies on the bounding box all around needs no records: the border codes say it all)
+  bool outline_ok = pieces[big].ragged || box_outline;   // (an outline that lies on the bounding box all around needs no records for a walk that LEAVES: the border codes say it all -- box_outline: records all the same, for sensors beyond the box that look back in)
   {
     std::vector<unsigned char> bad(holes.size(), 0);
     for (size_t q = 0; q < pieces.size(); ++q) {

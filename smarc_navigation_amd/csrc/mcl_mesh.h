@@ -408,7 +408,8 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
       halfedge::build_table(verts, tris, nt, twin, ccw, new_of_old, xmin, xmax, ymin, ymax, he);
       static_assert(sizeof(halfedge::Rec) == 2 * sizeof(uint4), "the device reads a half-edge record as two 16-byte words");
       const bool link = !(getenv("MCL_TIN_RIMS") && atoi(getenv("MCL_TIN_RIMS")) == 0);   // (0: no hole is crossed -- A/B, tests)
-      const halfedge::Links links = link ? halfedge::link_holes(he, nt) : halfedge::Links();
+      const bool box_outline = getenv("MCL_TIN_BOX_OUTLINE") && atoi(getenv("MCL_TIN_BOX_OUTLINE")) == 1;   // (mcl_halfedge.h: link an outline that lies on the bounding box all around as well -- INTEGRATION.md 4a)
+      const halfedge::Links links = link ? halfedge::link_holes(he, nt, box_outline) : halfedge::Links();
       m->tin_rims = links.nrim;
       m->tin_nhe = 3 * (size_t)nt;
       m->tin_outline = links.outline ? links.outline_base : 0;

@@ -716,6 +716,37 @@ def test_vehicle_beyond_a_ragged_outline_looks_back_in(where, eng, orc, monkeypa
     e.close()
 
 
+def test_vehicle_beyond_a_rectangular_tin_with_the_box_outline_linked(eng, orc, monkeypatch):
+    """A TIN whose outline lies on its bounding box all around needs no rim records for walks that LEAVE (the border codes
+    say it all), so none are made and a vehicle that leaves the map hands every particle to the ray traversal (11 ms per
+    step at 1 M).  MCL_TIN_BOX_OUTLINE=1 (read in mcl_set_map_mesh) links that outline all the same -- for deployments whose
+    tracks turn outside the surveyed area: the walk then starts where the fan plane runs onto the mesh, at the price of the
+    k_mbes_sweep<6> variant on every update (+ 12 % on the intact TIN).  Same rays either way, against the oracle."""
+    z, origin = _terrain(seed=48)
+    verts, tris = synth.mesh_tin(z, 1.0, origin, seed=17)
+    n, B = 2048, 128
+    soa = _cloud(n, 12, (3.0, 1.0, 0.05, 0.02, 0.02, 3.0), (10.0, origin[1] - 5.0, -2.0))
+    ba = synth.beam_angles(B)
+    omap = orc.Mesh(verts, tris)
+    _, ref = orc.mbes_update(soa, np.identity(4), [0] * 6, omap, ba, None, 0.2, 80.0)
+    assert (ref[:, B // 2] >= 80.0).all() and (ref < 80.0).mean() > 0.2     # every nadir misses, two fifths of the rays look back in
+    handed, got = {}, {}
+    for box in ('0', '1'):
+        monkeypatch.setenv('MCL_TIN_BOX_OUTLINE', box)
+        e = _engine(eng, soa, verts, tris)
+        got[box] = e.mbes_expected(0, n, ba, 80.0)
+        path, handed[box], _ = e.mbes_last_path()
+        assert path == 1
+        e.close()
+    print('rectangular TIN, vehicle 5 m beyond the box: handed over %d of %d, with the box outline linked %d; max |expected range error| %.2e / %.2e m' % (
+        handed['0'], n, handed['1'], np.abs(got['0'] - ref).max(), np.abs(got['1'] - ref).max()))
+    assert handed['0'] == n and handed['1'] < n // 50
+    for box in ('0', '1'):
+        err = np.abs(got[box] - ref)
+        assert (err > 1e-3).sum() <= err.size // 20000 + 2
+        outliers_explained(orc, omap, soa, ba, got[box], ref, 80.0, label='beyond the box, outline linked %s' % box)
+
+
 @pytest.mark.parametrize('seed', range(24))
 def test_tin_rims_fuzz_against_the_oracle(seed, eng, orc):
     """Random scenes for the walk through empty space: an irregular TIN with discs of triangles missing (a few or many, small
