@@ -544,7 +544,10 @@ int launch_mbes(mcl_handle* h, bool with_ranges, int B, double sigma, double r_m
       const size_t lds_s = ((size_t)B * (2 + SLICE_WAVES) + (size_t)SLICE_WAVES * (SLICE_LIST + 1)) * sizeof(float) + SLICE_LUT * sizeof(unsigned short);
       const size_t lds_g = (size_t)B * (3 + SLICE_G_WAVES) * sizeof(float) + (size_t)SLICE_G_TRIS * 9 * sizeof(float) +
                            SLICE_G_HASH * sizeof(unsigned) + SLICE_LUT * sizeof(unsigned short);
-      const bool fits = lds_g + 4096 <= (size_t)160 * 1024 && h->env_slice_group != 0;
+      // (the group kernel pays off on long lists; group and per-particle slice give the same bits -- tests/test_gpu_slice.py --,
+      //  so a short list, by the count of two updates ago, goes to the per-particle kernel alone: one launch less on every
+      //  update that hands nothing over)
+      const bool fits = lds_g + 4096 <= (size_t)160 * 1024 && h->env_slice_group != 0 && h_prev >= 8192;
       const unsigned hgrid = (unsigned)std::min<long long>(std::max<long long>((h_prev + SLICE_G - 1) / SLICE_G, 512), 4096);
       const unsigned pgrid = (unsigned)std::min<long long>(std::max<long long>((h_prev + SLICE_WAVES - 1) / SLICE_WAVES, 512), 2048);
       if (fits) {

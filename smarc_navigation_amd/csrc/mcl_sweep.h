@@ -1011,8 +1011,7 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   // CA -> CB), the cut (cs, ct); r.cuts counts them.
   struct RimCut {
     u32 best, cuts;
-    float cs, ct;
-    TinNode CA, CB;
+    float cs;
   };
   const auto rim_edges = [&](RimCut& r, const u32 rbase, const u32 rlen, u32 pos, const u32 cnt, const float s_min, const bool strict, const u32 skip, const bool box_too) {
     pos -= pos >= rlen ? rlen : 0u;
@@ -1027,15 +1026,12 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
       const TinNode Nn = node_of(qn);
       if ((__float_as_int(Nc.d) ^ __float_as_int(Nn.d)) < 0) {
         const float lam = Nc.d * fast_rcp(Nc.d - Nn.d);
-        const float sx = fmaf(lam, Nn.s - Nc.s, Nc.s), tx = fmaf(lam, Nn.t - Nc.t, Nc.t);
+        const float sx = fmaf(lam, Nn.s - Nc.s, Nc.s);
         const bool beyond = (strict ? sx > s_min : sx >= s_min) && cur != skip && (box_too || (int)qc.w >= 0);
         r.cuts += beyond ? 1u : 0u;
         const bool take = beyond && sx < r.cs;
         r.cs = take ? sx : r.cs;
-        r.ct = take ? tx : r.ct;
         r.best = take ? cur : r.best;
-        r.CA = sel(take, Nc, r.CA);
-        r.CB = sel(take, Nn, r.CB);
       }
       cur = nxt;
       qc = qn;
@@ -1049,9 +1045,6 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     r.best = 0xffffffffu;
     r.cuts = 0u;
     r.cs = __builtin_inff();
-    r.ct = 0.f;
-    r.CA.d = r.CA.s = r.CA.t = 0.f;
-    r.CB = r.CA;
     if (cbase == 0u) {
       rim_edges(r, rbase, rlen, 0u, rlen, s_min, strict, skip, box_too);
     } else {
@@ -1077,6 +1070,17 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     }
     return r;
   };
+  // ... and the cut itself, once more for the edge that was kept (the search carries three registers, not ten, beside the
+  // walk's state: the same expressions, the same bits): its ends -> (A, Bn), the cut -> (cs, ct)
+  const auto rim_enter = [&](const u32 best, const u32 rbase, const u32 rlen, TinNode& CA, TinNode& CB, float& cs, float& ct) {
+    u32 nx2 = best + 1u;
+    nx2 = nx2 >= rbase + rlen ? rbase : nx2;
+    CA = node_of(he_xyzn(best));
+    CB = node_of(he_xyzn(nx2));
+    const float lam = CA.d * fast_rcp(CA.d - CB.d);
+    cs = fmaf(lam, CB.s - CA.s, CA.s);
+    ct = fmaf(lam, CB.t - CA.t, CA.t);
+  };
   TinNode A, Bn;
   u32 nb;    // the half-edge through which the slice enters the next triangle (or a border code)
   bool ao;   // is A the ORIGIN of that half-edge (in the next triangle's own counter-clockwise order)?
@@ -1100,13 +1104,16 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     if (((rc.cuts & 1u) != 0u) == beyond) SWEEP_FAIL(4);   // (inside the outline and no triangle: a hole that is not linked; outside the named hole)
     if (none) return true;
     blind = rc.cuts == 0u;
-    if (!blind && !(rc.ct > 0.f)) SWEEP_FAIL(4);
-    A = rc.CA;
-    Bn = rc.CB;
+    s_cur = 0.f;
+    t_cur = 1.f;
+    A.d = A.s = A.t = 0.f;
+    Bn = A;
+    if (!blind) rim_enter(rc.best, rb, rw.z, A, Bn, s_cur, t_cur);
+    if (!(t_cur > 0.f)) SWEEP_FAIL(4);
     ao = true;
     nb = blind ? 0xfffffff0u : he_nb(rc.best);
-    s_cur = s_prev = blind ? 0.f : rc.cs;   // (the walk's first segment is the point on the rim: the beams up to it are taken by the gap, below)
-    t_cur = t_prev = blind ? 1.f : rc.ct;
+    s_prev = s_cur;   // (the walk's first segment is the point on the rim: the beams up to it are taken by the gap, below)
+    t_prev = t_cur;
   } else {
     // triangle T through its three records: 3 T + e holds the vertex opposite edge e, v_e+2, and -- next_a -- the
     // half-edge on the far side of edge e + 2.  So vertex j comes from record (j + 1) % 3 and the far side of edge j
@@ -1206,6 +1213,37 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
     gap_tan = bp != bp_in ? fmaxf(gap_tan, xs * fast_rcp(xt)) : gap_tan;
   };
   if (HOLES && in_gap && !blind) gap_beams(s_cur, t_cur);   // (the nadir ray goes through a gap: the beams from the nadir to the rim)
+  // into the triangle behind half-edge nb, whose record is (hq, hb): the new vertex replaces the one on ITS side of the
+  // plane (sides by the sign bit of the plane function) and always takes the role of A; the one that stays moves to Bn only
+  // when it was A (three selects).  The slice leaves through the edge that joins the new vertex to the one that stays: the
+  // entered half-edge runs a -> b, the new vertex N is opposite; a stays -> out through (N, a), whose far side is next_a
+  // and ends in N = A; b stays -> out through (b, N), next_b, which starts in N = A.  The cut of that edge -> (sp, tp).
+  // Returns true when the walk is over (not for the sweep).
+  const auto cross = [&](const uint4 hq, const u32 hb, float& sp, float& tp) -> bool {
+    const float rx = (__uint_as_float(hq.x) - Oxf) - dOx, ry = (__uint_as_float(hq.y) - Oyf) - dOy, rz = __uint_as_float(hq.z) - oz;
+    const float dN = fmaf(nx_, rx, fmaf(ny_, ry, nz_ * rz));
+    const bool keep_a = (__float_as_int(dN) ^ __float_as_int(A.d)) < 0;
+    const bool stays_a = keep_a == ao;   // the vertex that stays is the half-edge's origin
+    nb = stays_a ? hq.w : hb;
+    ao = !stays_a;
+    Bn.d = keep_a ? A.d : Bn.d;
+    Bn.s = keep_a ? A.s : Bn.s;
+    Bn.t = keep_a ? A.t : Bn.t;
+    A.d = dN;
+    A.s = fmaf(su, rx, fmaf(sv, ry, sz * rz));
+    A.t = fmaf(tu, rx, fmaf(tv, ry, tz * rz));
+    const float lam = A.d * fast_rcp(A.d - Bn.d);
+    sp = fmaf(lam, Bn.s - A.s, A.s);
+    tp = fmaf(lam, Bn.t - A.t, A.t);
+    // (HOLES: ... and not at a smaller tangent than a gap a beam looked into -- gap_tan = -inf until then: the fma is
+    //  + inf for t > 0 and NaN or - inf otherwise, and v_min returns the number)
+    if (!((HOLES ? fminf(tp, fmaf(-gap_tan, tp, sp)) : tp) > 0.f)) {
+      SWEEP_NOTE(tp > 0.f ? 15 : 12);
+      ok = false;
+      return true;
+    }
+    return false;
+  };
   // one step of the walk: resolve the beams of the segment (sp, tp) -> (sc, tc), then cross into the neighbour.  The new
   // vertex of the slice takes the place of the one before last and the CALLER swaps the roles (the loop is unrolled by
   // two).  Returns true when the walk is over.  EXITS: as in sweep_side, the tests that end a walk normally run every
@@ -1213,8 +1251,8 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
   const auto walk_step = [&](float& sp, float& tp, float& sc, float& tc, const int step, auto EXITS) -> bool {
     // the entered half-edge's record is in flight while the beams are resolved: the vertex the slice meets next and
     // the two half-edges it can leave through -- ONE dependent load per step
-    uint4 hq = he_xyzn(nb);
-    u32 hb = he_nb(nb);
+    const uint4 hq = he_xyzn(nb);
+    const u32 hb = he_nb(nb);
     const float dts = tc - tp;
     const float dss = sc - sp, num = fmaf(tp, dss, -(sp * dts));   // (the segment's constants of seg_tau)
     merge(msel, dss, num, tp, sc, tc, dts);
@@ -1239,60 +1277,40 @@ __device__ __forceinline__ bool sweep_side_tin(const MbesArgs& a, const MbesPose
       const uint4 rw = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (int)(k0 << 5) + 16, 0, 0));   // {half-edge, first record, edges, chunks | outline}
       const RimCut rc = rim_cut(rw.y, rw.z, rw.w & 0x7fffffffu, sc, false, k0, false);   // (every edge of the rim but the one reached)
       const u32 best = rc.best;
-      const float bs = rc.cs, bt = rc.ct;
       if (best == 0xffffffffu && (int)rw.w < 0) return true;   // beyond the OUTLINE and no way back in: nothing lies further out -- the beams left get r_max through the tail below
       // (a slice through a rim vertex can find the two cuts there in either order and go back and forth between the gap and
       //  a sliver: a side crosses SWEEP_TIN_GAPS gaps at most)
-      if (best == 0xffffffffu || !(bt > 0.f) || ++gaps > SWEEP_TIN_GAPS) {
+      if (best == 0xffffffffu || ++gaps > SWEEP_TIN_GAPS) {
         SWEEP_NOTE(14);
         ok = false;
         return true;
       }
-      gap_beams(bs, bt);   // the beams that look into the gap miss
+      // on from the far rim: in through the interior half-edge of that edge, which runs from its origin (-> A) to its end (-> Bn)
+      rim_enter(best, rw.y, rw.z, A, Bn, sc, tc);
+      if (!(tc > 0.f)) {
+        SWEEP_NOTE(14);
+        ok = false;
+        return true;
+      }
+      gap_beams(sc, tc);   // the beams that look into the gap miss
       if (decltype(EXITS)::value && bp == bp_end) return true;
-      // on from the far rim: in through the interior half-edge of that edge, which runs from its origin CA to CB
-      sc = bs;
-      tc = bt;
-      A = rc.CA;
-      Bn = rc.CB;
       ao = true;
+      // (the step ends HERE, through this path's own copy of the crossing: state that changed in this branch alone and
+      //  went on into the common code cost the loop eight register copies on every step -- 14 % of the kernel)
       nb = he_nb(best);
-      hq = he_xyzn(nb);
-      hb = he_nb(nb);
+      if (decltype(EXITS)::value && step > max_steps) {
+        SWEEP_NOTE(11);
+        ok = false;
+        return true;
+      }
+      return cross(he_xyzn(nb), he_nb(nb), sp, tp);
     }
     if (decltype(EXITS)::value && step > max_steps) {
       SWEEP_NOTE(11);
       ok = false;
       return true;
     }
-    // the new vertex replaces the one on ITS side of the plane (sides by the sign bit of the plane function) and
-    // always takes the role of A; the one that stays moves to Bn only when it was A (three selects).  The slice
-    // leaves through the edge that joins the new vertex to the one that stays: the entered half-edge runs a -> b,
-    // the new vertex N is opposite; a stays -> out through (N, a), whose far side is next_a and ends in N = A;
-    // b stays -> out through (b, N), next_b, which starts in N = A
-    const float rx = (__uint_as_float(hq.x) - Oxf) - dOx, ry = (__uint_as_float(hq.y) - Oyf) - dOy, rz = __uint_as_float(hq.z) - oz;
-    const float dN = fmaf(nx_, rx, fmaf(ny_, ry, nz_ * rz));
-    const bool keep_a = (__float_as_int(dN) ^ __float_as_int(A.d)) < 0;
-    const bool stays_a = keep_a == ao;   // the vertex that stays is the half-edge's origin
-    nb = stays_a ? hq.w : hb;
-    ao = !stays_a;
-    Bn.d = keep_a ? A.d : Bn.d;
-    Bn.s = keep_a ? A.s : Bn.s;
-    Bn.t = keep_a ? A.t : Bn.t;
-    A.d = dN;
-    A.s = fmaf(su, rx, fmaf(sv, ry, sz * rz));
-    A.t = fmaf(tu, rx, fmaf(tv, ry, tz * rz));
-    const float lam = A.d * fast_rcp(A.d - Bn.d);
-    sp = fmaf(lam, Bn.s - A.s, A.s);
-    tp = fmaf(lam, Bn.t - A.t, A.t);
-    // (HOLES: ... and not at a smaller tangent than a gap a beam looked into -- gap_tan = -inf until then: the fma is
-    //  + inf for t > 0 and NaN or - inf otherwise, and v_min returns the number)
-    if (!((HOLES ? fminf(tp, fmaf(-gap_tan, tp, sp)) : tp) > 0.f)) {
-      SWEEP_NOTE(tp > 0.f ? 15 : 12);
-      ok = false;
-      return true;
-    }
-    return false;
+    return cross(hq, hb, sp, tp);
   };
   if (!(HOLES && blind)) {
     for (int step = 1;; step += 2) {
@@ -1388,7 +1406,7 @@ __device__ __forceinline__ double sweep_lane(const MbesArgs& a, long long j0, lo
 // (register budgets: the lattice walk 8 waves / SIMD (64 VGPRs), grids and TINs 6; the sub-fan kernel over a grid 5 -- it
 //  carries the conic AND the start ray's footprint test, and spilled 8 B per lane at 6: small clouds, latency-bound anyway)
 template <int SURF, bool EXPECT_ONLY, bool SUB = false>
-__global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, SURF == 0 ? (SUB ? SWEEP_MIN_WAVES_GRID - 1 : SWEEP_MIN_WAVES_GRID) : (SURF == 5 || SURF == 6 ? SWEEP_MIN_WAVES_TIN : SWEEP_MIN_WAVES)) k_mbes_sweep(MbesArgs a) {
+__global__ void __launch_bounds__(SUB ? 64 * SWEEP_MAX_WAVES : SWEEP_THREADS, SURF == 0 ? (SUB ? SWEEP_MIN_WAVES_GRID - 1 : SWEEP_MIN_WAVES_GRID) : (SURF == 6 && !SUB && !EXPECT_ONLY ? 8 : (SURF == 5 || SURF == 6 ? SWEEP_MIN_WAVES_TIN : SWEEP_MIN_WAVES))) k_mbes_sweep(MbesArgs a) {
 #ifdef SWEEP_TIMELINE
   const unsigned long long tl0 = wall_clock64(), tc0 = __builtin_readcyclecounter();
 #endif

@@ -44,11 +44,11 @@ def test_headline_sweep_keeps_eight_waves_per_simd_and_uses_no_matrix_cores(tabl
     for surf in (2, 3):   # the two diagonals of a triangulated DEM: the same workload
         r = rows['void k_mbes_sweep<%d, false, false>' % surf]
         assert r['vgpr'] <= 64 and r['occ'] == 8 and r['scratch'] == 0, r
-    # the general TIN's walk keeps the same occupancy; its variant that crosses holes by their rims (SURF 6: only meshes WITH
-    # linked rims are launched on it) carries the rim search's registers and may drop two waves (measured: nothing lost -- the
-    # kernel is bound by vector issue)
-    r5, r6 = rows['void k_mbes_sweep<5, false, false>'], rows['void k_mbes_sweep<6, false, false>']
-    assert r5['vgpr'] <= 64 and r5['occ'] == 8 and r5['scratch'] == 0, r5
-    assert r6['vgpr'] <= 80 and r6['occ'] >= 6 and r6['scratch'] == 0, r6
+    # the general TIN's walk keeps the same occupancy, and so does its variant that goes on through holes and over the outline
+    # (SURF 6; the rim search carries three registers beside the walk's state and recomputes the cut it kept: at 75 registers
+    # and 6 waves per SIMD the launch was 11 % slower -- this walk waits for a dependent load on every step)
+    for surf in (5, 6):
+        r = rows['void k_mbes_sweep<%d, false, false>' % surf]
+        assert r['vgpr'] <= 64 and r['occ'] == 8 and r['scratch'] == 0, r
     assert 'v_mfma' not in asm   # nothing on this path is a dense contraction (north_star)
     assert 'v_pk_fma_f32' not in asm and 'v_pk_add_f32' not in asm   # -fno-slp-vectorize: packed f32 holds the SIMD twice
