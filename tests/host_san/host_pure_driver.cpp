@@ -228,12 +228,15 @@ static int check_halfedge_tables(std::mt19937_64& rng) {
 // inside its sphere); and WALKS by the kernel's rule (sweep_side_tin<.., HOLES>): at a rim the nearest cut further out --
 // found through the chunk spheres exactly as by brute force over every edge --, NO triangle between the two cuts, s never
 // decreasing; beyond the outline with no cut left, no triangle anywhere further along the line; an island's hole never linked.
+#ifndef RIM_TRIALS
+#define RIM_TRIALS 96   // (-DRIM_TRIALS=5000: a longer hunt, by hand)
+#endif
 static int check_hole_rims(std::mt19937_64& rng) {
   using halfedge::Rec;
   std::uniform_real_distribution<double> U01(0.0, 1.0);
   int linked_meshes = 0, refused = 0, outline_meshes = 0, chunked_meshes = 0;
   long crossings = 0, bays = 0, finals = 0, outside_starts = 0, blinds = 0;
-  for (int trial = 0; trial < 96; ++trial) {
+  for (int trial = 0; trial < RIM_TRIALS; ++trial) {
     const int kind = trial % 8;   // 0-2 discs, 3 a disc at the outline, 4 ring (island), 5-6 ragged outline + bays (+ discs), 7 a large hole
     const bool large = kind == 7, ragged = kind == 5 || kind == 6;
     const int nx = (large || ragged ? 22 : 9) + (int)(rng() % 10), ny = (large || ragged ? 20 : 9) + (int)(rng() % 10);
