@@ -257,6 +257,9 @@ inline Links link_holes(std::vector<Rec>& he, int64_t nt, bool box_outline = fal
   size_t big = 0;
   for (size_t q = 1; q < pieces.size(); ++q)
     if (pieces[q].area2 > pieces[big].area2) big = q;
+  // (the point-in-polygon tests below are pieces x (holes + outline edges): a mesh shattered into tens of thousands of scraps
+  //  would spend minutes here -- it gets no rims, its walks hand over as before)
+  if ((double)(pieces.size() - 1) * (double)(holes.size() + pieces[big].len) > 4e8) return out;
   bool outline_ok = pieces[big].ragged || box_outline;   // (an outline that lies on the bounding box all around needs no records for a walk that LEAVES: the border codes say it all -- box_outline: records all the same, for sensors beyond the box that look back in)
   {
     std::vector<unsigned char> bad(holes.size(), 0);

@@ -413,8 +413,13 @@ inline int mesh_build(const float* verts, int64_t nv, const uint32_t* tris, int6
       m->tin_rims = links.nrim;
       m->tin_nhe = 3 * (size_t)nt;
       m->tin_outline = links.outline ? links.outline_base : 0;
-      m->tin_holes = m->tin_rims != 0;
-      for (size_t q = 0; q < 3 * (size_t)nt && !m->tin_holes; ++q) m->tin_holes = he[q].next_a == halfedge::HOLE || he[q].next_b == halfedge::HOLE;
+      // (does a walk ever meet an edge with nothing behind it that is not on the bounding box -- a rim record or the HOLE
+      //  code?  Only such meshes stage their hand-overs through the fan slice, mcl_host_update.h; an outline on the box all
+      //  around, linked for sensors beyond it, is not one)
+      m->tin_holes = false;
+      for (size_t q = 0; q < 3 * (size_t)nt && !m->tin_holes; ++q)
+        m->tin_holes = (he[q].next_a >= 3 * (size_t)nt && he[q].next_a < 0xfffffff0u) || he[q].next_a == halfedge::HOLE ||
+                       (he[q].next_b >= 3 * (size_t)nt && he[q].next_b < 0xfffffff0u) || he[q].next_b == halfedge::HOLE;
       std::vector<uint32_t> cell_rim;
       if (m->tin_rims) {
         // which hole may lie under a sensor: every cell the hole's bounding box reaches into names the hole's first rim

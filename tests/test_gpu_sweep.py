@@ -721,7 +721,7 @@ def test_vehicle_beyond_a_rectangular_tin_with_the_box_outline_linked(eng, orc, 
     say it all), so none are made and a vehicle that leaves the map hands every particle to the ray traversal (11 ms per
     step at 1 M).  MCL_TIN_BOX_OUTLINE=1 (read in mcl_set_map_mesh) links that outline all the same -- for deployments whose
     tracks turn outside the surveyed area: the walk then starts where the fan plane runs onto the mesh, at the price of the
-    k_mbes_sweep<6> variant on every update (+ 4 % on the intact TIN).  Same rays either way, against the oracle."""
+    k_mbes_sweep<6> variant on every update (+ 3 % on the intact TIN).  Same rays either way, against the oracle."""
     z, origin = _terrain(seed=48)
     verts, tris = synth.mesh_tin(z, 1.0, origin, seed=17)
     n, B = 2048, 128
