@@ -953,7 +953,9 @@ def worker(a, rank, world, local_rank):
         # and swept on its node heights, no triangle record read); an irregular TIN takes the adjacency walk
         for key, leg, what in (('value_tin', 'mesh_tin', 'an irregular height-field TIN (the adjacency sweep k_mbes_sweep<5,...>), collapsed cloud like `value`'),
                                ('value_tin_shuffled_input', 'mesh_tin_shuffled', 'the same TIN handed over in random vertex / triangle order'),
-                               ('value_tin_healthy_cloud', 'mesh_tin_tempered', 'the TIN with a posterior that stays decimetres wide: the realistic deployment point')):
+                               ('value_tin_healthy_cloud', 'mesh_tin_tempered', 'the TIN with a posterior that stays decimetres wide: the realistic deployment point'),
+                               ('value_tin_gaps_everywhere', 'mesh_tin_gaps_everywhere', 'the TIN with a data gap per 6 x 6 m (13 % of its triangles missing): the walk crosses them by their rims'),
+                               ('value_tin_ragged_outline', 'mesh_tin_ragged_outline', 'the TIN with the outline of a real survey (sawtooth border, bays), the track 24 m inside it')):
             lg = extra.get(leg, {})
             if lg.get('ms_per_step'):
                 out[key] = round(1e3 / lg['ms_per_step'], 3)
